@@ -1,0 +1,403 @@
+/*
+ * gnx_oracle.c — CPU restatement of the Gnomix inference hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; gnomix_amd/ never does (the product path
+ * fails loudly when the HIP library is missing).
+ *
+ * Every function restates one row of SURVEY.md §8(a) from the formulas there and cites the
+ * reference file:line (under /root/reference) whose behaviour it follows.  Nothing here is
+ * copied from the reference: the reference is Python that delegates to sklearn / xgboost /
+ * libsvm / CRFsuite; this file is plain scalar C99.
+ *
+ * Pinning status (see DESIGN.md §3 and tests/golden/make_golden.py):
+ *   a1-a3 logistic base ............ pinned against the imported reference (golden G1)
+ *   a4/a4' CovRSK + SVC probability . pinned against the imported reference (golden G2)
+ *   a5 slide_window ................ pinned against the imported reference (golden G3)
+ *   a6 xgboost tree walk + softmax .. PARITY UNPINNED: xgboost==1.1.1 is a third-party wheel,
+ *                                     absent from /root/reference and from this image; restated
+ *                                     from its documented model schema (see gnxo_xgb_* below)
+ *   a7 CRFsuite marginals ........... PARITY UNPINNED: sklearn-crfsuite==0.3.6 / CRFsuite absent;
+ *                                     restated as the textbook scaled forward-backward
+ *   a8 argmax ....................... pinned (numpy first-max-wins)
+ *   a9 Gnofix control flow .......... pinned against the imported reference (golden G5)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GNXO_OK 0
+#define GNXO_EINVAL (-1)
+#define GNXO_ENOMEM (-2)
+
+/* ------------------------------------------------------------------------------------------
+ * a1  Base.pad  (src/Base/base.py:41-44)
+ *     Xp = [flip(X[:, :ctx]), X, flip(X[:, -ctx:])]   ->  column of X behind padded position p
+ * ---------------------------------------------------------------------------------------- */
+static inline int64_t pad_src(int64_t p, int64_t C, int64_t ctx) {
+  if (p < ctx) return ctx - 1 - p;
+  if (p < ctx + C) return p - ctx;
+  return C - 1 - (p - ctx - C);
+}
+
+int64_t gnxo_pad_src(int64_t p, int64_t C, int64_t ctx) { return pad_src(p, C, ctx); }
+
+/* ------------------------------------------------------------------------------------------
+ * a2+a3  Base.predict_proba_vectorized (src/Base/base.py:146-180) with
+ *        LogisticRegressionBase (src/Base/models.py:12-21) -> sklearn _predict_proba_lr (OvR):
+ *   window i<W-1 = Xp[:, i*M : i*M+M_];  last window = Xp[:, -(M_+rem):]   (base.py:157-164)
+ *   Z = Xw . coef^T + intercept   (the missing code 2 is used as the NUMBER 2)
+ *   P = 1/(1+exp(-Z));  P /= sum_a P
+ * coef is (W, A, ldc) row-major, ldc >= M_+rem, entries beyond a window's width ignored.
+ * B is (N, W, A) float64.
+ * ---------------------------------------------------------------------------------------- */
+int gnxo_base_lr(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t M, int64_t ctx,
+                 int64_t A, const double* coef, int64_t ldc, const double* intercept, double* B) {
+  if (M <= 0 || C < M || ctx < 0 || ctx > C || A <= 0 || A > 64) return GNXO_EINVAL;
+  const int64_t W = C / M, rem = C - M * W, M_ = M + 2 * ctx;
+  if (rem == 0) return GNXO_EINVAL; /* base.py:158 relies on C % M != 0 (gnomix.py:124-125) */
+  if (ldc < M_ + rem) return GNXO_EINVAL;
+  double p[64];
+  for (int64_t n = 0; n < N; ++n) {
+    const int8_t* x = X + n * ldx;
+    for (int64_t i = 0; i < W; ++i) {
+      const int64_t start = i * M, len = (i == W - 1) ? M_ + rem : M_;
+      double s = 0.0;
+      for (int64_t a = 0; a < A; ++a) {
+        const double* c = coef + (i * A + a) * ldc;
+        double z = 0.0;
+        for (int64_t k = 0; k < len; ++k) z += c[k] * (double)x[pad_src(start + k, C, ctx)];
+        z += intercept[i * A + a];
+        p[a] = 1.0 / (1.0 + exp(-z));
+        s += p[a];
+      }
+      for (int64_t a = 0; a < A; ++a) B[(n * W + i) * A + a] = p[a] / s;
+    }
+  }
+  return GNXO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a5  slide_window (src/Smooth/utils.py:4-29): reflect-pad by pad=(S+1)//2 windows, row (n,w) =
+ *     Bp[n, w:w+S].ravel() cast to float32.  slide_src maps padded window j=w+s to a window of B.
+ * ---------------------------------------------------------------------------------------- */
+static inline int64_t slide_src(int64_t j, int64_t W, int64_t pad) {
+  if (j < pad) return pad - 1 - j;
+  if (j < pad + W) return j - pad;
+  return W - 1 - (j - pad - W);
+}
+
+int64_t gnxo_slide_src(int64_t j, int64_t W, int64_t S) { return slide_src(j, W, (S + 1) / 2); }
+
+/* out: (N*W, S*A) float32.  B may be float64 (is_f64=1) or float32. */
+int gnxo_slide_window(const void* B, int is_f64, int64_t N, int64_t W, int64_t A, int64_t S,
+                      float* out) {
+  const int64_t pad = (S + 1) / 2;
+  if (W < pad) return GNXO_EINVAL;
+  for (int64_t n = 0; n < N; ++n)
+    for (int64_t w = 0; w < W; ++w) {
+      float* o = out + (n * W + w) * S * A;
+      for (int64_t s = 0; s < S; ++s) {
+        const int64_t src = slide_src(w + s, W, pad);
+        for (int64_t a = 0; a < A; ++a) {
+          const int64_t idx = (n * W + src) * A + a;
+          o[s * A + a] = is_f64 ? (float)((const double*)B)[idx] : ((const float*)B)[idx];
+        }
+      }
+    }
+  return GNXO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a6  XGB_Smoother model (src/Smooth/models.py:14-20) -> xgboost==1.1.1 (third-party, pinned in
+ *     requirements.txt:11; NOT in /root/reference, NOT installed: PARITY UNPINNED).
+ *     Call sites: smooth.py:46 (predict_proba), gnofix.py:157.
+ *
+ *     Restated from xgboost's documented model schema (doc/tutorials/saving_model + the JSON
+ *     schema: per tree left_children, right_children, split_indices, split_conditions,
+ *     default_left; tree_info = output group of each tree) and its CPU predictor:
+ *       leaf walk : at an internal node go LEFT iff fvalue < split_condition, missing (NaN) ->
+ *                   default child; a node is a leaf iff left_child == -1 and its value is
+ *                   split_condition (RegTree::GetLeafIndex / GetNext)
+ *       margin    : for each output group g, psum = 0f; for trees in model order with
+ *                   tree_info==g: psum += leaf (float32);  margin_g = base_margin + psum,
+ *                   base_margin = base_score (0.5 for multi:softprob) (CPUPredictor::PredValue)
+ *       transform : softmax (common/math.h Softmax): wmax=max; e_i = expf(x_i - wmax);
+ *                   wsum (double) += e_i;  out_i = e_i / (float)wsum
+ * Tree storage here = xgboost's own arrays, concatenated over trees (tree_off = node offsets).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_trees;
+  int32_t n_class;
+  const int32_t* tree_off;   /* n_trees+1 node offsets */
+  const int32_t* left;       /* child index within the tree, -1 = leaf */
+  const int32_t* right;
+  const int32_t* feat;       /* split_indices */
+  const float* cond;         /* split_conditions; leaf value at leaves */
+  const uint8_t* default_left; /* may be NULL (features are never NaN on this path) */
+  const int32_t* tree_class; /* tree_info */
+  float base_score;
+} gnxo_trees;
+
+static inline float tree_leaf(const gnxo_trees* T, int32_t t, const float* f) {
+  const int32_t o = T->tree_off[t];
+  int32_t nid = 0;
+  while (T->left[o + nid] != -1) {
+    const float fv = f[T->feat[o + nid]];
+    if (fv != fv) nid = (T->default_left && T->default_left[o + nid]) ? T->left[o + nid] : T->right[o + nid];
+    else nid = (fv < T->cond[o + nid]) ? T->left[o + nid] : T->right[o + nid];
+  }
+  return T->cond[o + nid];
+}
+
+static void xgb_row(const gnxo_trees* T, const float* f, float* out /* n_class */) {
+  const int K = T->n_class;
+  for (int g = 0; g < K; ++g) {
+    float psum = 0.0f;
+    for (int32_t t = 0; t < T->n_trees; ++t)
+      if (T->tree_class[t] == g) psum += tree_leaf(T, t, f);
+    out[g] = T->base_score + psum;
+  }
+  float wmax = out[0];
+  for (int g = 1; g < K; ++g) wmax = fmaxf(out[g], wmax);
+  double wsum = 0.0;
+  for (int g = 0; g < K; ++g) { out[g] = expf(out[g] - wmax); wsum += out[g]; }
+  for (int g = 0; g < K; ++g) out[g] /= (float)wsum;
+}
+
+/* model.predict_proba on an explicit feature matrix (R, F) float32 -> (R, n_class) float32 */
+int gnxo_xgb_predict_proba(const gnxo_trees* T, const float* feats, int64_t R, int64_t F, float* proba) {
+  for (int64_t r = 0; r < R; ++r) xgb_row(T, feats + r * F, proba + r * T->n_class);
+  return GNXO_OK;
+}
+
+/* a8 argmax, first max wins (np.argmax: smooth.py:61, gnomix.py:58) */
+static inline int32_t argmax_f32(const float* p, int K) {
+  int32_t b = 0;
+  for (int k = 1; k < K; ++k) if (p[k] > p[b]) b = k;
+  return b;
+}
+
+/* Smoother.predict_proba (smooth.py:40-56) for XGB_Smoother: slide_window -> model -> reshape,
+ * without materialising the (N*W, S*A) matrix.  B float64 or float32 (N,W,A); proba float32
+ * (N,W,A); labels int32 (N,W) (may be NULL). */
+int gnxo_smooth_xgb(const gnxo_trees* T, const void* B, int is_f64, int64_t N, int64_t W, int64_t A,
+                    int64_t S, float* proba, int32_t* labels) {
+  const int64_t pad = (S + 1) / 2;
+  if (W < pad || T->n_class != A) return GNXO_EINVAL;
+  float* f = (float*)malloc(sizeof(float) * (size_t)(S * A));
+  if (!f) return GNXO_ENOMEM;
+  for (int64_t n = 0; n < N; ++n)
+    for (int64_t w = 0; w < W; ++w) {
+      for (int64_t s = 0; s < S; ++s) {
+        const int64_t src = slide_src(w + s, W, pad);
+        for (int64_t a = 0; a < A; ++a) {
+          const int64_t idx = (n * W + src) * A + a;
+          f[s * A + a] = is_f64 ? (float)((const double*)B)[idx] : ((const float*)B)[idx];
+        }
+      }
+      float* o = proba + (n * W + w) * A;
+      xgb_row(T, f, o);
+      if (labels) labels[n * W + w] = argmax_f32(o, (int)A);
+    }
+  free(f);
+  return GNXO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a7  CRF_Smoother (src/Smooth/models.py:27-32, src/Smooth/crf.py:17-67) -> sklearn-crfsuite
+ *     0.3.6 / CRFsuite (third-party; absent: PARITY UNPINNED).  Features at position t are the
+ *     attributes "0".."A-1" with values B[n,t,a] (crf.py:24-27); all_possible_states and
+ *     all_possible_transitions (crf.py:12-13) give dense state weights theta[a][y] and transition
+ *     weights tau[y'][y].  predict_marginals (crf.py:65) = marginals of the linear chain:
+ *        state_t(y) = sum_a theta[a][y] * B[n,t,a];   psi_t(y) = exp(state_t(y))
+ *        alpha_0 = psi_0, alpha_t(y) = psi_t(y) * sum_y' alpha_{t-1}(y') exp(tau[y'][y]), each
+ *        alpha_t scaled to sum 1 (scale c_t);  beta_{W-1} = c_{W-1},
+ *        beta_t(y') = c_t * sum_y exp(tau[y'][y]) psi_{t+1}(y) beta_{t+1}(y)
+ *        marginal_t(y) = alpha_t(y) * beta_t(y) / c_t
+ *     (CRFsuite crf1d_context.c: crf1dc_alpha_score / crf1dc_beta_score / crf1dc_marginal_point.)
+ *     B float64 (N,W,A) -> proba float64 (N,W,A).
+ * ---------------------------------------------------------------------------------------- */
+int gnxo_smooth_crf(const double* B, int64_t N, int64_t W, int64_t A, const double* state /*A x A [attr][label]*/,
+                    const double* trans /*A x A [from][to]*/, double* proba, int32_t* labels) {
+  if (A > 64) return GNXO_EINVAL;
+  double* psi = (double*)malloc(sizeof(double) * (size_t)(W * A) * 3 + sizeof(double) * (size_t)(W + A * A));
+  if (!psi) return GNXO_ENOMEM;
+  double* alpha = psi + W * A;
+  double* beta = alpha + W * A;
+  double* scale = beta + W * A;
+  double* et = scale + W;
+  for (int64_t i = 0; i < A * A; ++i) et[i] = exp(trans[i]);
+  for (int64_t n = 0; n < N; ++n) {
+    const double* b = B + n * W * A;
+    for (int64_t t = 0; t < W; ++t)
+      for (int64_t y = 0; y < A; ++y) {
+        double s = 0.0;
+        for (int64_t a = 0; a < A; ++a) s += state[a * A + y] * b[t * A + a];
+        psi[t * A + y] = exp(s);
+      }
+    /* forward */
+    for (int64_t t = 0; t < W; ++t) {
+      double sum = 0.0;
+      for (int64_t y = 0; y < A; ++y) {
+        double v;
+        if (t == 0) v = psi[y];
+        else {
+          double acc = 0.0;
+          for (int64_t yp = 0; yp < A; ++yp) acc += alpha[(t - 1) * A + yp] * et[yp * A + y];
+          v = acc * psi[t * A + y];
+        }
+        alpha[t * A + y] = v;
+        sum += v;
+      }
+      scale[t] = (sum != 0.0) ? 1.0 / sum : 1.0;
+      for (int64_t y = 0; y < A; ++y) alpha[t * A + y] *= scale[t];
+    }
+    /* backward */
+    for (int64_t y = 0; y < A; ++y) beta[(W - 1) * A + y] = scale[W - 1];
+    for (int64_t t = W - 2; t >= 0; --t)
+      for (int64_t yp = 0; yp < A; ++yp) {
+        double acc = 0.0;
+        for (int64_t y = 0; y < A; ++y) acc += et[yp * A + y] * psi[(t + 1) * A + y] * beta[(t + 1) * A + y];
+        beta[t * A + yp] = acc * scale[t];
+      }
+    for (int64_t t = 0; t < W; ++t) {
+      double* o = proba + (n * W + t) * A;
+      for (int64_t y = 0; y < A; ++y) o[y] = alpha[t * A + y] * beta[t * A + y] / scale[t];
+      if (labels) {
+        int32_t bi = 0;
+        for (int64_t y = 1; y < A; ++y) if (o[y] > o[bi]) bi = (int32_t)y;
+        labels[n * W + t] = bi;
+      }
+    }
+  }
+  free(psi);
+  return GNXO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a4  CovRSK string kernel (src/Base/string_kernel.py:80-110).
+ *     K(x,y) = sum over positions t of cov_tri_t, where inside a run of equal symbols cov_tri
+ *     counts the m in Ms with m <= run-so-far (string_kernel.py:91-101), reset to 0 at a mismatch.
+ *     Symbols are compared as raw int8 (2==2 is a match).  Ms_ohe[r] = 1 iff r in Ms
+ *     (length >= M_+1).  K is (Nq, Nt) int64.
+ * ---------------------------------------------------------------------------------------- */
+int gnxo_covrsk(const int8_t* Xq, int64_t Nq, int64_t ldq, const int8_t* Xt, int64_t Nt, int64_t ldt,
+                int64_t Mw, const uint8_t* Ms_ohe, int64_t* K) {
+  for (int64_t q = 0; q < Nq; ++q)
+    for (int64_t r = 0; r < Nt; ++r) {
+      const int8_t* x = Xq + q * ldq;
+      const int8_t* y = Xt + r * ldt;
+      int64_t tri = 0, cov = 0, k = 0;
+      for (int64_t t = 0; t < Mw; ++t) {
+        if (x[t] == y[t]) { tri += 1; cov += Ms_ohe[tri]; k += cov; }
+        else { tri = 0; cov = 0; }
+      }
+      K[q * Nt + r] = k;
+    }
+  return GNXO_OK;
+}
+
+/* plain triangular-number string kernel (string_kernel.py:5-24): K = sum over runs L(L+1)/2 */
+int gnxo_string_kernel(const int8_t* Xq, int64_t Nq, int64_t ldq, const int8_t* Xt, int64_t Nt, int64_t ldt,
+                       int64_t Mw, int64_t* K) {
+  for (int64_t q = 0; q < Nq; ++q)
+    for (int64_t r = 0; r < Nt; ++r) {
+      const int8_t* x = Xq + q * ldq;
+      const int8_t* y = Xt + r * ldt;
+      int64_t tri = 0, k = 0;
+      for (int64_t t = 0; t < Mw; ++t) {
+        if (x[t] == y[t]) { tri += 1; k += tri; } else tri = 0;
+      }
+      K[q * Nt + r] = k;
+    }
+  return GNXO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a4'  SVC.predict_proba with a precomputed kernel row (sklearn -> libsvm; libsvm ships inside
+ *      the sklearn wheel, third-party: sklearn/svm/src/libsvm/svm.cpp — svm_predict_values,
+ *      sigmoid_predict, multiclass_probability, svm_predict_probability).  Restated:
+ *   SVs are grouped by class (n_support[c] each, start[c] = prefix sum); for the pair (i<j), p-th
+ *   pair:  dec = sum_{sv in i} dual[j-1][sv] K[sv] + sum_{sv in j} dual[i][sv] K[sv] - rho[p]
+ *   (sklearn stores _intercept_ = -rho);  r_ij = clip(sigmoid_predict(dec, probA[p], probB[p]),
+ *   1e-7, 1-1e-7), r_ji = 1 - r_ij;  Wu-Lin-Weng coupling (multiclass_probability).
+ *   Krow = K(query, all training rows); support[sv] indexes training rows.
+ * ---------------------------------------------------------------------------------------- */
+static double sigmoid_predict(double dec, double A_, double B_) {
+  const double fApB = dec * A_ + B_;
+  if (fApB >= 0) return exp(-fApB) / (1.0 + exp(-fApB));
+  return 1.0 / (1.0 + exp(fApB));
+}
+
+static void multiclass_probability(int k, const double* r /* k x k */, double* p) {
+  int t, j, iter, max_iter = (k > 100) ? k : 100;
+  double* Q = (double*)malloc(sizeof(double) * (size_t)(k * k + k));
+  double* Qp = Q + k * k;
+  double pQp, eps = 0.005 / k;
+  for (t = 0; t < k; t++) {
+    p[t] = 1.0 / k;
+    Q[t * k + t] = 0;
+    for (j = 0; j < t; j++) { Q[t * k + t] += r[j * k + t] * r[j * k + t]; Q[t * k + j] = Q[j * k + t]; }
+    for (j = t + 1; j < k; j++) { Q[t * k + t] += r[j * k + t] * r[j * k + t]; Q[t * k + j] = -r[j * k + t] * r[t * k + j]; }
+  }
+  for (iter = 0; iter < max_iter; iter++) {
+    pQp = 0;
+    for (t = 0; t < k; t++) {
+      Qp[t] = 0;
+      for (j = 0; j < k; j++) Qp[t] += Q[t * k + j] * p[j];
+      pQp += p[t] * Qp[t];
+    }
+    double max_error = 0;
+    for (t = 0; t < k; t++) { double e = fabs(Qp[t] - pQp); if (e > max_error) max_error = e; }
+    if (max_error < eps) break;
+    for (t = 0; t < k; t++) {
+      double diff = (-Qp[t] + pQp) / Q[t * k + t];
+      p[t] += diff;
+      pQp = (pQp + diff * (diff * Q[t * k + t] + 2 * Qp[t])) / (1 + diff) / (1 + diff);
+      for (j = 0; j < k; j++) { Qp[j] = (Qp[j] + diff * Q[t * k + j]) / (1 + diff); p[j] /= (1 + diff); }
+    }
+  }
+  free(Q);
+}
+
+/* Krow: (Nq, Nt) int64 kernel values; support: (nSV,) int32; dual: (k-1, nSV) double;
+ * intercept/probA/probB: (k(k-1)/2,) (sklearn _intercept_, _probA, _probB); n_support: (k,)
+ * proba out: (Nq, k) double */
+int gnxo_svc_predict_proba(const int64_t* Krow, int64_t Nq, int64_t Nt, int k, int64_t nSV,
+                           const int32_t* support, const double* dual, const double* intercept,
+                           const double* probA, const double* probB, const int32_t* n_support,
+                           double* proba) {
+  if (k < 2 || k > 64) return GNXO_EINVAL;
+  int start[64];
+  start[0] = 0;
+  for (int i = 1; i < k; ++i) start[i] = start[i - 1] + n_support[i - 1];
+  double* kv = (double*)malloc(sizeof(double) * (size_t)nSV + sizeof(double) * (size_t)(k * k));
+  if (!kv) return GNXO_ENOMEM;
+  double* r = kv + nSV;
+  const double min_prob = 1e-7;
+  for (int64_t q = 0; q < Nq; ++q) {
+    for (int64_t s = 0; s < nSV; ++s) kv[s] = (double)Krow[q * Nt + support[s]];
+    int p = 0;
+    for (int i = 0; i < k; ++i)
+      for (int j = i + 1; j < k; ++j) {
+        double sum = 0;
+        const int si = start[i], sj = start[j], ci = n_support[i], cj = n_support[j];
+        const double* c1 = dual + (int64_t)(j - 1) * nSV;
+        const double* c2 = dual + (int64_t)i * nSV;
+        for (int t = 0; t < ci; ++t) sum += c1[si + t] * kv[si + t];
+        for (int t = 0; t < cj; ++t) sum += c2[sj + t] * kv[sj + t];
+        sum += intercept[p]; /* = -rho[p] */
+        double v = sigmoid_predict(sum, probA[p], probB[p]);
+        if (v < min_prob) v = min_prob;
+        if (v > 1 - min_prob) v = 1 - min_prob;
+        r[i * k + j] = v;
+        r[j * k + i] = 1 - v;
+        ++p;
+      }
+    multiclass_probability(k, r, proba + q * k);
+  }
+  free(kv);
+  return GNXO_OK;
+}

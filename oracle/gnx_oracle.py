@@ -1,0 +1,352 @@
+"""ctypes front-end of the CPU oracle (oracle/gnx_oracle.c) + the host-side restatements that
+are control flow rather than arithmetic (CovSample, Gnofix loop).
+
+TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  gnomix_amd/ must never import this module.
+
+Reference rows restated: a1-a9.  Pinning status is in gnx_oracle.c's header.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgnx_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (seconds).  Returns the .so path."""
+    src = os.path.join(_HERE, "gnx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgnx_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.gnxo_pad_src.restype = C.c_int64
+        _lib.gnxo_pad_src.argtypes = [C.c_int64] * 3
+        _lib.gnxo_slide_src.restype = C.c_int64
+        _lib.gnxo_slide_src.argtypes = [C.c_int64] * 3
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise ValueError(f"oracle {what} failed with code {rc}")
+
+
+# ------------------------------------------------------------------------------------------------
+# a1-a3 logistic base
+# ------------------------------------------------------------------------------------------------
+def base_lr(X, M, ctx, coef, intercept):
+    """X (N,C) int8; coef (W,A,ldc) f64 zero-padded per window; intercept (W,A) -> B (N,W,A) f64.
+    Restates base.py:146-180 + models.py:12-21 (sklearn OvR logistic)."""
+    X = np.ascontiguousarray(X, dtype=np.int8)
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    intercept = np.ascontiguousarray(intercept, dtype=np.float64)
+    N, Cn = X.shape
+    W, A, ldc = coef.shape
+    assert W == Cn // M, (W, Cn, M)
+    B = np.empty((N, W, A), dtype=np.float64)
+    rc = lib().gnxo_base_lr(_p(X), C.c_int64(N), C.c_int64(Cn), C.c_int64(Cn), C.c_int64(M), C.c_int64(ctx),
+                            C.c_int64(A), _p(coef), C.c_int64(ldc), _p(intercept), _p(B))
+    _chk(rc, "base_lr")
+    return B
+
+
+# ------------------------------------------------------------------------------------------------
+# a5 slide_window
+# ------------------------------------------------------------------------------------------------
+def slide_window(B, S):
+    """(N,W,A) -> (N*W, S*A) float32   (Smooth/utils.py:4-29)"""
+    B = np.ascontiguousarray(B)
+    assert B.dtype in (np.float64, np.float32)
+    N, W, A = B.shape
+    out = np.empty((N * W, S * A), dtype=np.float32)
+    rc = lib().gnxo_slide_window(_p(B), C.c_int(B.dtype == np.float64), C.c_int64(N), C.c_int64(W), C.c_int64(A),
+                                 C.c_int64(S), _p(out))
+    _chk(rc, "slide_window")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# a6 xgboost-schema tree ensemble
+# ------------------------------------------------------------------------------------------------
+class _CTrees(C.Structure):
+    _fields_ = [("n_trees", C.c_int32), ("n_class", C.c_int32), ("tree_off", C.c_void_p), ("left", C.c_void_p),
+                ("right", C.c_void_p), ("feat", C.c_void_p), ("cond", C.c_void_p), ("default_left", C.c_void_p),
+                ("tree_class", C.c_void_p), ("base_score", C.c_float)]
+
+
+@dataclass
+class Trees:
+    """An xgboost-schema ensemble: per-tree node arrays concatenated, tree_off = node offsets.
+    left/right are child indices WITHIN the tree (-1 at leaves); cond holds the split condition
+    at internal nodes and the leaf value at leaves; tree_class = tree_info."""
+    tree_off: np.ndarray
+    left: np.ndarray
+    right: np.ndarray
+    feat: np.ndarray
+    cond: np.ndarray
+    tree_class: np.ndarray
+    n_class: int
+    base_score: float = 0.5
+    default_left: np.ndarray | None = None
+
+    def __post_init__(self):
+        self.tree_off = np.ascontiguousarray(self.tree_off, dtype=np.int32)
+        self.left = np.ascontiguousarray(self.left, dtype=np.int32)
+        self.right = np.ascontiguousarray(self.right, dtype=np.int32)
+        self.feat = np.ascontiguousarray(self.feat, dtype=np.int32)
+        self.cond = np.ascontiguousarray(self.cond, dtype=np.float32)
+        self.tree_class = np.ascontiguousarray(self.tree_class, dtype=np.int32)
+        if self.default_left is not None:
+            self.default_left = np.ascontiguousarray(self.default_left, dtype=np.uint8)
+
+    @property
+    def n_trees(self):
+        return len(self.tree_off) - 1
+
+    def _c(self):
+        return _CTrees(self.n_trees, self.n_class, _p(self.tree_off).value, _p(self.left).value, _p(self.right).value,
+                       _p(self.feat).value, _p(self.cond).value,
+                       _p(self.default_left).value if self.default_left is not None else None,
+                       _p(self.tree_class).value, self.base_score)
+
+
+def xgb_predict_proba(trees: Trees, feats):
+    """model.predict_proba on explicit features (R,F) -> (R,n_class) float32."""
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    R, F = feats.shape
+    out = np.empty((R, trees.n_class), dtype=np.float32)
+    ct = trees._c()
+    _chk(lib().gnxo_xgb_predict_proba(C.byref(ct), _p(feats), C.c_int64(R), C.c_int64(F), _p(out)), "xgb_predict_proba")
+    return out
+
+
+def smooth_xgb(trees: Trees, B, S):
+    """Smoother.predict_proba for XGB_Smoother (smooth.py:40-56): -> proba (N,W,A) f32, labels (N,W) int64."""
+    B = np.ascontiguousarray(B)
+    assert B.dtype in (np.float64, np.float32)
+    N, W, A = B.shape
+    proba = np.empty((N, W, A), dtype=np.float32)
+    labels = np.empty((N, W), dtype=np.int32)
+    ct = trees._c()
+    _chk(lib().gnxo_smooth_xgb(C.byref(ct), _p(B), C.c_int(B.dtype == np.float64), C.c_int64(N), C.c_int64(W),
+                               C.c_int64(A), C.c_int64(S), _p(proba), _p(labels)), "smooth_xgb")
+    return proba, labels.astype(np.int64)
+
+
+def random_trees(n_rounds, n_class, n_feat, depth=4, seed=0, thr_lo=0.0, thr_hi=1.0, leaf_scale=0.3,
+                 p_early_leaf=0.15):
+    """Synthetic xgboost-schema ensemble (round-major, tree t has class t % n_class — the layout
+    multi:softprob produces).  Some branches stop early (leaf at depth < max) as real boosters do."""
+    rng = np.random.RandomState(seed)
+    offs, L, R_, Fe, Cd, cls = [0], [], [], [], [], []
+    for t in range(n_rounds * n_class):
+        nodes = []  # (left,right,feat,cond)
+
+        def grow(d):
+            idx = len(nodes)
+            nodes.append(None)
+            if d == depth or (d > 0 and rng.rand() < p_early_leaf):
+                nodes[idx] = (-1, -1, 0, np.float32(rng.randn() * leaf_scale))
+            else:
+                f = rng.randint(n_feat)
+                thr = np.float32(rng.uniform(thr_lo, thr_hi))
+                l = grow(d + 1)
+                r = grow(d + 1)
+                nodes[idx] = (l, r, f, thr)
+            return idx
+
+        grow(0)
+        for (l, r, f, c) in nodes:
+            L.append(l); R_.append(r); Fe.append(f); Cd.append(c)
+        offs.append(len(L))
+        cls.append(t % n_class)
+    return Trees(np.array(offs), np.array(L), np.array(R_), np.array(Fe), np.array(Cd, dtype=np.float32),
+                 np.array(cls), n_class)
+
+
+# ------------------------------------------------------------------------------------------------
+# a7 CRF marginals
+# ------------------------------------------------------------------------------------------------
+def smooth_crf(B, state, trans):
+    """(N,W,A) f64 -> marginals (N,W,A) f64, labels (N,W).  state[a][y], trans[y'][y]."""
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    state = np.ascontiguousarray(state, dtype=np.float64)
+    trans = np.ascontiguousarray(trans, dtype=np.float64)
+    N, W, A = B.shape
+    proba = np.empty((N, W, A), dtype=np.float64)
+    labels = np.empty((N, W), dtype=np.int32)
+    _chk(lib().gnxo_smooth_crf(_p(B), C.c_int64(N), C.c_int64(W), C.c_int64(A), _p(state), _p(trans), _p(proba),
+                               _p(labels)), "smooth_crf")
+    return proba, labels.astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------
+# a4 CovRSK + SVC probability
+# ------------------------------------------------------------------------------------------------
+def cov_sample(M, alpha=0.6, beta=1.0, seed=37):
+    """CovSample (string_kernel.py:80-89): legacy MT19937 stream, one draw per m in 2..M."""
+    rs = np.random.RandomState(seed)  # == np.random.seed(seed); np.random.rand() draws
+    Ms = [1]
+    for m in range(2, M + 1):
+        if (1 - (alpha ** (m - Ms[-1] + 1))) * (m ** (-beta)) >= rs.random_sample():
+            Ms.append(m)
+    return Ms
+
+
+def ms_ohe(Ms, M):
+    o = np.zeros(M + 2, dtype=np.uint8)
+    o[np.asarray(Ms)] = 1
+    return o
+
+
+def covrsk(Xq, Xt, Ms=None):
+    Xq = np.ascontiguousarray(Xq, dtype=np.int8)
+    Xt = np.ascontiguousarray(Xt, dtype=np.int8)
+    Nq, Mw = Xq.shape
+    Nt = Xt.shape[0]
+    if Ms is None:
+        Ms = cov_sample(Mw)
+    ohe = ms_ohe(Ms, Mw)
+    K = np.empty((Nq, Nt), dtype=np.int64)
+    _chk(lib().gnxo_covrsk(_p(Xq), C.c_int64(Nq), C.c_int64(Mw), _p(Xt), C.c_int64(Nt), C.c_int64(Mw), C.c_int64(Mw),
+                           _p(ohe), _p(K)), "covrsk")
+    return K
+
+
+def string_kernel(Xq, Xt):
+    Xq = np.ascontiguousarray(Xq, dtype=np.int8)
+    Xt = np.ascontiguousarray(Xt, dtype=np.int8)
+    Nq, Mw = Xq.shape
+    Nt = Xt.shape[0]
+    K = np.empty((Nq, Nt), dtype=np.int64)
+    _chk(lib().gnxo_string_kernel(_p(Xq), C.c_int64(Nq), C.c_int64(Mw), _p(Xt), C.c_int64(Nt), C.c_int64(Mw),
+                                  C.c_int64(Mw), _p(K)), "string_kernel")
+    return K
+
+
+def svc_predict_proba(K, support, dual, intercept, probA, probB, n_support):
+    K = np.ascontiguousarray(K, dtype=np.int64)
+    support = np.ascontiguousarray(support, dtype=np.int32)
+    dual = np.ascontiguousarray(dual, dtype=np.float64)
+    intercept = np.ascontiguousarray(intercept, dtype=np.float64)
+    probA = np.ascontiguousarray(probA, dtype=np.float64)
+    probB = np.ascontiguousarray(probB, dtype=np.float64)
+    n_support = np.ascontiguousarray(n_support, dtype=np.int32)
+    Nq, Nt = K.shape
+    k = len(n_support)
+    out = np.empty((Nq, k), dtype=np.float64)
+    _chk(lib().gnxo_svc_predict_proba(_p(K), C.c_int64(Nq), C.c_int64(Nt), C.c_int(k), C.c_int64(len(support)),
+                                      _p(support), _p(dual), _p(intercept), _p(probA), _p(probB), _p(n_support),
+                                      _p(out)), "svc_predict_proba")
+    return out
+
+
+def base_windows(X, M, ctx):
+    """Yield (i, Xw) exactly as base.py:146-164 slices them (pad + window i; last window wider)."""
+    X = np.asarray(X)
+    N, Cn = X.shape
+    W = Cn // M
+    rem = Cn - M * W
+    M_ = M + 2 * ctx
+    idx = np.array([lib().gnxo_pad_src(p, Cn, ctx) for p in range(Cn + 2 * ctx)], dtype=np.int64)
+    for i in range(W):
+        ln = M_ + rem if i == W - 1 else M_
+        yield i, X[:, idx[i * M:i * M + ln]]
+
+
+def base_covrsk(X, M, ctx, windows):
+    """CovRSKBase.predict_proba: windows = list of dicts with Xfit, Ms, support, dual, intercept,
+    probA, probB, n_support per window -> B (N,W,A) f64 (models.py:195-215 + sklearn SVC)."""
+    out = []
+    for i, Xw in base_windows(X, M, ctx):
+        w = windows[i]
+        K = covrsk(Xw, w["Xfit"], w["Ms"])
+        out.append(svc_predict_proba(K, w["support"], w["dual"], w["intercept"], w["probA"], w["probB"], w["n_support"]))
+    return np.swapaxes(np.array(out), 0, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# a9 Gnofix control loop (gnofix.py:58-208 with its default arguments, phasing.py:182-198)
+# ------------------------------------------------------------------------------------------------
+def gnofix(M_hap, P_hap, B, S, predict_rows, predict_labels, max_it=50):
+    """One individual.  M_hap/P_hap: (C,) SNP vectors; B: (2,W,A) base probabilities.
+    predict_rows(rows (R,S*A)) -> (R,A) = smoother.model.predict_proba (gnofix.py:157);
+    predict_labels(B (2,W,A)) -> (2,W) = smoother.predict (gnofix.py:80,190).
+    Returns X_m, X_p, Y_m, Y_p, tracker(2,W), n_switches."""
+    B = np.array(B, copy=True)
+    _, W, A = B.shape
+    window_size = len(M_hap) // W  # gnofix.py:74 (C//W, may differ from M)
+    X_m = np.array(M_hap, dtype=int, copy=True)
+    X_p = np.array(P_hap, dtype=int, copy=True)
+    Y_m, Y_p = predict_labels(B).reshape(2, W)
+    half = (S - 1) // 2
+    c_lo, c_hi = half, W - 1 - half  # centers[0], centers[-1]  (gnofix.py:83)
+    trk_m, trk_p = np.zeros(W, dtype=int), np.ones(W, dtype=int)
+    seen = []
+    n_switch = 0
+    for _ in range(max_it):
+        if any(np.array_equal(X_m, s) for s in seen):  # gnofix.py:108-113
+            break
+        seen.append(X_m)
+        for w in range(1, W):
+            if Y_m[w] != Y_m[w - 1] or Y_p[w] != Y_p[w - 1]:  # check(): "disc_smooth" (gnofix.py:32)
+                center = min(max(w, c_lo), c_hi)  # gnofix.py:122-127
+                lo, hi = center - half, center + half + 1  # scope (gnofix.py:130)
+                m_o, p_o = B[0, lo:hi], B[1, lo:hi]
+                m_s = np.concatenate([B[0, lo:w], B[1, w:hi]])  # single switch at w (gnofix.py:134,144-153)
+                p_s = np.concatenate([B[1, lo:w], B[0, w:hi]])
+                rows = np.stack([m_o, p_o, m_s, p_s]).reshape(4, -1)
+                outs = np.asarray(predict_rows(rows)).reshape(2, 2, A)
+                probs = outs.max(axis=2).max(axis=1)  # prob_comp="max" (gnofix.py:162-163)
+                if probs[1] * 0.5 > probs[0] * 0.5:  # prior_switch_prob=0.5 (gnofix.py:171)
+                    Bm = np.concatenate([B[0, :w], B[1, w:]])
+                    Bp = np.concatenate([B[1, :w], B[0, w:]])
+                    B = np.stack([Bm, Bp])
+                    trk_m, trk_p = (np.concatenate([trk_m[:w], trk_p[w:]]), np.concatenate([trk_p[:w], trk_m[w:]]))
+                    i = w * window_size  # correct_phase_error (phasing.py:188-198)
+                    X_m, X_p = (np.concatenate([X_m[:i], X_p[i:]]), np.concatenate([X_p[:i], X_m[i:]]))
+                    Y_m, Y_p = predict_labels(B).reshape(2, W)
+                    n_switch += 1
+    return X_m, X_p, Y_m, Y_p, np.stack([trk_m, trk_p]), n_switch
+
+
+class OracleXGBSmoother:
+    """Duck-typed stand-in for the reference's XGB_Smoother (smooth.py:40-65 + models.py:8-24):
+    .S .W .A .gnofix .model.predict_proba / .predict_proba / .predict — lets the REFERENCE's own
+    gnofix()/Gnomix.phase() run with the oracle tree walker plugged in (golden G4/G5)."""
+
+    def __init__(self, trees: Trees, W, A, S):
+        self.trees, self.W, self.A, self.S = trees, W, A, S
+        self.gnofix = True
+        self.calibrate = False
+        self.model = self
+
+    def _model_predict_proba(self, rows):
+        return xgb_predict_proba(self.trees, np.asarray(rows, dtype=np.float32))
+
+    def predict_proba(self, B):
+        B = np.asarray(B)
+        if B.ndim == 2:  # used as .model.predict_proba(rows)
+            return self._model_predict_proba(B)
+        return smooth_xgb(self.trees, B, self.S)[0]
+
+    def predict(self, B):
+        return np.argmax(self.predict_proba(B), axis=-1)

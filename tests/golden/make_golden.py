@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the survey
+container (it is imported read-only from /root/reference; nothing of it is copied here).
+
+The reference has no tests and no golden vectors of its own, so every pin is an
+input/output pair produced by executing its own functions:
+
+  G1_lr.npz        LogisticRegressionBase.train + Base.predict_proba   (base.py:146-180, models.py:12-21)
+  G2_covrsk.npz    CovSample / CovRSK kernel / CovRSKBase.predict_proba (string_kernel.py:80-110, models.py:195-215)
+  G3_slide.npz     slide_window                                         (Smooth/utils.py:4-29)
+  G4_smooth.npz    XGB_Smoother.predict_proba/predict glue with the oracle tree walker plugged in
+                   as `.model` (smooth.py:40-65, models.py:22-24) — pins slide/f32 cast/reshape/argmax,
+                   NOT xgboost arithmetic (xgboost is absent: parity unpinned)
+  G5_gnofix.npz    gnofix() and Gnomix.phase() control flow with the same plug (gnofix.py:58-208,
+                   model.py:188-214, phasing.py:182-198)
+  G6_writers/      get_meta_data / write_msp / write_fb text              (postprocess.py:25-126)
+
+Third-party modules the reference imports at module import time but that are absent here
+(xgboost, allel, seaborn, calibration, sklearn_crfsuite) are replaced by empty stubs; no code path
+used below calls into them.  Skips cleanly when /root/reference is absent (e.g. on the GPU box).
+"""
+import os
+import sys
+import types
+import hashlib
+
+import numpy as np
+
+REF = os.environ.get("GNOMIX_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def _stub_modules():
+    for name in ["xgboost", "allel", "seaborn", "calibration", "sklearn_crfsuite"]:
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+    class _XGBClassifier:  # constructor-compatible placeholder; never fitted or called
+        def __init__(self, *a, **k):
+            self.kw = k
+    sys.modules["xgboost"].XGBClassifier = _XGBClassifier
+    class _CRF:
+        def __init__(self, *a, **k):
+            pass
+    sys.modules["sklearn_crfsuite"].CRF = _CRF
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        return False
+    _stub_modules()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    return True
+
+
+def synth_admixed(rng, n, C, A, W, M, miss=0.01, switch_p=0.02):
+    """Toy phased haplotypes: per-ancestry allele frequencies, ancestry piecewise-constant over windows."""
+    freq = rng.uniform(0.05, 0.95, size=(A, C))
+    y = np.empty((n, W), dtype=int)
+    for i in range(n):
+        a = rng.randint(A)
+        for w in range(W):
+            if rng.rand() < switch_p:
+                a = rng.randint(A)
+            y[i, w] = a
+    ysnp = np.repeat(y, M, axis=1)
+    ysnp = np.concatenate([ysnp, np.repeat(y[:, -1:], C - ysnp.shape[1], axis=1)], axis=1)
+    p = freq[ysnp, np.arange(C)[None, :]]
+    X = (rng.uniform(size=(n, C)) < p).astype(np.int8)
+    X[rng.uniform(size=(n, C)) < miss] = 2
+    return X, y
+
+
+def make_G1(out):
+    from src.Base.models import LogisticRegressionBase
+    rng = np.random.RandomState(94305)
+    C, M, A = 4037, 100, 7
+    W, ctx = C // M, 50
+    Xt, yt = synth_admixed(rng, 420, C, A, W, M)
+    # make sure every window sees every class (no classes_ remap in the vectorized path, base.py:176)
+    for w in range(W):
+        for a in range(A):
+            yt[a, w] = a
+    base = LogisticRegressionBase(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx,
+                                  n_jobs=1, seed=94305, verbose=False)
+    base.base_multithread = False  # serial dispatch: same arithmetic, no spawn pool (base.py:170-174)
+    base.train(Xt, yt)
+    Xq, _ = synth_admixed(rng, 24, C, A, W, M, miss=0.03, switch_p=0.1)
+    B = base.predict_proba(Xq)
+    M_ = M + 2 * ctx
+    rem = C - M * W
+    ldc = M_ + rem
+    coef = np.zeros((W, A, ldc))
+    icpt = np.zeros((W, A))
+    for i, m in enumerate(base.models):
+        assert list(m.classes_) == list(range(A))
+        coef[i, :, :m.coef_.shape[1]] = m.coef_
+        icpt[i] = m.intercept_
+    np.savez_compressed(out, C=C, M=M, A=A, ctx=ctx, X=Xq, coef=coef, intercept=icpt, B=B)
+    print("G1", B.shape, B.dtype)
+
+
+def make_G2(out):
+    import numpy
+    from src.Base import string_kernel as sk
+    anchors = {}
+    for m in (8, 20, 349, 499, 2000, 2500):
+        anchors[str(m)] = np.array(sk.CovSample(m, 0.6, 1.0, 37))
+    a = np.array([0, 1, 1, 0, 2, 2, 1, 0, 0, 1], dtype=np.int8)
+    b = np.array([0, 1, 0, 0, 2, 2, 1, 1, 0, 1], dtype=np.int8)
+    k_ab = sk.CovRSK_DP_triangular_numbers(a[None], b[None])
+    k_ab_plain = sk.string_kernel_DP_triangular_numbers(a[None], b[None])
+    ones = np.zeros((1, 8), dtype=np.int8)
+    k_eq = sk.CovRSK_DP_triangular_numbers(ones, ones)
+    k_eq_plain = sk.string_kernel_DP_triangular_numbers(ones, ones)
+
+    rng = np.random.RandomState(7)
+    C, M, A = 537, 50, 3
+    W, ctx = C // M, 25
+    Xt, yt = synth_admixed(rng, 60, C, A, W, M, switch_p=0.0)
+    for w in range(W):
+        for c in range(A):
+            yt[c * 2:(c * 2 + 2), w] = c
+    real_ver = numpy.__version__
+    numpy.__version__ = "1.26.4"  # models.py:200 parses the MINOR version ("2.2.6" -> 2 < 20)
+    try:
+        from src.Base.models import CovRSKBase
+        base = CovRSKBase(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx, n_jobs=1,
+                          seed=94305, verbose=False)
+    finally:
+        numpy.__version__ = real_ver
+    base.base_multithread = False
+    base.log_inference = False
+    np.random.seed(11)
+    base.train(Xt, yt)
+    Xq, _ = synth_admixed(rng, 10, C, A, W, M, miss=0.05, switch_p=0.2)
+    B = base.predict_proba(Xq)
+    d = dict(C=C, M=M, A=A, ctx=ctx, X=Xq, B=B, k_ab=k_ab, k_ab_plain=k_ab_plain, k_eq=k_eq, k_eq_plain=k_eq_plain,
+             a=a, b=b)
+    for k, v in anchors.items():
+        d["Ms_%s" % k] = v
+    # a kernel matrix for window 3, computed by the reference kernel
+    M_ = M + 2 * ctx
+    Xp = base.pad(Xq)
+    Xw3 = Xp[:, 3 * M:3 * M + M_]
+    for i, m in enumerate(base.models):
+        assert list(m.classes_) == list(range(A))
+        xf = getattr(m, "_BaseLibSVM__Xfit")
+        d["w%d_Xfit" % i] = np.asarray(xf, dtype=np.int8)
+        d["w%d_support" % i] = m.support_.astype(np.int32)
+        d["w%d_dual" % i] = m._dual_coef_
+        d["w%d_intercept" % i] = m._intercept_
+        d["w%d_probA" % i] = m._probA
+        d["w%d_probB" % i] = m._probB
+        d["w%d_nsv" % i] = m._n_support.astype(np.int32)
+    d["K_w3"] = sk.CovRSK_DP_triangular_numbers(Xw3, d["w3_Xfit"])
+    np.savez_compressed(out, **d)
+    print("G2", B.shape, {k: list(v) for k, v in anchors.items() if int(k) < 600})
+
+
+def make_G3(out):
+    from src.Smooth.utils import slide_window
+    rng = np.random.RandomState(3)
+    d = {}
+    B0 = np.arange(6, dtype=float).reshape(1, 6, 1)
+    d["tiny_B"] = B0
+    d["tiny_S3"] = slide_window(B0, 3)[0]
+    for name, (N, W, A, S) in {"a": (2, 9, 3, 5), "b": (3, 14, 2, 7), "c": (1, 80, 7, 75), "d": (2, 151, 4, 75)}.items():
+        B = rng.uniform(size=(N, W, A))
+        o = slide_window(B, S)[0]
+        d[name + "_B"] = B
+        d[name + "_S"] = S
+        if o.size < 20000:
+            d[name + "_out"] = o
+        else:  # big: keep a digest + strided sample of rows
+            d[name + "_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(o).tobytes()).digest(), dtype=np.uint8)
+            d[name + "_rows"] = np.arange(0, o.shape[0], 7)
+            d[name + "_out"] = o[::7]
+    np.savez_compressed(out, **d)
+    print("G3 ok")
+
+
+def handmade_smoothing_trees(A, S, reach=6):
+    """A tiny 'sensible' smoother in xgboost schema: class-c trees vote +/- by thresholding the base
+    probability of class c at windows near the centre of the sliding window (centre index = pad-1)."""
+    sys.path.insert(0, ROOT)
+    from oracle import gnx_oracle as O
+    pad = (S + 1) // 2
+    centre = pad - 1  # slide_window is centred on w-1+...: feature s=pad-1 is window w-1
+    offs, L, R, F, Cd, cls = [0], [], [], [], [], []
+    for k in range(-reach, reach + 1):
+        for c in range(A):
+            s = centre + 1 + k  # window w+k
+            f = s * A + c
+            wgt = 0.6 / (1 + abs(k))
+            # depth-2 tree: root on class-c prob at w+k; right child refines
+            nodes = [(1, 2, f, 0.5), (-1, -1, 0, -wgt), (3, 4, f, 0.8), (-1, -1, 0, wgt), (-1, -1, 0, 1.5 * wgt)]
+            for (l, r, ff, cc) in nodes:
+                L.append(l); R.append(r); F.append(ff); Cd.append(cc)
+            offs.append(len(L))
+            cls.append(c)
+    return O.Trees(np.array(offs), np.array(L), np.array(R), np.array(F), np.array(Cd, dtype=np.float32),
+                   np.array(cls), A)
+
+
+def trees_to_npz(prefix, T):
+    return {prefix + "tree_off": T.tree_off, prefix + "left": T.left, prefix + "right": T.right,
+            prefix + "feat": T.feat, prefix + "cond": T.cond, prefix + "tree_class": T.tree_class,
+            prefix + "n_class": T.n_class, prefix + "base_score": T.base_score}
+
+
+def make_G4(out):
+    sys.path.insert(0, ROOT)
+    from oracle import gnx_oracle as O
+    from src.Smooth.models import XGB_Smoother
+    rng = np.random.RandomState(4)
+    N, W, A, S = 5, 163, 7, 75
+    B = rng.dirichlet(np.ones(A) * 0.3, size=(N, W))
+    T = O.random_trees(6, A, S * A, depth=4, seed=5)
+    sm = XGB_Smoother(n_windows=W, num_ancestry=A, smooth_window_size=S, n_jobs=1, calibrate=False, mode_filter=0,
+                      seed=1, verbose=False)
+    sm.model = O.OracleXGBSmoother(T, W, A, S)  # the oracle tree walker stands in for XGBClassifier
+    proba = sm.predict_proba(B)
+    labels = sm.predict(B)
+    d = dict(B=B, S=S, proba=proba, labels=labels)
+    d.update(trees_to_npz("t_", T))
+    np.savez_compressed(out, **d)
+    print("G4", proba.shape, proba.dtype, labels.dtype)
+
+
+def make_G5(out):
+    sys.path.insert(0, ROOT)
+    from oracle import gnx_oracle as O
+    from src.Gnofix.gnofix import gnofix
+    from src.model import Gnomix
+    rng = np.random.RandomState(5)
+    W, A, S, Mw = 160, 4, 75, 6
+    Cn = W * Mw + 3
+    T = handmade_smoothing_trees(A, S)
+    sm = O.OracleXGBSmoother(T, W, A, S)
+    d = dict(W=W, A=A, S=S, C=Cn)
+    d.update(trees_to_npz("t_", T))
+
+    def individual(switch_points, seg_m, seg_p, noise=0.15):
+        """true ancestry per haplotype from segment lists, then scramble phase at switch_points"""
+        def expand(seg):
+            y = np.empty(W, dtype=int)
+            for (a, b, c) in seg:
+                y[a:b] = c
+            return y
+        ym, yp = expand(seg_m), expand(seg_p)
+        Bm = np.full((W, A), noise / (A - 1)); Bm[np.arange(W), ym] = 1 - noise
+        Bp = np.full((W, A), noise / (A - 1)); Bp[np.arange(W), yp] = 1 - noise
+        Bm = Bm * rng.uniform(0.8, 1.2, size=Bm.shape); Bm /= Bm.sum(1, keepdims=True)
+        Bp = Bp * rng.uniform(0.8, 1.2, size=Bp.shape); Bp /= Bp.sum(1, keepdims=True)
+        Xm = rng.randint(0, 2, size=Cn); Xp = rng.randint(0, 2, size=Cn)
+        for s in switch_points:
+            Bm, Bp = np.concatenate([Bm[:s], Bp[s:]]), np.concatenate([Bp[:s], Bm[s:]])
+            i = s * (Cn // W)
+            Xm, Xp = np.concatenate([Xm[:i], Xp[i:]]), np.concatenate([Xp[:i], Xm[i:]])
+        return Xm, Xp, np.stack([Bm, Bp])
+
+    cases = {
+        "none": individual([], [(0, W, 0)], [(0, W, 1)]),
+        "one": individual([70], [(0, W, 0)], [(0, W, 1)]),
+        "two": individual([50, 110], [(0, W, 2)], [(0, 90, 1), (90, W, 3)]),
+        "edges": individual([5, 152], [(0, W, 0)], [(0, W, 3)]),
+        "many": individual([20, 40, 41, 77, 120, 121, 122], [(0, 80, 0), (80, W, 2)], [(0, W, 1)]),
+    }
+    for name, (Xm, Xp, Bi) in cases.items():
+        r = gnofix(Xm, Xp, B=Bi, smoother=sm)
+        X_m, X_p, Y_m, Y_p, history, tracker = r
+        d[name + "_Xm"], d[name + "_Xp"], d[name + "_B"] = Xm, Xp, Bi
+        d[name + "_oXm"], d[name + "_oXp"], d[name + "_oYm"], d[name + "_oYp"] = X_m, X_p, Y_m, Y_p
+        d[name + "_trk"] = np.array(tracker)
+        d[name + "_nhist"] = history.shape[-1] if history.ndim == 3 else 1
+        print("G5", name, "history", d[name + "_nhist"])
+    # chaotic smoother (random trees): exercises many accepted/rejected switches and the max_it stop
+    Tr = O.random_trees(3, A, S * A, depth=4, seed=9, leaf_scale=1.0)
+    smr = O.OracleXGBSmoother(Tr, W, A, S)
+    Xm, Xp, Bi = individual([30, 90], [(0, W, 0)], [(0, W, 1)], noise=0.5)
+    r = gnofix(Xm, Xp, B=Bi, smoother=smr, max_it=4)
+    d.update(trees_to_npz("r_", Tr))
+    d["rand_Xm"], d["rand_Xp"], d["rand_B"] = Xm, Xp, Bi
+    d["rand_oXm"], d["rand_oXp"], d["rand_oYm"], d["rand_oYp"] = r[0], r[1], r[2], r[3]
+    d["rand_trk"] = np.array(r[5]); d["rand_nhist"] = r[4].shape[-1]
+    print("G5 rand history", d["rand_nhist"])
+    # Gnomix.phase wrapper (model.py:188-214) over 3 individuals
+    g = Gnomix.__new__(Gnomix)
+    g.smooth, g.W, g.A, g.base = sm, W, A, None
+    Xs, Bs = [], []
+    for name in ("one", "two", "none"):
+        Xm, Xp, Bi = cases[name]
+        Xs += [Xm, Xp]; Bs += [Bi[0], Bi[1]]
+    Xs, Bs = np.array(Xs), np.array(Bs)
+    Xph, Yph = g.phase(Xs, B=Bs)
+    d["phase_X"], d["phase_B"], d["phase_oX"], d["phase_oY"] = Xs, Bs, Xph, Yph
+    np.savez_compressed(out, **d)
+
+
+def make_G6(outdir):
+    import pandas as pd
+    from src.postprocess import get_meta_data, write_msp, write_fb
+    os.makedirs(outdir, exist_ok=True)
+    rng = np.random.RandomState(6)
+    W, M, A, n_ind = 7, 10, 3, 2
+    Cn = W * M + 4
+    model_pos = np.sort(rng.choice(np.arange(10000, 900000), size=Cn, replace=False))
+    query_pos = np.sort(rng.choice(model_pos, size=Cn - 9, replace=False))
+    gen_map_df = pd.DataFrame({"chm": ["22"] * 5, "pos": [5000, 200000, 400000, 700000, 1000000],
+                               "pos_cm": [0.0, 0.31, 0.7345678, 1.2, 2.05]})
+    meta = get_meta_data("22", model_pos, query_pos, W, M, gen_map_df)
+    proba = rng.dirichlet(np.ones(A), size=(2 * n_ind, W)).astype(np.float32)
+    labels = np.argmax(proba, axis=-1)
+    pops = ["AFR", "EUR", "EAS"]
+    samples = np.array(["HG001", "NA002"])
+    write_msp(os.path.join(outdir, "ref"), meta, labels, pops, samples)
+    write_fb(os.path.join(outdir, "ref"), meta, proba, pops, samples)
+    np.savez_compressed(os.path.join(outdir, "inputs.npz"), model_pos=model_pos, query_pos=query_pos,
+                        gm_pos=gen_map_df.pos.values, gm_cm=gen_map_df.pos_cm.values, proba=proba, labels=labels,
+                        W=W, M=M, A=A, pops=np.array(pops), samples=samples)
+    print("G6 ok")
+
+
+def main():
+    if not import_reference():
+        print("reference not found at", REF, "- nothing generated")
+        return 0
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6"]
+    if "G1" in which: make_G1(os.path.join(HERE, "G1_lr.npz"))
+    if "G2" in which: make_G2(os.path.join(HERE, "G2_covrsk.npz"))
+    if "G3" in which: make_G3(os.path.join(HERE, "G3_slide.npz"))
+    if "G4" in which: make_G4(os.path.join(HERE, "G4_smooth.npz"))
+    if "G5" in which: make_G5(os.path.join(HERE, "G5_gnofix.npz"))
+    if "G6" in which: make_G6(os.path.join(HERE, "G6_writers"))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

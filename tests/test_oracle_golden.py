@@ -1,0 +1,123 @@
+"""The oracle (oracle/) against the golden vectors produced by RUNNING THE REFERENCE
+(tests/golden/make_golden.py).  CPU only.  These tests pin the oracle; the -m gpu tests then
+compare the HIP path with the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, trees_from_npz
+
+
+def test_G1_logistic_base(oracle):
+    g = load_golden("G1_lr.npz")
+    B = oracle.base_lr(g["X"], int(g["M"]), int(g["ctx"]), g["coef"], g["intercept"])
+    assert B.shape == g["B"].shape and B.dtype == np.float64
+    # sklearn uses BLAS (unknown summation order): agreement is at f64 round-off, far below 1e-5
+    assert np.max(np.abs(B - g["B"])) < 1e-13
+    # what the smoother consumes is float32(B) (Smooth/utils.py:20): count bit differences
+    diff = np.count_nonzero(B.astype(np.float32) != g["B"].astype(np.float32))
+    assert diff <= 1, diff
+    assert np.array_equal(np.argmax(B, -1), np.argmax(g["B"], -1))
+    assert (g["X"] == 2).any()  # the fixture exercises the missing code
+
+
+def test_G1_rejects_C_multiple_of_M(oracle):
+    X = np.zeros((2, 40), dtype=np.int8)
+    with pytest.raises(ValueError):
+        oracle.base_lr(X, 10, 5, np.zeros((4, 2, 30)), np.zeros((4, 2)))
+
+
+def test_G2_covsample_anchors(oracle):
+    g = load_golden("G2_covrsk.npz")
+    for m in (8, 20, 349, 499, 2000, 2500):
+        assert oracle.cov_sample(m) == list(g["Ms_%d" % m])
+    assert oracle.cov_sample(349) == [1, 4, 8, 39, 42, 117]
+    assert oracle.cov_sample(2000) == [1, 4, 8, 39, 42, 117, 376, 866]
+
+
+def test_G2_kernel_known_answers(oracle):
+    g = load_golden("G2_covrsk.npz")
+    a, b = g["a"][None], g["b"][None]
+    assert oracle.covrsk(a, b)[0, 0] == g["k_ab"][0, 0] == 9
+    assert oracle.string_kernel(a, b)[0, 0] == g["k_ab_plain"][0, 0] == 16
+    z = np.zeros((1, 8), dtype=np.int8)
+    assert oracle.covrsk(z, z)[0, 0] == g["k_eq"][0, 0] == 14
+    assert oracle.string_kernel(z, z)[0, 0] == g["k_eq_plain"][0, 0] == 36
+
+
+def _g2_windows(g):
+    W = int(g["C"]) // int(g["M"])
+    ws = []
+    for i in range(W):
+        xf = g["w%d_Xfit" % i]
+        ws.append(dict(Xfit=xf, Ms=None, support=g["w%d_support" % i], dual=g["w%d_dual" % i],
+                       intercept=g["w%d_intercept" % i], probA=g["w%d_probA" % i], probB=g["w%d_probB" % i],
+                       n_support=g["w%d_nsv" % i]))
+    return ws
+
+
+def test_G2_covrsk_base(oracle):
+    g = load_golden("G2_covrsk.npz")
+    M, ctx = int(g["M"]), int(g["ctx"])
+    ws = _g2_windows(g)
+    for w in ws:
+        w["Ms"] = oracle.cov_sample(w["Xfit"].shape[1])
+    wins = dict(oracle.base_windows(g["X"], M, ctx))
+    assert np.array_equal(oracle.covrsk(wins[3], ws[3]["Xfit"], ws[3]["Ms"]), g["K_w3"])
+    B = oracle.base_covrsk(g["X"], M, ctx, ws)
+    assert B.shape == g["B"].shape
+    assert np.max(np.abs(B - g["B"])) < 1e-12
+    assert (g["X"] == 2).any()
+
+
+def test_G3_slide_window(oracle):
+    g = load_golden("G3_slide.npz")
+    assert np.array_equal(oracle.slide_window(g["tiny_B"], 3), g["tiny_S3"])
+    assert g["tiny_S3"].tolist() == [[1, 0, 0], [0, 0, 1], [0, 1, 2], [1, 2, 3], [2, 3, 4], [3, 4, 5]]
+    for name in "abcd":
+        B, S = g[name + "_B"], int(g[name + "_S"])
+        o = oracle.slide_window(B, S)
+        assert o.dtype == np.float32
+        if name + "_sha" in g:
+            assert hashlib.sha256(o.tobytes()).digest() == g[name + "_sha"].tobytes()
+            assert np.array_equal(o[g[name + "_rows"]], g[name + "_out"])
+        else:
+            assert np.array_equal(o, g[name + "_out"])
+
+
+def test_G4_smoother_glue(oracle):
+    g = load_golden("G4_smooth.npz")
+    T = trees_from_npz(oracle, g, "t_")
+    proba, labels = oracle.smooth_xgb(T, g["B"], int(g["S"]))
+    assert np.array_equal(proba, g["proba"])  # same walker on both sides: pins slide/cast/reshape/argmax
+    assert np.array_equal(labels, g["labels"])
+    assert np.allclose(proba.sum(-1), 1, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["none", "one", "two", "edges", "many", "rand"])
+def test_G5_gnofix(oracle, name):
+    g = load_golden("G5_gnofix.npz")
+    W, A, S = int(g["W"]), int(g["A"]), int(g["S"])
+    T = trees_from_npz(oracle, g, "r_" if name == "rand" else "t_")
+    rows = lambda r: oracle.xgb_predict_proba(T, r)
+    labs = lambda B: oracle.smooth_xgb(T, B, S)[1]
+    Xm, Xp, Ym, Yp, trk, nsw = oracle.gnofix(g[name + "_Xm"], g[name + "_Xp"], g[name + "_B"], S, rows, labs,
+                                             max_it=4 if name == "rand" else 50)
+    assert np.array_equal(Xm, g[name + "_oXm"]) and np.array_equal(Xp, g[name + "_oXp"])
+    assert np.array_equal(Ym, g[name + "_oYm"]) and np.array_equal(Yp, g[name + "_oYp"])
+    assert np.array_equal(trk, g[name + "_trk"])
+    assert nsw == int(g[name + "_nhist"]) - 2  # history = initial + one per accepted switch + final
+
+
+def test_G5_phase_wrapper(oracle):
+    g = load_golden("G5_gnofix.npz")
+    W, A, S = int(g["W"]), int(g["A"]), int(g["S"])
+    T = trees_from_npz(oracle, g, "t_")
+    rows = lambda r: oracle.xgb_predict_proba(T, r)
+    labs = lambda B: oracle.smooth_xgb(T, B, S)[1]
+    X, B = g["phase_X"], g["phase_B"]
+    for i in range(X.shape[0] // 2):
+        Xm, Xp, Ym, Yp, _, _ = oracle.gnofix(X[2 * i], X[2 * i + 1], B[2 * i:2 * i + 2], S, rows, labs)
+        assert np.array_equal(np.stack([Xm, Xp]), g["phase_oX"][2 * i:2 * i + 2])
+        assert np.array_equal(np.stack([Ym, Yp]), g["phase_oY"][2 * i:2 * i + 2])
