@@ -1,0 +1,173 @@
+"""ctypes binding of libgnomix_hip.so (include/gnomix_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or cannot be loaded the import of the
+compute entry points fails loudly (GnxLibraryError).  Build it with `python __graft_entry__.py`
+(or `make -C gnomix_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
+
+GNX_ABI_VERSION = 1
+GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
+BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC = 0, 1, 2
+SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF = 0, 1, 2
+K_BASE_LOGISTIC, K_SMOOTH_XGB, K_BASE_COVRSK, K_SMOOTH_CRF, K_GNOFIX, K_SMOOTH_ROWS = range(6)
+KERNEL_NAMES = {K_BASE_LOGISTIC: "k_base_logistic", K_SMOOTH_XGB: "k_smooth_xgb", K_BASE_COVRSK: "k_base_covrsk",
+                K_SMOOTH_CRF: "k_smooth_crf", K_GNOFIX: "k_gnofix", K_SMOOTH_ROWS: "k_smooth_rows"}
+
+
+class GnxLibraryError(ImportError):
+    pass
+
+
+class GnxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gnomix_hip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class SvcWindow(C.Structure):
+    _fields_ = [("xfit", C.c_void_p), ("n_fit", C.c_int32), ("width", C.c_int32), ("support", C.c_void_p),
+                ("n_sv", C.c_int32), ("dual_coef", C.c_void_p), ("intercept", C.c_void_p), ("prob_a", C.c_void_p),
+                ("prob_b", C.c_void_p), ("n_support", C.c_void_p), ("ms", C.c_void_p), ("n_ms", C.c_int32)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("A", C.c_int32), ("C", C.c_int64), ("M", C.c_int64), ("ctx", C.c_int64),
+                ("S", C.c_int32), ("base_kind", C.c_int32), ("smooth_kind", C.c_int32), ("reserved0", C.c_int32),
+                ("lr_coef", C.c_void_p), ("lr_ldc", C.c_int64), ("lr_intercept", C.c_void_p),
+                ("svc", C.c_void_p),
+                ("n_trees", C.c_int32), ("reserved1", C.c_int32), ("tree_off", C.c_void_p), ("left", C.c_void_p),
+                ("right", C.c_void_p), ("feat", C.c_void_p), ("cond", C.c_void_p), ("tree_class", C.c_void_p),
+                ("base_score", C.c_float), ("reserved2", C.c_int32),
+                ("crf_state", C.c_void_p), ("crf_trans", C.c_void_p)]
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [("C", C.c_int64), ("M", C.c_int64), ("ctx", C.c_int64), ("W", C.c_int64), ("A", C.c_int32),
+                ("S", C.c_int32), ("base_kind", C.c_int32), ("smooth_kind", C.c_int32), ("n_trees", C.c_int32),
+                ("tree_depth", C.c_int32), ("device_bytes", C.c_int64)]
+
+
+# every symbol include/gnomix_hip.h declares: (restype, argtypes)
+_VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64
+SYMBOLS = {
+    "gnx_abi_version": (C.c_int, []),
+    "gnx_init": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "gnx_ctx_free": (None, [_VP]),
+    "gnx_last_error": (C.c_char_p, [_VP]),
+    "gnx_set_stream": (C.c_int, [_VP, _VP]),
+    "gnx_synchronize": (C.c_int, [_VP]),
+    "gnx_model_load": (C.c_int, [_VP, C.POINTER(ModelDesc), C.POINTER(_VP)]),
+    "gnx_model_free": (None, [_VP]),
+    "gnx_model_get_info": (C.c_int, [_VP, C.POINTER(ModelInfo)]),
+    "gnx_base_predict": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP]),
+    "gnx_base_predict_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP]),
+    "gnx_smooth_predict": (C.c_int, [_VP, _VP, _I, _I64, _VP, _VP, _VP]),
+    "gnx_smooth_predict_dev": (C.c_int, [_VP, _VP, _I, _I64, _VP, _VP, _VP]),
+    "gnx_infer": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP, _VP]),
+    "gnx_infer_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP, _VP]),
+    "gnx_smooth_rows": (C.c_int, [_VP, _VP, _I64, _VP]),
+    "gnx_gnofix": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
+    "gnx_profile_enable": (C.c_int, [_VP, _I]),
+    "gnx_profile_reset": (C.c_int, [_VP]),
+    "gnx_profile_get": (C.c_int, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libgnomix_hip.so and type every entry point.  Raises GnxLibraryError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise GnxLibraryError(
+            f"{SO_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py` or "
+            f"`make -C gnomix_amd/csrc`).  gnomix_amd has no CPU fallback.")
+    try:
+        # torch (when installed) ships its own libamdhip64 with the same SONAME; importing it first makes
+        # this library and torch share ONE HIP runtime, so device pointers/streams are interchangeable.
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    try:
+        lib = C.CDLL(SO_PATH)
+    except OSError as e:
+        raise GnxLibraryError(f"cannot load {SO_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GnxLibraryError(f"{SO_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gnx_abi_version() != GNX_ABI_VERSION:
+        raise GnxLibraryError("libgnomix_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One gnx_ctx (one per device / per process under torch.distributed)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.gnx_init(int(device), C.byref(h))
+        self.h = h
+        self.device = int(device)
+        if rc != GNX_OK:
+            msg = self.lib.gnx_last_error(h).decode() if h else "gnx_init failed"
+            if h:
+                self.lib.gnx_ctx_free(h)
+            self.h = None
+            raise GnxError(rc, msg)
+
+    def check(self, rc):
+        if rc != GNX_OK:
+            raise GnxError(rc, self.lib.gnx_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.gnx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self.check(self.lib.gnx_synchronize(self.h))
+
+    def profile_enable(self, on=True):
+        self.check(self.lib.gnx_profile_enable(self.h, int(bool(on))))
+
+    def profile_reset(self):
+        self.check(self.lib.gnx_profile_reset(self.h))
+
+    def profile_get(self, kid):
+        ms, n = C.c_double(), C.c_int64()
+        self.check(self.lib.gnx_profile_get(self.h, int(kid), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self.h:
+            self.lib.gnx_ctx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,620 @@
+// gnx_api.hip — the C ABI of libgnomix_hip.so (include/gnomix_hip.h): contexts, model preparation
+// (weight re-layout, tree packing), host staging, profiling.  The kernels live in k_*.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "gnx_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static int fail(gnx_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                      \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      return fail((ctx), GNX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+  } while (0)
+
+static int ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes) {
+  if (bytes <= b.cap) return GNX_OK;
+  if (b.p) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  const size_t cap = bytes + (bytes >> 3) + 256;
+  hipError_t e = hipMalloc(&b.p, cap);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return fail(ctx, GNX_ENOMEM, std::string("hipMalloc(") + std::to_string(cap) + "): " + hipGetErrorString(e));
+  }
+  b.cap = cap;
+  return GNX_OK;
+}
+
+template <typename T>
+static int dev_upload(gnx_model* m, const std::vector<T>& h, const T** out, size_t pad_bytes = 0) {
+  gnx_ctx* ctx = m->ctx;
+  void* p = nullptr;
+  const size_t bytes = h.size() * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes + pad_bytes + 16);
+  if (e != hipSuccess) return fail(ctx, GNX_ENOMEM, std::string("hipMalloc model: ") + hipGetErrorString(e));
+  m->dev_allocs.push_back(p);
+  m->info.device_bytes += (int64_t)(bytes + pad_bytes + 16);
+  if (bytes) HIPCHK(ctx, hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice));
+  if (pad_bytes + 16) HIPCHK(ctx, hipMemset((char*)p + bytes, 0, pad_bytes + 16));
+  *out = (const T*)p;
+  return GNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling: one hipEvent pair per launch on the context stream
+// ------------------------------------------------------------------------------------------------
+struct ProfScope {
+  gnx_ctx* ctx;
+  int kid;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(gnx_ctx* c, int k) : ctx(c), kid(k) {
+    if (!ctx->prof) return;
+    auto get = [&]() {
+      hipEvent_t e = nullptr;
+      if (!ctx->prof_pool.empty()) { e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
+      else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+      return e;
+    };
+    a = get();
+    b = get();
+    if (a && b) (void)hipEventRecord(a, ctx->stream);
+  }
+  ~ProfScope() {
+    if (!ctx->prof || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof_pending.push_back({a, b, kid});
+  }
+};
+
+static void prof_drain(gnx_ctx* ctx) {
+  for (auto& pr : ctx->prof_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(pr.b) == hipSuccess && hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+      ctx->prof_ms[pr.kid] += ms;
+      ctx->prof_n[pr.kid] += 1;
+    }
+    ctx->prof_pool.push_back(pr.a);
+    ctx->prof_pool.push_back(pr.b);
+  }
+  ctx->prof_pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// model preparation: logistic base
+// ------------------------------------------------------------------------------------------------
+static int build_lr(gnx_model* m, const gnx_model_desc* d) {
+  gnx_ctx* ctx = m->ctx;
+  const int64_t C = d->C, M = d->M, cx = d->ctx;
+  const int A = d->A;
+  const int64_t W = C / M, rem = C - M * W, M_ = M + 2 * cx, Cp = C + 2 * cx;
+  if (!d->lr_coef || !d->lr_intercept) return fail(ctx, GNX_EINVAL, "logistic base: lr_coef / lr_intercept is NULL");
+  if (d->lr_ldc < M_ + rem) return fail(ctx, GNX_EINVAL, "logistic base: lr_ldc < M + 2*ctx + rem");
+  const int64_t R = (M_ + M - 1) / M;
+  const int64_t NC = R * A;
+  const int NT = (int)((NC + 15) / 16);
+  if (NT > 4)
+    return fail(ctx, GNX_EUNSUPPORTED, "logistic base: ceil((M+2ctx)/M)*A > 64 class columns per SNP (context ratio too large)");
+
+  auto wstart = [&](int64_t i) { return i * M; };                                // padded coords
+  auto wend = [&](int64_t i) { return (i < W - 1) ? i * M + M_ : Cp; };          // padded coords, exclusive
+  std::vector<int64_t> fpos((size_t)W);                                          // flush position, real coords
+  for (int64_t i = 0; i < W; ++i) fpos[(size_t)i] = std::min<int64_t>(wend(i) - cx, C);
+
+  // pieces end at distinct flush positions
+  std::vector<int64_t> bounds{0};
+  for (int64_t i = 0; i < W; ++i)
+    if (fpos[(size_t)i] > bounds.back()) bounds.push_back(fpos[(size_t)i]);
+  if (bounds.back() != C) return fail(ctx, GNX_EINVAL, "logistic base: internal piece construction failed");
+  const size_t n_pieces = bounds.size() - 1;
+
+  std::vector<int32_t> chunk_j0, chunk_flush0, chunk_nflush, piece_chunk0(n_pieces + 1);
+  std::vector<int64_t> chunk_end;  // real end (exclusive) of the piece the chunk belongs to
+  {
+    int64_t wi = 0;
+    for (size_t k = 0; k < n_pieces; ++k) {
+      piece_chunk0[k] = (int32_t)chunk_j0.size();
+      const int64_t b0 = bounds[k], b1 = bounds[k + 1];
+      const int64_t nch = (b1 - b0 + 63) / 64;
+      int64_t f0 = wi, nf = 0;
+      while (wi < W && fpos[(size_t)wi] == b1) { ++wi; ++nf; }
+      for (int64_t c = 0; c < nch; ++c) {
+        chunk_j0.push_back((int32_t)(b0 + 64 * c));
+        chunk_end.push_back(b1);
+        const bool last = (c == nch - 1);
+        chunk_flush0.push_back(last && nf ? (int32_t)f0 : -1);
+        chunk_nflush.push_back(last ? (int32_t)nf : 0);
+      }
+    }
+    piece_chunk0[n_pieces] = (int32_t)chunk_j0.size();
+  }
+  const size_t n_chunks = chunk_j0.size();
+
+  std::vector<int32_t> win_chunk0((size_t)W), win_chunk1((size_t)W);
+  for (int64_t i = 0; i < W; ++i) {
+    const int64_t s = std::max<int64_t>(wstart(i) - cx, 0);
+    size_t k = (size_t)(std::upper_bound(bounds.begin(), bounds.end(), s) - bounds.begin()) - 1;
+    if (k >= n_pieces) k = n_pieces - 1;
+    win_chunk0[(size_t)i] = piece_chunk0[k];
+    size_t kf = (size_t)(std::lower_bound(bounds.begin(), bounds.end(), fpos[(size_t)i]) - bounds.begin());
+    win_chunk1[(size_t)i] = piece_chunk0[kf];  // piece kf-1 ends at fpos -> one past its last chunk
+  }
+
+  // fragment-ordered, reflect-folded weights
+  std::vector<double> V(n_chunks * 16 * (size_t)NT * 64, 0.0);
+  const double* coef = d->lr_coef;
+  const int64_t ldc = d->lr_ldc;
+  for (size_t c = 0; c < n_chunks; ++c)
+    for (int t = 0; t < 16; ++t)
+      for (int kq = 0; kq < 4; ++kq) {
+        const int64_t j = (int64_t)chunk_j0[c] + 16 * kq + t;
+        if (j >= chunk_end[c]) continue;  // zero rows pad the piece to a multiple of 64 SNPs
+        const int64_t p = j + cx;
+        const int64_t i0 = std::min<int64_t>(p / M, W - 1);
+        for (int64_t slot = 0; slot < R; ++slot) {
+          int64_t i = i0 - (((i0 - slot) % R + R) % R);
+          if (i < 0 || p >= wend(i)) continue;
+          const int64_t ws_ = wstart(i), we_ = wend(i);
+          int64_t pp[3];
+          int np = 0;
+          if (j < cx) pp[np++] = cx - 1 - j;             // left reflection (base.py:42)
+          pp[np++] = p;                                   // direct
+          if (j >= C - cx) pp[np++] = 2 * C + cx - 1 - j; // right reflection (base.py:43)
+          for (int a = 0; a < A; ++a) {
+            double wsum = 0.0;
+            bool any = false;
+            for (int q = 0; q < np; ++q)
+              if (pp[q] >= ws_ && pp[q] < we_) {
+                wsum += coef[((size_t)i * A + a) * (size_t)ldc + (size_t)(pp[q] - ws_)];
+                any = true;
+              }
+            if (!any) continue;
+            const int64_t col = slot * A + a;
+            const int nt = (int)(col / 16), c16 = (int)(col % 16);
+            V[((c * 16 + (size_t)t) * NT + (size_t)nt) * 64 + (size_t)(kq * 16 + c16)] = wsum;
+          }
+        }
+      }
+
+  std::vector<double> icpt(d->lr_intercept, d->lr_intercept + (size_t)W * A);
+  int rc;
+  if ((rc = dev_upload(m, V, &m->lr.V)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, icpt, &m->lr.icpt)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, chunk_j0, &m->lr.chunk_j0)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, chunk_flush0, &m->lr.chunk_flush0)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, chunk_nflush, &m->lr.chunk_nflush)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, win_chunk0, &m->lr.win_chunk0)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, win_chunk1, &m->lr.win_chunk1)) != GNX_OK) return rc;
+  m->lr.n_chunks = (int32_t)n_chunks;
+  m->lr.R = (int32_t)R;
+  m->lr.NT = NT;
+  return GNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model preparation: xgboost-schema trees -> class-major complete heaps
+// ------------------------------------------------------------------------------------------------
+static int tree_depth(const gnx_model_desc* d, int32_t o, int32_t nid, int32_t n_nodes, int guard) {
+  if (guard > 64 || nid < 0 || nid >= n_nodes) return -1000;
+  if (d->left[o + nid] == -1) return 0;
+  const int l = tree_depth(d, o, d->left[o + nid], n_nodes, guard + 1);
+  const int r = tree_depth(d, o, d->right[o + nid], n_nodes, guard + 1);
+  if (l < 0 || r < 0) return -1000;
+  return 1 + std::max(l, r);
+}
+
+static void tree_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint8_t* out) {
+  const uint32_t n_int = (1u << D) - 1;
+  const bool leaf = (nid >= 0) && d->left[o + nid] == -1;
+  if (depth == D) {
+    float v = d->cond[o + nid];
+    std::memcpy(out + n_int * 8 + (j - (1u << D)) * 4, &v, 4);
+    return;
+  }
+  uint32_t foff;
+  float thr;
+  if (leaf) {  // early leaf: dummy split that always goes left, both subtrees carry the leaf value
+    foff = 0;
+    thr = std::numeric_limits<float>::infinity();
+    std::memcpy(out + (j - 1) * 8, &foff, 4);
+    std::memcpy(out + (j - 1) * 8 + 4, &thr, 4);
+    tree_fill(d, o, nid, 2 * j, depth + 1, D, out);
+    tree_fill(d, o, nid, 2 * j + 1, depth + 1, D, out);
+  } else {
+    foff = (uint32_t)d->feat[o + nid] * 4u;
+    thr = d->cond[o + nid];
+    std::memcpy(out + (j - 1) * 8, &foff, 4);
+    std::memcpy(out + (j - 1) * 8 + 4, &thr, 4);
+    tree_fill(d, o, d->left[o + nid], 2 * j, depth + 1, D, out);
+    tree_fill(d, o, d->right[o + nid], 2 * j + 1, depth + 1, D, out);
+  }
+}
+
+static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
+  gnx_ctx* ctx = m->ctx;
+  const int A = d->A, S = d->S, F = S * A;
+  if (d->n_trees <= 0 || !d->tree_off || !d->left || !d->right || !d->feat || !d->cond || !d->tree_class)
+    return fail(ctx, GNX_EINVAL, "xgb smoother: tree arrays missing");
+  const int64_t W = d->C / d->M;
+  if (W < 2 * (int64_t)S)  // src/Smooth/models.py:13
+    return fail(ctx, GNX_EINVAL, "Smoother size to large for given window size. ");
+  int D = 1;
+  for (int t = 0; t < d->n_trees; ++t) {
+    const int32_t o = d->tree_off[t], nn = d->tree_off[t + 1] - o;
+    if (nn <= 0) return fail(ctx, GNX_EINVAL, "xgb smoother: empty tree");
+    const int dep = tree_depth(d, o, 0, nn, 0);
+    if (dep < 0) return fail(ctx, GNX_EINVAL, "xgb smoother: malformed tree (child index out of range or depth > 64)");
+    D = std::max(D, dep);
+    if (d->tree_class[t] < 0 || d->tree_class[t] >= A) return fail(ctx, GNX_EINVAL, "xgb smoother: tree_class out of range");
+    for (int32_t k = 0; k < nn; ++k)
+      if (d->left[o + k] != -1 && (d->feat[o + k] < 0 || d->feat[o + k] >= F))
+        return fail(ctx, GNX_EINVAL, "xgb smoother: split feature outside the S*A sliding window");
+  }
+  if (D > 8) return fail(ctx, GNX_EUNSUPPORTED, "xgb smoother: tree depth > 8");
+  const int tree_bytes = (int)(((1u << D) - 1) * 8 + (1u << D) * 4);
+  const int G = std::max(1, std::min(25, 16384 / tree_bytes));
+
+  std::vector<int32_t> order;
+  order.reserve((size_t)d->n_trees);
+  std::vector<int32_t> group_tree0, group_class;
+  for (int c = 0; c < A; ++c) {
+    int in_group = 0;
+    for (int t = 0; t < d->n_trees; ++t) {
+      if (d->tree_class[t] != c) continue;
+      if (in_group == 0) { group_tree0.push_back((int32_t)order.size()); group_class.push_back(c); }
+      order.push_back(t);
+      if (++in_group == G) in_group = 0;
+    }
+  }
+  group_tree0.push_back((int32_t)order.size());
+  std::vector<uint8_t> packed((size_t)d->n_trees * tree_bytes, 0);
+  for (size_t k = 0; k < order.size(); ++k)
+    tree_fill(d, d->tree_off[order[k]], 0, 1, 0, D, packed.data() + k * tree_bytes);
+
+  int rc;
+  if ((rc = dev_upload(m, packed, &m->xgb.packed, 64)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, group_tree0, &m->xgb.group_tree0)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, group_class, &m->xgb.group_class)) != GNX_OK) return rc;
+  m->xgb.n_groups = (int32_t)group_class.size();
+  m->xgb.n_trees = d->n_trees;
+  m->xgb.D = D;
+  m->xgb.tree_bytes = tree_bytes;
+  m->xgb.max_group = G;
+  m->xgb.base_score = d->base_score;
+  m->info.n_trees = d->n_trees;
+  m->info.tree_depth = D;
+  return GNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int gnx_abi_version(void) { return GNX_ABI_VERSION; }
+
+int gnx_init(int device, gnx_ctx** out) {
+  if (!out) return GNX_EINVAL;
+  *out = nullptr;
+  gnx_ctx* ctx = new (std::nothrow) gnx_ctx();
+  if (!ctx) return GNX_ENOMEM;
+  ctx->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    // the context is returned so the caller can read the message, but it is unusable
+    ctx->err = std::string("gnx_init: ") + hipGetErrorString(e);
+    ctx->stream = nullptr;
+    *out = ctx;
+    return GNX_EHIP;
+  }
+  ctx->own_stream = true;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return GNX_OK;
+}
+
+void gnx_ctx_free(gnx_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  prof_drain(ctx);
+  for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
+  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc})
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* gnx_last_error(const gnx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int gnx_set_stream(gnx_ctx* ctx, void* hip_stream) {
+  if (!ctx) return GNX_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (hip_stream == nullptr) {
+    if (!ctx->own_stream) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+    return GNX_OK;
+  }
+  if (ctx->own_stream) {
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+  }
+  ctx->stream = (hipStream_t)hip_stream;
+  return GNX_OK;
+}
+
+int gnx_synchronize(gnx_ctx* ctx) {
+  if (!ctx) return GNX_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GNX_OK;
+}
+
+int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
+  if (!ctx || !out) return GNX_EINVAL;
+  *out = nullptr;
+  if (!ctx->stream) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
+  if (!d) return fail(ctx, GNX_EINVAL, "model description is NULL");
+  if (d->abi_version != GNX_ABI_VERSION) return fail(ctx, GNX_EINVAL, "gnx_model_desc.abi_version mismatch");
+  if (d->A < 2 || d->A > 32) return fail(ctx, GNX_EINVAL, "A (ancestries) must be in [2, 32]");
+  if (d->M <= 0 || d->C < d->M || d->ctx < 0 || d->ctx > d->C) return fail(ctx, GNX_EINVAL, "bad C / M / ctx");
+  if (d->C % d->M == 0)  // src/Base/base.py:158 + gnomix.py:124-125
+    return fail(ctx, GNX_EINVAL, "C % M == 0: the reference's window slicing (base.py:158) requires a remainder");
+  if (d->C > (int64_t)1 << 30) return fail(ctx, GNX_EINVAL, "C too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  gnx_model* m = new (std::nothrow) gnx_model();
+  if (!m) return fail(ctx, GNX_ENOMEM, "host allocation failed");
+  m->ctx = ctx;
+  m->info.C = d->C; m->info.M = d->M; m->info.ctx = d->ctx; m->info.W = d->C / d->M;
+  m->info.A = d->A; m->info.S = d->S; m->info.base_kind = d->base_kind; m->info.smooth_kind = d->smooth_kind;
+  int rc = GNX_OK;
+  switch (d->base_kind) {
+    case GNX_BASE_NONE: break;
+    case GNX_BASE_LOGISTIC: rc = build_lr(m, d); break;
+    case GNX_BASE_COVRSK_SVC: rc = fail(ctx, GNX_EUNSUPPORTED, "CovRSK/SVC base: kernel not built yet"); break;
+    default: rc = fail(ctx, GNX_EINVAL, "unknown base_kind");
+  }
+  if (rc == GNX_OK) switch (d->smooth_kind) {
+    case GNX_SMOOTH_NONE: break;
+    case GNX_SMOOTH_XGB:
+      if (d->S <= 0 || d->S % 2 == 0) rc = fail(ctx, GNX_EINVAL, "S must be odd and positive (smooth.py:14)");
+      else rc = build_xgb(m, d);
+      break;
+    case GNX_SMOOTH_CRF: rc = fail(ctx, GNX_EUNSUPPORTED, "CRF smoother: kernel not built yet"); break;
+    default: rc = fail(ctx, GNX_EINVAL, "unknown smooth_kind");
+  }
+  if (rc != GNX_OK) {
+    gnx_model_free(m);
+    return rc;
+  }
+  *out = m;
+  return GNX_OK;
+}
+
+void gnx_model_free(gnx_model* m) {
+  if (!m) return;
+  if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
+  for (void* p : m->dev_allocs) (void)hipFree(p);
+  delete m;
+}
+
+int gnx_model_get_info(const gnx_model* m, gnx_model_info* out) {
+  if (!m || !out) return GNX_EINVAL;
+  *out = m->info;
+  return GNX_OK;
+}
+
+// ---- base ------------------------------------------------------------------------------------------
+int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx, float* d_b32, double* d_b64) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (N < 0 || ldx < m->info.C || (N > 0 && !dX)) return fail(ctx, GNX_EINVAL, "base_predict: bad X / N / ldx");
+  if (N == 0 || (!d_b32 && !d_b64)) return GNX_OK;
+  if (m->info.base_kind != GNX_BASE_LOGISTIC) return fail(ctx, GNX_ESTATE, "model has no logistic base");
+  BaseLRLaunch L{};
+  L.X = dX;
+  L.x_end = dX + (N - 1) * ldx + m->info.C;
+  L.N = N; L.ldx = ldx; L.d = m->lr;
+  L.W = (int32_t)m->info.W; L.A = m->info.A;
+  L.b32 = d_b32; L.b64 = d_b64;
+  ProfScope ps(ctx, GNX_K_BASE_LOGISTIC);
+  HIPCHK(ctx, gnx_launch_base_logistic(L, ctx->n_cu, ctx->stream));
+  return GNX_OK;
+}
+
+// ---- smoother ------------------------------------------------------------------------------------
+int gnx_smooth_predict_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N, float* d_p32, double* d_p64,
+                           int32_t* d_lab) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (N < 0 || (N > 0 && !dB)) return fail(ctx, GNX_EINVAL, "smooth_predict: bad B / N");
+  if (N == 0) return GNX_OK;
+  if (m->info.smooth_kind == GNX_SMOOTH_XGB) {
+    const size_t n = (size_t)N * m->info.W * m->info.A;
+    if (!d_p32) {  // margins are parked in the f32 output: borrow a workspace
+      int rc = ws_reserve(ctx, ctx->ws_misc, n * sizeof(float));
+      if (rc != GNX_OK) return rc;
+      d_p32 = (float*)ctx->ws_misc.p;
+    }
+    SmoothXGBLaunch L{};
+    L.B = dB; L.b_is_f64 = b_is_f64; L.N = N;
+    L.W = (int32_t)m->info.W; L.A = m->info.A; L.S = m->info.S;
+    L.d = m->xgb; L.proba = d_p32; L.proba64 = d_p64; L.labels = d_lab;
+    ProfScope ps(ctx, GNX_K_SMOOTH_XGB);
+    HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->n_cu, ctx->stream));
+    return GNX_OK;
+  }
+  return fail(ctx, GNX_ESTATE, "model has no smoother this build can run");
+}
+
+int gnx_infer_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx, float* d_p32, double* d_p64, int32_t* d_lab) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (N <= 0) return N == 0 ? GNX_OK : fail(ctx, GNX_EINVAL, "infer: N < 0");
+  const size_t n = (size_t)N * m->info.W * m->info.A;
+  const bool f64 = (m->info.smooth_kind == GNX_SMOOTH_CRF);  // CRF consumes float64 base probabilities
+  int rc = ws_reserve(ctx, f64 ? ctx->ws_b64 : ctx->ws_b32, n * (f64 ? 8 : 4));
+  if (rc != GNX_OK) return rc;
+  rc = gnx_base_predict_dev(m, dX, N, ldx, f64 ? nullptr : (float*)ctx->ws_b32.p, f64 ? (double*)ctx->ws_b64.p : nullptr);
+  if (rc != GNX_OK) return rc;
+  return gnx_smooth_predict_dev(m, f64 ? ctx->ws_b64.p : ctx->ws_b32.p, f64, N, d_p32, d_p64, d_lab);
+}
+
+// ---- host-pointer entry points: stage, run, copy back, synchronise -------------------------------------
+static int64_t hap_batch(const gnx_model* m, int64_t N, int64_t ldx) {
+  // bound the staging workspaces (~1 GiB of X per batch); whole individuals per batch
+  int64_t nb = ((int64_t)1 << 30) / std::max<int64_t>(ldx, 1);
+  nb = std::max<int64_t>(2, nb & ~(int64_t)1);
+  (void)m;
+  return std::min(N, nb);
+}
+
+int gnx_base_predict(gnx_model* m, const int8_t* X, int64_t N, int64_t ldx, float* b32, double* b64) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (N < 0 || ldx < m->info.C || (N > 0 && !X)) return fail(ctx, GNX_EINVAL, "base_predict: bad X / N / ldx");
+  if (N == 0) return GNX_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t WA = (size_t)m->info.W * m->info.A;
+  const int64_t nb = hap_batch(m, N, ldx);
+  int rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)nb * ldx + 64)) != GNX_OK) return rc;
+  if (b32 && (rc = ws_reserve(ctx, ctx->ws_b32, nb * WA * 4)) != GNX_OK) return rc;
+  if (b64 && (rc = ws_reserve(ctx, ctx->ws_b64, nb * WA * 8)) != GNX_OK) return rc;
+  for (int64_t n0 = 0; n0 < N; n0 += nb) {
+    const int64_t n = std::min(nb, N - n0);
+    const size_t xbytes = (size_t)(n - 1) * ldx + m->info.C;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_x.p, X + n0 * ldx, xbytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = gnx_base_predict_dev(m, (const int8_t*)ctx->ws_x.p, n, ldx, b32 ? (float*)ctx->ws_b32.p : nullptr,
+                              b64 ? (double*)ctx->ws_b64.p : nullptr);
+    if (rc != GNX_OK) return rc;
+    if (b32) HIPCHK(ctx, hipMemcpyAsync(b32 + n0 * WA, ctx->ws_b32.p, n * WA * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (b64) HIPCHK(ctx, hipMemcpyAsync(b64 + n0 * WA, ctx->ws_b64.p, n * WA * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return GNX_OK;
+}
+
+int gnx_smooth_predict(gnx_model* m, const void* B, int b_is_f64, int64_t N, float* p32, double* p64, int32_t* lab) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (N < 0 || (N > 0 && !B)) return fail(ctx, GNX_EINVAL, "smooth_predict: bad B / N");
+  if (N == 0) return GNX_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t WA = (size_t)m->info.W * m->info.A, Wn = (size_t)m->info.W;
+  const size_t esz = b_is_f64 ? 8 : 4;
+  int rc;
+  gnx_devbuf& wb = b_is_f64 ? ctx->ws_b64 : ctx->ws_b32;
+  if ((rc = ws_reserve(ctx, wb, N * WA * esz)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_p32, N * WA * 4)) != GNX_OK) return rc;
+  if (p64 && (rc = ws_reserve(ctx, ctx->ws_p64, N * WA * 8)) != GNX_OK) return rc;
+  if (lab && (rc = ws_reserve(ctx, ctx->ws_lab, N * Wn * 4)) != GNX_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(wb.p, B, N * WA * esz, hipMemcpyHostToDevice, ctx->stream));
+  rc = gnx_smooth_predict_dev(m, wb.p, b_is_f64, N, (float*)ctx->ws_p32.p, p64 ? (double*)ctx->ws_p64.p : nullptr,
+                              lab ? (int32_t*)ctx->ws_lab.p : nullptr);
+  if (rc != GNX_OK) return rc;
+  if (p32) HIPCHK(ctx, hipMemcpyAsync(p32, ctx->ws_p32.p, N * WA * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (p64) HIPCHK(ctx, hipMemcpyAsync(p64, ctx->ws_p64.p, N * WA * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (lab) HIPCHK(ctx, hipMemcpyAsync(lab, ctx->ws_lab.p, N * Wn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GNX_OK;
+}
+
+int gnx_infer(gnx_model* m, const int8_t* X, int64_t N, int64_t ldx, float* p32, double* p64, int32_t* lab) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (N < 0 || ldx < m->info.C || (N > 0 && !X)) return fail(ctx, GNX_EINVAL, "infer: bad X / N / ldx");
+  if (N == 0) return GNX_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t WA = (size_t)m->info.W * m->info.A, Wn = (size_t)m->info.W;
+  const int64_t nb = hap_batch(m, N, ldx);
+  int rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)nb * ldx + 64)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_p32, nb * WA * 4)) != GNX_OK) return rc;
+  if (p64 && (rc = ws_reserve(ctx, ctx->ws_p64, nb * WA * 8)) != GNX_OK) return rc;
+  if (lab && (rc = ws_reserve(ctx, ctx->ws_lab, nb * Wn * 4)) != GNX_OK) return rc;
+  for (int64_t n0 = 0; n0 < N; n0 += nb) {
+    const int64_t n = std::min(nb, N - n0);
+    const size_t xbytes = (size_t)(n - 1) * ldx + m->info.C;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_x.p, X + n0 * ldx, xbytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = gnx_infer_dev(m, (const int8_t*)ctx->ws_x.p, n, ldx, (float*)ctx->ws_p32.p,
+                       p64 ? (double*)ctx->ws_p64.p : nullptr, lab ? (int32_t*)ctx->ws_lab.p : nullptr);
+    if (rc != GNX_OK) return rc;
+    if (p32) HIPCHK(ctx, hipMemcpyAsync(p32 + n0 * WA, ctx->ws_p32.p, n * WA * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (p64) HIPCHK(ctx, hipMemcpyAsync(p64 + n0 * WA, ctx->ws_p64.p, n * WA * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (lab) HIPCHK(ctx, hipMemcpyAsync(lab + n0 * Wn, ctx->ws_lab.p, n * Wn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return GNX_OK;
+}
+
+int gnx_smooth_rows(gnx_model* m, const float* rows, int64_t R, float* proba) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (m->info.smooth_kind != GNX_SMOOTH_XGB) return fail(ctx, GNX_ESTATE, "smooth_rows needs the XGB smoother");
+  if (R < 0 || (R > 0 && (!rows || !proba))) return fail(ctx, GNX_EINVAL, "smooth_rows: bad arguments");
+  if (R == 0) return GNX_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int F = m->info.S * m->info.A, A = m->info.A;
+  int rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_misc, (size_t)R * F * 4)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_p32, (size_t)R * A * 4)) != GNX_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ws_misc.p, rows, (size_t)R * F * 4, hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, GNX_K_SMOOTH_ROWS);
+    HIPCHK(ctx, gnx_launch_smooth_rows(m->xgb, (const float*)ctx->ws_misc.p, R, F, A, (float*)ctx->ws_p32.p, ctx->stream));
+  }
+  HIPCHK(ctx, hipMemcpyAsync(proba, ctx->ws_p32.p, (size_t)R * A * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GNX_OK;
+}
+
+int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_ind, int32_t max_it, int32_t* Y,
+               int32_t* n_switches) {
+  (void)X; (void)ldx; (void)B; (void)n_ind; (void)max_it; (void)Y; (void)n_switches;
+  if (!m) return GNX_EINVAL;
+  return fail(m->ctx, GNX_EUNSUPPORTED, "gnofix: kernel not built yet");
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------
+int gnx_profile_enable(gnx_ctx* ctx, int on) {
+  if (!ctx) return GNX_EINVAL;
+  if (!on) prof_drain(ctx);
+  ctx->prof = on != 0;
+  return GNX_OK;
+}
+
+int gnx_profile_reset(gnx_ctx* ctx) {
+  if (!ctx) return GNX_EINVAL;
+  prof_drain(ctx);
+  for (int k = 0; k < GNX_K_COUNT; ++k) { ctx->prof_ms[k] = 0; ctx->prof_n[k] = 0; }
+  return GNX_OK;
+}
+
+int gnx_profile_get(gnx_ctx* ctx, int kid, double* total_ms, int64_t* launches) {
+  if (!ctx || kid < 0 || kid >= GNX_K_COUNT) return GNX_EINVAL;
+  prof_drain(ctx);
+  if (total_ms) *total_ms = ctx->prof_ms[kid];
+  if (launches) *launches = ctx->prof_n[kid];
+  return GNX_OK;
+}
+
+}  // extern "C"

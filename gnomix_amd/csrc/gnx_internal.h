@@ -1,0 +1,106 @@
+// gnx_internal.h — shared between the C-ABI translation unit and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gnomix_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// context / model
+// ------------------------------------------------------------------------------------------------
+struct gnx_devbuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct gnx_prof_pair {
+  hipEvent_t a, b;
+  int kid;
+};
+
+struct gnx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int n_cu = 256;
+  // grow-only device workspaces (host-pointer entry points stage through these)
+  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc;
+  // profiling
+  bool prof = false;
+  std::vector<gnx_prof_pair> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[GNX_K_COUNT] = {0};
+  int64_t prof_n[GNX_K_COUNT] = {0};
+};
+
+// ---- logistic base (k_base_logistic.hip) ---------------------------------------------------------
+// The padded chromosome is processed in "pieces" that end exactly where a window ends, each piece in
+// chunks of 64 SNPs (one 16-byte load per lane).  Weights are stored in MFMA-fragment order.
+struct BaseLRDev {
+  const double* V = nullptr;        // [n_chunks][16 steps][NT][64 lanes]
+  const double* icpt = nullptr;     // [W][A]
+  const int32_t* chunk_j0 = nullptr;     // [n_chunks] first real SNP of the chunk
+  const int32_t* chunk_flush0 = nullptr; // [n_chunks] first window flushed after this chunk (-1 none)
+  const int32_t* chunk_nflush = nullptr; // [n_chunks] number of windows flushed after this chunk
+  const int32_t* win_chunk0 = nullptr;   // [W] first chunk a block must start from to compute window w
+  const int32_t* win_chunk1 = nullptr;   // [W] one past the chunk after which window w is flushed
+  int32_t n_chunks = 0;
+  int32_t R = 0;   // windows simultaneously active = column slots
+  int32_t NT = 0;  // 16-column tiles
+};
+
+struct BaseLRLaunch {
+  const int8_t* X;
+  const int8_t* x_end;  // one past the last readable byte of X
+  int64_t N, ldx;
+  BaseLRDev d;
+  int32_t W, A, wch;    // wch = windows per block
+  float* b32;
+  double* b64;
+};
+
+// ---- xgb smoother (k_smooth_xgb.hip) ----------------------------------------------------------------
+// Trees are re-ordered class-major and every tree is expanded to a complete binary tree of depth D:
+//   [ (2^D - 1) nodes {uint32 feature_byte_offset, float threshold} | 2^D float leaves ]
+// in heap order (children of 1-based node j are 2j, 2j+1; go right iff !(f < thr)).
+struct SmoothXGBDev {
+  const uint8_t* packed = nullptr;   // n_trees * tree_bytes
+  const int32_t* group_tree0 = nullptr;  // [n_groups+1] first tree of each staging group
+  const int32_t* group_class = nullptr;  // [n_groups]
+  int32_t n_groups = 0, n_trees = 0, D = 0, tree_bytes = 0, max_group = 0;
+  float base_score = 0.5f;
+};
+
+struct SmoothXGBLaunch {
+  const void* B;     // (N, W, A) float32 or float64
+  int32_t b_is_f64;
+  int64_t N;
+  int32_t W, A, S;
+  SmoothXGBDev d;
+  float* proba;      // (N, W, A): margins are parked here between class passes
+  double* proba64;   // optional widened copy
+  int32_t* labels;   // optional
+};
+
+struct gnx_model {
+  gnx_ctx* ctx = nullptr;
+  gnx_model_info info{};
+  std::vector<void*> dev_allocs;
+  BaseLRDev lr;
+  SmoothXGBDev xgb;
+  // class-major xgboost-schema copy for the rows kernel
+  const int32_t* rows_tree_off = nullptr;
+  // CRF
+  const double* crf_state = nullptr;  // device (A,A)
+  const double* crf_etrans = nullptr; // device (A,A) exp(trans)
+};
+
+// kernel launchers (defined in the .hip files)
+hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
+hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, int n_cu, hipStream_t s);
+hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
+                                  float* proba, hipStream_t s);
+size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

@@ -1,0 +1,61 @@
+"""HipGnomix — the inference surface of the reference's model object (src/model.py:12-214):
+predict / predict_proba / phase and the attributes run_inference() and the writers read
+(C, M, A, S, W, context, snp_pos, snp_ref, snp_alt, population_order, gen_map_df, base, smooth)."""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from .base import HipBase
+from .model import DeviceModel, GnxModelData
+from .smooth import HipSmoother
+
+
+class HipGnomix:
+
+    def __init__(self, data: GnxModelData, device: int = 0, ctx=None, calibrate=False, verbose=False):
+        self.data = data
+        self.dev = DeviceModel(data, ctx=ctx, device=device)
+        self.C, self.M, self.A, self.S = data.C, data.M, data.A, data.S
+        self.W = self.C // self.M
+        self.context = data.context
+        self.snp_pos, self.snp_ref, self.snp_alt = data.snp_pos, data.snp_ref, data.snp_alt
+        self.population_order = data.population_order
+        self.calibrate = calibrate
+        self.n_cores = None
+        self.verbose = verbose
+        self.gen_map_df = {}
+        if data.gen_map_pos is not None:
+            try:
+                import pandas as pd
+                self.gen_map_df = pd.DataFrame({"pos": data.gen_map_pos, "pos_cm": data.gen_map_cm})
+            except ImportError:
+                self.gen_map_df = {"pos": data.gen_map_pos, "pos_cm": data.gen_map_cm}
+        self.base = HipBase(self.dev, verbose=verbose)
+        self.smooth = HipSmoother(self.dev, calibrate=calibrate, verbose=verbose)
+        self.time = {}
+
+    @classmethod
+    def load(cls, path, **kw):
+        return cls(GnxModelData.load(path), **kw)
+
+    def predict(self, X):
+        """labels (N, W) — base + smoother fused on the device, B never leaves HBM (model.py:169-173)"""
+        _, lab = self.dev.infer(X, want_proba=False, want_labels=True)
+        return lab.astype(np.int64)
+
+    def predict_proba(self, X):
+        """probabilities (N, W, A) (model.py:175-179)"""
+        p, _ = self.dev.infer(X, want_proba=True, want_labels=False)
+        return p
+
+    def phase(self, X, B=None, verbose=False):
+        """Gnofix re-phasing (model.py:188-214): -> X_phased (N, C) int, Y_phased (N, W) int"""
+        assert self.smooth is not None, "Smoother is not trained, returning original haplotypes"
+        assert self.smooth.gnofix, "Type of Smoother ({}) does not currently support re-phasing".format(self.smooth)
+        X = np.asarray(X)
+        if B is None:
+            B = self.base.predict_proba(X)
+        Xp, Y, _ = self.dev.gnofix(X, B)
+        return Xp.astype(int), Y.astype(int)

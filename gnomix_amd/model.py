@@ -1,0 +1,315 @@
+"""Flat model container (".gnx") + the device model handle.
+
+The reference's model artefact is a pickle of src.model.Gnomix holding sklearn / xgboost objects
+(gnomix.py:26-35, 209).  GnxModelData is the same information as plain arrays — everything
+Gnomix.predict / predict_proba / phase and the writers consume (src/model.py:28-88) — so it can be
+saved without pickling third-party classes and handed to the C ABI (gnx_model_desc) as is.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+GNX_FILE_VERSION = 1
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+@dataclass
+class GnxModelData:
+    C: int
+    M: int
+    A: int
+    S: int = 75
+    context: int = 0                      # SNPs each side = int(M*context_ratio) (src/model.py:47)
+    base_kind: str | None = None          # "logistic" | "covrsk"
+    smooth_kind: str | None = None        # "xgb" | "crf"
+    # logistic base: coef_ / intercept_ of LogisticRegression per window (src/Base/models.py:12-21)
+    lr_coef: np.ndarray | None = None     # (W, A, ldc) float64, window i uses [:, :width_i]
+    lr_intercept: np.ndarray | None = None  # (W, A)
+    # CovRSK base: per-window fitted SVC (src/Base/models.py:195-215)
+    svc: list | None = None               # list of dicts: xfit, support, dual_coef, intercept, prob_a, prob_b, n_support, ms
+    # xgb smoother in xgboost's model schema (src/Smooth/models.py:14-20)
+    tree_off: np.ndarray | None = None
+    left: np.ndarray | None = None
+    right: np.ndarray | None = None
+    feat: np.ndarray | None = None
+    cond: np.ndarray | None = None
+    tree_class: np.ndarray | None = None
+    base_score: float = 0.5
+    # crf smoother (src/Smooth/crf.py)
+    crf_state: np.ndarray | None = None   # (A, A) [attribute][label]
+    crf_trans: np.ndarray | None = None   # (A, A) [from][to]
+    # dataset metadata used by the writers (src/model.py:40-44, 88)
+    snp_pos: np.ndarray | None = None
+    snp_ref: np.ndarray | None = None
+    snp_alt: np.ndarray | None = None
+    population_order: list | None = None
+    gen_map_pos: np.ndarray | None = None
+    gen_map_cm: np.ndarray | None = None
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def W(self):
+        return self.C // self.M  # src/model.py:32
+
+    @property
+    def rem(self):
+        return self.C - self.M * self.W
+
+    @property
+    def M_(self):
+        return self.M + 2 * self.context
+
+    def window_width(self, i):
+        return self.M_ + (self.rem if i == self.W - 1 else 0)  # base.py:163-164
+
+    @property
+    def n_trees(self):
+        return 0 if self.tree_off is None else len(self.tree_off) - 1
+
+    # ---- persistence -------------------------------------------------------------------------------
+    def save(self, path):
+        d = {"gnx_version": GNX_FILE_VERSION}
+        for k, v in self.__dict__.items():
+            if v is None or k in ("svc", "extra"):
+                continue
+            if k == "population_order":
+                d[k] = np.array([str(p) for p in v])
+            else:
+                d[k] = np.asarray(v)
+        if self.svc is not None:
+            d["svc_n"] = len(self.svc)
+            for i, w in enumerate(self.svc):
+                for kk, vv in w.items():
+                    d[f"svc{i}_{kk}"] = np.asarray(vv)
+        with open(path, "wb") as f:
+            np.savez_compressed(f, **d)
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path, allow_pickle=False)
+        if int(z["gnx_version"]) != GNX_FILE_VERSION:
+            raise ValueError("unsupported .gnx version")
+        kw = {}
+        for k in cls.__dataclass_fields__:
+            if k in z.files:
+                v = z[k]
+                if k in ("C", "M", "A", "S", "context"):
+                    v = int(v)
+                elif k == "base_score":
+                    v = float(v)
+                elif k in ("base_kind", "smooth_kind"):
+                    v = str(v)
+                elif k == "population_order":
+                    v = [str(p) for p in v]
+                kw[k] = v
+        m = cls(**kw)
+        if "svc_n" in z.files:
+            m.svc = []
+            for i in range(int(z["svc_n"])):
+                pre = f"svc{i}_"
+                m.svc.append({k[len(pre):]: z[k] for k in z.files if k.startswith(pre)})
+        return m
+
+    # ---- C ABI description ---------------------------------------------------------------------------
+    def to_desc(self):
+        """-> (gnx_model_desc, keepalive list of the arrays the pointers refer to)"""
+        keep = []
+
+        def ptr(a, dt):
+            a = _c(a, dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        d = _lib.ModelDesc()
+        d.abi_version = _lib.GNX_ABI_VERSION
+        d.A, d.C, d.M, d.ctx, d.S = int(self.A), int(self.C), int(self.M), int(self.context), int(self.S)
+        d.base_kind = {None: _lib.BASE_NONE, "logistic": _lib.BASE_LOGISTIC, "covrsk": _lib.BASE_COVRSK_SVC}[self.base_kind]
+        d.smooth_kind = {None: _lib.SMOOTH_NONE, "xgb": _lib.SMOOTH_XGB, "crf": _lib.SMOOTH_CRF}[self.smooth_kind]
+        W, A = self.W, self.A
+        if self.base_kind == "logistic":
+            coef = _c(self.lr_coef, np.float64)
+            if coef.shape[:2] != (W, A):
+                raise ValueError(f"lr_coef must be (W={W}, A={A}, ldc), got {coef.shape}")
+            icpt = _c(self.lr_intercept, np.float64)
+            if icpt.shape != (W, A):
+                raise ValueError("lr_intercept must be (W, A)")
+            d.lr_coef, d.lr_ldc, d.lr_intercept = ptr(coef, np.float64), coef.shape[2], ptr(icpt, np.float64)
+        elif self.base_kind == "covrsk":
+            if self.svc is None or len(self.svc) != W:
+                raise ValueError("svc must list one fitted SVC per window")
+            arr = (_lib.SvcWindow * W)()
+            for i, w in enumerate(self.svc):
+                xf = _c(w["xfit"], np.int8)
+                s = arr[i]
+                s.xfit, s.n_fit, s.width = ptr(xf, np.int8), xf.shape[0], xf.shape[1]
+                sup = _c(w["support"], np.int32)
+                s.support, s.n_sv = ptr(sup, np.int32), len(sup)
+                s.dual_coef = ptr(w["dual_coef"], np.float64)
+                s.intercept = ptr(w["intercept"], np.float64)
+                s.prob_a = ptr(w["prob_a"], np.float64)
+                s.prob_b = ptr(w["prob_b"], np.float64)
+                s.n_support = ptr(w["n_support"], np.int32)
+                ms = _c(w["ms"], np.int32)
+                s.ms, s.n_ms = ptr(ms, np.int32), len(ms)
+            keep.append(arr)
+            d.svc = C.addressof(arr)
+        if self.smooth_kind == "xgb":
+            d.n_trees = self.n_trees
+            d.tree_off = ptr(self.tree_off, np.int32)
+            d.left = ptr(self.left, np.int32)
+            d.right = ptr(self.right, np.int32)
+            d.feat = ptr(self.feat, np.int32)
+            d.cond = ptr(self.cond, np.float32)
+            d.tree_class = ptr(self.tree_class, np.int32)
+            d.base_score = float(self.base_score)
+        elif self.smooth_kind == "crf":
+            d.crf_state = ptr(self.crf_state, np.float64)
+            d.crf_trans = ptr(self.crf_trans, np.float64)
+        return d, keep
+
+
+class DeviceModel:
+    """gnx_model handle: the model resident in HBM of one device."""
+
+    def __init__(self, data: GnxModelData, ctx: _lib.Context | None = None, device: int = 0):
+        self.ctx = ctx or _lib.default_context(device)
+        self.lib = self.ctx.lib
+        self.data = data
+        desc, keep = data.to_desc()
+        h = C.c_void_p()
+        self.ctx.check(self.lib.gnx_model_load(self.ctx.h, C.byref(desc), C.byref(h)))
+        del keep
+        self.h = h
+        info = _lib.ModelInfo()
+        self.ctx.check(self.lib.gnx_model_get_info(h, C.byref(info)))
+        self.info = info
+        self.W, self.A, self.S, self.C, self.M = int(info.W), int(info.A), int(info.S), int(info.C), int(info.M)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gnx_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host (numpy) entry points: synchronous ------------------------------------------------------
+    def _x(self, X):
+        X = np.asarray(X)
+        if X.ndim != 2 or X.shape[1] != self.C:
+            raise ValueError(f"X must be (N, C={self.C}), got {X.shape}")
+        if X.dtype != np.int8:
+            X = X.astype(np.int8)  # vcf_to_npy hands int8 (src/utils.py:153)
+        return np.ascontiguousarray(X)
+
+    def base_predict(self, X, want_f32=False, want_f64=True):
+        X = self._x(X)
+        N = X.shape[0]
+        b32 = np.empty((N, self.W, self.A), np.float32) if want_f32 else None
+        b64 = np.empty((N, self.W, self.A), np.float64) if want_f64 else None
+        self.ctx.check(self.lib.gnx_base_predict(self.h, X.ctypes.data, N, X.shape[1],
+                                                 b32.ctypes.data if want_f32 else None,
+                                                 b64.ctypes.data if want_f64 else None))
+        return b32, b64
+
+    def _b(self, B):
+        B = np.asarray(B)
+        if B.ndim != 3 or B.shape[1:] != (self.W, self.A):
+            raise ValueError(f"B must be (N, W={self.W}, A={self.A}), got {B.shape}")
+        if B.dtype not in (np.float32, np.float64):
+            B = B.astype(np.float64)
+        return np.ascontiguousarray(B)
+
+    def smooth_predict(self, B, want_proba=True, want_labels=True, proba_dtype=None):
+        B = self._b(B)
+        N = B.shape[0]
+        native64 = self.data.smooth_kind == "crf"
+        pd = proba_dtype or (np.float64 if native64 else np.float32)
+        p = np.empty((N, self.W, self.A), pd) if want_proba else None
+        lab = np.empty((N, self.W), np.int32) if want_labels else None
+        p32 = p.ctypes.data if (want_proba and pd == np.float32) else None
+        p64 = p.ctypes.data if (want_proba and pd == np.float64) else None
+        self.ctx.check(self.lib.gnx_smooth_predict(self.h, B.ctypes.data, int(B.dtype == np.float64), N, p32, p64,
+                                                   lab.ctypes.data if want_labels else None))
+        return p, lab
+
+    def infer(self, X, want_proba=True, want_labels=True, proba_dtype=None):
+        X = self._x(X)
+        N = X.shape[0]
+        native64 = self.data.smooth_kind == "crf"
+        pd = proba_dtype or (np.float64 if native64 else np.float32)
+        p = np.empty((N, self.W, self.A), pd) if want_proba else None
+        lab = np.empty((N, self.W), np.int32) if want_labels else None
+        p32 = p.ctypes.data if (want_proba and pd == np.float32) else None
+        p64 = p.ctypes.data if (want_proba and pd == np.float64) else None
+        self.ctx.check(self.lib.gnx_infer(self.h, X.ctypes.data, N, X.shape[1], p32, p64,
+                                          lab.ctypes.data if want_labels else None))
+        return p, lab
+
+    def smooth_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        F = self.S * self.A
+        if rows.ndim != 2 or rows.shape[1] != F:
+            raise ValueError(f"rows must be (R, S*A={F})")
+        out = np.empty((rows.shape[0], self.A), np.float32)
+        self.ctx.check(self.lib.gnx_smooth_rows(self.h, rows.ctypes.data, rows.shape[0], out.ctypes.data))
+        return out
+
+    def gnofix(self, X, B, max_it=50):
+        X = np.ascontiguousarray(X, dtype=np.int8).copy()
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        n_ind = X.shape[0] // 2
+        Y = np.empty((2 * n_ind, self.W), np.int32)
+        nsw = np.empty((n_ind,), np.int32)
+        self.ctx.check(self.lib.gnx_gnofix(self.h, X.ctypes.data, X.shape[1], B.ctypes.data, n_ind, int(max_it),
+                                           Y.ctypes.data, nsw.ctypes.data))
+        return X, Y, nsw
+
+    # ---- device (torch tensor) entry points: asynchronous on torch's current stream ---------------------
+    def _bind_torch_stream(self):
+        import torch
+        self.ctx.set_stream(torch.cuda.current_stream(self.ctx.device).cuda_stream)
+
+    def infer_device(self, X_t, want_proba=True, want_labels=True):
+        """X_t: torch int8 CUDA tensor (N, C) resident in HBM -> (proba f32 tensor, labels i32 tensor)."""
+        import torch
+        assert X_t.is_cuda and X_t.dtype == torch.int8 and X_t.dim() == 2 and X_t.stride(1) == 1
+        self._bind_torch_stream()
+        N = X_t.shape[0]
+        p = torch.empty((N, self.W, self.A), dtype=torch.float32, device=X_t.device) if want_proba else None
+        lab = torch.empty((N, self.W), dtype=torch.int32, device=X_t.device) if want_labels else None
+        self.ctx.check(self.lib.gnx_infer_dev(self.h, X_t.data_ptr(), N, X_t.stride(0), p.data_ptr() if want_proba else None,
+                                              None, lab.data_ptr() if want_labels else None))
+        return p, lab
+
+    def base_predict_device(self, X_t, f64=False):
+        import torch
+        assert X_t.is_cuda and X_t.dtype == torch.int8 and X_t.dim() == 2 and X_t.stride(1) == 1
+        self._bind_torch_stream()
+        N = X_t.shape[0]
+        B = torch.empty((N, self.W, self.A), dtype=torch.float64 if f64 else torch.float32, device=X_t.device)
+        self.ctx.check(self.lib.gnx_base_predict_dev(self.h, X_t.data_ptr(), N, X_t.stride(0),
+                                                     None if f64 else B.data_ptr(), B.data_ptr() if f64 else None))
+        return B
+
+    def smooth_predict_device(self, B_t):
+        import torch
+        assert B_t.is_cuda and B_t.is_contiguous() and B_t.dtype in (torch.float32, torch.float64)
+        self._bind_torch_stream()
+        N = B_t.shape[0]
+        p = torch.empty((N, self.W, self.A), dtype=torch.float32, device=B_t.device)
+        lab = torch.empty((N, self.W), dtype=torch.int32, device=B_t.device)
+        self.ctx.check(self.lib.gnx_smooth_predict_dev(self.h, B_t.data_ptr(), int(B_t.dtype == torch.float64), N,
+                                                       p.data_ptr(), None, lab.data_ptr()))
+        return p, lab

@@ -1,0 +1,54 @@
+"""HipSmoother — the reference's Smoother plugin interface (src/Smooth/smooth.py:7-65) served by the
+HIP kernels.  `.model.predict_proba(rows)` is kept because Gnofix calls it (gnofix.py:157)."""
+from __future__ import annotations
+
+from time import time
+
+import numpy as np
+
+
+class _RowModel:
+    """stands where XGBClassifier stands: predict_proba on explicit (R, S*A) rows"""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def predict_proba(self, rows):
+        rows = np.asarray(rows)
+        return self.dev.smooth_rows(rows.reshape(rows.shape[0], -1))
+
+
+class HipSmoother:
+
+    def __init__(self, device_model, calibrate=None, mode_filter=0, n_jobs=None, seed=None, verbose=False):
+        d = device_model.data
+        self.dev = device_model
+        self.W = d.C // d.M
+        self.A = d.A
+        self.S = d.S if d.S % 2 else d.S - 1   # smooth.py:14
+        self.calibrate = calibrate
+        self.calibrator = None
+        self.mode_filter = mode_filter
+        self.n_jobs = n_jobs
+        self.seed = seed
+        self.verbose = verbose
+        self.gnofix = d.smooth_kind == "xgb"   # only XGB_Smoother sets it (Smooth/models.py:12)
+        self.model = _RowModel(device_model) if d.smooth_kind == "xgb" else None
+        self.time = {}
+
+    def predict_proba(self, B):
+        """B (N, W, A) -> (N, W, A): float32 for the xgb smoother, float64 for crf (smooth.py:40-56)."""
+        t = time()
+        if self.calibrate:
+            if self.calibrator is None:
+                print("No calibrator found, returning original probabilities.")  # smooth.py:49-50
+        proba, _ = self.dev.smooth_predict(B, want_proba=True, want_labels=False)
+        self.time["inference"] = time() - t
+        return proba.reshape(-1, self.W, self.A)
+
+    def predict(self, B):
+        """argmax labels (N, W) int64, first max wins (smooth.py:58-65)."""
+        if self.mode_filter:
+            raise NotImplementedError("mode_filter != 0 is out of scope (default 0; broken on scipy>=1.11 in the reference)")
+        _, lab = self.dev.smooth_predict(B, want_proba=False, want_labels=True)
+        return lab.astype(np.int64)

@@ -1,0 +1,101 @@
+"""Synthetic models and query data of the shapes BASELINE.json names: there is no
+network, so pre-trained model.pkl files and the demo VCF are unavailable; weights are random-init
+of the reference's architecture (per-window liblinear-style logistic models, multi:softprob trees of
+depth <= 4, tree t of round r belongs to class t % A)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .model import GnxModelData
+
+# chr22-like shape of config 2 (W = 370 is pinned by demo.ipynb cell 13; M = 1000 is our choice)
+CHR22 = dict(C=370_500, M=1000, A=7, S=75, context=500)
+# synthetic per-chromosome window counts for the whole-genome config
+GENOME_W = [1431, 1344, 1117, 1073, 1020, 960, 936, 840, 832, 906, 791, 873, 629, 601, 709, 670, 642, 589, 539, 541,
+            314, 370]
+
+
+def synthetic_trees(n_rounds, A, n_feat, depth=4, seed=0, thr_lo=0.02, thr_hi=0.5, leaf_scale=0.3,
+                    p_early_leaf=0.1):
+    rng = np.random.RandomState(seed)
+    off, L, R, F, Cd, cls = [0], [], [], [], [], []
+    for t in range(n_rounds * A):
+        nodes = []
+
+        def grow(d):
+            idx = len(nodes)
+            nodes.append(None)
+            if d == depth or (d > 0 and rng.rand() < p_early_leaf):
+                nodes[idx] = (-1, -1, 0, np.float32(rng.randn() * leaf_scale))
+            else:
+                f = rng.randint(n_feat)
+                thr = np.float32(rng.uniform(thr_lo, thr_hi))
+                l = grow(d + 1)
+                r = grow(d + 1)
+                nodes[idx] = (l, r, f, thr)
+            return idx
+
+        grow(0)
+        for (l, r, f, c) in nodes:
+            L.append(l); R.append(r); F.append(f); Cd.append(c)
+        off.append(len(L))
+        cls.append(t % A)
+    return dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
+                feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32))
+
+
+def synthetic_model(C, M, A, S=75, context=None, n_rounds=100, depth=4, seed=0, base="logistic", smooth="xgb",
+                    coef_sd=0.05, icpt_sd=0.5):
+    """Random-init model of the reference architecture (LogisticRegressionBase + XGB_Smoother by default)."""
+    rng = np.random.RandomState(seed)
+    context = int(M * 0.5) if context is None else int(context)
+    W = C // M
+    rem = C - M * W
+    assert rem > 0, "the reference requires C % M != 0 (gnomix.py:124-125)"
+    m = GnxModelData(C=C, M=M, A=A, S=S, context=context)
+    if base == "logistic":
+        ldc = M + 2 * context + rem
+        m.base_kind = "logistic"
+        m.lr_coef = (rng.standard_normal((W, A, ldc)) * coef_sd)
+        m.lr_intercept = rng.standard_normal((W, A)) * icpt_sd
+    if smooth == "xgb":
+        m.smooth_kind = "xgb"
+        for k, v in synthetic_trees(n_rounds, A, S * A, depth=depth, seed=seed + 1).items():
+            setattr(m, k, v)
+    elif smooth == "crf":
+        m.smooth_kind = "crf"
+        m.crf_state = rng.standard_normal((A, A)) * 2.0 + 4.0 * np.eye(A)
+        m.crf_trans = rng.standard_normal((A, A)) * 0.5 + 3.0 * np.eye(A)
+    m.population_order = ["POP%d" % a for a in range(A)]
+    return m
+
+
+def synthetic_X(N, C, seed=94305, miss=0.01):
+    """Phased haplotypes: per-SNP allele frequency ~ U(0.05, 0.95), `miss` of the entries set to 2."""
+    rng = np.random.RandomState(seed)
+    p = rng.uniform(0.05, 0.95, size=C).astype(np.float32)
+    X = np.empty((N, C), dtype=np.int8)
+    step = max(1, (1 << 24) // C)
+    for n0 in range(0, N, step):
+        n1 = min(N, n0 + step)
+        u = rng.random_sample((n1 - n0, C)).astype(np.float32)
+        X[n0:n1] = u < p
+        X[n0:n1][rng.random_sample((n1 - n0, C)) < miss] = 2
+    return X
+
+
+def synthetic_X_device(N, C, device, seed=94305, miss=0.01):
+    """The same distribution generated directly in HBM (torch is only the allocator / RNG here)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    p = torch.empty(C, device=device, dtype=torch.float32).uniform_(0.05, 0.95, generator=g)
+    X = torch.empty((N, C), device=device, dtype=torch.int8)
+    step = max(1, (1 << 26) // C)
+    for n0 in range(0, N, step):
+        n1 = min(N, n0 + step)
+        u = torch.rand((n1 - n0, C), device=device, generator=g)
+        x = (u < p).to(torch.int8)
+        x[torch.rand((n1 - n0, C), device=device, generator=g) < miss] = 2
+        X[n0:n1] = x
+    return X

@@ -1,0 +1,185 @@
+/*
+ * gnomix_hip.h — C ABI of libgnomix_hip.so: the MI355X (gfx950) implementation of the Gnomix
+ * inference hot path  X (phased SNPs, int8) -> per-window base classifier -> B -> sliding-window
+ * smoother -> per-window ancestry probabilities / labels  (+ the Gnofix re-phasing loop).
+ *
+ * The reference (AI-sandbox/gnomix, /root/reference) is pure Python and has no FFI of its own; the
+ * entry points below are what a binding for this path replaces, one per reference call site:
+ *
+ *   gnx_model_load        <- pickle.load of src.model.Gnomix            gnomix.py:26-35 (load_model)
+ *   gnx_base_predict      <- Base.predict_proba(X)                      src/Base/base.py:129-180, gnomix.py:55
+ *   gnx_smooth_predict    <- Smoother.predict_proba(B) / .predict(B)    src/Smooth/smooth.py:40-65, gnomix.py:57-58
+ *   gnx_infer             <- Gnomix.predict_proba(X) / .predict(X)      src/model.py:169-179, gnomix.py:72
+ *   gnx_smooth_rows       <- smoother.model.predict_proba(rows)         src/Gnofix/gnofix.py:157
+ *   gnx_gnofix            <- Gnomix.phase(X, B) -> gnofix() per indiv.  src/model.py:188-214, src/Gnofix/gnofix.py:58-208
+ *
+ * Conventions
+ *   - return 0 (GNX_OK) or a negative GNX_E* code; the message is kept per context (gnx_last_error).
+ *     No exception or signal crosses this ABI.  (The reference aborts with Python assert/exception:
+ *     src/model.py:193-194, src/Smooth/models.py:13, src/Smooth/smooth.py:31 — the Python mirror in
+ *     gnomix_amd/ turns the codes back into those exceptions.)
+ *   - plain pointers and sizes only; the library never frees or keeps caller memory
+ *     (gnx_model_load copies what it needs).
+ *   - un-suffixed entry points take HOST pointers, are synchronous and stage through the context's
+ *     device workspaces; *_dev entry points take DEVICE pointers (same device as the context), are
+ *     asynchronous on the context stream (gnx_set_stream / gnx_synchronize) and never allocate
+ *     when the workspace is already large enough.
+ *   - one gnx_ctx per device; a context and its models are not thread-safe (the reference is
+ *     single-threaded at this level: src/model.py:205); different contexts may live on different
+ *     threads or processes (one process per GPU under torch.distributed).
+ *   - haplotype rows 2i, 2i+1 of X are the two haplotypes of individual i (src/utils.py:121-123);
+ *     X values are {0,1,2=missing} int8, the value 2 enters the logistic model as the number 2
+ *     (sklearn sees it as a feature value) and string kernels as a third symbol.
+ */
+#ifndef GNOMIX_HIP_H
+#define GNOMIX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNX_ABI_VERSION 1
+
+typedef struct gnx_ctx gnx_ctx;
+typedef struct gnx_model gnx_model;
+
+enum {
+  GNX_OK = 0,
+  GNX_EINVAL = -1,       /* bad argument / inconsistent model description */
+  GNX_ENOMEM = -2,       /* host or device allocation failed */
+  GNX_EHIP = -3,         /* HIP runtime error (message has the hipError string) */
+  GNX_EUNSUPPORTED = -4, /* valid in the reference but not built here (message says what) */
+  GNX_ESTATE = -5        /* call not valid for this model (e.g. phasing with a CRF smoother) */
+};
+
+enum { GNX_BASE_NONE = 0, GNX_BASE_LOGISTIC = 1, GNX_BASE_COVRSK_SVC = 2 };
+enum { GNX_SMOOTH_NONE = 0, GNX_SMOOTH_XGB = 1, GNX_SMOOTH_CRF = 2 };
+
+/* kernel ids for gnx_profile_get */
+enum {
+  GNX_K_BASE_LOGISTIC = 0,
+  GNX_K_SMOOTH_XGB = 1,
+  GNX_K_BASE_COVRSK = 2,
+  GNX_K_SMOOTH_CRF = 3,
+  GNX_K_GNOFIX = 4,
+  GNX_K_SMOOTH_ROWS = 5,
+  GNX_K_COUNT = 6
+};
+
+/* Per-window SVC of CovRSKBase (src/Base/models.py:195-215 -> sklearn.svm.SVC(kernel=callable,
+ * probability=True)); field names follow the fitted sklearn attributes. */
+typedef struct gnx_svc_window {
+  const int8_t* xfit;       /* (n_fit, width) training rows, row-major (sklearn __Xfit) */
+  int32_t n_fit;
+  int32_t width;            /* M_ (or M_+rem for the last window) */
+  const int32_t* support;   /* (n_sv,) indices into xfit (support_) */
+  int32_t n_sv;
+  const double* dual_coef;  /* (A-1, n_sv) (_dual_coef_) */
+  const double* intercept;  /* (A(A-1)/2,) (_intercept_ = -rho) */
+  const double* prob_a;     /* (A(A-1)/2,) (_probA) */
+  const double* prob_b;     /* (A(A-1)/2,) (_probB) */
+  const int32_t* n_support; /* (A,) (_n_support) */
+  const int32_t* ms;        /* CovSample lengths for this width (string_kernel.py:80-89) */
+  int32_t n_ms;
+} gnx_svc_window;
+
+/* Everything a pickled src.model.Gnomix carries for inference (src/model.py:28-88), as flat host
+ * arrays.  W = C / M (src/model.py:32); the reference requires C % M != 0 (gnomix.py:124-125). */
+typedef struct gnx_model_desc {
+  int32_t abi_version; /* GNX_ABI_VERSION */
+  int32_t A;           /* ancestries */
+  int64_t C;           /* SNPs */
+  int64_t M;           /* window size in SNPs */
+  int64_t ctx;         /* context SNPs each side = int(M*context_ratio) (src/model.py:47) */
+  int32_t S;           /* smoother width in windows, odd (src/Smooth/smooth.py:14) */
+  int32_t base_kind;   /* GNX_BASE_* */
+  int32_t smooth_kind; /* GNX_SMOOTH_* */
+  int32_t reserved0;
+
+  /* GNX_BASE_LOGISTIC: LogisticRegression(solver=liblinear) per window, OvR (models.py:12-21) */
+  const double* lr_coef;      /* (W, A, lr_ldc): coef_ of window i in [i][a][0:width_i], rest ignored */
+  int64_t lr_ldc;             /* >= M + 2ctx + rem */
+  const double* lr_intercept; /* (W, A) */
+
+  /* GNX_BASE_COVRSK_SVC */
+  const gnx_svc_window* svc;  /* (W,) */
+
+  /* GNX_SMOOTH_XGB: xgboost model schema, node arrays of all trees concatenated
+   * (src/Smooth/models.py:14-20: multi:softprob, tree t belongs to class tree_class[t]) */
+  int32_t n_trees;
+  int32_t reserved1;
+  const int32_t* tree_off;   /* (n_trees+1,) node offsets */
+  const int32_t* left;       /* child index within the tree, -1 at leaves */
+  const int32_t* right;
+  const int32_t* feat;       /* split feature = s*A + a of the (S*A)-wide sliding window */
+  const float* cond;         /* split condition (go left iff f < cond); leaf value at leaves */
+  const int32_t* tree_class; /* (n_trees,) */
+  float base_score;          /* 0.5 */
+  int32_t reserved2;
+
+  /* GNX_SMOOTH_CRF: linear-chain CRF (src/Smooth/crf.py:9-15) */
+  const double* crf_state;   /* (A, A) [attribute a][label y] */
+  const double* crf_trans;   /* (A, A) [from y'][to y] */
+} gnx_model_desc;
+
+typedef struct gnx_model_info {
+  int64_t C, M, ctx, W;
+  int32_t A, S, base_kind, smooth_kind;
+  int32_t n_trees, tree_depth;
+  int64_t device_bytes; /* HBM held by the model */
+} gnx_model_info;
+
+int gnx_abi_version(void);
+
+/* context */
+int gnx_init(int device, gnx_ctx** out);
+void gnx_ctx_free(gnx_ctx* ctx);
+const char* gnx_last_error(const gnx_ctx* ctx);
+int gnx_set_stream(gnx_ctx* ctx, void* hip_stream); /* borrow a hipStream_t (NULL = own stream) */
+int gnx_synchronize(gnx_ctx* ctx);
+
+/* model */
+int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* desc, gnx_model** out);
+void gnx_model_free(gnx_model* model);
+int gnx_model_get_info(const gnx_model* model, gnx_model_info* out);
+
+/* Base.predict_proba: X (N, ldx>=C) int8 -> B (N, W, A).  Either output may be NULL.
+ * b_f32 is what the XGB smoother consumes (src/Smooth/utils.py:20), b_f64 what the reference returns. */
+int gnx_base_predict(gnx_model* model, const int8_t* X, int64_t N, int64_t ldx, float* b_f32, double* b_f64);
+int gnx_base_predict_dev(gnx_model* model, const int8_t* dX, int64_t N, int64_t ldx, float* d_b_f32, double* d_b_f64);
+
+/* Smoother.predict_proba / predict: B (N, W, A) (float64 if b_is_f64 else float32) ->
+ * proba (N, W, A) and labels (N, W) (argmax, first max wins).  Any output may be NULL.
+ * XGB computes in float32 (proba_f64 is the widened copy); CRF computes in float64. */
+int gnx_smooth_predict(gnx_model* model, const void* B, int b_is_f64, int64_t N, float* proba_f32,
+                       double* proba_f64, int32_t* labels);
+int gnx_smooth_predict_dev(gnx_model* model, const void* dB, int b_is_f64, int64_t N, float* d_proba_f32,
+                           double* d_proba_f64, int32_t* d_labels);
+
+/* Gnomix.predict_proba / predict: base + smoother with B kept on the device. */
+int gnx_infer(gnx_model* model, const int8_t* X, int64_t N, int64_t ldx, float* proba_f32, double* proba_f64,
+              int32_t* labels);
+int gnx_infer_dev(gnx_model* model, const int8_t* dX, int64_t N, int64_t ldx, float* d_proba_f32,
+                  double* d_proba_f64, int32_t* d_labels);
+
+/* smoother.model.predict_proba on explicit rows (R, S*A) float32 -> (R, A) float32 (XGB only). */
+int gnx_smooth_rows(gnx_model* model, const float* rows, int64_t R, float* proba);
+
+/* Gnomix.phase: for each of n_ind individuals (haplotype rows 2i, 2i+1 of X and of B) run the
+ * Gnofix loop with the reference's default arguments.  X (2*n_ind, ldx) int8 is re-phased IN
+ * PLACE, B (2*n_ind, W, A) float64 is read only, Y (2*n_ind, W) receives Gnofix's labels and
+ * n_switches (n_ind,) (may be NULL) the number of accepted switches. */
+int gnx_gnofix(gnx_model* model, int8_t* X, int64_t ldx, const double* B, int64_t n_ind, int32_t max_it,
+               int32_t* Y, int32_t* n_switches);
+
+/* per-kernel device time, measured with hipEvents on the context stream around every launch */
+int gnx_profile_enable(gnx_ctx* ctx, int on);
+int gnx_profile_reset(gnx_ctx* ctx);
+int gnx_profile_get(gnx_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNOMIX_HIP_H */

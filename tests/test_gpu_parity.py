@@ -1,0 +1,235 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Bars (BASELINE.json north_star): argmax labels bit-identical; probabilities within 1e-5.
+For the f32 tree pass we additionally assert BIT equality with the oracle (same f32 order of
+operations), and for the f64 logistic base <= 1e-12 absolute on B with the float32 cast that the
+smoother consumes differing in at most a handful of entries (MFMA summation order != sequential)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, trees_from_npz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import gnomix_amd
+    gnomix_amd.load_library()
+    return gnomix_amd
+
+
+def _oracle_trees(O, d):
+    return O.Trees(d.tree_off, d.left, d.right, d.feat, d.cond, d.tree_class, d.A, d.base_score)
+
+
+def _lr_data(ga, C, M, A, ctx, seed):
+    from gnomix_amd import synth
+    return synth.synthetic_model(C=C, M=M, A=A, S=5, context=ctx, seed=seed, smooth=None)
+
+
+# ---------------------------------------------------------------- logistic base ------------------
+def test_base_golden_G1(ga, oracle):
+    g = load_golden("G1_lr.npz")
+    d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=int(g["A"]), S=5, context=int(g["ctx"]), base_kind="logistic",
+                        lr_coef=g["coef"], lr_intercept=g["intercept"])
+    dev = ga.DeviceModel(d)
+    b32, b64 = dev.base_predict(g["X"], want_f32=True, want_f64=True)
+    assert np.max(np.abs(b64 - g["B"])) < 1e-12          # vs the REFERENCE's own output
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(g["B"], -1))
+    assert np.count_nonzero(b32 != g["B"].astype(np.float32)) <= 2
+    assert np.array_equal(b32, b64.astype(np.float32))
+
+
+@pytest.mark.parametrize("C,M,A,ctx,N", [
+    (4037, 100, 7, 50, 24),      # default context ratio 0.5
+    (4037, 100, 7, 0, 5),        # no context
+    (2531, 100, 3, 30, 70),      # ratio 0.3: windows end mid-piece
+    (1999, 64, 2, 32, 130),      # M multiple of 64
+    (3001, 100, 12, 50, 33),     # A=12: 24 columns -> 2 MFMA column tiles
+    (1503, 100, 16, 50, 9),      # A=16
+    (2777, 100, 5, 120, 40),     # ratio 1.2: 4 windows per SNP, left/right reflection reaches window 1
+    (1237, 50, 7, 25, 600),      # more haplotypes than one 64-row wave tile; exercises MT=4 kernels
+    (1237, 50, 7, 25, 1),        # a single haplotype
+    (937, 300, 4, 150, 66),      # W=3 windows only
+])
+def test_base_vs_oracle(ga, oracle, C, M, A, ctx, N):
+    from gnomix_amd import synth
+    d = _lr_data(ga, C, M, A, ctx, seed=C + A)
+    X = synth.synthetic_X(N, C, seed=N, miss=0.03)
+    dev = ga.DeviceModel(d)
+    b32, b64 = dev.base_predict(X, want_f32=True, want_f64=True)
+    ref = oracle.base_lr(X, M, ctx, d.lr_coef, d.lr_intercept)
+    assert b64.shape == ref.shape
+    assert np.max(np.abs(b64 - ref)) < 1e-12
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(ref, -1))
+    assert np.count_nonzero(b32 != ref.astype(np.float32)) <= max(2, ref.size // 100000)
+    assert np.allclose(b64.sum(-1), 1.0, atol=1e-12)
+
+
+def test_base_transpose_detecting(ga, oracle):
+    """asymmetric weights + one-hot haplotypes: catches row/column swaps in the MFMA C/D mapping"""
+    C, M, A, ctx = 1037, 100, 7, 50
+    d = _lr_data(ga, C, M, A, ctx, seed=1)
+    W = C // M
+    d.lr_coef = np.zeros_like(d.lr_coef)
+    d.lr_intercept = np.zeros_like(d.lr_intercept)
+    for w in range(W):
+        for a in range(A):
+            d.lr_coef[w, a, :] = 0.001 * (a + 1) * (1 + (np.arange(d.lr_coef.shape[2]) % 13)) * (1 if (w + a) % 2 else -1)
+    X = np.zeros((80, C), dtype=np.int8)
+    for n in range(80):
+        X[n, (n * 37) % C::(n + 3)] = 1 + (n % 2)
+    dev = ga.DeviceModel(d)
+    _, b64 = dev.base_predict(X)
+    ref = oracle.base_lr(X, M, ctx, d.lr_coef, d.lr_intercept)
+    assert np.max(np.abs(b64 - ref)) < 1e-13
+
+
+def test_base_rejects_bad_geometry(ga):
+    from gnomix_amd import synth
+    d = synth.synthetic_model(C=1037, M=100, A=7, S=5, smooth=None)
+    d.C = 1000  # C % M == 0 (base.py:158)
+    d.lr_coef = d.lr_coef[:10]
+    d.lr_intercept = d.lr_intercept[:10]
+    with pytest.raises(ga.GnxError):
+        ga.DeviceModel(d)
+    d2 = synth.synthetic_model(C=1037, M=100, A=7, S=5, smooth=None)
+    dev = ga.DeviceModel(d2)
+    with pytest.raises(ValueError):
+        dev.base_predict(np.zeros((3, 999), dtype=np.int8))
+
+
+def test_base_empty_input(ga):
+    from gnomix_amd import synth
+    d = synth.synthetic_model(C=1037, M=100, A=7, S=5, smooth=None)
+    dev = ga.DeviceModel(d)
+    _, b = dev.base_predict(np.zeros((0, 1037), dtype=np.int8))
+    assert b.shape == (0, 10, 7)
+
+
+# ---------------------------------------------------------------- xgb smoother ---------------------
+def test_smooth_golden_G4(ga, oracle):
+    g = load_golden("G4_smooth.npz")
+    N, W, A = g["B"].shape
+    S = int(g["S"])
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=S, context=5, smooth_kind="xgb", tree_off=g["t_tree_off"],
+                        left=g["t_left"], right=g["t_right"], feat=g["t_feat"], cond=g["t_cond"],
+                        tree_class=g["t_tree_class"], base_score=float(g["t_base_score"]))
+    dev = ga.DeviceModel(d)
+    proba, lab = dev.smooth_predict(g["B"])
+    assert np.array_equal(lab, g["labels"])
+    assert np.array_equal(proba, g["proba"])  # bit-exact f32
+
+
+@pytest.mark.parametrize("N,W,A,S,rounds,depth", [
+    (5, 163, 7, 75, 6, 4),
+    (33, 370, 7, 75, 10, 4),     # chr22 window count, ragged last strip (370 = 5*64 + 50)
+    (17, 200, 3, 75, 8, 4),
+    (9, 150, 12, 75, 5, 4),      # A=12 (config 5)
+    (40, 64, 4, 31, 7, 4),       # exactly one strip
+    (3, 65, 2, 31, 9, 3),        # shallow trees -> runtime-depth kernel
+    (6, 90, 5, 41, 4, 6),        # deep trees
+    (1, 160, 7, 75, 20, 4),      # single haplotype
+    (70, 130, 8, 61, 3, 4),      # even A (bank-conflicted layout, same results)
+])
+def test_smooth_vs_oracle(ga, oracle, N, W, A, S, rounds, depth):
+    from gnomix_amd import synth
+    rng = np.random.RandomState(N * W + A)
+    B = rng.dirichlet(np.ones(A) * 0.4, size=(N, W))
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=S, context=5, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(rounds, A, S * A, depth=depth, seed=W, thr_lo=0.0, thr_hi=0.7, p_early_leaf=0.2).items():
+        setattr(d, k, v)
+    dev = ga.DeviceModel(d)
+    T = _oracle_trees(oracle, d)
+    p_ref, l_ref = oracle.smooth_xgb(T, B, S)
+    for Bin in (B, B.astype(np.float32)):
+        p_ref, l_ref = oracle.smooth_xgb(T, Bin, S)
+        proba, lab = dev.smooth_predict(Bin)
+        assert np.array_equal(lab, l_ref)
+        assert np.array_equal(proba, p_ref)
+    p64, _ = dev.smooth_predict(B, proba_dtype=np.float64)
+    assert np.array_equal(p64, p_ref_f64(oracle, T, B, S))
+
+
+def p_ref_f64(oracle, T, B, S):
+    return oracle.smooth_xgb(T, B, S)[0].astype(np.float64)
+
+
+def test_smooth_rows_vs_oracle(ga, oracle):
+    from gnomix_amd import synth
+    A, S = 7, 75
+    d = ga.GnxModelData(C=1603, M=10, A=A, S=S, context=5, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(15, A, S * A, seed=2).items():
+        setattr(d, k, v)
+    dev = ga.DeviceModel(d)
+    rows = np.random.RandomState(0).uniform(size=(37, S * A)).astype(np.float32)
+    assert np.array_equal(dev.smooth_rows(rows), oracle.xgb_predict_proba(_oracle_trees(oracle, d), rows))
+
+
+def test_smoother_too_large_is_rejected(ga):
+    from gnomix_amd import synth
+    d = ga.GnxModelData(C=1003, M=10, A=3, S=75, context=5, smooth_kind="xgb")  # W=100 < 2*S (models.py:13)
+    for k, v in synth.synthetic_trees(2, 3, 75 * 3).items():
+        setattr(d, k, v)
+    with pytest.raises(ga.GnxError, match="Smoother size to large"):
+        ga.DeviceModel(d)
+
+
+# ---------------------------------------------------------------- whole path ------------------------
+@pytest.mark.parametrize("C,M,A,S,N", [(16037, 100, 7, 75, 50), (9531, 50, 4, 31, 21), (20011, 100, 12, 75, 12)])
+def test_infer_vs_oracle(ga, oracle, C, M, A, S, N):
+    from gnomix_amd import synth
+    d = synth.synthetic_model(C=C, M=M, A=A, S=S, n_rounds=15, seed=C)
+    X = synth.synthetic_X(N, C, seed=5, miss=0.02)
+    g = ga.HipGnomix(d)
+    proba = g.predict_proba(X)
+    labels = g.predict(X)
+    B = oracle.base_lr(X, M, d.context, d.lr_coef, d.lr_intercept)
+    p_ref, l_ref = oracle.smooth_xgb(_oracle_trees(oracle, d), B, S)
+    assert labels.dtype == np.int64 and proba.dtype == np.float32
+    assert np.array_equal(labels, l_ref)
+    assert np.max(np.abs(proba - p_ref)) <= 1e-5
+    # plugin-style use, as run_inference does it (gnomix.py:55-58)
+    Bq = g.base.predict_proba(X)
+    assert Bq.dtype == np.float64 and np.max(np.abs(Bq - B)) < 1e-12
+    yp = g.smooth.predict_proba(Bq)
+    assert np.array_equal(np.argmax(yp, axis=-1), l_ref)
+    assert np.array_equal(g.smooth.predict(Bq), l_ref)
+
+
+def test_full_size_properties_chr22(ga, oracle):
+    """BASELINE config-2 shape (C=370500, W=370, A=7, S=75, 700 trees): size-independent properties +
+    a sample of haplotypes against the oracle."""
+    import torch
+    from gnomix_amd import synth
+    d = synth.synthetic_model(seed=0, **synth.CHR22)
+    dev = ga.DeviceModel(d)
+    N = 512
+    Xd = synth.synthetic_X_device(N, d.C, "cuda:0", seed=94305)
+    p, lab = dev.infer_device(Xd)
+    torch.cuda.synchronize()
+    p, lab = p.cpu().numpy(), lab.cpu().numpy()
+    assert np.allclose(p.sum(-1), 1.0, atol=2e-6)
+    assert np.array_equal(lab, np.argmax(p, -1))
+    # permutation equivariance + batch-split independence (bit-exact)
+    perm = torch.randperm(N, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1))
+    p2, lab2 = dev.infer_device(Xd[perm].contiguous())
+    torch.cuda.synchronize()
+    assert np.array_equal(p2.cpu().numpy(), p[perm.cpu().numpy()])
+    p3, _ = dev.infer_device(Xd[100:137])
+    torch.cuda.synchronize()
+    assert np.array_equal(p3.cpu().numpy(), p[100:137])
+    # strided rows (ldx > C)
+    Xs = torch.zeros((8, d.C + 77), dtype=torch.int8, device="cuda:0")
+    Xs[:, :d.C] = Xd[:8]
+    p4, _ = dev.infer_device(Xs[:, :d.C])
+    torch.cuda.synchronize()
+    assert np.array_equal(p4.cpu().numpy(), p[:8])
+    # oracle on a sample
+    idx = [0, 1, 255, 511]
+    Xh = Xd[idx].cpu().numpy()
+    B = oracle.base_lr(Xh, d.M, d.context, d.lr_coef, d.lr_intercept)
+    p_ref, l_ref = oracle.smooth_xgb(_oracle_trees(oracle, d), B, d.S)
+    assert np.array_equal(lab[idx], l_ref)
+    assert np.max(np.abs(p[idx] - p_ref)) <= 1e-5
