@@ -6,8 +6,10 @@ compute entry points fails loudly (GnxLibraryError).  Build it with `python __gr
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
@@ -124,6 +126,8 @@ class Context:
         rc = self.lib.gnx_init(int(device), C.byref(h))
         self.h = h
         self.device = int(device)
+        self._models = weakref.WeakSet()
+        _live_contexts.add(self)
         if rc != GNX_OK:
             msg = self.lib.gnx_last_error(h).decode() if h else "gnx_init failed"
             if h:
@@ -153,6 +157,8 @@ class Context:
         return ms.value, n.value
 
     def close(self):
+        for m in list(getattr(self, "_models", ())):
+            m.close()
         if self.h:
             self.lib.gnx_ctx_free(self.h)
             self.h = None
@@ -165,6 +171,18 @@ class Context:
 
 
 _default_ctx = {}
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _shutdown():
+    # free device state while the HIP runtime is still alive (interpreter teardown order is undefined)
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+    _default_ctx.clear()
 
 
 def default_context(device: int = 0) -> Context:

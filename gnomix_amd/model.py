@@ -188,15 +188,16 @@ class DeviceModel:
         self.ctx.check(self.lib.gnx_model_load(self.ctx.h, C.byref(desc), C.byref(h)))
         del keep
         self.h = h
+        self.ctx._models.add(self)
         info = _lib.ModelInfo()
         self.ctx.check(self.lib.gnx_model_get_info(h, C.byref(info)))
         self.info = info
         self.W, self.A, self.S, self.C, self.M = int(info.W), int(info.A), int(info.S), int(info.C), int(info.M)
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and self.ctx.h:
             self.lib.gnx_model_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
