@@ -65,6 +65,7 @@ SYMBOLS = {
     "gnx_ctx_free": (None, [_VP]),
     "gnx_last_error": (C.c_char_p, [_VP]),
     "gnx_set_stream": (C.c_int, [_VP, _VP]),
+    "gnx_reset_stream": (C.c_int, [_VP]),
     "gnx_synchronize": (C.c_int, [_VP]),
     "gnx_model_load": (C.c_int, [_VP, C.POINTER(ModelDesc), C.POINTER(_VP)]),
     "gnx_model_free": (None, [_VP]),
@@ -141,6 +142,9 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self.check(self.lib.gnx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def reset_stream(self):
+        self.check(self.lib.gnx_reset_stream(self.h))
 
     def synchronize(self):
         self.check(self.lib.gnx_synchronize(self.h))

@@ -325,6 +325,7 @@ int gnx_init(int device, gnx_ctx** out) {
     return GNX_EHIP;
   }
   ctx->own_stream = true;
+  ctx->usable = true;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
   *out = ctx;
@@ -333,7 +334,7 @@ int gnx_init(int device, gnx_ctx** out) {
 
 void gnx_ctx_free(gnx_ctx* ctx) {
   if (!ctx) return;
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
   for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc})
@@ -346,19 +347,22 @@ const char* gnx_last_error(const gnx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 int gnx_set_stream(gnx_ctx* ctx, void* hip_stream) {
   if (!ctx) return GNX_EINVAL;
+  if (!ctx->own_stream && ctx->stream == (hipStream_t)hip_stream) return GNX_OK;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (hip_stream == nullptr) {
-    if (!ctx->own_stream) {
-      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-      ctx->own_stream = true;
-    }
-    return GNX_OK;
-  }
   if (ctx->own_stream) {
     (void)hipStreamDestroy(ctx->stream);
     ctx->own_stream = false;
   }
-  ctx->stream = (hipStream_t)hip_stream;
+  ctx->stream = (hipStream_t)hip_stream;  // NULL = the default stream (what torch uses unless told otherwise)
+  return GNX_OK;
+}
+
+int gnx_reset_stream(gnx_ctx* ctx) {
+  if (!ctx) return GNX_EINVAL;
+  if (ctx->own_stream) return GNX_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->own_stream = true;
   return GNX_OK;
 }
 
@@ -371,7 +375,7 @@ int gnx_synchronize(gnx_ctx* ctx) {
 int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
   if (!ctx || !out) return GNX_EINVAL;
   *out = nullptr;
-  if (!ctx->stream) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
+  if (!ctx->usable) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
   if (!d) return fail(ctx, GNX_EINVAL, "model description is NULL");
   if (d->abi_version != GNX_ABI_VERSION) return fail(ctx, GNX_EINVAL, "gnx_model_desc.abi_version mismatch");
   if (d->A < 2 || d->A > 32) return fail(ctx, GNX_EINVAL, "A (ancestries) must be in [2, 32]");
@@ -411,7 +415,7 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
 
 void gnx_model_free(gnx_model* m) {
   if (!m) return;
-  if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
+  if (m->ctx && m->ctx->usable) (void)hipStreamSynchronize(m->ctx->stream);
   for (void* p : m->dev_allocs) (void)hipFree(p);
   delete m;
 }

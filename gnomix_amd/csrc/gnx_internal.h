@@ -24,6 +24,7 @@ struct gnx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  bool usable = false;
   std::string err;
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)

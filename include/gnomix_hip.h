@@ -137,7 +137,8 @@ int gnx_abi_version(void);
 int gnx_init(int device, gnx_ctx** out);
 void gnx_ctx_free(gnx_ctx* ctx);
 const char* gnx_last_error(const gnx_ctx* ctx);
-int gnx_set_stream(gnx_ctx* ctx, void* hip_stream); /* borrow a hipStream_t (NULL = own stream) */
+int gnx_set_stream(gnx_ctx* ctx, void* hip_stream); /* borrow a hipStream_t; NULL is HIP's default (null) stream */
+int gnx_reset_stream(gnx_ctx* ctx);                 /* back to the context's own non-blocking stream */
 int gnx_synchronize(gnx_ctx* ctx);
 
 /* model */
