@@ -283,6 +283,9 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
     }
   }
   group_tree0.push_back((int32_t)order.size());
+  std::vector<int32_t> class_tree0((size_t)A + 1, 0);
+  for (int t = 0; t < d->n_trees; ++t) class_tree0[(size_t)d->tree_class[t] + 1] += 1;
+  for (int c = 0; c < A; ++c) class_tree0[(size_t)c + 1] += class_tree0[(size_t)c];
   std::vector<uint8_t> packed((size_t)d->n_trees * tree_bytes, 0);
   for (size_t k = 0; k < order.size(); ++k)
     tree_fill(d, d->tree_off[order[k]], 0, 1, 0, D, packed.data() + k * tree_bytes);
@@ -291,6 +294,7 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
   if ((rc = dev_upload(m, packed, &m->xgb.packed, 64)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, group_tree0, &m->xgb.group_tree0)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, group_class, &m->xgb.group_class)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, class_tree0, &m->class_tree0)) != GNX_OK) return rc;
   m->xgb.n_groups = (int32_t)group_class.size();
   m->xgb.n_trees = d->n_trees;
   m->xgb.D = D;
@@ -299,6 +303,18 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
   m->xgb.base_score = d->base_score;
   m->info.n_trees = d->n_trees;
   m->info.tree_depth = D;
+  return GNX_OK;
+}
+
+static int build_crf(gnx_model* m, const gnx_model_desc* d) {
+  gnx_ctx* ctx = m->ctx;
+  const int A = d->A;
+  if (!d->crf_state || !d->crf_trans) return fail(ctx, GNX_EINVAL, "crf smoother: crf_state / crf_trans is NULL");
+  std::vector<double> st(d->crf_state, d->crf_state + (size_t)A * A), et((size_t)A * A);
+  for (int i = 0; i < A * A; ++i) et[(size_t)i] = std::exp(d->crf_trans[i]);
+  int rc;
+  if ((rc = dev_upload(m, st, &m->crf_state)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, et, &m->crf_etrans)) != GNX_OK) return rc;
   return GNX_OK;
 }
 
@@ -337,7 +353,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc})
+  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale})
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -402,7 +418,7 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
       if (d->S <= 0 || d->S % 2 == 0) rc = fail(ctx, GNX_EINVAL, "S must be odd and positive (smooth.py:14)");
       else rc = build_xgb(m, d);
       break;
-    case GNX_SMOOTH_CRF: rc = fail(ctx, GNX_EUNSUPPORTED, "CRF smoother: kernel not built yet"); break;
+    case GNX_SMOOTH_CRF: rc = build_crf(m, d); break;
     default: rc = fail(ctx, GNX_EINVAL, "unknown smooth_kind");
   }
   if (rc != GNX_OK) {
@@ -466,7 +482,25 @@ int gnx_smooth_predict_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N
     HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->n_cu, ctx->stream));
     return GNX_OK;
   }
-  return fail(ctx, GNX_ESTATE, "model has no smoother this build can run");
+  if (m->info.smooth_kind == GNX_SMOOTH_CRF) {
+    const size_t n = (size_t)N * m->info.W * m->info.A;
+    int rc;
+    double* alpha = d_p64;
+    if (!alpha) {
+      if ((rc = ws_reserve(ctx, ctx->ws_misc, n * sizeof(double))) != GNX_OK) return rc;
+      alpha = (double*)ctx->ws_misc.p;
+    }
+    if ((rc = ws_reserve(ctx, ctx->ws_scale, (size_t)N * m->info.W * sizeof(double))) != GNX_OK) return rc;
+    SmoothCRFLaunch L{};
+    L.B = dB; L.b_is_f64 = b_is_f64; L.N = N; L.W = (int32_t)m->info.W; L.A = m->info.A;
+    L.state = m->crf_state; L.etrans = m->crf_etrans;
+    L.alpha = alpha; L.scale = (double*)ctx->ws_scale.p;
+    L.proba64 = d_p64; L.proba32 = d_p32; L.labels = d_lab;
+    ProfScope ps(ctx, GNX_K_SMOOTH_CRF);
+    HIPCHK(ctx, gnx_launch_smooth_crf(L, ctx->stream));
+    return GNX_OK;
+  }
+  return fail(ctx, GNX_ESTATE, "model has no smoother");
 }
 
 int gnx_infer_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx, float* d_p32, double* d_p64, int32_t* d_lab) {
@@ -528,12 +562,13 @@ int gnx_smooth_predict(gnx_model* m, const void* B, int b_is_f64, int64_t N, flo
   int rc;
   gnx_devbuf& wb = b_is_f64 ? ctx->ws_b64 : ctx->ws_b32;
   if ((rc = ws_reserve(ctx, wb, N * WA * esz)) != GNX_OK) return rc;
-  if ((rc = ws_reserve(ctx, ctx->ws_p32, N * WA * 4)) != GNX_OK) return rc;
+  const bool xgb = m->info.smooth_kind == GNX_SMOOTH_XGB;
+  if ((p32 || xgb) && (rc = ws_reserve(ctx, ctx->ws_p32, N * WA * 4)) != GNX_OK) return rc;
   if (p64 && (rc = ws_reserve(ctx, ctx->ws_p64, N * WA * 8)) != GNX_OK) return rc;
   if (lab && (rc = ws_reserve(ctx, ctx->ws_lab, N * Wn * 4)) != GNX_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(wb.p, B, N * WA * esz, hipMemcpyHostToDevice, ctx->stream));
-  rc = gnx_smooth_predict_dev(m, wb.p, b_is_f64, N, (float*)ctx->ws_p32.p, p64 ? (double*)ctx->ws_p64.p : nullptr,
-                              lab ? (int32_t*)ctx->ws_lab.p : nullptr);
+  rc = gnx_smooth_predict_dev(m, wb.p, b_is_f64, N, (p32 || xgb) ? (float*)ctx->ws_p32.p : nullptr,
+                              p64 ? (double*)ctx->ws_p64.p : nullptr, lab ? (int32_t*)ctx->ws_lab.p : nullptr);
   if (rc != GNX_OK) return rc;
   if (p32) HIPCHK(ctx, hipMemcpyAsync(p32, ctx->ws_p32.p, N * WA * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (p64) HIPCHK(ctx, hipMemcpyAsync(p64, ctx->ws_p64.p, N * WA * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -593,9 +628,60 @@ int gnx_smooth_rows(gnx_model* m, const float* rows, int64_t R, float* proba) {
 
 int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_ind, int32_t max_it, int32_t* Y,
                int32_t* n_switches) {
-  (void)X; (void)ldx; (void)B; (void)n_ind; (void)max_it; (void)Y; (void)n_switches;
   if (!m) return GNX_EINVAL;
-  return fail(m->ctx, GNX_EUNSUPPORTED, "gnofix: kernel not built yet");
+  gnx_ctx* ctx = m->ctx;
+  // src/model.py:194: only a smoother with .gnofix == True (XGB_Smoother) supports re-phasing
+  if (m->info.smooth_kind != GNX_SMOOTH_XGB)
+    return fail(ctx, GNX_ESTATE, "Type of Smoother does not currently support re-phasing");
+  if (n_ind < 0 || ldx < m->info.C || max_it < 0 || (n_ind > 0 && (!X || !B || !Y)))
+    return fail(ctx, GNX_EINVAL, "gnofix: bad arguments");
+  if (n_ind == 0) return GNX_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int W = (int)m->info.W, A = m->info.A, S = m->info.S, pad = (S + 1) / 2;
+  const size_t WA = (size_t)W * A, NWD = (size_t)(W + 31) / 32;
+  bool in_lds = gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, true) <= 150 * 1024;
+  if (gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, in_lds) > 160 * 1024)
+    return fail(ctx, GNX_EUNSUPPORTED, "gnofix: model too large for the LDS working set (n_trees * 16 B + S*A*8 B)");
+  // batches of individuals bound the staging workspaces (~1 GiB of X)
+  int64_t nb = std::max<int64_t>(1, (((int64_t)1 << 30) / std::max<int64_t>(ldx, 1)) / 2);
+  nb = std::min(nb, n_ind);
+  int rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)2 * nb * ldx + 64)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_b64, (size_t)2 * nb * WA * 8)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_p32, (size_t)2 * nb * WA * 4)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_lab, (size_t)2 * nb * W * 4 * 2 + (size_t)nb * 4)) != GNX_OK) return rc;
+  size_t misc = (size_t)nb * std::max(max_it, 1) * NWD * 4;
+  const size_t bp_off = (misc + 255) & ~(size_t)255;
+  if (!in_lds) misc = bp_off + (size_t)nb * 2 * (W + 2 * pad) * A * 4;
+  if ((rc = ws_reserve(ctx, ctx->ws_misc, misc + 256)) != GNX_OK) return rc;
+  for (int64_t i0 = 0; i0 < n_ind; i0 += nb) {
+    const int64_t n = std::min(nb, n_ind - i0);
+    int8_t* dX = (int8_t*)ctx->ws_x.p;
+    double* dB = (double*)ctx->ws_b64.p;
+    int32_t* dY0 = (int32_t*)ctx->ws_lab.p;
+    int32_t* dY = dY0 + (size_t)2 * nb * W;
+    int32_t* dNs = dY + (size_t)2 * nb * W;
+    HIPCHK(ctx, hipMemcpyAsync(dX, X + 2 * i0 * ldx, (size_t)(2 * n - 1) * ldx + m->info.C, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dB, B + (size_t)2 * i0 * WA, (size_t)2 * n * WA * 8, hipMemcpyHostToDevice, ctx->stream));
+    // initial labels = smoother.predict(B) for every haplotype at once (gnofix.py:80)
+    rc = gnx_smooth_predict_dev(m, dB, 1, 2 * n, (float*)ctx->ws_p32.p, nullptr, dY0);
+    if (rc != GNX_OK) return rc;
+    GnofixLaunch L{};
+    L.X = dX; L.ldx = ldx; L.C = m->info.C; L.B = dB; L.Y0 = dY0; L.Yout = dY; L.n_switches = dNs;
+    L.W = W; L.A = A; L.S = S; L.max_it = max_it; L.d = m->xgb; L.class_tree0 = m->class_tree0;
+    L.bp_in_lds = in_lds ? 1 : 0;
+    L.hist = (uint32_t*)ctx->ws_misc.p;
+    L.bp_scratch = in_lds ? nullptr : (float*)((char*)ctx->ws_misc.p + bp_off);
+    {
+      ProfScope ps(ctx, GNX_K_GNOFIX);
+      HIPCHK(ctx, gnx_launch_gnofix(L, n, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(X + 2 * i0 * ldx, dX, (size_t)(2 * n - 1) * ldx + m->info.C, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(Y + (size_t)2 * i0 * W, dY, (size_t)2 * n * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_switches) HIPCHK(ctx, hipMemcpyAsync(n_switches + i0, dNs, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return GNX_OK;
 }
 
 // ---- profiling ---------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ struct gnx_ctx {
   std::string err;
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)
-  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc;
+  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -86,6 +86,37 @@ struct SmoothXGBLaunch {
   int32_t* labels;   // optional
 };
 
+// ---- crf smoother (k_smooth_crf.hip) ------------------------------------------------------------------
+struct SmoothCRFLaunch {
+  const void* B;          // (N, W, A) float64 or float32
+  int32_t b_is_f64;
+  int64_t N;
+  int32_t W, A;
+  const double* state;    // device (A, A) theta[a][y]
+  const double* etrans;   // device (A, A) exp(tau)[y'][y]
+  double* alpha;          // (N, W, A) scratch for the scaled forward variables (may alias proba64)
+  double* scale;          // (N, W) scratch
+  double* proba64;        // optional
+  float* proba32;         // optional
+  int32_t* labels;        // optional
+};
+
+// ---- gnofix (k_gnofix.hip) ----------------------------------------------------------------------------
+struct GnofixLaunch {
+  int8_t* X;               // (2*n_ind, ldx) re-phased in place
+  int64_t ldx, C;
+  const double* B;         // (2*n_ind, W, A) base probabilities
+  const int32_t* Y0;       // (2*n_ind, W) initial smoother labels
+  int32_t* Yout;           // (2*n_ind, W)
+  int32_t* n_switches;     // (n_ind,) optional
+  int32_t W, A, S, max_it;
+  SmoothXGBDev d;
+  const int32_t* class_tree0;  // [A+1] tree ranges per class in the packed (class-major) order
+  int32_t bp_in_lds;
+  float* bp_scratch;       // [n_ind][2][W+2pad][A] when the strips do not fit LDS
+  uint32_t* hist;          // [n_ind][max_it][ceil(W/32)] convergence signatures
+};
+
 struct gnx_model {
   gnx_ctx* ctx = nullptr;
   gnx_model_info info{};
@@ -93,7 +124,7 @@ struct gnx_model {
   BaseLRDev lr;
   SmoothXGBDev xgb;
   // class-major xgboost-schema copy for the rows kernel
-  const int32_t* rows_tree_off = nullptr;
+  const int32_t* class_tree0 = nullptr;  // device [A+1]
   // CRF
   const double* crf_state = nullptr;  // device (A,A)
   const double* crf_etrans = nullptr; // device (A,A) exp(trans)
@@ -104,4 +135,7 @@ hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);
+hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
+size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
+hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

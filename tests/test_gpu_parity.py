@@ -239,3 +239,93 @@ def test_full_size_properties_chr22(ga, oracle):
     p_ref, l_ref = oracle.smooth_xgb(_oracle_trees(oracle, d), B, d.S)
     assert np.array_equal(lab[idx], l_ref)
     assert np.max(np.abs(p[idx] - p_ref)) <= 1e-5
+
+
+# ---------------------------------------------------------------- crf smoother ----------------------
+@pytest.mark.parametrize("N,W,A", [(5, 40, 7), (70, 370, 7), (33, 150, 12), (9, 97, 2), (1, 30, 3), (40, 64, 16)])
+def test_crf_vs_oracle(ga, oracle, N, W, A):
+    rng = np.random.RandomState(N + W)
+    B = rng.dirichlet(np.ones(A) * 0.5, size=(N, W))
+    state = rng.standard_normal((A, A)) * 2 + 4 * np.eye(A)
+    trans = rng.standard_normal((A, A)) * 0.5 + 3 * np.eye(A)
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=75, context=5, smooth_kind="crf", crf_state=state, crf_trans=trans)
+    dev = ga.DeviceModel(d)
+    p_ref, l_ref = oracle.smooth_crf(B, state, trans)
+    p, lab = dev.smooth_predict(B)
+    assert p.dtype == np.float64
+    assert np.max(np.abs(p - p_ref)) < 1e-11
+    assert np.array_equal(lab, l_ref)
+    assert np.allclose(p.sum(-1), 1.0, atol=1e-10)
+    p32, _ = dev.smooth_predict(B, proba_dtype=np.float32)
+    assert np.array_equal(p32, p.astype(np.float32))
+    sm = ga.HipSmoother(dev)
+    assert sm.gnofix is False and np.array_equal(sm.predict(B), l_ref)
+
+
+def test_crf_end_to_end_and_no_phasing(ga, oracle):
+    from gnomix_amd import synth
+    d = synth.synthetic_model(C=12037, M=100, A=12, S=75, seed=4, smooth="crf")
+    X = synth.synthetic_X(30, d.C, seed=2)
+    g = ga.HipGnomix(d)
+    p = g.predict_proba(X)
+    B = oracle.base_lr(X, d.M, d.context, d.lr_coef, d.lr_intercept)
+    p_ref, l_ref = oracle.smooth_crf(B, d.crf_state, d.crf_trans)
+    assert np.max(np.abs(p - p_ref)) < 1e-9
+    assert np.array_equal(g.predict(X), l_ref)
+    with pytest.raises(AssertionError, match="does not currently support re-phasing"):  # src/model.py:194
+        g.phase(X)
+
+
+# ---------------------------------------------------------------- gnofix ----------------------------
+def _gnofix_model(ga, g, prefix):
+    W, A, S, C = int(g["W"]), int(g["A"]), int(g["S"]), int(g["C"])
+    return ga.GnxModelData(C=C, M=C // W, A=A, S=S, context=0, smooth_kind="xgb", tree_off=g[prefix + "tree_off"],
+                           left=g[prefix + "left"], right=g[prefix + "right"], feat=g[prefix + "feat"],
+                           cond=g[prefix + "cond"], tree_class=g[prefix + "tree_class"],
+                           base_score=float(g[prefix + "base_score"]))
+
+
+@pytest.mark.parametrize("name", ["none", "one", "two", "edges", "many", "rand"])
+def test_gnofix_golden_G5(ga, name):
+    g = load_golden("G5_gnofix.npz")
+    dev = ga.DeviceModel(_gnofix_model(ga, g, "r_" if name == "rand" else "t_"))
+    X = np.stack([g[name + "_Xm"], g[name + "_Xp"]]).astype(np.int8)
+    Xo, Y, nsw = dev.gnofix(X, g[name + "_B"], max_it=4 if name == "rand" else 50)
+    assert np.array_equal(Xo[0], g[name + "_oXm"]) and np.array_equal(Xo[1], g[name + "_oXp"])   # vs the REFERENCE's gnofix()
+    assert np.array_equal(Y[0], g[name + "_oYm"]) and np.array_equal(Y[1], g[name + "_oYp"])
+    assert int(nsw[0]) == int(g[name + "_nhist"]) - 2
+
+
+def test_phase_wrapper_golden_G5(ga):
+    g = load_golden("G5_gnofix.npz")
+    hip = ga.HipGnomix(_gnofix_model(ga, g, "t_"))
+    Xph, Yph = hip.phase(g["phase_X"], B=g["phase_B"])
+    assert np.array_equal(Xph, g["phase_oX"]) and np.array_equal(Yph, g["phase_oY"])  # vs reference Gnomix.phase()
+
+
+def test_gnofix_vs_oracle_random_individuals(ga, oracle):
+    """more individuals, chaotic smoother: many accepted switches, edge windows, max_it stops"""
+    from gnomix_amd import synth
+    W, A, S = 170, 5, 75
+    C = W * 7 + 5
+    d = ga.GnxModelData(C=C, M=7, A=A, S=S, context=0, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(6, A, S * A, seed=3, thr_lo=0.0, thr_hi=0.6, leaf_scale=1.0).items():
+        setattr(d, k, v)
+    dev = ga.DeviceModel(d)
+    T = _oracle_trees(oracle, d)
+    rng = np.random.RandomState(0)
+    n_ind = 12
+    X = rng.randint(0, 3, size=(2 * n_ind, C)).astype(np.int8)
+    X[6:8, :] = X[6:7, :]          # an individual with identical haplotypes (convergence signature path)
+    B = rng.dirichlet(np.ones(A) * 0.3, size=(2 * n_ind, W))
+    Xo, Y, nsw = dev.gnofix(X, B, max_it=6)
+    rows = lambda r: oracle.xgb_predict_proba(T, r)
+    labs = lambda b: oracle.smooth_xgb(T, b, S)[1]
+    tot = 0
+    for i in range(n_ind):
+        Xm, Xp, Ym, Yp, _, ns = oracle.gnofix(X[2 * i], X[2 * i + 1], B[2 * i:2 * i + 2], S, rows, labs, max_it=6)
+        assert np.array_equal(Xo[2 * i], Xm) and np.array_equal(Xo[2 * i + 1], Xp), i
+        assert np.array_equal(Y[2 * i], Ym) and np.array_equal(Y[2 * i + 1], Yp), i
+        assert int(nsw[i]) == ns
+        tot += ns
+    assert tot > 10  # the case really exercises accepted switches
