@@ -1,0 +1,119 @@
+"""Converters: reference objects -> GnxModelData (the export a maintainer runs once per model.pkl).
+
+`from_reference_model` needs the packages the pickle itself needs (sklearn, and xgboost or
+sklearn_crfsuite for the smoother): they are only touched through public fitted attributes.
+`trees_from_xgb_json` parses xgboost's documented JSON dump (Booster.get_dump(dump_format="json")),
+so it is testable without xgboost installed."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+
+from .model import GnxModelData
+
+
+def cov_sample(width, alpha=0.6, beta=1.0, seed=37):
+    """Substring lengths of the covering random string kernel for a window of `width` SNPs
+    (reference src/Base/string_kernel.py:80-89: legacy MT19937 stream seeded per call, one uniform draw
+    per m = 2..width).  The sequence is prefix-stable in `width`."""
+    rs = np.random.RandomState(seed)
+    ms = [1]
+    for m in range(2, int(width) + 1):
+        if (1 - (alpha ** (m - ms[-1] + 1))) * (m ** (-beta)) >= rs.random_sample():
+            ms.append(m)
+    return np.asarray(ms, dtype=np.int32)
+
+
+def svc_window_from_sklearn(svc, width):
+    """One fitted sklearn.svm.SVC(kernel=callable, probability=True) -> the dict GnxModelData.svc holds."""
+    xfit = getattr(svc, "_BaseLibSVM__Xfit")
+    return dict(xfit=np.ascontiguousarray(xfit, dtype=np.int8), support=svc.support_.astype(np.int32),
+                dual_coef=np.ascontiguousarray(svc._dual_coef_, dtype=np.float64),
+                intercept=np.ascontiguousarray(svc._intercept_, dtype=np.float64),
+                prob_a=np.ascontiguousarray(svc._probA, dtype=np.float64),
+                prob_b=np.ascontiguousarray(svc._probB, dtype=np.float64),
+                n_support=svc._n_support.astype(np.int32), ms=cov_sample(width))
+
+
+def trees_from_xgb_json(dumps, n_class, base_score=0.5):
+    """xgboost JSON tree dumps (list of str, one per tree, model order) -> xgboost-schema arrays.
+    JSON nodes: {"nodeid", "split": "f12", "split_condition", "yes", "no", "missing", "children"} or {"nodeid","leaf"};
+    `yes` is the child taken when feature < split_condition."""
+    off, L, R, F, Cd, cls = [0], [], [], [], [], []
+    for t, s in enumerate(dumps):
+        root = json.loads(s) if isinstance(s, str) else s
+        nodes = {}
+
+        def visit(nd):
+            nodes[nd["nodeid"]] = nd
+            for ch in nd.get("children", []):
+                visit(ch)
+
+        visit(root)
+        ids = sorted(nodes)
+        remap = {nid: k for k, nid in enumerate(ids)}
+        if remap[root["nodeid"]] != 0:
+            raise ValueError("tree root must have the smallest node id")
+        for nid in ids:
+            nd = nodes[nid]
+            if "leaf" in nd:
+                L.append(-1); R.append(-1); F.append(0); Cd.append(np.float32(nd["leaf"]))
+            else:
+                f = nd["split"]
+                f = int(f[1:]) if isinstance(f, str) and f.startswith("f") else int(f)
+                L.append(remap[nd["yes"]]); R.append(remap[nd["no"]]); F.append(f)
+                Cd.append(np.float32(nd["split_condition"]))
+        off.append(len(L))
+        cls.append(t % n_class)
+    return dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
+                feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32),
+                base_score=float(base_score))
+
+
+def from_reference_model(model) -> GnxModelData:
+    """An unpickled reference `src.model.Gnomix` -> GnxModelData."""
+    C, M, A = int(model.C), int(model.M), int(model.A)
+    d = GnxModelData(C=C, M=M, A=A, S=int(model.smooth.S), context=int(model.context))
+    W = C // M
+    models = model.base.models
+    first = type(models[0]).__name__
+    if first == "LogisticRegression":
+        ldc = d.M_ + d.rem
+        d.base_kind = "logistic"
+        d.lr_coef = np.zeros((W, A, ldc))
+        d.lr_intercept = np.zeros((W, A))
+        for i, m in enumerate(models):
+            if list(m.classes_) != list(range(A)):
+                raise ValueError(f"window {i}: classes_ != 0..A-1 (the vectorized reference path has no remap, base.py:176)")
+            d.lr_coef[i, :, :m.coef_.shape[1]] = m.coef_
+            d.lr_intercept[i] = m.intercept_
+    elif first == "SVC":
+        d.base_kind = "covrsk"
+        d.svc = [svc_window_from_sklearn(m, d.window_width(i)) for i, m in enumerate(models)]
+    else:
+        raise NotImplementedError(f"base model {first}")
+    sm = type(model.smooth).__name__
+    if sm == "XGB_Smoother":
+        booster = model.smooth.model.get_booster()
+        t = trees_from_xgb_json(booster.get_dump(dump_format="json"), A)
+        d.smooth_kind = "xgb"
+        for k, v in t.items():
+            setattr(d, k, v)
+    elif sm == "CRF_Smoother":
+        crf = model.smooth.model.CRF
+        d.smooth_kind = "crf"
+        d.crf_state = np.zeros((A, A))
+        d.crf_trans = np.zeros((A, A))
+        for (attr, label), w in crf.state_features_.items():
+            d.crf_state[int(attr), int(label)] = w
+        for (y0, y1), w in crf.transition_features_.items():
+            d.crf_trans[int(y0), int(y1)] = w
+    else:
+        raise NotImplementedError(f"smoother {sm}")
+    d.snp_pos, d.snp_ref, d.snp_alt = model.snp_pos, model.snp_ref, model.snp_alt
+    d.population_order = list(model.population_order) if model.population_order is not None else None
+    gm = getattr(model, "gen_map_df", None)
+    if gm is not None and len(gm):
+        d.gen_map_pos, d.gen_map_cm = np.asarray(gm["pos"]), np.asarray(gm["pos_cm"])
+    return d

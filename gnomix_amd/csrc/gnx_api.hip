@@ -306,6 +306,86 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
   return GNX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// model preparation: CovRSK / SVC base — support vectors as bit-planes, run-length table g
+// ------------------------------------------------------------------------------------------------
+static int build_covrsk(gnx_model* m, const gnx_model_desc* d) {
+  gnx_ctx* ctx = m->ctx;
+  const int A = d->A, P = A * (A - 1) / 2;
+  const int64_t C = d->C, M = d->M, W = C / M, rem = C - M * W, M_ = M + 2 * d->ctx;
+  if (!d->svc) return fail(ctx, GNX_EINVAL, "covrsk base: svc array is NULL");
+  if (A > 13) return fail(ctx, GNX_EUNSUPPORTED, "covrsk base: more than 13 ancestries");
+  std::vector<SvcWinDev> wins((size_t)W);
+  std::vector<uint32_t> svbits, gtab;
+  std::vector<double> coef;
+  std::vector<std::pair<std::vector<int32_t>, int32_t>> gkeys;  // (ms, width) -> offset
+  std::vector<int32_t> goffs;
+  int max_nw = 0, max_width = 0;
+  for (int64_t i = 0; i < W; ++i) {
+    const gnx_svc_window& sw = d->svc[i];
+    const int64_t width = (i == W - 1) ? M_ + rem : M_;
+    if (sw.width != width) return fail(ctx, GNX_EINVAL, "covrsk base: svc[i].width != window width (M+2ctx, +rem for the last)");
+    if (!sw.xfit || !sw.support || !sw.dual_coef || !sw.intercept || !sw.prob_a || !sw.prob_b || !sw.n_support || !sw.ms ||
+        sw.n_sv <= 0 || sw.n_ms <= 0)
+      return fail(ctx, GNX_EINVAL, "covrsk base: incomplete svc window");
+    SvcWinDev& wd = wins[(size_t)i];
+    wd.width = (int32_t)width;
+    wd.nw = (int32_t)((width + 31) / 32);
+    wd.n_sv = sw.n_sv;
+    max_nw = std::max(max_nw, wd.nw);
+    max_width = std::max(max_width, wd.width);
+    int acc = 0;
+    for (int c = 0; c < A; ++c) { wd.cls_start[c] = acc; acc += sw.n_support[c]; }
+    wd.cls_start[A] = acc;
+    if (acc != sw.n_sv) return fail(ctx, GNX_EINVAL, "covrsk base: sum(n_support) != n_sv");
+    // g(L) = sum_{m in Ms, m <= L} (L - m + 1): K adds g(run length) per maximal match run
+    std::vector<int32_t> ms(sw.ms, sw.ms + sw.n_ms);
+    int32_t goff = -1;
+    for (size_t k = 0; k < gkeys.size(); ++k)
+      if (gkeys[k].first == ms && gkeys[k].second == wd.width) goff = goffs[k];
+    if (goff < 0) {
+      goff = (int32_t)gtab.size();
+      for (int64_t Lr = 0; Lr <= width; ++Lr) {
+        uint64_t g = 0;
+        for (int32_t mm : ms) if (mm >= 1 && mm <= Lr) g += (uint64_t)(Lr - mm + 1);
+        gtab.push_back((uint32_t)g);
+      }
+      gkeys.push_back({ms, wd.width});
+      goffs.push_back(goff);
+    }
+    wd.g_off = goff;
+    wd.sv_off = (int64_t)svbits.size();
+    for (int k = 0; k < sw.n_sv; ++k) {
+      const int32_t r = sw.support[k];
+      if (r < 0 || r >= sw.n_fit) return fail(ctx, GNX_EINVAL, "covrsk base: support index out of range");
+      const int8_t* row = sw.xfit + (size_t)r * width;
+      const size_t base = svbits.size();
+      svbits.resize(base + 2 * (size_t)wd.nw, 0u);
+      for (int64_t t = 0; t < width; ++t) {
+        const uint32_t v = (uint32_t)(uint8_t)row[t];
+        if (v > 3) return fail(ctx, GNX_EUNSUPPORTED, "covrsk base: training symbols outside {0,1,2,3}");
+        svbits[base + (size_t)(t >> 5)] |= (v & 1u) << (t & 31);
+        svbits[base + (size_t)wd.nw + (size_t)(t >> 5)] |= ((v >> 1) & 1u) << (t & 31);
+      }
+    }
+    wd.coef_off = (int64_t)coef.size();
+    coef.insert(coef.end(), sw.dual_coef, sw.dual_coef + (size_t)(A - 1) * sw.n_sv);
+    coef.insert(coef.end(), sw.intercept, sw.intercept + P);
+    coef.insert(coef.end(), sw.prob_a, sw.prob_a + P);
+    coef.insert(coef.end(), sw.prob_b, sw.prob_b + P);
+  }
+  if (gnx_covrsk_lds_bytes(A, max_nw, max_width) > 160 * 1024)
+    return fail(ctx, GNX_EUNSUPPORTED, "covrsk base: window too wide for the LDS working set");
+  int rc;
+  if ((rc = dev_upload(m, wins, &m->svc.win)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, svbits, &m->svc.svbits, 64)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, coef, &m->svc.coef)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, gtab, &m->svc.gtab)) != GNX_OK) return rc;
+  m->svc.max_nw = max_nw;
+  m->svc.max_width = max_width;
+  return GNX_OK;
+}
+
 static int build_crf(gnx_model* m, const gnx_model_desc* d) {
   gnx_ctx* ctx = m->ctx;
   const int A = d->A;
@@ -353,7 +433,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale})
+  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits})
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -409,7 +489,7 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
   switch (d->base_kind) {
     case GNX_BASE_NONE: break;
     case GNX_BASE_LOGISTIC: rc = build_lr(m, d); break;
-    case GNX_BASE_COVRSK_SVC: rc = fail(ctx, GNX_EUNSUPPORTED, "CovRSK/SVC base: kernel not built yet"); break;
+    case GNX_BASE_COVRSK_SVC: rc = build_covrsk(m, d); break;
     default: rc = fail(ctx, GNX_EINVAL, "unknown base_kind");
   }
   if (rc == GNX_OK) switch (d->smooth_kind) {
@@ -448,7 +528,22 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
   gnx_ctx* ctx = m->ctx;
   if (N < 0 || ldx < m->info.C || (N > 0 && !dX)) return fail(ctx, GNX_EINVAL, "base_predict: bad X / N / ldx");
   if (N == 0 || (!d_b32 && !d_b64)) return GNX_OK;
-  if (m->info.base_kind != GNX_BASE_LOGISTIC) return fail(ctx, GNX_ESTATE, "model has no logistic base");
+  if (m->info.base_kind == GNX_BASE_COVRSK_SVC) {
+    const int64_t Cp = m->info.C + 2 * m->info.ctx, nwp = (Cp + 31) / 32 + 2;
+    int rc = ws_reserve(ctx, ctx->ws_bits, (size_t)N * 2 * nwp * 4);
+    if (rc != GNX_OK) return rc;
+    ProfScope ps(ctx, GNX_K_BASE_COVRSK);
+    HIPCHK(ctx, gnx_launch_pack_bits(dX, N, ldx, m->info.C, m->info.ctx, nwp, (uint32_t*)ctx->ws_bits.p, ctx->stream));
+    CovRSKLaunch L{};
+    L.planes = (const uint32_t*)ctx->ws_bits.p; L.N = N; L.nwp = nwp; L.M = m->info.M;
+    L.W = (int32_t)m->info.W; L.A = m->info.A;
+    L.win = m->svc.win; L.svbits = m->svc.svbits; L.coef = m->svc.coef; L.gtab = m->svc.gtab;
+    L.max_nw = m->svc.max_nw; L.max_width = m->svc.max_width;
+    L.b32 = d_b32; L.b64 = d_b64;
+    HIPCHK(ctx, gnx_launch_covrsk(L, ctx->stream));
+    return GNX_OK;
+  }
+  if (m->info.base_kind != GNX_BASE_LOGISTIC) return fail(ctx, GNX_ESTATE, "model has no base classifier");
   BaseLRLaunch L{};
   L.X = dX;
   L.x_end = dX + (N - 1) * ldx + m->info.C;

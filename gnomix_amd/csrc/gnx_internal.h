@@ -28,7 +28,7 @@ struct gnx_ctx {
   std::string err;
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)
-  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale;
+  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -101,6 +101,35 @@ struct SmoothCRFLaunch {
   int32_t* labels;        // optional
 };
 
+// ---- CovRSK / SVC base (k_base_covrsk.hip) ------------------------------------------------------------
+struct SvcWinDev {
+  int32_t width, nw, n_sv, g_off;  // window width in SNPs, 32-bit words per plane, support vectors, offset into gtab
+  int64_t sv_off;                  // offset (uint32 units) of this window's SV bit-planes: [sv][plane][nw]
+  int64_t coef_off;                // offset (doubles): dual (A-1, n_sv) | intercept P | probA P | probB P
+  int32_t cls_start[36];           // SV index range per class (prefix sums of n_support)
+};
+
+struct CovRSKDev {
+  const SvcWinDev* win = nullptr;
+  const uint32_t* svbits = nullptr;
+  const double* coef = nullptr;
+  const uint32_t* gtab = nullptr;
+  int32_t max_nw = 0, max_width = 0;
+};
+
+struct CovRSKLaunch {
+  const uint32_t* planes;  // (N, 2, nwp) bit-planes of padded X
+  int64_t N, nwp, M;
+  int32_t W, A;
+  const SvcWinDev* win;
+  const uint32_t* svbits;
+  const double* coef;
+  const uint32_t* gtab;
+  int32_t max_nw, max_width;
+  float* b32;
+  double* b64;
+};
+
 // ---- gnofix (k_gnofix.hip) ----------------------------------------------------------------------------
 struct GnofixLaunch {
   int8_t* X;               // (2*n_ind, ldx) re-phased in place
@@ -123,6 +152,7 @@ struct gnx_model {
   std::vector<void*> dev_allocs;
   BaseLRDev lr;
   SmoothXGBDev xgb;
+  CovRSKDev svc;
   // class-major xgboost-schema copy for the rows kernel
   const int32_t* class_tree0 = nullptr;  // device [A+1]
   // CRF
@@ -135,6 +165,10 @@ hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);
+hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwp,
+                                uint32_t* planes, hipStream_t s);
+hipError_t gnx_launch_covrsk(const CovRSKLaunch& L, hipStream_t s);
+size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width);
 hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
 size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);

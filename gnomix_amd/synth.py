@@ -99,3 +99,31 @@ def synthetic_X_device(N, C, device, seed=94305, miss=0.01):
         x[torch.rand((n1 - n0, C), device=device, generator=g) < miss] = 2
         X[n0:n1] = x
     return X
+
+
+def synthetic_svc_model(C, M, A, context=None, n_fit_per_class=20, sv_frac=0.7, seed=0, S=75, smooth=None):
+    """Random-parameter CovRSK/SVC base of the reference architecture (src/Base/models.py:195-215):
+    per window an SVC over `A*n_fit_per_class` training haplotypes with a random subset as support vectors."""
+    from .convert import cov_sample
+    rng = np.random.RandomState(seed)
+    context = int(M * 0.5) if context is None else int(context)
+    m = synthetic_model(C, M, A, S=S, context=context, seed=seed, base=None, smooth=smooth)
+    m.base_kind = "covrsk"
+    W, P = m.W, A * (A - 1) // 2
+    m.svc = []
+    n_fit = A * n_fit_per_class
+    for i in range(W):
+        width = m.window_width(i)
+        xfit = (rng.random_sample((n_fit, width)) < rng.uniform(0.1, 0.9, size=width)).astype(np.int8)
+        xfit[rng.random_sample(xfit.shape) < 0.01] = 2
+        cls = np.repeat(np.arange(A), n_fit_per_class)
+        sup = np.sort(np.concatenate([np.where(cls == c)[0][rng.random_sample(n_fit_per_class) < sv_frac] for c in range(A)]))
+        for c in range(A):  # every class keeps at least one SV
+            if not (cls[sup] == c).any():
+                sup = np.sort(np.append(sup, c * n_fit_per_class))
+        n_support = np.array([(cls[sup] == c).sum() for c in range(A)], np.int32)
+        m.svc.append(dict(xfit=xfit, support=sup.astype(np.int32),
+                          dual_coef=rng.standard_normal((A - 1, len(sup))) * 0.01,
+                          intercept=rng.standard_normal(P) * 0.3, prob_a=-np.abs(rng.standard_normal(P)) - 0.5,
+                          prob_b=rng.standard_normal(P) * 0.2, n_support=n_support, ms=cov_sample(width)))
+    return m

@@ -329,3 +329,55 @@ def test_gnofix_vs_oracle_random_individuals(ga, oracle):
         assert int(nsw[i]) == ns
         tot += ns
     assert tot > 10  # the case really exercises accepted switches
+
+
+# ---------------------------------------------------------------- CovRSK / SVC base ------------------
+def _svc_oracle_windows(d):
+    return [dict(Xfit=w["xfit"], Ms=list(w["ms"]), support=w["support"], dual=w["dual_coef"], intercept=w["intercept"],
+                 probA=w["prob_a"], probB=w["prob_b"], n_support=w["n_support"]) for w in d.svc]
+
+
+def test_covrsk_golden_G2(ga, oracle):
+    from gnomix_amd import convert
+    g = load_golden("G2_covrsk.npz")
+    C, M, A, ctx = int(g["C"]), int(g["M"]), int(g["A"]), int(g["ctx"])
+    W = C // M
+    d = ga.GnxModelData(C=C, M=M, A=A, S=5, context=ctx, base_kind="covrsk")
+    d.svc = []
+    for i in range(W):
+        xf = g["w%d_Xfit" % i]
+        d.svc.append(dict(xfit=xf, support=g["w%d_support" % i], dual_coef=g["w%d_dual" % i], intercept=g["w%d_intercept" % i],
+                          prob_a=g["w%d_probA" % i], prob_b=g["w%d_probB" % i], n_support=g["w%d_nsv" % i],
+                          ms=convert.cov_sample(xf.shape[1])))
+    dev = ga.DeviceModel(d)
+    b32, b64 = dev.base_predict(g["X"], want_f32=True, want_f64=True)
+    assert np.max(np.abs(b64 - g["B"])) < 1e-12          # vs the REFERENCE's CovRSKBase.predict_proba
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(g["B"], -1))
+    assert np.array_equal(b32, b64.astype(np.float32))
+
+
+@pytest.mark.parametrize("C,M,A,ctx,N,nfit", [
+    (1537, 100, 3, 50, 70, 12),       # width 200 = 7 words (partial last word), last window 237
+    (3511, 175, 7, 87, 130, 20),      # config-3 geometry: M=175, width 349 -> Ms = [1,4,8,39,42,117]
+    (1029, 64, 4, 32, 5, 8),          # width 128: exact multiple of 32
+    (2011, 500, 2, 250, 33, 30),      # width 1000 (>866: all eight canonical lengths), binary problem
+    (1237, 50, 12, 25, 64, 6),        # A=12
+])
+def test_covrsk_vs_oracle(ga, oracle, C, M, A, ctx, N, nfit):
+    from gnomix_amd import synth
+    d = synth.synthetic_svc_model(C, M, A, context=ctx, n_fit_per_class=nfit, seed=C)
+    # related haplotypes: queries copy training rows over long stretches so long match runs occur
+    rng = np.random.RandomState(N)
+    X = synth.synthetic_X(N, C, seed=N, miss=0.02)
+    for n in range(0, N, 2):
+        w = rng.randint(d.W)
+        src = d.svc[w]["xfit"][rng.randint(d.svc[w]["xfit"].shape[0])]
+        lo = max(0, w * M - ctx)
+        ln = min(len(src), C - lo)
+        X[n, lo:lo + ln] = src[:ln] if w * M - ctx >= 0 else src[ctx:ctx + ln]
+    dev = ga.DeviceModel(d)
+    _, b64 = dev.base_predict(X)
+    ref = oracle.base_covrsk(X, M, ctx, _svc_oracle_windows(d))
+    assert np.max(np.abs(b64 - ref)) < 1e-12
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(ref, -1))
+    assert np.allclose(b64.sum(-1), 1.0, atol=1e-9)

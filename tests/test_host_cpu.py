@@ -74,3 +74,28 @@ def test_synthetic_trees_match_oracle_schema(oracle):
     f = np.random.RandomState(0).uniform(size=(20, 33)).astype(np.float32)
     p = oracle.xgb_predict_proba(T, f)
     assert p.shape == (20, 3) and np.allclose(p.sum(1), 1, atol=1e-6)
+
+
+def test_cov_sample_matches_oracle_and_anchors(oracle):
+    from gnomix_amd import convert
+    for m in (8, 20, 349, 499, 2000, 2500):
+        assert list(convert.cov_sample(m)) == oracle.cov_sample(m)
+    assert list(convert.cov_sample(349)) == [1, 4, 8, 39, 42, 117]
+
+
+def test_trees_from_xgb_json_roundtrip(oracle):
+    """hand-written JSON in xgboost's dump format -> arrays -> same predictions as the arrays' own walk"""
+    import json
+    from gnomix_amd import convert
+    t0 = {"nodeid": 0, "depth": 0, "split": "f3", "split_condition": 0.25, "yes": 1, "no": 2, "missing": 1, "children": [
+        {"nodeid": 1, "leaf": -0.1},
+        {"nodeid": 2, "depth": 1, "split": "f0", "split_condition": 0.5, "yes": 3, "no": 4, "missing": 3, "children": [
+            {"nodeid": 3, "leaf": 0.2}, {"nodeid": 4, "leaf": 0.3}]}]}
+    t1 = {"nodeid": 0, "leaf": 0.05}
+    t = convert.trees_from_xgb_json([json.dumps(t0), json.dumps(t1)], n_class=2)
+    assert t["left"].tolist() == [1, -1, 3, -1, -1, -1] and t["feat"].tolist()[:3] == [3, 0, 0]
+    T = oracle.Trees(t["tree_off"], t["left"], t["right"], t["feat"], t["cond"], t["tree_class"], 2)
+    f = np.array([[0.6, 0, 0, 0.3], [0.1, 0, 0, 0.9], [0.9, 0, 0, 0.1]], dtype=np.float32)
+    m = np.log(oracle.xgb_predict_proba(T, f))
+    want = np.array([0.3, 0.2, -0.1]) - 0.05  # margin difference class0 - class1
+    assert np.allclose(m[:, 0] - m[:, 1], want, atol=1e-6)
