@@ -372,9 +372,11 @@ def test_covrsk_vs_oracle(ga, oracle, C, M, A, ctx, N, nfit):
     for n in range(0, N, 2):
         w = rng.randint(d.W)
         src = d.svc[w]["xfit"][rng.randint(d.svc[w]["xfit"].shape[0])]
-        lo = max(0, w * M - ctx)
-        ln = min(len(src), C - lo)
-        X[n, lo:lo + ln] = src[:ln] if w * M - ctx >= 0 else src[ctx:ctx + ln]
+        start = w * M - ctx
+        seg = src if start >= 0 else src[-start:]
+        lo = max(0, start)
+        ln = min(len(seg), C - lo)
+        X[n, lo:lo + ln] = seg[:ln]
     dev = ga.DeviceModel(d)
     _, b64 = dev.base_predict(X)
     ref = oracle.base_covrsk(X, M, ctx, _svc_oracle_windows(d))
