@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -157,7 +158,11 @@ static int build_lr(gnx_model* m, const gnx_model_desc* d) {
   }
 
   // fragment-ordered, reflect-folded weights
+  const char* impl = std::getenv("GNX_BASE_LR_IMPL");  // "i8" (default, exact fixed point) or "f64" (f64 MFMA)
+  m->lr_i8 = !(impl && std::string(impl) == "f64");
   std::vector<double> V(n_chunks * 16 * (size_t)NT * 64, 0.0);
+  std::vector<int32_t> Vwin(m->lr_i8 ? V.size() : 0, -1);
+  std::vector<double> maxabs((size_t)W, 0.0);
   const double* coef = d->lr_coef;
   const int64_t ldc = d->lr_ldc;
   for (size_t c = 0; c < n_chunks; ++c)
@@ -187,14 +192,45 @@ static int build_lr(gnx_model* m, const gnx_model_desc* d) {
             if (!any) continue;
             const int64_t col = slot * A + a;
             const int nt = (int)(col / 16), c16 = (int)(col % 16);
-            V[((c * 16 + (size_t)t) * NT + (size_t)nt) * 64 + (size_t)(kq * 16 + c16)] = wsum;
+            const size_t vi = ((c * 16 + (size_t)t) * NT + (size_t)nt) * 64 + (size_t)(kq * 16 + c16);
+            V[vi] = wsum;
+            if (m->lr_i8) {
+              Vwin[vi] = (int32_t)i;
+              maxabs[(size_t)i] = std::max(maxabs[(size_t)i], std::fabs(wsum));
+            }
           }
         }
       }
 
   std::vector<double> icpt(d->lr_intercept, d->lr_intercept + (size_t)W * A);
   int rc;
-  if ((rc = dev_upload(m, V, &m->lr.V)) != GNX_OK) return rc;
+  if (m->lr_i8) {
+    // exact fixed point: q = round(c * 2^f_w), |q| < 2^54, seven balanced base-256 digits per weight
+    std::vector<int> fexp((size_t)W, 0);
+    std::vector<double> wscale((size_t)W, 1.0);
+    for (int64_t i = 0; i < W; ++i) {
+      if (!(maxabs[(size_t)i] < 1e300)) return fail(ctx, GNX_EINVAL, "logistic base: non-finite coefficient");
+      if (maxabs[(size_t)i] > 0.0) fexp[(size_t)i] = 53 - std::ilogb(maxabs[(size_t)i]);
+      wscale[(size_t)i] = std::ldexp(1.0, -fexp[(size_t)i]);
+    }
+    std::vector<int8_t> V8(n_chunks * (size_t)NT * 7 * 64 * 16, 0);
+    for (size_t c = 0; c < n_chunks; ++c)
+      for (int t = 0; t < 16; ++t)
+        for (int nt = 0; nt < NT; ++nt)
+          for (int ln = 0; ln < 64; ++ln) {
+            const size_t vi = ((c * 16 + (size_t)t) * NT + (size_t)nt) * 64 + (size_t)ln;
+            const int32_t wi = Vwin[vi];
+            if (wi < 0 || V[vi] == 0.0) continue;
+            long long q = std::llrint(std::ldexp(V[vi], fexp[(size_t)wi]));
+            for (int l = 0; l < 7; ++l) {
+              long long dg = (l < 6) ? ((((q + 128) % 256) + 256) % 256) - 128 : q;
+              V8[(((c * NT + (size_t)nt) * 7 + (size_t)l) * 64 + (size_t)ln) * 16 + (size_t)t] = (int8_t)dg;
+              q = (q - dg) / 256;
+            }
+          }
+    if ((rc = dev_upload(m, V8, &m->lr.V8, 64)) != GNX_OK) return rc;
+    if ((rc = dev_upload(m, wscale, &m->lr.wscale)) != GNX_OK) return rc;
+  } else if ((rc = dev_upload(m, V, &m->lr.V)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, icpt, &m->lr.icpt)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, chunk_j0, &m->lr.chunk_j0)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, chunk_flush0, &m->lr.chunk_flush0)) != GNX_OK) return rc;
@@ -551,7 +587,8 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
   L.W = (int32_t)m->info.W; L.A = m->info.A;
   L.b32 = d_b32; L.b64 = d_b64;
   ProfScope ps(ctx, GNX_K_BASE_LOGISTIC);
-  HIPCHK(ctx, gnx_launch_base_logistic(L, ctx->n_cu, ctx->stream));
+  if (m->lr_i8) HIPCHK(ctx, gnx_launch_base_logistic_i8(L, ctx->n_cu, ctx->stream));
+  else HIPCHK(ctx, gnx_launch_base_logistic(L, ctx->n_cu, ctx->stream));
   return GNX_OK;
 }
 

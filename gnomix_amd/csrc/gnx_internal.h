@@ -41,7 +41,9 @@ struct gnx_ctx {
 // The padded chromosome is processed in "pieces" that end exactly where a window ends, each piece in
 // chunks of 64 SNPs (one 16-byte load per lane).  Weights are stored in MFMA-fragment order.
 struct BaseLRDev {
-  const double* V = nullptr;        // [n_chunks][16 steps][NT][64 lanes]
+  const double* V = nullptr;        // f64 path: [n_chunks][16 steps][NT][64 lanes]
+  const int8_t* V8 = nullptr;       // i8 path: [n_chunks][NT][7 limbs][64 lanes][16 bytes] balanced base-256 digits
+  const double* wscale = nullptr;   // i8 path: [W] 2^-f_w
   const double* icpt = nullptr;     // [W][A]
   const int32_t* chunk_j0 = nullptr;     // [n_chunks] first real SNP of the chunk
   const int32_t* chunk_flush0 = nullptr; // [n_chunks] first window flushed after this chunk (-1 none)
@@ -59,6 +61,7 @@ struct BaseLRLaunch {
   int64_t N, ldx;
   BaseLRDev d;
   int32_t W, A, wch;    // wch = windows per block
+  int32_t n_htiles;     // i8 path: haplotype tiles (1-D XCD-aware grid)
   float* b32;
   double* b64;
 };
@@ -151,6 +154,7 @@ struct gnx_model {
   gnx_model_info info{};
   std::vector<void*> dev_allocs;
   BaseLRDev lr;
+  bool lr_i8 = true;
   SmoothXGBDev xgb;
   CovRSKDev svc;
   // class-major xgboost-schema copy for the rows kernel
@@ -162,6 +166,7 @@ struct gnx_model {
 
 // kernel launchers (defined in the .hip files)
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
+hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);

@@ -38,7 +38,14 @@ def _lr_data(ga, C, M, A, ctx, seed):
 
 
 # ---------------------------------------------------------------- logistic base ------------------
-def test_base_golden_G1(ga, oracle):
+@pytest.fixture(params=["i8", "f64"])
+def lr_impl(request, monkeypatch):
+    """both arithmetic variants of the logistic pass: exact int8-limb fixed point (default) and f64 MFMA"""
+    monkeypatch.setenv("GNX_BASE_LR_IMPL", request.param)
+    return request.param
+
+
+def test_base_golden_G1(ga, oracle, lr_impl):
     g = load_golden("G1_lr.npz")
     d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=int(g["A"]), S=5, context=int(g["ctx"]), base_kind="logistic",
                         lr_coef=g["coef"], lr_intercept=g["intercept"])
@@ -62,7 +69,7 @@ def test_base_golden_G1(ga, oracle):
     (1237, 50, 7, 25, 1),        # a single haplotype
     (937, 300, 4, 150, 66),      # W=3 windows only
 ])
-def test_base_vs_oracle(ga, oracle, C, M, A, ctx, N):
+def test_base_vs_oracle(ga, oracle, lr_impl, C, M, A, ctx, N):
     from gnomix_amd import synth
     d = _lr_data(ga, C, M, A, ctx, seed=C + A)
     X = synth.synthetic_X(N, C, seed=N, miss=0.03)
@@ -76,7 +83,7 @@ def test_base_vs_oracle(ga, oracle, C, M, A, ctx, N):
     assert np.allclose(b64.sum(-1), 1.0, atol=1e-12)
 
 
-def test_base_transpose_detecting(ga, oracle):
+def test_base_transpose_detecting(ga, oracle, lr_impl):
     """asymmetric weights + one-hot haplotypes: catches row/column swaps in the MFMA C/D mapping"""
     C, M, A, ctx = 1037, 100, 7, 50
     d = _lr_data(ga, C, M, A, ctx, seed=1)
