@@ -238,6 +238,11 @@ static int build_lr(gnx_model* m, const gnx_model_desc* d) {
   if ((rc = dev_upload(m, win_chunk0, &m->lr.win_chunk0)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, win_chunk1, &m->lr.win_chunk1)) != GNX_OK) return rc;
   m->lr.n_chunks = (int32_t)n_chunks;
+  {
+    int32_t mx = 1;
+    for (size_t k = 0; k < n_pieces; ++k) mx = std::max(mx, piece_chunk0[k + 1] - piece_chunk0[k]);
+    m->lr.max_piece_chunks = mx;
+  }
   m->lr.R = (int32_t)R;
   m->lr.NT = NT;
   return GNX_OK;
@@ -469,7 +474,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits})
+  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow})
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -580,9 +585,19 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     return GNX_OK;
   }
   if (m->info.base_kind != GNX_BASE_LOGISTIC) return fail(ctx, GNX_ESTATE, "model has no base classifier");
+  // the kernels fetch 16-byte pieces of 64-SNP chunks unconditionally: only the last row could read past X
+  {
+    const size_t need = (size_t)m->info.C + 128;
+    if (ctx->ws_lastrow.cap < need) {
+      int rc = ws_reserve(ctx, ctx->ws_lastrow, need);
+      if (rc != GNX_OK) return rc;
+      HIPCHK(ctx, hipMemsetAsync(ctx->ws_lastrow.p, 0, ctx->ws_lastrow.cap, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lastrow.p, dX + (N - 1) * ldx, (size_t)m->info.C, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   BaseLRLaunch L{};
   L.X = dX;
-  L.x_end = dX + (N - 1) * ldx + m->info.C;
+  L.last_row = (const int8_t*)ctx->ws_lastrow.p;
   L.N = N; L.ldx = ldx; L.d = m->lr;
   L.W = (int32_t)m->info.W; L.A = m->info.A;
   L.b32 = d_b32; L.b64 = d_b64;

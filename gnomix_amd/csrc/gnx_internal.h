@@ -28,7 +28,7 @@ struct gnx_ctx {
   std::string err;
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)
-  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits;
+  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -53,15 +53,19 @@ struct BaseLRDev {
   int32_t n_chunks = 0;
   int32_t R = 0;   // windows simultaneously active = column slots
   int32_t NT = 0;  // 16-column tiles
+  int32_t max_piece_chunks = 0;  // longest piece, in chunks
 };
 
 struct BaseLRLaunch {
   const int8_t* X;
-  const int8_t* x_end;  // one past the last readable byte of X
+  const int8_t* last_row;  // zero-padded (64 B) device copy of haplotype N-1: the only row whose tail reads could leave X
   int64_t N, ldx;
   BaseLRDev d;
   int32_t W, A, wch;    // wch = windows per block
   int32_t n_htiles;     // i8 path: haplotype tiles (1-D XCD-aware grid)
+  int32_t flags;        // development ablation switches (0 in production)
+  int32_t max_chunks;   // i8 path: upper bound of chunks one block walks (sizes its LDS tables)
+  int32_t max_wins;     // i8 path: upper bound of windows one block may flush
   float* b32;
   double* b64;
 };

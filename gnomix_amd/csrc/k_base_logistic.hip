@@ -26,15 +26,10 @@ struct __attribute__((packed, aligned(1))) xbytes16 { uint32_t v[4]; };
 
 constexpr int WAVES = 4;
 
-__device__ __forceinline__ xbytes16 load_x16(const int8_t* p, const int8_t* x_end) {
+__device__ __forceinline__ xbytes16 load_x16(const int8_t* p) {
+  // unconditional (unaligned) global_load_dwordx4; the last row is served from a zero-padded copy
   xbytes16 r;
-  if (__builtin_expect(p + 16 <= x_end, 1)) {
-    __builtin_memcpy(&r, p, 16);  // one (unaligned) global_load_dwordx4
-  } else {  // last bytes of the matrix: never read past the allocation
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0;
-    for (int b = 0; b < 16; ++b)
-      if (p + b < x_end) r.v[b >> 2] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
-  }
+  __builtin_memcpy(&r, p, 16);
   return r;
 }
 
@@ -60,9 +55,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic(BaseLRLaunch L) {
   const int8_t* xrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    int64_t n = n0 + mt * 16 + i16;
-    if (n > L.N - 1) n = L.N - 1;  // clamp: rows past N read valid memory, never written
-    xrow[mt] = L.X + n * L.ldx + 16 * kq;
+    const int64_t n = n0 + mt * 16 + i16;  // rows >= N-1 read the padded copy of the last row
+    xrow[mt] = (n >= L.N - 1 ? L.last_row : L.X + n * L.ldx) + 16 * kq;
   }
 
   d4 acc[MT][NT];
@@ -76,7 +70,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic(BaseLRLaunch L) {
   {
     const int j0 = L.d.chunk_j0[c_begin];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xn[mt] = load_x16(xrow[mt] + j0, L.x_end);
+    for (int mt = 0; mt < MT; ++mt) xn[mt] = load_x16(xrow[mt] + j0);
   }
 
   for (int c = c_begin; c < c_end; ++c) {
@@ -86,7 +80,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic(BaseLRLaunch L) {
     if (c + 1 < c_end) {
       const int j0n = L.d.chunk_j0[c + 1];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xn[mt] = load_x16(xrow[mt] + j0n, L.x_end);
+      for (int mt = 0; mt < MT; ++mt) xn[mt] = load_x16(xrow[mt] + j0n);
     }
     const double* vp = L.d.V + ((size_t)c * 16 * NT) * 64 + lane;
 #pragma unroll

@@ -17,6 +17,8 @@
 //    window; X streams HBM -> VGPR two chunks ahead; the epilogue needs no LDS (every lane owns whole
 //    logits; only the A-way normaliser crosses lanes, by a 16-lane butterfly).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "gnx_internal.h"
 
@@ -27,16 +29,12 @@ struct __attribute__((packed, aligned(1))) xbytes16 { v4i v; };
 
 constexpr int LIMBS = 7;
 
-__device__ __forceinline__ v4i load_x16(const int8_t* p, const int8_t* x_end) {
+__device__ __forceinline__ v4i load_x16(const int8_t* p) {
+  // one unconditional (unaligned) global_load_dwordx4: no branch, so consecutive loads stay in flight together.
+  // Reads may run up to 63 bytes past the end of a row: rows other than the last read their successor, the last
+  // row is served from a zero-padded copy (BaseLRLaunch::last_row), bytes past C only ever meet zero weights.
   xbytes16 r;
-  if (__builtin_expect(p + 16 <= x_end, 1)) {
-    __builtin_memcpy(&r, p, 16);
-  } else {
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (int b = 0; b < 16; ++b)
-      if (p + b < x_end) w[b >> 2] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
-    r.v = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-  }
+  __builtin_memcpy(&r, p, 16);
   return r.v;
 }
 
@@ -47,15 +45,70 @@ __device__ __forceinline__ double combine(const v4i (&acc)[LIMBS], int reg, doub
   return ((double)hi * 16777216.0 + (double)lo) * scale;
 }
 
-template <int MT, int NT, int WAVES>
+// MT 16-row tiles per wave, NT column tiles, WAVES waves per block; one pipeline step = 128 SNPs (2 chunks).
+//
+// X path: every thread fetches 16-byte pieces such that 8 consecutive lanes cover 128 contiguous bytes of ONE
+// haplotype row (whole cache lines instead of 16 rows x 64 B per wave instruction), parks them in VGPRs for
+// TWO compute phases (two register stages: enough bytes in flight to cover HBM latency), then writes them into
+// an LDS tile laid out
+//     slot(piece p, row r) = p*ROWS + (r ^ p)          (16 bytes per slot)
+// which is conflict-free both for the ds_write_b128 of the fetch layout (8 lanes = 8 pieces of one row) and for
+// the ds_read_b128 of the MFMA A-operand layout (lane&15 = row, lane>>4 = piece within the chunk).
+// workgroup barrier that orders LDS traffic only: __syncthreads() also carries a fence that makes hipcc drain the
+// outstanding global loads (s_waitcnt vmcnt(0)), which would serialise the HBM prefetch with every barrier
+#define GNX_LDS_BARRIER()                                   \
+  {                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+    asm volatile("" ::: "memory");                          \
+  }
+
+#define GNX_STAGE_LOAD(XS, VS, STEP)                                                                  \
+  {                                                                                                   \
+    const int st_ = min((STEP), n_steps - 1); /* clamped: tail iterations re-fetch the last step */ \
+    int cx_ = st_ * CPS + (fp >> 2);                                                                  \
+    if (cx_ > n_chunks - 1) cx_ = n_chunks - 1;                                                       \
+    const int j0_ = tab_j0[cx_];                                                                      \
+    _Pragma("unroll") for (int q = 0; q < XPT; ++q)                                                   \
+        XS[q] = load_x16(frow[q] + j0_);                 \
+    const int c0_ = c_begin + st_ * CPS;                                                              \
+    const int last_ = min(CPS, c_end - c0_) * (CHUNK_BYTES / 16) - 1;                                 \
+    const v4i* src_ = reinterpret_cast<const v4i*>(L.d.V8 + (size_t)c0_ * CHUNK_BYTES);           \
+    _Pragma("unroll") for (int v = 0; v < VPT; ++v) VS[v] = src_[min(v * THREADS + tid, last_)];      \
+  }
+
+#define GNX_STAGE_STORE(XS, VS, STEP)                                                                 \
+  {                                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < XPT; ++q) *reinterpret_cast<v4i*>(xt + fslot[q]) = XS[q];   \
+    v4i* dst_ = reinterpret_cast<v4i*>(vbuf + (size_t)((STEP) & 1) * STEP_BYTES);                 \
+    _Pragma("unroll") for (int v = 0; v < VPT; ++v) {                                                 \
+      const int e_ = v * THREADS + tid;                                                               \
+      if (e_ < STEP_BYTES / 16) dst_[e_] = VS[v];                                                     \
+    }                                                                                                 \
+  }
+
+template <int MT, int NT, int WAVES, int CPS>
 __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8(BaseLRLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t vlds[];
+  static_assert(CPS == 2, "a step is 2 chunks = 8 pieces of 16 SNPs");
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int CHUNK_BYTES = NT * LIMBS * 1024;  // digit planes of one 64-SNP chunk
+  constexpr int STEP_BYTES = CPS * CHUNK_BYTES;
   constexpr int THREADS = WAVES * 64;
-  constexpr int VPT = (CHUNK_BYTES / 16 + THREADS - 1) / THREADS;  // 16-byte pieces per thread
+  constexpr int ROWS = WAVES * MT * 16;           // haplotypes per block
+  constexpr int XT_BYTES = ROWS * 128;            // X tile of one step
+  constexpr int XPT = ROWS * 8 / THREADS;         // 16-byte X pieces per thread per step (= MT*2)
+  constexpr int VPT = (STEP_BYTES / 16 + THREADS - 1) / THREADS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   const int A = L.A, W = L.W, R = L.d.R;
+  uint8_t* xt = lds;                               // [8 pieces][ROWS] x 16 B, single buffer
+  uint8_t* vbuf = lds + XT_BYTES;                  // [2][STEP_BYTES]
+  double* zb = reinterpret_cast<double*>(vbuf + 2 * STEP_BYTES) + (size_t)wave * (MT * 16) * A;
+  double* tab_ic = reinterpret_cast<double*>(vbuf + 2 * STEP_BYTES) + (size_t)ROWS * A;  // [max_wins][A] intercepts
+  double* tab_sc = tab_ic + (size_t)L.max_wins * A;                                       // [max_wins] 2^-f_w
+  int* tab_j0 = reinterpret_cast<int*>(tab_sc + L.max_wins);
+  int* tab_nfl = tab_j0 + L.max_chunks;
+  int* tab_fl0 = tab_nfl + L.max_chunks;
 
   // XCD-aware decomposition: consecutive block ids go to consecutive XCDs, so give all blocks of one
   // window range to ONE XCD (its L2 then serves the range's weights to every haplotype tile)
@@ -71,14 +124,36 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8(BaseLRLaunch L)
   const int wb = min(W, wa + L.wch);
   const int c_begin = L.d.win_chunk0[wa];
   const int c_end = L.d.win_chunk1[wb - 1];
-  const int64_t n0 = ((int64_t)htile * WAVES + wave) * (MT * 16);
+  const int n_chunks = c_end - c_begin;
+  const int n_steps = (n_chunks + CPS - 1) / CPS;
+  const int64_t n0b = (int64_t)htile * ROWS;       // first haplotype of the block
+  const int64_t n0 = n0b + (int64_t)wave * (MT * 16);
 
-  const int8_t* xrow[MT];
+  // the block's slice of the chunk tables lives in LDS (no dependent global loads in the pipeline)
+  for (int e = tid; e < n_chunks; e += THREADS) {
+    tab_j0[e] = L.d.chunk_j0[c_begin + e];
+    tab_nfl[e] = L.d.chunk_nflush[c_begin + e];
+    tab_fl0[e] = L.d.chunk_flush0[c_begin + e];
+  }
+  // windows that can be flushed while walking [c_begin, c_end): from the first flush on, wch + R + 1 of them at most
+  const int wt0 = max(0, wa - R - 1);
+  for (int e = tid; e < L.max_wins; e += THREADS) {
+    const int w = min(wt0 + e, W - 1);
+    tab_sc[e] = L.d.wscale[w];
+    for (int a = 0; a < A; ++a) tab_ic[e * A + a] = L.d.icpt[w * A + a];
+  }
+  __syncthreads();
+
+  // fetch layout: piece = tid & 7 (16 SNPs), rows tid>>3, +THREADS/8, ...
+  const int fp = tid & 7;
+  const int8_t* frow[XPT];
+  int fslot[XPT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int64_t n = n0 + mt * 16 + i16;
-    if (n > L.N - 1) n = L.N - 1;
-    xrow[mt] = L.X + n * L.ldx + 16 * kq;
+  for (int q = 0; q < XPT; ++q) {
+    const int r = (tid >> 3) + q * (THREADS / 8);
+    const int64_t n = n0b + r;  // rows >= N-1 read the padded copy of the last row (rows past N are never written)
+    frow[q] = (n >= L.N - 1 ? L.last_row : L.X + n * L.ldx) + 16 * (fp & 3);
+    fslot[q] = (fp * ROWS + (r ^ fp)) * 16;
   }
 
   v4i acc[MT][NT][LIMBS];
@@ -89,135 +164,118 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8(BaseLRLaunch L)
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) acc[mt][nt][l] = v4i{0, 0, 0, 0};
 
-  // ---- pipeline prologue ----
-  uint4 vst[VPT];
-  auto v_load = [&](int c) {
-    const uint4* src = reinterpret_cast<const uint4*>(L.d.V8 + (size_t)c * CHUNK_BYTES);
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) {
-      const int e = v * THREADS + tid;
-      if (e < CHUNK_BYTES / 16) vst[v] = src[e];
-    }
-  };
-  auto v_store = [&](int buf) {
-    uint4* dst = reinterpret_cast<uint4*>(vlds + (size_t)buf * CHUNK_BYTES);
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) {
-      const int e = v * THREADS + tid;
-      if (e < CHUNK_BYTES / 16) dst[e] = vst[v];
-    }
-  };
-  v4i x0[MT], x1[MT];  // X of chunk c (x0) and c+1 (x1); c+2 is issued while c computes
-  {
-    const int j0 = L.d.chunk_j0[c_begin];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) x0[mt] = load_x16(xrow[mt] + j0, L.x_end);
-    if (c_begin + 1 < c_end) {
-      const int j1 = L.d.chunk_j0[c_begin + 1];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) x1[mt] = load_x16(xrow[mt] + j1, L.x_end);
-    }
-  }
-  v_load(c_begin);
-  v_store(0);
-  __syncthreads();
+  // two register stages: stage A holds even steps, stage B odd steps
+  v4i xsA[XPT], xsB[XPT];
+  v4i vsA[VPT], vsB[VPT];
 
-  for (int c = c_begin; c < c_end; ++c) {
-    const int buf = (c - c_begin) & 1;
-    v4i x2[MT];
-    if (c + 2 < c_end) {
-      const int j2 = L.d.chunk_j0[c + 2];
+  auto compute_step = [&](int s) {
+    const uint8_t* sb = vbuf + (size_t)(s & 1) * STEP_BYTES;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) x2[mt] = load_x16(xrow[mt] + j2, L.x_end);
-    }
-    if (c + 1 < c_end) v_load(c + 1);
-
-    const v4i* vb = reinterpret_cast<const v4i*>(vlds + (size_t)buf * CHUNK_BYTES) + lane;
+    for (int k = 0; k < CPS; ++k) {
+      const int cl = s * CPS + k;  // chunk index local to the block
+      if (cl >= n_chunks) break;
+      v4i xa[MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int l = 0; l < LIMBS; ++l) {
-        const v4i b = vb[(nt * LIMBS + l) * 64];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt][nt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(x0[mt], b, acc[mt][nt][l], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) {
+        const int r = wave * (MT * 16) + mt * 16 + i16;
+        const int pc = 4 * k + kq;
+        xa[mt] = *reinterpret_cast<const v4i*>(xt + (pc * ROWS + (r ^ pc)) * 16);
       }
-
-    // ---- piece end: windows that finished here ----
-    const int nfl = L.d.chunk_nflush[c];
-    if (nfl > 0) {
-      const int w0 = L.d.chunk_flush0[c];
-      for (int w = w0; w < w0 + nfl; ++w) {
-        const int cbase = (w % R) * A;
-        const bool emit = (w >= wa) && (w < wb);
-        const double scale = L.d.wscale[w];
+      const v4i* vb = reinterpret_cast<const v4i*>(sb + (size_t)k * CHUNK_BYTES) + lane;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          double p[NT][4];
-          double sum[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int col = nt * 16 + i16 - cbase;
-            const bool mine = (col >= 0) && (col < A);
-            const double ic = mine ? L.d.icpt[w * A + col] : 0.0;
+        for (int l = 0; l < LIMBS; ++l) {
+          const v4i b = vb[(nt * LIMBS + l) * 64];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const double z = combine(acc[mt][nt], r, scale) + ic;
-              p[nt][r] = (mine && emit) ? 1.0 / (1.0 + exp(-z)) : 0.0;
-              sum[r] += p[nt][r];
-            }
-#pragma unroll
-            for (int l = 0; l < LIMBS; ++l)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[mt][nt][l][r] = mine ? 0 : acc[mt][nt][l][r];
+          for (int mt = 0; mt < MT; ++mt) {
+            acc[mt][nt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][nt][l], 0, 0, 0);
           }
-          if (emit) {
-            // normaliser: sum over the A class lanes of this 16-lane row group (other lanes contribute 0)
+        }
+
+      // ---- piece end: windows that finished here (block-uniform) ----
+      const int nfl = tab_nfl[cl];
+      if (nfl > 0) {
+        const int w0 = tab_fl0[cl];
+        for (int w = w0; w < w0 + nfl; ++w) {
+          const int cbase = (w % R) * A;
+          const double scale = tab_sc[w - wt0];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              double s = sum[r];
-              s += __shfl_xor(s, 1, 64);
-              s += __shfl_xor(s, 2, 64);
-              s += __shfl_xor(s, 4, 64);
-              s += __shfl_xor(s, 8, 64);
-              sum[r] = s;
-            }
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               const int col = nt * 16 + i16 - cbase;
-              if (col >= 0 && col < A) {
+              const bool mine = (col >= 0) && (col < A);
+              if (mine) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  // int32 16x16 C/D layout: column = lane&15, row = 4*(lane>>4) + reg
-                  const int64_t n = n0 + mt * 16 + 4 * kq + r;
-                  if (n < L.N) {
-                    const double v = p[nt][r] / sum[r];
-                    const size_t o = ((size_t)n * W + w) * A + col;
-                    if (L.b64) L.b64[o] = v;
-                    if (L.b32) L.b32[o] = (float)v;
-                  }
-                }
+                for (int r = 0; r < 4; ++r)  // int32 16x16 C/D layout: column = lane&15, row = 4*(lane>>4) + reg
+                  zb[(mt * 16 + 4 * kq + r) * A + col] = combine(acc[mt][nt], r, scale);
+              }
+#pragma unroll
+              for (int l = 0; l < LIMBS; ++l)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][l][r] = mine ? 0 : acc[mt][nt][l][r];
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zb is wave-private: LDS ops of one wave complete in order
+          if (w >= wa && w < wb && lane < MT * 16) {
+            const int64_t n = n0 + lane;
+            double* z = zb + lane * A;
+            double sum = 0.0;
+            for (int a = 0; a < A; ++a) {
+              const double p = 1.0 / (1.0 + exp(-(z[a] + tab_ic[(w - wt0) * A + a])));
+              z[a] = p;
+              sum += p;
+            }
+            if (n < L.N) {
+              const size_t o = ((size_t)n * W + w) * A;
+              for (int a = 0; a < A; ++a) {
+                const double v = z[a] / sum;
+                if (L.b64) L.b64[o + a] = v;
+                if (L.b32) L.b32[o + a] = (float)v;
               }
             }
           }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
       }
     }
+  };
 
-    if (c + 1 < c_end) v_store(buf ^ 1);
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { x0[mt] = x1[mt]; x1[mt] = x2[mt]; }
+  // ---- prologue: step 0 into LDS, step 1 in flight in stage B ----
+  GNX_STAGE_LOAD(xsA, vsA, 0);
+  GNX_STAGE_STORE(xsA, vsA, 0);
+  GNX_STAGE_LOAD(xsB, vsB, 1);
+  __syncthreads();
+
+  for (int s = 0; s < n_steps; s += 2) {
+    // straight-line body (no branches around the memory operations: hipcc's waitcnt insertion stays counted)
+    // even step s: request s+2 into stage A (free: step s is already in LDS), compute, publish s+1 from stage B
+    GNX_STAGE_LOAD(xsA, vsA, s + 2);
+    compute_step(s);
+    GNX_LDS_BARRIER();  // every wave is done with the X tile and with plane buffer (s+1)&1's previous contents
+    GNX_STAGE_STORE(xsB, vsB, s + 1);
+    GNX_LDS_BARRIER();
+    // odd step s+1: request s+3 into stage B, compute, publish s+2 from stage A
+    GNX_STAGE_LOAD(xsB, vsB, s + 3);
+    compute_step(s + 1);  // no-op past the last chunk
+    GNX_LDS_BARRIER();
+    GNX_STAGE_STORE(xsA, vsA, s + 2);
+    GNX_LDS_BARRIER();
   }
 }
+#undef GNX_LDS_BARRIER
+#undef GNX_STAGE_LOAD
+#undef GNX_STAGE_STORE
 
-template <int MT, int NT, int WAVES>
+template <int MT, int NT, int WAVES, int CPS>
 hipError_t launch(const BaseLRLaunch& L, int n_cu, hipStream_t s) {
   BaseLRLaunch P = L;
   const int haps_per_block = WAVES * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
-  // window ranges: a multiple of 8 (one XCD each), ~2-3 blocks per CU in total
-  int64_t want = (3LL * n_cu + gx - 1) / gx;
+  // window ranges: a multiple of 8 (one XCD each), ~3 blocks per CU in total
+  int bpc = 3;
+  if (const char* t = std::getenv("GNX_LR_BPC")) bpc = std::max(1, std::atoi(t));
+  int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
   want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
   int wch = (int)((L.W + want - 1) / want);
   if (wch < 4) wch = 4;
@@ -225,21 +283,42 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, hipStream_t s) {
   const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
   P.wch = wch;
   P.n_htiles = (int)gx;
-  const size_t lds = (size_t)2 * NT * LIMBS * 1024;
-  hipLaunchKernelGGL((k_base_logistic_i8<MT, NT, WAVES>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
+  P.max_chunks = (wch + L.d.R + 2) * L.d.max_piece_chunks + 8;
+  P.max_wins = wch + 2 * L.d.R + 4;
+  const size_t lds = (size_t)WAVES * MT * 16 * 128 + (size_t)2 * CPS * NT * LIMBS * 1024 + (size_t)WAVES * MT * 16 * L.A * sizeof(double) +
+                     (size_t)3 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_logistic_i8<MT, NT, WAVES, CPS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_base_logistic_i8<MT, NT, WAVES, CPS>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
   return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, hipStream_t s) {
-  if (L.N <= 0) return hipSuccess;
+hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L0, int n_cu, hipStream_t s) {
+  if (L0.N <= 0) return hipSuccess;
+  BaseLRLaunch L = L0;
   const bool small = L.N <= 64 * 8;
+  // tuning / ablation knobs (development only): GNX_LR_TUNE="mt,waves,cps", GNX_LR_FLAGS=bitmask
+  int tm = 0, tw = 0, tc = 0;
+  if (const char* t = std::getenv("GNX_LR_TUNE")) std::sscanf(t, "%d,%d,%d", &tm, &tw, &tc);
+  if (const char* f = std::getenv("GNX_LR_FLAGS")) L.flags = std::atoi(f);
+  if (L.d.NT == 1 && tm) {
+    (void)tc;
+    if (tm == 1 && tw == 4) return launch<1, 1, 4, 2>(L, n_cu, s);
+    if (tm == 1 && tw == 8) return launch<1, 1, 8, 2>(L, n_cu, s);
+    if (tm == 1 && tw == 16) return launch<1, 1, 16, 2>(L, n_cu, s);
+    if (tm == 2 && tw == 4) return launch<2, 1, 4, 2>(L, n_cu, s);
+    if (tm == 2 && tw == 8) return launch<2, 1, 8, 2>(L, n_cu, s);
+    if (tm == 4 && tw == 4) return launch<4, 1, 4, 2>(L, n_cu, s);
+    if (tm == 4 && tw == 8) return launch<4, 1, 8, 2>(L, n_cu, s);
+    return hipErrorInvalidValue;
+  }
   switch (L.d.NT) {
-    case 1: return small ? launch<1, 1, 4>(L, n_cu, s) : launch<4, 1, 4>(L, n_cu, s);
-    case 2: return small ? launch<1, 2, 4>(L, n_cu, s) : launch<2, 2, 4>(L, n_cu, s);
-    case 3: return launch<1, 3, 4>(L, n_cu, s);
-    case 4: return launch<1, 4, 4>(L, n_cu, s);
+    case 1: return small ? launch<1, 1, 4, 2>(L, n_cu, s) : launch<2, 1, 8, 2>(L, n_cu, s);
+    case 2: return small ? launch<1, 2, 4, 2>(L, n_cu, s) : launch<2, 2, 4, 2>(L, n_cu, s);
+    case 3: return launch<1, 3, 4, 2>(L, n_cu, s);
+    case 4: return launch<1, 4, 4, 2>(L, n_cu, s);
     default: return hipErrorInvalidValue;
   }
 }
