@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-F64_MFMA_PEAK_TF = 78.6    # AMD public spec for MI355X FP64 matrix (not in the local guide)
+I8_MFMA_PEAK_TOPS = 3944.0 # MI355X_MICROARCH.md: int8 MFMA 16x16x64 measured ceiling (~2x bf16 dense)
+F64_MFMA_PEAK_TF = 78.6    # AMD public spec for MI355X FP64 matrix (only used when GNX_BASE_LR_IMPL=f64)
 
 
 def main():
@@ -99,13 +100,18 @@ def main():
     # algorithmic bytes per haplotype
     bytes_base = C + W * A * 4
     bytes_sm = 2 * W * A * 4 + W
-    flops_base = 2.0 * A * (data.M + 2 * data.context) * W
+    flops_base = 2.0 * A * (data.M + 2 * data.context) * W          # useful multiply-adds of the logits, as flops
+    lr_impl = os.environ.get("GNX_BASE_LR_IMPL", "i8")
+    # matrix-pipe work actually issued per haplotype by the exact int8 path: ~C/64 chunks x 7 digit planes x one
+    # 16x16x64 MFMA per 16 haplotypes
+    i8_ops = (C / 64.0) * 7 * (2 * 16 * 16 * 64) / 16.0
     node_steps = W * data.n_trees * 4
     kernels = {
         "k_base_logistic": {"avg_ms": avg_base * 1e3, "launches": n_base, "alg_GBps": bytes_base * N / avg_base / 1e9 if avg_base else None,
                             "hbm_frac": bytes_base * N / avg_base / 1e9 / HBM_PEAK_GBS if avg_base else None,
-                            "f64_TFLOPs": flops_base * N / avg_base / 1e12 if avg_base else None,
-                            "f64_mfma_frac": flops_base * N / avg_base / 1e12 / F64_MFMA_PEAK_TF if avg_base else None},
+                            "impl": lr_impl, "logit_TFLOPs_equiv": flops_base * N / avg_base / 1e12 if avg_base else None,
+                            "mfma_frac": (i8_ops * N / avg_base / 1e12 / I8_MFMA_PEAK_TOPS if lr_impl == "i8" else
+                                          flops_base * N / avg_base / 1e12 / F64_MFMA_PEAK_TF) if avg_base else None},
         "k_smooth_xgb": {"avg_ms": avg_sm * 1e3, "launches": n_sm, "alg_GBps": bytes_sm * N / avg_sm / 1e9 if avg_sm else None,
                          "hbm_frac": bytes_sm * N / avg_sm / 1e9 / HBM_PEAK_GBS if avg_sm else None,
                          "node_steps_per_s": node_steps * N / avg_sm if avg_sm else None},
@@ -123,16 +129,19 @@ def main():
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "note": "algorithmic bytes/launch = %d B/haplotype x %d haplotypes; the tree pass is LDS-gather/VALU bound "
-                        "(%.3g node-steps/s), the f64 logistic pass MFMA-f64 bound — see `kernels`" %
-                        (dom_bytes, N, kernels["k_smooth_xgb"]["node_steps_per_s"] or 0)}
+                "note": "algorithmic bytes/launch = %d B/haplotype x %d haplotypes (SURVEY.md 8d). The tree pass is LDS-gather "
+                        "bound (%.3g node-steps/s), not HBM bound; the logistic pass streams X once and is the HBM-bound "
+                        "kernel of the path: %.0f GB/s = %.1f%% of peak - see `kernels`" %
+                        (dom_bytes, N, kernels["k_smooth_xgb"]["node_steps_per_s"] or 0,
+                         kernels["k_base_logistic"]["alg_GBps"] or 0, 100 * (kernels["k_base_logistic"]["hbm_frac"] or 0))}
 
     hps = world * N * args.steps / dt
     res = {
         "metric": "haplotypes/sec (+ windows/sec) chr22 7-ancestry inference",
         "value": hps, "unit": "haplotypes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 (logistic base, MFMA) + f32 (tree smoother)", "data": "synthetic",
+        "dtype": "int8 x 7-digit fixed-point weights -> exact i32/i64 logits, f64 sigmoid (logistic base); f32 (tree smoother)",
+        "data": "synthetic",
         "config": {"workload": "configs[1]: chr22-like C=370500 M=1000 ctx=500 W=370 A=7 S=75, logistic base + xgb smoother "
                                "(100 rounds x 7 trees, depth<=4), %d synthetic haplotypes per GPU resident in HBM" % N,
                    "haplotypes_per_gpu": N, "sharding": "haplotypes across ranks, no data-path collective"},

@@ -260,31 +260,32 @@ static int tree_depth(const gnx_model_desc* d, int32_t o, int32_t nid, int32_t n
   return 1 + std::max(l, r);
 }
 
+// subtree rooted at xgboost node `nid` (or a replicated early leaf) -> heap slot j of the packed layout
 static void tree_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint8_t* out) {
-  const uint32_t n_int = (1u << D) - 1;
-  const bool leaf = (nid >= 0) && d->left[o + nid] == -1;
-  if (depth == D) {
-    float v = d->cond[o + nid];
-    std::memcpy(out + n_int * 8 + (j - (1u << D)) * 4, &v, 4);
+  const uint32_t half = 1u << (D - 1);
+  const bool leaf = d->left[o + nid] == -1;
+  const float inf = std::numeric_limits<float>::infinity();
+  if (depth == D - 1) {  // last split level: 16-byte node carrying both leaves
+    uint32_t foff = 0;
+    float thr = inf, ll, lr;
+    if (leaf) { ll = lr = d->cond[o + nid]; }  // early leaf: dummy split, both sides the leaf value
+    else {
+      foff = (uint32_t)d->feat[o + nid] * 4u;
+      thr = d->cond[o + nid];
+      ll = d->cond[o + d->left[o + nid]];
+      lr = d->cond[o + d->right[o + nid]];
+    }
+    uint8_t* p = out + (size_t)(j - half) * 16;
+    std::memcpy(p, &foff, 4); std::memcpy(p + 4, &thr, 4); std::memcpy(p + 8, &ll, 4); std::memcpy(p + 12, &lr, 4);
     return;
   }
-  uint32_t foff;
-  float thr;
-  if (leaf) {  // early leaf: dummy split that always goes left, both subtrees carry the leaf value
-    foff = 0;
-    thr = std::numeric_limits<float>::infinity();
-    std::memcpy(out + (j - 1) * 8, &foff, 4);
-    std::memcpy(out + (j - 1) * 8 + 4, &thr, 4);
-    tree_fill(d, o, nid, 2 * j, depth + 1, D, out);
-    tree_fill(d, o, nid, 2 * j + 1, depth + 1, D, out);
-  } else {
-    foff = (uint32_t)d->feat[o + nid] * 4u;
-    thr = d->cond[o + nid];
-    std::memcpy(out + (j - 1) * 8, &foff, 4);
-    std::memcpy(out + (j - 1) * 8 + 4, &thr, 4);
-    tree_fill(d, o, d->left[o + nid], 2 * j, depth + 1, D, out);
-    tree_fill(d, o, d->right[o + nid], 2 * j + 1, depth + 1, D, out);
-  }
+  uint32_t foff = 0;
+  float thr = inf;  // early leaf: always go left (f < +inf), both subtrees replicate the leaf
+  if (!leaf) { foff = (uint32_t)d->feat[o + nid] * 4u; thr = d->cond[o + nid]; }
+  uint8_t* p = out + (size_t)half * 16 + (size_t)(j - 1) * 8;
+  std::memcpy(p, &foff, 4); std::memcpy(p + 4, &thr, 4);
+  tree_fill(d, o, leaf ? nid : d->left[o + nid], 2 * j, depth + 1, D, out);
+  tree_fill(d, o, leaf ? nid : d->right[o + nid], 2 * j + 1, depth + 1, D, out);
 }
 
 static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
@@ -308,8 +309,8 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
         return fail(ctx, GNX_EINVAL, "xgb smoother: split feature outside the S*A sliding window");
   }
   if (D > 8) return fail(ctx, GNX_EUNSUPPORTED, "xgb smoother: tree depth > 8");
-  const int tree_bytes = (int)(((1u << D) - 1) * 8 + (1u << D) * 4);
-  const int G = std::max(1, std::min(25, 16384 / tree_bytes));
+  const int tree_bytes = gnx_tree_bytes(D);
+  const int G = std::max(1, std::min(24, 16384 / tree_bytes));
 
   std::vector<int32_t> order;
   order.reserve((size_t)d->n_trees);

@@ -71,9 +71,11 @@ struct BaseLRLaunch {
 };
 
 // ---- xgb smoother (k_smooth_xgb.hip) ----------------------------------------------------------------
-// Trees are re-ordered class-major and every tree is expanded to a complete binary tree of depth D:
-//   [ (2^D - 1) nodes {uint32 feature_byte_offset, float threshold} | 2^D float leaves ]
-// in heap order (children of 1-based node j are 2j, 2j+1; go right iff !(f < thr)).
+// Trees are re-ordered class-major and every tree is expanded to a complete binary tree of depth D >= 1,
+// heap order (children of 1-based node j are 2j, 2j+1; go right iff !(f < thr)):
+//   [ 2^(D-1) last-level nodes x 16 B {uint32 feature_byte_offset, float threshold, float leaf_left, float leaf_right}
+//   | 2^(D-1)-1 upper nodes x 8 B {uint32 feature_byte_offset, float threshold} | pad to 16 B ]
+// The last split and its two leaves arrive in ONE 16-byte read (192 B per tree at D=4).
 struct SmoothXGBDev {
   const uint8_t* packed = nullptr;   // n_trees * tree_bytes
   const int32_t* group_tree0 = nullptr;  // [n_groups+1] first tree of each staging group
@@ -81,6 +83,31 @@ struct SmoothXGBDev {
   int32_t n_groups = 0, n_trees = 0, D = 0, tree_bytes = 0, max_group = 0;
   float base_score = 0.5f;
 };
+
+static inline int gnx_tree_bytes(int D) {
+  const int half = 1 << (D - 1);
+  return ((half * 16 + (half - 1) * 8) + 15) & ~15;
+}
+
+#if defined(__HIPCC__)
+// generic-pointer walker (global or LDS tree, global or LDS feature row); row is indexed in BYTES by the node
+__device__ __forceinline__ float gnx_walk(const uint8_t* tb, const uint8_t* row, int D) {
+  const uint32_t half = 1u << (D - 1);
+  uint32_t j = 1;
+  for (int d = 0; d < D - 1; ++d) {
+    uint2 nd;
+    __builtin_memcpy(&nd, tb + half * 16 + (j - 1) * 8, 8);
+    float fv;
+    __builtin_memcpy(&fv, row + nd.x, 4);
+    j = 2 * j + ((fv < __uint_as_float(nd.y)) ? 0u : 1u);
+  }
+  uint4 n4;
+  __builtin_memcpy(&n4, tb + (j - half) * 16, 16);
+  float fv;
+  __builtin_memcpy(&fv, row + n4.x, 4);
+  return (fv < __uint_as_float(n4.y)) ? __uint_as_float(n4.z) : __uint_as_float(n4.w);
+}
+#endif
 
 struct SmoothXGBLaunch {
   const void* B;     // (N, W, A) float32 or float64

@@ -29,19 +29,6 @@ __device__ __forceinline__ int slide_src(int j, int W, int pad) {
   return W - 1 - (j - pad - W);
 }
 
-__device__ __forceinline__ float walk_g(const uint8_t* tb, const float* row, int D) {
-  uint32_t j = 1;
-  for (int d = 0; d < D; ++d) {
-    uint2 nd;
-    __builtin_memcpy(&nd, tb + (j - 1) * 8, 8);
-    const float fv = row[nd.x >> 2];
-    j = 2 * j + ((fv < __uint_as_float(nd.y)) ? 0u : 1u);
-  }
-  float leaf;
-  __builtin_memcpy(&leaf, tb + ((1u << D) - 1) * 8 + (j - (1u << D)) * 4, 4);
-  return leaf;
-}
-
 __device__ __forceinline__ void softmax_row(float* m, int A) {  // xgboost Softmax, in place
   float wmax = m[0];
   for (int a = 1; a < A; ++a) wmax = fmaxf(m[a], wmax);
@@ -132,7 +119,7 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
       for (int e = tid; e < 4 * NT; e += THREADS) {
         const int r = e & 3, t = e >> 2;
         const float* row = (r < 2) ? (bp + ((size_t)r * Wp + pad + lo) * A) : (swrows + (size_t)(r - 2) * F);
-        leafbuf[(size_t)r * NT + t] = walk_g(L.d.packed + (size_t)t * L.d.tree_bytes, row, D);
+        leafbuf[(size_t)r * NT + t] = gnx_walk(L.d.packed + (size_t)t * L.d.tree_bytes, reinterpret_cast<const uint8_t*>(row), D);
       }
       __syncthreads();
       if (tid < 4 * A) {  // per (row, class): in-order float32 sum of that class's trees (class-major packing)
@@ -212,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
           const float* row = row_ptr(h, relist[k]);
           float ps = 0.f;
           for (int t = L.class_tree0[c]; t < L.class_tree0[c + 1]; ++t)
-            ps += walk_g(L.d.packed + (size_t)t * L.d.tree_bytes, row, D);
+            ps += gnx_walk(L.d.packed + (size_t)t * L.d.tree_bytes, reinterpret_cast<const uint8_t*>(row), D);
           marg[rr * A + c] = L.d.base_score + ps;
         }
         __syncthreads();

@@ -19,12 +19,14 @@
 //    the order of the restated xgboost predictor; margins are parked in the output buffer, then
 //    one softmax/argmax pass (expf evaluated as float(exp(double)), which agrees with glibc's
 //    correctly-rounded expf).
+#include <cstdio>
+#include <cstdlib>
+
 #include "gnx_internal.h"
 
 namespace {
 
-constexpr int THREADS = 256;
-constexpr int WS = 64;  // windows per strip = one wave width
+constexpr int WS = 64;  // windows per segment = one wave width
 
 __device__ __forceinline__ int slide_src(int j, int W, int pad) {
   // reflect padding of slide_window (src/Smooth/utils.py:14-17)
@@ -35,49 +37,43 @@ __device__ __forceinline__ int slide_src(int j, int W, int pad) {
 
 template <int D>
 __device__ __forceinline__ float walk(const uint8_t* tb, const uint8_t* rowbase) {
+  constexpr uint32_t half = 1u << (D - 1);
   uint32_t j = 1;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const uint2 nd = *reinterpret_cast<const uint2*>(tb + (j - 1) * 8);
+  for (int d = 0; d < D - 1; ++d) {
+    const uint2 nd = *reinterpret_cast<const uint2*>(tb + half * 16 + (j - 1) * 8);
     const float fv = *reinterpret_cast<const float*>(rowbase + nd.x);
     j = 2 * j + ((fv < __uint_as_float(nd.y)) ? 0u : 1u);
   }
-  return *reinterpret_cast<const float*>(tb + ((1u << D) - 1) * 8 + (j - (1u << D)) * 4);
+  const uint4 n4 = *reinterpret_cast<const uint4*>(tb + (j - half) * 16);  // last split + both leaves in one read
+  const float fv = *reinterpret_cast<const float*>(rowbase + n4.x);
+  return (fv < __uint_as_float(n4.y)) ? __uint_as_float(n4.z) : __uint_as_float(n4.w);
 }
 
-__device__ __forceinline__ float walk_rt(const uint8_t* tb, const uint8_t* rowbase, int D) {
-  uint32_t j = 1;
-  for (int d = 0; d < D; ++d) {
-    const uint2 nd = *reinterpret_cast<const uint2*>(tb + (j - 1) * 8);
-    const float fv = *reinterpret_cast<const float*>(rowbase + nd.x);
-    j = 2 * j + ((fv < __uint_as_float(nd.y)) ? 0u : 1u);
-  }
-  return *reinterpret_cast<const float*>(tb + ((1u << D) - 1) * 8 + (j - (1u << D)) * 4);
-}
-
-// RPL rows per lane; DT = compile-time depth (0 = runtime)
-template <int RPL, int DT>
-__global__ __launch_bounds__(THREADS) void k_smooth_xgb(SmoothXGBLaunch L) {
+// One wave = one haplotype x RPL consecutive 64-window segments (RPL rows per lane, all on the same LDS strip);
+// NWAVE haplotypes per block.  DT = compile-time depth (0 = runtime).
+template <int RPL, int NWAVE, int DT>
+__global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb(SmoothXGBLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int THREADS = NWAVE * 64;
   const int A = L.A, W = L.W, S = L.S, pad = (S + 1) / 2;
   const int D = DT ? DT : L.d.D;
   const int tree_bytes = L.d.tree_bytes;
-  constexpr int HPB = (THREADS / 64) * RPL;      // haplotypes per block
-  const int strip_w = WS + S - 1;                // padded windows held per haplotype
+  const int strip_w = RPL * WS + S - 1;          // padded windows held per haplotype
   const int strip_bytes = strip_w * A * 4;
-  const int buf_bytes = (L.d.max_group * tree_bytes + 15) & ~15;
-  uint8_t* strip = lds;                          // [HPB][strip_w][A] float
-  uint8_t* tbuf0 = lds + (((size_t)HPB * strip_bytes + 15) & ~(size_t)15);
+  const int buf_bytes = L.d.max_group * tree_bytes;  // multiple of 16
+  uint8_t* strip = lds;                          // [NWAVE][strip_w][A] float
+  uint8_t* tbuf0 = lds + (((size_t)NWAVE * strip_bytes + 15) & ~(size_t)15);
   uint8_t* tbuf1 = tbuf0 + buf_bytes;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t h0 = (int64_t)blockIdx.y * HPB;
-  const int w0 = blockIdx.x * WS;
+  const int64_t h0 = (int64_t)blockIdx.y * NWAVE;
+  const int w0 = blockIdx.x * (RPL * WS);
 
   // ---- stage the reflected base-probability strips ----
   {
     const int per_h = strip_w * A;
-    for (int e = tid; e < HPB * per_h; e += THREADS) {
+    for (int e = tid; e < NWAVE * per_h; e += THREADS) {
       const int hl = e / per_h, r = e - hl * per_h;
       const int q = r / A, a = r - q * A;
       const int64_t n = h0 + hl;
@@ -91,60 +87,53 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xgb(SmoothXGBLaunch L) {
     }
   }
 
+  const int64_t n = h0 + wave;
   const uint8_t* rowbase[RPL];
   bool valid[RPL];
   size_t orow[RPL];
 #pragma unroll
   for (int k = 0; k < RPL; ++k) {
-    const int hl = wave * RPL + k;
-    rowbase[k] = strip + (size_t)hl * strip_bytes + (size_t)lane * A * 4;
-    const int64_t n = h0 + hl;
-    const int w = w0 + lane;
+    rowbase[k] = strip + (size_t)wave * strip_bytes + (size_t)(k * WS + lane) * A * 4;
+    const int w = w0 + k * WS + lane;
     valid[k] = (n < L.N) && (w < W);
     orow[k] = ((size_t)(valid[k] ? n : 0) * W + (valid[k] ? w : 0)) * A;
   }
 
   // ---- tree groups through the double-buffered LDS window ----
   const int ng = L.d.n_groups;
-  constexpr int MAXV = 4;  // uint4 staging registers per thread (>= ceil(buf_bytes / (THREADS*16)))
+  constexpr int MAXV = (16384 / 16 + THREADS - 1) / THREADS;  // 16-byte staging pieces per thread (buf <= 16 KB)
   uint4 stg[MAXV];
-  auto g_load = [&](int g) {
-    const int t0 = L.d.group_tree0[g], t1 = L.d.group_tree0[g + 1];
-    const int nbytes = (t1 - t0) * tree_bytes;  // tree_bytes is a multiple of 8; packed is 16-aligned + padded
-    const uint4* src = reinterpret_cast<const uint4*>(L.d.packed + (size_t)t0 * tree_bytes);
-    const bool al16 = ((((size_t)t0 * tree_bytes) & 15) == 0);
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int off = (v * THREADS + tid) * 16;
-      if (off < nbytes) {
-        if (al16) stg[v] = src[v * THREADS + tid];
-        else __builtin_memcpy(&stg[v], reinterpret_cast<const uint8_t*>(src) + off, 16);
-      }
-    }
-  };
-  auto g_store = [&](int g, uint8_t* dst) {
-    const int t0 = L.d.group_tree0[g], t1 = L.d.group_tree0[g + 1];
-    const int nbytes = (t1 - t0) * tree_bytes;
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int off = (v * THREADS + tid) * 16;
-      if (off < nbytes) *reinterpret_cast<uint4*>(dst + off) = stg[v];
-    }
-  };
+  const int nv = (buf_bytes / 16 + THREADS - 1) / THREADS;
+  // unconditional clamped loads: no branch around a load, so hipcc keeps its waits counted
+#define GNX_G_LOAD(g)                                                                               \
+  {                                                                                                 \
+    const int t0_ = L.d.group_tree0[g], t1_ = L.d.group_tree0[(g) + 1];                             \
+    const int last_ = (t1_ - t0_) * tree_bytes / 16 - 1;                                            \
+    const uint4* src_ = reinterpret_cast<const uint4*>(L.d.packed + (size_t)t0_ * tree_bytes);      \
+    _Pragma("unroll") for (int v = 0; v < MAXV; ++v) if (v < nv) stg[v] = src_[min(v * THREADS + tid, last_)]; \
+  }
+#define GNX_G_STORE(dst)                                                                            \
+  {                                                                                                 \
+    _Pragma("unroll") for (int v = 0; v < MAXV; ++v) {                                              \
+      const int e_ = v * THREADS + tid;                                                             \
+      if (v < nv && e_ * 16 < buf_bytes) *reinterpret_cast<uint4*>((dst) + (size_t)e_ * 16) = stg[v]; \
+    }                                                                                               \
+  }
 
   float psum[RPL];
 #pragma unroll
   for (int k = 0; k < RPL; ++k) psum[k] = 0.f;
 
-  g_load(0);
-  g_store(0, tbuf0);
+  GNX_G_LOAD(0);
+  GNX_G_STORE(tbuf0);
   __syncthreads();
 
   int cur_class = L.d.group_class[0];
   for (int g = 0; g < ng; ++g) {
     uint8_t* cur = (g & 1) ? tbuf1 : tbuf0;
     uint8_t* nxt = (g & 1) ? tbuf0 : tbuf1;
-    if (g + 1 < ng) g_load(g + 1);
+    const int gn = min(g + 1, ng - 1);  // clamped: the last iteration re-fetches its own group
+    GNX_G_LOAD(gn);
 
     const int cls = L.d.group_class[g];
     if (cls != cur_class) {  // class finished: park its margin (base_score + psum)
@@ -162,13 +151,15 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xgb(SmoothXGBLaunch L) {
       for (int k = 0; k < RPL; ++k) {
         float leaf;
         if constexpr (DT > 0) leaf = walk<DT>(tb, rowbase[k]);
-        else leaf = walk_rt(tb, rowbase[k], D);
+        else leaf = gnx_walk(tb, rowbase[k], D);
         psum[k] += leaf;
       }
     }
-    if (g + 1 < ng) g_store(g + 1, nxt);
+    GNX_G_STORE(nxt);
     __syncthreads();
   }
+#undef GNX_G_LOAD
+#undef GNX_G_STORE
 #pragma unroll
   for (int k = 0; k < RPL; ++k)
     if (valid[k]) L.proba[orow[k] + cur_class] = L.d.base_score + psum[k];
@@ -217,19 +208,8 @@ __global__ __launch_bounds__(256) void k_smooth_rows(SmoothXGBDev d, const float
     const uint8_t* rb = reinterpret_cast<const uint8_t*>(feats + rl * F);
     for (int g = 0; g < d.n_groups; ++g) {
       if (d.group_class[g] != cls) continue;
-      for (int t = d.group_tree0[g]; t < d.group_tree0[g + 1]; ++t) {
-        const uint8_t* tb = d.packed + (size_t)t * d.tree_bytes;
-        uint32_t j = 1;
-        for (int dd = 0; dd < d.D; ++dd) {
-          uint2 nd;
-          __builtin_memcpy(&nd, tb + (j - 1) * 8, 8);
-          const float fv = *reinterpret_cast<const float*>(rb + nd.x);
-          j = 2 * j + ((fv < __uint_as_float(nd.y)) ? 0u : 1u);
-        }
-        float leaf;
-        __builtin_memcpy(&leaf, tb + ((1u << d.D) - 1) * 8 + (j - (1u << d.D)) * 4, 4);
-        psum += leaf;
-      }
+      for (int t = d.group_tree0[g]; t < d.group_tree0[g + 1]; ++t)
+        psum += gnx_walk(d.packed + (size_t)t * d.tree_bytes, rb, d.D);
     }
     marg[rl * A + cls] = d.base_score + psum;
   }
@@ -245,38 +225,53 @@ __global__ __launch_bounds__(256) void k_smooth_rows(SmoothXGBDev d, const float
   }
 }
 
-template <int RPL>
+template <int RPL, int NWAVE>
 size_t lds_bytes(const SmoothXGBDev& d, int A, int S) {
-  const size_t strip = (size_t)(THREADS / 64) * RPL * (WS + S - 1) * A * 4;
-  const size_t buf = ((size_t)d.max_group * d.tree_bytes + 15) & ~(size_t)15;
-  return ((strip + 15) & ~(size_t)15) + 2 * buf;
+  const size_t strip = (size_t)NWAVE * (RPL * WS + S - 1) * A * 4;
+  return ((strip + 15) & ~(size_t)15) + 2 * (size_t)d.max_group * d.tree_bytes;
 }
 
-template <int RPL>
+template <int RPL, int NWAVE>
 hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
-  constexpr int HPB = (THREADS / 64) * RPL;
-  const dim3 grid((unsigned)((L.W + WS - 1) / WS), (unsigned)((L.N + HPB - 1) / HPB));
-  const size_t lds = lds_bytes<RPL>(L.d, L.A, L.S);
+  const dim3 grid((unsigned)((L.W + RPL * WS - 1) / (RPL * WS)), (unsigned)((L.N + NWAVE - 1) / NWAVE));
+  const size_t lds = lds_bytes<RPL, NWAVE>(L.d, L.A, L.S);
   if (L.d.D == 4) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb<RPL, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_smooth_xgb<RPL, 4>), grid, dim3(THREADS), lds, s, L);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb<RPL, NWAVE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_smooth_xgb<RPL, NWAVE, 4>), grid, dim3(NWAVE * 64), lds, s, L);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb<RPL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_smooth_xgb<RPL, 0>), grid, dim3(THREADS), lds, s, L);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb<RPL, NWAVE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_smooth_xgb<RPL, NWAVE, 0>), grid, dim3(NWAVE * 64), lds, s, L);
   }
   return hipGetLastError();
 }
 
 }  // namespace
 
-size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S) { return lds_bytes<4>(d, A, S); }
+size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S) { return lds_bytes<1, 1>(d, A, S); }
 
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, int /*n_cu*/, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
-  // 4 rows per lane (16 haplotypes x 64 windows per block) unless that does not fit LDS or N is tiny
-  if (L.N >= 16 && lds_bytes<4>(L.d, L.A, L.S) <= 80 * 1024) return launch<4>(L, s);
-  if (L.N >= 8 && lds_bytes<2>(L.d, L.A, L.S) <= 80 * 1024) return launch<2>(L, s);
-  if (lds_bytes<1>(L.d, L.A, L.S) <= 160 * 1024) return launch<1>(L, s);
+  // rows per lane = 64-window segments one wave walks on its haplotype's strip; more segments per strip = less halo
+  // and more independent chains per lane, bounded by LDS (want >= 2-3 blocks per CU)
+  const int nseg = (L.W + WS - 1) / WS;
+  int rpl = 0, nw = 0;
+  if (const char* t = std::getenv("GNX_SM_TUNE")) std::sscanf(t, "%d,%d", &rpl, &nw);
+  if (!rpl) {
+    // measured on chr22 (W=370, A=7, 700 trees): 3 segments x 4 waves is the sweet spot (2.07 ms / 10k haplotypes);
+    // 6-8 segments per lane lose to LDS/issue pressure, 1 segment pays 2.2x halo
+    rpl = nseg >= 3 ? 3 : nseg;
+    nw = 4;
+    auto fits = [&](int r, int w) {
+      return (size_t)w * (r * WS + L.S - 1) * L.A * 4 + 2 * (size_t)L.d.max_group * L.d.tree_bytes + 64 <= 80 * 1024;
+    };
+    while (!fits(rpl, nw) && nw > 1) nw = (nw == 4) ? 3 : nw - 1;
+    while (!fits(rpl, nw) && rpl > 1) --rpl;
+    if (nw == 2 && rpl == 3) nw = 1;  // not instantiated
+  }
+#define GNX_SM_CASE(R_, W_) if (rpl == R_ && nw == W_) return launch<R_, W_>(L, s);
+  GNX_SM_CASE(3, 4) GNX_SM_CASE(3, 3) GNX_SM_CASE(3, 1) GNX_SM_CASE(2, 4) GNX_SM_CASE(2, 3) GNX_SM_CASE(2, 2) GNX_SM_CASE(2, 1)
+  GNX_SM_CASE(1, 4) GNX_SM_CASE(1, 3) GNX_SM_CASE(1, 2) GNX_SM_CASE(1, 1) GNX_SM_CASE(4, 4) GNX_SM_CASE(6, 4)
+#undef GNX_SM_CASE
   return hipErrorInvalidValue;
 }
 
