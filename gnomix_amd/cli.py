@@ -1,0 +1,111 @@
+"""Command-line surface of the reference's pre-trained mode (gnomix.py:318-355, 359-370, 404-412):
+
+    python -m gnomix_amd <query_file> <output_basename> <chr_nr> <phase> <path_to_model>
+
+`path_to_model` is a flat `.gnx` model (gnomix_amd.GnxModelData.save) or a reference `model.pkl[.gz]`
+(unpickling one needs what the pickle needs — sklearn, xgboost and the reference's `src` package on sys.path —
+and goes through gnomix_amd.convert.from_reference_model).  Training mode (7-8 arguments) is out of scope.
+Outputs: <output_basename>/query_results.msp, .fb (+ .lai, query_results_bed/, query_file_phased.vcf as configured).
+"""
+from __future__ import annotations
+
+import gzip
+import os
+import pickle
+import sys
+
+import numpy as np
+
+USAGE = ("Usage when using a pre-trained model:\n"
+         "   $ python3 gnomix.py <query_file> <output_basename> <chr_nr> <phase> <path_to_model>\n"
+         "(training a model from scratch is not part of the MI355X inference path; train with the reference and export)")
+
+
+def load_model(path_to_model, device=0, verbose=True):
+    """gnomix.py:26-35 — .gnx directly, .pkl / .pkl.gz through the converter"""
+    from .gnomix import HipGnomix
+    from .model import GnxModelData
+    if verbose:
+        print("Loading model...")
+    if path_to_model.endswith(".gnx"):
+        return HipGnomix(GnxModelData.load(path_to_model), device=device)
+    from .convert import from_reference_model
+    opener = gzip.open if path_to_model.endswith(".gz") else open
+    with opener(path_to_model, "rb") as f:
+        ref_model = pickle.load(f)
+    return HipGnomix(from_reference_model(ref_model), device=device)
+
+
+def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False):
+    """gnomix.py:37-100 with the HIP model behind the same calls"""
+    from . import postprocess as pp
+    from . import vcfio
+    query_file, chm, output_path = base_args["query_file"], base_args["chm"], base_args["output_basename"]
+    if verbose:
+        print("Loading and processing query file...")
+    vcf = vcfio.read_vcf(query_file, chm=chm)
+    X, vcf_idx, fmt_idx = vcfio.vcf_to_npy(vcf, model.snp_pos, model.snp_ref, return_idx=True, verbose=verbose)
+    if verbose:
+        print("Inferring ancestry on query data...")
+    B = model.base.predict_proba(X)
+    if not base_args["phase"]:
+        proba = model.smooth.predict_proba(B)
+        labels = np.argmax(proba, axis=-1)
+    else:
+        X_phased, labels = model.phase(X, B=B)
+        if verbose:
+            print("Writing phased SNPs to disk...")
+        upd = {"variants/REF": np.asarray(model.snp_ref)[fmt_idx],
+               "variants/ALT": np.asarray(model.snp_alt)[fmt_idx].reshape(len(fmt_idx), 1)}
+        vcf_ph = vcfio.update_vcf(vcf, mask=vcf_idx, Updates=upd)
+        vcfio.npy_to_vcf(vcf_ph, X_phased[:, fmt_idx], output_path + "/" + "query_file_phased",
+                         headers=vcfio.read_headers(query_file))
+        proba = model.predict_proba(X_phased)
+    if verbose:
+        print("Saving results...")
+    gm_pos, gm_cm = model.data.gen_map_pos, model.data.gen_map_cm
+    meta = pp.get_meta_data(chm, model.snp_pos, vcf["variants/POS"], model.W, model.M, gm_pos, gm_cm)
+    out_prefix = output_path + "/" + "query_results"
+    pp.write_msp(out_prefix, meta, labels, model.population_order, vcf["samples"])
+    pp.write_fb(out_prefix, meta, proba, model.population_order, vcf["samples"])
+    if snp_level:
+        pp.msp_to_lai(out_prefix + ".msp", vcf["variants/POS"], out_prefix + ".lai")
+    if bed_file_output:
+        pp.msp_to_bed(out_prefix + ".msp", output_path + "/" + "query_results_bed", pop_order=model.population_order)
+    return out_prefix
+
+
+def main(argv=None):
+    argv = list(sys.argv if argv is None else argv)
+    if len(argv) in (8, 9):
+        print("Training mode is not part of this build.\n" + USAGE)
+        return 2
+    if len(argv) != 6:
+        if len(argv) > 1:
+            print("Error: Incorrect number of arguments.")
+        print(USAGE)
+        return 0
+    base_args = {"mode": "pre-trained", "query_file": argv[1] if argv[1].strip() != "None" else None,
+                 "output_basename": argv[2], "chm": argv[3], "phase": argv[4].lower() == "true", "path_to_model": argv[5]}
+    os.makedirs(base_args["output_basename"], exist_ok=True)
+    config = {"model": {}, "inference": {}}
+    if os.path.exists("./config.yaml"):
+        import yaml
+        with open("./config.yaml") as f:
+            config = yaml.safe_load(f) or config
+    print("Launching in pre-trained mode...")
+    model = load_model(base_args["path_to_model"])
+    model.n_cores = (config.get("model") or {}).get("n_cores")            # gnomix.py:365-367
+    model.calibrate = (config.get("model") or {}).get("calibrate")
+    model.smooth.calibrate = model.calibrate
+    model.base.vectorize = True                                           # gnomix.py:370
+    if base_args["query_file"]:
+        print("Launching inference...")
+        inf = config.get("inference") or {}
+        run_inference(base_args, model, snp_level=bool(inf.get("snp_level_inference")),
+                      bed_file_output=bool(inf.get("bed_file_output")), verbose=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,133 @@
+"""Writers on the output side of the hot path: window metadata, .msp, .fb (+ .lai, .bed).
+
+Mirrors the reference's src/postprocess.py:25-210 byte for byte (pinned by tests/golden/G6_writers, produced by
+running the reference's own get_meta_data / write_msp / write_fb).  numpy only; no pandas needed."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def _fmt(v):
+    """str() of a numpy scalar the way `np.array([...mixed...]).astype(str)` / pandas print it: shortest repr"""
+    if isinstance(v, (np.floating, float)):
+        return str(np.float64(v)) if not isinstance(v, np.float32) else str(v)
+    return str(v)
+
+
+def get_meta_data(chm, model_pos, query_pos, n_wind, wind_size, gen_map_pos, gen_map_cm):
+    """Window table of the .msp/.fb files (postprocess.py:25-67): columns chm, spos, epos, sgpos, egpos, "n snps".
+    Returns a dict of equal-length lists/arrays (a stand-in for the reference's DataFrame)."""
+    model_pos = np.asarray(model_pos)
+    query_pos = np.asarray(query_pos)
+    C = len(model_pos)
+    idx = np.arange(0, C, wind_size)
+    spos_idx = idx[:-1]
+    epos_idx = np.concatenate([idx[1:-1], np.array([C])]) - 1
+    spos, epos = model_pos[spos_idx], model_pos[epos_idx]
+    gpos = np.asarray(gen_map_pos, dtype=float)
+    gcm = np.asarray(gen_map_cm, dtype=float)
+
+    def interp(x):  # linear interpolation, ends clamped to the first/last cM (interp1d(fill_value=end_pts))
+        x = np.asarray(x, dtype=float)
+        k = np.clip(np.searchsorted(gpos, x, side="left"), 1, len(gpos) - 1)  # interp1d: x_new in (x[k-1], x[k]]
+        lo, hi = k - 1, k
+        slope = (gcm[hi] - gcm[lo]) / (gpos[hi] - gpos[lo])
+        y = slope * (x - gpos[lo]) + gcm[lo]
+        y = np.where(x < gpos[0], gcm[0], y)
+        y = np.where(x > gpos[-1], gcm[-1], y)
+        return y
+
+    sgpos = np.round(interp(spos), 5)
+    egpos = np.round(interp(epos), 5)
+    n_snps = np.zeros_like(epos)
+    q = 0
+    for w in range(n_wind - 1):
+        while q < len(query_pos) and query_pos[q] <= epos[w]:
+            n_snps[w] += 1
+            q += 1
+    n_snps[n_wind - 1] = len(query_pos) - q
+    return {"chm": [chm] * n_wind, "spos": spos, "epos": epos, "sgpos": sgpos, "egpos": egpos, "n snps": n_snps}
+
+
+META_COLUMNS = ["chm", "spos", "epos", "sgpos", "egpos", "n snps"]
+
+
+def _meta_strings(meta):
+    n = len(meta["spos"])
+    return [[_fmt(meta[c][i]) for c in META_COLUMNS] for i in range(n)]
+
+
+def write_msp(msp_prefix, meta_data, pred_labels, populations, query_samples):
+    """<prefix>.msp (postprocess.py:84-98): pred_labels (N, W) ints, haplotype columns sample.0 / sample.1"""
+    rows = _meta_strings(meta_data)
+    lab = np.asarray(pred_labels)
+    with open(msp_prefix + ".msp", "w") as f:
+        f.write("#Subpopulation order/codes: ")
+        f.write("\t".join([str(pop) + "=" + str(i) for i, pop in enumerate(populations)]) + "\n")
+        f.write("#" + "\t".join(META_COLUMNS) + "\t")
+        f.write("\t".join([str(s) for q in query_samples for s in (str(q) + ".0", str(q) + ".1")]) + "\n")
+        for l, r in enumerate(rows):
+            f.write("\t".join(r + [str(v) for v in lab[:, l]]))
+            f.write("\n")
+
+
+def write_fb(fb_prefix, meta_data, proba, ancestry, query_samples):
+    """<prefix>.fb (postprocess.py:100-126): proba (N, W, A); float32 values are printed with their shortest repr"""
+    proba = np.asarray(proba)
+    n_rows = len(meta_data["spos"])
+    se = np.stack([np.asarray(meta_data["spos"]).astype(int), np.asarray(meta_data["epos"]).astype(int)], axis=1)
+    pp = np.round(np.mean(se, axis=1)).astype(int)
+    gp = np.mean(np.stack([np.asarray(meta_data["sgpos"], dtype=float), np.asarray(meta_data["egpos"], dtype=float)], 1), axis=1)
+    header = ["chromosome", "physical position", "genetic_position", "genetic_marker_index"]
+    header += [":::".join([str(q), h, str(a)]) for q in query_samples for h in ["hap1", "hap2"] for a in ancestry]
+    fb_prob = np.swapaxes(proba, 1, 2).reshape(-1, n_rows).T  # (W, N*A)
+    with open(fb_prefix + ".fb", "w") as f:
+        f.write("#reference_panel_population:\t")
+        f.write("\t".join([str(a) for a in ancestry]) + "\n")
+        f.write("\t".join(header) + "\n")
+        for r in range(n_rows):
+            vals = [str(meta_data["chm"][r]), str(pp[r]), _fmt(np.float64(gp[r])), "."]
+            vals += [_fmt(v) for v in fb_prob[r]]
+            f.write("\t".join(vals) + "\n")
+
+
+def msp_to_lai(msp_file, positions, lai_file=None):
+    """SNP-level labels (postprocess.py:128-160): every window row repeated `n snps` times."""
+    with open(msp_file) as f:
+        first, second = f.readline(), f.readline()
+        rows = [ln.rstrip("\n").split("\t") for ln in f if ln.strip()]
+    samples = second[:-1].split("\t")[6:]
+    n_reps = np.array([int(r[5]) for r in rows])
+    assert n_reps.sum() == len(positions)
+    data = np.array([[int(v) for v in r[6:]] for r in rows])
+    snp = np.repeat(data, n_reps, axis=0)
+    if lai_file is not None:
+        with open(lai_file, "w") as f:
+            f.write(first)
+            f.write("position\t" + "\t".join(samples) + "\n")
+            for p, r in zip(positions, snp):
+                f.write(str(p) + "\t" + "\t".join(str(v) for v in r) + "\n")
+    return samples, snp
+
+
+def msp_to_bed(msp_file, root, pop_order=None):
+    """one run-length encoded .bed per haplotype column (postprocess.py:162-210)"""
+    with open(msp_file) as f:
+        f.readline()
+        header = f.readline().rstrip("\n").split("\t")
+        rows = [ln.rstrip("\n").split("\t") for ln in f if ln.strip()]
+    os.makedirs(root, exist_ok=True)
+    lab = (lambda a: a) if pop_order is None else (lambda a: pop_order[int(a)])
+    for ci, sample in enumerate(header[6:]):
+        out = []
+        start = 0
+        for i in range(1, len(rows) + 1):
+            if i == len(rows) or rows[i][6 + ci] != rows[start][6 + ci]:
+                out.append((rows[start][0], rows[start][1], rows[i - 1][2], lab(rows[start][6 + ci]), rows[start][3], rows[i - 1][4]))
+                start = i
+        with open(os.path.join(root, sample.replace(".", "_") + ".bed"), "w") as f:
+            f.write("chm\tspos\tepos\tancestry\tsgpos\tegpos\n")
+            for r in out:
+                f.write("\t".join(str(v) for v in r) + "\n")

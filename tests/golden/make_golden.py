@@ -14,6 +14,7 @@ input/output pair produced by executing its own functions:
   G5_gnofix.npz    gnofix() and Gnomix.phase() control flow with the same plug (gnofix.py:58-208,
                    model.py:188-214, phasing.py:182-198)
   G6_writers/      get_meta_data / write_msp / write_fb text              (postprocess.py:25-126)
+  G7_vcf.npz       vcf_to_npy on a synthetic allel-style dict            (utils.py:104-159)
 
 Third-party modules the reference imports at module import time but that are absent here
 (xgboost, allel, seaborn, calibration, sklearn_crfsuite) are replaced by empty stubs; no code path
@@ -324,17 +325,44 @@ def make_G6(outdir):
     print("G6 ok")
 
 
+def make_G7(out):
+    """vcf_to_npy (src/utils.py:104-159) on a synthetic scikit-allel-style dict: SNP intersection with the model,
+    REF-mismatch flip, missing calls and multi-allelic codes -> 2"""
+    from src.utils import vcf_to_npy
+    rng = np.random.RandomState(7)
+    n_var, n_ind, Cm = 60, 5, 50
+    all_pos = np.sort(rng.choice(np.arange(1000, 9000), size=80, replace=False))
+    model_pos = np.sort(rng.choice(all_pos, size=Cm, replace=False))
+    vcf_pos = np.sort(rng.choice(all_pos, size=n_var, replace=False))
+    bases = np.array(list("ACGT"))
+    model_ref = bases[rng.randint(4, size=Cm)]
+    vcf_ref = bases[rng.randint(4, size=n_var)]
+    common, mi, vi = np.intersect1d(model_pos, vcf_pos, return_indices=True)
+    agree = rng.rand(len(common)) < 0.7
+    vcf_ref[vi[agree]] = model_ref[mi[agree]]
+    gt = rng.randint(0, 2, size=(n_var, n_ind, 2)).astype(np.int8)
+    gt[rng.rand(*gt.shape) < 0.05] = -1
+    gt[rng.rand(*gt.shape) < 0.03] = 2
+    vd = {"calldata/GT": gt, "variants/POS": vcf_pos, "variants/REF": vcf_ref}
+    X, vcf_idx, fmt_idx = vcf_to_npy(vd, model_pos, model_ref, return_idx=True, verbose=False)
+    X2 = vcf_to_npy({"calldata/GT": gt.copy(), "variants/POS": vcf_pos, "variants/REF": vcf_ref}, verbose=False)
+    np.savez_compressed(out, gt=gt, vcf_pos=vcf_pos, vcf_ref=vcf_ref.astype("U1"), model_pos=model_pos,
+                        model_ref=model_ref.astype("U1"), X=X, vcf_idx=vcf_idx, fmt_idx=fmt_idx, X_nofmt=X2)
+    print("G7", X.shape, X.dtype)
+
+
 def main():
     if not import_reference():
         print("reference not found at", REF, "- nothing generated")
         return 0
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7"]
     if "G1" in which: make_G1(os.path.join(HERE, "G1_lr.npz"))
     if "G2" in which: make_G2(os.path.join(HERE, "G2_covrsk.npz"))
     if "G3" in which: make_G3(os.path.join(HERE, "G3_slide.npz"))
     if "G4" in which: make_G4(os.path.join(HERE, "G4_smooth.npz"))
     if "G5" in which: make_G5(os.path.join(HERE, "G5_gnofix.npz"))
     if "G6" in which: make_G6(os.path.join(HERE, "G6_writers"))
+    if "G7" in which: make_G7(os.path.join(HERE, "G7_vcf.npz"))
     return 0
 
 

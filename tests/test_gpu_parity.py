@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): argmax labels bit-identical; probabilities with
 For the f32 tree pass we additionally assert BIT equality with the oracle (same f32 order of
 operations), and for the f64 logistic base <= 1e-12 absolute on B with the float32 cast that the
 smoother consumes differing in at most a handful of entries (MFMA summation order != sequential)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -390,3 +392,62 @@ def test_covrsk_vs_oracle(ga, oracle, C, M, A, ctx, N, nfit):
     assert np.max(np.abs(b64 - ref)) < 1e-12
     assert np.array_equal(np.argmax(b64, -1), np.argmax(ref, -1))
     assert np.allclose(b64.sum(-1), 1.0, atol=1e-9)
+
+
+# ---------------------------------------------------------------- CLI end to end ------------------------
+def _write_synth_vcf(path, pos, ref, alt, X, samples, chm="22"):
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##contig=<ID=%s>\n" % chm)
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples) + "\n")
+        for v in range(len(pos)):
+            gt = ["%s|%s" % ("." if X[2 * i, v] == 2 else X[2 * i, v], "." if X[2 * i + 1, v] == 2 else X[2 * i + 1, v])
+                  for i in range(len(samples))]
+            f.write("%s\t%d\trs%d\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (chm, pos[v], v, ref[v], alt[v], "\t".join(gt)))
+
+
+@pytest.mark.parametrize("phase", [False, True])
+def test_cli_end_to_end(ga, oracle, tmp_path, phase):
+    from gnomix_amd import synth, cli, postprocess
+    d = synth.synthetic_model(C=16037, M=100, A=4, S=75, n_rounds=8, seed=11)
+    rng = np.random.RandomState(1)
+    d.snp_pos = np.sort(rng.choice(np.arange(10_000, 5_000_000), size=d.C, replace=False))
+    d.snp_ref = rng.choice(list("ACGT"), size=d.C)
+    d.snp_alt = rng.choice(list("ACGT"), size=d.C)
+    d.gen_map_pos = np.array([1, 1_000_000, 3_000_000, 6_000_000])
+    d.gen_map_cm = np.array([0.0, 1.1, 3.7, 7.2])
+    mp = str(tmp_path / "model.gnx")
+    d.save(mp)
+    n_ind = 3
+    keep = np.sort(rng.choice(d.C, size=d.C - 500, replace=False))      # the query lacks 500 model SNPs
+    Xq = synth.synthetic_X(2 * n_ind, d.C, seed=3, miss=0.01)
+    ref = d.snp_ref.copy()
+    flip = rng.rand(d.C) < 0.05                                          # 5 % REF mismatches get flipped
+    ref[flip] = np.where(ref[flip] == "A", "C", "A")
+    vcf = str(tmp_path / "q.vcf")
+    _write_synth_vcf(vcf, d.snp_pos[keep], ref[keep], d.snp_alt[keep], Xq[:, keep], ["S%d" % i for i in range(n_ind)])
+    out = str(tmp_path / "out")
+    assert cli.main(["gnomix.py", vcf, out, "22", "True" if phase else "False", mp]) == 0
+    msp = open(out + "/query_results.msp").read().splitlines()
+    fb = open(out + "/query_results.fb").read().splitlines()
+    assert len(msp) == 2 + d.W and len(fb) == 2 + d.W
+    assert msp[1].split("\t")[6:] == ["S0.0", "S0.1", "S1.0", "S1.1", "S2.0", "S2.1"]
+    # what the model saw: model-order matrix with missing SNPs = 2 and flipped REFs
+    Xm = np.full((2 * n_ind, d.C), 2, dtype=np.int8)
+    Xm[:, keep] = Xq[:, keep]
+    fl = flip & np.isin(np.arange(d.C), keep)
+    Xm[:, fl] = np.where(Xm[:, fl] == 2, 2, 1 - Xm[:, fl])
+    B = oracle.base_lr(Xm, d.M, d.context, d.lr_coef, d.lr_intercept)
+    T = _oracle_trees(oracle, d)
+    lab_file = np.array([[int(v) for v in ln.split("\t")[6:]] for ln in msp[2:]]).T
+    if not phase:
+        p_ref, l_ref = oracle.smooth_xgb(T, B, d.S)
+        assert np.array_equal(lab_file, l_ref)
+        p_file = np.array([[float(v) for v in ln.split("\t")[4:]] for ln in fb[2:]], dtype=np.float32)
+        assert np.max(np.abs(p_file - np.swapaxes(p_ref, 1, 2).reshape(-1, d.W).T)) <= 1e-5
+    else:
+        rows = lambda r: oracle.xgb_predict_proba(T, r)
+        labs = lambda b: oracle.smooth_xgb(T, b, d.S)[1]
+        for i in range(n_ind):
+            _, _, Ym, Yp, _, _ = oracle.gnofix(Xm[2 * i], Xm[2 * i + 1], B[2 * i:2 * i + 2], d.S, rows, labs)
+            assert np.array_equal(lab_file[2 * i], Ym) and np.array_equal(lab_file[2 * i + 1], Yp)
+        assert os.path.exists(out + "/query_file_phased.vcf")

@@ -99,3 +99,61 @@ def test_trees_from_xgb_json_roundtrip(oracle):
     m = np.log(oracle.xgb_predict_proba(T, f))
     want = np.array([0.3, 0.2, -0.1]) - 0.05  # margin difference class0 - class1
     assert np.allclose(m[:, 0] - m[:, 1], want, atol=1e-6)
+
+
+def test_writers_match_reference_bytes(tmp_path):
+    """G6: .msp / .fb text produced by the reference's own writers on the same inputs"""
+    from gnomix_amd import postprocess as pp
+    g = np.load(os.path.join(ROOT, "tests", "golden", "G6_writers", "inputs.npz"), allow_pickle=False)
+    meta = pp.get_meta_data("22", g["model_pos"], g["query_pos"], int(g["W"]), int(g["M"]), g["gm_pos"], g["gm_cm"])
+    out = str(tmp_path / "ours")
+    pp.write_msp(out, meta, g["labels"], list(g["pops"]), list(g["samples"]))
+    pp.write_fb(out, meta, g["proba"], list(g["pops"]), list(g["samples"]))
+    ref = os.path.join(ROOT, "tests", "golden", "G6_writers", "ref")
+    assert open(out + ".msp").read() == open(ref + ".msp").read()
+    assert open(out + ".fb").read() == open(ref + ".fb").read()
+    samples, snp = pp.msp_to_lai(out + ".msp", g["query_pos"], str(tmp_path / "o.lai"))
+    assert snp.shape == (len(g["query_pos"]), 4) and samples[0] == "HG001.0"
+    pp.msp_to_bed(out + ".msp", str(tmp_path / "bed"), pop_order=list(g["pops"]))
+    assert os.path.exists(str(tmp_path / "bed" / "HG001_0.bed"))
+
+
+def test_vcf_to_npy_matches_reference():
+    """G7: the reference's own vcf_to_npy output on the same scikit-allel-style dict"""
+    from gnomix_amd import vcfio
+    g = np.load(os.path.join(ROOT, "tests", "golden", "G7_vcf.npz"), allow_pickle=False)
+    vd = {"calldata/GT": g["gt"].copy(), "variants/POS": g["vcf_pos"], "variants/REF": g["vcf_ref"]}
+    X, vi, fi = vcfio.vcf_to_npy(vd, g["model_pos"], g["model_ref"], return_idx=True, verbose=False)
+    assert X.dtype == np.int8 and np.array_equal(X, g["X"])
+    assert np.array_equal(vi, g["vcf_idx"]) and np.array_equal(fi, g["fmt_idx"])
+    assert (X == 2).any() and set(np.unique(X)) <= {0, 1, 2}
+    X2 = vcfio.vcf_to_npy({"calldata/GT": g["gt"].copy(), "variants/POS": g["vcf_pos"], "variants/REF": g["vcf_ref"]}, verbose=False)
+    assert np.array_equal(X2, g["X_nofmt"])
+
+
+def test_vcf_text_roundtrip(tmp_path):
+    from gnomix_amd import vcfio
+    p = tmp_path / "q.vcf"
+    lines = ["##fileformat=VCFv4.2", "##contig=<ID=22>", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2",
+             "22\t100\trs1\tA\tG\t.\tPASS\t.\tGT\t0|1\t1|1", "22\t150\trs2\tC\tT,G\t50\tPASS\t.\tGT:DP\t.|0:3\t2|0:4",
+             "21\t10\trs0\tA\tC\t.\tPASS\t.\tGT\t0|0\t0|1"]
+    p.write_text("\n".join(lines) + "\n")
+    d = vcfio.read_vcf(str(p), chm="22")
+    assert d["calldata/GT"].shape == (2, 2, 2) and list(d["samples"]) == ["S1", "S2"]
+    assert d["calldata/GT"][1, 0, 0] == -1 and d["calldata/GT"][1, 1, 0] == 2 and list(d["variants/POS"]) == [100, 150]
+    X = vcfio.vcf_to_npy(d, verbose=False)
+    assert X.tolist() == [[0, 2], [1, 0], [1, 2], [1, 0]]
+    assert vcfio.read_headers(str(p)).count("##") == 2
+    out = vcfio.npy_to_vcf(d, X, str(tmp_path / "phased"), headers=vcfio.read_headers(str(p)))
+    d2 = vcfio.read_vcf(out, chm="22")
+    assert np.array_equal(vcfio.vcf_to_npy(d2, verbose=False), X)
+    assert vcfio.read_vcf(str(p), chm="7")["calldata/GT"].shape[0] == 3  # unknown region -> whole file (utils.py:72-78)
+
+
+def test_cli_usage_and_training_mode_messages(capsys):
+    from gnomix_amd import cli
+    assert cli.main(["gnomix.py"]) == 0
+    assert "Usage when using a pre-trained model" in capsys.readouterr().out
+    assert cli.main(["gnomix.py", "a", "b"]) == 0
+    assert "Incorrect number of arguments" in capsys.readouterr().out
+    assert cli.main(["gnomix.py"] + ["x"] * 7) == 2
