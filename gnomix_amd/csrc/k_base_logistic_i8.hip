@@ -314,9 +314,17 @@ hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L0, int n_cu, hipStre
     if (tm == 4 && tw == 8) return launch<4, 1, 8, 2>(L, n_cu, s);
     return hipErrorInvalidValue;
   }
+  if (L.d.NT == 2 && tm) {
+    if (tm == 1 && tw == 4) return launch<1, 2, 4, 2>(L, n_cu, s);
+    if (tm == 1 && tw == 8) return launch<1, 2, 8, 2>(L, n_cu, s);
+    if (tm == 1 && tw == 16) return launch<1, 2, 16, 2>(L, n_cu, s);
+    if (tm == 2 && tw == 4) return launch<2, 2, 4, 2>(L, n_cu, s);
+    if (tm == 2 && tw == 8) return launch<2, 2, 8, 2>(L, n_cu, s);
+    return hipErrorInvalidValue;
+  }
   switch (L.d.NT) {
     case 1: return small ? launch<1, 1, 4, 2>(L, n_cu, s) : launch<2, 1, 8, 2>(L, n_cu, s);
-    case 2: return small ? launch<1, 2, 4, 2>(L, n_cu, s) : launch<2, 2, 4, 2>(L, n_cu, s);
+    case 2: return small ? launch<1, 2, 4, 2>(L, n_cu, s) : launch<2, 2, 8, 2>(L, n_cu, s);  // A=12: 2.0 TB/s measured
     case 3: return launch<1, 3, 4, 2>(L, n_cu, s);
     case 4: return launch<1, 4, 4, 2>(L, n_cu, s);
     default: return hipErrorInvalidValue;

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Measurements of BASELINE.json's other configs on ONE GPU (not the driver's bench line; numbers go to DESIGN.md §5).
+
+  python scripts/bench_configs.py [c3] [c4] [c5a] [c5b]
+
+All inputs synthetic and resident in HBM; per-GPU shard sizes of the multi-GPU configs (N/8)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import gnomix_amd
+from gnomix_amd import synth, _lib
+
+
+def timed(fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def prof(ctx):
+    out = {}
+    for k, name in _lib.KERNEL_NAMES.items():
+        ms, n = ctx.profile_get(k)
+        if n:
+            out[name] = round(ms / n, 4)
+    return out
+
+
+def c4(N=12500):
+    """whole genome, 22 chromosomes, A=7, LR + xgb; N = 100k/8 haplotypes per GPU, chromosome-major batches"""
+    tot_t, tot_w, rows = 0.0, 0, []
+    for k, Wk in enumerate(synth.GENOME_W):
+        C = 1000 * Wk + 500
+        data = synth.synthetic_model(C=C, M=1000, A=7, S=75, seed=k)
+        model = gnomix_amd.DeviceModel(data)
+        del data
+        X = synth.synthetic_X_device(N, C, "cuda:0", seed=k)
+        model.ctx.profile_reset(); model.ctx.profile_enable(True)
+        dt = timed(lambda: model.infer_device(X), reps=2)
+        model.ctx.profile_enable(False)
+        rows.append((k + 1, Wk, round(dt * 1e3, 2), prof(model.ctx)))
+        tot_t += dt; tot_w += Wk
+        model.close(); del X, model
+        torch.cuda.empty_cache()
+        print("chr%d W=%d %.2f ms" % (k + 1, Wk, dt * 1e3), flush=True)
+    res = {"config": "c4 whole genome 22 chr, A=7, LR+xgb", "haplotypes_per_gpu": N, "sum_W": tot_w,
+           "seconds_per_batch": tot_t, "haplotypes_per_s_per_gpu": N / tot_t, "hap_windows_per_s": N * tot_w / tot_t,
+           "projected_8gpu_haplotypes_per_s": 8 * N / tot_t}
+    print(json.dumps(res))
+    return res
+
+
+def c3(N=4096):
+    """chr1 array density: C=250400, M=175, A=7, CovRSK/SVC base (1400 training haplotypes per window, all SVs) + xgb"""
+    C, M, A = 250_400, 175, 7
+    t0 = time.time()
+    data = synth.synthetic_svc_model(C, M, A, n_fit_per_class=200, sv_frac=1.1, seed=0, S=75, smooth="xgb")
+    print("model synthesised in %.0f s" % (time.time() - t0), flush=True)
+    t0 = time.time()
+    model = gnomix_amd.DeviceModel(data)
+    print("model loaded in %.0f s" % (time.time() - t0), flush=True)
+    X = synth.synthetic_X_device(N, C, "cuda:0", seed=1)
+    model.ctx.profile_reset(); model.ctx.profile_enable(True)
+    dt = timed(lambda: model.infer_device(X), reps=1, warm=1)
+    model.ctx.profile_enable(False)
+    W = data.W
+    nsv = 1400
+    res = {"config": "c3 chr1 array, CovRSK base + xgb", "haplotypes": N, "W": W, "seconds": dt, "haplotypes_per_s": N / dt,
+           "symbol_compares_per_s": N * W * nsv * (M + 2 * (M // 2)) / dt, "kernels_ms": prof(model.ctx)}
+    print(json.dumps(res))
+    return res
+
+
+def c5a(N=25000):
+    """chr1 WGS density, A=12, LR + CRF (the reference rejects CRF + Gnofix: src/model.py:194)"""
+    C, M, A = 1_431_500, 1000, 12
+    data = synth.synthetic_model(C=C, M=M, A=A, S=75, seed=5, smooth="crf")
+    model = gnomix_amd.DeviceModel(data)
+    X = synth.synthetic_X_device(N, C, "cuda:0", seed=2)
+    model.ctx.profile_reset(); model.ctx.profile_enable(True)
+    dt = timed(lambda: model.infer_device(X), reps=2)
+    model.ctx.profile_enable(False)
+    res = {"config": "c5a chr1 WGS A=12 LR+CRF", "haplotypes_per_gpu": N, "W": data.W, "seconds": dt,
+           "haplotypes_per_s_per_gpu": N / dt, "alg_GBps_base": (C + data.W * A * 8) * N / dt / 1e9, "kernels_ms": prof(model.ctx)}
+    print(json.dumps(res))
+    return res
+
+
+def c5b(n_ind=2048):
+    """chr1 WGS density, A=12, LR + xgb + Gnofix re-phasing loop (host-pointer ABI: includes staging)"""
+    C, M, A = 1_431_500, 1000, 12
+    data = synth.synthetic_model(C=C, M=M, A=A, S=75, seed=6)
+    model = gnomix_amd.DeviceModel(data)
+    Xd = synth.synthetic_X_device(2 * n_ind, C, "cuda:0", seed=3)
+    Bd = model.base_predict_device(Xd, f64=True)
+    torch.cuda.synchronize()
+    X, B = Xd.cpu().numpy(), Bd.cpu().numpy()
+    del Xd, Bd
+    model.ctx.profile_reset(); model.ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    Xo, Y, nsw = model.gnofix(X, B)
+    dt = time.perf_counter() - t0
+    model.ctx.profile_enable(False)
+    res = {"config": "c5b chr1 WGS A=12 LR+xgb+Gnofix", "individuals": n_ind, "seconds_incl_staging": dt,
+           "individuals_per_s": n_ind / dt, "mean_switches": float(nsw.mean()), "kernels_ms": prof(model.ctx)}
+    print(json.dumps(res))
+    return res
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c4", "c5a", "c5b", "c3"]
+    out = {}
+    for w in which:
+        out[w] = globals()[w]()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)

@@ -451,3 +451,26 @@ def test_cli_end_to_end(ga, oracle, tmp_path, phase):
             _, _, Ym, Yp, _, _ = oracle.gnofix(Xm[2 * i], Xm[2 * i + 1], B[2 * i:2 * i + 2], d.S, rows, labs)
             assert np.array_equal(lab_file[2 * i], Ym) and np.array_equal(lab_file[2 * i + 1], Yp)
         assert os.path.exists(out + "/query_file_phased.vcf")
+
+
+def test_gnofix_strips_in_global_scratch(ga, oracle):
+    """an individual whose two padded strips exceed the LDS budget takes the global-scratch path"""
+    from gnomix_amd import synth
+    W, A, S = 1500, 12, 75
+    C = W * 3 + 2
+    d = ga.GnxModelData(C=C, M=3, A=A, S=S, context=0, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(2, A, S * A, seed=8, thr_lo=0.0, thr_hi=0.4, leaf_scale=1.0).items():
+        setattr(d, k, v)
+    dev = ga.DeviceModel(d)
+    T = _oracle_trees(oracle, d)
+    rng = np.random.RandomState(2)
+    X = rng.randint(0, 2, size=(4, C)).astype(np.int8)
+    B = rng.dirichlet(np.ones(A) * 0.2, size=(4, W))
+    Xo, Y, nsw = dev.gnofix(X, B, max_it=2)
+    rows = lambda r: oracle.xgb_predict_proba(T, r)
+    labs = lambda b: oracle.smooth_xgb(T, b, S)[1]
+    for i in range(2):
+        Xm, Xp, Ym, Yp, _, ns = oracle.gnofix(X[2 * i], X[2 * i + 1], B[2 * i:2 * i + 2], S, rows, labs, max_it=2)
+        assert np.array_equal(Xo[2 * i], Xm) and np.array_equal(Xo[2 * i + 1], Xp)
+        assert np.array_equal(Y[2 * i], Ym) and np.array_equal(Y[2 * i + 1], Yp) and int(nsw[i]) == ns
+    assert int(nsw.sum()) > 0
