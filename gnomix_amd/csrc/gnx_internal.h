@@ -28,7 +28,7 @@ struct gnx_ctx {
   std::string err;
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)
-  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow;
+  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -138,6 +138,7 @@ struct SmoothCRFLaunch {
 // ---- CovRSK / SVC base (k_base_covrsk.hip) ------------------------------------------------------------
 struct SvcWinDev {
   int32_t width, nw, n_sv, g_off;  // window width in SNPs, 32-bit words per plane, support vectors, offset into gtab
+  int32_t n_ms, pad0;              // number of substring lengths (fast path: prefix of the canonical list)
   int64_t sv_off;                  // offset (uint32 units) of this window's SV bit-planes: [sv][plane][nw]
   int64_t coef_off;                // offset (doubles): dual (A-1, n_sv) | intercept P | probA P | probB P
   int32_t cls_start[36];           // SV index range per class (prefix sums of n_support)
@@ -149,6 +150,7 @@ struct CovRSKDev {
   const double* coef = nullptr;
   const uint32_t* gtab = nullptr;
   int32_t max_nw = 0, max_width = 0;
+  std::vector<int32_t> fast_nw;  // host: per window, words of the AND-shift fast path (0 = generic kernel)
 };
 
 struct CovRSKLaunch {
@@ -162,6 +164,11 @@ struct CovRSKLaunch {
   int32_t max_nw, max_width;
   float* b32;
   double* b64;
+  double* rpair;            // (rpair_haps, W, A(A-1)/2) clipped pairwise probabilities between the two passes
+  int64_t rpair_haps;       // haplotypes per chunk of the pairwise buffer
+  int64_t n_first, n_count; // chunk being processed (set by the launcher)
+  int32_t w_first;          // first window of the grid (set by the launcher)
+  const int32_t* host_fast_nw;  // HOST pointer: per-window fast-path word count (launcher only)
 };
 
 // ---- gnofix (k_gnofix.hip) ----------------------------------------------------------------------------

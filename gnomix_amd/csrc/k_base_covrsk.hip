@@ -56,10 +56,13 @@ __device__ __forceinline__ double sigmoid_predict(double dec, double pa, double 
   return 1.0 / (1.0 + exp(f));
 }
 
-__global__ __launch_bounds__(64) void k_covrsk_svc(CovRSKLaunch L) {
+// pass 2a: kernel values + pairwise decision values + Platt sigmoids -> r_ij (i<j) in global memory.
+// Small LDS footprint (query bit-planes, g table, the P accumulators of 64 queries) so that many waves are resident:
+// the run-peeling loop is latency-bound (LDS lookups, scalar loads), occupancy is what hides it.
+__global__ __launch_bounds__(64) void k_covrsk_dec(CovRSKLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int lane = threadIdx.x;
-  const int w = blockIdx.y;
+  const int w = L.w_first + blockIdx.y;
   const int A = L.A, P = A * (A - 1) / 2;
   const SvcWinDev win = L.win[w];
   const int NW = win.nw, width = win.width, n_sv = win.n_sv;
@@ -69,12 +72,10 @@ __global__ __launch_bounds__(64) void k_covrsk_svc(CovRSKLaunch L) {
   uint32_t* xq = reinterpret_cast<uint32_t*>(carve((size_t)2 * L.max_nw * 64 * 4));  // [plane][word][lane]
   uint32_t* gl = reinterpret_cast<uint32_t*>(carve((size_t)(L.max_width + 2) * 4));   // g[0..width]
   double* dec = reinterpret_cast<double*>(carve((size_t)P * 64 * 8));                 // [pair][lane]
-  double* Q = reinterpret_cast<double*>(carve((size_t)A * A * 64 * 8));               // [t][j][lane]
-  double* Qp = reinterpret_cast<double*>(carve((size_t)A * 64 * 8));
-  double* pr = reinterpret_cast<double*>(carve((size_t)A * 64 * 8));
 
-  const int64_t n = (int64_t)blockIdx.x * 64 + lane;
-  const int64_t nc = n < L.N ? n : L.N - 1;
+  const int64_t n = L.n_first + (int64_t)blockIdx.x * 64 + lane;  // haplotype index within the whole batch
+  const int64_t n_end = L.n_first + L.n_count;
+  const int64_t nc = n < n_end ? n : n_end - 1;
 
   // ---- query window bits: funnel-shift the padded planes to the window start (w*M) ----
   {
@@ -138,21 +139,182 @@ __global__ __launch_bounds__(64) void k_covrsk_svc(CovRSKLaunch L) {
     }
   }
 
-  // ---- Platt sigmoids (svm_predict_probability) ----
+  // ---- Platt sigmoids (svm_predict_probability): r_ij, i<j ----
   const double* icpt = dual + (size_t)(A - 1) * n_sv;
   const double* pA = icpt + P;
   const double* pB = pA + P;
   const double min_prob = 1e-7;
-  for (int p = 0; p < P; ++p) {
-    const double d = dec[p * 64 + lane] + icpt[p];  // sklearn _intercept_ = -rho
-    double v = sigmoid_predict(d, pA[p], pB[p]);
-    v = fmin(fmax(v, min_prob), 1 - min_prob);
-    dec[p * 64 + lane] = v;  // r[i][j], i<j; r[j][i] = 1 - v
+  if (n < n_end) {
+    double* out = L.rpair + (((size_t)(n - L.n_first)) * L.W + w) * P;
+    for (int p = 0; p < P; ++p) {
+      const double d = dec[p * 64 + lane] + icpt[p];  // sklearn _intercept_ = -rho
+      double v = sigmoid_predict(d, pA[p], pB[p]);
+      out[p] = fmin(fmax(v, min_prob), 1 - min_prob);
+    }
   }
+}
+
+// ---- fast path of pass 2a: branch-free AND-shift counting for the canonical CovSample lengths ----------------
+// #matching substrings of length m = popcount(r_m), r_m[t] = AND_{k<m} e[t+k].  With the lengths the reference's
+// CovSample(seed=37) always produces (prefix of 1,4,8,39,42,117,376: string_kernel.py:80-89) r_m comes from a
+// doubling chain r_2p = r_p & (r_p >> p) plus r_m = r_a & (r_b >> (m-b)) (a+b >= m), all shifts compile-time, the
+// NWT-word bit vectors in registers: ~30 straight-line VALU ops per word, no loop, no divergence, no LDS in the loop.
+template <int NWT>
+struct BitVec {
+  uint32_t w[NWT];
+};
+
+template <int NWT, int K>
+__device__ __forceinline__ BitVec<NWT> shr(const BitVec<NWT>& a) {  // result[t] = a[t + K]
+  constexpr int q = K / 32, s = K % 32;
+  BitVec<NWT> r;
+#pragma unroll
+  for (int i = 0; i < NWT; ++i) {
+    const uint32_t lo = (i + q < NWT) ? a.w[i + q] : 0u;
+    const uint32_t hi = (i + q + 1 < NWT) ? a.w[i + q + 1] : 0u;
+    r.w[i] = s ? __funnelshift_r(lo, hi, s) : lo;
+  }
+  return r;
+}
+
+template <int NWT>
+__device__ __forceinline__ BitVec<NWT> band(const BitVec<NWT>& a, const BitVec<NWT>& b) {
+  BitVec<NWT> r;
+#pragma unroll
+  for (int i = 0; i < NWT; ++i) r.w[i] = a.w[i] & b.w[i];
+  return r;
+}
+
+template <int NWT>
+__device__ __forceinline__ uint32_t pop(const BitVec<NWT>& a) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NWT; ++i) c += __popc(a.w[i]);
+  return c;
+}
+
+template <int NWT>
+__device__ __forceinline__ bool any_bit(const BitVec<NWT>& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < NWT; ++i) o |= a.w[i];
+  return o != 0;
+}
+
+template <int NWT>
+__global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int lane = threadIdx.x;
+  const int w = L.w_first + blockIdx.y;
+  const int A = L.A, P = A * (A - 1) / 2;
+  const SvcWinDev win = L.win[w];
+  const int NW = win.nw, width = win.width, n_sv = win.n_sv, n_ms = win.n_ms;
+  double* dec = reinterpret_cast<double*>(lds);  // [pair][lane]
+
+  const int64_t n = L.n_first + (int64_t)blockIdx.x * 64 + lane;
+  const int64_t n_end = L.n_first + L.n_count;
+  const int64_t nc = n < n_end ? n : n_end - 1;
+
+  BitVec<NWT> xl, xh;
+  {
+    const int64_t s = (int64_t)w * L.M;
+    const int64_t w0 = s >> 5;
+    const int sh = (int)(s & 31);
+    const uint32_t* s0 = L.planes + (nc * 2 + 0) * L.nwp + w0;
+    const uint32_t* s1 = L.planes + (nc * 2 + 1) * L.nwp + w0;
+#pragma unroll
+    for (int i = 0; i < NWT; ++i) {
+      uint32_t a = 0, b = 0;
+      if (i < NW) {
+        a = sh ? ((s0[i] >> sh) | (s0[i + 1] << (32 - sh))) : s0[i];
+        b = sh ? ((s1[i] >> sh) | (s1[i + 1] << (32 - sh))) : s1[i];
+        if (i == NW - 1 && (width & 31)) { a &= (1u << (width & 31)) - 1u; b &= (1u << (width & 31)) - 1u; }
+      }
+      xl.w[i] = a;
+      xh.w[i] = b;
+    }
+  }
+  BitVec<NWT> valid;  // bit t set iff t < width
+#pragma unroll
+  for (int i = 0; i < NWT; ++i) valid.w[i] = (i < NW - 1) ? 0xffffffffu : (i == NW - 1 ? ((width & 31) ? ((1u << (width & 31)) - 1u) : 0xffffffffu) : 0u);
+  for (int p = 0; p < P; ++p) dec[p * 64 + lane] = 0.0;
+
+  const double* dual = L.coef + win.coef_off;
+  for (int c = 0; c < A; ++c) {
+    for (int sv = win.cls_start[c]; sv < win.cls_start[c + 1]; ++sv) {
+      const uint32_t* yb = L.svbits + win.sv_off + (size_t)sv * 2 * NW;  // wave-uniform
+      BitVec<NWT> e;
+#pragma unroll
+      for (int i = 0; i < NWT; ++i) {
+        const uint32_t yl = (i < NW) ? yb[i] : 0u, yh = (i < NW) ? yb[NW + i] : 0u;
+        e.w[i] = ~((xl.w[i] ^ yl) | (xh.w[i] ^ yh)) & valid.w[i];
+      }
+      uint32_t K = pop(e);                                              // m = 1
+      const BitVec<NWT> r2 = band(e, shr<NWT, 1>(e));
+      const BitVec<NWT> r4 = band(r2, shr<NWT, 2>(r2));
+      if (n_ms > 1) K += pop(r4);                                       // m = 4
+      const BitVec<NWT> r8 = band(r4, shr<NWT, 4>(r4));
+      if (n_ms > 2) K += pop(r8);                                       // m = 8
+      if (n_ms > 3) {
+        const BitVec<NWT> r16 = band(r8, shr<NWT, 8>(r8));
+        const BitVec<NWT> r32 = band(r16, shr<NWT, 16>(r16));
+        if (__any(any_bit(r32))) {                                      // wave-uniform: some query has a run >= 32
+          K += pop(band(r32, shr<NWT, 31>(r8)));                        // m = 39 = [t,t+32) & [t+31,t+39)
+          if (n_ms > 4) K += pop(band(r32, shr<NWT, 26>(r16)));         // m = 42 = [t,t+32) & [t+26,t+42)
+          if (n_ms > 5) {
+            const BitVec<NWT> r64 = band(r32, shr<NWT, 32>(r32));
+            if (__any(any_bit(r64))) {
+              K += pop(band(r64, shr<NWT, 53>(r64)));                   // m = 117 = [t,t+64) & [t+53,t+117)
+              if (n_ms > 6) {
+                const BitVec<NWT> r128 = band(r64, shr<NWT, 64>(r64));
+                const BitVec<NWT> r256 = band(r128, shr<NWT, 128>(r128));
+                K += pop(band(r256, shr<NWT, 248>(r128)));              // m = 376 = [t,t+256) & [t+248,t+376)
+              }
+            }
+          }
+        }
+      }
+      const double Kd = (double)K;
+      for (int o = 0; o < A; ++o) {
+        if (o == c) continue;
+        const int row = (o > c) ? o - 1 : o;
+        const int p = (o > c) ? pair_index(c, o, A) : pair_index(o, c, A);
+        dec[p * 64 + lane] += dual[(size_t)row * n_sv + sv] * Kd;
+      }
+    }
+  }
+  const double* icpt = dual + (size_t)(A - 1) * n_sv;
+  const double* pA = icpt + P;
+  const double* pB = pA + P;
+  const double min_prob = 1e-7;
+  if (n < n_end) {
+    double* out = L.rpair + (((size_t)(n - L.n_first)) * L.W + w) * P;
+    for (int p = 0; p < P; ++p) {
+      const double d = dec[p * 64 + lane] + icpt[p];
+      double v = sigmoid_predict(d, pA[p], pB[p]);
+      out[p] = fmin(fmax(v, min_prob), 1 - min_prob);
+    }
+  }
+}
+
+// pass 2b: multiclass_probability (Wu, Lin, Weng 2004) per (haplotype, window); thread-private arrays live in LDS as
+// [index][thread] (dynamic indexing without scratch).  Tiny next to pass 2a.
+__global__ __launch_bounds__(64) void k_svc_couple(CovRSKLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int lane = threadIdx.x;
+  const int A = L.A, P = A * (A - 1) / 2;
+  double* rr = reinterpret_cast<double*>(lds);          // [P][64]
+  double* Q = rr + (size_t)P * 64;                      // [A*A][64]
+  double* Qp = Q + (size_t)A * A * 64;                  // [A][64]
+  double* pr = Qp + (size_t)A * 64;                     // [A][64]
+  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;  // (n_local, w) flattened
+  const int64_t total = L.n_count * L.W;
+  const int64_t ic = idx < total ? idx : total - 1;
+  const double* in = L.rpair + (size_t)ic * P;
+  for (int p = 0; p < P; ++p) rr[p * 64 + lane] = in[p];
   auto r = [&](int i, int j) -> double {
-    return (i < j) ? dec[pair_index(i, j, A) * 64 + lane] : 1.0 - dec[pair_index(j, i, A) * 64 + lane];
+    return (i < j) ? rr[pair_index(i, j, A) * 64 + lane] : 1.0 - rr[pair_index(j, i, A) * 64 + lane];
   };
-  // ---- multiclass_probability (Wu, Lin, Weng 2004) ----
   const int k = A;
   const int max_iter = k > 100 ? k : 100;
   const double eps = 0.005 / k;
@@ -184,8 +346,9 @@ __global__ __launch_bounds__(64) void k_covrsk_svc(CovRSKLaunch L) {
       for (int j = 0; j < k; ++j) { QP(j) = (QP(j) + diff * QQ(t, j)) / (1 + diff); PP(j) /= (1 + diff); }
     }
   }
-  if (n < L.N) {
-    const size_t o = ((size_t)n * L.W + w) * A;
+  if (idx < total) {
+    const int64_t nl = idx / L.W, w = idx - nl * L.W;
+    const size_t o = ((size_t)(L.n_first + nl) * L.W + w) * A;
     for (int a = 0; a < A; ++a) {
       const double v = PP(a);
       if (L.b64) L.b64[o + a] = v;
@@ -202,8 +365,9 @@ __global__ __launch_bounds__(64) void k_covrsk_svc(CovRSKLaunch L) {
 size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width) {
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
   const int P = A * (A - 1) / 2;
-  return r16((size_t)2 * max_nw * 64 * 4) + r16((size_t)(max_width + 2) * 4) + r16((size_t)P * 64 * 8) +
-         r16((size_t)A * A * 64 * 8) + 2 * r16((size_t)A * 64 * 8);
+  const size_t dec = r16((size_t)2 * max_nw * 64 * 4) + r16((size_t)(max_width + 2) * 4) + r16((size_t)P * 64 * 8);
+  const size_t couple = (size_t)(P + A * A + 2 * A) * 64 * 8;
+  return dec > couple ? dec : couple;
 }
 
 hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwp,
@@ -214,10 +378,39 @@ hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t
   return hipGetLastError();
 }
 
-hipError_t gnx_launch_covrsk(const CovRSKLaunch& L, hipStream_t s) {
-  if (L.N <= 0) return hipSuccess;
-  const size_t lds = gnx_covrsk_lds_bytes(L.A, L.max_nw, L.max_width);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_covrsk_svc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_covrsk_svc, dim3((unsigned)((L.N + 63) / 64), (unsigned)L.W), dim3(64), lds, s, L);
+hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
+  if (L0.N <= 0) return hipSuccess;
+  const int A = L0.A, P = A * (A - 1) / 2;
+  auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const size_t lds_dec = r16((size_t)2 * L0.max_nw * 64 * 4) + r16((size_t)(L0.max_width + 2) * 4) + r16((size_t)P * 64 * 8);
+  const size_t lds_cpl = (size_t)(P + A * A + 2 * A) * 64 * 8;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_covrsk_dec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dec);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svc_couple), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cpl);
+  // the pairwise probabilities travel through a bounded global buffer: haplotypes in chunks of rpair_haps
+  for (int64_t n0 = 0; n0 < L0.N; n0 += L0.rpair_haps) {
+    CovRSKLaunch L = L0;
+    L.n_first = n0;
+    L.n_count = (L0.N - n0 < L0.rpair_haps) ? L0.N - n0 : L0.rpair_haps;
+    // consecutive windows with the same (fast-path word count) go in one grid
+    for (int w0 = 0; w0 < L.W;) {
+      const int key = L0.host_fast_nw[w0];
+      int w1 = w0 + 1;
+      while (w1 < L.W && L0.host_fast_nw[w1] == key) ++w1;
+      L.w_first = w0;
+      const dim3 grid((unsigned)((L.n_count + 63) / 64), (unsigned)(w1 - w0));
+      const size_t lds_fast = (size_t)P * 64 * 8;
+      switch (key) {
+#define GNX_FAST_CASE(NWT_) case NWT_: hipLaunchKernelGGL(k_covrsk_dec_fast<NWT_>, grid, dim3(64), lds_fast, s, L); break;
+        GNX_FAST_CASE(1) GNX_FAST_CASE(2) GNX_FAST_CASE(3) GNX_FAST_CASE(4) GNX_FAST_CASE(5) GNX_FAST_CASE(6) GNX_FAST_CASE(7)
+        GNX_FAST_CASE(8) GNX_FAST_CASE(9) GNX_FAST_CASE(10) GNX_FAST_CASE(11) GNX_FAST_CASE(12) GNX_FAST_CASE(13)
+        GNX_FAST_CASE(14) GNX_FAST_CASE(15) GNX_FAST_CASE(16)
+#undef GNX_FAST_CASE
+        default: hipLaunchKernelGGL(k_covrsk_dec, grid, dim3(64), lds_dec, s, L); break;  // 0: generic run peeling
+      }
+      w0 = w1;
+    }
+    const int64_t total = L.n_count * L.W;
+    hipLaunchKernelGGL(k_svc_couple, dim3((unsigned)((total + 63) / 64)), dim3(64), lds_cpl, s, L);
+  }
   return hipGetLastError();
 }

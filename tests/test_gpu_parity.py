@@ -371,6 +371,7 @@ def test_covrsk_golden_G2(ga, oracle):
     (1029, 64, 4, 32, 5, 8),          # width 128: exact multiple of 32
     (2011, 500, 2, 250, 33, 30),      # width 1000 (>866: all eight canonical lengths), binary problem
     (1237, 50, 12, 25, 64, 6),        # A=12
+    (1711, 200, 3, 100, 40, 10),      # width 400 (13 words): all seven lengths of the AND-shift fast path, incl. 376
 ])
 def test_covrsk_vs_oracle(ga, oracle, C, M, A, ctx, N, nfit):
     from gnomix_amd import synth
