@@ -127,3 +127,65 @@ def synthetic_svc_model(C, M, A, context=None, n_fit_per_class=20, sv_frac=0.7, 
                           intercept=rng.standard_normal(P) * 0.3, prob_a=-np.abs(rng.standard_normal(P)) - 0.5,
                           prob_b=rng.standard_normal(P) * 0.2, n_support=n_support, ms=cov_sample(width)))
     return m
+
+
+def synthetic_smoothing_trees(n_rounds, A, S, depth=4, seed=0, reach=8, noise_leaf=0.01):
+    """An ensemble that behaves like a TRAINED smoother (labels piecewise constant along the chromosome) while keeping
+    the cost profile of the reference's 100-round model: the first 2*reach+1 rounds are signal trees (class c votes by
+    thresholding the class-c base probability at windows w-reach..w+reach around the centre of the sliding window),
+    the remaining rounds are full-depth random trees with tiny leaves."""
+    rng = np.random.RandomState(seed)
+    pad = (S + 1) // 2
+    off, L, R, F, Cd, cls = [0], [], [], [], [], []
+    n_sig = min(n_rounds, 2 * reach + 1)
+    for r in range(n_sig):
+        k = r - reach
+        for c in range(A):
+            f = (pad + k) * A + c            # slide_window is centred on w-1: feature s=pad is window w
+            wgt = np.float32(0.6 / (1 + abs(k)))
+            nodes = [(1, 2, f, np.float32(0.5)), (-1, -1, 0, -wgt), (3, 4, f, np.float32(0.8)), (-1, -1, 0, wgt),
+                     (-1, -1, 0, np.float32(1.5) * wgt)]
+            for (l, rr, ff, cc) in nodes:
+                L.append(l); R.append(rr); F.append(ff); Cd.append(cc)
+            off.append(len(L)); cls.append(c)
+    rest = synthetic_trees(n_rounds - n_sig, A, S * A, depth=depth, seed=seed + 1, leaf_scale=noise_leaf, p_early_leaf=0.0) \
+        if n_rounds > n_sig else None
+    out = dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
+               feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32))
+    if rest is not None:
+        base = out["tree_off"][-1]
+        out = dict(tree_off=np.concatenate([out["tree_off"], rest["tree_off"][1:] + base]).astype(np.int32),
+                   left=np.concatenate([out["left"], rest["left"]]), right=np.concatenate([out["right"], rest["right"]]),
+                   feat=np.concatenate([out["feat"], rest["feat"]]), cond=np.concatenate([out["cond"], rest["cond"]]),
+                   tree_class=np.concatenate([out["tree_class"], rest["tree_class"]]))
+    return out
+
+
+def synthetic_phased_individuals(n_ind, W, A, seed=0, mean_segments=3, phase_errors=2, noise=0.15):
+    """Base probabilities (2*n_ind, W, A) float64 of admixed individuals whose two haplotypes carry `phase_errors`
+    switch errors each (the situation Gnofix repairs): piecewise-constant true ancestry, noisy one-hot B."""
+    rng = np.random.RandomState(seed)
+    B = np.empty((2 * n_ind, W, A))
+    for i in range(n_ind):
+        ys = []
+        for h in range(2):
+            cuts = np.sort(rng.choice(np.arange(40, W - 40), size=rng.poisson(mean_segments - 1), replace=False)) if W > 100 else []
+            y = np.empty(W, dtype=int)
+            a = rng.randint(A)
+            prev = 0
+            for c in list(cuts) + [W]:
+                y[prev:c] = a
+                a = (a + 1 + rng.randint(A - 1)) % A
+                prev = c
+            ys.append(y)
+        b = []
+        for y in ys:
+            p = np.full((W, A), noise / (A - 1))
+            p[np.arange(W), y] = 1 - noise
+            p *= rng.uniform(0.8, 1.2, size=p.shape)
+            b.append(p / p.sum(1, keepdims=True))
+        bm, bp = b
+        for s in np.sort(rng.choice(np.arange(10, W - 10), size=phase_errors, replace=False)):
+            bm, bp = np.concatenate([bm[:s], bp[s:]]), np.concatenate([bp[:s], bm[s:]])
+        B[2 * i], B[2 * i + 1] = bm, bp
+    return B
