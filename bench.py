@@ -28,8 +28,8 @@ F64_MFMA_PEAK_TF = 78.6    # AMD public spec for MI355X FP64 matrix (only used w
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--haps", type=int, default=10000, help="haplotypes per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--seed", type=int, default=94305)
@@ -153,7 +153,7 @@ def main():
         from oracle import gnx_oracle as O
         O.build()
         T = O.Trees(data.tree_off, data.left, data.right, data.feat, data.cond, data.tree_class, data.A, data.base_score)
-        Xh = X[:512].cpu().numpy()
+        Xh = X[:2048].cpu().numpy()
 
         def cpu_pass(xs):
             B = O.base_lr(xs, data.M, data.context, data.lr_coef, data.lr_intercept)
@@ -162,7 +162,7 @@ def main():
         c0 = time.perf_counter()
         cpu_pass(Xh[:4])
         per = (time.perf_counter() - c0) / 4
-        n_s = int(max(4, min(512, args.cpu_seconds / max(per, 1e-6))))
+        n_s = int(max(4, min(2048, args.cpu_seconds / max(per, 1e-6))))
         c0 = time.perf_counter()
         p_ref, l_ref = cpu_pass(Xh[:n_s])
         cdt = time.perf_counter() - c0

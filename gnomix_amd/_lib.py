@@ -78,6 +78,7 @@ SYMBOLS = {
     "gnx_infer_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP, _VP]),
     "gnx_smooth_rows": (C.c_int, [_VP, _VP, _I64, _VP]),
     "gnx_gnofix": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
+    "gnx_gnofix_dev": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
     "gnx_profile_enable": (C.c_int, [_VP, _I]),
     "gnx_profile_reset": (C.c_int, [_VP]),
     "gnx_profile_get": (C.c_int, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -484,7 +484,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair})
+  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0})
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -792,56 +792,81 @@ int gnx_smooth_rows(gnx_model* m, const float* rows, int64_t R, float* proba) {
   return GNX_OK;
 }
 
-int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_ind, int32_t max_it, int32_t* Y,
-               int32_t* n_switches) {
-  if (!m) return GNX_EINVAL;
+static int gnofix_check(gnx_model* m, int64_t ldx, int64_t n_ind, int32_t max_it, bool ptrs_ok, bool* in_lds) {
   gnx_ctx* ctx = m->ctx;
   // src/model.py:194: only a smoother with .gnofix == True (XGB_Smoother) supports re-phasing
   if (m->info.smooth_kind != GNX_SMOOTH_XGB)
     return fail(ctx, GNX_ESTATE, "Type of Smoother does not currently support re-phasing");
-  if (n_ind < 0 || ldx < m->info.C || max_it < 0 || (n_ind > 0 && (!X || !B || !Y)))
-    return fail(ctx, GNX_EINVAL, "gnofix: bad arguments");
-  if (n_ind == 0) return GNX_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (n_ind < 0 || ldx < m->info.C || max_it < 0 || (n_ind > 0 && !ptrs_ok)) return fail(ctx, GNX_EINVAL, "gnofix: bad arguments");
+  const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
+  *in_lds = gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, true) <= 150 * 1024;
+  if (gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, *in_lds) > 160 * 1024)
+    return fail(ctx, GNX_EUNSUPPORTED, "gnofix: model too large for the LDS working set (n_trees * 16 B + S*A*8 B)");
+  return GNX_OK;
+}
+
+// device-resident batch: initial labels with the batched smoother kernel, then one workgroup per individual
+static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int64_t n, int32_t max_it, int32_t* dY,
+                          int32_t* dNs, bool in_lds) {
+  gnx_ctx* ctx = m->ctx;
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S, pad = (S + 1) / 2;
   const size_t WA = (size_t)W * A, NWD = (size_t)(W + 31) / 32;
-  bool in_lds = gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, true) <= 150 * 1024;
-  if (gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, in_lds) > 160 * 1024)
-    return fail(ctx, GNX_EUNSUPPORTED, "gnofix: model too large for the LDS working set (n_trees * 16 B + S*A*8 B)");
+  int rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_p32, (size_t)2 * n * WA * 4)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_y0, (size_t)2 * n * W * 4)) != GNX_OK) return rc;
+  size_t misc = (size_t)n * std::max(max_it, 1) * NWD * 4;
+  const size_t bp_off = (misc + 255) & ~(size_t)255;
+  if (!in_lds) misc = bp_off + (size_t)n * 2 * (W + 2 * pad) * A * 4;
+  if ((rc = ws_reserve(ctx, ctx->ws_misc, misc + 256)) != GNX_OK) return rc;
+  int32_t* dY0 = (int32_t*)ctx->ws_y0.p;
+  // initial labels = smoother.predict(B) for every haplotype at once (gnofix.py:80)
+  rc = gnx_smooth_predict_dev(m, dB, 1, 2 * n, (float*)ctx->ws_p32.p, nullptr, dY0);
+  if (rc != GNX_OK) return rc;
+  GnofixLaunch L{};
+  L.X = dX; L.ldx = ldx; L.C = m->info.C; L.B = dB; L.Y0 = dY0; L.Yout = dY; L.n_switches = dNs;
+  L.W = W; L.A = A; L.S = S; L.max_it = max_it; L.d = m->xgb; L.class_tree0 = m->class_tree0;
+  L.bp_in_lds = in_lds ? 1 : 0;
+  L.hist = (uint32_t*)ctx->ws_misc.p;
+  L.bp_scratch = in_lds ? nullptr : (float*)((char*)ctx->ws_misc.p + bp_off);
+  ProfScope ps(ctx, GNX_K_GNOFIX);
+  HIPCHK(ctx, gnx_launch_gnofix(L, n, ctx->stream));
+  return GNX_OK;
+}
+
+int gnx_gnofix_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int64_t n_ind, int32_t max_it, int32_t* dY,
+                   int32_t* d_n_switches) {
+  if (!m) return GNX_EINVAL;
+  bool in_lds = true;
+  int rc = gnofix_check(m, ldx, n_ind, max_it, dX && dB && dY, &in_lds);
+  if (rc != GNX_OK || n_ind == 0) return rc;
+  return gnofix_run_dev(m, dX, ldx, dB, n_ind, max_it, dY, d_n_switches, in_lds);
+}
+
+int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_ind, int32_t max_it, int32_t* Y,
+               int32_t* n_switches) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  bool in_lds = true;
+  int rc = gnofix_check(m, ldx, n_ind, max_it, X && B && Y, &in_lds);
+  if (rc != GNX_OK || n_ind == 0) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int W = (int)m->info.W;
+  const size_t WA = (size_t)W * m->info.A;
   // batches of individuals bound the staging workspaces (~1 GiB of X)
   int64_t nb = std::max<int64_t>(1, (((int64_t)1 << 30) / std::max<int64_t>(ldx, 1)) / 2);
   nb = std::min(nb, n_ind);
-  int rc;
   if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)2 * nb * ldx + 64)) != GNX_OK) return rc;
   if ((rc = ws_reserve(ctx, ctx->ws_b64, (size_t)2 * nb * WA * 8)) != GNX_OK) return rc;
-  if ((rc = ws_reserve(ctx, ctx->ws_p32, (size_t)2 * nb * WA * 4)) != GNX_OK) return rc;
-  if ((rc = ws_reserve(ctx, ctx->ws_lab, (size_t)2 * nb * W * 4 * 2 + (size_t)nb * 4)) != GNX_OK) return rc;
-  size_t misc = (size_t)nb * std::max(max_it, 1) * NWD * 4;
-  const size_t bp_off = (misc + 255) & ~(size_t)255;
-  if (!in_lds) misc = bp_off + (size_t)nb * 2 * (W + 2 * pad) * A * 4;
-  if ((rc = ws_reserve(ctx, ctx->ws_misc, misc + 256)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_lab, (size_t)2 * nb * W * 4 + (size_t)nb * 4)) != GNX_OK) return rc;
   for (int64_t i0 = 0; i0 < n_ind; i0 += nb) {
     const int64_t n = std::min(nb, n_ind - i0);
     int8_t* dX = (int8_t*)ctx->ws_x.p;
     double* dB = (double*)ctx->ws_b64.p;
-    int32_t* dY0 = (int32_t*)ctx->ws_lab.p;
-    int32_t* dY = dY0 + (size_t)2 * nb * W;
+    int32_t* dY = (int32_t*)ctx->ws_lab.p;
     int32_t* dNs = dY + (size_t)2 * nb * W;
     HIPCHK(ctx, hipMemcpyAsync(dX, X + 2 * i0 * ldx, (size_t)(2 * n - 1) * ldx + m->info.C, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dB, B + (size_t)2 * i0 * WA, (size_t)2 * n * WA * 8, hipMemcpyHostToDevice, ctx->stream));
-    // initial labels = smoother.predict(B) for every haplotype at once (gnofix.py:80)
-    rc = gnx_smooth_predict_dev(m, dB, 1, 2 * n, (float*)ctx->ws_p32.p, nullptr, dY0);
-    if (rc != GNX_OK) return rc;
-    GnofixLaunch L{};
-    L.X = dX; L.ldx = ldx; L.C = m->info.C; L.B = dB; L.Y0 = dY0; L.Yout = dY; L.n_switches = dNs;
-    L.W = W; L.A = A; L.S = S; L.max_it = max_it; L.d = m->xgb; L.class_tree0 = m->class_tree0;
-    L.bp_in_lds = in_lds ? 1 : 0;
-    L.hist = (uint32_t*)ctx->ws_misc.p;
-    L.bp_scratch = in_lds ? nullptr : (float*)((char*)ctx->ws_misc.p + bp_off);
-    {
-      ProfScope ps(ctx, GNX_K_GNOFIX);
-      HIPCHK(ctx, gnx_launch_gnofix(L, n, ctx->stream));
-    }
+    if ((rc = gnofix_run_dev(m, dX, ldx, dB, n, max_it, dY, dNs, in_lds)) != GNX_OK) return rc;
     HIPCHK(ctx, hipMemcpyAsync(X + 2 * i0 * ldx, dX, (size_t)(2 * n - 1) * ldx + m->info.C, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(Y + (size_t)2 * i0 * W, dY, (size_t)2 * n * W * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (n_switches) HIPCHK(ctx, hipMemcpyAsync(n_switches + i0, dNs, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -28,7 +28,7 @@ struct gnx_ctx {
   std::string err;
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)
-  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair;
+  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair, ws_y0;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;

@@ -304,6 +304,19 @@ class DeviceModel:
                                                      None if f64 else B.data_ptr(), B.data_ptr() if f64 else None))
         return B
 
+    def gnofix_device(self, X_t, B_t, max_it=50):
+        """X_t (2n, C) int8 CUDA tensor re-phased IN PLACE, B_t (2n, W, A) float64 -> (labels i32 (2n, W), n_switches i32 (n,))"""
+        import torch
+        assert X_t.is_cuda and X_t.dtype == torch.int8 and X_t.stride(1) == 1
+        assert B_t.is_cuda and B_t.dtype == torch.float64 and B_t.is_contiguous()
+        self._bind_torch_stream()
+        n_ind = X_t.shape[0] // 2
+        Y = torch.empty((2 * n_ind, self.W), dtype=torch.int32, device=X_t.device)
+        ns = torch.empty((n_ind,), dtype=torch.int32, device=X_t.device)
+        self.ctx.check(self.lib.gnx_gnofix_dev(self.h, X_t.data_ptr(), X_t.stride(0), B_t.data_ptr(), n_ind, int(max_it),
+                                               Y.data_ptr(), ns.data_ptr()))
+        return Y, ns
+
     def smooth_predict_device(self, B_t):
         import torch
         assert B_t.is_cuda and B_t.is_contiguous() and B_t.dtype in (torch.float32, torch.float64)

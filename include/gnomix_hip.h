@@ -174,6 +174,8 @@ int gnx_smooth_rows(gnx_model* model, const float* rows, int64_t R, float* proba
  * n_switches (n_ind,) (may be NULL) the number of accepted switches. */
 int gnx_gnofix(gnx_model* model, int8_t* X, int64_t ldx, const double* B, int64_t n_ind, int32_t max_it,
                int32_t* Y, int32_t* n_switches);
+int gnx_gnofix_dev(gnx_model* model, int8_t* dX, int64_t ldx, const double* dB, int64_t n_ind, int32_t max_it,
+                   int32_t* dY, int32_t* d_n_switches);
 
 /* per-kernel device time, measured with hipEvents on the context stream around every launch */
 int gnx_profile_enable(gnx_ctx* ctx, int on);
