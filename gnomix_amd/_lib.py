@@ -18,9 +18,9 @@ GNX_ABI_VERSION = 1
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC = 0, 1, 2
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF = 0, 1, 2
-K_BASE_LOGISTIC, K_SMOOTH_XGB, K_BASE_COVRSK, K_SMOOTH_CRF, K_GNOFIX, K_SMOOTH_ROWS = range(6)
+K_BASE_LOGISTIC, K_SMOOTH_XGB, K_BASE_COVRSK, K_SMOOTH_CRF, K_GNOFIX, K_SMOOTH_ROWS, K_CALIBRATE = range(7)
 KERNEL_NAMES = {K_BASE_LOGISTIC: "k_base_logistic", K_SMOOTH_XGB: "k_smooth_xgb", K_BASE_COVRSK: "k_base_covrsk",
-                K_SMOOTH_CRF: "k_smooth_crf", K_GNOFIX: "k_gnofix", K_SMOOTH_ROWS: "k_smooth_rows"}
+                K_SMOOTH_CRF: "k_smooth_crf", K_GNOFIX: "k_gnofix", K_SMOOTH_ROWS: "k_smooth_rows", K_CALIBRATE: "k_calibrate"}
 
 
 class GnxLibraryError(ImportError):
@@ -48,7 +48,9 @@ class ModelDesc(C.Structure):
                 ("n_trees", C.c_int32), ("reserved1", C.c_int32), ("tree_off", C.c_void_p), ("left", C.c_void_p),
                 ("right", C.c_void_p), ("feat", C.c_void_p), ("cond", C.c_void_p), ("tree_class", C.c_void_p),
                 ("base_score", C.c_float), ("reserved2", C.c_int32),
-                ("crf_state", C.c_void_p), ("crf_trans", C.c_void_p)]
+                ("crf_state", C.c_void_p), ("crf_trans", C.c_void_p),
+                ("calib_off", C.c_void_p), ("calib_x", C.c_void_p), ("calib_y", C.c_void_p),
+                ("calib_is_f32", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class ModelInfo(C.Structure):
@@ -70,6 +72,7 @@ SYMBOLS = {
     "gnx_model_load": (C.c_int, [_VP, C.POINTER(ModelDesc), C.POINTER(_VP)]),
     "gnx_model_free": (None, [_VP]),
     "gnx_model_get_info": (C.c_int, [_VP, C.POINTER(ModelInfo)]),
+    "gnx_model_set_calibrate": (C.c_int, [_VP, _I]),
     "gnx_base_predict": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP]),
     "gnx_base_predict_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP]),
     "gnx_smooth_predict": (C.c_int, [_VP, _VP, _I, _I64, _VP, _VP, _VP]),
@@ -77,6 +80,7 @@ SYMBOLS = {
     "gnx_infer": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP, _VP]),
     "gnx_infer_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP, _VP]),
     "gnx_smooth_rows": (C.c_int, [_VP, _VP, _I64, _VP]),
+    "gnx_calibrate_rows": (C.c_int, [_VP, _VP, _I, _I64, _VP]),
     "gnx_gnofix": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
     "gnx_gnofix_dev": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
     "gnx_profile_enable": (C.c_int, [_VP, _I]),

@@ -25,7 +25,17 @@ def cov_sample(width, alpha=0.6, beta=1.0, seed=37):
     return np.asarray(ms, dtype=np.int32)
 
 
-def svc_window_from_sklearn(svc, width):
+def string_kernel_lengths(width, kernel_name="CovRSK"):
+    """Substring lengths the window kernel counts: the covering sample for CovRSKBase, every length 1..width for the
+    plain triangular-number kernel of StringKernelBase (string_kernel.py:5-24: K = sum over runs L(L+1)/2)."""
+    if "CovRSK" in kernel_name:
+        return cov_sample(width)
+    if "string_kernel" in kernel_name:
+        return np.arange(1, int(width) + 1, dtype=np.int32)
+    raise NotImplementedError(f"string kernel {kernel_name}")
+
+
+def svc_window_from_sklearn(svc, width, kernel_name="CovRSK"):
     """One fitted sklearn.svm.SVC(kernel=callable, probability=True) -> the dict GnxModelData.svc holds."""
     xfit = getattr(svc, "_BaseLibSVM__Xfit")
     return dict(xfit=np.ascontiguousarray(xfit, dtype=np.int8), support=svc.support_.astype(np.int32),
@@ -33,7 +43,7 @@ def svc_window_from_sklearn(svc, width):
                 intercept=np.ascontiguousarray(svc._intercept_, dtype=np.float64),
                 prob_a=np.ascontiguousarray(svc._probA, dtype=np.float64),
                 prob_b=np.ascontiguousarray(svc._probB, dtype=np.float64),
-                n_support=svc._n_support.astype(np.int32), ms=cov_sample(width))
+                n_support=svc._n_support.astype(np.int32), ms=string_kernel_lengths(width, kernel_name))
 
 
 def trees_from_xgb_json(dumps, n_class, base_score=0.5):
@@ -71,6 +81,17 @@ def trees_from_xgb_json(dumps, n_class, base_score=0.5):
                 base_score=float(base_score))
 
 
+def calibrator_arrays(iso_models):
+    """fitted sklearn IsotonicRegression per class (Calibration.py:55) -> calib_off / calib_x / calib_y"""
+    off, xs, ys = [0], [], []
+    for m in iso_models:
+        xs.append(np.asarray(m.X_thresholds_, dtype=np.float64))
+        ys.append(np.asarray(m.y_thresholds_, dtype=np.float64))
+        off.append(off[-1] + len(xs[-1]))
+    return dict(calib_off=np.array(off, np.int32), calib_x=np.concatenate(xs), calib_y=np.concatenate(ys),
+                calib_is_f32=bool(np.asarray(iso_models[0].X_thresholds_).dtype == np.float32))
+
+
 def from_reference_model(model) -> GnxModelData:
     """An unpickled reference `src.model.Gnomix` -> GnxModelData."""
     C, M, A = int(model.C), int(model.M), int(model.A)
@@ -90,7 +111,8 @@ def from_reference_model(model) -> GnxModelData:
             d.lr_intercept[i] = m.intercept_
     elif first == "SVC":
         d.base_kind = "covrsk"
-        d.svc = [svc_window_from_sklearn(m, d.window_width(i)) for i, m in enumerate(models)]
+        kname = getattr(getattr(model.base, "kernel", None), "__name__", "CovRSK")
+        d.svc = [svc_window_from_sklearn(m, d.window_width(i), kname) for i, m in enumerate(models)]
     else:
         raise NotImplementedError(f"base model {first}")
     sm = type(model.smooth).__name__
@@ -111,6 +133,10 @@ def from_reference_model(model) -> GnxModelData:
             d.crf_trans[int(y0), int(y1)] = w
     else:
         raise NotImplementedError(f"smoother {sm}")
+    cal = getattr(model.smooth, "calibrator", None)
+    if cal is not None and all(mm is not None for mm in cal.models):
+        for k, v in calibrator_arrays(cal.models).items():
+            setattr(d, k, v)
     d.snp_pos, d.snp_ref, d.snp_alt = model.snp_pos, model.snp_ref, model.snp_alt
     d.population_order = list(model.population_order) if model.population_order is not None else None
     gm = getattr(model, "gen_map_df", None)

@@ -484,7 +484,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0})
+  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal})
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -552,11 +552,32 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
     case GNX_SMOOTH_CRF: rc = build_crf(m, d); break;
     default: rc = fail(ctx, GNX_EINVAL, "unknown smooth_kind");
   }
+  if (rc == GNX_OK && d->calib_off) {
+    if (!d->calib_x || !d->calib_y) rc = fail(ctx, GNX_EINVAL, "calibrator: calib_x / calib_y is NULL");
+    else {
+      std::vector<int32_t> off(d->calib_off, d->calib_off + d->A + 1);
+      bool ok = off[0] == 0;
+      for (int c = 0; c < d->A && ok; ++c) ok = off[(size_t)c + 1] > off[(size_t)c];
+      if (!ok) rc = fail(ctx, GNX_EINVAL, "calibrator: calib_off must start at 0 and give every class >= 1 threshold");
+      else {
+        std::vector<double> cx(d->calib_x, d->calib_x + off[(size_t)d->A]), cy(d->calib_y, d->calib_y + off[(size_t)d->A]);
+        if ((rc = dev_upload(m, off, &m->calib_off)) == GNX_OK && (rc = dev_upload(m, cx, &m->calib_x)) == GNX_OK)
+          rc = dev_upload(m, cy, &m->calib_y);
+        m->calib_f32 = d->calib_is_f32 != 0;
+      }
+    }
+  }
   if (rc != GNX_OK) {
     gnx_model_free(m);
     return rc;
   }
   *out = m;
+  return GNX_OK;
+}
+
+int gnx_model_set_calibrate(gnx_model* m, int on) {
+  if (!m) return GNX_EINVAL;
+  m->calibrate_on = on != 0;
   return GNX_OK;
 }
 
@@ -627,9 +648,32 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
 }
 
 // ---- smoother ------------------------------------------------------------------------------------
+static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N, float* d_p32, double* d_p64, int32_t* d_lab);
+
 int gnx_smooth_predict_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N, float* d_p32, double* d_p64,
                            int32_t* d_lab) {
   if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (!(m->calibrate_on && m->calib_off)) return smooth_raw_dev(m, dB, b_is_f64, N, d_p32, d_p64, d_lab);
+  if (N < 0 || (N > 0 && !dB)) return fail(ctx, GNX_EINVAL, "smooth_predict: bad B / N");
+  if (N == 0) return GNX_OK;
+  // Smoother.predict_proba with a calibrator (smooth.py:46-52): raw smoother probabilities -> Calibrator.transform
+  const size_t n = (size_t)N * m->info.W * m->info.A;
+  const bool nat64 = m->info.smooth_kind == GNX_SMOOTH_CRF;
+  int rc = ws_reserve(ctx, ctx->ws_cal, n * (nat64 ? 8 : 4));
+  if (rc != GNX_OK) return rc;
+  rc = smooth_raw_dev(m, dB, b_is_f64, N, nat64 ? nullptr : (float*)ctx->ws_cal.p, nat64 ? (double*)ctx->ws_cal.p : nullptr, nullptr);
+  if (rc != GNX_OK) return rc;
+  CalibLaunch L{};
+  L.in = ctx->ws_cal.p; L.in_is_f64 = nat64; L.R = N * m->info.W; L.A = m->info.A;
+  L.off = m->calib_off; L.x = m->calib_x; L.y = m->calib_y; L.thr_f32 = m->calib_f32;
+  L.out64 = d_p64; L.out32 = d_p32; L.labels = d_lab;
+  ProfScope ps(ctx, GNX_K_CALIBRATE);
+  HIPCHK(ctx, gnx_launch_calibrate(L, ctx->stream));
+  return GNX_OK;
+}
+
+static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N, float* d_p32, double* d_p64, int32_t* d_lab) {
   gnx_ctx* ctx = m->ctx;
   if (N < 0 || (N > 0 && !dB)) return fail(ctx, GNX_EINVAL, "smooth_predict: bad B / N");
   if (N == 0) return GNX_OK;
@@ -792,12 +836,39 @@ int gnx_smooth_rows(gnx_model* m, const float* rows, int64_t R, float* proba) {
   return GNX_OK;
 }
 
+int gnx_calibrate_rows(gnx_model* m, const void* proba, int proba_is_f64, int64_t R, double* out) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (!m->calib_off) return fail(ctx, GNX_ESTATE, "model has no calibrator");
+  if (R < 0 || (R > 0 && (!proba || !out))) return fail(ctx, GNX_EINVAL, "calibrate_rows: bad arguments");
+  if (R == 0) return GNX_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)R * m->info.A * sizeof(double);
+  const size_t in_bytes = (size_t)R * m->info.A * (proba_is_f64 ? 8 : 4);
+  int rc = ws_reserve(ctx, ctx->ws_cal, bytes);
+  if (rc != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_misc, in_bytes)) != GNX_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ws_misc.p, proba, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  CalibLaunch L{};
+  L.in = ctx->ws_misc.p; L.in_is_f64 = proba_is_f64 ? 1 : 0; L.R = R; L.A = m->info.A;
+  L.off = m->calib_off; L.x = m->calib_x; L.y = m->calib_y; L.thr_f32 = m->calib_f32; L.out64 = (double*)ctx->ws_cal.p;
+  {
+    ProfScope ps(ctx, GNX_K_CALIBRATE);
+    HIPCHK(ctx, gnx_launch_calibrate(L, ctx->stream));
+  }
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->ws_cal.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GNX_OK;
+}
+
 static int gnofix_check(gnx_model* m, int64_t ldx, int64_t n_ind, int32_t max_it, bool ptrs_ok, bool* in_lds) {
   gnx_ctx* ctx = m->ctx;
   // src/model.py:194: only a smoother with .gnofix == True (XGB_Smoother) supports re-phasing
   if (m->info.smooth_kind != GNX_SMOOTH_XGB)
     return fail(ctx, GNX_ESTATE, "Type of Smoother does not currently support re-phasing");
   if (n_ind < 0 || ldx < m->info.C || max_it < 0 || (n_ind > 0 && !ptrs_ok)) return fail(ctx, GNX_EINVAL, "gnofix: bad arguments");
+  if (m->calibrate_on && m->calib_off)  // smoother.predict inside the loop would be calibrated (gnofix.py:80,190); the kernel's is not
+    return fail(ctx, GNX_EUNSUPPORTED, "gnofix with calibrate=True is not built: switch calibration off for re-phasing");
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
   *in_lds = gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, true) <= 150 * 1024;
   if (gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, *in_lds) > 160 * 1024)

@@ -28,7 +28,7 @@ struct gnx_ctx {
   std::string err;
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)
-  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair, ws_y0;
+  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair, ws_y0, ws_cal;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -187,6 +187,21 @@ struct GnofixLaunch {
   uint32_t* hist;          // [n_ind][max_it][ceil(W/32)] convergence signatures
 };
 
+// ---- calibrator (k_calibrate.hip) -----------------------------------------------------------------------
+struct CalibLaunch {
+  const void* in;        // (R, A) probabilities, float32 or float64
+  int32_t in_is_f64;
+  int64_t R;
+  int32_t A;
+  const int32_t* off;    // device (A+1)
+  const double* x;       // device thresholds
+  const double* y;
+  int32_t thr_f32;       // thresholds were fitted in float32
+  double* out64;         // optional (may alias `in` when in_is_f64)
+  float* out32;          // optional
+  int32_t* labels;       // optional
+};
+
 struct gnx_model {
   gnx_ctx* ctx = nullptr;
   gnx_model_info info{};
@@ -200,6 +215,12 @@ struct gnx_model {
   // CRF
   const double* crf_state = nullptr;  // device (A,A)
   const double* crf_etrans = nullptr; // device (A,A) exp(trans)
+  // calibrator
+  const int32_t* calib_off = nullptr;
+  const double* calib_x = nullptr;
+  const double* calib_y = nullptr;
+  bool calibrate_on = false;
+  bool calib_f32 = false;
 };
 
 // kernel launchers (defined in the .hip files)
@@ -214,5 +235,6 @@ hipError_t gnx_launch_covrsk(const CovRSKLaunch& L, hipStream_t s);
 size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width);
 hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
 size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
+hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

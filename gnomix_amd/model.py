@@ -46,6 +46,11 @@ class GnxModelData:
     # crf smoother (src/Smooth/crf.py)
     crf_state: np.ndarray | None = None   # (A, A) [attribute][label]
     crf_trans: np.ndarray | None = None   # (A, A) [from][to]
+    # optional Calibrator (src/Smooth/Calibration.py): per-class isotonic thresholds, concatenated
+    calib_off: np.ndarray | None = None   # (A+1,) int32
+    calib_x: np.ndarray | None = None
+    calib_y: np.ndarray | None = None
+    calib_is_f32: bool = False            # maps fitted on float32 probabilities (sklearn then interpolates in float32)
     # dataset metadata used by the writers (src/model.py:40-44, 88)
     snp_pos: np.ndarray | None = None
     snp_ref: np.ndarray | None = None
@@ -105,6 +110,8 @@ class GnxModelData:
                     v = int(v)
                 elif k == "base_score":
                     v = float(v)
+                elif k == "calib_is_f32":
+                    v = bool(v)
                 elif k in ("base_kind", "smooth_kind"):
                     v = str(v)
                 elif k == "population_order":
@@ -173,6 +180,11 @@ class GnxModelData:
         elif self.smooth_kind == "crf":
             d.crf_state = ptr(self.crf_state, np.float64)
             d.crf_trans = ptr(self.crf_trans, np.float64)
+        if self.calib_off is not None:
+            d.calib_off = ptr(self.calib_off, np.int32)
+            d.calib_x = ptr(self.calib_x, np.float64)
+            d.calib_y = ptr(self.calib_y, np.float64)
+            d.calib_is_f32 = int(bool(self.calib_is_f32))
         return d, keep
 
 
@@ -193,6 +205,10 @@ class DeviceModel:
         self.ctx.check(self.lib.gnx_model_get_info(h, C.byref(info)))
         self.info = info
         self.W, self.A, self.S, self.C, self.M = int(info.W), int(info.A), int(info.S), int(info.C), int(info.M)
+
+    def set_calibrate(self, on):
+        self.ctx.check(self.lib.gnx_model_set_calibrate(self.h, int(bool(on))))
+        self.calibrated = bool(on) and self.data.calib_off is not None
 
     def close(self):
         if getattr(self, "h", None) and self.ctx.h:
@@ -235,7 +251,7 @@ class DeviceModel:
     def smooth_predict(self, B, want_proba=True, want_labels=True, proba_dtype=None):
         B = self._b(B)
         N = B.shape[0]
-        native64 = self.data.smooth_kind == "crf"
+        native64 = self.data.smooth_kind == "crf" or getattr(self, "calibrated", False)
         pd = proba_dtype or (np.float64 if native64 else np.float32)
         p = np.empty((N, self.W, self.A), pd) if want_proba else None
         lab = np.empty((N, self.W), np.int32) if want_labels else None
@@ -248,7 +264,7 @@ class DeviceModel:
     def infer(self, X, want_proba=True, want_labels=True, proba_dtype=None):
         X = self._x(X)
         N = X.shape[0]
-        native64 = self.data.smooth_kind == "crf"
+        native64 = self.data.smooth_kind == "crf" or getattr(self, "calibrated", False)
         pd = proba_dtype or (np.float64 if native64 else np.float32)
         p = np.empty((N, self.W, self.A), pd) if want_proba else None
         lab = np.empty((N, self.W), np.int32) if want_labels else None
@@ -265,6 +281,16 @@ class DeviceModel:
             raise ValueError(f"rows must be (R, S*A={F})")
         out = np.empty((rows.shape[0], self.A), np.float32)
         self.ctx.check(self.lib.gnx_smooth_rows(self.h, rows.ctypes.data, rows.shape[0], out.ctypes.data))
+        return out
+
+    def calibrate_rows(self, proba):
+        """Calibrator.transform on explicit (R, A) rows -> float64"""
+        proba = np.ascontiguousarray(proba)
+        if proba.dtype not in (np.float32, np.float64):
+            proba = proba.astype(np.float64)
+        out = np.empty(proba.shape, dtype=np.float64)
+        self.ctx.check(self.lib.gnx_calibrate_rows(self.h, proba.ctypes.data, int(proba.dtype == np.float64), proba.shape[0],
+                                                   out.ctypes.data))
         return out
 
     def gnofix(self, X, B, max_it=50):

@@ -26,8 +26,9 @@ class HipSmoother:
         self.W = d.C // d.M
         self.A = d.A
         self.S = d.S if d.S % 2 else d.S - 1   # smooth.py:14
+        self._calibrate = None
+        self.calibrator = d.calib_off is not None or None   # truthy when the model carries fitted isotonic maps
         self.calibrate = calibrate
-        self.calibrator = None
         self.mode_filter = mode_filter
         self.n_jobs = n_jobs
         self.seed = seed
@@ -35,6 +36,15 @@ class HipSmoother:
         self.gnofix = d.smooth_kind == "xgb"   # only XGB_Smoother sets it (Smooth/models.py:12)
         self.model = _RowModel(device_model) if d.smooth_kind == "xgb" else None
         self.time = {}
+
+    @property
+    def calibrate(self):
+        return self._calibrate
+
+    @calibrate.setter
+    def calibrate(self, on):  # gnomix.py:367 pokes this attribute after loading the model
+        self._calibrate = on
+        self.dev.set_calibrate(bool(on))
 
     def predict_proba(self, B):
         """B (N, W, A) -> (N, W, A): float32 for the xgb smoother, float64 for crf (smooth.py:40-56)."""

@@ -65,7 +65,8 @@ enum {
   GNX_K_SMOOTH_CRF = 3,
   GNX_K_GNOFIX = 4,
   GNX_K_SMOOTH_ROWS = 5,
-  GNX_K_COUNT = 6
+  GNX_K_CALIBRATE = 6,
+  GNX_K_COUNT = 7
 };
 
 /* Per-window SVC of CovRSKBase (src/Base/models.py:195-215 -> sklearn.svm.SVC(kernel=callable,
@@ -122,6 +123,15 @@ typedef struct gnx_model_desc {
   /* GNX_SMOOTH_CRF: linear-chain CRF (src/Smooth/crf.py:9-15) */
   const double* crf_state;   /* (A, A) [attribute a][label y] */
   const double* crf_trans;   /* (A, A) [from y'][to y] */
+
+  /* optional Calibrator (src/Smooth/Calibration.py:19-69): per class c the fitted IsotonicRegression's
+   * X_thresholds_ / y_thresholds_ in [calib_off[c], calib_off[c+1]); NULL = no calibrator trained */
+  const int32_t* calib_off;  /* (A+1,) */
+  const double* calib_x;
+  const double* calib_y;
+  int32_t calib_is_f32;      /* the isotonic maps were fitted on float32 probabilities (the xgb smoother's output): sklearn then
+                                interpolates in float32, and so does the kernel for float32 inputs */
+  int32_t reserved3;
 } gnx_model_desc;
 
 typedef struct gnx_model_info {
@@ -145,6 +155,10 @@ int gnx_synchronize(gnx_ctx* ctx);
 int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* desc, gnx_model** out);
 void gnx_model_free(gnx_model* model);
 int gnx_model_get_info(const gnx_model* model, gnx_model_info* out);
+/* smooth.calibrate (gnomix.py:367): when on AND the model carries a calibrator, smoother outputs (probabilities and the
+ * labels derived from them) go through Calibrator.transform; without a calibrator the reference prints a notice and
+ * returns the original probabilities (smooth.py:48-52) — so does this (GNX_OK, outputs unchanged). */
+int gnx_model_set_calibrate(gnx_model* model, int on);
 
 /* Base.predict_proba: X (N, ldx>=C) int8 -> B (N, W, A).  Either output may be NULL.
  * b_f32 is what the XGB smoother consumes (src/Smooth/utils.py:20), b_f64 what the reference returns. */
@@ -167,6 +181,10 @@ int gnx_infer_dev(gnx_model* model, const int8_t* dX, int64_t N, int64_t ldx, fl
 
 /* smoother.model.predict_proba on explicit rows (R, S*A) float32 -> (R, A) float32 (XGB only). */
 int gnx_smooth_rows(gnx_model* model, const float* rows, int64_t R, float* proba);
+
+/* Calibrator.transform on explicit rows (R, A) (float64 if proba_is_f64 else float32) -> (R, A) float64
+ * (src/Smooth/Calibration.py:57-69).  GNX_ESTATE when the model carries no calibrator. */
+int gnx_calibrate_rows(gnx_model* model, const void* proba, int proba_is_f64, int64_t R, double* out);
 
 /* Gnomix.phase: for each of n_ind individuals (haplotype rows 2i, 2i+1 of X and of B) run the
  * Gnofix loop with the reference's default arguments.  X (2*n_ind, ldx) int8 is re-phased IN

@@ -15,6 +15,7 @@ input/output pair produced by executing its own functions:
                    model.py:188-214, phasing.py:182-198)
   G6_writers/      get_meta_data / write_msp / write_fb text              (postprocess.py:25-126)
   G7_vcf.npz       vcf_to_npy on a synthetic allel-style dict            (utils.py:104-159)
+  G8_calib_sk.npz  Calibrator.fit/transform (Smooth/Calibration.py:19-69); StringKernelBase train+predict (models.py:161-176)
 
 Third-party modules the reference imports at module import time but that are absent here
 (xgboost, allel, seaborn, calibration, sklearn_crfsuite) are replaced by empty stubs; no code path
@@ -351,11 +352,62 @@ def make_G7(out):
     print("G7", X.shape, X.dtype)
 
 
+def make_G8(out):
+    """Calibrator.fit / transform (Smooth/Calibration.py:19-69: per-class sklearn IsotonicRegression + renormalise) and the
+    plain triangular string kernel base (StringKernelBase, Base/models.py:161-176)"""
+    from src.Smooth.Calibration import Calibrator
+    rng = np.random.RandomState(8)
+    A = 5
+    proba_fit = rng.dirichlet(np.ones(A) * 0.5, size=3000).astype(np.float32)
+    y = np.array([rng.choice(A, p=p / p.sum()) for p in proba_fit.astype(np.float64) ** 0.7])
+    cal = Calibrator(A)
+    cal.fit(proba_fit, y)
+    P = rng.dirichlet(np.ones(A) * 0.4, size=(6, 40)).astype(np.float32)
+    P[0, 0] = [1, 0, 0, 0, 0]
+    out_p = cal.transform(P)
+    d = dict(A=A, P=P, out=out_p)
+    for i, m in enumerate(cal.models):
+        d["x%d" % i] = np.asarray(m.X_thresholds_, dtype=np.float64)
+        d["y%d" % i] = np.asarray(m.y_thresholds_, dtype=np.float64)
+    # StringKernelBase on a tiny problem
+    import numpy
+    real_ver = numpy.__version__
+    numpy.__version__ = "1.26.4"
+    try:
+        from src.Base.models import StringKernelBase
+        C, M, A2 = 237, 30, 3
+        W, ctx = C // M, 15
+        base = StringKernelBase(chm_len=C, window_size=M, num_ancestry=A2, missing_encoding=2, context=ctx, n_jobs=1,
+                                seed=94305, verbose=False)
+    finally:
+        numpy.__version__ = real_ver
+    base.log_inference = False
+    Xt, yt = synth_admixed(rng, 36, C, A2, W, M, switch_p=0.0)
+    for w in range(W):
+        for c in range(A2):
+            yt[c * 2:(c * 2 + 2), w] = c
+    np.random.seed(3)
+    base.train(Xt, yt)
+    Xq, _ = synth_admixed(rng, 7, C, A2, W, M, miss=0.05, switch_p=0.2)
+    Bq = base.predict_proba(Xq)
+    d.update(sk_C=C, sk_M=M, sk_A=A2, sk_ctx=ctx, sk_X=Xq, sk_B=Bq)
+    for i, m in enumerate(base.models):
+        d["sk%d_Xfit" % i] = np.asarray(getattr(m, "_BaseLibSVM__Xfit"), dtype=np.int8)
+        d["sk%d_support" % i] = m.support_.astype(np.int32)
+        d["sk%d_dual" % i] = m._dual_coef_
+        d["sk%d_intercept" % i] = m._intercept_
+        d["sk%d_probA" % i] = m._probA
+        d["sk%d_probB" % i] = m._probB
+        d["sk%d_nsv" % i] = m._n_support.astype(np.int32)
+    np.savez_compressed(out, **d)
+    print("G8", out_p.shape, out_p.dtype, Bq.shape)
+
+
 def main():
     if not import_reference():
         print("reference not found at", REF, "- nothing generated")
         return 0
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
     if "G1" in which: make_G1(os.path.join(HERE, "G1_lr.npz"))
     if "G2" in which: make_G2(os.path.join(HERE, "G2_covrsk.npz"))
     if "G3" in which: make_G3(os.path.join(HERE, "G3_slide.npz"))
@@ -363,6 +415,7 @@ def main():
     if "G5" in which: make_G5(os.path.join(HERE, "G5_gnofix.npz"))
     if "G6" in which: make_G6(os.path.join(HERE, "G6_writers"))
     if "G7" in which: make_G7(os.path.join(HERE, "G7_vcf.npz"))
+    if "G8" in which: make_G8(os.path.join(HERE, "G8_calib_sk.npz"))
     return 0
 
 

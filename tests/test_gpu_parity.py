@@ -475,3 +475,60 @@ def test_gnofix_strips_in_global_scratch(ga, oracle):
         assert np.array_equal(Xo[2 * i], Xm) and np.array_equal(Xo[2 * i + 1], Xp)
         assert np.array_equal(Y[2 * i], Ym) and np.array_equal(Y[2 * i + 1], Yp) and int(nsw[i]) == ns
     assert int(nsw.sum()) > 0
+
+
+# ---------------------------------------------------------------- calibrator, plain string kernel -------
+def test_calibrator_golden_G8(ga, oracle):
+    """Smoother.predict_proba with calibrate=True: raw smoother output -> the reference's Calibrator.transform"""
+    from gnomix_amd import synth
+    g = load_golden("G8_calib_sk.npz")
+    A = int(g["A"])
+    N, W, _ = g["P"].shape
+    # a smoother whose raw output is exactly P: CRF with zero transitions and identity-log state weights is awkward, so
+    # drive the calibration stage directly through an xgb model with ONE depth-1 tree per class is not exact either ->
+    # use the CRF smoother with state = 0, trans = 0 on B: marginals are uniform; instead test the kernel via the
+    # ABI's own composition: smooth_predict on a model whose trees are all zero-leaf gives uniform margins, not P.
+    # The direct route: calibrate_only through a tiny model whose smoother is the identity on one-hot-free inputs does not
+    # exist in the reference either, so the golden pins k_calibrate through DeviceModel.calibrate_rows.
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=5, context=5, smooth_kind="crf", crf_state=np.zeros((A, A)), crf_trans=np.zeros((A, A)))
+    off = [0]
+    for i in range(A):
+        off.append(off[-1] + len(g["x%d" % i]))
+    d.calib_off = np.array(off, np.int32)
+    d.calib_x = np.concatenate([g["x%d" % i] for i in range(A)])
+    d.calib_y = np.concatenate([g["y%d" % i] for i in range(A)])
+    d.calib_is_f32 = True    # fitted on float32 probabilities (make_golden.py)
+    dev = ga.DeviceModel(d)
+    out = dev.calibrate_rows(g["P"].reshape(-1, A)).reshape(N, W, A)
+    assert out.dtype == np.float64
+    assert np.max(np.abs(out - g["out"])) < 1e-12       # vs the REFERENCE's Calibrator.transform (numpy >= 2 float64 path)
+    assert np.allclose(out.sum(-1), 1.0, atol=1e-12)
+    # end to end: calibrate on -> uniform CRF marginals (state = trans = 0) go through the same maps
+    sm = ga.HipSmoother(dev, calibrate=True)
+    B = np.random.RandomState(0).dirichlet(np.ones(A), size=(3, W))
+    p = sm.predict_proba(B)
+    want = dev.calibrate_rows(np.full((3 * W, A), 1.0 / A)).reshape(3, W, A)
+    assert p.dtype == np.float64 and np.max(np.abs(p - want)) < 1e-12
+    assert np.array_equal(sm.predict(B), np.argmax(want, -1))
+    sm.calibrate = False
+    assert np.allclose(sm.predict_proba(B), 1.0 / A, atol=1e-12)
+
+
+def test_string_kernel_base_golden_G8(ga, oracle):
+    """StringKernelBase (plain triangular-number kernel = every substring length) through the generic run kernel"""
+    from gnomix_amd import convert
+    g = load_golden("G8_calib_sk.npz")
+    C, M, A, ctx = int(g["sk_C"]), int(g["sk_M"]), int(g["sk_A"]), int(g["sk_ctx"])
+    W = C // M
+    d = ga.GnxModelData(C=C, M=M, A=A, S=5, context=ctx, base_kind="covrsk")
+    d.svc = []
+    for i in range(W):
+        xf = g["sk%d_Xfit" % i]
+        d.svc.append(dict(xfit=xf, support=g["sk%d_support" % i], dual_coef=g["sk%d_dual" % i], intercept=g["sk%d_intercept" % i],
+                          prob_a=g["sk%d_probA" % i], prob_b=g["sk%d_probB" % i], n_support=g["sk%d_nsv" % i],
+                          ms=convert.string_kernel_lengths(xf.shape[1], "string_kernel_DP_triangular_numbers")))
+    dev = ga.DeviceModel(d)
+    _, b64 = dev.base_predict(g["sk_X"])
+    assert np.max(np.abs(b64 - g["sk_B"])) < 1e-12      # vs the REFERENCE's StringKernelBase.predict_proba
+    K = oracle.string_kernel(np.zeros((1, 8), np.int8), np.zeros((1, 8), np.int8))
+    assert K[0, 0] == 36
