@@ -349,6 +349,110 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// model preparation: forest base — per-window xgboost-schema trees -> per-window class-major complete heaps
+// ------------------------------------------------------------------------------------------------
+static int forest_depth(const gnx_model_desc* d, int32_t o, int32_t nid, int32_t n_nodes, int guard) {
+  if (guard > 64 || nid < 0 || nid >= n_nodes) return -1000;
+  if (d->fb_left[o + nid] == -1) return 0;
+  const int l = forest_depth(d, o, d->fb_left[o + nid], n_nodes, guard + 1);
+  const int r = forest_depth(d, o, d->fb_right[o + nid], n_nodes, guard + 1);
+  if (l < 0 || r < 0) return -1000;
+  return 1 + std::max(l, r);
+}
+
+static void forest_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint8_t* out) {
+  const uint32_t half = 1u << (D - 1);
+  const bool leaf = d->fb_left[o + nid] == -1;
+  const float inf = std::numeric_limits<float>::infinity();
+  // early leaf: dummy split on SNP 0 with threshold +inf and default-left: every value (missing or not) goes left
+  uint32_t fw = 0x80000000u;
+  float thr = inf;
+  if (!leaf) {
+    fw = (uint32_t)d->fb_feat[o + nid] | ((d->fb_default_left && d->fb_default_left[o + nid]) ? 0x80000000u : 0u);
+    thr = d->fb_cond[o + nid];
+  }
+  if (depth == D - 1) {
+    float ll, lr;
+    if (leaf) ll = lr = d->fb_cond[o + nid];
+    else {
+      const int32_t cl = d->fb_left[o + nid], cr = d->fb_right[o + nid];
+      ll = d->fb_cond[o + cl];
+      lr = d->fb_cond[o + cr];
+    }
+    uint8_t* p = out + (size_t)(j - half) * 16;
+    std::memcpy(p, &fw, 4); std::memcpy(p + 4, &thr, 4); std::memcpy(p + 8, &ll, 4); std::memcpy(p + 12, &lr, 4);
+    return;
+  }
+  uint8_t* p = out + (size_t)half * 16 + (size_t)(j - 1) * 8;
+  std::memcpy(p, &fw, 4); std::memcpy(p + 4, &thr, 4);
+  forest_fill(d, o, leaf ? nid : d->fb_left[o + nid], 2 * j, depth + 1, D, out);
+  forest_fill(d, o, leaf ? nid : d->fb_right[o + nid], 2 * j + 1, depth + 1, D, out);
+}
+
+static int build_forest(gnx_model* m, const gnx_model_desc* d) {
+  gnx_ctx* ctx = m->ctx;
+  const int A = d->A;
+  const int64_t C = d->C, M = d->M, W = C / M, rem = C - M * W, M_ = M + 2 * d->ctx;
+  if (d->fb_n_trees <= 0 || !d->fb_win_tree0 || !d->fb_tree_off || !d->fb_left || !d->fb_right || !d->fb_feat || !d->fb_cond)
+    return fail(ctx, GNX_EINVAL, "forest base: tree arrays missing");
+  if (A > 2 && !d->fb_tree_class) return fail(ctx, GNX_EINVAL, "forest base: fb_tree_class is NULL");
+  if (d->fb_missing < 0 || d->fb_missing > 3) return fail(ctx, GNX_EINVAL, "forest base: missing code must be in [0, 3]");
+  if (!(d->fb_base_score > 0.f && d->fb_base_score < 1.f) && A == 2)
+    return fail(ctx, GNX_EINVAL, "forest base: binary:logistic needs base_score in (0, 1)");
+  if (d->fb_win_tree0[0] != 0 || d->fb_win_tree0[W] != d->fb_n_trees)
+    return fail(ctx, GNX_EINVAL, "forest base: fb_win_tree0 must run from 0 to fb_n_trees");
+  int D = 1, max_trees = 0;
+  for (int64_t w = 0; w < W; ++w) {
+    const int32_t t0 = d->fb_win_tree0[w], t1 = d->fb_win_tree0[w + 1];
+    if (t1 < t0) return fail(ctx, GNX_EINVAL, "forest base: fb_win_tree0 not monotone");
+    max_trees = std::max(max_trees, t1 - t0);
+    const int64_t width = (w == W - 1) ? M_ + rem : M_;
+    for (int32_t t = t0; t < t1; ++t) {
+      const int32_t o = d->fb_tree_off[t], nn = d->fb_tree_off[t + 1] - o;
+      if (nn <= 0) return fail(ctx, GNX_EINVAL, "forest base: empty tree");
+      const int dep = forest_depth(d, o, 0, nn, 0);
+      if (dep < 0) return fail(ctx, GNX_EINVAL, "forest base: malformed tree (child index out of range or depth > 64)");
+      D = std::max(D, dep);
+      if (A > 2 && (d->fb_tree_class[t] < 0 || d->fb_tree_class[t] >= A))
+        return fail(ctx, GNX_EINVAL, "forest base: fb_tree_class out of range");
+      for (int32_t k = 0; k < nn; ++k)
+        if (d->fb_left[o + k] != -1 && (d->fb_feat[o + k] < 0 || d->fb_feat[o + k] >= width))
+          return fail(ctx, GNX_EINVAL, "forest base: split feature outside the window's padded slice");
+    }
+  }
+  if (D > 8) return fail(ctx, GNX_EUNSUPPORTED, "forest base: tree depth > 8");
+  const int tree_bytes = gnx_tree_bytes(D);
+  const int max_words = (int)((M_ + rem + 15) / 16) + 1;
+  if (gnx_forest_lds_bytes(A, max_words, max_trees, tree_bytes, 64) > (size_t)160 * 1024)
+    return fail(ctx, GNX_EUNSUPPORTED, "forest base: one window's trees and SNPs exceed the 160 KB LDS");
+
+  std::vector<uint8_t> packed((size_t)d->fb_n_trees * tree_bytes, 0);
+  std::vector<int32_t> win_tree0(d->fb_win_tree0, d->fb_win_tree0 + W + 1);
+  std::vector<int32_t> wct((size_t)W * (A + 1), 0);
+  size_t k = 0;
+  for (int64_t w = 0; w < W; ++w) {
+    const int32_t t0 = win_tree0[(size_t)w], t1 = win_tree0[(size_t)w + 1];
+    int32_t* ct = wct.data() + (size_t)w * (A + 1);
+    for (int c = 0; c < (A == 2 ? 1 : A); ++c) {
+      ct[c] = (int32_t)(k - (size_t)t0);
+      for (int32_t t = t0; t < t1; ++t) {
+        if (A > 2 && d->fb_tree_class[t] != c) continue;
+        forest_fill(d, d->fb_tree_off[t], 0, 1, 0, D, packed.data() + k * tree_bytes);
+        ++k;
+      }
+    }
+    for (int c = (A == 2 ? 1 : A); c <= A; ++c) ct[c] = t1 - t0;
+  }
+  int rc;
+  if ((rc = dev_upload(m, packed, &m->forest.packed, 64)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, win_tree0, &m->forest.win_tree0)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, wct, &m->forest.win_class_tree0)) != GNX_OK) return rc;
+  m->forest.D = D; m->forest.tree_bytes = tree_bytes; m->forest.max_trees = max_trees; m->forest.max_words = max_words;
+  m->forest.missing = d->fb_missing; m->forest.base_score = d->fb_base_score;
+  return GNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // model preparation: CovRSK / SVC base — support vectors as bit-planes, run-length table g
 // ------------------------------------------------------------------------------------------------
 static int build_covrsk(gnx_model* m, const gnx_model_desc* d) {
@@ -541,6 +645,7 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
     case GNX_BASE_NONE: break;
     case GNX_BASE_LOGISTIC: rc = build_lr(m, d); break;
     case GNX_BASE_COVRSK_SVC: rc = build_covrsk(m, d); break;
+    case GNX_BASE_FOREST: rc = build_forest(m, d); break;
     default: rc = fail(ctx, GNX_EINVAL, "unknown base_kind");
   }
   if (rc == GNX_OK) switch (d->smooth_kind) {
@@ -622,6 +727,24 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
       L.rpair_haps = haps;
     }
     HIPCHK(ctx, gnx_launch_covrsk(L, ctx->stream));
+    return GNX_OK;
+  }
+  if (m->info.base_kind == GNX_BASE_FOREST) {
+    const int64_t Cp = m->info.C + 2 * m->info.ctx, nwq = (Cp + 15) / 16 + 2;
+    int rc = ws_reserve(ctx, ctx->ws_bits, (size_t)N * nwq * 4);
+    if (rc != GNX_OK) return rc;
+    ProfScope ps(ctx, GNX_K_BASE_FOREST);
+    HIPCHK(ctx, gnx_launch_pack2(dX, N, ldx, m->info.C, m->info.ctx, nwq, (uint32_t*)ctx->ws_bits.p, ctx->stream));
+    ForestLaunch L{};
+    L.q = (const uint32_t*)ctx->ws_bits.p; L.N = N; L.nwq = nwq; L.M = m->info.M;
+    L.width = m->info.M + 2 * m->info.ctx;
+    L.width_last = L.width + (m->info.C - m->info.M * m->info.W);
+    L.W = (int32_t)m->info.W; L.A = m->info.A; L.D = m->forest.D; L.tree_bytes = m->forest.tree_bytes;
+    L.max_trees = m->forest.max_trees; L.max_words = m->forest.max_words; L.missing = m->forest.missing;
+    L.base_score = m->forest.base_score;
+    L.packed = m->forest.packed; L.win_tree0 = m->forest.win_tree0; L.win_class_tree0 = m->forest.win_class_tree0;
+    L.b32 = d_b32; L.b64 = d_b64;
+    HIPCHK(ctx, gnx_launch_base_forest(L, ctx->stream));
     return GNX_OK;
   }
   if (m->info.base_kind != GNX_BASE_LOGISTIC) return fail(ctx, GNX_ESTATE, "model has no base classifier");

@@ -202,6 +202,29 @@ struct CalibLaunch {
   int32_t* labels;       // optional
 };
 
+// ---- forest base (k_base_forest.hip) ------------------------------------------------------------------
+// Trees use the smoother's packed complete-heap layout, except that the first word of a node is
+// (default_left << 31) | SNP index within the window instead of a byte offset.
+struct ForestDev {
+  const uint8_t* packed = nullptr;          // fb_n_trees * tree_bytes, per window class-major
+  const int32_t* win_tree0 = nullptr;       // [W+1]
+  const int32_t* win_class_tree0 = nullptr; // [W][A+1] class ranges relative to the window's first tree
+  int32_t D = 0, tree_bytes = 0, max_trees = 0, max_words = 0, missing = 2;
+  float base_score = 0.5f;
+};
+
+struct ForestLaunch {
+  const uint32_t* q;  // (N, nwq) 2-bit packed padded X
+  int64_t N, nwq, M, width, width_last;
+  int32_t W, A, D, tree_bytes, max_trees, max_words, missing;
+  float base_score;
+  const uint8_t* packed;
+  const int32_t* win_tree0;
+  const int32_t* win_class_tree0;
+  float* b32;
+  double* b64;
+};
+
 struct gnx_model {
   gnx_ctx* ctx = nullptr;
   gnx_model_info info{};
@@ -210,6 +233,7 @@ struct gnx_model {
   bool lr_i8 = true;
   SmoothXGBDev xgb;
   CovRSKDev svc;
+  ForestDev forest;
   // class-major xgboost-schema copy for the rows kernel
   const int32_t* class_tree0 = nullptr;  // device [A+1]
   // CRF
@@ -237,4 +261,8 @@ hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s
 size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
 hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
+hipError_t gnx_launch_pack2(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwq, uint32_t* q,
+                            hipStream_t s);
+hipError_t gnx_launch_base_forest(const ForestLaunch& L, hipStream_t s);
+size_t gnx_forest_lds_bytes(int A, int max_words, int max_trees, int tree_bytes, int threads);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

@@ -28,13 +28,24 @@ class GnxModelData:
     A: int
     S: int = 75
     context: int = 0                      # SNPs each side = int(M*context_ratio) (src/model.py:47)
-    base_kind: str | None = None          # "logistic" | "covrsk"
+    base_kind: str | None = None          # "logistic" | "covrsk" | "forest"
     smooth_kind: str | None = None        # "xgb" | "crf"
     # logistic base: coef_ / intercept_ of LogisticRegression per window (src/Base/models.py:12-21)
     lr_coef: np.ndarray | None = None     # (W, A, ldc) float64, window i uses [:, :width_i]
     lr_intercept: np.ndarray | None = None  # (W, A)
     # CovRSK base: per-window fitted SVC (src/Base/models.py:195-215)
     svc: list | None = None               # list of dicts: xfit, support, dual_coef, intercept, prob_a, prob_b, n_support, ms
+    # forest base: per-window XGBClassifier (src/Base/models.py:24-35), xgboost model schema, all windows concatenated
+    fb_win_tree0: np.ndarray | None = None   # (W+1,) first tree of each window
+    fb_tree_off: np.ndarray | None = None
+    fb_left: np.ndarray | None = None
+    fb_right: np.ndarray | None = None
+    fb_feat: np.ndarray | None = None        # SNP index within the window's padded slice
+    fb_cond: np.ndarray | None = None
+    fb_default_left: np.ndarray | None = None
+    fb_tree_class: np.ndarray | None = None
+    fb_base_score: float = 0.5
+    fb_missing: int = 2                      # missing_encoding (src/Base/base.py:25)
     # xgb smoother in xgboost's model schema (src/Smooth/models.py:14-20)
     tree_off: np.ndarray | None = None
     left: np.ndarray | None = None
@@ -106,9 +117,9 @@ class GnxModelData:
         for k in cls.__dataclass_fields__:
             if k in z.files:
                 v = z[k]
-                if k in ("C", "M", "A", "S", "context"):
+                if k in ("C", "M", "A", "S", "context", "fb_missing"):
                     v = int(v)
-                elif k == "base_score":
+                elif k in ("base_score", "fb_base_score"):
                     v = float(v)
                 elif k == "calib_is_f32":
                     v = bool(v)
@@ -138,7 +149,8 @@ class GnxModelData:
         d = _lib.ModelDesc()
         d.abi_version = _lib.GNX_ABI_VERSION
         d.A, d.C, d.M, d.ctx, d.S = int(self.A), int(self.C), int(self.M), int(self.context), int(self.S)
-        d.base_kind = {None: _lib.BASE_NONE, "logistic": _lib.BASE_LOGISTIC, "covrsk": _lib.BASE_COVRSK_SVC}[self.base_kind]
+        d.base_kind = {None: _lib.BASE_NONE, "logistic": _lib.BASE_LOGISTIC, "covrsk": _lib.BASE_COVRSK_SVC,
+                       "forest": _lib.BASE_FOREST}[self.base_kind]
         d.smooth_kind = {None: _lib.SMOOTH_NONE, "xgb": _lib.SMOOTH_XGB, "crf": _lib.SMOOTH_CRF}[self.smooth_kind]
         W, A = self.W, self.A
         if self.base_kind == "logistic":
@@ -168,6 +180,23 @@ class GnxModelData:
                 s.ms, s.n_ms = ptr(ms, np.int32), len(ms)
             keep.append(arr)
             d.svc = C.addressof(arr)
+        elif self.base_kind == "forest":
+            wt0 = _c(self.fb_win_tree0, np.int32)
+            if wt0.shape != (W + 1,):
+                raise ValueError("fb_win_tree0 must be (W+1,)")
+            d.fb_n_trees = len(self.fb_tree_off) - 1
+            d.fb_missing = int(self.fb_missing)
+            d.fb_win_tree0 = ptr(wt0, np.int32)
+            d.fb_tree_off = ptr(self.fb_tree_off, np.int32)
+            d.fb_left = ptr(self.fb_left, np.int32)
+            d.fb_right = ptr(self.fb_right, np.int32)
+            d.fb_feat = ptr(self.fb_feat, np.int32)
+            d.fb_cond = ptr(self.fb_cond, np.float32)
+            dl = self.fb_default_left if self.fb_default_left is not None else np.zeros(len(self.fb_left), np.uint8)
+            d.fb_default_left = ptr(dl, np.uint8)
+            tc = self.fb_tree_class if self.fb_tree_class is not None else np.zeros(d.fb_n_trees, np.int32)
+            d.fb_tree_class = ptr(tc, np.int32)
+            d.fb_base_score = float(self.fb_base_score)
         if self.smooth_kind == "xgb":
             d.n_trees = self.n_trees
             d.tree_off = ptr(self.tree_off, np.int32)

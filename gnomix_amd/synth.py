@@ -129,6 +129,52 @@ def synthetic_svc_model(C, M, A, context=None, n_fit_per_class=20, sv_frac=0.7, 
     return m
 
 
+def synthetic_forest_model(C, M, A, context=None, n_rounds=20, depth=4, seed=0, S=75, smooth=None, p_early_leaf=0.1,
+                           missing=2):
+    """Random tree-ensemble base of the reference architecture (XGBBase, src/Base/models.py:24-35: per window
+    XGBClassifier(n_estimators=20, max_depth=4)): `n_rounds` rounds per window, A trees per round (one when A == 2,
+    binary:logistic), split features = SNPs of the window's padded slice, thresholds 0.5 / 1.5 (what splits on
+    {0, 1} data with code-2 cells produce), random default directions for the missing code."""
+    rng = np.random.RandomState(seed)
+    context = int(M * 0.5) if context is None else int(context)
+    m = synthetic_model(C, M, A, S=S, context=context, seed=seed, base=None, smooth=smooth)
+    m.base_kind = "forest"
+    per_round = 1 if A == 2 else A
+    off, L, R, F, Cd, Dl, cls, wt0 = [0], [], [], [], [], [], [], [0]
+    for i in range(m.W):
+        width = m.window_width(i)
+        for t in range(n_rounds * per_round):
+            nodes = []
+
+            def grow(d):
+                idx = len(nodes)
+                nodes.append(None)
+                if d == depth or (d > 0 and rng.rand() < p_early_leaf):
+                    nodes[idx] = (-1, -1, 0, np.float32(rng.randn() * 0.2), 0)
+                else:
+                    f = rng.randint(width)
+                    thr = np.float32(0.5 if rng.rand() < 0.85 else 1.5)
+                    dl = int(rng.rand() < 0.5)
+                    l = grow(d + 1)
+                    r = grow(d + 1)
+                    nodes[idx] = (l, r, f, thr, dl)
+                return idx
+
+            grow(0)
+            for (l, r, f, c, dl) in nodes:
+                L.append(l); R.append(r); F.append(f); Cd.append(c); Dl.append(dl)
+            off.append(len(L))
+            cls.append(t % per_round)
+        wt0.append(len(off) - 1)
+    m.fb_win_tree0 = np.array(wt0, np.int32)
+    m.fb_tree_off = np.array(off, np.int32)
+    m.fb_left, m.fb_right, m.fb_feat = np.array(L, np.int32), np.array(R, np.int32), np.array(F, np.int32)
+    m.fb_cond, m.fb_default_left = np.array(Cd, np.float32), np.array(Dl, np.uint8)
+    m.fb_tree_class = np.array(cls, np.int32)
+    m.fb_base_score, m.fb_missing = 0.5, int(missing)
+    return m
+
+
 def synthetic_smoothing_trees(n_rounds, A, S, depth=4, seed=0, reach=8, noise_leaf=0.01):
     """An ensemble that behaves like a TRAINED smoother (labels piecewise constant along the chromosome) while keeping
     the cost profile of the reference's 100-round model: the first 2*reach+1 rounds are signal trees (class c votes by

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 1
+#define GNX_ABI_VERSION 2
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -54,7 +54,7 @@ enum {
   GNX_ESTATE = -5        /* call not valid for this model (e.g. phasing with a CRF smoother) */
 };
 
-enum { GNX_BASE_NONE = 0, GNX_BASE_LOGISTIC = 1, GNX_BASE_COVRSK_SVC = 2 };
+enum { GNX_BASE_NONE = 0, GNX_BASE_LOGISTIC = 1, GNX_BASE_COVRSK_SVC = 2, GNX_BASE_FOREST = 3 };
 enum { GNX_SMOOTH_NONE = 0, GNX_SMOOTH_XGB = 1, GNX_SMOOTH_CRF = 2 };
 
 /* kernel ids for gnx_profile_get */
@@ -66,7 +66,8 @@ enum {
   GNX_K_GNOFIX = 4,
   GNX_K_SMOOTH_ROWS = 5,
   GNX_K_CALIBRATE = 6,
-  GNX_K_COUNT = 7
+  GNX_K_BASE_FOREST = 7,
+  GNX_K_COUNT = 8
 };
 
 /* Per-window SVC of CovRSKBase (src/Base/models.py:195-215 -> sklearn.svm.SVC(kernel=callable,
@@ -132,6 +133,24 @@ typedef struct gnx_model_desc {
   int32_t calib_is_f32;      /* the isotonic maps were fitted on float32 probabilities (the xgb smoother's output): sklearn then
                                 interpolates in float32, and so does the kernel for float32 inputs */
   int32_t reserved3;
+
+  /* GNX_BASE_FOREST: one gradient-boosted tree ensemble per window (XGBBase, src/Base/models.py:24-35:
+   * XGBClassifier(n_estimators=20, max_depth=4, missing=missing_encoding)); xgboost model schema, all windows'
+   * trees concatenated.  A >= 3: multi:softprob, tree t adds to class fb_tree_class[t]; A == 2: binary:logistic
+   * (every tree adds to the one margin, fb_tree_class ignored).  Split features are SNP indices WITHIN the
+   * window's padded slice [i*M, i*M + width_i).  A SNP equal to fb_missing follows fb_default_left. */
+  int32_t fb_n_trees;
+  int32_t fb_missing;               /* missing_encoding, 2 (src/Base/base.py:25) */
+  const int32_t* fb_win_tree0;      /* (W+1,) first tree of each window */
+  const int32_t* fb_tree_off;       /* (fb_n_trees+1,) node offsets */
+  const int32_t* fb_left;           /* child index within the tree, -1 at leaves */
+  const int32_t* fb_right;
+  const int32_t* fb_feat;
+  const float* fb_cond;             /* split condition (left iff x < cond); leaf value at leaves */
+  const uint8_t* fb_default_left;   /* per node: 1 = missing goes left */
+  const int32_t* fb_tree_class;     /* (fb_n_trees,) */
+  float fb_base_score;              /* 0.5 */
+  int32_t reserved4;
 } gnx_model_desc;
 
 typedef struct gnx_model_info {

@@ -401,3 +401,62 @@ int gnxo_svc_predict_proba(const int64_t* Krow, int64_t Nq, int64_t Nt, int k, i
   free(kv);
   return GNXO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Tree-ensemble bases ("forest" bases): XGBBase (src/Base/models.py:24-35): per window
+ *   XGBClassifier(n_estimators=20, max_depth=4, learning_rate=0.1, missing=missing_encoding).predict_proba(Xw)
+ * -> xgboost==1.1.1 (third-party, absent: PARITY UNPINNED).  Restated from the same documented schema as the
+ * smoother (gnxo_xgb_* above) plus the parts this path adds:
+ *   - features are the window's SNPs cast to float32; a value equal to `missing` is dropped from the DMatrix, i.e.
+ *     the walk takes the node's DEFAULT child (default_left) there;
+ *   - A >= 3: objective multi:softprob (margin_c = base_score + sum, softmax);  A == 2: binary:logistic, one tree
+ *     per round, margin = logit(base_score) + sum leaves, p1 = 1/(1+expf(-margin)), proba = [1-p1, p1].
+ * Trees of all windows are concatenated; win_tree0[w]..win_tree0[w+1] are window w's trees.  B is (N, W, A) float32.
+ * ---------------------------------------------------------------------------------------- */
+static inline float forest_leaf(const gnxo_trees* T, int32_t t, const int8_t* xw, int missing) {
+  const int32_t o = T->tree_off[t];
+  int32_t nid = 0;
+  while (T->left[o + nid] != -1) {
+    const int v = xw[T->feat[o + nid]];
+    if (v == missing) nid = (T->default_left && T->default_left[o + nid]) ? T->left[o + nid] : T->right[o + nid];
+    else nid = ((float)v < T->cond[o + nid]) ? T->left[o + nid] : T->right[o + nid];
+  }
+  return T->cond[o + nid];
+}
+
+int gnxo_base_forest(const gnxo_trees* T, const int32_t* win_tree0, const int8_t* X, int64_t N, int64_t ldx, int64_t C,
+                     int64_t M, int64_t ctx, int64_t A, int missing, float* B) {
+  const int64_t W = C / M, rem = C - M * W, M_ = M + 2 * ctx;
+  if (rem == 0 || A < 2 || A > 64) return GNXO_EINVAL;
+  int8_t* xw = (int8_t*)malloc((size_t)(M_ + rem));
+  if (!xw) return GNXO_ENOMEM;
+  float out[64];
+  for (int64_t n = 0; n < N; ++n)
+    for (int64_t i = 0; i < W; ++i) {
+      const int64_t len = (i == W - 1) ? M_ + rem : M_;
+      for (int64_t k = 0; k < len; ++k) xw[k] = X[n * ldx + pad_src(i * M + k, C, ctx)];
+      float* o = B + (n * W + i) * A;
+      if (A == 2) {
+        float psum = 0.0f;
+        for (int32_t t = win_tree0[i]; t < win_tree0[i + 1]; ++t) psum += forest_leaf(T, t, xw, missing);
+        const float margin = logf(T->base_score / (1.0f - T->base_score)) + psum;  /* ProbToMargin of binary:logistic */
+        const float p1 = 1.0f / (1.0f + expf(-margin));
+        o[0] = 1.0f - p1;
+        o[1] = p1;
+      } else {
+        for (int g = 0; g < A; ++g) {
+          float psum = 0.0f;
+          for (int32_t t = win_tree0[i]; t < win_tree0[i + 1]; ++t)
+            if (T->tree_class[t] == g) psum += forest_leaf(T, t, xw, missing);
+          out[g] = T->base_score + psum;
+        }
+        float wmax = out[0];
+        for (int g = 1; g < A; ++g) wmax = fmaxf(out[g], wmax);
+        double wsum = 0.0;
+        for (int g = 0; g < A; ++g) { out[g] = expf(out[g] - wmax); wsum += out[g]; }
+        for (int g = 0; g < A; ++g) o[g] = out[g] / (float)wsum;
+      }
+    }
+  free(xw);
+  return GNXO_OK;
+}

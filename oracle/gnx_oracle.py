@@ -151,6 +151,19 @@ def smooth_xgb(trees: Trees, B, S):
     return proba, labels.astype(np.int64)
 
 
+def base_forest(trees: Trees, win_tree0, X, M, ctx, A, missing=2):
+    """XGBBase.predict_proba (Base/models.py:24-35): per-window xgboost forests on the window's SNPs -> B (N,W,A) f32"""
+    X = np.ascontiguousarray(X, dtype=np.int8)
+    win_tree0 = np.ascontiguousarray(win_tree0, dtype=np.int32)
+    N, Cn = X.shape
+    W = Cn // M
+    B = np.empty((N, W, A), dtype=np.float32)
+    ct = trees._c()
+    _chk(lib().gnxo_base_forest(C.byref(ct), _p(win_tree0), _p(X), C.c_int64(N), C.c_int64(Cn), C.c_int64(Cn), C.c_int64(M),
+                                C.c_int64(ctx), C.c_int64(A), C.c_int(missing), _p(B)), "base_forest")
+    return B
+
+
 def random_trees(n_rounds, n_class, n_feat, depth=4, seed=0, thr_lo=0.0, thr_hi=1.0, leaf_scale=0.3,
                  p_early_leaf=0.15):
     """Synthetic xgboost-schema ensemble (round-major, tree t has class t % n_class — the layout

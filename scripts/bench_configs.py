@@ -134,6 +134,25 @@ def c5b(n_ind=4096):
     return res
 
 
+def cf(N=10000):
+    """chr22 (config 2 geometry) with the tree-ensemble base: XGBBase shape, 20 rounds x 7 classes, depth 4, per window"""
+    C, M, A = 370_500, 1000, 7
+    t0 = time.time()
+    data = synth.synthetic_forest_model(C, M, A, n_rounds=20, depth=4, seed=0, S=75, smooth="xgb")
+    print("model synthesised in %.0f s" % (time.time() - t0), flush=True)
+    model = gnomix_amd.DeviceModel(data)
+    X = synth.synthetic_X_device(N, C, "cuda:0", seed=1)
+    model.ctx.profile_reset(); model.ctx.profile_enable(True)
+    dt = timed(lambda: model.infer_device(X), reps=3, warm=1)
+    model.ctx.profile_enable(False)
+    k = prof(model.ctx)
+    res = {"config": "cf chr22, forest base (20 rounds x 7, depth 4) + xgb", "haplotypes": N, "W": data.W, "seconds": dt,
+           "haplotypes_per_s": N / dt, "kernels_ms": k,
+           "base_node_steps_per_s": N * data.W * 140 * 4 / (k.get("k_base_forest", float("nan")) * 1e-3)}
+    print(json.dumps(res))
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c4", "c5a", "c5b", "c3"]
     out = {}

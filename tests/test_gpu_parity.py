@@ -532,3 +532,67 @@ def test_string_kernel_base_golden_G8(ga, oracle):
     assert np.max(np.abs(b64 - g["sk_B"])) < 1e-12      # vs the REFERENCE's StringKernelBase.predict_proba
     K = oracle.string_kernel(np.zeros((1, 8), np.int8), np.zeros((1, 8), np.int8))
     assert K[0, 0] == 36
+
+
+# ---------------------------------------------------------------- forest base (XGBBase) ----------
+def _forest_oracle_trees(O, d):
+    return O.Trees(d.fb_tree_off, d.fb_left, d.fb_right, d.fb_feat, d.fb_cond, d.fb_tree_class, d.A, d.fb_base_score,
+                   default_left=d.fb_default_left)
+
+
+@pytest.mark.parametrize("C,M,A,ctx,N,rounds,depth", [
+    (4037, 100, 7, 50, 70, 20, 4),     # the reference's XGBBase shape: 20 rounds, depth 4, A trees per round
+    (4037, 100, 2, 50, 33, 20, 4),     # A == 2: binary:logistic, one tree per round
+    (2531, 100, 3, 30, 300, 5, 2),     # more haplotypes than one 256-thread tile; shallow trees
+    (1999, 64, 4, 0, 65, 3, 6),        # no context, deep trees, window start not on a 16-SNP word
+    (937, 300, 12, 150, 1, 7, 1),      # stumps ("forest-of-stumps"), 3 windows, a single haplotype
+    (1237, 48, 5, 24, 129, 4, 3),      # M multiple of 16: window starts on word boundaries
+])
+def test_forest_base_vs_oracle(ga, oracle, C, M, A, ctx, N, rounds, depth):
+    from gnomix_amd import synth
+    d = synth.synthetic_forest_model(C, M, A, context=ctx, n_rounds=rounds, depth=depth, seed=C + A, p_early_leaf=0.2)
+    X = synth.synthetic_X(N, C, seed=N + 1, miss=0.08)
+    dev = ga.DeviceModel(d)
+    b32, b64 = dev.base_predict(X, want_f32=True, want_f64=True)
+    ref = oracle.base_forest(_forest_oracle_trees(oracle, d), d.fb_win_tree0, X, M, ctx, A, missing=2)
+    _close_f32(b32, ref)
+    assert np.array_equal(b64, b32.astype(np.float64))
+    # the missing code matters: flipping every default direction must change some outputs
+    d2 = synth.synthetic_forest_model(C, M, A, context=ctx, n_rounds=rounds, depth=depth, seed=C + A, p_early_leaf=0.2)
+    d2.fb_default_left = 1 - d2.fb_default_left
+    b32b, _ = ga.DeviceModel(d2).base_predict(X, want_f32=True, want_f64=False)
+    ref2 = oracle.base_forest(_forest_oracle_trees(oracle, d2), d2.fb_win_tree0, X, M, ctx, A, missing=2)
+    _close_f32(b32b, ref2)
+    assert not np.array_equal(ref, ref2)
+
+
+def test_forest_base_end_to_end_with_smoother(ga, oracle):
+    """forest base -> xgb smoother in one gnx_infer call == oracle base_forest -> oracle smoother"""
+    from gnomix_amd import synth
+    C, M, A, S, N = 9037, 100, 5, 31, 40
+    d = synth.synthetic_forest_model(C, M, A, n_rounds=20, depth=4, seed=3, S=S, smooth="xgb")
+    X = synth.synthetic_X(N, C, seed=5, miss=0.02)
+    dev = ga.DeviceModel(d)
+    p32, lab = dev.infer(X)
+    b32, _ = dev.base_predict(X, want_f32=True, want_f64=False)
+    ref_p, _ = oracle.smooth_xgb(_oracle_trees(oracle, d), b32, S)   # from the device's own B: isolates the smoother
+    _close_f32(p32, ref_p)
+    assert np.array_equal(lab, np.argmax(ref_p, -1))
+    Bo = oracle.base_forest(_forest_oracle_trees(oracle, d), d.fb_win_tree0, X, M, d.context, A)
+    lab_o = oracle.smooth_xgb(_oracle_trees(oracle, d), Bo, S)[1]
+    assert np.mean(lab != lab_o) < 1e-3   # expf last-bit differences in B may flip a knife-edge window
+
+
+def test_forest_base_rejects_bad_models(ga):
+    from gnomix_amd import synth
+    d = synth.synthetic_forest_model(1237, 100, 3, n_rounds=2, depth=2, seed=1)
+    d.fb_feat = d.fb_feat.copy()
+    internal = np.where(d.fb_left != -1)[0]
+    d.fb_feat[internal[0]] = 10 ** 6
+    with pytest.raises(ga.GnxError, match="split feature outside"):
+        ga.DeviceModel(d)
+    d = synth.synthetic_forest_model(1237, 100, 3, n_rounds=2, depth=2, seed=1)
+    d.fb_win_tree0 = d.fb_win_tree0.copy()
+    d.fb_win_tree0[-1] -= 1
+    with pytest.raises(ga.GnxError, match="fb_win_tree0"):
+        ga.DeviceModel(d)

@@ -121,3 +121,33 @@ def test_G5_phase_wrapper(oracle):
         Xm, Xp, Ym, Yp, _, _ = oracle.gnofix(X[2 * i], X[2 * i + 1], B[2 * i:2 * i + 2], S, rows, labs)
         assert np.array_equal(np.stack([Xm, Xp]), g["phase_oX"][2 * i:2 * i + 2])
         assert np.array_equal(np.stack([Ym, Yp]), g["phase_oY"][2 * i:2 * i + 2])
+
+
+def test_forest_base_hand_computed(oracle):
+    """XGBBase restatement (PARITY UNPINNED: xgboost absent) checked against values worked out by hand:
+    C=5, M=2, ctx=1 -> W=2, padded X = [x0 | x0..x4 | x4]; window 0 = padded[0:4], window 1 = padded[2:7]."""
+    O = oracle
+    X = np.array([[1, 0, 2, 1, 0]], np.int8)            # padded: 1 1 0 2 1 0 0
+    # window 0: one stump on SNP 2 (x=0): left 0.3 / right -0.1;  window 1: stump on SNP 1 (x=2, missing) default left
+    tr = O.Trees(tree_off=[0, 3, 6], left=[1, -1, -1, 1, -1, -1], right=[2, -1, -1, 2, -1, -1], feat=[2, 0, 0, 1, 0, 0],
+                 cond=[0.5, 0.3, -0.1, 0.5, 0.7, -0.4], tree_class=[0, 0], n_class=2, base_score=0.5,
+                 default_left=[0, 0, 0, 1, 0, 0])
+    B = O.base_forest(tr, [0, 1, 2], X, 2, 1, 2, missing=2)
+    p0 = np.float32(1) / (np.float32(1) + np.exp(np.float32(-0.3)))
+    p1 = np.float32(1) / (np.float32(1) + np.exp(np.float32(-0.7)))
+    assert np.allclose(B[0, 0], [1 - p0, p0], atol=1e-7)
+    assert np.allclose(B[0, 1], [1 - p1, p1], atol=1e-7)
+    tr.default_left = np.array([0, 0, 0, 0, 0, 0], np.uint8)   # missing now goes right
+    B = O.base_forest(tr, [0, 1, 2], X, 2, 1, 2, missing=2)
+    p1 = np.float32(1) / (np.float32(1) + np.exp(np.float32(0.4)))
+    assert np.allclose(B[0, 1], [1 - p1, p1], atol=1e-7)
+    # A = 3: softmax over per-class sums, base_score cancels
+    tr3 = O.Trees(tree_off=[0, 3, 4, 5, 8, 9, 10], left=[1, -1, -1, -1, -1, 1, -1, -1, -1, -1],
+                  right=[2, -1, -1, -1, -1, 2, -1, -1, -1, -1], feat=[0, 0, 0, 0, 0, 4, 0, 0, 0, 0],
+                  cond=[0.5, 0.2, 0.9, 0.1, -0.3, 1.5, 0.6, -0.6, 0.0, 0.25], tree_class=[0, 1, 2, 0, 1, 2], n_class=3)
+    B = O.base_forest(tr3, [0, 3, 6], X, 2, 1, 3)
+    m0 = np.array([0.9, 0.1, -0.3])       # window 0: SNP0 = 1 -> right leaf 0.9
+    m1 = np.array([0.6, 0.0, 0.25])       # window 1: SNP4 of padded[2:7] = 0 < 1.5 -> left leaf 0.6
+    for w, mm in enumerate((m0, m1)):
+        e = np.exp(mm - mm.max())
+        assert np.allclose(B[0, w], e / e.sum(), atol=1e-6)
