@@ -50,7 +50,7 @@ def trees_from_xgb_json(dumps, n_class, base_score=0.5):
     """xgboost JSON tree dumps (list of str, one per tree, model order) -> xgboost-schema arrays.
     JSON nodes: {"nodeid", "split": "f12", "split_condition", "yes", "no", "missing", "children"} or {"nodeid","leaf"};
     `yes` is the child taken when feature < split_condition."""
-    off, L, R, F, Cd, cls = [0], [], [], [], [], []
+    off, L, R, F, Cd, Dl, cls = [0], [], [], [], [], [], []
     for t, s in enumerate(dumps):
         root = json.loads(s) if isinstance(s, str) else s
         nodes = {}
@@ -68,17 +68,36 @@ def trees_from_xgb_json(dumps, n_class, base_score=0.5):
         for nid in ids:
             nd = nodes[nid]
             if "leaf" in nd:
-                L.append(-1); R.append(-1); F.append(0); Cd.append(np.float32(nd["leaf"]))
+                L.append(-1); R.append(-1); F.append(0); Cd.append(np.float32(nd["leaf"])); Dl.append(0)
             else:
                 f = nd["split"]
                 f = int(f[1:]) if isinstance(f, str) and f.startswith("f") else int(f)
                 L.append(remap[nd["yes"]]); R.append(remap[nd["no"]]); F.append(f)
                 Cd.append(np.float32(nd["split_condition"]))
+                Dl.append(int(nd.get("missing", nd["yes"]) == nd["yes"]))
         off.append(len(L))
         cls.append(t % n_class)
     return dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
                 feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32),
-                base_score=float(base_score))
+                base_score=float(base_score), default_left=np.array(Dl, np.uint8))
+
+
+def forest_from_xgb_json(window_dumps, n_class, base_score=0.5, missing=2):
+    """Per-window xgboost JSON dumps (XGBBase: one XGBClassifier per window, src/Base/models.py:24-35) -> the fb_*
+    arrays of GnxModelData.  multi:softprob lays trees out round-major (tree t -> class t % A); binary:logistic
+    (A == 2) has one tree per round."""
+    per_round = 1 if n_class == 2 else n_class
+    parts = [trees_from_xgb_json(dumps, per_round, base_score) for dumps in window_dumps]
+    wt0 = np.concatenate([[0], np.cumsum([len(p["tree_off"]) - 1 for p in parts])]).astype(np.int32)
+    node0 = np.concatenate([[0], np.cumsum([p["tree_off"][-1] for p in parts])])
+    return dict(fb_win_tree0=wt0,
+                fb_tree_off=np.concatenate([p["tree_off"][:-1] + node0[i] for i, p in enumerate(parts)]
+                                           + [[node0[-1]]]).astype(np.int32),
+                fb_left=np.concatenate([p["left"] for p in parts]), fb_right=np.concatenate([p["right"] for p in parts]),
+                fb_feat=np.concatenate([p["feat"] for p in parts]), fb_cond=np.concatenate([p["cond"] for p in parts]),
+                fb_default_left=np.concatenate([p["default_left"] for p in parts]),
+                fb_tree_class=np.concatenate([p["tree_class"] for p in parts]),
+                fb_base_score=float(base_score), fb_missing=int(missing))
 
 
 def calibrator_arrays(iso_models):
@@ -113,6 +132,11 @@ def from_reference_model(model) -> GnxModelData:
         d.base_kind = "covrsk"
         kname = getattr(getattr(model.base, "kernel", None), "__name__", "CovRSK")
         d.svc = [svc_window_from_sklearn(m, d.window_width(i), kname) for i, m in enumerate(models)]
+    elif first == "XGBClassifier":  # XGBBase (src/Base/models.py:24-35)
+        d.base_kind = "forest"
+        dumps = [m.get_booster().get_dump(dump_format="json") for m in models]
+        for k, v in forest_from_xgb_json(dumps, A, missing=int(getattr(model.base, "missing_encoding", 2))).items():
+            setattr(d, k, v)
     else:
         raise NotImplementedError(f"base model {first}")
     sm = type(model.smooth).__name__
@@ -121,7 +145,8 @@ def from_reference_model(model) -> GnxModelData:
         t = trees_from_xgb_json(booster.get_dump(dump_format="json"), A)
         d.smooth_kind = "xgb"
         for k, v in t.items():
-            setattr(d, k, v)
+            if k != "default_left":  # smoother features are probabilities, never missing
+                setattr(d, k, v)
     elif sm == "CRF_Smoother":
         crf = model.smooth.model.CRF
         d.smooth_kind = "crf"

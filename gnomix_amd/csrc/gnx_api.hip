@@ -360,33 +360,30 @@ static int forest_depth(const gnx_model_desc* d, int32_t o, int32_t nid, int32_t
   return 1 + std::max(l, r);
 }
 
-static void forest_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint8_t* out) {
-  const uint32_t half = 1u << (D - 1);
+// Forest trees use their own compact heap: 2^D node words (slot 0 unused) followed by 2^D float leaves.  A node word is
+// (SNP index within the window << 4) | left-mask, bit v of the mask = "a SNP of value v goes left": SNPs only take
+// the values 0..3, so `float(v) < threshold` and the missing code's default direction fold into 4 bits at load time.
+static void forest_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint32_t* nodes,
+                        float* leaves) {
   const bool leaf = d->fb_left[o + nid] == -1;
-  const float inf = std::numeric_limits<float>::infinity();
-  // early leaf: dummy split on SNP 0 with threshold +inf and default-left: every value (missing or not) goes left
-  uint32_t fw = 0x80000000u;
-  float thr = inf;
-  if (!leaf) {
-    fw = (uint32_t)d->fb_feat[o + nid] | ((d->fb_default_left && d->fb_default_left[o + nid]) ? 0x80000000u : 0u);
-    thr = d->fb_cond[o + nid];
-  }
-  if (depth == D - 1) {
-    float ll, lr;
-    if (leaf) ll = lr = d->fb_cond[o + nid];
-    else {
-      const int32_t cl = d->fb_left[o + nid], cr = d->fb_right[o + nid];
-      ll = d->fb_cond[o + cl];
-      lr = d->fb_cond[o + cr];
-    }
-    uint8_t* p = out + (size_t)(j - half) * 16;
-    std::memcpy(p, &fw, 4); std::memcpy(p + 4, &thr, 4); std::memcpy(p + 8, &ll, 4); std::memcpy(p + 12, &lr, 4);
+  if (depth == D) {  // D is the ensemble's maximum depth: nid is a leaf here
+    leaves[j - (1u << D)] = d->fb_cond[o + nid];
     return;
   }
-  uint8_t* p = out + (size_t)half * 16 + (size_t)(j - 1) * 8;
-  std::memcpy(p, &fw, 4); std::memcpy(p + 4, &thr, 4);
-  forest_fill(d, o, leaf ? nid : d->fb_left[o + nid], 2 * j, depth + 1, D, out);
-  forest_fill(d, o, leaf ? nid : d->fb_right[o + nid], 2 * j + 1, depth + 1, D, out);
+  uint32_t word = 0xFu;  // early leaf: every value goes left, both subtrees replicate the leaf
+  if (!leaf) {
+    const float thr = d->fb_cond[o + nid];
+    const bool dl = d->fb_default_left && d->fb_default_left[o + nid];
+    uint32_t mask = 0;
+    for (int v = 0; v < 4; ++v) {
+      const bool left = (v == d->fb_missing) ? dl : ((float)v < thr);
+      mask |= (left ? 1u : 0u) << v;
+    }
+    word = ((uint32_t)d->fb_feat[o + nid] << 4) | mask;
+  }
+  nodes[j] = word;
+  forest_fill(d, o, leaf ? nid : d->fb_left[o + nid], 2 * j, depth + 1, D, nodes, leaves);
+  forest_fill(d, o, leaf ? nid : d->fb_right[o + nid], 2 * j + 1, depth + 1, D, nodes, leaves);
 }
 
 static int build_forest(gnx_model* m, const gnx_model_desc* d) {
@@ -421,8 +418,9 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
     }
   }
   if (D > 8) return fail(ctx, GNX_EUNSUPPORTED, "forest base: tree depth > 8");
-  const int tree_bytes = gnx_tree_bytes(D);
-  const int max_words = (int)((M_ + rem + 15) / 16) + 1;
+  if (C < 16) return fail(ctx, GNX_EUNSUPPORTED, "forest base: fewer than 16 SNPs");
+  const int tree_bytes = 8 << D;
+  const int max_words = (int)((M_ + rem + 15) / 16);
   if (gnx_forest_lds_bytes(A, max_words, max_trees, tree_bytes, 64) > (size_t)160 * 1024)
     return fail(ctx, GNX_EUNSUPPORTED, "forest base: one window's trees and SNPs exceed the 160 KB LDS");
 
@@ -437,7 +435,8 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
       ct[c] = (int32_t)(k - (size_t)t0);
       for (int32_t t = t0; t < t1; ++t) {
         if (A > 2 && d->fb_tree_class[t] != c) continue;
-        forest_fill(d, d->fb_tree_off[t], 0, 1, 0, D, packed.data() + k * tree_bytes);
+        uint8_t* tb = packed.data() + k * tree_bytes;
+        forest_fill(d, d->fb_tree_off[t], 0, 1, 0, D, reinterpret_cast<uint32_t*>(tb), reinterpret_cast<float*>(tb + ((size_t)4 << D)));
         ++k;
       }
     }
@@ -730,13 +729,9 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     return GNX_OK;
   }
   if (m->info.base_kind == GNX_BASE_FOREST) {
-    const int64_t Cp = m->info.C + 2 * m->info.ctx, nwq = (Cp + 15) / 16 + 2;
-    int rc = ws_reserve(ctx, ctx->ws_bits, (size_t)N * nwq * 4);
-    if (rc != GNX_OK) return rc;
     ProfScope ps(ctx, GNX_K_BASE_FOREST);
-    HIPCHK(ctx, gnx_launch_pack2(dX, N, ldx, m->info.C, m->info.ctx, nwq, (uint32_t*)ctx->ws_bits.p, ctx->stream));
     ForestLaunch L{};
-    L.q = (const uint32_t*)ctx->ws_bits.p; L.N = N; L.nwq = nwq; L.M = m->info.M;
+    L.X = dX; L.N = N; L.ldx = ldx; L.C = m->info.C; L.ctx = m->info.ctx; L.M = m->info.M;
     L.width = m->info.M + 2 * m->info.ctx;
     L.width_last = L.width + (m->info.C - m->info.M * m->info.W);
     L.W = (int32_t)m->info.W; L.A = m->info.A; L.D = m->forest.D; L.tree_bytes = m->forest.tree_bytes;

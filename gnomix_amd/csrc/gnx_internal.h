@@ -203,8 +203,8 @@ struct CalibLaunch {
 };
 
 // ---- forest base (k_base_forest.hip) ------------------------------------------------------------------
-// Trees use the smoother's packed complete-heap layout, except that the first word of a node is
-// (default_left << 31) | SNP index within the window instead of a byte offset.
+// Per tree: 2^D node words (heap slot 0 unused; (SNP index within the window << 4) | left-mask over the SNP values
+// 0..3) followed by 2^D float leaves.
 struct ForestDev {
   const uint8_t* packed = nullptr;          // fb_n_trees * tree_bytes, per window class-major
   const int32_t* win_tree0 = nullptr;       // [W+1]
@@ -214,9 +214,9 @@ struct ForestDev {
 };
 
 struct ForestLaunch {
-  const uint32_t* q;  // (N, nwq) 2-bit packed padded X
-  int64_t N, nwq, M, width, width_last;
-  int32_t W, A, D, tree_bytes, max_trees, max_words, missing;
+  const int8_t* X;    // (N, ldx)
+  int64_t N, ldx, C, ctx, M, width, width_last;
+  int32_t W, A, D, tree_bytes, max_trees, max_words, missing, w_first;
   float base_score;
   const uint8_t* packed;
   const int32_t* win_tree0;
@@ -261,8 +261,6 @@ hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s
 size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
 hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
-hipError_t gnx_launch_pack2(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwq, uint32_t* q,
-                            hipStream_t s);
 hipError_t gnx_launch_base_forest(const ForestLaunch& L, hipStream_t s);
 size_t gnx_forest_lds_bytes(int A, int max_words, int max_trees, int tree_bytes, int threads);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

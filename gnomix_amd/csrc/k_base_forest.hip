@@ -6,15 +6,24 @@
 // multi:softprob for A >= 3, binary:logistic for A == 2).  No reference mode selects these bases (README.md:120-146
 // shows how to plug them in), they are the "forest-of-stumps" family of the north star.
 //
-//  * pass 1 (k_pack2): X int8 {0,1,2} -> 2 bits per SNP over the reflect-PADDED coordinate, 16 SNPs per word;
-//  * pass 2 (k_base_forest): one wave = 64 haplotypes of one window.  The window's 2-bit words sit in LDS as
-//    [word][lane] (lanes on the same split read consecutive banks), its trees — complete depth-D heaps in the packed
-//    layout of the smoother, with the default direction in bit 31 of the feature word and the feature as a SNP index —
-//    next to them; a lane walks TP trees at a time (independent chains), sums each class in tree order (float32, as
-//    the restated predictor does), parks the margins in LDS, then applies softmax / sigmoid in float32.
+// One thread = one haplotype of one window; a block = T = 64*waves haplotypes of that window.
+//  * staging: every wave reads ITS OWN 64 haplotypes' SNP bytes of the window straight from X (16 SNPs = one
+//    unaligned 16-byte load per lane, 8 lanes along a row = one 128-byte line, LB loads in flight per lane),
+//    squeezes them to 2 bits per SNP and stores them in LDS as xw[word][hap]: during the walks a lane's bank is then
+//    fixed by its haplotype, so lanes that sit on different split SNPs never conflict.  Reflect padding
+//    (base.py:146-151) only touches the first / last ctx SNPs of a row: those words take a per-byte path.
+//  * the window's trees sit next to the tile as compact heaps: one 32-bit word per node = (SNP index << 4) | left-mask
+//    (bit v = "value v goes left": SNPs only take the values 0..3, so the float compare and the missing code's
+//    default direction were folded into 4 bits by the loader), then the 2^D float leaves.  A lane walks TP trees at
+//    a time level by level (TP independent LDS chains), adds the leaves of each class in tree order (float32, as
+//    the restated predictor does), parks the margins in LDS and applies softmax / sigmoid in float32.
 #include "gnx_internal.h"
 
+#include <cstdlib>
+
 namespace {
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int64_t pad_src(int64_t p, int64_t C, int64_t ctx) {
   if (p < ctx) return ctx - 1 - p;
@@ -22,73 +31,98 @@ __device__ __forceinline__ int64_t pad_src(int64_t p, int64_t C, int64_t ctx) {
   return C - 1 - (p - ctx - C);
 }
 
-// one thread = one 16-SNP word of the padded 2-bit matrix
-__global__ __launch_bounds__(256) void k_pack2(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwq,
-                                               uint32_t* q) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * nwq) return;
-  const int64_t n = idx / nwq, wd = idx - n * nwq;
-  const int64_t Cp = C + 2 * ctx;
-  const int8_t* x = X + n * ldx;
-  uint32_t v = 0;
-  for (int b = 0; b < 16; ++b) {
-    const int64_t p = wd * 16 + b;
-    if (p < Cp) v |= ((uint32_t)(uint8_t)x[pad_src(p, C, ctx)] & 3u) << (2 * b);
-  }
-  q[n * nwq + wd] = v;
+// 4 SNP bytes (values 0..3) -> 8 bits
+__device__ __forceinline__ uint32_t squeeze4(uint32_t d) {
+  const uint32_t x = d & 0x03030303u;
+  const uint32_t y = x | (x >> 6);
+  return (y | (y >> 12)) & 0xffu;
 }
 
-constexpr int TP = 4;  // trees walked concurrently per lane
+constexpr int TP = 8;  // trees walked concurrently per lane
+constexpr int LB = 16;  // 16-byte loads in flight per lane while staging
 
-__device__ __forceinline__ float forest_walk(const uint8_t* tb, const uint32_t* xw, int T, int D, int missing) {
-  const uint32_t half = 1u << (D - 1);
-  uint32_t j = 1;
-  for (int d = 0; d < D - 1; ++d) {
-    const uint2 nd = *reinterpret_cast<const uint2*>(tb + half * 16 + (j - 1) * 8);
-    const uint32_t f = nd.x & 0x7fffffffu;
-    const int v = (int)((xw[(f >> 4) * T] >> (2 * (f & 15))) & 3u);
-    const bool left = (v == missing) ? (nd.x >> 31) != 0 : ((float)v < __uint_as_float(nd.y));
-    j = 2 * j + (left ? 0u : 1u);
-  }
-  const uint4 n4 = *reinterpret_cast<const uint4*>(tb + (j - half) * 16);
-  const uint32_t f = n4.x & 0x7fffffffu;
-  const int v = (int)((xw[(f >> 4) * T] >> (2 * (f & 15))) & 3u);
-  const bool left = (v == missing) ? (n4.x >> 31) != 0 : ((float)v < __uint_as_float(n4.y));
-  return left ? __uint_as_float(n4.z) : __uint_as_float(n4.w);
+// left iff bit v of the node's mask is set, v = the 2-bit SNP value
+__device__ __forceinline__ uint32_t step(uint32_t j, uint32_t nd, uint32_t xv) {
+  const uint32_t v = (xv >> ((nd >> 3) & 30u)) & 3u;
+  return 2 * j + (((nd >> v) & 1u) ^ 1u);
 }
 
+template <int D, int NT>
+__device__ __forceinline__ void walk(const uint8_t* tb, int tree_bytes, const uint32_t* xcol, int T, float* leaf) {
+  uint32_t j[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) j[k] = 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    uint32_t nd[NT], xv[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) nd[k] = reinterpret_cast<const uint32_t*>(tb + k * tree_bytes)[j[k]];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) xv[k] = xcol[(nd[k] >> 8) * T];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) j[k] = step(j[k], nd[k], xv[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) leaf[k] = reinterpret_cast<const float*>(tb + k * tree_bytes)[j[k]];  // leaves follow the 2^D nodes
+}
+
+template <int D>
 __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int lane = threadIdx.x, T = blockDim.x;  // T = 64 * waves, one thread = one haplotype
-  const int w = blockIdx.y;
-  const int A = L.A, D = L.D, tree_bytes = L.tree_bytes;
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6;
+  const int w = L.w_first + blockIdx.y;
+  const int A = L.A, tree_bytes = L.tree_bytes;
+  const int64_t C = L.C, ctx = L.ctx, Cp = C + 2 * ctx;
   const int64_t width = (w == L.W - 1) ? L.width_last : L.width;
   const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
 
-  uint32_t* xw = reinterpret_cast<uint32_t*>(lds) + lane;                            // [max_words][T], this lane's column
-  uint8_t* tr = lds + (size_t)L.max_words * T * 4;                                   // trees of this window
-  float* marg = reinterpret_cast<float*>(tr + (((size_t)L.max_trees * tree_bytes + 15) & ~(size_t)15)) + lane;  // [A][T]
+  uint32_t* xw = reinterpret_cast<uint32_t*>(lds);                                    // [max_words][T]
+  uint8_t* tr = lds + (size_t)L.max_words * T * 4;                                    // trees of this window
+  float* marg = reinterpret_cast<float*>(tr + (((size_t)L.max_trees * tree_bytes + 15) & ~(size_t)15)) + tid;  // [A][T]
 
-  const int64_t n = (int64_t)blockIdx.x * T + lane;
-  const int64_t nc = n < L.N ? n : L.N - 1;
-
-  // window bits: 2-bit funnel shift to the window start (padded SNP w*M), 16 SNPs per word
+  // ---- stage this wave's 64 haplotypes: 8 haplotypes x 8 words per wave instruction -----------------------
   {
-    const int64_t s = (int64_t)w * L.M;
-    const int64_t w0 = s >> 4;
-    const int sh = (int)(s & 15) * 2;
-    const uint32_t* src = L.q + nc * L.nwq + w0;
+    const int64_t s = (int64_t)w * L.M;  // padded coordinate of the window's first SNP
     const int nw = (int)((width + 15) >> 4);
-    for (int i = 0; i < nw; ++i) {
-      const uint32_t a = src[i], b = src[i + 1];  // the packed rows carry 2 spare words
-      xw[(size_t)i * T] = sh ? ((a >> sh) | (b << (32 - sh))) : a;
+    const int wsub = lane & 7, hsub = lane >> 3;
+    const int64_t cmax = C - 16;  // the model loader guarantees C >= 16
+    for (int hb = 0; hb < 8; ++hb) {
+      const int h = wv * 64 + hb * 8 + hsub;
+      int64_t n = (int64_t)blockIdx.x * T + h;
+      n = n < L.N ? n : L.N - 1;
+      const int8_t* row = L.X + n * L.ldx;
+      uint32_t* col = xw + h;
+      for (int wb = 0; wb < nw; wb += 8 * LB) {
+        v4u v[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {  // unconditional loads at clamped addresses: all LB are in flight together
+          int64_t c0 = s + 16 * (int64_t)(wb + 8 * u + wsub) - ctx;
+          c0 = c0 < 0 ? 0 : (c0 > cmax ? cmax : c0);
+          __builtin_memcpy(&v[u], row + c0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+          const int wd = wb + 8 * u + wsub;
+          const int64_t p0 = s + 16 * (int64_t)wd;
+          uint32_t q = squeeze4(v[u].x) | (squeeze4(v[u].y) << 8) | (squeeze4(v[u].z) << 16) | (squeeze4(v[u].w) << 24);
+          if (wd < nw && (p0 < ctx || p0 + 16 > ctx + C)) {  // rare: the word touches the reflect padding / the row's end
+            q = 0;
+            for (int b = 0; b < 16; ++b) {
+              const int64_t p = p0 + b;
+              if (p < Cp) q |= ((uint32_t)(uint8_t)row[pad_src(p, C, ctx)] & 3u) << (2 * b);
+            }
+          }
+          if (wd < nw) col[(size_t)wd * T] = q;
+        }
+      }
     }
   }
-  for (int e = lane; e < nt * tree_bytes / 16; e += T)
+  for (int e = tid; e < nt * tree_bytes / 16; e += T)
     reinterpret_cast<uint4*>(tr)[e] = reinterpret_cast<const uint4*>(L.packed + (size_t)t0 * tree_bytes)[e];
   __syncthreads();
 
-  // class-major packing per window: trees of class c are contiguous, in model order
+  // ---- walks: class-major packing per window, trees of class c contiguous and in model order ----------------
+  const uint32_t* xcol = xw + tid;
   const int32_t* cls0 = L.win_class_tree0 + (size_t)w * (A + 1);  // [A+1] offsets relative to t0
   const int n_groups = (A == 2) ? 1 : A;
   for (int c = 0; c < n_groups; ++c) {
@@ -97,14 +131,18 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
     int t = a0;
     for (; t + TP <= a1; t += TP) {
       float leaf[TP];
-#pragma unroll
-      for (int k = 0; k < TP; ++k) leaf[k] = forest_walk(tr + (size_t)(t + k) * tree_bytes, xw, T, D, L.missing);
+      walk<D, TP>(tr + (size_t)t * tree_bytes, tree_bytes, xcol, T, leaf);
 #pragma unroll
       for (int k = 0; k < TP; ++k) psum += leaf[k];  // tree order
     }
-    for (; t < a1; ++t) psum += forest_walk(tr + (size_t)t * tree_bytes, xw, T, D, L.missing);
+    for (; t < a1; ++t) {
+      float leaf[1];
+      walk<D, 1>(tr + (size_t)t * tree_bytes, tree_bytes, xcol, T, leaf);
+      psum += leaf[0];
+    }
     marg[c * T] = psum;
   }
+  const int64_t n = (int64_t)blockIdx.x * T + tid;
   if (n >= L.N) return;
   const size_t o = ((size_t)n * L.W + w) * A;
   if (A == 2) {
@@ -133,28 +171,53 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
   }
 }
 
+template <int D>
+hipError_t launch_d(const ForestLaunch& L, int n_windows, int threads, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_forest<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)160 * 1024));
+  hipLaunchKernelGGL(k_base_forest<D>, dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)n_windows), dim3(threads), lds, s, L);
+  return hipGetLastError();
+}
+
+// windows [w_first, w_first + n_windows) with an X tile of max_words words per haplotype
+hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int max_words, hipStream_t s) {
+  if (n_windows <= 0) return hipSuccess;
+  // the walks are issue-bound with one wave per SIMD and staging does not overlap them inside a block: take as many
+  // waves per CU as the LDS holds (the X tile is 4 * max_words bytes per haplotype)
+  constexpr size_t kLds = (size_t)160 * 1024;
+  L.w_first = w_first;
+  L.max_words = max_words;
+  int threads = 0;
+  if (const char* e = std::getenv("GNX_FOREST_T")) threads = std::atoi(e) / 64 * 64;
+  if (threads < 64 || threads > 256) threads = 256;
+  while (threads > 64 && gnx_forest_lds_bytes(L.A, max_words, L.max_trees, L.tree_bytes, threads) > kLds) threads -= 64;
+  while (threads > 64 && (int64_t)(threads - 64) >= L.N) threads -= 64;
+  const size_t lds = gnx_forest_lds_bytes(L.A, max_words, L.max_trees, L.tree_bytes, threads);
+  if (lds > kLds) return hipErrorInvalidValue;
+  switch (L.D) {
+    case 1: return launch_d<1>(L, n_windows, threads, lds, s);
+    case 2: return launch_d<2>(L, n_windows, threads, lds, s);
+    case 3: return launch_d<3>(L, n_windows, threads, lds, s);
+    case 4: return launch_d<4>(L, n_windows, threads, lds, s);
+    case 5: return launch_d<5>(L, n_windows, threads, lds, s);
+    case 6: return launch_d<6>(L, n_windows, threads, lds, s);
+    case 7: return launch_d<7>(L, n_windows, threads, lds, s);
+    case 8: return launch_d<8>(L, n_windows, threads, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 }  // namespace
 
 size_t gnx_forest_lds_bytes(int A, int max_words, int max_trees, int tree_bytes, int threads) {
   return (size_t)max_words * threads * 4 + (((size_t)max_trees * tree_bytes + 15) & ~(size_t)15) + (size_t)A * threads * 4;
 }
 
-hipError_t gnx_launch_pack2(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwq, uint32_t* q,
-                            hipStream_t s) {
-  if (N <= 0) return hipSuccess;
-  const int64_t total = N * nwq;
-  hipLaunchKernelGGL(k_pack2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, N, ldx, C, ctx, nwq, q);
-  return hipGetLastError();
-}
-
 hipError_t gnx_launch_base_forest(const ForestLaunch& L, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
-  int threads = 256;  // as many waves as fit the 160 KB LDS next to the window's trees
-  while (threads > 64 && gnx_forest_lds_bytes(L.A, L.max_words, L.max_trees, L.tree_bytes, threads) > (size_t)160 * 1024) threads -= 64;
-  while (threads > 64 && (int64_t)(threads - 64) >= L.N) threads -= 64;
-  const size_t lds = gnx_forest_lds_bytes(L.A, L.max_words, L.max_trees, L.tree_bytes, threads);
-  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_forest), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_base_forest, dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)L.W), dim3(threads), lds, s, L);
-  return hipGetLastError();
+  // the last window is wider by C mod M (base.py:163-164): its own launch, so that the others get the smaller tile
+  const int words = (int)((L.width + 15) >> 4), words_last = (int)((L.width_last + 15) >> 4);
+  hipError_t e = launch_range(L, 0, L.W - 1, words, s);
+  if (e != hipSuccess) return e;
+  return launch_range(L, L.W - 1, 1, words_last, s);
 }

@@ -157,3 +157,40 @@ def test_cli_usage_and_training_mode_messages(capsys):
     assert cli.main(["gnomix.py", "a", "b"]) == 0
     assert "Incorrect number of arguments" in capsys.readouterr().out
     assert cli.main(["gnomix.py"] + ["x"] * 7) == 2
+
+
+def test_forest_model_gnx_roundtrip_and_desc(tmp_path):
+    """forest-base arrays survive the .gnx container and fill the gnx_model_desc fields the header declares"""
+    from gnomix_amd import synth, GnxModelData, _lib
+    d = synth.synthetic_forest_model(1237, 100, 3, n_rounds=2, depth=3, seed=4)
+    p = tmp_path / "f.gnx"
+    d.save(p)
+    e = GnxModelData.load(p)
+    assert e.base_kind == "forest" and e.fb_missing == 2 and e.fb_base_score == 0.5
+    for k in ("fb_win_tree0", "fb_tree_off", "fb_left", "fb_right", "fb_feat", "fb_cond", "fb_default_left", "fb_tree_class"):
+        assert np.array_equal(getattr(d, k), getattr(e, k)), k
+    desc, keep = e.to_desc()
+    assert desc.base_kind == _lib.BASE_FOREST and desc.fb_n_trees == len(d.fb_tree_off) - 1
+    assert desc.fb_win_tree0 and desc.fb_default_left and desc.fb_tree_class
+
+
+def test_forest_from_xgb_json(oracle):
+    """per-window JSON dumps -> fb_* arrays; the dump's "missing" child becomes the default direction"""
+    import json
+    from gnomix_amd import convert
+    w0 = [{"nodeid": 0, "split": "f1", "split_condition": 0.5, "yes": 1, "no": 2, "missing": 2, "children": [
+        {"nodeid": 1, "leaf": 0.4}, {"nodeid": 2, "leaf": -0.2}]}]
+    w1 = [{"nodeid": 0, "split": "f3", "split_condition": 1.5, "yes": 1, "no": 2, "missing": 1, "children": [
+        {"nodeid": 1, "leaf": 0.1}, {"nodeid": 2, "leaf": 0.6}]}, {"nodeid": 0, "leaf": -0.05}]
+    f = convert.forest_from_xgb_json([[json.dumps(t) for t in w0], [json.dumps(t) for t in w1]], n_class=2)
+    assert f["fb_win_tree0"].tolist() == [0, 1, 3] and f["fb_tree_off"].tolist() == [0, 3, 6, 7]
+    assert f["fb_default_left"].tolist() == [0, 0, 0, 1, 0, 0, 0]
+    T = oracle.Trees(f["fb_tree_off"], f["fb_left"], f["fb_right"], f["fb_feat"], f["fb_cond"], f["fb_tree_class"], 2,
+                     default_left=f["fb_default_left"])
+    X = np.array([[0, 2, 1, 2, 0]], np.int8)            # C=5, M=2, ctx=1: padded 0 0 2 1 2 0 0
+    B = oracle.base_forest(T, f["fb_win_tree0"], X, 2, 1, 2)
+    # window 0 = padded[0:4] = 0 0 2 1: SNP1 = 0 < 0.5 -> 0.4;  window 1 = padded[2:7] = 2 1 2 0 0: SNP3 = 0 < 1.5 -> 0.1 - 0.05
+    assert np.allclose(B[0, :, 1], 1 / (1 + np.exp(-np.array([0.4, 0.05]))), atol=1e-6)
+    X[0, 0] = 2                                          # padded 2 2 2 1 ...: window 0 SNP1 missing -> "no" child (-0.2)
+    B = oracle.base_forest(T, f["fb_win_tree0"], X, 2, 1, 2)
+    assert np.allclose(B[0, 0, 1], 1 / (1 + np.exp(0.2)), atol=1e-6)
