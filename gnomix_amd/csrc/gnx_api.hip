@@ -288,6 +288,101 @@ static void tree_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t 
   tree_fill(d, o, leaf ? nid : d->right[o + nid], 2 * j + 1, depth + 1, D, out);
 }
 
+// rank-quantised tree (layout in gnx_internal.h: SmoothXGBDev::rk_packed)
+static void tree_fill_rk(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D,
+                         const std::vector<float>& U, int stride, uint32_t* nodes, float* leaves) {
+  const bool leaf = d->left[o + nid] == -1;
+  if (depth == D) {
+    leaves[j - (1u << D)] = d->cond[o + nid];
+    return;
+  }
+  uint32_t word = 0xFFFFu << 16;  // early leaf: every rank is < 0xFFFF -> left; both subtrees replicate the leaf
+  if (!leaf) {
+    const float thr = d->cond[o + nid];
+    uint32_t field;
+    if (thr != thr || thr == -std::numeric_limits<float>::infinity()) field = 0;           // p < thr never holds
+    else if (thr == std::numeric_limits<float>::infinity()) field = 0xFFFFu;                // always holds
+    else field = (uint32_t)(std::lower_bound(U.begin(), U.end(), thr) - U.begin()) + 1u;    // p < U[k] <=> rank(p) < k+1
+    const int f = d->feat[o + nid], A = d->A;
+    const uint32_t off = (uint32_t)(((f % A) * stride + f / A) * 2);
+    word = (field << 16) | off;
+  }
+  nodes[j] = word;
+  tree_fill_rk(d, o, leaf ? nid : d->left[o + nid], 2 * j, depth + 1, D, U, stride, nodes, leaves);
+  tree_fill_rk(d, o, leaf ? nid : d->right[o + nid], 2 * j + 1, depth + 1, D, U, stride, nodes, leaves);
+}
+
+static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector<int32_t>& order, int D) {
+  const char* impl = std::getenv("GNX_SMOOTH_IMPL");  // "rk" (default: 16-bit ranks) or "f32" (float features)
+  if (impl && std::string(impl) == "f32") return GNX_OK;
+  const int A = d->A, S = d->S;
+  std::vector<float> U;
+  for (int t = 0; t < d->n_trees; ++t)
+    for (int32_t k = d->tree_off[t]; k < d->tree_off[t + 1]; ++k)
+      if (d->left[k] != -1 && std::isfinite(d->cond[k])) U.push_back(d->cond[k]);
+  std::sort(U.begin(), U.end());
+  U.erase(std::unique(U.begin(), U.end()), U.end());
+  // segments per strip: 2-4 independent walks per lane are enough to cover the LDS latency and keep the strips small
+  // (measured on chr22: 3 -> 1.73 ms, 2 -> 1.76, 6 -> 1.85); among those the split of the chromosome that wastes the
+  // fewest 64-window segments
+  const int nseg = (int)((d->C / d->M + 63) / 64);
+  int rpl = 1;
+  if (nseg >= 2) {
+    int best_waste = 1 << 30;
+    for (int r : {3, 2, 4}) {
+      const int waste = (nseg + r - 1) / r * r - nseg;
+      if (waste < best_waste) { best_waste = waste; rpl = r; }
+    }
+  }
+  if (const char* e = std::getenv("GNX_RK_RPL")) rpl = std::max(1, std::min(GNX_RK_RPL_MAX, std::atoi(e)));
+  int stride = rpl * 64 + S - 1;
+  stride += stride & 1;
+  if (U.size() > 65000 || (size_t)A * stride * 2 > 65535) return GNX_OK;  // does not fit 16 bits: float kernel only
+  if (U.empty()) U.push_back(0.5f);
+  const int K = (int)U.size();
+  // bucket b covers [b/1024, (b+1)/1024) (bucket 0 also everything below, bucket 1023 everything above):
+  // rank(p) lies in [#{U < lower edge}, #{U < upper edge}]
+  std::vector<uint32_t> lut(1024);
+  int steps = 0;
+  for (int b = 0; b < 1024; ++b) {
+    const int lo = b == 0 ? 0 : (int)(std::lower_bound(U.begin(), U.end(), (float)b / 1024.0f) - U.begin());
+    const int hi = b == 1023 ? K : (int)(std::lower_bound(U.begin(), U.end(), (float)(b + 1) / 1024.0f) - U.begin());
+    lut[(size_t)b] = (uint32_t)lo | ((uint32_t)hi << 16);
+    int st = 0;
+    while ((1 << st) < hi - lo + 1) ++st;
+    steps = std::max(steps, st);
+  }
+  const int tree_bytes = 8 << D;
+  int group_bytes = 4096;  // per staging buffer; two of them per block
+  if (const char* e = std::getenv("GNX_RK_GROUP_BYTES")) group_bytes = std::max(tree_bytes, std::min(8192, std::atoi(e)));
+  const int G = std::max(1, group_bytes / tree_bytes);
+  std::vector<int32_t> group_tree0, group_class;
+  {
+    int in_group = 0, cur = -1;
+    for (size_t k = 0; k < order.size(); ++k) {
+      const int c = d->tree_class[order[k]];
+      if (c != cur || in_group == G) { group_tree0.push_back((int32_t)k); group_class.push_back(c); in_group = 0; cur = c; }
+      ++in_group;
+    }
+    group_tree0.push_back((int32_t)order.size());
+  }
+  std::vector<uint8_t> packed(order.size() * (size_t)tree_bytes, 0);
+  for (size_t k = 0; k < order.size(); ++k) {
+    uint8_t* tb = packed.data() + k * tree_bytes;
+    tree_fill_rk(d, d->tree_off[order[k]], 0, 1, 0, D, U, stride, reinterpret_cast<uint32_t*>(tb),
+                 reinterpret_cast<float*>(tb + ((size_t)4 << D)));
+  }
+  int rc;
+  if ((rc = dev_upload(m, packed, &m->xgb.rk_packed, 64)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, U, &m->xgb.rk_thr, 64)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, lut, &m->xgb.rk_lut)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, group_tree0, &m->xgb.rk_group_tree0)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, group_class, &m->xgb.rk_group_class)) != GNX_OK) return rc;
+  m->xgb.rk_K = K; m->xgb.rk_steps = steps; m->xgb.rk_stride = stride; m->xgb.rk_tree_bytes = tree_bytes;
+  m->xgb.rk_n_groups = (int32_t)group_class.size(); m->xgb.rk_max_group = G; m->xgb.rk_rpl = rpl;
+  return GNX_OK;
+}
+
 static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
   gnx_ctx* ctx = m->ctx;
   const int A = d->A, S = d->S, F = S * A;
@@ -345,7 +440,7 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
   m->xgb.base_score = d->base_score;
   m->info.n_trees = d->n_trees;
   m->info.tree_depth = D;
-  return GNX_OK;
+  return build_xgb_rk(m, d, order, D);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -807,7 +902,8 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     L.W = (int32_t)m->info.W; L.A = m->info.A; L.S = m->info.S;
     L.d = m->xgb; L.proba = d_p32; L.proba64 = d_p64; L.labels = d_lab;
     ProfScope ps(ctx, GNX_K_SMOOTH_XGB);
-    HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->n_cu, ctx->stream));
+    if (m->xgb.rk_packed) HIPCHK(ctx, gnx_launch_smooth_xgb_rk(L, ctx->stream));
+    else HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->n_cu, ctx->stream));
     return GNX_OK;
   }
   if (m->info.smooth_kind == GNX_SMOOTH_CRF) {

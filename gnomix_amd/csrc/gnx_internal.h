@@ -82,7 +82,21 @@ struct SmoothXGBDev {
   const int32_t* group_class = nullptr;  // [n_groups]
   int32_t n_groups = 0, n_trees = 0, D = 0, tree_bytes = 0, max_group = 0;
   float base_score = 0.5f;
+  // rank-quantised copy for k_smooth_xgb_rk (NULL when the ensemble does not fit 16-bit ranks / offsets):
+  // every split threshold is replaced by its index in the sorted list of all thresholds, every base probability by
+  // the number of thresholds <= it, so `p < threshold` becomes a 16-bit integer compare with the same outcome.
+  // Per tree: 2^D node words (heap slot 0 unused; (rank field << 16) | byte offset into the class-major u16 strip)
+  // followed by 2^D float leaves.
+  const uint8_t* rk_packed = nullptr;
+  const float* rk_thr = nullptr;         // [rk_K] sorted distinct finite thresholds
+  const uint32_t* rk_lut = nullptr;      // [1024] first | (last << 16) candidate index per 1/1024-wide bucket
+  const int32_t* rk_group_tree0 = nullptr;
+  const int32_t* rk_group_class = nullptr;
+  int32_t rk_K = 0, rk_steps = 0, rk_stride = 0, rk_tree_bytes = 0, rk_n_groups = 0, rk_max_group = 0;
+  int32_t rk_rpl = 0;                    // 64-window segments per strip the node offsets were laid out for
 };
+
+constexpr int GNX_RK_RPL_MAX = 6;  // most 64-window segments per strip the rank kernel is instantiated for
 
 static inline int gnx_tree_bytes(int D) {
   const int half = 1 << (D - 1);
@@ -251,6 +265,7 @@ struct gnx_model {
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, int n_cu, hipStream_t s);
+hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);
 hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwp,

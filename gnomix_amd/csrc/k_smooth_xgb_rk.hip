@@ -1,0 +1,331 @@
+// k_smooth_xgb_rk.hip — the sliding-window tree smoother on 16-bit RANKS (default variant of k_smooth_xgb).
+//
+// Same contract and same arithmetic as k_smooth_xgb.hip (slide_window + XGBClassifier.predict_proba + argmax,
+// reference src/Smooth/utils.py:4-29, src/Smooth/smooth.py:40-65, src/Smooth/models.py:8-24).  The float kernel is
+// bound by the LDS pipe (12 bytes fetched per lane per node: an 8-byte node and a 4-byte probability) with the VALU
+// close behind.  A tree only ever asks "p < threshold", and there are at most a few ten thousand distinct thresholds
+// in an ensemble, so the model loader sorts them once and
+//   * a base probability p becomes r(p) = #{thresholds <= p}  (16 bits, computed while the strip is staged: a
+//     1024-bucket table narrows the search to a handful of candidates, then a fixed-length branchless bisection),
+//   * a node becomes ONE 32-bit word: (k+1) << 16 | byte offset of its feature in the strip, k = index of its threshold;
+//     p < U[k]  <=>  r(p) < k+1, so every walk takes exactly the branch the float compare takes and lands on the same
+//     leaf; the leaves stay float32 and are summed in the same order -> margins bit-identical to the float kernel.
+// Per node a lane now fetches 4 + 2 bytes, and the level costs 4 VALU ops (address, address, compare, add-with-carry).
+// The strip is class-major ([class][padded window] u16) so that the lanes of a wave sitting on the same node read
+// consecutive halfwords.
+#include <cstdio>
+#include <cstdlib>
+
+#include "gnx_internal.h"
+
+namespace {
+
+constexpr int WS = 64;  // windows per segment = one wave width
+
+__device__ __forceinline__ int slide_src(int j, int W, int pad) {
+  // reflect padding of slide_window (src/Smooth/utils.py:14-17)
+  if (j < pad) return pad - 1 - j;
+  if (j < pad + W) return j - pad;
+  return W - 1 - (j - pad - W);
+}
+
+// NV independent rank computations side by side: r = #{U[k] <= p}; NaN -> 0xFFFF ("never less than a threshold")
+template <int NV>
+__device__ __forceinline__ void ranks(const float* __restrict__ U, const uint32_t* __restrict__ lut, int K, int steps,
+                                      const float* p, uint32_t* r) {
+  int lo[NV], hi[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float sc = p[i] * 1024.0f;
+    int b = (int)fminf(fmaxf(sc, 0.0f), 1023.0f);  // NaN -> 0 (fmaxf drops it), fixed up below
+    const uint32_t e = lut[b];
+    lo[i] = (int)(e & 0xffffu);
+    hi[i] = (int)(e >> 16);
+  }
+  for (int s = 0; s < steps; ++s) {
+    float u[NV];
+    int mid[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      mid[i] = (lo[i] + hi[i]) >> 1;
+      u[i] = U[min(mid[i], K - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool open = lo[i] < hi[i];
+      const bool up = open && (u[i] <= p[i]);
+      hi[i] = (open && !up) ? mid[i] : hi[i];
+      lo[i] = up ? mid[i] + 1 : lo[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) r[i] = (p[i] != p[i]) ? 0xFFFFu : (uint32_t)lo[i];
+}
+
+// One level for R segments at once: j = 2j + (r >= rank field of the node), as v_cmp (SDWA picks the field out of the
+// node word) + v_addc (the compare's mask is the carry-in).  hipcc's own lowering of the same C++ spends ~7 VALU ops
+// per level on bit bookkeeping; this is 2, which is what makes the LDS pipe the bound again.  gfx950 wants two wait
+// states between a VALU write of an SGPR pair and a VALU read of it: with R >= 3 the other segments' instructions
+// provide them, smaller R pads with s_nop.
+template <int R>
+__device__ __forceinline__ void step_rk(uint32_t* j, const uint32_t* nd, const uint32_t* r) {
+  if constexpr (R == 1) {
+    uint64_t c0;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n0], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %[j0], %[c0], %[j0], %[j0], %[c0]"
+        : [j0] "+v"(j[0]), [c0] "=&s"(c0)
+        : [n0] "v"(nd[0]), [r0] "v"(r[0]));
+  } else if constexpr (R == 2) {
+    uint64_t c0, c1;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n0], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c1], %[n1], %[r1] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %[j0], %[c0], %[j0], %[j0], %[c0]\n\t"
+        "v_addc_co_u32 %[j1], %[c1], %[j1], %[j1], %[c1]"
+        : [j0] "+v"(j[0]), [j1] "+v"(j[1]), [c0] "=&s"(c0), [c1] "=&s"(c1)
+        : [n0] "v"(nd[0]), [r0] "v"(r[0]), [n1] "v"(nd[1]), [r1] "v"(r[1]));
+  } else if constexpr (R == 3) {
+    uint64_t c0, c1, c2;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n0], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c1], %[n1], %[r1] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c2], %[n2], %[r2] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_addc_co_u32 %[j0], %[c0], %[j0], %[j0], %[c0]\n\t"
+        "v_addc_co_u32 %[j1], %[c1], %[j1], %[j1], %[c1]\n\t"
+        "v_addc_co_u32 %[j2], %[c2], %[j2], %[j2], %[c2]"
+        : [j0] "+v"(j[0]), [j1] "+v"(j[1]), [j2] "+v"(j[2]), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
+        : [n0] "v"(nd[0]), [r0] "v"(r[0]), [n1] "v"(nd[1]), [r1] "v"(r[1]), [n2] "v"(nd[2]), [r2] "v"(r[2]));
+  } else if constexpr (R == 4) {
+    step_rk<2>(j, nd, r);
+    step_rk<2>(j + 2, nd + 2, r + 2);
+  } else if constexpr (R == 5) {
+    step_rk<3>(j, nd, r);
+    step_rk<2>(j + 3, nd + 3, r + 3);
+  } else {
+    static_assert(R == 6, "segments per strip");
+    step_rk<3>(j, nd, r);
+    step_rk<3>(j + 3, nd + 3, r + 3);
+  }
+}
+
+// D levels for the R segments of a lane: tb = the tree's 2^D node words + 2^D leaves (LDS), rb = the lane's origin in
+// its strip (LDS); segment k sits 64 windows = 128 bytes further
+template <int D, int R>
+__device__ __forceinline__ void walk_rk(const uint8_t* tb, const uint8_t* rb, float* psum) {
+  uint32_t j[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) j[k] = 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    uint32_t nd[R], r[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) nd[k] = reinterpret_cast<const uint32_t*>(tb)[j[k]];
+#pragma unroll
+    for (int k = 0; k < R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (nd[k] & 0xffffu));
+    step_rk<R>(j, nd, r);
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) psum[k] += reinterpret_cast<const float*>(tb)[j[k]];
+}
+
+__device__ __forceinline__ float walk_rk_rt(const uint8_t* tb, const uint8_t* rb, int D) {
+  uint32_t j = 1;
+  for (int d = 0; d < D; ++d) {
+    const uint32_t nd = reinterpret_cast<const uint32_t*>(tb)[j];
+    const uint32_t r = *reinterpret_cast<const uint16_t*>(rb + (nd & 0xffffu));
+    j = 2 * j + ((r < (nd >> 16)) ? 0u : 1u);
+  }
+  return reinterpret_cast<const float*>(tb)[j];
+}
+
+// One wave = one haplotype x RPL consecutive 64-window segments; NWAVE haplotypes per block.  DT = depth (0 = runtime).
+template <int RPL, int NWAVE, int DT>
+__global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int THREADS = NWAVE * 64;
+  const int A = L.A, W = L.W, S = L.S, pad = (S + 1) / 2;
+  const int D = DT ? DT : L.d.D;
+  const int tree_bytes = L.d.rk_tree_bytes;
+  const int stride = L.d.rk_stride;              // halfwords per class row (>= RPL*64 + S - 1)
+  const int strip_w = RPL * WS + S - 1;          // padded windows held per haplotype
+  const int strip_bytes = A * stride * 2;
+  const int buf_bytes = L.d.rk_max_group * tree_bytes;  // multiple of 16
+  uint8_t* strip = lds;                          // [NWAVE][A][stride] u16
+  uint8_t* tbuf0 = lds + (((size_t)NWAVE * strip_bytes + 15) & ~(size_t)15);
+  uint8_t* tbuf1 = tbuf0 + buf_bytes;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t h0 = (int64_t)blockIdx.y * NWAVE;
+  const int w0 = blockIdx.x * (RPL * WS);
+
+  // ---- stage the reflected base-probability strips as ranks -------------------------------------------------
+  {
+    constexpr int NV = 4;
+    const int per_h = strip_w * A;
+    const int total = NWAVE * per_h;
+    for (int e0 = tid; e0 < total; e0 += NV * THREADS) {
+      float p[NV];
+      uint32_t r[NV];
+      int dst[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e = min(e0 + i * THREADS, total - 1);  // clamped: loads stay unconditional
+        const int hl = e / per_h, rr = e - hl * per_h;
+        const int q = rr / A, a = rr - q * A;
+        const int64_t n = min(h0 + hl, L.N - 1);
+        const int j = min(w0 + q, W + 2 * pad - 1);
+        const size_t idx = ((size_t)n * W + slide_src(j, W, pad)) * A + a;
+        p[i] = L.b_is_f64 ? (float)reinterpret_cast<const double*>(L.B)[idx] : reinterpret_cast<const float*>(L.B)[idx];
+        dst[i] = (hl * A + a) * stride + q;
+      }
+      ranks<NV>(L.d.rk_thr, L.d.rk_lut, L.d.rk_K, L.d.rk_steps, p, r);
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (e0 + i * THREADS < total) reinterpret_cast<uint16_t*>(strip)[dst[i]] = (uint16_t)r[i];
+    }
+  }
+
+  const int64_t n = h0 + wave;
+  const uint8_t* rowbase[RPL];
+  bool valid[RPL];
+  size_t orow[RPL];
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    rowbase[k] = strip + (size_t)wave * strip_bytes + (size_t)(k * WS + lane) * 2;
+    const int w = w0 + k * WS + lane;
+    valid[k] = (n < L.N) && (w < W);
+    orow[k] = ((size_t)(valid[k] ? n : 0) * W + (valid[k] ? w : 0)) * A;
+  }
+
+  // ---- tree groups through the double-buffered LDS window ----
+  const int ng = L.d.rk_n_groups;
+  constexpr int MAXV = (8192 / 16 + THREADS - 1) / THREADS;  // 16-byte staging pieces per thread (buf <= 8 KB)
+  uint4 stg[MAXV];
+  const int nv = (buf_bytes / 16 + THREADS - 1) / THREADS;
+  // unconditional clamped loads: no branch around a load, so hipcc keeps its waits counted
+#define GNX_G_LOAD(g)                                                                               \
+  {                                                                                                 \
+    const int t0_ = L.d.rk_group_tree0[g], t1_ = L.d.rk_group_tree0[(g) + 1];                       \
+    const int last_ = (t1_ - t0_) * tree_bytes / 16 - 1;                                            \
+    const uint4* src_ = reinterpret_cast<const uint4*>(L.d.rk_packed + (size_t)t0_ * tree_bytes);   \
+    _Pragma("unroll") for (int v = 0; v < MAXV; ++v) if (v < nv) stg[v] = src_[min(v * THREADS + tid, last_)]; \
+  }
+#define GNX_G_STORE(dst)                                                                            \
+  {                                                                                                 \
+    _Pragma("unroll") for (int v = 0; v < MAXV; ++v) {                                              \
+      const int e_ = v * THREADS + tid;                                                             \
+      if (v < nv && e_ * 16 < buf_bytes) *reinterpret_cast<uint4*>((dst) + (size_t)e_ * 16) = stg[v]; \
+    }                                                                                               \
+  }
+
+  float psum[RPL];
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) psum[k] = 0.f;
+
+  GNX_G_LOAD(0);
+  GNX_G_STORE(tbuf0);
+  __syncthreads();
+
+  int cur_class = L.d.rk_group_class[0];
+  for (int g = 0; g < ng; ++g) {
+    uint8_t* cur = (g & 1) ? tbuf1 : tbuf0;
+    uint8_t* nxt = (g & 1) ? tbuf0 : tbuf1;
+    const int gn = min(g + 1, ng - 1);  // clamped: the last iteration re-fetches its own group
+    GNX_G_LOAD(gn);
+
+    const int cls = L.d.rk_group_class[g];
+    if (cls != cur_class) {  // class finished: park its margin (base_score + psum)
+#pragma unroll
+      for (int k = 0; k < RPL; ++k) {
+        if (valid[k]) L.proba[orow[k] + cur_class] = L.d.base_score + psum[k];
+        psum[k] = 0.f;
+      }
+      cur_class = cls;
+    }
+    const int nt = L.d.rk_group_tree0[g + 1] - L.d.rk_group_tree0[g];
+    for (int t = 0; t < nt; ++t) {
+      const uint8_t* tb = cur + (size_t)t * tree_bytes;
+      if constexpr (DT > 0) walk_rk<DT, RPL>(tb, rowbase[0], psum);
+      else {
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) psum[k] += walk_rk_rt(tb, rowbase[k], D);
+      }
+    }
+    GNX_G_STORE(nxt);
+    __syncthreads();
+  }
+#undef GNX_G_LOAD
+#undef GNX_G_STORE
+#pragma unroll
+  for (int k = 0; k < RPL; ++k)
+    if (valid[k]) L.proba[orow[k] + cur_class] = L.d.base_score + psum[k];
+
+  // ---- softmax (xgboost common/math.h Softmax) + argmax, per row, by the lane that wrote the margins ----
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    if (!valid[k]) continue;
+    float* o = L.proba + orow[k];
+    float wmax = o[0];
+    for (int a = 1; a < A; ++a) wmax = fmaxf(o[a], wmax);
+    double wsum = 0.0;
+    for (int a = 0; a < A; ++a) {
+      const float e = (float)exp((double)(o[a] - wmax));
+      o[a] = e;
+      wsum += (double)e;
+    }
+    const float fs = (float)wsum;
+    int best = 0;
+    float bv = -1.f;
+    for (int a = 0; a < A; ++a) {
+      const float p = o[a] / fs;
+      o[a] = p;
+      if (L.proba64) L.proba64[orow[k] + a] = (double)p;
+      if (p > bv) { bv = p; best = a; }
+    }
+    if (L.labels) L.labels[orow[k] / A] = best;
+  }
+}
+
+template <int NWAVE>
+size_t lds_bytes(const SmoothXGBDev& d, int A) {
+  const size_t strip = (size_t)NWAVE * A * d.rk_stride * 2;
+  return ((strip + 15) & ~(size_t)15) + 2 * (size_t)d.rk_max_group * d.rk_tree_bytes;
+}
+
+template <int RPL, int NWAVE>
+hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
+  const dim3 grid((unsigned)((L.W + RPL * WS - 1) / (RPL * WS)), (unsigned)((L.N + NWAVE - 1) / NWAVE));
+  const size_t lds = lds_bytes<NWAVE>(L.d, L.A);
+  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  if (L.d.D == 4) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb_rk<RPL, NWAVE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_smooth_xgb_rk<RPL, NWAVE, 4>), grid, dim3(NWAVE * 64), lds, s, L);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb_rk<RPL, NWAVE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_smooth_xgb_rk<RPL, NWAVE, 0>), grid, dim3(NWAVE * 64), lds, s, L);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L0, hipStream_t s) {
+  if (L0.N <= 0) return hipSuccess;
+  SmoothXGBLaunch L = L0;
+  if (const char* t = std::getenv("GNX_RK_STEPS")) L.d.rk_steps = std::atoi(t);  // experiments only
+  const int rpl = L.d.rk_rpl;  // fixed at model load: the node offsets encode the strip stride
+  int nw = 0;
+  if (const char* t = std::getenv("GNX_SM_NW")) nw = std::atoi(t);
+  if (nw != 2 && nw != 4 && nw != 8) {
+    // as many waves per CU as the LDS allows: 8-wave blocks unless 4-wave blocks pack the 160 KB better
+    const size_t l8 = lds_bytes<8>(L.d, L.A), l4 = lds_bytes<4>(L.d, L.A);
+    const size_t w8 = l8 <= (size_t)160 * 1024 ? ((size_t)160 * 1024 / l8) * 8 : 0, w4 = l4 <= (size_t)160 * 1024 ? ((size_t)160 * 1024 / l4) * 4 : 0;
+    nw = (w8 >= w4 && w8 > 0) ? 8 : (w4 > 0 ? 4 : 2);
+    if (L.N < 8) nw = L.N < 3 ? 2 : 4;
+  }
+#define GNX_SM_CASE(R_) \
+  if (rpl == R_) return nw == 8 ? launch<R_, 8>(L, s) : (nw == 4 ? launch<R_, 4>(L, s) : launch<R_, 2>(L, s));
+  GNX_SM_CASE(1) GNX_SM_CASE(2) GNX_SM_CASE(3) GNX_SM_CASE(4) GNX_SM_CASE(5) GNX_SM_CASE(6)
+#undef GNX_SM_CASE
+  return hipErrorInvalidValue;
+}

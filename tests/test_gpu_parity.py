@@ -596,3 +596,41 @@ def test_forest_base_rejects_bad_models(ga):
     d.fb_win_tree0[-1] -= 1
     with pytest.raises(ga.GnxError, match="fb_win_tree0"):
         ga.DeviceModel(d)
+
+
+# ---------------------------------------------------------------- rank-quantised smoother vs float smoother --------
+@pytest.mark.parametrize("W,A,S,rounds,depth", [(370, 7, 75, 12, 4), (131, 3, 31, 6, 5), (160, 12, 75, 4, 2), (500, 5, 75, 8, 4)])
+def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S, rounds, depth):
+    """k_smooth_xgb_rk replaces every `p < threshold` by a 16-bit rank compare: outputs must be BIT-identical to the
+    float kernel, including probabilities that sit exactly on a threshold (p == thr goes right), just below / above
+    one, 0, 1, values outside [0, 1], infinities and NaN (never < anything)."""
+    from gnomix_amd import synth
+    rng = np.random.RandomState(W + A)
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=S, context=5, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(rounds, A, S * A, depth=depth, seed=W, thr_lo=0.0, thr_hi=1.0, p_early_leaf=0.15).items():
+        setattr(d, k, v)
+    N = 24
+    B = rng.dirichlet(np.ones(A) * 0.4, size=(N, W)).astype(np.float32)
+    thr = d.cond[d.left != -1]
+    pick = rng.choice(thr, size=B.shape)
+    m = rng.random_sample(B.shape)
+    B = np.where(m < 0.25, pick, B)                                            # exactly on a threshold
+    B = np.where((m >= 0.25) & (m < 0.35), np.nextafter(pick, np.float32(-1)), B)   # one ulp below
+    B = np.where((m >= 0.35) & (m < 0.45), np.nextafter(pick, np.float32(2)), B)    # one ulp above
+    special = np.array([0.0, 1.0, -0.25, 1.75, np.inf, -np.inf, np.nan, 1e-30, -0.0], np.float32)
+    sp = m > 0.97
+    sp[8:] = False                                                            # keep some haplotypes finite for the oracle
+    B = np.where(sp, rng.choice(special, size=B.shape), B).astype(np.float32)
+    monkeypatch.setenv("GNX_SMOOTH_IMPL", "f32")
+    pf, lf = ga.DeviceModel(d).smooth_predict(B)
+    monkeypatch.setenv("GNX_SMOOTH_IMPL", "rk")
+    for rpl in ("1", "2", "3", "4", "5", "6"):
+        monkeypatch.setenv("GNX_RK_RPL", rpl)
+        pr, lr = ga.DeviceModel(d).smooth_predict(B)
+        assert np.array_equal(pf, pr, equal_nan=True), rpl
+        assert np.array_equal(lf, lr), rpl
+    finite = np.isfinite(B).all(axis=(1, 2))                                  # oracle as the third opinion
+    T = _oracle_trees(oracle, d)
+    p_ref, l_ref = oracle.smooth_xgb(T, B[finite], S)
+    assert np.array_equal(lf[finite], l_ref)
+    _close_f32(pf[finite], p_ref)
