@@ -116,6 +116,17 @@ def main():
                          "hbm_frac": bytes_sm * N / avg_sm / 1e9 / HBM_PEAK_GBS if avg_sm else None,
                          "node_steps_per_s": node_steps * N / avg_sm if avg_sm else None},
     }
+    # LDS-pipe occupancy of the tree pass from the committed counter pass (profiles/*_pmc.json: SQ_LDS_IDX_ACTIVE summed over
+    # the 256 CUs / (256 x launch duration x 2.4 GHz)); informational, the live numbers are the event timings above
+    try:
+        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+        pm = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
+        for k, v in pm.items():
+            if "k_smooth_xgb" in k and "SQ_LDS_IDX_ACTIVE" in v and avg_sm:
+                kernels["k_smooth_xgb"]["lds_pipe_busy_frac"] = v["SQ_LDS_IDX_ACTIVE"]["avg_per_launch"] / (256 * avg_sm * 2.4e9)
+                kernels["k_smooth_xgb"]["lds_pipe_source"] = pmcs[-1]
+    except Exception:
+        pass
     dom = "k_smooth_xgb" if avg_sm >= avg_base else "k_base_logistic"
     dom_bytes = bytes_sm if dom == "k_smooth_xgb" else bytes_base
     dom_avg = avg_sm if dom == "k_smooth_xgb" else avg_base

@@ -682,7 +682,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal})
+  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal, &ctx->ws_marg})
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -901,6 +901,11 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     L.B = dB; L.b_is_f64 = b_is_f64; L.N = N;
     L.W = (int32_t)m->info.W; L.A = m->info.A; L.S = m->info.S;
     L.d = m->xgb; L.proba = d_p32; L.proba64 = d_p64; L.labels = d_lab;
+    if (m->xgb.rk_packed) {
+      int rc = ws_reserve(ctx, ctx->ws_marg, n * sizeof(float));
+      if (rc != GNX_OK) return rc;
+      L.marg = (float*)ctx->ws_marg.p;
+    }
     ProfScope ps(ctx, GNX_K_SMOOTH_XGB);
     if (m->xgb.rk_packed) HIPCHK(ctx, gnx_launch_smooth_xgb_rk(L, ctx->stream));
     else HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->n_cu, ctx->stream));

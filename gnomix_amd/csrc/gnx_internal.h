@@ -28,7 +28,7 @@ struct gnx_ctx {
   std::string err;
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)
-  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair, ws_y0, ws_cal;
+  gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair, ws_y0, ws_cal, ws_marg;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -129,7 +129,8 @@ struct SmoothXGBLaunch {
   int64_t N;
   int32_t W, A, S;
   SmoothXGBDev d;
-  float* proba;      // (N, W, A): margins are parked here between class passes
+  float* proba;      // (N, W, A): the float kernel parks its margins here between class passes
+  float* marg;       // (A, N*W) class-major margin scratch of the rank kernel (coalesced parking)
   double* proba64;   // optional widened copy
   int32_t* labels;   // optional
 };

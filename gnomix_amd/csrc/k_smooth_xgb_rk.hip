@@ -189,12 +189,13 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
   const uint8_t* rowbase[RPL];
   bool valid[RPL];
   size_t orow[RPL];
+  const size_t NW = (size_t)L.N * W;  // class stride of the margin scratch
 #pragma unroll
   for (int k = 0; k < RPL; ++k) {
     rowbase[k] = strip + (size_t)wave * strip_bytes + (size_t)(k * WS + lane) * 2;
     const int w = w0 + k * WS + lane;
     valid[k] = (n < L.N) && (w < W);
-    orow[k] = ((size_t)(valid[k] ? n : 0) * W + (valid[k] ? w : 0)) * A;
+    orow[k] = (size_t)(valid[k] ? n : 0) * W + (valid[k] ? w : 0);  // row index (n, w)
   }
 
   // ---- tree groups through the double-buffered LDS window ----
@@ -234,10 +235,10 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
     GNX_G_LOAD(gn);
 
     const int cls = L.d.rk_group_class[g];
-    if (cls != cur_class) {  // class finished: park its margin (base_score + psum)
+    if (cls != cur_class) {  // class finished: park its margin (base_score + psum), class-major = full cache lines
 #pragma unroll
       for (int k = 0; k < RPL; ++k) {
-        if (valid[k]) L.proba[orow[k] + cur_class] = L.d.base_score + psum[k];
+        if (valid[k]) L.marg[(size_t)cur_class * NW + orow[k]] = L.d.base_score + psum[k];
         psum[k] = 0.f;
       }
       cur_class = cls;
@@ -258,18 +259,19 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
 #undef GNX_G_STORE
 #pragma unroll
   for (int k = 0; k < RPL; ++k)
-    if (valid[k]) L.proba[orow[k] + cur_class] = L.d.base_score + psum[k];
+    if (valid[k]) L.marg[(size_t)cur_class * NW + orow[k]] = L.d.base_score + psum[k];
 
   // ---- softmax (xgboost common/math.h Softmax) + argmax, per row, by the lane that wrote the margins ----
 #pragma unroll
   for (int k = 0; k < RPL; ++k) {
     if (!valid[k]) continue;
-    float* o = L.proba + orow[k];
-    float wmax = o[0];
-    for (int a = 1; a < A; ++a) wmax = fmaxf(o[a], wmax);
+    const float* mg = L.marg + orow[k];
+    float* o = L.proba + orow[k] * A;
+    float wmax = mg[0];
+    for (int a = 1; a < A; ++a) wmax = fmaxf(mg[(size_t)a * NW], wmax);
     double wsum = 0.0;
     for (int a = 0; a < A; ++a) {
-      const float e = (float)exp((double)(o[a] - wmax));
+      const float e = (float)exp((double)(mg[(size_t)a * NW] - wmax));
       o[a] = e;
       wsum += (double)e;
     }
@@ -279,10 +281,10 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
     for (int a = 0; a < A; ++a) {
       const float p = o[a] / fs;
       o[a] = p;
-      if (L.proba64) L.proba64[orow[k] + a] = (double)p;
+      if (L.proba64) L.proba64[orow[k] * A + a] = (double)p;
       if (p > bv) { bv = p; best = a; }
     }
-    if (L.labels) L.labels[orow[k] / A] = best;
+    if (L.labels) L.labels[orow[k]] = best;
   }
 }
 
