@@ -100,6 +100,33 @@ def forest_from_xgb_json(window_dumps, n_class, base_score=0.5, missing=2):
                 fb_base_score=float(base_score), fb_missing=int(missing))
 
 
+def rforest_from_sklearn(models, n_class):
+    """Per-window fitted sklearn RandomForestClassifier (RFBase, src/Base/models.py:54-66) -> the rf_* arrays.
+    rf_value[node] is what DecisionTreeClassifier.predict_proba returns for a sample that ends in `node`: tree_.value's
+    row, divided by its sum on the scikit-learn versions whose predict_proba still normalises (counts in tree_.value)."""
+    import inspect
+    from sklearn.tree import DecisionTreeClassifier
+    normalise = "normalizer" in inspect.getsource(DecisionTreeClassifier.predict_proba)
+    wt0, off, L, R, F, T, V = [0], [0], [], [], [], [], []
+    for i, m in enumerate(models):
+        if list(m.classes_) != list(range(n_class)):
+            raise ValueError(f"window {i}: classes_ != 0..A-1 (the vectorized reference path has no remap, base.py:176)")
+        for e in m.estimators_:
+            t = e.tree_
+            proba = np.array(t.value[:, 0, :n_class], dtype=np.float64)
+            if normalise:
+                normalizer = proba.sum(axis=1)[:, np.newaxis]
+                normalizer[normalizer == 0.0] = 1.0
+                proba /= normalizer
+            L.append(np.asarray(t.children_left, np.int32)); R.append(np.asarray(t.children_right, np.int32))
+            F.append(np.where(t.children_left == -1, 0, t.feature).astype(np.int32))
+            T.append(np.asarray(t.threshold, np.float64)); V.append(proba)
+            off.append(off[-1] + t.node_count)
+        wt0.append(len(off) - 1)
+    return dict(rf_win_tree0=np.array(wt0, np.int32), rf_tree_off=np.array(off, np.int32), rf_left=np.concatenate(L),
+                rf_right=np.concatenate(R), rf_feat=np.concatenate(F), rf_thr=np.concatenate(T), rf_value=np.concatenate(V))
+
+
 def calibrator_arrays(iso_models):
     """fitted sklearn IsotonicRegression per class (Calibration.py:55) -> calib_off / calib_x / calib_y"""
     off, xs, ys = [0], [], []
@@ -136,6 +163,10 @@ def from_reference_model(model) -> GnxModelData:
         d.base_kind = "forest"
         dumps = [m.get_booster().get_dump(dump_format="json") for m in models]
         for k, v in forest_from_xgb_json(dumps, A, missing=int(getattr(model.base, "missing_encoding", 2))).items():
+            setattr(d, k, v)
+    elif first == "RandomForestClassifier":  # RFBase (src/Base/models.py:54-66)
+        d.base_kind = "rforest"
+        for k, v in rforest_from_sklearn(models, A).items():
             setattr(d, k, v)
     else:
         raise NotImplementedError(f"base model {first}")

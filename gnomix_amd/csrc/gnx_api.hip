@@ -547,6 +547,81 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// model preparation: random-forest base — sklearn tree arrays -> mask-node heaps + expanded leaf rows
+// ------------------------------------------------------------------------------------------------
+static int rf_depth(const gnx_model_desc* d, int32_t o, int32_t nid, int32_t n_nodes, int guard) {
+  if (guard > 64 || nid < 0 || nid >= n_nodes) return -1000;
+  if (d->rf_left[o + nid] == -1) return 0;
+  const int l = rf_depth(d, o, d->rf_left[o + nid], n_nodes, guard + 1);
+  const int r = rf_depth(d, o, d->rf_right[o + nid], n_nodes, guard + 1);
+  if (l < 0 || r < 0) return -1000;
+  return 1 + std::max(l, r);
+}
+
+static void rf_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint32_t* nodes,
+                    double* leafval) {
+  const bool leaf = d->rf_left[o + nid] == -1;
+  if (depth == D) {
+    std::memcpy(leafval + (size_t)(j - (1u << D)) * d->A, d->rf_value + (size_t)(o + nid) * d->A, (size_t)d->A * sizeof(double));
+    return;
+  }
+  uint32_t word = 0xFu;  // early leaf: every value goes left, both subtrees replicate the leaf
+  if (!leaf) {
+    uint32_t mask = 0;
+    for (int v = 0; v < 4; ++v) mask |= (((double)(float)v <= d->rf_thr[o + nid]) ? 1u : 0u) << v;  // _tree.pyx: X[i, f] <= threshold
+    word = ((uint32_t)d->rf_feat[o + nid] << 4) | mask;
+  }
+  nodes[j] = word;
+  rf_fill(d, o, leaf ? nid : d->rf_left[o + nid], 2 * j, depth + 1, D, nodes, leafval);
+  rf_fill(d, o, leaf ? nid : d->rf_right[o + nid], 2 * j + 1, depth + 1, D, nodes, leafval);
+}
+
+static int build_rforest(gnx_model* m, const gnx_model_desc* d) {
+  gnx_ctx* ctx = m->ctx;
+  const int A = d->A;
+  const int64_t C = d->C, M = d->M, W = C / M, rem = C - M * W, M_ = M + 2 * d->ctx;
+  if (d->rf_n_trees <= 0 || !d->rf_win_tree0 || !d->rf_tree_off || !d->rf_left || !d->rf_right || !d->rf_feat || !d->rf_thr || !d->rf_value)
+    return fail(ctx, GNX_EINVAL, "rforest base: tree arrays missing");
+  if (d->rf_win_tree0[0] != 0 || d->rf_win_tree0[W] != d->rf_n_trees)
+    return fail(ctx, GNX_EINVAL, "rforest base: rf_win_tree0 must run from 0 to rf_n_trees");
+  if (C < 16) return fail(ctx, GNX_EUNSUPPORTED, "rforest base: fewer than 16 SNPs");
+  int D = 1, max_trees = 0;
+  for (int64_t w = 0; w < W; ++w) {
+    const int32_t t0 = d->rf_win_tree0[w], t1 = d->rf_win_tree0[w + 1];
+    if (t1 <= t0) return fail(ctx, GNX_EINVAL, "rforest base: every window needs at least one tree");
+    max_trees = std::max(max_trees, t1 - t0);
+    const int64_t width = (w == W - 1) ? M_ + rem : M_;
+    for (int32_t t = t0; t < t1; ++t) {
+      const int32_t o = d->rf_tree_off[t], nn = d->rf_tree_off[t + 1] - o;
+      if (nn <= 0) return fail(ctx, GNX_EINVAL, "rforest base: empty tree");
+      const int dep = rf_depth(d, o, 0, nn, 0);
+      if (dep < 0) return fail(ctx, GNX_EINVAL, "rforest base: malformed tree (child index out of range or depth > 64)");
+      D = std::max(D, dep);
+      for (int32_t k = 0; k < nn; ++k)
+        if (d->rf_left[o + k] != -1 && (d->rf_feat[o + k] < 0 || d->rf_feat[o + k] >= width))
+          return fail(ctx, GNX_EINVAL, "rforest base: split feature outside the window's padded slice");
+    }
+  }
+  if (D > 8) return fail(ctx, GNX_EUNSUPPORTED, "rforest base: tree depth > 8");
+  const int tree_bytes = std::max(16, 4 << D);
+  const int max_words = (int)((M_ + rem + 15) / 16);
+  if (gnx_forest_lds_bytes(A, max_words, max_trees, tree_bytes, 64) > (size_t)160 * 1024)
+    return fail(ctx, GNX_EUNSUPPORTED, "rforest base: one window's trees and SNPs exceed the 160 KB LDS");
+  std::vector<uint8_t> packed((size_t)d->rf_n_trees * tree_bytes, 0);
+  std::vector<double> leafval((size_t)d->rf_n_trees * ((size_t)1 << D) * A, 0.0);
+  for (int32_t t = 0; t < d->rf_n_trees; ++t)
+    rf_fill(d, d->rf_tree_off[t], 0, 1, 0, D, reinterpret_cast<uint32_t*>(packed.data() + (size_t)t * tree_bytes),
+            leafval.data() + (size_t)t * ((size_t)1 << D) * A);
+  std::vector<int32_t> win_tree0(d->rf_win_tree0, d->rf_win_tree0 + W + 1);
+  int rc;
+  if ((rc = dev_upload(m, packed, &m->forest.packed, 64)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, leafval, &m->forest.rf_leafval)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, win_tree0, &m->forest.win_tree0)) != GNX_OK) return rc;
+  m->forest.D = D; m->forest.tree_bytes = tree_bytes; m->forest.max_trees = max_trees; m->forest.max_words = max_words;
+  return GNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // model preparation: CovRSK / SVC base — support vectors as bit-planes, run-length table g
 // ------------------------------------------------------------------------------------------------
 static int build_covrsk(gnx_model* m, const gnx_model_desc* d) {
@@ -740,6 +815,7 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
     case GNX_BASE_LOGISTIC: rc = build_lr(m, d); break;
     case GNX_BASE_COVRSK_SVC: rc = build_covrsk(m, d); break;
     case GNX_BASE_FOREST: rc = build_forest(m, d); break;
+    case GNX_BASE_RFOREST: rc = build_rforest(m, d); break;
     default: rc = fail(ctx, GNX_EINVAL, "unknown base_kind");
   }
   if (rc == GNX_OK) switch (d->smooth_kind) {
@@ -823,7 +899,7 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     HIPCHK(ctx, gnx_launch_covrsk(L, ctx->stream));
     return GNX_OK;
   }
-  if (m->info.base_kind == GNX_BASE_FOREST) {
+  if (m->info.base_kind == GNX_BASE_FOREST || m->info.base_kind == GNX_BASE_RFOREST) {
     ProfScope ps(ctx, GNX_K_BASE_FOREST);
     ForestLaunch L{};
     L.X = dX; L.N = N; L.ldx = ldx; L.C = m->info.C; L.ctx = m->info.ctx; L.M = m->info.M;
@@ -833,6 +909,7 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     L.max_trees = m->forest.max_trees; L.max_words = m->forest.max_words; L.missing = m->forest.missing;
     L.base_score = m->forest.base_score;
     L.packed = m->forest.packed; L.win_tree0 = m->forest.win_tree0; L.win_class_tree0 = m->forest.win_class_tree0;
+    L.rf_leafval = m->forest.rf_leafval;
     L.b32 = d_b32; L.b64 = d_b64;
     HIPCHK(ctx, gnx_launch_base_forest(L, ctx->stream));
     return GNX_OK;

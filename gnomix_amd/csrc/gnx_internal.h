@@ -226,6 +226,7 @@ struct ForestDev {
   const int32_t* win_class_tree0 = nullptr; // [W][A+1] class ranges relative to the window's first tree
   int32_t D = 0, tree_bytes = 0, max_trees = 0, max_words = 0, missing = 2;
   float base_score = 0.5f;
+  const double* rf_leafval = nullptr;       // random forest: [tree][2^D heap leaf][A] class-probability rows
 };
 
 struct ForestLaunch {
@@ -236,6 +237,7 @@ struct ForestLaunch {
   const uint8_t* packed;
   const int32_t* win_tree0;
   const int32_t* win_class_tree0;
+  const double* rf_leafval;  // non-NULL selects the random-forest kernel
   float* b32;
   double* b64;
 };

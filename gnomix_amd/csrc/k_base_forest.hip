@@ -66,21 +66,10 @@ __device__ __forceinline__ void walk(const uint8_t* tb, int tree_bytes, const ui
   for (int k = 0; k < NT; ++k) leaf[k] = reinterpret_cast<const float*>(tb + k * tree_bytes)[j[k]];  // leaves follow the 2^D nodes
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6;
-  const int w = L.w_first + blockIdx.y;
-  const int A = L.A, tree_bytes = L.tree_bytes;
+// Stage the calling wave's 64 haplotypes of window w: 8 haplotypes x 8 words per wave instruction.
+__device__ __forceinline__ void stage_window(const ForestLaunch& L, int w, int64_t width, uint32_t* xw, int T) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t C = L.C, ctx = L.ctx, Cp = C + 2 * ctx;
-  const int64_t width = (w == L.W - 1) ? L.width_last : L.width;
-  const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
-
-  uint32_t* xw = reinterpret_cast<uint32_t*>(lds);                                    // [max_words][T]
-  uint8_t* tr = lds + (size_t)L.max_words * T * 4;                                    // trees of this window
-  float* marg = reinterpret_cast<float*>(tr + (((size_t)L.max_trees * tree_bytes + 15) & ~(size_t)15)) + tid;  // [A][T]
-
-  // ---- stage this wave's 64 haplotypes: 8 haplotypes x 8 words per wave instruction -----------------------
   {
     const int64_t s = (int64_t)w * L.M;  // padded coordinate of the window's first SNP
     const int nw = (int)((width + 15) >> 4);
@@ -117,6 +106,22 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
       }
     }
   }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int w = L.w_first + blockIdx.y;
+  const int A = L.A, tree_bytes = L.tree_bytes;
+  const int64_t width = (w == L.W - 1) ? L.width_last : L.width;
+  const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
+
+  uint32_t* xw = reinterpret_cast<uint32_t*>(lds);                                    // [max_words][T]
+  uint8_t* tr = lds + (size_t)L.max_words * T * 4;                                    // trees of this window
+  float* marg = reinterpret_cast<float*>(tr + (((size_t)L.max_trees * tree_bytes + 15) & ~(size_t)15)) + tid;  // [A][T]
+
+  stage_window(L, w, width, xw, T);
   for (int e = tid; e < nt * tree_bytes / 16; e += T)
     reinterpret_cast<uint4*>(tr)[e] = reinterpret_cast<const uint4*>(L.packed + (size_t)t0 * tree_bytes)[e];
   __syncthreads();
@@ -171,6 +176,63 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
   }
 }
 
+// ---- random-forest variant (RFBase, src/Base/models.py:54-66) --------------------------------------------------------
+// Same tile, same mask nodes (mask bit v = "float32(v) <= threshold"); a leaf contributes its class-probability row
+// (float64, expanded per heap slot in global memory: 20 trees x 16 leaves x A doubles per window stay in L1/L2), the
+// rows are added in estimator order and divided by the tree count, as ForestClassifier.predict_proba does.
+template <int AMAX>
+__global__ __launch_bounds__(256) void k_base_rforest(ForestLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int w = L.w_first + blockIdx.y;
+  const int A = L.A, D = L.D, tree_bytes = L.tree_bytes;
+  const int64_t width = (w == L.W - 1) ? L.width_last : L.width;
+  const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
+  uint32_t* xw = reinterpret_cast<uint32_t*>(lds);   // [max_words][T]
+  uint8_t* tr = lds + (size_t)L.max_words * T * 4;   // node words of this window's trees
+  stage_window(L, w, width, xw, T);
+  for (int e = tid; e < nt * tree_bytes / 16; e += T)
+    reinterpret_cast<uint4*>(tr)[e] = reinterpret_cast<const uint4*>(L.packed + (size_t)t0 * tree_bytes)[e];
+  __syncthreads();
+
+  const uint32_t* xcol = xw + tid;
+  double acc[AMAX];
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) acc[a] = 0.0;
+  const size_t leaves = (size_t)1 << D;
+  for (int t = 0; t < nt; ++t) {
+    const uint32_t* nodes = reinterpret_cast<const uint32_t*>(tr + (size_t)t * tree_bytes);
+    uint32_t j = 1;
+    for (int d = 0; d < D; ++d) {
+      const uint32_t nd = nodes[j];
+      j = step(j, nd, xcol[(nd >> 8) * T]);
+    }
+    const double* v = L.rf_leafval + ((size_t)(t0 + t) * leaves + (j - (uint32_t)leaves)) * A;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A) acc[a] += v[a];  // estimator order
+  }
+  const int64_t n = (int64_t)blockIdx.x * T + tid;
+  if (n >= L.N) return;
+  const size_t o = ((size_t)n * L.W + w) * A;
+  const double cnt = (double)nt;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a)
+    if (a < A) {
+      const double p = acc[a] / cnt;
+      if (L.b64) L.b64[o + a] = p;
+      if (L.b32) L.b32[o + a] = (float)p;
+    }
+}
+
+template <int AMAX>
+hipError_t launch_rf(const ForestLaunch& L, int n_windows, int threads, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_rforest<AMAX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)160 * 1024));
+  hipLaunchKernelGGL(k_base_rforest<AMAX>, dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)n_windows), dim3(threads), lds, s, L);
+  return hipGetLastError();
+}
+
 template <int D>
 hipError_t launch_d(const ForestLaunch& L, int n_windows, int threads, size_t lds, hipStream_t s) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_forest<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -194,6 +256,11 @@ hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int max_word
   while (threads > 64 && (int64_t)(threads - 64) >= L.N) threads -= 64;
   const size_t lds = gnx_forest_lds_bytes(L.A, max_words, L.max_trees, L.tree_bytes, threads);
   if (lds > kLds) return hipErrorInvalidValue;
+  if (L.rf_leafval) {
+    if (L.A <= 8) return launch_rf<8>(L, n_windows, threads, lds, s);
+    if (L.A <= 16) return launch_rf<16>(L, n_windows, threads, lds, s);
+    return launch_rf<32>(L, n_windows, threads, lds, s);
+  }
   switch (L.D) {
     case 1: return launch_d<1>(L, n_windows, threads, lds, s);
     case 2: return launch_d<2>(L, n_windows, threads, lds, s);

@@ -28,7 +28,7 @@ class GnxModelData:
     A: int
     S: int = 75
     context: int = 0                      # SNPs each side = int(M*context_ratio) (src/model.py:47)
-    base_kind: str | None = None          # "logistic" | "covrsk" | "forest"
+    base_kind: str | None = None          # "logistic" | "covrsk" | "forest" | "rforest"
     smooth_kind: str | None = None        # "xgb" | "crf"
     # logistic base: coef_ / intercept_ of LogisticRegression per window (src/Base/models.py:12-21)
     lr_coef: np.ndarray | None = None     # (W, A, ldc) float64, window i uses [:, :width_i]
@@ -46,6 +46,14 @@ class GnxModelData:
     fb_tree_class: np.ndarray | None = None
     fb_base_score: float = 0.5
     fb_missing: int = 2                      # missing_encoding (src/Base/base.py:25)
+    # rforest base: per-window sklearn RandomForestClassifier (src/Base/models.py:54-66), tree_ arrays concatenated
+    rf_win_tree0: np.ndarray | None = None   # (W+1,)
+    rf_tree_off: np.ndarray | None = None
+    rf_left: np.ndarray | None = None
+    rf_right: np.ndarray | None = None
+    rf_feat: np.ndarray | None = None
+    rf_thr: np.ndarray | None = None         # float64
+    rf_value: np.ndarray | None = None       # (n_nodes, A) float64: predict_proba row of each node
     # xgb smoother in xgboost's model schema (src/Smooth/models.py:14-20)
     tree_off: np.ndarray | None = None
     left: np.ndarray | None = None
@@ -150,7 +158,7 @@ class GnxModelData:
         d.abi_version = _lib.GNX_ABI_VERSION
         d.A, d.C, d.M, d.ctx, d.S = int(self.A), int(self.C), int(self.M), int(self.context), int(self.S)
         d.base_kind = {None: _lib.BASE_NONE, "logistic": _lib.BASE_LOGISTIC, "covrsk": _lib.BASE_COVRSK_SVC,
-                       "forest": _lib.BASE_FOREST}[self.base_kind]
+                       "forest": _lib.BASE_FOREST, "rforest": _lib.BASE_RFOREST}[self.base_kind]
         d.smooth_kind = {None: _lib.SMOOTH_NONE, "xgb": _lib.SMOOTH_XGB, "crf": _lib.SMOOTH_CRF}[self.smooth_kind]
         W, A = self.W, self.A
         if self.base_kind == "logistic":
@@ -197,6 +205,21 @@ class GnxModelData:
             tc = self.fb_tree_class if self.fb_tree_class is not None else np.zeros(d.fb_n_trees, np.int32)
             d.fb_tree_class = ptr(tc, np.int32)
             d.fb_base_score = float(self.fb_base_score)
+        elif self.base_kind == "rforest":
+            wt0 = _c(self.rf_win_tree0, np.int32)
+            if wt0.shape != (W + 1,):
+                raise ValueError("rf_win_tree0 must be (W+1,)")
+            val = _c(self.rf_value, np.float64)
+            if val.ndim != 2 or val.shape[1] != A or val.shape[0] != len(self.rf_left):
+                raise ValueError("rf_value must be (n_nodes, A)")
+            d.rf_n_trees = len(self.rf_tree_off) - 1
+            d.rf_win_tree0 = ptr(wt0, np.int32)
+            d.rf_tree_off = ptr(self.rf_tree_off, np.int32)
+            d.rf_left = ptr(self.rf_left, np.int32)
+            d.rf_right = ptr(self.rf_right, np.int32)
+            d.rf_feat = ptr(self.rf_feat, np.int32)
+            d.rf_thr = ptr(self.rf_thr, np.float64)
+            d.rf_value = ptr(val, np.float64)
         if self.smooth_kind == "xgb":
             d.n_trees = self.n_trees
             d.tree_off = ptr(self.tree_off, np.int32)

@@ -175,6 +175,44 @@ def synthetic_forest_model(C, M, A, context=None, n_rounds=20, depth=4, seed=0, 
     return m
 
 
+def synthetic_rforest_model(C, M, A, context=None, n_trees=20, depth=4, seed=0, S=75, smooth=None, p_early_leaf=0.1):
+    """Random forest base of the reference architecture (RFBase, src/Base/models.py:54-66: per window
+    RandomForestClassifier(n_estimators=20, max_depth=4)) in sklearn's tree_ arrays: thresholds 0.5 / 1.5, leaf rows =
+    random class distributions (what predict_proba returns at a leaf)."""
+    rng = np.random.RandomState(seed)
+    context = int(M * 0.5) if context is None else int(context)
+    m = synthetic_model(C, M, A, S=S, context=context, seed=seed, base=None, smooth=smooth)
+    m.base_kind = "rforest"
+    off, L, R, F, T, V, wt0 = [0], [], [], [], [], [], [0]
+    for i in range(m.W):
+        width = m.window_width(i)
+        for t in range(n_trees):
+            nodes = []
+
+            def grow(d):
+                idx = len(nodes)
+                nodes.append(None)
+                if d == depth or (d > 0 and rng.rand() < p_early_leaf):
+                    nodes[idx] = (-1, -1, 0, -2.0, rng.dirichlet(np.ones(A) * 0.5))
+                else:
+                    f = rng.randint(width)
+                    thr = 0.5 if rng.rand() < 0.85 else 1.5
+                    l = grow(d + 1)
+                    r = grow(d + 1)
+                    nodes[idx] = (l, r, f, thr, rng.dirichlet(np.ones(A)))
+                return idx
+
+            grow(0)
+            for (l, r, f, thr, v) in nodes:
+                L.append(l); R.append(r); F.append(f); T.append(thr); V.append(v)
+            off.append(len(L))
+        wt0.append(len(off) - 1)
+    m.rf_win_tree0, m.rf_tree_off = np.array(wt0, np.int32), np.array(off, np.int32)
+    m.rf_left, m.rf_right, m.rf_feat = np.array(L, np.int32), np.array(R, np.int32), np.array(F, np.int32)
+    m.rf_thr, m.rf_value = np.array(T, np.float64), np.array(V, np.float64)
+    return m
+
+
 def synthetic_smoothing_trees(n_rounds, A, S, depth=4, seed=0, reach=8, noise_leaf=0.01):
     """An ensemble that behaves like a TRAINED smoother (labels piecewise constant along the chromosome) while keeping
     the cost profile of the reference's 100-round model: the first 2*reach+1 rounds are signal trees (class c votes by

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 2
+#define GNX_ABI_VERSION 3
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -54,7 +54,7 @@ enum {
   GNX_ESTATE = -5        /* call not valid for this model (e.g. phasing with a CRF smoother) */
 };
 
-enum { GNX_BASE_NONE = 0, GNX_BASE_LOGISTIC = 1, GNX_BASE_COVRSK_SVC = 2, GNX_BASE_FOREST = 3 };
+enum { GNX_BASE_NONE = 0, GNX_BASE_LOGISTIC = 1, GNX_BASE_COVRSK_SVC = 2, GNX_BASE_FOREST = 3, GNX_BASE_RFOREST = 4 };
 enum { GNX_SMOOTH_NONE = 0, GNX_SMOOTH_XGB = 1, GNX_SMOOTH_CRF = 2 };
 
 /* kernel ids for gnx_profile_get */
@@ -151,6 +151,20 @@ typedef struct gnx_model_desc {
   const int32_t* fb_tree_class;     /* (fb_n_trees,) */
   float fb_base_score;              /* 0.5 */
   int32_t reserved4;
+
+  /* GNX_BASE_RFOREST: one random forest per window (RFBase, src/Base/models.py:54-66:
+   * RandomForestClassifier(n_estimators=20, max_depth=4)); sklearn's tree arrays (tree_.children_left/right, feature,
+   * threshold) of all trees of all windows concatenated.  Left iff float32(x) <= threshold; a leaf contributes its
+   * class-probability row rf_value[node]; the window's output is the mean over its trees (float64). */
+  int32_t rf_n_trees;
+  int32_t reserved5;
+  const int32_t* rf_win_tree0;      /* (W+1,) */
+  const int32_t* rf_tree_off;       /* (rf_n_trees+1,) node offsets */
+  const int32_t* rf_left;           /* -1 at leaves */
+  const int32_t* rf_right;
+  const int32_t* rf_feat;           /* SNP index within the window's padded slice */
+  const double* rf_thr;
+  const double* rf_value;           /* (n_nodes, A) what DecisionTreeClassifier.predict_proba returns at that node */
 } gnx_model_desc;
 
 typedef struct gnx_model_info {

@@ -460,3 +460,44 @@ int gnxo_base_forest(const gnxo_trees* T, const int32_t* win_tree0, const int8_t
   free(xw);
   return GNXO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * RFBase (src/Base/models.py:54-66): per window sklearn RandomForestClassifier(n_estimators=20, max_depth=4)
+ * .predict_proba(Xw).  scikit-learn IS installed here, so this restatement is pinned against the reference's own
+ * RFBase objects (tests/golden/G9_rf.npz).  sklearn semantics restated:
+ *   - sklearn/tree/_tree.pyx  Tree._apply_dense: X is cast to float32; at an internal node go LEFT iff
+ *     X[i, feature] <= threshold (threshold is float64); leaves have children_left == -1;
+ *   - DecisionTreeClassifier.predict_proba: the leaf's class-weight row, divided by its sum (the converter stores the rows
+ *     already normalised with the same numpy expression, `value` below);
+ *   - ForestClassifier.predict_proba (sklearn/ensemble/_forest.py): all_proba += tree proba for every tree (float64; the
+ *     reference runs the trees of a window single-threaded, models.py:62-63, so in estimator order), then
+ *     all_proba /= n_estimators.
+ * Code 2 ("missing") is an ordinary number here.  B is (N, W, A) float64.
+ * ---------------------------------------------------------------------------------------- */
+int gnxo_base_rforest(const int32_t* win_tree0, const int32_t* tree_off, const int32_t* left, const int32_t* right,
+                      const int32_t* feat, const double* thr, const double* value, const int8_t* X, int64_t N, int64_t ldx,
+                      int64_t C, int64_t M, int64_t ctx, int64_t A, double* B) {
+  const int64_t W = C / M, rem = C - M * W, M_ = M + 2 * ctx;
+  if (rem == 0 || A < 2 || A > 64) return GNXO_EINVAL;
+  int8_t* xw = (int8_t*)malloc((size_t)(M_ + rem));
+  if (!xw) return GNXO_ENOMEM;
+  for (int64_t n = 0; n < N; ++n)
+    for (int64_t i = 0; i < W; ++i) {
+      const int64_t len = (i == W - 1) ? M_ + rem : M_;
+      for (int64_t k = 0; k < len; ++k) xw[k] = X[n * ldx + pad_src(i * M + k, C, ctx)];
+      double* o = B + (n * W + i) * A;
+      for (int64_t a = 0; a < A; ++a) o[a] = 0.0;
+      const int32_t t0 = win_tree0[i], t1 = win_tree0[i + 1];
+      for (int32_t t = t0; t < t1; ++t) {
+        const int32_t off = tree_off[t];
+        int32_t nid = 0;
+        while (left[off + nid] != -1) nid = ((double)(float)xw[feat[off + nid]] <= thr[off + nid]) ? left[off + nid] : right[off + nid];
+        const double* v = value + (size_t)(off + nid) * A;
+        for (int64_t a = 0; a < A; ++a) o[a] += v[a];
+      }
+      const double nt = (double)(t1 - t0);
+      for (int64_t a = 0; a < A; ++a) o[a] /= nt;
+    }
+  free(xw);
+  return GNXO_OK;
+}

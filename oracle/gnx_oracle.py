@@ -164,6 +164,21 @@ def base_forest(trees: Trees, win_tree0, X, M, ctx, A, missing=2):
     return B
 
 
+def base_rforest(rf, X, M, ctx, A):
+    """RFBase.predict_proba (Base/models.py:54-66): rf = dict(win_tree0, tree_off, left, right, feat, thr, value) with
+    sklearn's tree arrays concatenated over trees and windows, value = normalised leaf rows (n_nodes, A) -> B (N,W,A) f64"""
+    X = np.ascontiguousarray(X, dtype=np.int8)
+    N, Cn = X.shape
+    W = Cn // M
+    i32 = lambda k: np.ascontiguousarray(rf[k], dtype=np.int32)
+    f64 = lambda k: np.ascontiguousarray(rf[k], dtype=np.float64)
+    a = [i32("win_tree0"), i32("tree_off"), i32("left"), i32("right"), i32("feat"), f64("thr"), f64("value")]
+    B = np.empty((N, W, A), dtype=np.float64)
+    _chk(lib().gnxo_base_rforest(*[_p(x) for x in a], _p(X), C.c_int64(N), C.c_int64(Cn), C.c_int64(Cn), C.c_int64(M),
+                                 C.c_int64(ctx), C.c_int64(A), _p(B)), "base_rforest")
+    return B
+
+
 def random_trees(n_rounds, n_class, n_feat, depth=4, seed=0, thr_lo=0.0, thr_hi=1.0, leaf_scale=0.3,
                  p_early_leaf=0.15):
     """Synthetic xgboost-schema ensemble (round-major, tree t has class t % n_class — the layout

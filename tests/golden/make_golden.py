@@ -403,11 +403,36 @@ def make_G8(out):
     print("G8", out_p.shape, out_p.dtype, Bq.shape)
 
 
+def make_G9(out):
+    """RFBase (src/Base/models.py:54-66) trained and run by the reference's own Base machinery: scikit-learn is
+    installed, so the tree-ensemble base family has a real pin.  base_multithread is switched off exactly as in G1
+    (serial dispatch, same arithmetic); the forests themselves run single-threaded (models.py:62-63)."""
+    from src.Base.models import RFBase
+    sys.path.insert(0, ROOT)
+    from gnomix_amd.convert import rforest_from_sklearn
+    rng = np.random.RandomState(94309)
+    C, M, A = 2537, 100, 5
+    W, ctx = C // M, 50
+    Xt, yt = synth_admixed(rng, 300, C, A, W, M)
+    for w in range(W):
+        for a in range(A):
+            yt[a, w] = a
+    base = RFBase(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx, n_jobs=1, seed=94309, verbose=False)
+    base.base_multithread = False
+    np.random.seed(94309)  # RandomForestClassifier(random_state=None) draws from numpy's global state
+    base.train(Xt, yt)
+    Xq, _ = synth_admixed(rng, 40, C, A, W, M, miss=0.05, switch_p=0.1)
+    B = base.predict_proba(Xq)
+    rf = rforest_from_sklearn(base.models, A)
+    np.savez_compressed(out, C=C, M=M, A=A, ctx=ctx, X=Xq, B=B, **rf)
+    print("G9", B.shape, B.dtype, "trees", len(rf["rf_tree_off"]) - 1, "nodes", len(rf["rf_left"]))
+
+
 def main():
     if not import_reference():
         print("reference not found at", REF, "- nothing generated")
         return 0
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9"]
     if "G1" in which: make_G1(os.path.join(HERE, "G1_lr.npz"))
     if "G2" in which: make_G2(os.path.join(HERE, "G2_covrsk.npz"))
     if "G3" in which: make_G3(os.path.join(HERE, "G3_slide.npz"))
@@ -416,6 +441,7 @@ def main():
     if "G6" in which: make_G6(os.path.join(HERE, "G6_writers"))
     if "G7" in which: make_G7(os.path.join(HERE, "G7_vcf.npz"))
     if "G8" in which: make_G8(os.path.join(HERE, "G8_calib_sk.npz"))
+    if "G9" in which: make_G9(os.path.join(HERE, "G9_rf.npz"))
     return 0
 
 

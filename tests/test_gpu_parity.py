@@ -634,3 +634,37 @@ def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S
     p_ref, l_ref = oracle.smooth_xgb(T, B[finite], S)
     assert np.array_equal(lf[finite], l_ref)
     _close_f32(pf[finite], p_ref)
+
+
+# ---------------------------------------------------------------- random-forest base (RFBase) -----
+def _rf_dict(d):
+    return {k[3:]: getattr(d, k) for k in ("rf_win_tree0", "rf_tree_off", "rf_left", "rf_right", "rf_feat", "rf_thr", "rf_value")}
+
+
+def test_rforest_base_golden_G9(ga, oracle):
+    """k_base_rforest against the REFERENCE's RFBase.predict_proba output (sklearn forests): bit-exact float64"""
+    g = load_golden("G9_rf.npz")
+    d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=int(g["A"]), S=5, context=int(g["ctx"]), base_kind="rforest",
+                        **{k: g[k] for k in g.files if k.startswith("rf_")})
+    dev = ga.DeviceModel(d)
+    b32, b64 = dev.base_predict(g["X"], want_f32=True, want_f64=True)
+    assert np.array_equal(b64, g["B"])
+    assert np.array_equal(b32, g["B"].astype(np.float32))
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(g["B"], -1))
+
+
+@pytest.mark.parametrize("C,M,A,ctx,N,trees,depth", [
+    (4037, 100, 7, 50, 70, 20, 4),      # the reference's RFBase shape
+    (2531, 100, 3, 30, 300, 5, 2),      # more haplotypes than one tile
+    (1999, 64, 12, 0, 65, 7, 6),        # A > 8: 16-class accumulator variant, deep trees, no context
+    (937, 300, 20, 150, 1, 3, 1),       # stumps, A > 16, a single haplotype
+    (1237, 48, 2, 24, 129, 9, 3),
+])
+def test_rforest_base_vs_oracle(ga, oracle, C, M, A, ctx, N, trees, depth):
+    from gnomix_amd import synth
+    d = synth.synthetic_rforest_model(C, M, A, context=ctx, n_trees=trees, depth=depth, seed=C + A, p_early_leaf=0.2)
+    X = synth.synthetic_X(N, C, seed=N + 2, miss=0.08)
+    b32, b64 = ga.DeviceModel(d).base_predict(X, want_f32=True, want_f64=True)
+    ref = oracle.base_rforest(_rf_dict(d), X, M, ctx, A)
+    assert np.array_equal(b64, ref)
+    assert np.array_equal(b32, ref.astype(np.float32))

@@ -194,3 +194,26 @@ def test_forest_from_xgb_json(oracle):
     X[0, 0] = 2                                          # padded 2 2 2 1 ...: window 0 SNP1 missing -> "no" child (-0.2)
     B = oracle.base_forest(T, f["fb_win_tree0"], X, 2, 1, 2)
     assert np.allclose(B[0, 0, 1], 1 / (1 + np.exp(0.2)), atol=1e-6)
+
+
+def test_rforest_converter_against_sklearn(oracle):
+    """rforest_from_sklearn + the oracle's RF walk == RandomForestClassifier.predict_proba on every window (bit-exact)"""
+    from sklearn.ensemble import RandomForestClassifier
+    from gnomix_amd import convert
+    rng = np.random.RandomState(3)
+    C, M, ctx, A, N = 457, 50, 25, 4, 60
+    W, rem, M_ = C // M, C % M, M + 2 * ctx
+    X = (rng.random_sample((200, C)) < 0.4).astype(np.int8)
+    X[rng.random_sample(X.shape) < 0.05] = 2
+    y = rng.randint(0, A, size=(200, W))
+    y[:A] = np.arange(A)[:, None]
+    Xp = np.concatenate([X[:, :ctx][:, ::-1], X, X[:, -ctx:][:, ::-1]], axis=1)   # Base.pad (base.py:41-44)
+    models, ref = [], []
+    for i in range(W):
+        sl = slice(i * M, i * M + M_) if i < W - 1 else slice(Xp.shape[1] - (M_ + rem), Xp.shape[1])
+        m = RandomForestClassifier(n_estimators=7, max_depth=4, n_jobs=1, random_state=i).fit(Xp[:, sl], y[:, i])
+        models.append(m)
+        ref.append(m.predict_proba(Xp[:N, sl]))
+    rf = convert.rforest_from_sklearn(models, A)
+    B = oracle.base_rforest({k[3:]: v for k, v in rf.items()}, X[:N], M, ctx, A)
+    assert np.array_equal(B, np.swapaxes(np.array(ref), 0, 1))

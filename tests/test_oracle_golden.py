@@ -151,3 +151,13 @@ def test_forest_base_hand_computed(oracle):
     for w, mm in enumerate((m0, m1)):
         e = np.exp(mm - mm.max())
         assert np.allclose(B[0, w], e / e.sum(), atol=1e-6)
+
+
+def test_rforest_base_golden_G9(oracle):
+    """RFBase restatement against the REFERENCE's own RFBase.predict_proba (sklearn forests trained by Base.train)"""
+    g = load_golden("G9_rf.npz")
+    rf = {k[3:]: g[k] for k in g.files if k.startswith("rf_")}
+    B = oracle.base_rforest(rf, g["X"], int(g["M"]), int(g["ctx"]), int(g["A"]))
+    assert B.shape == g["B"].shape
+    assert np.array_equal(B, g["B"])           # bit-exact: same float64 adds in estimator order, same division
+    assert np.allclose(B.sum(-1), 1.0, atol=1e-12)
