@@ -237,6 +237,8 @@ static int build_lr(gnx_model* m, const gnx_model_desc* d) {
   if ((rc = dev_upload(m, chunk_nflush, &m->lr.chunk_nflush)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, win_chunk0, &m->lr.win_chunk0)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, win_chunk1, &m->lr.win_chunk1)) != GNX_OK) return rc;
+  m->lr_h_win_chunk0 = win_chunk0;
+  m->lr_h_win_chunk1 = win_chunk1;
   m->lr.n_chunks = (int32_t)n_chunks;
   {
     int32_t mx = 1;
@@ -929,6 +931,7 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
   L.X = dX;
   L.last_row = (const int8_t*)ctx->ws_lastrow.p;
   L.N = N; L.ldx = ldx; L.d = m->lr;
+  L.h_win_chunk0 = m->lr_h_win_chunk0.data(); L.h_win_chunk1 = m->lr_h_win_chunk1.data();
   L.W = (int32_t)m->info.W; L.A = m->info.A;
   L.b32 = d_b32; L.b64 = d_b64;
   ProfScope ps(ctx, GNX_K_BASE_LOGISTIC);

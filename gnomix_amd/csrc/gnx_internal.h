@@ -61,6 +61,8 @@ struct BaseLRLaunch {
   const int8_t* last_row;  // zero-padded (64 B) device copy of haplotype N-1: the only row whose tail reads could leave X
   int64_t N, ldx;
   BaseLRDev d;
+  const int32_t* h_win_chunk0;  // HOST copies of d.win_chunk0/1 (launcher only: exact size of the per-block LDS tables)
+  const int32_t* h_win_chunk1;
   int32_t W, A, wch;    // wch = windows per block
   int32_t n_htiles;     // i8 path: haplotype tiles (1-D XCD-aware grid)
   int32_t flags;        // development ablation switches (0 in production)
@@ -247,6 +249,7 @@ struct gnx_model {
   gnx_model_info info{};
   std::vector<void*> dev_allocs;
   BaseLRDev lr;
+  std::vector<int32_t> lr_h_win_chunk0, lr_h_win_chunk1;
   bool lr_i8 = true;
   SmoothXGBDev xgb;
   CovRSKDev svc;

@@ -272,25 +272,44 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, hipStream_t s) {
   BaseLRLaunch P = L;
   const int haps_per_block = WAVES * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
-  // window ranges: a multiple of 8 (one XCD each), ~3 blocks per CU in total
+  // window ranges: a multiple of 8 (one XCD each), ~3 blocks per CU in total; more (shorter) ranges if the per-block
+  // chunk / window tables would not fit the LDS next to the tiles (long chromosomes with few haplotype tiles)
   int bpc = 3;
   if (const char* t = std::getenv("GNX_LR_BPC")) bpc = std::max(1, std::atoi(t));
   int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
   want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
-  int wch = (int)((L.W + want - 1) / want);
-  if (wch < 4) wch = 4;
-  const int n_ranges = (L.W + wch - 1) / wch;
+  int wch = 0, n_ranges = 0;
+  size_t lds = 0;
+  for (;; want += 8) {
+    wch = (int)((L.W + want - 1) / want);
+    if (wch < 4) wch = 4;
+    n_ranges = (L.W + wch - 1) / wch;
+    int max_chunks = 0;
+    if (L.h_win_chunk0 && L.h_win_chunk1) {  // exact: the longest chunk span any range walks
+      for (int r = 0; r < n_ranges; ++r) {
+        const int wa = r * wch, wb = std::min(L.W, wa + wch);
+        max_chunks = std::max(max_chunks, L.h_win_chunk1[(size_t)wb - 1] - L.h_win_chunk0[(size_t)wa]);
+      }
+      max_chunks += 8;
+    } else {
+      max_chunks = (wch + L.d.R + 2) * L.d.max_piece_chunks + 8;
+    }
+    P.max_chunks = max_chunks;
+    P.max_wins = wch + 2 * L.d.R + 4;
+    lds = (size_t)WAVES * MT * 16 * 128 + (size_t)2 * CPS * NT * LIMBS * 1024 + (size_t)WAVES * MT * 16 * L.A * sizeof(double) +
+          (size_t)3 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
+    if (lds <= (size_t)160 * 1024 || wch == 4) break;
+  }
+  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
   P.wch = wch;
   P.n_htiles = (int)gx;
-  P.max_chunks = (wch + L.d.R + 2) * L.d.max_piece_chunks + 8;
-  P.max_wins = wch + 2 * L.d.R + 4;
-  const size_t lds = (size_t)WAVES * MT * 16 * 128 + (size_t)2 * CPS * NT * LIMBS * 1024 + (size_t)WAVES * MT * 16 * L.A * sizeof(double) +
-                     (size_t)3 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_logistic_i8<MT, NT, WAVES, CPS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((k_base_logistic_i8<MT, NT, WAVES, CPS>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
-  return hipGetLastError();
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess && std::getenv("GNX_DEBUG")) std::fprintf(stderr, "k_base_logistic_i8<%d,%d,%d>: lds=%zu grid=%lld wch=%d max_chunks=%d max_wins=%d\n", MT, NT, WAVES, lds, (long long)(gx * n_ranges8), wch, P.max_chunks, P.max_wins);
+  return e;
 }
 
 }  // namespace

@@ -153,10 +153,25 @@ def cf(N=10000):
     return res
 
 
+def crf_(N=10000):
+    """chr22 geometry with the random-forest base (RFBase shape: 20 trees of depth 4 per window) + xgb smoother"""
+    C, M, A = 370_500, 1000, 7
+    data = synth.synthetic_rforest_model(C, M, A, n_trees=20, depth=4, seed=0, S=75, smooth="xgb")
+    model = gnomix_amd.DeviceModel(data)
+    X = synth.synthetic_X_device(N, C, "cuda:0", seed=1)
+    model.ctx.profile_reset(); model.ctx.profile_enable(True)
+    dt = timed(lambda: model.infer_device(X), reps=3, warm=1)
+    model.ctx.profile_enable(False)
+    res = {"config": "rf chr22, random-forest base (20 trees, depth 4) + xgb", "haplotypes": N, "W": data.W, "seconds": dt,
+           "haplotypes_per_s": N / dt, "kernels_ms": prof(model.ctx)}
+    print(json.dumps(res))
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c4", "c5a", "c5b", "c3"]
     out = {}
     for w in which:
-        out[w] = globals()[w]()
+        out[w] = globals()["crf_" if w == "rf" else w]()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)

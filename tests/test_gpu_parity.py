@@ -668,3 +668,18 @@ def test_rforest_base_vs_oracle(ga, oracle, C, M, A, ctx, N, trees, depth):
     ref = oracle.base_rforest(_rf_dict(d), X, M, ctx, A)
     assert np.array_equal(b64, ref)
     assert np.array_equal(b32, ref.astype(np.float32))
+
+
+def test_base_long_chromosome_many_windows(ga, oracle):
+    """chr1-sized window count with 12 ancestries and only a few haplotype tiles: the per-block chunk / window tables of
+    the logistic kernel must be sized from the real chunk spans (the first sizing rule asked for 187 KB of LDS here)"""
+    from gnomix_amd import synth
+    C, M, A, ctx, N = 1431 * 400 + 211, 400, 12, 200, 600
+    d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=ctx, seed=5, smooth=None)
+    X = synth.synthetic_X(N, C, seed=9, miss=0.02)
+    dev = ga.DeviceModel(d)
+    _, big = dev.base_predict(X, want_f32=False, want_f64=True)          # 256-haplotype tiles
+    _, small = dev.base_predict(X[:48], want_f32=False, want_f64=True)   # 64-haplotype tiles, other launch geometry
+    assert np.array_equal(big[:48], small)                                # exact integer logits: tiling-independent
+    ref = oracle.base_lr(X[:6], M, ctx, d.lr_coef, d.lr_intercept)
+    assert np.max(np.abs(big[:6] - ref)) < 1e-12
