@@ -2,16 +2,15 @@
 
     python -m gnomix_amd <query_file> <output_basename> <chr_nr> <phase> <path_to_model>
 
-`path_to_model` is a flat `.gnx` model (gnomix_amd.GnxModelData.save) or a reference `model.pkl[.gz]`
-(unpickling one needs what the pickle needs — sklearn, xgboost and the reference's `src` package on sys.path —
-and goes through gnomix_amd.convert.from_reference_model).  Training mode (7-8 arguments) is out of scope.
+`path_to_model` is a flat `.gnx` model (gnomix_amd.GnxModelData.save) or a reference `model.pkl[.gz]`, which is read
+with a restricted unpickler (gnomix_amd.refpickle: neither the reference's `src` package nor xgboost is needed; CRF
+models still need sklearn_crfsuite's attributes in the pickle) and converted by gnomix_amd.convert.from_reference_model.
+Training mode (7-8 arguments) is out of scope.
 Outputs: <output_basename>/query_results.msp, .fb (+ .lai, query_results_bed/, query_file_phased.vcf as configured).
 """
 from __future__ import annotations
 
-import gzip
 import os
-import pickle
 import sys
 
 import numpy as np
@@ -30,10 +29,9 @@ def load_model(path_to_model, device=0, verbose=True):
     if path_to_model.endswith(".gnx"):
         return HipGnomix(GnxModelData.load(path_to_model), device=device)
     from .convert import from_reference_model
-    opener = gzip.open if path_to_model.endswith(".gz") else open
-    with opener(path_to_model, "rb") as f:
-        ref_model = pickle.load(f)
-    return HipGnomix(from_reference_model(ref_model), device=device)
+    from .refpickle import load_reference_pickle
+    # restricted unpickling: the reference's `src` package and xgboost are NOT needed (and nothing of them is executed)
+    return HipGnomix(from_reference_model(load_reference_pickle(path_to_model)), device=device)
 
 
 def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False):

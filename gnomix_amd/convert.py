@@ -82,12 +82,33 @@ def trees_from_xgb_json(dumps, n_class, base_score=0.5):
                 base_score=float(base_score), default_left=np.array(Dl, np.uint8))
 
 
+def xgb_trees_of(xgb_obj, n_class):
+    """xgboost-schema arrays of a fitted XGBClassifier: through the real booster's JSON dump when xgboost is importable and
+    the object is real, else from the raw booster bytes a stubbed pickle carries (gnomix_amd.refpickle.parse_xgb_raw)."""
+    from .refpickle import booster_bytes, parse_xgb_raw
+    raw = booster_bytes(xgb_obj)
+    if raw is not None:
+        t = parse_xgb_raw(raw)
+        per_round = 1 if n_class == 2 and t["n_class"] <= 1 else n_class
+        if len(t["tree_class"]) != len(t["tree_off"]) - 1 or (len(t["tree_class"]) and t["tree_class"].max() >= max(per_round, 1)):
+            raise ValueError("xgboost model: tree_info does not match the number of classes")
+        return {k: t[k] for k in ("tree_off", "left", "right", "feat", "cond", "tree_class", "base_score", "default_left")}
+    booster = xgb_obj.get_booster()
+    return trees_from_xgb_json(booster.get_dump(dump_format="json"), 1 if n_class == 2 else n_class)
+
+
 def forest_from_xgb_json(window_dumps, n_class, base_score=0.5, missing=2):
     """Per-window xgboost JSON dumps (XGBBase: one XGBClassifier per window, src/Base/models.py:24-35) -> the fb_*
     arrays of GnxModelData.  multi:softprob lays trees out round-major (tree t -> class t % A); binary:logistic
     (A == 2) has one tree per round."""
     per_round = 1 if n_class == 2 else n_class
     parts = [trees_from_xgb_json(dumps, per_round, base_score) for dumps in window_dumps]
+    return forest_from_parts(parts, missing=missing)
+
+
+def forest_from_parts(parts, missing=2):
+    """per-window xgboost-schema dicts (trees_from_xgb_json / refpickle.parse_xgb_raw) -> the fb_* arrays"""
+    base_score = parts[0]["base_score"] if parts else 0.5
     wt0 = np.concatenate([[0], np.cumsum([len(p["tree_off"]) - 1 for p in parts])]).astype(np.int32)
     node0 = np.concatenate([[0], np.cumsum([p["tree_off"][-1] for p in parts])])
     return dict(fb_win_tree0=wt0,
@@ -161,8 +182,8 @@ def from_reference_model(model) -> GnxModelData:
         d.svc = [svc_window_from_sklearn(m, d.window_width(i), kname) for i, m in enumerate(models)]
     elif first == "XGBClassifier":  # XGBBase (src/Base/models.py:24-35)
         d.base_kind = "forest"
-        dumps = [m.get_booster().get_dump(dump_format="json") for m in models]
-        for k, v in forest_from_xgb_json(dumps, A, missing=int(getattr(model.base, "missing_encoding", 2))).items():
+        parts = [xgb_trees_of(m, A) for m in models]
+        for k, v in forest_from_parts(parts, missing=int(getattr(model.base, "missing_encoding", 2))).items():
             setattr(d, k, v)
     elif first == "RandomForestClassifier":  # RFBase (src/Base/models.py:54-66)
         d.base_kind = "rforest"
@@ -172,8 +193,9 @@ def from_reference_model(model) -> GnxModelData:
         raise NotImplementedError(f"base model {first}")
     sm = type(model.smooth).__name__
     if sm == "XGB_Smoother":
-        booster = model.smooth.model.get_booster()
-        t = trees_from_xgb_json(booster.get_dump(dump_format="json"), A)
+        t = xgb_trees_of(model.smooth.model, A)
+        if A == 2 and len(t["tree_class"]) and t["tree_class"].max() == 0:
+            raise NotImplementedError("binary:logistic smoother (A == 2 trained by xgboost's sklearn wrapper)")
         d.smooth_kind = "xgb"
         for k, v in t.items():
             if k != "default_left":  # smoother features are probabilities, never missing

@@ -82,3 +82,42 @@ def test_export_calibrator_and_string_kernel_lengths(ref):
     assert list(convert.string_kernel_lengths(5, "string_kernel_DP_triangular_numbers_multithread")) == [1, 2, 3, 4, 5]
     with pytest.raises(NotImplementedError):
         convert.string_kernel_lengths(5, "poly_kernel")
+
+
+def test_restricted_unpickle_of_real_reference_objects(ref, oracle, tmp_path):
+    """pickle REAL reference objects (src.Base.models.LogisticRegressionBase / RFBase trained by Base.train), read the
+    pickle back with gnomix_amd.refpickle (which never imports `src`), convert, and reproduce the reference's output"""
+    import pickle
+    import warnings
+    from src.Base.models import LogisticRegressionBase, RFBase
+    from gnomix_amd import convert, refpickle
+    rng = np.random.RandomState(2)
+    C, M, A = 937, 50, 3
+    W, ctx = C // M, 25
+    Xt, yt = ref.synth_admixed(rng, 150, C, A, W, M)
+    for w in range(W):
+        yt[:A, w] = np.arange(A)
+    Xq, _ = ref.synth_admixed(rng, 7, C, A, W, M, miss=0.05)
+    for cls in (LogisticRegressionBase, RFBase):
+        base = cls(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx, n_jobs=1, seed=1, verbose=False)
+        base.base_multithread = False
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            base.train(Xt, yt)
+        B_ref = base.predict_proba(Xq)
+        sm, st, tr = _fake_crf_smoother(A, 75, rng)
+        model = types.SimpleNamespace(C=C, M=M, A=A, context=ctx, base=base, smooth=sm, snp_pos=np.arange(C), snp_ref=None,
+                                      snp_alt=None, population_order=["a", "b", "c"], gen_map_df=None)
+        p = tmp_path / (cls.__name__ + ".pkl")
+        with open(p, "wb") as f:
+            pickle.dump({"base": base}, f)
+        got = refpickle.load_reference_pickle(str(p))["base"]
+        assert isinstance(got, refpickle.Stub) and type(got).__name__ == cls.__name__ and type(got).__module__ == "src.Base.models"
+        model.base = got
+        d = convert.from_reference_model(model)
+        if cls is LogisticRegressionBase:
+            B = oracle.base_lr(Xq, M, ctx, d.lr_coef, d.lr_intercept)
+            assert np.max(np.abs(B - B_ref)) < 1e-13
+        else:
+            rf = {k[3:]: getattr(d, k) for k in ("rf_win_tree0", "rf_tree_off", "rf_left", "rf_right", "rf_feat", "rf_thr", "rf_value")}
+            assert np.array_equal(oracle.base_rforest(rf, Xq, M, ctx, A), B_ref)
