@@ -217,3 +217,9 @@ def test_rforest_converter_against_sklearn(oracle):
     rf = convert.rforest_from_sklearn(models, A)
     B = oracle.base_rforest({k[3:]: v for k, v in rf.items()}, X[:N], M, ctx, A)
     assert np.array_equal(B, np.swapaxes(np.array(ref), 0, 1))
+
+
+def test_graft_entry_build_passes():
+    """the driver's "does it build" hook: compiles (no-op when up to date), loads the library, checks the ABI version"""
+    import __graft_entry__ as g
+    g.build()
