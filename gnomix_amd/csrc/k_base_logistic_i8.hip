@@ -278,6 +278,7 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, hipStream_t s) {
   if (const char* t = std::getenv("GNX_LR_BPC")) bpc = std::max(1, std::atoi(t));
   int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
   want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
+  if (const char* t = std::getenv("GNX_LR_WANT")) want = std::max(1, std::atoi(t));
   int wch = 0, n_ranges = 0;
   size_t lds = 0;
   for (;; want += 8) {
