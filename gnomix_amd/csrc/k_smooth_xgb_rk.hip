@@ -311,10 +311,8 @@ hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
 
 }  // namespace
 
-hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L0, hipStream_t s) {
-  if (L0.N <= 0) return hipSuccess;
-  SmoothXGBLaunch L = L0;
-  if (const char* t = std::getenv("GNX_RK_STEPS")) L.d.rk_steps = std::atoi(t);  // experiments only
+hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, hipStream_t s) {
+  if (L.N <= 0) return hipSuccess;
   const int rpl = L.d.rk_rpl;  // fixed at model load: the node offsets encode the strip stride
   int nw = 0;
   if (const char* t = std::getenv("GNX_SM_NW")) nw = std::atoi(t);
