@@ -223,3 +223,27 @@ def test_graft_entry_build_passes():
     """the driver's "does it build" hook: compiles (no-op when up to date), loads the library, checks the ABI version"""
     import __graft_entry__ as g
     g.build()
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """compile a C probe against include/gnomix_hip.h and compare sizeof / offsetof of every struct field with the
+    ctypes mirrors in gnomix_amd/_lib.py (a drifting field would corrupt every model load silently)"""
+    import ctypes as C
+    import subprocess
+    from gnomix_amd import _lib
+    structs = {"gnx_model_desc": _lib.ModelDesc, "gnx_svc_window": _lib.SvcWindow, "gnx_model_info": _lib.ModelInfo}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "gnomix_hip.h"', 'int main(void) {']
+    for cname, ct in structs.items():
+        src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            src.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "probe.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, ct in structs.items():
+        assert int(out[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
