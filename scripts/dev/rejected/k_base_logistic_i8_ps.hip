@@ -148,8 +148,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8_ps(BaseLRLaunch
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // prologue only: group 0 has landed
   __syncthreads();
 
-  // one chunk: hand slot P to the MFMAs, refill it with chunk CL + PF (clamped: the tail re-fetches the last chunk)
-#define GNX_PS_CHUNK(P, CL, KLOC)                                                                    \
+  // one chunk: hand slot P to the MFMAs, refill it with chunk CL + PF (clamped: the tail re-fetches the last chunk); the
+  // digit planes of the NEXT chunk of the group (BN, clamped to the group's last chunk) are read from LDS while the
+  // MFMAs of this one (BC) run: without that the 7 ds_read_b128 latencies of a chunk were exposed one by one
+  // (3200 cycles per chunk and wave for 224 cycles of MFMA work)
+#define GNX_PS_CHUNK(P, CL, KLOC, BC, BN)                                                            \
   {                                                                                                   \
     v4i xa[MT];                                                                                       \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xa[mt] = xs[P][mt];                             \
@@ -157,29 +160,42 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8_ps(BaseLRLaunch
       const int j0_ = tab_j0[min((CL) + PF, n_chunks - 1)];                                           \
       _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xs[P][mt] = load_x16(rowp[mt] + j0_);         \
     }                                                                                                 \
-    const v4i* vb = reinterpret_cast<const v4i*>(pb + (size_t)(KLOC) * CHUNK_BYTES) + lane;           \
+    const v4i* vn = reinterpret_cast<const v4i*>(pb + (size_t)min((KLOC) + 1, cn - 1) * CHUNK_BYTES) + lane; \
+    _Pragma("unroll") for (int l = 0; l < LIMBS; ++l) BN[l] = vn[l * 64];                             \
     _Pragma("unroll") for (int l = 0; l < LIMBS; ++l) {                                               \
-      const v4i b = vb[l * 64];                                                                       \
       _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
-          acc[mt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][l], 0, 0, 0);         \
+          acc[mt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], BC[l], acc[mt][l], 0, 0, 0);     \
     }                                                                                                 \
   }
 
+  v4i bA[LIMBS], bB[LIMBS];
   for (int g = 0; g < n_groups; ++g) {
     dma_group(g + 1);  // the other buffer: every wave left it at the barrier that ended group g-1
     const uint8_t* pb = pbuf + (size_t)(g & 1) * GROUP_BYTES;
     const int c0 = grp_c0[g], cn = grp_c0[g + 1] - c0;
+    {
+      const v4i* v0 = reinterpret_cast<const v4i*>(pb) + lane;
+#pragma unroll
+      for (int l = 0; l < LIMBS; ++l) bA[l] = v0[l * 64];
+    }
     int k = 0;
 #pragma unroll 1
     for (; k + PF <= cn; k += PF) {
 #pragma unroll
-      for (int p = 0; p < PF; ++p) GNX_PS_CHUNK(p, c0 + k + p, k + p);
+      for (int p = 0; p < PF; p += 2) {
+        GNX_PS_CHUNK(p, c0 + k + p, k + p, bA, bB);
+        GNX_PS_CHUNK(p + 1, c0 + k + p + 1, k + p + 1, bB, bA);
+      }
     }
     const int rem = cn - k;  // < PF chunks left (block-uniform): slots 0..rem-1, then rotate the ring back into phase
     if (rem > 0) {
 #pragma unroll
       for (int p = 0; p < PF - 1; ++p)
-        if (p < rem) GNX_PS_CHUNK(p, c0 + k + p, k + p);
+        if (p < rem) {
+          GNX_PS_CHUNK(p, c0 + k + p, k + p, bA, bB);
+#pragma unroll
+          for (int l = 0; l < LIMBS; ++l) bA[l] = bB[l];
+        }
       v4i t[PF][MT];
 #pragma unroll
       for (int p = 0; p < PF; ++p)
