@@ -1029,6 +1029,7 @@ int gnx_infer_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx, float*
 static int64_t hap_batch(const gnx_model* m, int64_t N, int64_t ldx) {
   // bound the staging workspaces (~1 GiB of X per batch); whole individuals per batch
   int64_t nb = ((int64_t)1 << 30) / std::max<int64_t>(ldx, 1);
+  if (const char* e = std::getenv("GNX_HOST_BATCH")) nb = std::atoll(e);  // tests: force several batches on small inputs
   nb = std::max<int64_t>(2, nb & ~(int64_t)1);
   (void)m;
   return std::min(N, nb);
@@ -1224,6 +1225,7 @@ int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_
   const size_t WA = (size_t)W * m->info.A;
   // batches of individuals bound the staging workspaces (~1 GiB of X)
   int64_t nb = std::max<int64_t>(1, (((int64_t)1 << 30) / std::max<int64_t>(ldx, 1)) / 2);
+  if (const char* e = std::getenv("GNX_HOST_BATCH")) nb = std::max<int64_t>(1, std::atoll(e) / 2);
   nb = std::min(nb, n_ind);
   if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)2 * nb * ldx + 64)) != GNX_OK) return rc;
   if ((rc = ws_reserve(ctx, ctx->ws_b64, (size_t)2 * nb * WA * 8)) != GNX_OK) return rc;

@@ -683,3 +683,25 @@ def test_base_long_chromosome_many_windows(ga, oracle):
     assert np.array_equal(big[:48], small)                                # exact integer logits: tiling-independent
     ref = oracle.base_lr(X[:6], M, ctx, d.lr_coef, d.lr_intercept)
     assert np.max(np.abs(big[:6] - ref)) < 1e-12
+
+
+# ---------------------------------------------------------------- host-pointer staging in several batches ---------
+def test_host_path_batching_is_invisible(ga, monkeypatch):
+    """the host-pointer entry points stage X in batches (~1 GiB); force batches of 6 haplotypes / 3 individuals on small
+    inputs and require bit-identical results to the single-batch run (offsets, last partial batch, workspace reuse)"""
+    from gnomix_amd import synth
+    C, M, A, S, N = 6037, 100, 5, 21, 40
+    d = synth.synthetic_model(C=C, M=M, A=A, S=S, n_rounds=10, seed=8)
+    X = synth.synthetic_X(N, C, seed=4, miss=0.02)
+    ref_dev = ga.DeviceModel(d)
+    b32_ref, b64_ref = ref_dev.base_predict(X, want_f32=True, want_f64=True)
+    p_ref, l_ref = ref_dev.infer(X)
+    Xg, yg, ns = ref_dev.gnofix(X, b64_ref)
+    monkeypatch.setenv("GNX_HOST_BATCH", "6")
+    dev = ga.DeviceModel(d)
+    b32, b64 = dev.base_predict(X, want_f32=True, want_f64=True)
+    p, l = dev.infer(X)
+    assert np.array_equal(b32, b32_ref) and np.array_equal(b64, b64_ref)
+    assert np.array_equal(p, p_ref) and np.array_equal(l, l_ref)
+    Xg2, yg2, ns2 = dev.gnofix(X, b64_ref)
+    assert np.array_equal(Xg2, Xg) and np.array_equal(yg2, yg) and np.array_equal(ns2, ns)
