@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _library_is_built():
+    """a fresh clone has no libgnomix_hip.so (build artefacts are git-ignored): build it once (hipcc cross-compiles
+    gfx950 without a GPU; a no-op when it is up to date), exactly what __graft_entry__.build() does"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "gnomix_amd", "csrc")])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import gnx_oracle as O
