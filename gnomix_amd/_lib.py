@@ -71,6 +71,8 @@ class ModelInfo(C.Structure):
 _VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64
 SYMBOLS = {
     "gnx_abi_version": (C.c_int, []),
+    "gnx_host_alloc": (_I, [_VP, C.c_size_t, C.POINTER(_VP)]),
+    "gnx_host_free": (_I, [_VP, _VP]),
     "gnx_init": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "gnx_ctx_free": (None, [_VP]),
     "gnx_last_error": (C.c_char_p, [_VP]),
@@ -161,6 +163,20 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.gnx_synchronize(self.h))
+
+    def pinned_empty(self, shape, dtype):
+        """numpy array over page-locked host memory (gnx_host_alloc): X / B / outputs kept in such arrays cross PCIe by DMA
+        at link rate instead of through the runtime's pageable staging.  Freed when the array (its base) is collected."""
+        import numpy as np
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        self.check(self.lib.gnx_host_alloc(self.h, C.c_size_t(n), C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        lib, h, addr = self.lib, self.h, p.value
+        weakref.finalize(buf, lambda: lib.gnx_host_free(h, C.c_void_p(addr)))
+        arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        return arr
 
     def profile_enable(self, on=True):
         self.check(self.lib.gnx_profile_enable(self.h, int(bool(on))))

@@ -788,6 +788,21 @@ int gnx_reset_stream(gnx_ctx* ctx) {
   return GNX_OK;
 }
 
+int gnx_host_alloc(gnx_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return GNX_EINVAL;
+  *out = nullptr;
+  if (!ctx->usable) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return GNX_OK;
+}
+
+int gnx_host_free(gnx_ctx* ctx, void* p) {
+  if (!ctx) return GNX_EINVAL;
+  if (p) HIPCHK(ctx, hipHostFree(p));
+  return GNX_OK;
+}
+
 int gnx_synchronize(gnx_ctx* ctx) {
   if (!ctx) return GNX_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

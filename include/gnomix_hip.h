@@ -34,6 +34,7 @@
 #ifndef GNOMIX_HIP_H
 #define GNOMIX_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -183,6 +184,11 @@ const char* gnx_last_error(const gnx_ctx* ctx);
 int gnx_set_stream(gnx_ctx* ctx, void* hip_stream); /* borrow a hipStream_t; NULL is HIP's default (null) stream */
 int gnx_reset_stream(gnx_ctx* ctx);                 /* back to the context's own non-blocking stream */
 int gnx_synchronize(gnx_ctx* ctx);
+/* page-locked host memory for the host-pointer entry points: buffers allocated here move over PCIe by DMA at link rate
+ * (pageable memory goes through the runtime's staging copies).  The reference hands over numpy arrays (gnomix.py:48-49):
+ * a caller that lets its VCF reader fill a buffer from gnx_host_alloc avoids that extra pass. */
+int gnx_host_alloc(gnx_ctx* ctx, size_t bytes, void** out);
+int gnx_host_free(gnx_ctx* ctx, void* p);
 
 /* model */
 int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* desc, gnx_model** out);

@@ -11,3 +11,12 @@ for rep in range(3):
     p, lab = g.dev.infer(X)
     dt = time.perf_counter() - t0
     print("host-pointer gnx_infer: N=%d %.3f s  %.0f haplotypes/s  (%.1f GB/s of X over PCIe)" % (N, dt, N / dt, N * data.C / dt / 1e9), flush=True)
+
+# the same through page-locked arrays (Context.pinned_empty): input and outputs
+Xp = g.dev.ctx.pinned_empty(X.shape, np.int8)
+Xp[...] = X
+for rep in range(3):
+    t0 = time.perf_counter()
+    p, lab = g.dev.infer(Xp)
+    dt = time.perf_counter() - t0
+    print("pinned X        gnx_infer: N=%d %.3f s  %.0f haplotypes/s  (%.1f GB/s of X over PCIe)" % (N, dt, N / dt, N * data.C / dt / 1e9), flush=True)

@@ -705,3 +705,17 @@ def test_host_path_batching_is_invisible(ga, monkeypatch):
     assert np.array_equal(p, p_ref) and np.array_equal(l, l_ref)
     Xg2, yg2, ns2 = dev.gnofix(X, b64_ref)
     assert np.array_equal(Xg2, Xg) and np.array_equal(yg2, yg) and np.array_equal(ns2, ns)
+
+
+def test_pinned_host_arrays(ga):
+    """Context.pinned_empty (gnx_host_alloc): numpy arrays over page-locked memory work as inputs of the host-pointer path"""
+    from gnomix_amd import synth
+    d = synth.synthetic_model(C=3037, M=100, A=3, S=11, n_rounds=4, seed=2)
+    X = synth.synthetic_X(10, d.C, seed=3)
+    dev = ga.DeviceModel(d)
+    Xp = dev.ctx.pinned_empty(X.shape, np.int8)
+    Xp[...] = X
+    p0, l0 = dev.infer(X)
+    p1, l1 = dev.infer(Xp)
+    assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
+    del Xp
