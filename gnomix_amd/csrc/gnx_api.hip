@@ -132,12 +132,16 @@ static int build_lr(gnx_model* m, const gnx_model_desc* d) {
     for (size_t k = 0; k < n_pieces; ++k) {
       piece_chunk0[k] = (int32_t)chunk_j0.size();
       const int64_t b0 = bounds[k], b1 = bounds[k + 1];
-      const int64_t nch = (b1 - b0 + 63) / 64;
+      const int64_t nreal = (b1 - b0 + 63) / 64;
+      // every piece holds an EVEN number of chunks (the kernels step two chunks at a time and flush between steps):
+      // an odd piece gets one all-zero chunk that re-reads the bytes of its last chunk
+      const int64_t nch = nreal + (nreal & 1);
       int64_t f0 = wi, nf = 0;
       while (wi < W && fpos[(size_t)wi] == b1) { ++wi; ++nf; }
       for (int64_t c = 0; c < nch; ++c) {
-        chunk_j0.push_back((int32_t)(b0 + 64 * c));
-        chunk_end.push_back(b1);
+        const bool dummy = c >= nreal;
+        chunk_j0.push_back((int32_t)(b0 + 64 * std::min(c, nreal - 1)));
+        chunk_end.push_back(dummy ? b0 : b1);  // j >= chunk_end skips every weight of a dummy chunk
         const bool last = (c == nch - 1);
         chunk_flush0.push_back(last && nf ? (int32_t)f0 : -1);
         chunk_nflush.push_back(last ? (int32_t)nf : 0);

@@ -193,8 +193,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8(BaseLRLaunch L)
           }
         }
 
-      // ---- piece end: windows that finished here (block-uniform) ----
-      const int nfl = tab_nfl[cl];
+      // ---- piece end: windows that finished here (block-uniform); pieces hold an even number of chunks (model load
+      // pads them), so only the second chunk of a step can end one ----
+      const int nfl = (k == CPS - 1) ? tab_nfl[cl] : 0;
       if (nfl > 0) {
         const int w0 = tab_fl0[cl];
         for (int w = w0; w < w0 + nfl; ++w) {
