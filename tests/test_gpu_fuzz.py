@@ -1,0 +1,81 @@
+"""-m gpu: seeded random geometries through the whole path (base -> smoother) against the oracle.  Every case draws the
+chromosome length, window size, context ratio, number of ancestries, smoother width / kind, tree depth, missing rate and
+haplotype count at random; sizes stay small enough for the scalar oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.RandomState(1000 + seed)
+    M = int(rng.choice([16, 37, 50, 64, 100, 128, 250]))
+    ratio = float(rng.choice([0.0, 0.25, 0.5, 0.5, 1.0, 1.3]))
+    ctx = int(M * ratio)
+    S = int(rng.choice([5, 11, 21, 31, 75]))
+    W = int(rng.randint(2 * S, 2 * S + 120))
+    rem = int(rng.randint(1, M))
+    A = int(rng.choice([2, 3, 4, 5, 7, 8, 12, 16, 24]))
+    N = int(rng.choice([1, 2, 7, 33, 64, 65, 130, 513, 700]))
+    smooth = str(rng.choice(["xgb", "xgb", "crf"]))
+    depth = int(rng.choice([1, 2, 3, 4, 4, 5, 6]))
+    rounds = int(rng.randint(1, 9))
+    miss = float(rng.choice([0.0, 0.01, 0.1]))
+    return dict(C=W * M + rem, M=M, ctx=ctx, S=S, A=A, N=N, smooth=smooth, depth=depth, rounds=rounds, miss=miss, seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_random_geometry_vs_oracle(oracle, seed):
+    import gnomix_amd
+    from gnomix_amd import synth
+    gnomix_amd.load_library()
+    c = _case(seed)
+    R = (c["M"] + 2 * c["ctx"] + c["M"] - 1) // c["M"]
+    if R * c["A"] > 64:
+        pytest.skip("more than 64 class columns per SNP: rejected at model load (covered by test_base_rejects_bad_geometry)")
+    d = synth.synthetic_model(C=c["C"], M=c["M"], A=c["A"], S=c["S"], context=c["ctx"], seed=c["seed"], smooth=c["smooth"],
+                              n_rounds=c["rounds"], depth=c["depth"])
+    X = synth.synthetic_X(c["N"], c["C"], seed=c["seed"] + 7, miss=c["miss"])
+    dev = gnomix_amd.DeviceModel(d)
+    proba, labels = dev.infer(X)
+    b32, b64 = dev.base_predict(X, want_f32=True, want_f64=True)
+    n_chk = min(c["N"], 6)                               # oracle rows: first few and (when there are more) the last ones
+    rows = np.unique(np.concatenate([np.arange(n_chk), np.arange(max(0, c["N"] - 3), c["N"])]))
+    Bo = oracle.base_lr(X[rows], c["M"], c["ctx"], d.lr_coef, d.lr_intercept)
+    assert np.max(np.abs(b64[rows] - Bo)) < 1e-12, c
+    if c["smooth"] == "xgb":
+        T = oracle.Trees(d.tree_off, d.left, d.right, d.feat, d.cond, d.tree_class, d.A, d.base_score)
+        po, lo = oracle.smooth_xgb(T, b32[rows], c["S"])     # from the device's own float32 B: isolates the smoother
+    else:
+        po, lo = oracle.smooth_crf(b64[rows], d.crf_state, d.crf_trans)
+    assert np.array_equal(labels[rows], lo), c
+    assert np.max(np.abs(proba[rows] - po)) < 1e-5, c
+    dev.close()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_geometry_tree_bases_vs_oracle(oracle, seed):
+    """the same draw for the boosted-tree and random-forest bases (base probabilities only)"""
+    import gnomix_amd
+    from gnomix_amd import synth
+    c = _case(500 + seed)
+    rng = np.random.RandomState(seed)
+    A = min(c["A"], 16)
+    trees, depth = int(rng.randint(1, 8)), int(rng.randint(1, 7))
+    X = synth.synthetic_X(c["N"], c["C"], seed=seed + 3, miss=max(c["miss"], 0.03))
+    rows = np.unique(np.concatenate([np.arange(min(c["N"], 5)), np.arange(max(0, c["N"] - 2), c["N"])]))
+    if seed % 2 == 0:
+        d = synth.synthetic_forest_model(c["C"], c["M"], A, context=c["ctx"], n_rounds=trees, depth=depth, seed=seed, p_early_leaf=0.2)
+        b32, b64 = gnomix_amd.DeviceModel(d).base_predict(X, want_f32=True, want_f64=True)
+        T = oracle.Trees(d.fb_tree_off, d.fb_left, d.fb_right, d.fb_feat, d.fb_cond, d.fb_tree_class, d.A, d.fb_base_score,
+                         default_left=d.fb_default_left)
+        ref = oracle.base_forest(T, d.fb_win_tree0, X[rows], c["M"], c["ctx"], A, missing=2)
+        assert np.max(np.abs(b32[rows] - ref)) <= 2.4e-7, c
+        assert np.array_equal(b64, b32.astype(np.float64))
+    else:
+        d = synth.synthetic_rforest_model(c["C"], c["M"], A, context=c["ctx"], n_trees=trees, depth=depth, seed=seed, p_early_leaf=0.2)
+        b32, b64 = gnomix_amd.DeviceModel(d).base_predict(X, want_f32=True, want_f64=True)
+        rf = {k[3:]: getattr(d, k) for k in ("rf_win_tree0", "rf_tree_off", "rf_left", "rf_right", "rf_feat", "rf_thr", "rf_value")}
+        ref = oracle.base_rforest(rf, X[rows], c["M"], c["ctx"], A)
+        assert np.array_equal(b64[rows], ref), c
+        assert np.array_equal(b32, b64.astype(np.float32))
