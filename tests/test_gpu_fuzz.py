@@ -79,3 +79,68 @@ def test_random_geometry_tree_bases_vs_oracle(oracle, seed):
         ref = oracle.base_rforest(rf, X[rows], c["M"], c["ctx"], A)
         assert np.array_equal(b64[rows], ref), c
         assert np.array_equal(b32, b64.astype(np.float32))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_gnofix_vs_oracle(oracle, seed):
+    """random smoother geometry, random individuals (some with identical haplotypes), random iteration cap"""
+    import gnomix_amd
+    from gnomix_amd import synth
+    rng = np.random.RandomState(7000 + seed)
+    A = int(rng.choice([2, 3, 5, 7, 12]))
+    S = int(rng.choice([5, 11, 31, 75]))
+    W = int(rng.randint(2 * S, 2 * S + 90))
+    M = int(rng.choice([3, 7, 16]))
+    C = W * M + int(rng.randint(1, M))
+    max_it = int(rng.choice([1, 3, 6, 50]))
+    d = gnomix_amd.GnxModelData(C=C, M=M, A=A, S=S, context=0, smooth_kind="xgb")
+    trained = seed % 3 == 0   # a smoother that behaves like a trained one (few switches) or a chaotic random one (many)
+    trees = synth.synthetic_smoothing_trees(6, A, S, seed=seed, reach=min(8, (S - 1) // 2)) if trained else \
+        synth.synthetic_trees(int(rng.randint(2, 7)), A, S * A, seed=seed, thr_lo=0.0, thr_hi=0.6, leaf_scale=1.0)
+    for k, v in trees.items():
+        setattr(d, k, v)
+    dev = gnomix_amd.DeviceModel(d)
+    T = oracle.Trees(d.tree_off, d.left, d.right, d.feat, d.cond, d.tree_class, d.A, d.base_score)
+    n_ind = int(rng.randint(1, 6))
+    X = rng.randint(0, 3, size=(2 * n_ind, C)).astype(np.int8)
+    if n_ind > 1:
+        X[2:4] = X[2:3]
+    B = rng.dirichlet(np.ones(A) * 0.3, size=(2 * n_ind, W))
+    Xo, Y, nsw = dev.gnofix(X, B, max_it=max_it)
+    rows = lambda r: oracle.xgb_predict_proba(T, r)
+    labs = lambda b: oracle.smooth_xgb(T, b, S)[1]
+    for i in range(n_ind):
+        Xm, Xp, Ym, Yp, _, ns = oracle.gnofix(X[2 * i], X[2 * i + 1], B[2 * i:2 * i + 2], S, rows, labs, max_it=max_it)
+        assert np.array_equal(Xo[2 * i], Xm) and np.array_equal(Xo[2 * i + 1], Xp), (seed, i)
+        assert np.array_equal(Y[2 * i], Ym) and np.array_equal(Y[2 * i + 1], Yp), (seed, i)
+        assert int(nsw[i]) == ns, (seed, i)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_covrsk_vs_oracle(oracle, seed):
+    """random window widths (canonical-length fast path and generic path), class counts and support-vector sets"""
+    import gnomix_amd
+    from gnomix_amd import synth
+    rng = np.random.RandomState(9000 + seed)
+    M = int(rng.choice([20, 33, 64, 100, 175, 260]))
+    ctx = int(M * float(rng.choice([0.0, 0.5, 1.0])))
+    A = int(rng.choice([2, 3, 4, 7]))
+    W = int(rng.randint(3, 9))
+    C = W * M + int(rng.randint(1, M))
+    N = int(rng.choice([1, 5, 64, 70]))
+    d = synth.synthetic_svc_model(C, M, A, context=ctx, n_fit_per_class=int(rng.randint(3, 12)), seed=seed)
+    X = synth.synthetic_X(N, C, seed=seed, miss=0.03)
+    for n in range(0, N, 2):   # related haplotypes: long match runs
+        w = rng.randint(d.W)
+        src = d.svc[w]["xfit"][rng.randint(d.svc[w]["xfit"].shape[0])]
+        start = w * M - ctx
+        seg = src if start >= 0 else src[-start:]
+        lo = max(0, start)
+        ln = min(len(seg), C - lo)
+        X[n, lo:lo + ln] = seg[:ln]
+    _, b64 = gnomix_amd.DeviceModel(d).base_predict(X)
+    ow = [dict(Xfit=w["xfit"], Ms=list(w["ms"]), support=w["support"], dual=w["dual_coef"], intercept=w["intercept"],
+               probA=w["prob_a"], probB=w["prob_b"], n_support=w["n_support"]) for w in d.svc]
+    ref = oracle.base_covrsk(X, M, ctx, ow)
+    assert np.max(np.abs(b64 - ref)) < 1e-12, seed
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(ref, -1))
