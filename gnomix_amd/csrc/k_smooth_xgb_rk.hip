@@ -108,6 +108,57 @@ __device__ __forceinline__ void step_rk(uint32_t* j, const uint32_t* nd, const u
   }
 }
 
+// Level 0 with the level-1 node picked on the way: the root and its two children are words 1..3 of the tree, i.e. ONE
+// wave-uniform ds_read_b128 of the tree's first 16 bytes; the child is selected by the compare's own mask (v_cndmask),
+// which replaces an address computation + an LDS node read per segment (VALU-neutral, 3 LDS instructions fewer per tree).
+template <int R>
+__device__ __forceinline__ void step_sel_rk(uint32_t* j, uint32_t root, const uint32_t* r, uint32_t lo, uint32_t hi, uint32_t* nxt) {
+  if constexpr (R == 1) {
+    uint64_t c0;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %[x0], %[lo], %[hi], %[c0]\n\t"  /* before the addc: its carry-out overwrites the mask */
+        "v_addc_co_u32 %[j0], %[c0], %[j0], %[j0], %[c0]"
+        : [j0] "+v"(j[0]), [x0] "=&v"(nxt[0]), [c0] "=&s"(c0)
+        : [n] "v"(root), [r0] "v"(r[0]), [lo] "v"(lo), [hi] "v"(hi));
+  } else if constexpr (R == 2) {
+    uint64_t c0, c1;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c1], %[n], %[r1] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32 %[x0], %[lo], %[hi], %[c0]\n\t"
+        "v_cndmask_b32 %[x1], %[lo], %[hi], %[c1]\n\t"
+        "v_addc_co_u32 %[j0], %[c0], %[j0], %[j0], %[c0]\n\t"
+        "v_addc_co_u32 %[j1], %[c1], %[j1], %[j1], %[c1]"
+        : [j0] "+v"(j[0]), [j1] "+v"(j[1]), [x0] "=&v"(nxt[0]), [x1] "=&v"(nxt[1]), [c0] "=&s"(c0), [c1] "=&s"(c1)
+        : [n] "v"(root), [r0] "v"(r[0]), [r1] "v"(r[1]), [lo] "v"(lo), [hi] "v"(hi));
+  } else if constexpr (R == 3) {
+    uint64_t c0, c1, c2;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c1], %[n], %[r1] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c2], %[n], %[r2] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cndmask_b32 %[x0], %[lo], %[hi], %[c0]\n\t"
+        "v_cndmask_b32 %[x1], %[lo], %[hi], %[c1]\n\t"
+        "v_cndmask_b32 %[x2], %[lo], %[hi], %[c2]\n\t"
+        "v_addc_co_u32 %[j0], %[c0], %[j0], %[j0], %[c0]\n\t"
+        "v_addc_co_u32 %[j1], %[c1], %[j1], %[j1], %[c1]\n\t"
+        "v_addc_co_u32 %[j2], %[c2], %[j2], %[j2], %[c2]"
+        : [j0] "+v"(j[0]), [j1] "+v"(j[1]), [j2] "+v"(j[2]), [x0] "=&v"(nxt[0]), [x1] "=&v"(nxt[1]), [x2] "=&v"(nxt[2]),
+          [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
+        : [n] "v"(root), [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [lo] "v"(lo), [hi] "v"(hi));
+  } else if constexpr (R == 4) {
+    step_sel_rk<2>(j, root, r, lo, hi, nxt);
+    step_sel_rk<2>(j + 2, root, r + 2, lo, hi, nxt + 2);
+  } else if constexpr (R == 5) {
+    step_sel_rk<3>(j, root, r, lo, hi, nxt);
+    step_sel_rk<2>(j + 3, root, r + 3, lo, hi, nxt + 3);
+  } else {
+    static_assert(R == 6, "segments per strip");
+    step_sel_rk<3>(j, root, r, lo, hi, nxt);
+    step_sel_rk<3>(j + 3, root, r + 3, lo, hi, nxt + 3);
+  }
+}
+
 // D levels for the R segments of a lane: tb = the tree's 2^D node words + 2^D leaves (LDS), rb = the lane's origin in
 // its strip (LDS); segment k sits 64 windows = 128 bytes further
 template <int D, int R>
@@ -115,9 +166,18 @@ __device__ __forceinline__ void walk_rk(const uint8_t* tb, const uint8_t* rb, fl
   uint32_t j[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) j[k] = 1;
+  uint32_t nd[R], r[R];
+  if constexpr (D >= 2) {
+    const uint4 top = *reinterpret_cast<const uint4*>(tb);  // words 0..3: (unused, root, left child, right child)
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    uint32_t nd[R], r[R];
+    for (int k = 0; k < R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (top.y & 0xffffu));
+    step_sel_rk<R>(j, top.y, r, top.z, top.w, nd);
+#pragma unroll
+    for (int k = 0; k < R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (nd[k] & 0xffffu));
+    step_rk<R>(j, nd, r);
+  }
+#pragma unroll
+  for (int d = (D >= 2 ? 2 : 0); d < D; ++d) {
 #pragma unroll
     for (int k = 0; k < R; ++k) nd[k] = reinterpret_cast<const uint32_t*>(tb)[j[k]];
 #pragma unroll
