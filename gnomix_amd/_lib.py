@@ -14,7 +14,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 3
+GNX_ABI_VERSION = 4
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF = 0, 1, 2
@@ -38,7 +38,8 @@ class GnxError(RuntimeError):
 class SvcWindow(C.Structure):
     _fields_ = [("xfit", C.c_void_p), ("n_fit", C.c_int32), ("width", C.c_int32), ("support", C.c_void_p),
                 ("n_sv", C.c_int32), ("dual_coef", C.c_void_p), ("intercept", C.c_void_p), ("prob_a", C.c_void_p),
-                ("prob_b", C.c_void_p), ("n_support", C.c_void_p), ("ms", C.c_void_p), ("n_ms", C.c_int32)]
+                ("prob_b", C.c_void_p), ("n_support", C.c_void_p), ("ms", C.c_void_p), ("n_ms", C.c_int32),
+                ("kernel_kind", C.c_int32), ("poly_p", C.c_double), ("run_value", C.c_void_p)]
 
 
 class ModelDesc(C.Structure):

@@ -38,12 +38,23 @@ def string_kernel_lengths(width, kernel_name="CovRSK"):
 def svc_window_from_sklearn(svc, width, kernel_name="CovRSK"):
     """One fitted sklearn.svm.SVC(kernel=callable, probability=True) -> the dict GnxModelData.svc holds."""
     xfit = getattr(svc, "_BaseLibSVM__Xfit")
-    return dict(xfit=np.ascontiguousarray(xfit, dtype=np.int8), support=svc.support_.astype(np.int32),
-                dual_coef=np.ascontiguousarray(svc._dual_coef_, dtype=np.float64),
-                intercept=np.ascontiguousarray(svc._intercept_, dtype=np.float64),
-                prob_a=np.ascontiguousarray(svc._probA, dtype=np.float64),
-                prob_b=np.ascontiguousarray(svc._probB, dtype=np.float64),
-                n_support=svc._n_support.astype(np.int32), ms=string_kernel_lengths(width, kernel_name))
+    d = dict(xfit=np.ascontiguousarray(xfit, dtype=np.int8), support=svc.support_.astype(np.int32),
+             dual_coef=np.ascontiguousarray(svc._dual_coef_, dtype=np.float64),
+             intercept=np.ascontiguousarray(svc._intercept_, dtype=np.float64),
+             prob_a=np.ascontiguousarray(svc._probA, dtype=np.float64),
+             prob_b=np.ascontiguousarray(svc._probB, dtype=np.float64),
+             n_support=svc._n_support.astype(np.int32))
+    if "poly" in kernel_name:   # PolynomialStringKernelBase (models.py:178-193): poly_kernel(X, Y, p=1.2)
+        d.update(poly_run_values(width))
+    else:
+        d["ms"] = string_kernel_lengths(width, kernel_name)
+    return d
+
+
+def poly_run_values(width, p=1.2):
+    """what a run of L equal SNPs contributes to the polynomial string kernel (string_kernel.py:52: contigs ** p), computed
+    by numpy exactly as the reference computes it (int64 array ** float)"""
+    return dict(poly_p=float(p), run_value=np.arange(int(width) + 1, dtype=np.int64) ** p)
 
 
 def trees_from_xgb_json(dumps, n_class, base_score=0.5):

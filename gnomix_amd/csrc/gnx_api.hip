@@ -646,9 +646,11 @@ static int build_covrsk(gnx_model* m, const gnx_model_desc* d) {
     const gnx_svc_window& sw = d->svc[i];
     const int64_t width = (i == W - 1) ? M_ + rem : M_;
     if (sw.width != width) return fail(ctx, GNX_EINVAL, "covrsk base: svc[i].width != window width (M+2ctx, +rem for the last)");
-    if (!sw.xfit || !sw.support || !sw.dual_coef || !sw.intercept || !sw.prob_a || !sw.prob_b || !sw.n_support || !sw.ms ||
-        sw.n_sv <= 0 || sw.n_ms <= 0)
+    const bool poly = sw.kernel_kind == GNX_SVC_KERNEL_POLY;
+    if (!sw.xfit || !sw.support || !sw.dual_coef || !sw.intercept || !sw.prob_a || !sw.prob_b || !sw.n_support || sw.n_sv <= 0 ||
+        (poly ? (!sw.run_value || !(sw.poly_p > 0.0)) : (!sw.ms || sw.n_ms <= 0)))
       return fail(ctx, GNX_EINVAL, "covrsk base: incomplete svc window");
+    if (sw.kernel_kind != GNX_SVC_KERNEL_SUBSTRINGS && !poly) return fail(ctx, GNX_EINVAL, "covrsk base: unknown kernel_kind");
     SvcWinDev& wd = wins[(size_t)i];
     wd.width = (int32_t)width;
     wd.nw = (int32_t)((width + 31) / 32);
@@ -660,8 +662,9 @@ static int build_covrsk(gnx_model* m, const gnx_model_desc* d) {
     wd.cls_start[A] = acc;
     if (acc != sw.n_sv) return fail(ctx, GNX_EINVAL, "covrsk base: sum(n_support) != n_sv");
     // g(L) = sum_{m in Ms, m <= L} (L - m + 1): K adds g(run length) per maximal match run
-    std::vector<int32_t> ms(sw.ms, sw.ms + sw.n_ms);
-    int32_t goff = -1;
+    std::vector<int32_t> ms;
+    if (!poly) ms.assign(sw.ms, sw.ms + sw.n_ms);
+    int32_t goff = poly ? 0 : -1;
     for (size_t k = 0; k < gkeys.size(); ++k)
       if (gkeys[k].first == ms && gkeys[k].second == wd.width) goff = goffs[k];
     if (goff < 0) {
@@ -675,9 +678,12 @@ static int build_covrsk(gnx_model* m, const gnx_model_desc* d) {
       goffs.push_back(goff);
     }
     wd.g_off = goff;
-    wd.n_ms = sw.n_ms;
-    wd.pad0 = 0;
-    {  // fast path: lengths are a prefix of what CovSample(seed=37) yields, and the window fits 16 words
+    wd.n_ms = poly ? 0 : sw.n_ms;
+    wd.poly = poly ? 1 : 0;
+    wd.rv_off = 0;
+    wd.poly_p = poly ? sw.poly_p : 0.0;
+    if (poly) m->svc.fast_nw.push_back(-1);  // its own kernel
+    else {  // fast path: lengths are a prefix of what CovSample(seed=37) yields, and the window fits 16 words
       static const int32_t canon[] = {1, 4, 8, 39, 42, 117, 376};
       bool ok = sw.n_ms <= 7 && wd.nw <= 16;
       for (int k = 0; ok && k < sw.n_ms; ++k) ok = (sw.ms[k] == canon[k]);
@@ -703,7 +709,12 @@ static int build_covrsk(gnx_model* m, const gnx_model_desc* d) {
     coef.insert(coef.end(), sw.intercept, sw.intercept + P);
     coef.insert(coef.end(), sw.prob_a, sw.prob_a + P);
     coef.insert(coef.end(), sw.prob_b, sw.prob_b + P);
+    if (poly) {
+      wd.rv_off = (int64_t)coef.size();
+      coef.insert(coef.end(), sw.run_value, sw.run_value + (size_t)width + 1);
+    }
   }
+  if (gtab.empty()) gtab.push_back(0u);
   if (gnx_covrsk_lds_bytes(A, max_nw, max_width) > 160 * 1024)
     return fail(ctx, GNX_EUNSUPPORTED, "covrsk base: window too wide for the LDS working set");
   int rc;

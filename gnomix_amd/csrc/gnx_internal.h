@@ -155,10 +155,13 @@ struct SmoothCRFLaunch {
 // ---- CovRSK / SVC base (k_base_covrsk.hip) ------------------------------------------------------------
 struct SvcWinDev {
   int32_t width, nw, n_sv, g_off;  // window width in SNPs, 32-bit words per plane, support vectors, offset into gtab
-  int32_t n_ms, pad0;              // number of substring lengths (fast path: prefix of the canonical list)
+  int32_t n_ms, poly;              // number of substring lengths (fast path: prefix of the canonical list); poly = 1:
+                                   // polynomial string kernel, run values at coef[rv_off + L], exponent poly_p
   int64_t sv_off;                  // offset (uint32 units) of this window's SV bit-planes: [sv][plane][nw]
   int64_t coef_off;                // offset (doubles): dual (A-1, n_sv) | intercept P | probA P | probB P
   int32_t cls_start[36];           // SV index range per class (prefix sums of n_support)
+  int64_t rv_off;
+  double poly_p;
 };
 
 struct CovRSKDev {

@@ -59,6 +59,7 @@ __device__ __forceinline__ double sigmoid_predict(double dec, double pa, double 
 // pass 2a: kernel values + pairwise decision values + Platt sigmoids -> r_ij (i<j) in global memory.
 // Small LDS footprint (query bit-planes, g table, the P accumulators of 64 queries) so that many waves are resident:
 // the run-peeling loop is latency-bound (LDS lookups, scalar loads), occupancy is what hides it.
+template <bool POLY>
 __global__ __launch_bounds__(64) void k_covrsk_dec(CovRSKLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int lane = threadIdx.x;
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(64) void k_covrsk_dec(CovRSKLaunch L) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { uint8_t* p = lds + off; off += (bytes + 15) & ~(size_t)15; return p; };
   uint32_t* xq = reinterpret_cast<uint32_t*>(carve((size_t)2 * L.max_nw * 64 * 4));  // [plane][word][lane]
-  uint32_t* gl = reinterpret_cast<uint32_t*>(carve((size_t)(L.max_width + 2) * 4));   // g[0..width]
+  uint32_t* gl = reinterpret_cast<uint32_t*>(carve((size_t)(L.max_width + 2) * 8));   // g[0..width] (uint32), or run values (double)
+  const double* rv = reinterpret_cast<const double*>(gl);
   double* dec = reinterpret_cast<double*>(carve((size_t)P * 64 * 8));                 // [pair][lane]
 
   const int64_t n = L.n_first + (int64_t)blockIdx.x * 64 + lane;  // haplotype index within the whole batch
@@ -92,7 +94,11 @@ __global__ __launch_bounds__(64) void k_covrsk_dec(CovRSKLaunch L) {
       }
     }
   }
-  for (int i = lane; i <= width; i += 64) gl[i] = L.gtab[win.g_off + i];
+  if constexpr (POLY) {
+    for (int i = lane; i <= width; i += 64) reinterpret_cast<double*>(gl)[i] = L.coef[win.rv_off + i];
+  } else {
+    for (int i = lane; i <= width; i += 64) gl[i] = L.gtab[win.g_off + i];
+  }
   for (int p = 0; p < P; ++p) dec[p * 64 + lane] = 0.0;
   __syncthreads();
 
@@ -102,33 +108,109 @@ __global__ __launch_bounds__(64) void k_covrsk_dec(CovRSKLaunch L) {
   for (int c = 0; c < A; ++c) {
     for (int sv = win.cls_start[c]; sv < win.cls_start[c + 1]; ++sv) {
       const uint32_t* yb = L.svbits + win.sv_off + (size_t)sv * 2 * NW;  // wave-uniform -> scalar loads
-      uint32_t K = 0, run = 0;
-      for (int i = 0; i < NW; ++i) {
-        const uint32_t yl = yb[i], yh = yb[NW + i];
-        const uint32_t xl = xq[(size_t)i * 64 + lane], xh = xq[((size_t)L.max_nw + i) * 64 + lane];
-        uint32_t e = ~((xl ^ yl) | (xh ^ yh));
-        if (i == NW - 1) e &= tail_mask;
-        if (e == 0xffffffffu) { run += 32; continue; }
-        // trailing ones continue the carried run
-        uint32_t t = (uint32_t)__builtin_ctz(~e);
-        run += t;
-        K += gl[run];
-        run = 0;
-        e >>= t;
-        uint32_t rem = 32 - t;
-        while (e) {
-          const uint32_t z = (uint32_t)__builtin_ctz(e);
-          e >>= z;
-          rem -= z;
-          const uint32_t o = (uint32_t)__builtin_ctz(~e);  // e has zeros above bit rem-1, so o <= rem
-          if (o == rem) { run = o; break; }                // the run touches the end of the word: carry
-          K += gl[o];
-          e >>= o;
-          rem -= o;
+      double Kd;
+      if constexpr (POLY) {
+        // polynomial string kernel (string_kernel.py:40-61): contigs = run lengths, one per mismatch plus the final one;
+        // K = int(np.sum(contigs ** p) / p) with numpy's pairwise summation order restated element by element
+        auto ebits = [&](int i) -> uint32_t {
+          const uint32_t e = ~((xq[(size_t)i * 64 + lane] ^ yb[i]) | (xq[((size_t)L.max_nw + i) * 64 + lane] ^ yb[NW + i]));
+          return (i == NW - 1) ? (e & tail_mask) : e;
+        };
+        int n_el = 1;
+        for (int i = 0; i < NW; ++i) {
+          const int valid = (i == NW - 1 && (width & 31)) ? (width & 31) : 32;
+          n_el += valid - __builtin_popcount(ebits(i));
         }
+        int pos = 0;  // generator state: next SNP to look at
+        auto next_val = [&]() -> double {
+          int Lr = 0;
+          while (pos < width) {
+            const int wi = pos >> 5, b = pos & 31;
+            const uint32_t mm = (~ebits(wi)) >> b;  // mismatches from `pos` on (bits past the window read as mismatches)
+            if (mm != 0u) {
+              const int z = __builtin_ctz(mm);
+              if (pos + z < width) { Lr += z; pos += z + 1; return rv[Lr]; }
+              Lr += width - pos; pos = width;
+              return rv[Lr];
+            }
+            const int take = min(32 - b, width - pos);
+            Lr += take; pos += take;
+          }
+          return rv[Lr];  // the run closed by the end of the window
+        };
+        auto leaf = [&](int m) -> double {  // numpy DOUBLE_pairwise_sum for n <= 128
+          if (m < 8) {
+            double res = 0.;
+            for (int i = 0; i < m; ++i) res += next_val();
+            return res;
+          }
+          double r0 = next_val(), r1 = next_val(), r2 = next_val(), r3 = next_val(), r4 = next_val(), r5 = next_val(),
+                 r6 = next_val(), r7 = next_val();
+          int i = 8;
+          for (; i < m - (m % 8); i += 8) {
+            r0 += next_val(); r1 += next_val(); r2 += next_val(); r3 += next_val();
+            r4 += next_val(); r5 += next_val(); r6 += next_val(); r7 += next_val();
+          }
+          double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+          for (; i < m; ++i) res += next_val();
+          return res;
+        };
+        // the recursion  PW(n) = PW(n2) + PW(n - n2), n2 = n/2 rounded down to a multiple of 8, n > 128, made iterative
+        int fsz[12], fst[12];
+        double flv[12];
+        int top = 0;
+        fsz[0] = n_el; fst[0] = 0;
+        double ret = 0.0;
+        bool have = false;
+        while (top >= 0) {
+          if (!have) {
+            if (fsz[top] <= 128) { ret = leaf(fsz[top]); have = true; --top; }
+            else {
+              int n2 = fsz[top] / 2; n2 -= n2 % 8;
+              fst[top] = 0;
+              fsz[top + 1] = n2; fst[top + 1] = 0;
+              ++top;
+            }
+          } else if (fst[top] == 0) {
+            flv[top] = ret; fst[top] = 1; have = false;
+            int n2 = fsz[top] / 2; n2 -= n2 % 8;
+            fsz[top + 1] = fsz[top] - n2; fst[top + 1] = 0;
+            ++top;
+          } else {
+            ret = flv[top] + ret;
+            --top;
+          }
+        }
+        Kd = (double)(long long)(ret / win.poly_p);  // numpy float -> int assignment truncates toward zero
+      } else {
+        uint32_t K = 0, run = 0;
+        for (int i = 0; i < NW; ++i) {
+          const uint32_t yl = yb[i], yh = yb[NW + i];
+          const uint32_t xl = xq[(size_t)i * 64 + lane], xh = xq[((size_t)L.max_nw + i) * 64 + lane];
+          uint32_t e = ~((xl ^ yl) | (xh ^ yh));
+          if (i == NW - 1) e &= tail_mask;
+          if (e == 0xffffffffu) { run += 32; continue; }
+          // trailing ones continue the carried run
+          uint32_t t = (uint32_t)__builtin_ctz(~e);
+          run += t;
+          K += gl[run];
+          run = 0;
+          e >>= t;
+          uint32_t rem = 32 - t;
+          while (e) {
+            const uint32_t z = (uint32_t)__builtin_ctz(e);
+            e >>= z;
+            rem -= z;
+            const uint32_t o = (uint32_t)__builtin_ctz(~e);  // e has zeros above bit rem-1, so o <= rem
+            if (o == rem) { run = o; break; }                // the run touches the end of the word: carry
+            K += gl[o];
+            e >>= o;
+            rem -= o;
+          }
+        }
+        K += gl[run];
+        Kd = (double)K;
       }
-      K += gl[run];
-      const double Kd = (double)K;
       // libsvm predict_values order: every pair (i<j) sums its class-i SVs (coef row j-1) then its class-j SVs (row i)
       for (int o = 0; o < A; ++o) {
         if (o == c) continue;
@@ -365,7 +447,7 @@ __global__ __launch_bounds__(64) void k_svc_couple(CovRSKLaunch L) {
 size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width) {
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
   const int P = A * (A - 1) / 2;
-  const size_t dec = r16((size_t)2 * max_nw * 64 * 4) + r16((size_t)(max_width + 2) * 4) + r16((size_t)P * 64 * 8);
+  const size_t dec = r16((size_t)2 * max_nw * 64 * 4) + r16((size_t)(max_width + 2) * 8) + r16((size_t)P * 64 * 8);
   const size_t couple = (size_t)(P + A * A + 2 * A) * 64 * 8;
   return dec > couple ? dec : couple;
 }
@@ -382,9 +464,10 @@ hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
   if (L0.N <= 0) return hipSuccess;
   const int A = L0.A, P = A * (A - 1) / 2;
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  const size_t lds_dec = r16((size_t)2 * L0.max_nw * 64 * 4) + r16((size_t)(L0.max_width + 2) * 4) + r16((size_t)P * 64 * 8);
+  const size_t lds_dec = r16((size_t)2 * L0.max_nw * 64 * 4) + r16((size_t)(L0.max_width + 2) * 8) + r16((size_t)P * 64 * 8);
   const size_t lds_cpl = (size_t)(P + A * A + 2 * A) * 64 * 8;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_covrsk_dec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dec);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_covrsk_dec<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dec);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_covrsk_dec<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dec);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svc_couple), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cpl);
   // the pairwise probabilities travel through a bounded global buffer: haplotypes in chunks of rpair_haps
   for (int64_t n0 = 0; n0 < L0.N; n0 += L0.rpair_haps) {
@@ -405,7 +488,8 @@ hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
         GNX_FAST_CASE(8) GNX_FAST_CASE(9) GNX_FAST_CASE(10) GNX_FAST_CASE(11) GNX_FAST_CASE(12) GNX_FAST_CASE(13)
         GNX_FAST_CASE(14) GNX_FAST_CASE(15) GNX_FAST_CASE(16)
 #undef GNX_FAST_CASE
-        default: hipLaunchKernelGGL(k_covrsk_dec, grid, dim3(64), lds_dec, s, L); break;  // 0: generic run peeling
+        case -1: hipLaunchKernelGGL(k_covrsk_dec<true>, grid, dim3(64), lds_dec, s, L); break;  // polynomial string kernel
+        default: hipLaunchKernelGGL(k_covrsk_dec<false>, grid, dim3(64), lds_dec, s, L); break;  // 0: generic run peeling
       }
       w0 = w1;
     }

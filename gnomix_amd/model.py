@@ -184,8 +184,15 @@ class GnxModelData:
                 s.prob_a = ptr(w["prob_a"], np.float64)
                 s.prob_b = ptr(w["prob_b"], np.float64)
                 s.n_support = ptr(w["n_support"], np.int32)
-                ms = _c(w["ms"], np.int32)
-                s.ms, s.n_ms = ptr(ms, np.int32), len(ms)
+                if "poly_p" in w and float(w["poly_p"]) > 0:   # polynomial string kernel (string_kernel.py:40-61)
+                    rv = _c(w["run_value"], np.float64)
+                    if len(rv) < xf.shape[1] + 1:
+                        raise ValueError("run_value must hold width+1 values")
+                    s.kernel_kind, s.poly_p, s.run_value = 1, float(w["poly_p"]), ptr(rv, np.float64)
+                    s.ms, s.n_ms = None, 0
+                else:
+                    ms = _c(w["ms"], np.int32)
+                    s.ms, s.n_ms = ptr(ms, np.int32), len(ms)
             keep.append(arr)
             d.svc = C.addressof(arr)
         elif self.base_kind == "forest":

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 3
+#define GNX_ABI_VERSION 4
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -55,6 +55,7 @@ enum {
   GNX_ESTATE = -5        /* call not valid for this model (e.g. phasing with a CRF smoother) */
 };
 
+enum { GNX_SVC_KERNEL_SUBSTRINGS = 0, GNX_SVC_KERNEL_POLY = 1 };
 enum { GNX_BASE_NONE = 0, GNX_BASE_LOGISTIC = 1, GNX_BASE_COVRSK_SVC = 2, GNX_BASE_FOREST = 3, GNX_BASE_RFOREST = 4 };
 enum { GNX_SMOOTH_NONE = 0, GNX_SMOOTH_XGB = 1, GNX_SMOOTH_CRF = 2 };
 
@@ -84,8 +85,12 @@ typedef struct gnx_svc_window {
   const double* prob_a;     /* (A(A-1)/2,) (_probA) */
   const double* prob_b;     /* (A(A-1)/2,) (_probB) */
   const int32_t* n_support; /* (A,) (_n_support) */
-  const int32_t* ms;        /* CovSample lengths for this width (string_kernel.py:80-89) */
+  const int32_t* ms;        /* CovSample lengths for this width (string_kernel.py:80-89); unused for GNX_SVC_KERNEL_POLY */
   int32_t n_ms;
+  int32_t kernel_kind;      /* GNX_SVC_KERNEL_*: 0 = substring counts over the lengths `ms` (CovRSK; every length = the plain
+                               string kernel), 1 = polynomial string kernel (string_kernel.py:40-61) */
+  double poly_p;            /* POLY: K = int(np.sum(run_value[run lengths]) / poly_p), p = 1.2 in the reference */
+  const double* run_value;  /* POLY: (width+1,) value of a run of L equal SNPs = L ** p as numpy computed it */
 } gnx_svc_window;
 
 /* Everything a pickled src.model.Gnomix carries for inference (src/model.py:28-88), as flat host

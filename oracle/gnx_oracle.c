@@ -501,3 +501,61 @@ int gnxo_base_rforest(const int32_t* win_tree0, const int32_t* tree_off, const i
   free(xw);
   return GNXO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Polynomial string kernel (src/Base/string_kernel.py:40-61, PolynomialStringKernelBase models.py:178-193):
+ *   contigs = lengths of the runs of equal SNPs, a run being closed by every mismatch and by the end of the window
+ *             (so two adjacent mismatches contribute a 0);  K = int( np.sum(contigs ** p) / p )   (K is an int matrix).
+ * `run_value[L]` = L ** p as numpy computed it (the caller passes np.arange(width+1) ** p: data, not code).
+ * np.sum over a contiguous float64 vector is NOT a left-to-right sum: numpy/core/src/umath/loops_utils.h.src
+ * `DOUBLE_pairwise_sum`, reached through the add.reduce inner loop over the whole vector (initial value = the identity 0):
+ *   S = PW(a, n)     (pinned against np.sum itself by tests/test_oracle_golden.py::test_numpy_pairwise_sum_order)
+ *   PW(a, n): n < 8   -> 0. + a[0] + a[1] + ...                       (left to right)
+ *             n <= 128 -> r[k] = a[k] (k < 8); r[k] += a[i + k] for i = 8, 16, ... < n - n % 8;
+ *                         ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the n % 8 tail left to right
+ *             else     -> n2 = n / 2; n2 -= n2 % 8;  PW(a, n2) + PW(a + n2, n - n2)
+ * ---------------------------------------------------------------------------------------- */
+static double np_pairwise(const double* a, int64_t n) {
+  if (n < 8) {
+    double res = 0.;
+    for (int64_t i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int64_t i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int64_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+
+int gnxo_poly_kernel(const int8_t* Xq, int64_t Nq, int64_t ldq, const int8_t* Xt, int64_t Nt, int64_t ldt, int64_t Mw,
+                     const double* run_value, double p, int64_t* K) {
+  double* c = (double*)malloc((size_t)(Mw + 2) * sizeof(double));
+  if (!c) return GNXO_ENOMEM;
+  for (int64_t q = 0; q < Nq; ++q)
+    for (int64_t r = 0; r < Nt; ++r) {
+      const int8_t* x = Xq + q * ldq;
+      const int8_t* y = Xt + r * ldt;
+      int64_t n = 0, counter = 0;
+      for (int64_t j = 0; j < Mw; ++j) {
+        if (x[j] == y[j]) ++counter;
+        else { c[n++] = run_value[counter]; counter = 0; }
+      }
+      c[n++] = run_value[counter];
+      const double s = np_pairwise(c, n);
+      K[q * Nt + r] = (int64_t)(s / p);  /* numpy float -> int assignment truncates toward zero */
+    }
+  free(c);
+  return GNXO_OK;
+}
+
+/* np.sum of a contiguous float64 vector, exposed so that the tests can pin the summation order against numpy itself */
+double gnxo_np_sum(const double* a, int64_t n) { return n <= 0 ? 0.0 : np_pairwise(a, n); }

@@ -270,6 +270,20 @@ def string_kernel(Xq, Xt):
     return K
 
 
+def poly_kernel(Xq, Xt, run_value, p):
+    """poly_kernel (string_kernel.py:40-61): run_value = np.arange(width+1) ** p -> K (Nq, Nt) int64"""
+    Xq = np.ascontiguousarray(Xq, dtype=np.int8)
+    Xt = np.ascontiguousarray(Xt, dtype=np.int8)
+    rv = np.ascontiguousarray(run_value, dtype=np.float64)
+    Nq, Mw = Xq.shape
+    Nt = Xt.shape[0]
+    assert len(rv) >= Mw + 1
+    K = np.empty((Nq, Nt), dtype=np.int64)
+    _chk(lib().gnxo_poly_kernel(_p(Xq), C.c_int64(Nq), C.c_int64(Mw), _p(Xt), C.c_int64(Nt), C.c_int64(Mw), C.c_int64(Mw),
+                                _p(rv), C.c_double(p), _p(K)), "poly_kernel")
+    return K
+
+
 def svc_predict_proba(K, support, dual, intercept, probA, probB, n_support):
     K = np.ascontiguousarray(K, dtype=np.int64)
     support = np.ascontiguousarray(support, dtype=np.int32)
@@ -306,7 +320,7 @@ def base_covrsk(X, M, ctx, windows):
     out = []
     for i, Xw in base_windows(X, M, ctx):
         w = windows[i]
-        K = covrsk(Xw, w["Xfit"], w["Ms"])
+        K = poly_kernel(Xw, w["Xfit"], w["run_value"], w["poly_p"]) if w.get("poly_p") else covrsk(Xw, w["Xfit"], w["Ms"])
         out.append(svc_predict_proba(K, w["support"], w["dual"], w["intercept"], w["probA"], w["probB"], w["n_support"]))
     return np.swapaxes(np.array(out), 0, 1)
 

@@ -428,11 +428,52 @@ def make_G9(out):
     print("G9", B.shape, B.dtype, "trees", len(rf["rf_tree_off"]) - 1, "nodes", len(rf["rf_left"]))
 
 
+def make_G10(out):
+    """PolynomialStringKernelBase (src/Base/models.py:178-193): SVC(kernel=poly_kernel, probability=True) per window, trained
+    and run by the reference's own Base machinery; also the raw kernel matrix of one window (string_kernel.py:40-61)."""
+    from src.Base.models import PolynomialStringKernelBase
+    from src.Base.string_kernel import poly_kernel
+    sys.path.insert(0, ROOT)
+    from gnomix_amd.convert import svc_window_from_sklearn
+    rng = np.random.RandomState(94310)
+    C, M, A = 457, 50, 3
+    W, ctx = C // M, 25
+    Xt, yt = synth_admixed(rng, 45, C, A, W, M)
+    for w in range(W):
+        for a in range(A):
+            yt[a, w] = a
+    import numpy
+    real_ver = numpy.__version__
+    numpy.__version__ = "1.26.4"  # models.py:183 parses the MINOR version ("2.2.6" -> 2 < 20)
+    try:
+        base = PolynomialStringKernelBase(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx, n_jobs=1,
+                                          seed=94310, verbose=False)
+    finally:
+        numpy.__version__ = real_ver
+    base.base_multithread = False
+    base.log_inference = False
+    np.random.seed(94310)   # libsvm's probability cross-validation shuffles with rand(): sklearn seeds it from numpy
+    base.train(Xt, yt)
+    Xq, _ = synth_admixed(rng, 14, C, A, W, M, miss=0.05, switch_p=0.1)
+    Xq[0] = Xt[3]; Xq[1, :200] = Xt[5, :200]     # long matching runs
+    B = base.predict_proba(Xq)
+    M_ = M + 2 * ctx
+    wins = [svc_window_from_sklearn(m, M_ + (C - M * W if i == W - 1 else 0), "poly_kernel") for i, m in enumerate(base.models)]
+    flat = {}
+    for i, w in enumerate(wins):
+        for k, v in w.items():
+            flat["svc%d_%s" % (i, k)] = np.asarray(v)
+    Xp = np.concatenate([Xq[:, :ctx][:, ::-1], Xq, Xq[:, -ctx:][:, ::-1]], axis=1)
+    K0 = poly_kernel(Xp[:, :M_], wins[0]["xfit"], p=1.2)
+    np.savez_compressed(out, C=C, M=M, A=A, ctx=ctx, X=Xq, B=B, K0=K0, n_win=W, **flat)
+    print("G10", B.shape, "K0", K0.shape, K0.max())
+
+
 def main():
     if not import_reference():
         print("reference not found at", REF, "- nothing generated")
         return 0
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10"]
     if "G1" in which: make_G1(os.path.join(HERE, "G1_lr.npz"))
     if "G2" in which: make_G2(os.path.join(HERE, "G2_covrsk.npz"))
     if "G3" in which: make_G3(os.path.join(HERE, "G3_slide.npz"))
@@ -442,6 +483,7 @@ def main():
     if "G7" in which: make_G7(os.path.join(HERE, "G7_vcf.npz"))
     if "G8" in which: make_G8(os.path.join(HERE, "G8_calib_sk.npz"))
     if "G9" in which: make_G9(os.path.join(HERE, "G9_rf.npz"))
+    if "G10" in which: make_G10(os.path.join(HERE, "G10_poly.npz"))
     return 0
 
 

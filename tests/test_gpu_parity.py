@@ -719,3 +719,51 @@ def test_pinned_host_arrays(ga):
     p1, l1 = dev.infer(Xp)
     assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
     del Xp
+
+
+# ---------------------------------------------------------------- polynomial string kernel base -----------------
+def test_poly_string_kernel_golden_G10(ga, oracle):
+    """k_covrsk_dec<POLY> + SVC coupling against the reference's PolynomialStringKernelBase.predict_proba"""
+    g = load_golden("G10_poly.npz")
+    wins = []
+    for i in range(int(g["n_win"])):
+        pre = "svc%d_" % i
+        wins.append({k[len(pre):]: g[k] for k in g.files if k.startswith(pre)})
+    d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=int(g["A"]), S=5, context=int(g["ctx"]), base_kind="covrsk", svc=wins)
+    _, b64 = ga.DeviceModel(d).base_predict(g["X"])
+    assert np.max(np.abs(b64 - g["B"])) < 1e-12
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(g["B"], -1))
+
+
+@pytest.mark.parametrize("M,ctx,A,N,nfit,pmatch", [
+    (100, 50, 3, 70, 8, 0.5),        # ~100 mismatches per window: one numpy leaf block
+    (300, 150, 2, 33, 6, 0.5),       # ~300 run lengths: the pairwise recursion splits once
+    (700, 350, 4, 5, 5, 0.45),       # ~800: two levels of splits, odd remainders
+    (260, 0, 3, 64, 6, 0.97),        # few mismatches: n < 8 and n < 128 paths, long runs
+    (64, 32, 5, 129, 4, 0.7),
+])
+def test_poly_string_kernel_vs_oracle(ga, oracle, M, ctx, A, N, nfit, pmatch):
+    from gnomix_amd import synth, convert
+    W = 4
+    C = W * M + M // 3 + 1
+    d = synth.synthetic_svc_model(C, M, A, context=ctx, n_fit_per_class=nfit, seed=M + A)
+    for i, w in enumerate(d.svc):
+        w.pop("ms")
+        w.update(convert.poly_run_values(d.window_width(i)))
+    rng = np.random.RandomState(N)
+    X = synth.synthetic_X(N, C, seed=N, miss=0.02)
+    for n in range(N):           # queries related to training rows with probability pmatch per SNP
+        w = rng.randint(d.W)
+        src = d.svc[w]["xfit"][rng.randint(d.svc[w]["xfit"].shape[0])]
+        start = w * M - ctx
+        seg = src if start >= 0 else src[-start:]
+        lo = max(0, start)
+        ln = min(len(seg), C - lo)
+        keep = rng.random_sample(ln) < pmatch
+        X[n, lo:lo + ln] = np.where(keep, seg[:ln], X[n, lo:lo + ln])
+    _, b64 = ga.DeviceModel(d).base_predict(X)
+    ow = [dict(Xfit=w["xfit"], support=w["support"], dual=w["dual_coef"], intercept=w["intercept"], probA=w["prob_a"],
+               probB=w["prob_b"], n_support=w["n_support"], run_value=w["run_value"], poly_p=w["poly_p"]) for w in d.svc]
+    ref = oracle.base_covrsk(X, M, ctx, ow)
+    assert np.max(np.abs(b64 - ref)) < 1e-12
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(ref, -1))

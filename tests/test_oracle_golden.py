@@ -161,3 +161,39 @@ def test_rforest_base_golden_G9(oracle):
     assert B.shape == g["B"].shape
     assert np.array_equal(B, g["B"])           # bit-exact: same float64 adds in estimator order, same division
     assert np.allclose(B.sum(-1), 1.0, atol=1e-12)
+
+
+def test_numpy_pairwise_sum_order(oracle):
+    """np.sum of a float64 vector is a pairwise sum: the restatement must reproduce numpy bit for bit at every length"""
+    import ctypes as C
+    L = oracle.lib()
+    L.gnxo_np_sum.restype = C.c_double
+    rng = np.random.RandomState(1)
+    for n in list(range(1, 300)) + [511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2500, 4096, 5001]:
+        a = (rng.random_sample(n) * rng.choice([1, 1e3, 1e-3])) ** 1.2
+        assert L.gnxo_np_sum(a.ctypes.data_as(C.c_void_p), C.c_int64(n)) == np.sum(a), n
+
+
+def _poly_windows(g):
+    wins = []
+    for i in range(int(g["n_win"])):
+        pre = "svc%d_" % i
+        w = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+        wins.append(w)
+    return wins
+
+
+def test_poly_string_kernel_golden_G10(oracle):
+    """polynomial string kernel + SVC probabilities against the reference's PolynomialStringKernelBase output"""
+    g = load_golden("G10_poly.npz")
+    wins = _poly_windows(g)
+    C_, M, ctx = int(g["C"]), int(g["M"]), int(g["ctx"])
+    X = g["X"]
+    Xp = np.concatenate([X[:, :ctx][:, ::-1], X, X[:, -ctx:][:, ::-1]], axis=1)
+    K0 = oracle.poly_kernel(Xp[:, :M + 2 * ctx], wins[0]["xfit"], wins[0]["run_value"], float(wins[0]["poly_p"]))
+    assert np.array_equal(K0, g["K0"])                    # the reference's own poly_kernel matrix, exactly
+    ow = [dict(Xfit=w["xfit"], support=w["support"], dual=w["dual_coef"], intercept=w["intercept"], probA=w["prob_a"],
+               probB=w["prob_b"], n_support=w["n_support"], run_value=w["run_value"], poly_p=float(w["poly_p"])) for w in wins]
+    B = oracle.base_covrsk(X, M, ctx, ow)
+    assert np.max(np.abs(B - g["B"])) < 1e-12
+    assert np.array_equal(np.argmax(B, -1), np.argmax(g["B"], -1))
