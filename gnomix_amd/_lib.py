@@ -14,14 +14,14 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 4
+GNX_ABI_VERSION = 5
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
-SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF = 0, 1, 2
-K_BASE_LOGISTIC, K_SMOOTH_XGB, K_BASE_COVRSK, K_SMOOTH_CRF, K_GNOFIX, K_SMOOTH_ROWS, K_CALIBRATE, K_BASE_FOREST = range(8)
+SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
+K_BASE_LOGISTIC, K_SMOOTH_XGB, K_BASE_COVRSK, K_SMOOTH_CRF, K_GNOFIX, K_SMOOTH_ROWS, K_CALIBRATE, K_BASE_FOREST, K_SMOOTH_CNN = range(9)
 KERNEL_NAMES = {K_BASE_LOGISTIC: "k_base_logistic", K_SMOOTH_XGB: "k_smooth_xgb", K_BASE_COVRSK: "k_base_covrsk",
                 K_SMOOTH_CRF: "k_smooth_crf", K_GNOFIX: "k_gnofix", K_SMOOTH_ROWS: "k_smooth_rows", K_CALIBRATE: "k_calibrate",
-                K_BASE_FOREST: "k_base_forest"}
+                K_BASE_FOREST: "k_base_forest", K_SMOOTH_CNN: "k_smooth_cnn"}
 
 
 class GnxLibraryError(ImportError):
@@ -59,7 +59,7 @@ class ModelDesc(C.Structure):
                 ("fb_base_score", C.c_float), ("reserved4", C.c_int32),
                 ("rf_n_trees", C.c_int32), ("reserved5", C.c_int32), ("rf_win_tree0", C.c_void_p), ("rf_tree_off", C.c_void_p),
                 ("rf_left", C.c_void_p), ("rf_right", C.c_void_p), ("rf_feat", C.c_void_p), ("rf_thr", C.c_void_p),
-                ("rf_value", C.c_void_p)]
+                ("rf_value", C.c_void_p), ("cnn_weight", C.c_void_p), ("cnn_bias", C.c_void_p)]
 
 
 class ModelInfo(C.Structure):

@@ -220,6 +220,13 @@ def from_reference_model(model) -> GnxModelData:
             d.crf_state[int(attr), int(label)] = w
         for (y0, y1), w in crf.transition_features_.items():
             d.crf_trans[int(y0), int(y1)] = w
+    elif sm == "CNN_Smoother":  # mode "large" (src/model.py:65-67): src.Smooth.cnn.CNN holds nn.Sequential(nn.Conv1d(A, A, S))
+        conv = model.smooth.model.smoothNet[0]
+        d.smooth_kind = "cnn"
+        d.cnn_weight = np.ascontiguousarray(conv.weight.detach().cpu().numpy(), dtype=np.float32)
+        d.cnn_bias = np.ascontiguousarray(conv.bias.detach().cpu().numpy(), dtype=np.float32)
+        if d.cnn_weight.shape != (A, A, d.S):
+            raise ValueError(f"CNN smoother: Conv1d weight {d.cnn_weight.shape} != (A, A, S) = ({A}, {A}, {d.S})")
     else:
         raise NotImplementedError(f"smoother {sm}")
     cal = getattr(model.smooth, "calibrator", None)

@@ -857,6 +857,14 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
       else rc = build_xgb(m, d);
       break;
     case GNX_SMOOTH_CRF: rc = build_crf(m, d); break;
+    case GNX_SMOOTH_CNN:
+      if (d->S <= 0 || d->S % 2 == 0) rc = fail(ctx, GNX_EINVAL, "S must be odd and positive (smooth.py:14)");
+      else if (!d->cnn_weight || !d->cnn_bias) rc = fail(ctx, GNX_EINVAL, "cnn smoother: cnn_weight / cnn_bias is NULL");
+      else {
+        std::vector<float> wv(d->cnn_weight, d->cnn_weight + (size_t)d->A * d->A * d->S), bv(d->cnn_bias, d->cnn_bias + d->A);
+        if ((rc = dev_upload(m, wv, &m->cnn_weight)) == GNX_OK) rc = dev_upload(m, bv, &m->cnn_bias);
+      }
+      break;
     default: rc = fail(ctx, GNX_EINVAL, "unknown smooth_kind");
   }
   if (rc == GNX_OK && d->calib_off) {
@@ -1037,6 +1045,15 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     L.proba64 = d_p64; L.proba32 = d_p32; L.labels = d_lab;
     ProfScope ps(ctx, GNX_K_SMOOTH_CRF);
     HIPCHK(ctx, gnx_launch_smooth_crf(L, ctx->stream));
+    return GNX_OK;
+  }
+  if (m->info.smooth_kind == GNX_SMOOTH_CNN) {
+    SmoothCNNLaunch L{};
+    L.B = dB; L.b_is_f64 = b_is_f64; L.N = N; L.W = (int32_t)m->info.W; L.A = m->info.A; L.S = m->info.S;
+    L.weight = m->cnn_weight; L.bias = m->cnn_bias;
+    L.proba32 = d_p32; L.proba64 = d_p64; L.labels = d_lab;
+    ProfScope ps(ctx, GNX_K_SMOOTH_CNN);
+    HIPCHK(ctx, gnx_launch_smooth_cnn(L, ctx->stream));
     return GNX_OK;
   }
   return fail(ctx, GNX_ESTATE, "model has no smoother");

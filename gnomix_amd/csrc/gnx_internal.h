@@ -152,6 +152,19 @@ struct SmoothCRFLaunch {
   int32_t* labels;        // optional
 };
 
+// ---- cnn smoother (k_smooth_cnn.hip) -----------------------------------------------------------------
+struct SmoothCNNLaunch {
+  const void* B;          // (N, W, A) float32 or float64 (cast to float32 as torch.tensor(B, dtype=torch.float) does)
+  int32_t b_is_f64;
+  int64_t N;
+  int32_t W, A, S, w_in_lds;
+  const float* weight;    // device (A_out, A_in, S)
+  const float* bias;      // device (A_out,)
+  float* proba32;         // optional
+  double* proba64;        // optional
+  int32_t* labels;        // optional
+};
+
 // ---- CovRSK / SVC base (k_base_covrsk.hip) ------------------------------------------------------------
 struct SvcWinDev {
   int32_t width, nw, n_sv, g_off;  // window width in SNPs, 32-bit words per plane, support vectors, offset into gtab
@@ -262,6 +275,8 @@ struct gnx_model {
   // CRF
   const double* crf_state = nullptr;  // device (A,A)
   const double* crf_etrans = nullptr; // device (A,A) exp(trans)
+  const float* cnn_weight = nullptr;  // device (A, A, S)
+  const float* cnn_bias = nullptr;    // device (A,)
   // calibrator
   const int32_t* calib_off = nullptr;
   const double* calib_x = nullptr;
@@ -285,6 +300,7 @@ hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s
 size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
 hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
+hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);
 hipError_t gnx_launch_base_forest(const ForestLaunch& L, hipStream_t s);
 size_t gnx_forest_lds_bytes(int A, int max_words, int max_trees, int tree_bytes, int threads);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

@@ -29,7 +29,7 @@ class GnxModelData:
     S: int = 75
     context: int = 0                      # SNPs each side = int(M*context_ratio) (src/model.py:47)
     base_kind: str | None = None          # "logistic" | "covrsk" | "forest" | "rforest"
-    smooth_kind: str | None = None        # "xgb" | "crf"
+    smooth_kind: str | None = None        # "xgb" | "crf" | "cnn"
     # logistic base: coef_ / intercept_ of LogisticRegression per window (src/Base/models.py:12-21)
     lr_coef: np.ndarray | None = None     # (W, A, ldc) float64, window i uses [:, :width_i]
     lr_intercept: np.ndarray | None = None  # (W, A)
@@ -65,6 +65,9 @@ class GnxModelData:
     # crf smoother (src/Smooth/crf.py)
     crf_state: np.ndarray | None = None   # (A, A) [attribute][label]
     crf_trans: np.ndarray | None = None   # (A, A) [from][to]
+    # cnn smoother (src/Smooth/cnn.py): Conv1d(A, A, S) weight (A_out, A_in, S) and bias (A_out,), float32
+    cnn_weight: np.ndarray | None = None
+    cnn_bias: np.ndarray | None = None
     # optional Calibrator (src/Smooth/Calibration.py): per-class isotonic thresholds, concatenated
     calib_off: np.ndarray | None = None   # (A+1,) int32
     calib_x: np.ndarray | None = None
@@ -159,7 +162,7 @@ class GnxModelData:
         d.A, d.C, d.M, d.ctx, d.S = int(self.A), int(self.C), int(self.M), int(self.context), int(self.S)
         d.base_kind = {None: _lib.BASE_NONE, "logistic": _lib.BASE_LOGISTIC, "covrsk": _lib.BASE_COVRSK_SVC,
                        "forest": _lib.BASE_FOREST, "rforest": _lib.BASE_RFOREST}[self.base_kind]
-        d.smooth_kind = {None: _lib.SMOOTH_NONE, "xgb": _lib.SMOOTH_XGB, "crf": _lib.SMOOTH_CRF}[self.smooth_kind]
+        d.smooth_kind = {None: _lib.SMOOTH_NONE, "xgb": _lib.SMOOTH_XGB, "crf": _lib.SMOOTH_CRF, "cnn": _lib.SMOOTH_CNN}[self.smooth_kind]
         W, A = self.W, self.A
         if self.base_kind == "logistic":
             coef = _c(self.lr_coef, np.float64)
@@ -239,6 +242,12 @@ class GnxModelData:
         elif self.smooth_kind == "crf":
             d.crf_state = ptr(self.crf_state, np.float64)
             d.crf_trans = ptr(self.crf_trans, np.float64)
+        elif self.smooth_kind == "cnn":
+            wgt = _c(self.cnn_weight, np.float32)
+            if wgt.shape != (A, A, int(self.S)):
+                raise ValueError(f"cnn_weight must be (A, A, S) = ({A}, {A}, {self.S}), got {wgt.shape}")
+            d.cnn_weight = ptr(wgt, np.float32)
+            d.cnn_bias = ptr(_c(self.cnn_bias, np.float32).reshape(A), np.float32)
         if self.calib_off is not None:
             d.calib_off = ptr(self.calib_off, np.int32)
             d.calib_x = ptr(self.calib_x, np.float64)

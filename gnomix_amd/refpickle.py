@@ -10,6 +10,7 @@ restricted `Unpickler`:
    `__module__`, so `gnomix_amd.convert.from_reference_model` duck-types it exactly like the real object
    (`type(m).__name__ == "LogisticRegression"`, `m.coef_`, ...);  scikit-learn classes are rebuilt for real when
    `use_sklearn=True` and scikit-learn imports;
+ * torch objects (the CNN smoother of the "large" mode pickles an `nn.Sequential`) are rebuilt by torch when it imports;
  * anything else raises `pickle.UnpicklingError` (a pickle is code: nothing outside the lists above is ever
    imported or called).
 
@@ -109,6 +110,11 @@ class RefUnpickler(pickle.Unpickler):
             return super().find_class(module, name)
         if module == "copyreg" and name == "_reconstructor":
             return super().find_class(module, name)
+        if root == "torch":  # the CNN smoother pickles a real torch module: rebuilt by torch itself (tensors, Parameters)
+            try:
+                return super().find_class(module, name)
+            except Exception as e:
+                raise pickle.UnpicklingError(f"the pickle holds torch objects and torch is not importable: {e}")
         if root in ("sklearn",) and self.use_sklearn:
             try:
                 return super().find_class(module, name)

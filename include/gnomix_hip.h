@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 4
+#define GNX_ABI_VERSION 5
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -57,7 +57,7 @@ enum {
 
 enum { GNX_SVC_KERNEL_SUBSTRINGS = 0, GNX_SVC_KERNEL_POLY = 1 };
 enum { GNX_BASE_NONE = 0, GNX_BASE_LOGISTIC = 1, GNX_BASE_COVRSK_SVC = 2, GNX_BASE_FOREST = 3, GNX_BASE_RFOREST = 4 };
-enum { GNX_SMOOTH_NONE = 0, GNX_SMOOTH_XGB = 1, GNX_SMOOTH_CRF = 2 };
+enum { GNX_SMOOTH_NONE = 0, GNX_SMOOTH_XGB = 1, GNX_SMOOTH_CRF = 2, GNX_SMOOTH_CNN = 3 };
 
 /* kernel ids for gnx_profile_get */
 enum {
@@ -69,7 +69,8 @@ enum {
   GNX_K_SMOOTH_ROWS = 5,
   GNX_K_CALIBRATE = 6,
   GNX_K_BASE_FOREST = 7,
-  GNX_K_COUNT = 8
+  GNX_K_SMOOTH_CNN = 8,
+  GNX_K_COUNT = 9
 };
 
 /* Per-window SVC of CovRSKBase (src/Base/models.py:195-215 -> sklearn.svm.SVC(kernel=callable,
@@ -171,6 +172,11 @@ typedef struct gnx_model_desc {
   const int32_t* rf_feat;           /* SNP index within the window's padded slice */
   const double* rf_thr;
   const double* rf_value;           /* (n_nodes, A) what DecisionTreeClassifier.predict_proba returns at that node */
+
+  /* GNX_SMOOTH_CNN: the "large" mode's smoother (src/Smooth/cnn.py:37-55): one Conv1d(A, A, kernel_size=S,
+   * padding=(S-1)/2, zero padding — see k_smooth_cnn.hip) over the windows + softmax over the A output channels */
+  const float* cnn_weight;          /* (A_out, A_in, S) smoothNet[0].weight */
+  const float* cnn_bias;            /* (A_out,) smoothNet[0].bias */
 } gnx_model_desc;
 
 typedef struct gnx_model_info {

@@ -559,3 +559,46 @@ int gnxo_poly_kernel(const int8_t* Xq, int64_t Nq, int64_t ldq, const int8_t* Xt
 
 /* np.sum of a contiguous float64 vector, exposed so that the tests can pin the summation order against numpy itself */
 double gnxo_np_sum(const double* a, int64_t n) { return n <= 0 ? 0.0 : np_pairwise(a, n); }
+
+/* ------------------------------------------------------------------------------------------
+ * CNN smoother of the "large" mode (src/Smooth/models.py:35-42, src/Smooth/cnn.py:37-55, 166-171, 173-184):
+ *   B (N, W, A) -> torch.tensor(transpose(B, [0, 2, 1]), dtype=torch.float) -> nn.Conv1d(A, A, kernel_size=S,
+ *   padding=(S-1)//2, padding_mode="reflection") -> nn.Softmax(dim=1) -> swapaxes -> (N, W, A) float32.
+ * "reflection" is not a padding mode torch implements: torch <= 1.4 falls through to zero padding, torch >= 1.5 refuses to
+ * build the layer, so the reference's CNN zero-pads wherever it runs; the golden vector (G11) is produced by the
+ * reference's own CNN class under exactly that reading.  float32 arithmetic as in torch; the order in which the backend
+ * sums the A*S taps is not defined, so this restatement (taps in (a_in, s) order) agrees with torch to a few float32 ulps
+ * and is compared at the north star's 1e-5.
+ * weight is torch's (A_out, A_in, S), bias (A_out,).
+ * ---------------------------------------------------------------------------------------- */
+int gnxo_smooth_cnn(const double* B, int64_t N, int64_t W, int64_t A, int64_t S, const float* weight, const float* bias,
+                    float* proba, int64_t* labels) {
+  if (S <= 0 || S % 2 == 0 || A < 1 || A > 64) return GNXO_EINVAL;
+  const int64_t pad = (S - 1) / 2;
+  float out[64];
+  for (int64_t n = 0; n < N; ++n)
+    for (int64_t w = 0; w < W; ++w) {
+      for (int64_t y = 0; y < A; ++y) {
+        float acc = bias[y];
+        for (int64_t a = 0; a < A; ++a)
+          for (int64_t s = 0; s < S; ++s) {
+            const int64_t ww = w + s - pad;
+            if (ww < 0 || ww >= W) continue;  /* zero padding */
+            acc += (float)B[(n * W + ww) * A + a] * weight[(y * A + a) * S + s];
+          }
+        out[y] = acc;
+      }
+      float mx = out[0];
+      for (int64_t y = 1; y < A; ++y) mx = fmaxf(mx, out[y]);
+      float sum = 0.0f;
+      for (int64_t y = 0; y < A; ++y) { out[y] = expf(out[y] - mx); sum += out[y]; }
+      int64_t best = 0;
+      for (int64_t y = 0; y < A; ++y) {
+        const float p = out[y] / sum;
+        proba[(n * W + w) * A + y] = p;
+        if (p > proba[(n * W + w) * A + best]) best = y;
+      }
+      if (labels) labels[n * W + w] = best;
+    }
+  return GNXO_OK;
+}

@@ -229,6 +229,20 @@ def smooth_crf(B, state, trans):
 # ------------------------------------------------------------------------------------------------
 # a4 CovRSK + SVC probability
 # ------------------------------------------------------------------------------------------------
+def smooth_cnn(B, weight, bias):
+    """CNN_Smoother.predict_proba / predict (Smooth/cnn.py): B (N,W,A) -> proba (N,W,A) f32, labels (N,W) int64"""
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    wgt = np.ascontiguousarray(weight, dtype=np.float32)
+    bs = np.ascontiguousarray(bias, dtype=np.float32)
+    N, W, A = B.shape
+    S = wgt.shape[2]
+    proba = np.empty((N, W, A), dtype=np.float32)
+    labels = np.empty((N, W), dtype=np.int64)
+    _chk(lib().gnxo_smooth_cnn(_p(B), C.c_int64(N), C.c_int64(W), C.c_int64(A), C.c_int64(S), _p(wgt), _p(bs), _p(proba),
+                               _p(labels)), "smooth_cnn")
+    return proba, labels
+
+
 def cov_sample(M, alpha=0.6, beta=1.0, seed=37):
     """CovSample (string_kernel.py:80-89): legacy MT19937 stream, one draw per m in 2..M."""
     rs = np.random.RandomState(seed)  # == np.random.seed(seed); np.random.rand() draws

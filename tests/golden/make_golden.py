@@ -469,11 +469,44 @@ def make_G10(out):
     print("G10", B.shape, "K0", K0.shape, K0.max())
 
 
+def make_G11(out):
+    """CNN_Smoother ("large" mode, src/Smooth/models.py:35-42, cnn.py).  The reference builds nn.Conv1d with
+    padding_mode="reflection", which torch <= 1.4 silently treats as zero padding and torch >= 1.5 rejects; the layer is
+    constructed here the only way it ever ran — zero padding — by translating that one string while the reference's own
+    CNN class is instantiated; everything else (as_torch_tensor, forward_tensors, Softmax, swapaxes) is the reference's."""
+    import torch
+    from torch import nn
+    real_conv = nn.Conv1d
+
+    class Conv1dOldTorch(real_conv):
+        def __init__(self, *a, padding_mode="zeros", **k):
+            super().__init__(*a, padding_mode="zeros" if padding_mode == "reflection" else padding_mode, **k)
+
+    from src.Smooth import cnn as ref_cnn
+    nn.Conv1d = Conv1dOldTorch
+    try:
+        torch.manual_seed(94311)
+        A, S, W, N = 5, 21, 90, 9
+        model = ref_cnn.CNN(num_classes=A, num_features=S)
+    finally:
+        nn.Conv1d = real_conv
+    model.eval()
+    rng = np.random.RandomState(94311)
+    B = rng.dirichlet(np.ones(A) * 0.4, size=(N, W))
+    with torch.no_grad():
+        proba = model.predict_proba(B)
+        labels = model.predict(B)
+    wgt = model.smoothNet[0].weight.detach().numpy().copy()
+    bias = model.smoothNet[0].bias.detach().numpy().copy()
+    np.savez_compressed(out, A=A, S=S, W=W, B=B, weight=wgt, bias=bias, proba=proba, labels=labels)
+    print("G11", proba.shape, proba.dtype, labels.shape)
+
+
 def main():
     if not import_reference():
         print("reference not found at", REF, "- nothing generated")
         return 0
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11"]
     if "G1" in which: make_G1(os.path.join(HERE, "G1_lr.npz"))
     if "G2" in which: make_G2(os.path.join(HERE, "G2_covrsk.npz"))
     if "G3" in which: make_G3(os.path.join(HERE, "G3_slide.npz"))
@@ -484,6 +517,7 @@ def main():
     if "G8" in which: make_G8(os.path.join(HERE, "G8_calib_sk.npz"))
     if "G9" in which: make_G9(os.path.join(HERE, "G9_rf.npz"))
     if "G10" in which: make_G10(os.path.join(HERE, "G10_poly.npz"))
+    if "G11" in which: make_G11(os.path.join(HERE, "G11_cnn.npz"))
     return 0
 
 

@@ -767,3 +767,49 @@ def test_poly_string_kernel_vs_oracle(ga, oracle, M, ctx, A, N, nfit, pmatch):
     ref = oracle.base_covrsk(X, M, ctx, ow)
     assert np.max(np.abs(b64 - ref)) < 1e-12
     assert np.array_equal(np.argmax(b64, -1), np.argmax(ref, -1))
+
+
+# ---------------------------------------------------------------- CNN smoother ("large" mode) -------------------
+def test_cnn_smoother_golden_G11(ga, oracle):
+    g = load_golden("G11_cnn.npz")
+    A, S, W = int(g["A"]), int(g["S"]), int(g["W"])
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=S, context=5, smooth_kind="cnn", cnn_weight=g["weight"], cnn_bias=g["bias"])
+    proba, labels = ga.DeviceModel(d).smooth_predict(g["B"])
+    assert proba.dtype == np.float32
+    assert np.max(np.abs(proba - g["proba"])) < 1e-5       # vs the REFERENCE's output
+    assert np.array_equal(labels, g["labels"])
+
+
+@pytest.mark.parametrize("N,W,A,S", [(5, 163, 7, 75), (33, 370, 7, 75), (9, 150, 12, 31), (1, 64, 2, 5), (70, 130, 20, 41), (3, 200, 32, 75)])
+def test_cnn_smoother_vs_oracle(ga, oracle, N, W, A, S):
+    rng = np.random.RandomState(N * W + A)
+    B = rng.dirichlet(np.ones(A) * 0.4, size=(N, W))
+    wgt = (rng.standard_normal((A, A, S)) * 0.3).astype(np.float32)
+    bias = (rng.standard_normal(A) * 0.2).astype(np.float32)
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=S, context=5, smooth_kind="cnn", cnn_weight=wgt, cnn_bias=bias)
+    dev = ga.DeviceModel(d)
+    p_ref, l_ref = oracle.smooth_cnn(B, wgt, bias)
+    for Bin in (B, B.astype(np.float32)):
+        proba, labels = dev.smooth_predict(Bin)
+        assert np.max(np.abs(proba - p_ref)) < 1e-5
+        close = np.sort(p_ref, -1)[..., -1] - np.sort(p_ref, -1)[..., -2] < 1e-5     # ties within the tolerance may flip
+        assert np.array_equal(labels[~close], l_ref[~close])
+    p64, _ = dev.smooth_predict(B, proba_dtype=np.float64)
+    assert np.array_equal(p64, dev.smooth_predict(B)[0].astype(np.float64))
+
+
+def test_cnn_end_to_end(ga, oracle):
+    """"large" mode shape: logistic base -> CNN smoother in one gnx_infer call"""
+    from gnomix_amd import synth
+    C, M, A, S, N = 9037, 100, 5, 31, 40
+    d = synth.synthetic_model(C=C, M=M, A=A, S=S, seed=3, smooth=None)
+    rng = np.random.RandomState(1)
+    d.smooth_kind = "cnn"
+    d.cnn_weight = (rng.standard_normal((A, A, S)) * 0.3).astype(np.float32)
+    d.cnn_bias = (rng.standard_normal(A) * 0.2).astype(np.float32)
+    X = synth.synthetic_X(N, C, seed=5, miss=0.02)
+    p, lab = ga.DeviceModel(d).infer(X)
+    Bo = oracle.base_lr(X, M, d.context, d.lr_coef, d.lr_intercept)
+    po, lo = oracle.smooth_cnn(Bo, d.cnn_weight, d.cnn_bias)
+    assert np.max(np.abs(p - po)) < 1e-5
+    assert np.mean(lab != lo) < 1e-3

@@ -197,3 +197,12 @@ def test_poly_string_kernel_golden_G10(oracle):
     B = oracle.base_covrsk(X, M, ctx, ow)
     assert np.max(np.abs(B - g["B"])) < 1e-12
     assert np.array_equal(np.argmax(B, -1), np.argmax(g["B"], -1))
+
+
+def test_cnn_smoother_golden_G11(oracle):
+    """CNN smoother restatement against the reference's CNN.predict_proba / predict (torch conv1d + softmax)"""
+    g = load_golden("G11_cnn.npz")
+    proba, labels = oracle.smooth_cnn(g["B"], g["weight"], g["bias"])
+    assert proba.dtype == np.float32 and proba.shape == g["proba"].shape
+    assert np.max(np.abs(proba - g["proba"])) < 1e-5      # the backend's tap order is not defined: a few float32 ulps
+    assert np.array_equal(labels, g["labels"])

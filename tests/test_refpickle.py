@@ -170,3 +170,46 @@ def test_model_pkl_without_reference_packages(oracle, tmp_path):
                 got, want = got[T["left"] != -1], want[T["left"] != -1]
             assert np.array_equal(got, want), k
         assert d.population_order == ["P0", "P1", "P2"] and len(d.snp_pos) == C
+
+
+def test_cnn_smoother_pickle_roundtrip(tmp_path):
+    """"large" mode: the pickled smoother holds a torch nn.Sequential(nn.Conv1d) — rebuilt by torch, converted to cnn_* arrays"""
+    torch = pytest.importorskip("torch")
+    from sklearn.linear_model import LogisticRegression
+    rng = np.random.RandomState(1)
+    C, M, A, S, ctx = 457, 50, 3, 5, 25
+    W, rem, M_ = C // M, C % M, M + 2 * ctx
+    mods = _fake_reference_modules()
+    cnn_mod = types.ModuleType("src.Smooth.cnn")
+    cnn_mod.CNN = type("CNN", (), {"__module__": "src.Smooth.cnn"})
+    mods["src.Smooth.cnn"] = cnn_mod
+    mods["src.Smooth.models"].CNN_Smoother = type("CNN_Smoother", (), {"__module__": "src.Smooth.models"})
+    sys.modules.update(mods)
+    try:
+        lrs = []
+        for i in range(W):
+            width = M_ + (rem if i == W - 1 else 0)
+            lrs.append(LogisticRegression(solver="liblinear").fit((rng.random_sample((40, width)) < 0.4).astype(np.int8), np.arange(40) % A))
+        base = mods["src.Base.models"].LogisticRegressionBase()
+        base.models = lrs
+        net = cnn_mod.CNN()
+        conv = torch.nn.Conv1d(A, A, S, padding=(S - 1) // 2)
+        conv.padding_mode = "reflection"   # what the reference's constructor asks for (and old torch stored)
+        net.smoothNet = torch.nn.Sequential(conv)
+        sm = mods["src.Smooth.models"].CNN_Smoother()
+        sm.model, sm.S, sm.calibrator = net, S, None
+        g = mods["src.model"].Gnomix()
+        g.C, g.M, g.A, g.W, g.context, g.base, g.smooth = C, M, A, W, ctx, base, sm
+        g.snp_pos = g.snp_ref = g.snp_alt = None
+        g.population_order, g.gen_map_df = None, None
+        path = tmp_path / "large.pkl"
+        with open(path, "wb") as f:
+            pickle.dump(g, f)
+    finally:
+        for k in mods:
+            sys.modules.pop(k, None)
+    d = convert.from_reference_model(refpickle.load_reference_pickle(str(path)))
+    assert d.smooth_kind == "cnn" and d.cnn_weight.shape == (A, A, S) and d.cnn_weight.dtype == np.float32
+    assert np.array_equal(d.cnn_weight, conv.weight.detach().numpy()) and np.array_equal(d.cnn_bias, conv.bias.detach().numpy())
+    desc, keep = d.to_desc()
+    assert desc.cnn_weight and desc.cnn_bias
