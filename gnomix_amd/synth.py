@@ -62,6 +62,10 @@ def synthetic_model(C, M, A, S=75, context=None, n_rounds=100, depth=4, seed=0, 
         m.smooth_kind = "xgb"
         for k, v in synthetic_trees(n_rounds, A, S * A, depth=depth, seed=seed + 1).items():
             setattr(m, k, v)
+    elif smooth == "cnn":
+        m.smooth_kind = "cnn"
+        m.cnn_weight = (rng.standard_normal((A, A, S)) * (1.0 / np.sqrt(A * S)) * 3.0).astype(np.float32)
+        m.cnn_bias = (rng.standard_normal(A) * 0.2).astype(np.float32)
     elif smooth == "crf":
         m.smooth_kind = "crf"
         m.crf_state = rng.standard_normal((A, A)) * 2.0 + 4.0 * np.eye(A)
