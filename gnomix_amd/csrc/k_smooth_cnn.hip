@@ -25,12 +25,13 @@ __global__ __launch_bounds__(256) void k_smooth_cnn(SmoothCNNLaunch L) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
   const int strip_w = WS + S - 1;
   const bool wl = L.w_in_lds != 0;                               // weights that do not fit the LDS stay in global memory
-  float* wgt = reinterpret_cast<float*>(lds);                   // [A_in][S][A_out]
-  float* strip = wgt + (wl ? (size_t)A * S * A : 0);             // [nwave][strip_w][A]
+  const int AP = (A + 3) & ~3;                                   // weight rows padded to whole float4s (one tap = AP/4 LDS reads)
+  float* wgt = reinterpret_cast<float*>(lds);                   // [A_in][S][AP]
+  float* strip = wgt + (wl ? (size_t)A * S * AP : 0);            // [nwave][strip_w][A]
   if (wl)
-    for (int e = tid; e < A * S * A; e += blockDim.x) {
-      const int ai = e / (S * A), r = e - ai * S * A, s = r / A, ao = r - s * A;
-      wgt[e] = L.weight[((size_t)ao * A + ai) * S + s];          // torch layout (out, in, k)
+    for (int e = tid; e < A * S * AP; e += blockDim.x) {
+      const int ai = e / (S * AP), r = e - ai * S * AP, s = r / AP, ao = r - s * AP;
+      wgt[e] = ao < A ? L.weight[((size_t)ao * A + ai) * S + s] : 0.f;  // torch layout (out, in, k)
     }
   const int64_t n = (int64_t)blockIdx.y * nwave + wave;
   const int w0 = blockIdx.x * WS;
@@ -55,10 +56,16 @@ __global__ __launch_bounds__(256) void k_smooth_cnn(SmoothCNNLaunch L) {
     for (int s = 0; s < S; ++s) {
       const float x = st[(size_t)(lane + s) * A + ai];
       if (wl) {
-        const float* wr = wgt + ((size_t)ai * S + s) * A;
+        const float4* wr = reinterpret_cast<const float4*>(wgt + ((size_t)ai * S + s) * AP);  // wave-uniform address
 #pragma unroll
-        for (int y = 0; y < AMAX; ++y)
-          if (y < A) acc[y] = fmaf(x, wr[y], acc[y]);
+        for (int q = 0; q < AMAX / 4; ++q)
+          if (4 * q < A) {
+            const float4 w4 = wr[q];
+            acc[4 * q + 0] = fmaf(x, w4.x, acc[4 * q + 0]);  // outputs past A accumulate zeros and are never read
+            acc[4 * q + 1] = fmaf(x, w4.y, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(x, w4.z, acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(x, w4.w, acc[4 * q + 3]);
+          }
       } else {
 #pragma unroll
         for (int y = 0; y < AMAX; ++y)
@@ -94,8 +101,9 @@ hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L0, hipStream_t s) {
   if (L0.N <= 0) return hipSuccess;
   SmoothCNNLaunch L = L0;
   int nwave = 4;
-  L.w_in_lds = ((size_t)L.A * L.S * L.A * sizeof(float) <= (size_t)96 * 1024) ? 1 : 0;
-  auto lds_of = [&](int nw) { return ((L.w_in_lds ? (size_t)L.A * L.S * L.A : 0) + (size_t)nw * (WS + L.S - 1) * L.A) * sizeof(float); };
+  const int AP = (L.A + 3) & ~3;
+  L.w_in_lds = ((size_t)L.A * L.S * AP * sizeof(float) <= (size_t)96 * 1024) ? 1 : 0;
+  auto lds_of = [&](int nw) { return ((L.w_in_lds ? (size_t)L.A * L.S * AP : 0) + (size_t)nw * (WS + L.S - 1) * L.A) * sizeof(float); };
   while (nwave > 1 && lds_of(nwave) > (size_t)128 * 1024) nwave >>= 1;
   const size_t lds = lds_of(nwave);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;

@@ -168,6 +168,24 @@ def crf_(N=10000):
     return res
 
 
+def modes(N=10000):
+    """chr22 geometry (config 2) under the reference's other modes: fast = LR + CRF, large = LR + CNN (model.py:50-72)"""
+    out = {}
+    for name, smooth in (("default (LR + xgb)", "xgb"), ("fast (LR + CRF)", "crf"), ("large (LR + CNN)", "cnn")):
+        data = synth.synthetic_model(seed=0, n_rounds=100, smooth=smooth, **synth.CHR22)
+        model = gnomix_amd.DeviceModel(data)
+        X = synth.synthetic_X_device(N, data.C, "cuda:0", seed=1)
+        model.ctx.profile_reset(); model.ctx.profile_enable(True)
+        dt = timed(lambda: model.infer_device(X), reps=5, warm=2)
+        model.ctx.profile_enable(False)
+        out[name] = {"haplotypes_per_s": N / dt, "ms": dt * 1e3, "kernels_ms": prof(model.ctx)}
+        model.close(); del X, model
+        torch.cuda.empty_cache()
+    res = {"config": "chr22, 10k haplotypes, the reference's modes", "modes": out}
+    print(json.dumps(res))
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c4", "c5a", "c5b", "c3"]
     out = {}
