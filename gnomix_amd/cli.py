@@ -31,7 +31,13 @@ def load_model(path_to_model, device=0, verbose=True):
     from .convert import from_reference_model
     from .refpickle import load_reference_pickle
     # restricted unpickling: the reference's `src` package and xgboost are NOT needed (and nothing of them is executed)
-    return HipGnomix(from_reference_model(load_reference_pickle(path_to_model)), device=device)
+    try:
+        ref_model = load_reference_pickle(path_to_model)
+    except Exception as e:   # e.g. estimators pickled by an incompatible scikit-learn: fall back to attribute bags
+        if verbose:
+            print("rebuilding scikit-learn objects failed (%s): reading their attributes only" % type(e).__name__)
+        ref_model = load_reference_pickle(path_to_model, use_sklearn=False)
+    return HipGnomix(from_reference_model(ref_model), device=device)
 
 
 def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False):

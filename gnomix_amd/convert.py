@@ -132,6 +132,21 @@ def forest_from_parts(parts, missing=2):
                 fb_base_score=float(base_score), fb_missing=int(missing))
 
 
+class _TreeView:
+    """sklearn.tree._tree.Tree, real or as the attribute bag a stubbed pickle carries (Tree.__getstate__: `nodes` is a
+    structured array with left_child / right_child / feature / threshold, `values` the (n_nodes, n_outputs, n_classes) array)"""
+
+    def __init__(self, t):
+        if hasattr(t, "children_left"):
+            self.children_left, self.children_right = np.asarray(t.children_left), np.asarray(t.children_right)
+            self.feature, self.threshold, self.value = np.asarray(t.feature), np.asarray(t.threshold), np.asarray(t.value)
+        else:
+            nodes = t.nodes
+            self.children_left, self.children_right = np.asarray(nodes["left_child"]), np.asarray(nodes["right_child"])
+            self.feature, self.threshold, self.value = np.asarray(nodes["feature"]), np.asarray(nodes["threshold"]), np.asarray(t.values)
+        self.node_count = len(self.children_left)
+
+
 def rforest_from_sklearn(models, n_class):
     """Per-window fitted sklearn RandomForestClassifier (RFBase, src/Base/models.py:54-66) -> the rf_* arrays.
     rf_value[node] is what DecisionTreeClassifier.predict_proba returns for a sample that ends in `node`: tree_.value's
@@ -139,14 +154,16 @@ def rforest_from_sklearn(models, n_class):
     import inspect
     from sklearn.tree import DecisionTreeClassifier
     normalise = "normalizer" in inspect.getsource(DecisionTreeClassifier.predict_proba)
+    # (a stubbed pickle of an older scikit-learn carries class COUNTS in tree_.value: rows that do not sum to 1 are
+    # normalised below exactly as that version's predict_proba did)
     wt0, off, L, R, F, T, V = [0], [0], [], [], [], [], []
     for i, m in enumerate(models):
         if list(m.classes_) != list(range(n_class)):
             raise ValueError(f"window {i}: classes_ != 0..A-1 (the vectorized reference path has no remap, base.py:176)")
         for e in m.estimators_:
-            t = e.tree_
+            t = _TreeView(e.tree_)
             proba = np.array(t.value[:, 0, :n_class], dtype=np.float64)
-            if normalise:
+            if normalise or not np.allclose(proba.sum(axis=1), 1.0, atol=1e-9):
                 normalizer = proba.sum(axis=1)[:, np.newaxis]
                 normalizer[normalizer == 0.0] = 1.0
                 proba /= normalizer

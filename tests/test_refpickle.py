@@ -213,3 +213,23 @@ def test_cnn_smoother_pickle_roundtrip(tmp_path):
     assert np.array_equal(d.cnn_weight, conv.weight.detach().numpy()) and np.array_equal(d.cnn_bias, conv.bias.detach().numpy())
     desc, keep = d.to_desc()
     assert desc.cnn_weight and desc.cnn_bias
+
+
+def test_random_forest_from_stubbed_pickle(oracle, tmp_path):
+    """use_sklearn=False: RandomForestClassifier / DecisionTreeClassifier / Tree become attribute bags (Tree state = `nodes`
+    structured array + `values`); the converter reads those and reproduces predict_proba through the oracle"""
+    from sklearn.ensemble import RandomForestClassifier
+    rng = np.random.RandomState(5)
+    A, width, n = 3, 40, 80
+    X = (rng.random_sample((n, width)) < 0.4).astype(np.int8)
+    y = np.arange(n) % A
+    rf = RandomForestClassifier(n_estimators=5, max_depth=3, n_jobs=1, random_state=0).fit(X, y)
+    p = tmp_path / "rf.pkl"
+    with open(p, "wb") as f:
+        pickle.dump([rf], f)
+    stub = refpickle.load_reference_pickle(str(p), use_sklearn=False)[0]
+    assert isinstance(stub, refpickle.Stub) and type(stub).__name__ == "RandomForestClassifier"
+    arrs = convert.rforest_from_sklearn([stub], A)
+    real = convert.rforest_from_sklearn([rf], A)
+    for k in real:
+        assert np.array_equal(arrs[k], real[k]), k
