@@ -141,8 +141,8 @@ def main():
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "note": "algorithmic bytes/launch = %d B/haplotype x %d haplotypes (SURVEY.md 8d). The tree pass is LDS-gather "
-                        "bound (%.3g node-steps/s), not HBM bound; the logistic pass streams X once and is the HBM-bound "
+                "note": "algorithmic bytes/launch = %d B/haplotype x %d haplotypes (SURVEY.md 8d). The tree pass is bound by the LDS pipe "
+                        "(%.3g node-steps/s; kernels.k_smooth_xgb.lds_pipe_busy_frac), not by HBM; the logistic pass streams X once and is the HBM-bound "
                         "kernel of the path: %.0f GB/s = %.1f%% of peak - see `kernels`" %
                         (dom_bytes, N, kernels["k_smooth_xgb"]["node_steps_per_s"] or 0,
                          kernels["k_base_logistic"]["alg_GBps"] or 0, 100 * (kernels["k_base_logistic"]["hbm_frac"] or 0))}
