@@ -5,15 +5,24 @@
 One "step" = one pass of the hot path (X int8 resident in HBM -> B -> proba f32 + labels) over the
 batch.  Haplotypes shard across ranks with no data-path collective (weak scaling: per-GPU batch fixed).
 
-  python bench.py [--gpus N --steps K --warmup W]           (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel,
-measured with hipEvents on the launch stream inside libgnomix_hip) and, at N=1, `cpu_baseline`
-(the oracle's C restatement timed on this box's host cores on a bounded sample).
+N > 1 without a torch.distributed environment: bench.py launches its own N ranks (re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`), one process per GPU,
+backend nccl (= RCCL); it refuses (non-zero exit, no JSON) when the box has fewer than N GPUs or when the
+WORLD_SIZE it finds differs from --gpus.  GNX_BENCH_FORCE_DIST=1 runs the N=1 case through the same
+process-group / RCCL code (what a 1-GPU box can exercise of it).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, measured
+with hipEvents on the launch stream inside libgnomix_hip), `e2e` (host pointers in, labels out, PCIe included —
+never `value`) and, at N=1, `cpu_baseline` (the oracle's C restatement timed on ALL of this box's host cores on a
+bounded sample, base and smoother timed separately).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +32,34 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 I8_MFMA_PEAK_TOPS = 3944.0 # MI355X_MICROARCH.md: int8 MFMA 16x16x64 measured ceiling (~2x bf16 dense)
 F64_MFMA_PEAK_TF = 78.6    # AMD public spec for MI355X FP64 matrix (only used when GNX_BASE_LR_IMPL=f64)
+N_CU, CLK_GHZ = 256, 2.4   # MI355X_MICROARCH.md: 256 CUs, 2.4 GHz peak engine clock
+# LDS pipe: 128 B/clk/CU (MI355X_MICROARCH.md) = 32 four-byte lanes per clock.  A tree node-step needs at least ONE
+# data-dependent LDS gather per lane (the feature the node asks for), so the LDS-bound ceiling of the tree pass is
+# 256 CU x 2.4 GHz x 32 lanes = 1.966e13 node-steps/s.
+LDS_PEAK_NODE_STEPS = N_CU * CLK_GHZ * 1e9 * 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_launch(args):
+    """--gpus N > 1 outside torchrun: spawn the N ranks ourselves (one process per GPU over RCCL)."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but this box exposes %d GPU(s): refusing to run (a smaller world would "
+                         "silently report a different experiment)\n" % (args.gpus, have))
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -31,32 +68,49 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--haps", type=int, default=10000, help="haplotypes per GPU per step")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=32, help="host threads of the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline core-seconds budget scale (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
+    ap.add_argument("--e2e-steps", type=int, default=3, help="host-pointer (PCIe-inclusive) passes at N=1 (0 = skip)")
     ap.add_argument("--seed", type=int, default=94305)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    in_dist_env = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not in_dist_env and args.gpus > 1:
+        sys.exit(_self_launch(args))
+    rank = int(os.environ.get("RANK", "0")) if in_dist_env else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_dist_env else 1
+    local = int(os.environ.get("LOCAL_RANK", "0")) if in_dist_env else 0
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to run" % (args.gpus, world))
 
     import numpy as np
     import torch
     import gnomix_amd
     from gnomix_amd import synth, _lib
+    from gnomix_amd.dist import infer_sharded
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU %d" % (rank, local))
     dist = None
+    backend = None
     if world > 1 or os.environ.get("GNX_BENCH_FORCE_DIST"):  # the env knob lets a 1-GPU box exercise the RCCL code path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        backend = dist.get_backend()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     cfg = dict(synth.CHR22)
     data = synth.synthetic_model(seed=0, n_rounds=100, **cfg)
-    model = gnomix_amd.DeviceModel(data, device=local)
+    model = gnomix_amd.DeviceModel(data, ctx=_lib.Context(local))   # one gnx_ctx per process, bound to this rank's GPU
     ctx = model.ctx
     N = args.haps
     X = synth.synthetic_X_device(N, data.C, dev, seed=args.seed + rank)   # resident in HBM before timing
@@ -86,12 +140,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # gather-only epilogue OUTSIDE the timed region: every rank's label checksum reaches rank 0
-    lab_sum = out[1].to(torch.int64).sum().reshape(1)
+    # gather-only epilogue OUTSIDE the timed region: the product's own gather (gnomix_amd.dist, dst = rank 0) moves every
+    # rank's labels of the last step to rank 0, which checksums them
+    lab_sum = None
     if dist is not None:
-        sums = [torch.zeros_like(lab_sum) for _ in range(world)]
-        dist.all_gather(sums, lab_sum)
-        lab_sum = torch.stack(sums).sum().reshape(1)
+        # infer_sharded slices rows [lo, hi) of a "full" matrix; here every rank already holds its own shard, so the
+        # shard function ignores the slice and returns this rank's outputs of the last step
+        class _Rows:
+            shape = (N * world, data.C)
+
+            def __getitem__(self, sl):
+                return X
+
+        (lab_all,) = infer_sharded(lambda xs: (out[1],), _Rows(), dst=0)
+        if rank == 0:
+            assert lab_all.shape == (N * world, model.W)
+            lab_sum = int(lab_all.to(torch.int64).sum().item())
+    else:
+        lab_sum = int(out[1].to(torch.int64).sum().item())
 
     W, A, C = model.W, model.A, model.C
     ms_base, n_base = ctx.profile_get(_lib.K_BASE_LOGISTIC)
@@ -115,37 +181,35 @@ def main():
                                           flops_base * N / avg_base / 1e12 / F64_MFMA_PEAK_TF) if avg_base else None},
         "k_smooth_xgb": {"avg_ms": avg_sm * 1e3, "launches": n_sm, "alg_GBps": bytes_sm * N / avg_sm / 1e9 if avg_sm else None,
                          "hbm_frac": bytes_sm * N / avg_sm / 1e9 / HBM_PEAK_GBS if avg_sm else None,
-                         "node_steps_per_s": node_steps * N / avg_sm if avg_sm else None},
+                         "node_steps_per_s": node_steps * N / avg_sm if avg_sm else None,
+                         "lds_frac": node_steps * N / avg_sm / LDS_PEAK_NODE_STEPS if avg_sm else None},
     }
-    # LDS-pipe occupancy of the tree pass from the committed counter pass (profiles/*_pmc.json: SQ_LDS_IDX_ACTIVE summed over
-    # the 256 CUs / (256 x launch duration x 2.4 GHz)); informational, the live numbers are the event timings above
+    # counters are NOT collected in this run (rocprofv3 --pmc needs its own passes: scripts/collect_profiles.sh);
+    # what is printed under "counters" is the committed summary of the same command, named, never mixed with live times
+    counters = {}
     try:
-        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
-        pm = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
-        for k, v in pm.items():
-            if "k_smooth_xgb" in k and "SQ_LDS_IDX_ACTIVE" in v and avg_sm:
-                kernels["k_smooth_xgb"]["lds_pipe_busy_frac"] = v["SQ_LDS_IDX_ACTIVE"]["avg_per_launch"] / (256 * avg_sm * 2.4e9)
-                kernels["k_smooth_xgb"]["lds_pipe_source"] = pmcs[-1]
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):
+            counters = json.load(open(tp))
     except Exception:
-        pass
+        counters = {}
     dom = "k_smooth_xgb" if avg_sm >= avg_base else "k_base_logistic"
-    dom_bytes = bytes_sm if dom == "k_smooth_xgb" else bytes_base
-    dom_avg = avg_sm if dom == "k_smooth_xgb" else avg_base
-    achieved = dom_bytes * N / dom_avg / 1e9 if dom_avg else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom)
-        except Exception:
-            traffic = None
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "note": "algorithmic bytes/launch = %d B/haplotype x %d haplotypes (SURVEY.md 8d). The tree pass is bound by the LDS pipe "
-                        "(%.3g node-steps/s; kernels.k_smooth_xgb.lds_pipe_busy_frac), not by HBM; the logistic pass streams X once and is the HBM-bound "
-                        "kernel of the path: %.0f GB/s = %.1f%% of peak - see `kernels`" %
-                        (dom_bytes, N, kernels["k_smooth_xgb"]["node_steps_per_s"] or 0,
-                         kernels["k_base_logistic"]["alg_GBps"] or 0, 100 * (kernels["k_base_logistic"]["hbm_frac"] or 0))}
+    traffic = counters.get(dom) if isinstance(counters.get(dom), (int, float)) else None
+    if dom == "k_smooth_xgb":
+        ach = kernels[dom]["node_steps_per_s"] or 0.0
+        roofline = {"kernel": dom, "bound": "lds", "achieved": ach / 1e9, "peak": LDS_PEAK_NODE_STEPS / 1e9, "unit": "Gnode-steps/s",
+                    "frac": ach / LDS_PEAK_NODE_STEPS, "traffic": traffic,
+                    "hbm_view": {"achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["hbm_frac"]},
+                    "note": "the tree pass moves %d B/haplotype (SURVEY.md 8d) but does %d node-steps/haplotype: it is bound by the LDS "
+                            "gather pipe, not by HBM (hbm_view is the HBM reading of the same launch).  peak = 256 CU x 2.4 GHz x 32 LDS "
+                            "lanes/clk with one data-dependent gather per node-step.  The HBM-bound kernel of the path is the logistic "
+                            "pass: %.0f GB/s algorithmic = %.1f%% of the 8 TB/s peak (kernels.k_base_logistic)" %
+                            (bytes_sm, node_steps, kernels["k_base_logistic"]["alg_GBps"] or 0, 100 * (kernels["k_base_logistic"]["hbm_frac"] or 0))}
+    else:
+        ach = kernels[dom]["alg_GBps"] or 0.0
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic,
+                    "note": "algorithmic bytes/launch = %d B/haplotype x %d haplotypes (SURVEY.md 8d)" % (bytes_base, N)}
 
     hps = world * N * args.steps / dt
     res = {
@@ -156,45 +220,103 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: chr22-like C=370500 M=1000 ctx=500 W=370 A=7 S=75, logistic base + xgb smoother "
                                "(100 rounds x 7 trees, depth<=4), %d synthetic haplotypes per GPU resident in HBM" % N,
-                   "haplotypes_per_gpu": N, "sharding": "haplotypes across ranks, no data-path collective"},
+                   "haplotypes_per_gpu": N, "sharding": "haplotypes across ranks, no data-path collective",
+                   "dist_backend": backend},
         "windows_per_s": hps * W,
-        "roofline": roofline, "kernels": kernels, "label_checksum": int(lab_sum.item()),
+        "roofline": roofline, "kernels": kernels, "label_checksum": lab_sum,
     }
+    if counters:
+        res["counters"] = {"source": counters.get("source", "profiles/traffic_latest.json"), "hbm_bytes_per_launch": {
+            k: v for k, v in counters.items() if isinstance(v, (int, float))}}
+
+    # ---- PCIe-inclusive rate: host pointers in, labels + probabilities out (never `value`) ----------------------------
+    if rank == 0 and world == 1 and args.e2e_steps > 0:
+        try:
+            res["e2e"] = _e2e(model, X, args.e2e_steps, out)
+        except Exception as e:  # the headline line must still print
+            res["e2e"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        from oracle import gnx_oracle as O
-        O.build()
-        T = O.Trees(data.tree_off, data.left, data.right, data.feat, data.cond, data.tree_class, data.A, data.base_score)
-        Xh = X[:16384].cpu().numpy()
-
-        def cpu_pass(xs):
-            B = O.base_lr(xs, data.M, data.context, data.lr_coef, data.lr_intercept)
-            return O.smooth_xgb(T, B, data.S)
-
-        # the port is scalar C; haplotypes are independent, so the host's cores are used by running disjoint slices of the
-        # sample through it from a thread pool (ctypes releases the GIL during the call; every call owns its scratch)
-        from concurrent.futures import ThreadPoolExecutor
-        c0 = time.perf_counter()
-        cpu_pass(Xh[:4])
-        per = (time.perf_counter() - c0) / 4                     # seconds per haplotype on one core
-        cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        n_s = int(max(4 * cores, min(Xh.shape[0], cores * args.cpu_seconds / max(per, 1e-6))))
-        n_s -= n_s % cores
-        chunk = n_s // cores
-        c0 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=cores) as pool:
-            parts = list(pool.map(lambda i: cpu_pass(Xh[i * chunk:(i + 1) * chunk]), range(cores)))
-        cdt = time.perf_counter() - c0
-        l_ref = np.concatenate([p[1] for p in parts])
-        same = bool((out[1][:n_s].cpu().numpy() == l_ref).all())
-        res["cpu_baseline"] = {"value": n_s / cdt, "unit": "haplotypes/s", "cores": cores, "kind": "port",
-                               "sample": "%d haplotypes of the same workload through oracle/gnx_oracle.c (scalar C), %d threads x %d "
-                                         "haplotypes, %.1f s wall; one core alone: %.1f haplotypes/s; host has %d cores; labels identical "
-                                         "to GPU on the sample: %s" % (n_s, cores, chunk, cdt, 1.0 / per, os.cpu_count(), same)}
+        res["cpu_baseline"] = _cpu_baseline(args, data, X, out)
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _e2e(model, X, steps, out_dev):
+    """X in page-locked host memory -> gnx_infer* (H2D, kernels, D2H of labels + probabilities) -> host arrays"""
+    import numpy as np
+    import torch
+    ctx = model.ctx
+    N, C = X.shape
+    Xh = ctx.pinned_empty((N, C), np.int8)
+    torch.from_numpy(Xh).copy_(X.cpu())
+    res = {}
+    p, lab = model.infer(Xh)     # warm-up (workspaces, first touch of the outputs)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p, lab = model.infer(Xh)
+    dt = (time.perf_counter() - t0) / steps
+    same = bool((torch.from_numpy(lab) == out_dev[1].cpu()).all())
+    res["int8"] = {"haplotypes_per_s": N / dt, "ms": dt * 1e3, "x_GBps": N * C / dt / 1e9, "labels_equal_device_path": same}
+    if hasattr(model, "infer_packed"):
+        Xp = model.pack_x(Xh)
+        p2, lab2 = model.infer_packed(Xp, N)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p2, lab2 = model.infer_packed(Xp, N)
+        dt2 = (time.perf_counter() - t0) / steps
+        res["packed2bit"] = {"haplotypes_per_s": N / dt2, "ms": dt2 * 1e3, "x_GBps": Xp.nbytes / dt2 / 1e9,
+                             "bit_identical_to_int8_path": bool(np.array_equal(lab2, lab) and np.array_equal(p2, p))}
+    res["e2e_haplotypes_per_s"] = max(v["haplotypes_per_s"] for v in res.values() if isinstance(v, dict))
+    res["note"] = "host pointers in (page-locked), probabilities f32 + labels i32 out, PCIe both ways included; never `value`"
+    return res
+
+
+def _cpu_baseline(args, data, X, out_dev):
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import gnx_oracle as O
+    O.build()
+    T = O.Trees(data.tree_off, data.left, data.right, data.feat, data.cond, data.tree_class, data.A, data.base_score)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, args.cpu_threads or avail)
+    Xh = X.cpu().numpy()
+    # one core alone first (also sizes the sample): the port is scalar C, haplotypes are independent, so every core runs
+    # a disjoint slice through it from a thread pool (ctypes releases the GIL; every call owns its scratch)
+    c0 = time.perf_counter()
+    B4 = O.base_lr(Xh[:4], data.M, data.context, data.lr_coef, data.lr_intercept)
+    c1 = time.perf_counter()
+    O.smooth_xgb(T, B4, data.S)
+    c2 = time.perf_counter()
+    per = (c2 - c0) / 4
+    # bounded sample: ~cpu_seconds of wall time per core at most, never more than the batch
+    n_s = int(min(Xh.shape[0], max(2 * cores, cores * args.cpu_seconds / max(per, 1e-6))))
+    n_s -= n_s % cores
+    chunk = n_s // cores
+    sl = [slice(i * chunk, (i + 1) * chunk) for i in range(cores)]
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        c0 = time.perf_counter()
+        Bs = list(pool.map(lambda s: O.base_lr(Xh[s], data.M, data.context, data.lr_coef, data.lr_intercept), sl))
+        c1 = time.perf_counter()
+        parts = list(pool.map(lambda b: O.smooth_xgb(T, b, data.S), Bs))
+        c2 = time.perf_counter()
+    l_ref = np.concatenate([p[1] for p in parts])
+    same = bool((out_dev[1][:n_s].cpu().numpy() == l_ref).all())
+    t_base, t_sm = c1 - c0, c2 - c1
+    return {"value": n_s / (t_base + t_sm), "unit": "haplotypes/s", "cores": cores, "kind": "port",
+            "base_lr_haplotypes_per_s": n_s / t_base, "smooth_xgb_haplotypes_per_s": n_s / t_sm,
+            "one_core_haplotypes_per_s": 1.0 / per,
+            "sample": "%d haplotypes of the same workload through oracle/gnx_oracle.c — the SCALAR C port of the reference's "
+                      "algorithm, not the reference — on %d threads x %d haplotypes (host reports %d cores, %d usable): logistic "
+                      "base %.2f s, tree smoother %.2f s wall; labels identical to the GPU's on the sample: %s.  Context "
+                      "(BASELINE.md 2, the reference itself, 8 cores of the survey container): base 815 haplotypes/s, "
+                      "slide_window 225 haplotypes/s (xgboost itself absent there)" %
+                      (n_s, cores, chunk, os.cpu_count() or 0, avail, t_base, t_sm, same)}
 
 
 if __name__ == "__main__":

@@ -47,7 +47,7 @@ class ModelDesc(C.Structure):
                 ("S", C.c_int32), ("base_kind", C.c_int32), ("smooth_kind", C.c_int32), ("reserved0", C.c_int32),
                 ("lr_coef", C.c_void_p), ("lr_ldc", C.c_int64), ("lr_intercept", C.c_void_p),
                 ("svc", C.c_void_p),
-                ("n_trees", C.c_int32), ("reserved1", C.c_int32), ("tree_off", C.c_void_p), ("left", C.c_void_p),
+                ("n_trees", C.c_int32), ("n_nodes", C.c_int32), ("tree_off", C.c_void_p), ("left", C.c_void_p),
                 ("right", C.c_void_p), ("feat", C.c_void_p), ("cond", C.c_void_p), ("tree_class", C.c_void_p),
                 ("base_score", C.c_float), ("reserved2", C.c_int32),
                 ("crf_state", C.c_void_p), ("crf_trans", C.c_void_p),
@@ -56,8 +56,8 @@ class ModelDesc(C.Structure):
                 ("fb_n_trees", C.c_int32), ("fb_missing", C.c_int32), ("fb_win_tree0", C.c_void_p),
                 ("fb_tree_off", C.c_void_p), ("fb_left", C.c_void_p), ("fb_right", C.c_void_p), ("fb_feat", C.c_void_p),
                 ("fb_cond", C.c_void_p), ("fb_default_left", C.c_void_p), ("fb_tree_class", C.c_void_p),
-                ("fb_base_score", C.c_float), ("reserved4", C.c_int32),
-                ("rf_n_trees", C.c_int32), ("reserved5", C.c_int32), ("rf_win_tree0", C.c_void_p), ("rf_tree_off", C.c_void_p),
+                ("fb_base_score", C.c_float), ("fb_n_nodes", C.c_int32),
+                ("rf_n_trees", C.c_int32), ("rf_n_nodes", C.c_int32), ("rf_win_tree0", C.c_void_p), ("rf_tree_off", C.c_void_p),
                 ("rf_left", C.c_void_p), ("rf_right", C.c_void_p), ("rf_feat", C.c_void_p), ("rf_thr", C.c_void_p),
                 ("rf_value", C.c_void_p), ("cnn_weight", C.c_void_p), ("cnn_bias", C.c_void_p)]
 

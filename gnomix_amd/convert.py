@@ -94,18 +94,28 @@ def trees_from_xgb_json(dumps, n_class, base_score=0.5):
 
 
 def xgb_trees_of(xgb_obj, n_class):
-    """xgboost-schema arrays of a fitted XGBClassifier: through the real booster's JSON dump when xgboost is importable and
-    the object is real, else from the raw booster bytes a stubbed pickle carries (gnomix_amd.refpickle.parse_xgb_raw)."""
+    """xgboost-schema arrays of a fitted XGBClassifier.  Always through the booster's own serialised model
+    (gnomix_amd.refpickle.parse_xgb_raw): the raw bytes a stubbed pickle carries, or `Booster.save_raw()` of a real
+    object — so trees-per-round, tree_info (the class of every tree) and base_score come from the booster itself and are
+    never guessed from A (an A == 2 smoother trained as multi:softprob num_class=2, src/Smooth/models.py:14-20, has two
+    trees per round; XGBBase with A == 2 is binary:logistic with one)."""
     from .refpickle import booster_bytes, parse_xgb_raw
     raw = booster_bytes(xgb_obj)
-    if raw is not None:
-        t = parse_xgb_raw(raw)
-        per_round = 1 if n_class == 2 and t["n_class"] <= 1 else n_class
-        if len(t["tree_class"]) != len(t["tree_off"]) - 1 or (len(t["tree_class"]) and t["tree_class"].max() >= max(per_round, 1)):
-            raise ValueError("xgboost model: tree_info does not match the number of classes")
-        return {k: t[k] for k in ("tree_off", "left", "right", "feat", "cond", "tree_class", "base_score", "default_left")}
-    booster = xgb_obj.get_booster()
-    return trees_from_xgb_json(booster.get_dump(dump_format="json"), 1 if n_class == 2 else n_class)
+    if raw is None:
+        booster = xgb_obj.get_booster()
+        try:
+            raw = booster.save_raw(raw_format="json")   # xgboost >= 1.6
+        except TypeError:
+            raw = booster.save_raw()                     # xgboost 1.1.1: legacy binary
+    t = parse_xgb_raw(bytes(raw))
+    n_out = max(int(t["n_class"]), 1)
+    if n_out > 1 and n_out != n_class:
+        raise ValueError(f"xgboost model: num_class={n_out} but the Gnomix model has A={n_class}")
+    if n_out == 1 and n_class != 2:
+        raise ValueError("xgboost model: single-output booster for a model with more than 2 ancestries")
+    if len(t["tree_class"]) != len(t["tree_off"]) - 1 or (len(t["tree_class"]) and t["tree_class"].max() >= n_out):
+        raise ValueError("xgboost model: tree_info does not match the number of classes")
+    return {k: t[k] for k in ("tree_off", "left", "right", "feat", "cond", "tree_class", "base_score", "default_left")}
 
 
 def forest_from_xgb_json(window_dumps, n_class, base_score=0.5, missing=2):
@@ -187,6 +197,24 @@ def calibrator_arrays(iso_models):
                 calib_is_f32=bool(np.asarray(iso_models[0].X_thresholds_).dtype == np.float32))
 
 
+def lr_rows_from_sklearn(coef_, intercept_, n_class):
+    """coef_ / intercept_ of one fitted LogisticRegression(solver="liblinear") -> the (A, width) / (A,) rows of the
+    one-vs-rest form the kernel evaluates, P_a = expit(z_a) / sum_b expit(z_b).
+    A >= 3: sklearn's `_predict_proba_lr` is exactly that form, the arrays pass through.
+    A == 2: sklearn keeps ONE row (coef_ (1, n), intercept_ (1,)) and returns [1 - expit(z), expit(z)]; since
+    1 - expit(z) = expit(-z) and expit(-z) + expit(z) = 1 the same probabilities are the OvR form of the two rows
+    (-coef_, +coef_) / (-b, +b) — copying the single row into both classes would give 0.5 / 0.5 everywhere."""
+    coef = np.asarray(coef_, dtype=np.float64)
+    icpt = np.asarray(intercept_, dtype=np.float64).reshape(-1)
+    if coef.ndim != 2:
+        raise ValueError("coef_ must be 2-D")
+    if n_class == 2 and coef.shape[0] == 1:
+        return np.concatenate([-coef, coef], axis=0), np.array([-icpt[0], icpt[0]])
+    if coef.shape[0] != n_class or icpt.shape[0] != n_class:
+        raise ValueError(f"coef_ has {coef.shape[0]} rows for {n_class} classes")
+    return coef, icpt
+
+
 def from_reference_model(model) -> GnxModelData:
     """An unpickled reference `src.model.Gnomix` -> GnxModelData."""
     C, M, A = int(model.C), int(model.M), int(model.A)
@@ -202,8 +230,9 @@ def from_reference_model(model) -> GnxModelData:
         for i, m in enumerate(models):
             if list(m.classes_) != list(range(A)):
                 raise ValueError(f"window {i}: classes_ != 0..A-1 (the vectorized reference path has no remap, base.py:176)")
-            d.lr_coef[i, :, :m.coef_.shape[1]] = m.coef_
-            d.lr_intercept[i] = m.intercept_
+            coef, icpt = lr_rows_from_sklearn(m.coef_, m.intercept_, A)
+            d.lr_coef[i, :, :coef.shape[1]] = coef
+            d.lr_intercept[i] = icpt
     elif first == "SVC":
         d.base_kind = "covrsk"
         kname = getattr(getattr(model.base, "kernel", None), "__name__", "CovRSK")

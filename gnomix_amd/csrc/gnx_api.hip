@@ -7,6 +7,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <utility>
 
 #include "gnx_internal.h"
 
@@ -257,13 +258,34 @@ static int build_lr(gnx_model* m, const gnx_model_desc* d) {
 // ------------------------------------------------------------------------------------------------
 // model preparation: xgboost-schema trees -> class-major complete heaps
 // ------------------------------------------------------------------------------------------------
-static int tree_depth(const gnx_model_desc* d, int32_t o, int32_t nid, int32_t n_nodes, int guard) {
-  if (guard > 64 || nid < 0 || nid >= n_nodes) return -1000;
-  if (d->left[o + nid] == -1) return 0;
-  const int l = tree_depth(d, o, d->left[o + nid], n_nodes, guard + 1);
-  const int r = tree_depth(d, o, d->right[o + nid], n_nodes, guard + 1);
-  if (l < 0 || r < 0) return -1000;
-  return 1 + std::max(l, r);
+// Depth of one tree given as child arrays (-1 at leaves), or -1 when it is not a tree: child index out of range, a node
+// reachable twice (cycle / shared subtree: the visit count is bounded by the node count, so a malformed input costs
+// O(n_nodes), not 2^depth) or deeper than 64.  Iterative: nothing here recurses on caller-supplied data.
+static int checked_tree_depth(const int32_t* left, const int32_t* right, int32_t n_nodes) {
+  if (n_nodes <= 0) return -1;
+  std::vector<uint8_t> seen((size_t)n_nodes, 0);
+  std::vector<std::pair<int32_t, int32_t>> stack{{0, 0}};
+  int depth = 0;
+  while (!stack.empty()) {
+    const auto [nid, dep] = stack.back();
+    stack.pop_back();
+    if (nid < 0 || nid >= n_nodes || seen[(size_t)nid] || dep > 64) return -1;
+    seen[(size_t)nid] = 1;
+    depth = std::max(depth, dep);
+    const int32_t l = left[nid], r = right[nid];
+    if (l == -1) continue;  // leaf (xgboost / sklearn mark leaves by left == -1)
+    stack.push_back({l, dep + 1});
+    stack.push_back({r, dep + 1});
+  }
+  return depth;
+}
+
+// node offsets of concatenated trees: start at 0, strictly increasing, end at the caller's node count when given
+static bool checked_tree_offsets(const int32_t* off, int32_t n_trees, int32_t n_nodes) {
+  if (!off || off[0] != 0) return false;
+  for (int32_t t = 0; t < n_trees; ++t)
+    if (off[t + 1] <= off[t]) return false;
+  return n_nodes <= 0 || off[n_trees] == n_nodes;
 }
 
 // subtree rooted at xgboost node `nid` (or a replicated early leaf) -> heap slot j of the packed layout
@@ -397,12 +419,13 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
   const int64_t W = d->C / d->M;
   if (W < 2 * (int64_t)S)  // src/Smooth/models.py:13
     return fail(ctx, GNX_EINVAL, "Smoother size to large for given window size. ");
+  if (!checked_tree_offsets(d->tree_off, d->n_trees, d->n_nodes))
+    return fail(ctx, GNX_EINVAL, "xgb smoother: tree_off must start at 0, increase strictly and end at n_nodes");
   int D = 1;
   for (int t = 0; t < d->n_trees; ++t) {
     const int32_t o = d->tree_off[t], nn = d->tree_off[t + 1] - o;
-    if (nn <= 0) return fail(ctx, GNX_EINVAL, "xgb smoother: empty tree");
-    const int dep = tree_depth(d, o, 0, nn, 0);
-    if (dep < 0) return fail(ctx, GNX_EINVAL, "xgb smoother: malformed tree (child index out of range or depth > 64)");
+    const int dep = checked_tree_depth(d->left + o, d->right + o, nn);
+    if (dep < 0) return fail(ctx, GNX_EINVAL, "xgb smoother: malformed tree (child index out of range, node reachable twice or depth > 64)");
     D = std::max(D, dep);
     if (d->tree_class[t] < 0 || d->tree_class[t] >= A) return fail(ctx, GNX_EINVAL, "xgb smoother: tree_class out of range");
     for (int32_t k = 0; k < nn; ++k)
@@ -452,15 +475,6 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
 // ------------------------------------------------------------------------------------------------
 // model preparation: forest base — per-window xgboost-schema trees -> per-window class-major complete heaps
 // ------------------------------------------------------------------------------------------------
-static int forest_depth(const gnx_model_desc* d, int32_t o, int32_t nid, int32_t n_nodes, int guard) {
-  if (guard > 64 || nid < 0 || nid >= n_nodes) return -1000;
-  if (d->fb_left[o + nid] == -1) return 0;
-  const int l = forest_depth(d, o, d->fb_left[o + nid], n_nodes, guard + 1);
-  const int r = forest_depth(d, o, d->fb_right[o + nid], n_nodes, guard + 1);
-  if (l < 0 || r < 0) return -1000;
-  return 1 + std::max(l, r);
-}
-
 // Forest trees use their own compact heap: 2^D node words (slot 0 unused) followed by 2^D float leaves.  A node word is
 // (SNP index within the window << 4) | left-mask, bit v of the mask = "a SNP of value v goes left": SNPs only take
 // the values 0..3, so `float(v) < threshold` and the missing code's default direction fold into 4 bits at load time.
@@ -499,17 +513,19 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
     return fail(ctx, GNX_EINVAL, "forest base: binary:logistic needs base_score in (0, 1)");
   if (d->fb_win_tree0[0] != 0 || d->fb_win_tree0[W] != d->fb_n_trees)
     return fail(ctx, GNX_EINVAL, "forest base: fb_win_tree0 must run from 0 to fb_n_trees");
+  for (int64_t w = 0; w < W; ++w)
+    if (d->fb_win_tree0[w + 1] < d->fb_win_tree0[w]) return fail(ctx, GNX_EINVAL, "forest base: fb_win_tree0 not monotone");
+  if (!checked_tree_offsets(d->fb_tree_off, d->fb_n_trees, d->fb_n_nodes))
+    return fail(ctx, GNX_EINVAL, "forest base: fb_tree_off must start at 0, increase strictly and end at fb_n_nodes");
   int D = 1, max_trees = 0;
   for (int64_t w = 0; w < W; ++w) {
     const int32_t t0 = d->fb_win_tree0[w], t1 = d->fb_win_tree0[w + 1];
-    if (t1 < t0) return fail(ctx, GNX_EINVAL, "forest base: fb_win_tree0 not monotone");
     max_trees = std::max(max_trees, t1 - t0);
     const int64_t width = (w == W - 1) ? M_ + rem : M_;
     for (int32_t t = t0; t < t1; ++t) {
       const int32_t o = d->fb_tree_off[t], nn = d->fb_tree_off[t + 1] - o;
-      if (nn <= 0) return fail(ctx, GNX_EINVAL, "forest base: empty tree");
-      const int dep = forest_depth(d, o, 0, nn, 0);
-      if (dep < 0) return fail(ctx, GNX_EINVAL, "forest base: malformed tree (child index out of range or depth > 64)");
+      const int dep = checked_tree_depth(d->fb_left + o, d->fb_right + o, nn);
+      if (dep < 0) return fail(ctx, GNX_EINVAL, "forest base: malformed tree (child index out of range, node reachable twice or depth > 64)");
       D = std::max(D, dep);
       if (A > 2 && (d->fb_tree_class[t] < 0 || d->fb_tree_class[t] >= A))
         return fail(ctx, GNX_EINVAL, "forest base: fb_tree_class out of range");
@@ -555,15 +571,6 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
 // ------------------------------------------------------------------------------------------------
 // model preparation: random-forest base — sklearn tree arrays -> mask-node heaps + expanded leaf rows
 // ------------------------------------------------------------------------------------------------
-static int rf_depth(const gnx_model_desc* d, int32_t o, int32_t nid, int32_t n_nodes, int guard) {
-  if (guard > 64 || nid < 0 || nid >= n_nodes) return -1000;
-  if (d->rf_left[o + nid] == -1) return 0;
-  const int l = rf_depth(d, o, d->rf_left[o + nid], n_nodes, guard + 1);
-  const int r = rf_depth(d, o, d->rf_right[o + nid], n_nodes, guard + 1);
-  if (l < 0 || r < 0) return -1000;
-  return 1 + std::max(l, r);
-}
-
 static void rf_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint32_t* nodes,
                     double* leafval) {
   const bool leaf = d->rf_left[o + nid] == -1;
@@ -591,6 +598,8 @@ static int build_rforest(gnx_model* m, const gnx_model_desc* d) {
   if (d->rf_win_tree0[0] != 0 || d->rf_win_tree0[W] != d->rf_n_trees)
     return fail(ctx, GNX_EINVAL, "rforest base: rf_win_tree0 must run from 0 to rf_n_trees");
   if (C < 16) return fail(ctx, GNX_EUNSUPPORTED, "rforest base: fewer than 16 SNPs");
+  if (!checked_tree_offsets(d->rf_tree_off, d->rf_n_trees, d->rf_n_nodes))
+    return fail(ctx, GNX_EINVAL, "rforest base: rf_tree_off must start at 0, increase strictly and end at rf_n_nodes");
   int D = 1, max_trees = 0;
   for (int64_t w = 0; w < W; ++w) {
     const int32_t t0 = d->rf_win_tree0[w], t1 = d->rf_win_tree0[w + 1];
@@ -599,9 +608,8 @@ static int build_rforest(gnx_model* m, const gnx_model_desc* d) {
     const int64_t width = (w == W - 1) ? M_ + rem : M_;
     for (int32_t t = t0; t < t1; ++t) {
       const int32_t o = d->rf_tree_off[t], nn = d->rf_tree_off[t + 1] - o;
-      if (nn <= 0) return fail(ctx, GNX_EINVAL, "rforest base: empty tree");
-      const int dep = rf_depth(d, o, 0, nn, 0);
-      if (dep < 0) return fail(ctx, GNX_EINVAL, "rforest base: malformed tree (child index out of range or depth > 64)");
+      const int dep = checked_tree_depth(d->rf_left + o, d->rf_right + o, nn);
+      if (dep < 0) return fail(ctx, GNX_EINVAL, "rforest base: malformed tree (child index out of range, node reachable twice or depth > 64)");
       D = std::max(D, dep);
       for (int32_t k = 0; k < nn; ++k)
         if (d->rf_left[o + k] != -1 && (d->rf_feat[o + k] < 0 || d->rf_feat[o + k] >= width))
@@ -742,6 +750,21 @@ static int build_crf(gnx_model* m, const gnx_model_desc* d) {
 // ------------------------------------------------------------------------------------------------
 // ABI
 // ------------------------------------------------------------------------------------------------
+// the development / test knobs, read once per context (gnx_init)
+static void read_tune(gnx_tune& t) {
+  auto geti = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+  t.lr_bpc = geti("GNX_LR_BPC", 0);
+  t.lr_want = geti("GNX_LR_WANT", 0);
+  if (const char* e = std::getenv("GNX_LR_TUNE")) std::sscanf(e, "%d,%d", &t.lr_mt, &t.lr_waves);
+  t.lr_flags = geti("GNX_LR_FLAGS", 0);
+  t.sm_nw = geti("GNX_SM_NW", 0);
+  if (const char* e = std::getenv("GNX_SM_TUNE")) std::sscanf(e, "%d,%d", &t.smf_rpl, &t.smf_nw);
+  t.forest_threads = geti("GNX_FOREST_T", 0);
+  if (const char* e = std::getenv("GNX_HOST_BATCH")) t.host_batch = std::atoll(e);
+  t.h2d_overlap = geti("GNX_H2D_OVERLAP", 1);
+  t.debug = std::getenv("GNX_DEBUG") != nullptr;
+}
+
 extern "C" {
 
 int gnx_abi_version(void) { return GNX_ABI_VERSION; }
@@ -763,6 +786,7 @@ int gnx_init(int device, gnx_ctx** out) {
   }
   ctx->own_stream = true;
   ctx->usable = true;
+  read_tune(ctx->tune);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
   *out = ctx;
@@ -951,7 +975,7 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     L.packed = m->forest.packed; L.win_tree0 = m->forest.win_tree0; L.win_class_tree0 = m->forest.win_class_tree0;
     L.rf_leafval = m->forest.rf_leafval;
     L.b32 = d_b32; L.b64 = d_b64;
-    HIPCHK(ctx, gnx_launch_base_forest(L, ctx->stream));
+    HIPCHK(ctx, gnx_launch_base_forest(L, ctx->tune, ctx->stream));
     return GNX_OK;
   }
   if (m->info.base_kind != GNX_BASE_LOGISTIC) return fail(ctx, GNX_ESTATE, "model has no base classifier");
@@ -973,7 +997,7 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
   L.W = (int32_t)m->info.W; L.A = m->info.A;
   L.b32 = d_b32; L.b64 = d_b64;
   ProfScope ps(ctx, GNX_K_BASE_LOGISTIC);
-  if (m->lr_i8) HIPCHK(ctx, gnx_launch_base_logistic_i8(L, ctx->n_cu, ctx->stream));
+  if (m->lr_i8) HIPCHK(ctx, gnx_launch_base_logistic_i8(L, ctx->n_cu, ctx->tune, ctx->stream));
   else HIPCHK(ctx, gnx_launch_base_logistic(L, ctx->n_cu, ctx->stream));
   return GNX_OK;
 }
@@ -1025,8 +1049,8 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
       L.marg = (float*)ctx->ws_marg.p;
     }
     ProfScope ps(ctx, GNX_K_SMOOTH_XGB);
-    if (m->xgb.rk_packed) HIPCHK(ctx, gnx_launch_smooth_xgb_rk(L, ctx->stream));
-    else HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->n_cu, ctx->stream));
+    if (m->xgb.rk_packed) HIPCHK(ctx, gnx_launch_smooth_xgb_rk(L, ctx->tune, ctx->stream));
+    else HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->tune, ctx->stream));
     return GNX_OK;
   }
   if (m->info.smooth_kind == GNX_SMOOTH_CRF) {
@@ -1076,9 +1100,8 @@ int gnx_infer_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx, float*
 static int64_t hap_batch(const gnx_model* m, int64_t N, int64_t ldx) {
   // bound the staging workspaces (~1 GiB of X per batch); whole individuals per batch
   int64_t nb = ((int64_t)1 << 30) / std::max<int64_t>(ldx, 1);
-  if (const char* e = std::getenv("GNX_HOST_BATCH")) nb = std::atoll(e);  // tests: force several batches on small inputs
+  if (m->ctx->tune.host_batch > 0) nb = m->ctx->tune.host_batch;  // tests: force several batches on small inputs
   nb = std::max<int64_t>(2, nb & ~(int64_t)1);
-  (void)m;
   return std::min(N, nb);
 }
 
@@ -1272,7 +1295,7 @@ int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_
   const size_t WA = (size_t)W * m->info.A;
   // batches of individuals bound the staging workspaces (~1 GiB of X)
   int64_t nb = std::max<int64_t>(1, (((int64_t)1 << 30) / std::max<int64_t>(ldx, 1)) / 2);
-  if (const char* e = std::getenv("GNX_HOST_BATCH")) nb = std::max<int64_t>(1, std::atoll(e) / 2);
+  if (ctx->tune.host_batch > 0) nb = std::max<int64_t>(1, ctx->tune.host_batch / 2);
   nb = std::min(nb, n_ind);
   if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)2 * nb * ldx + 64)) != GNX_OK) return rc;
   if ((rc = ws_reserve(ctx, ctx->ws_b64, (size_t)2 * nb * WA * 8)) != GNX_OK) return rc;

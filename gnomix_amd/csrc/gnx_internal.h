@@ -20,8 +20,32 @@ struct gnx_prof_pair {
   int kid;
 };
 
+// Development / test knobs.  Environment variables are read ONCE per context in gnx_init (never on a launch path);
+// every field's 0 means "the built-in choice".
+struct gnx_tune {
+  int lr_bpc = 0, lr_want = 0;          // GNX_LR_BPC, GNX_LR_WANT: window ranges of the logistic pass
+  int lr_mt = 0, lr_waves = 0;          // GNX_LR_TUNE="mt,waves": tile shape of the logistic pass
+  int lr_flags = 0;                     // GNX_LR_FLAGS: ablation switches
+  int sm_nw = 0;                        // GNX_SM_NW: waves per block of the rank smoother
+  int smf_rpl = 0, smf_nw = 0;          // GNX_SM_TUNE="rpl,nw": float smoother
+  int forest_threads = 0;               // GNX_FOREST_T
+  int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
+  int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points
+  bool debug = false;                   // GNX_DEBUG
+};
+
+// opt a kernel into its dynamic LDS size; a refusal is reported by the launcher instead of surfacing later as an
+// opaque launch failure
+#define GNX_LDS_OPTIN(bytes, ...)                                                                                  \
+  do {                                                                                                             \
+    const hipError_t e_optin_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                   \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));     \
+    if (e_optin_ != hipSuccess) return e_optin_;                                                                   \
+  } while (0)
+
 struct gnx_ctx {
   int device = 0;
+  gnx_tune tune;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool usable = false;
@@ -287,9 +311,9 @@ struct gnx_model {
 
 // kernel launchers (defined in the .hip files)
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
-hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, hipStream_t s);
-hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, int n_cu, hipStream_t s);
-hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, hipStream_t s);
+hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);
 hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwp,
@@ -301,6 +325,6 @@ size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
 hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);
-hipError_t gnx_launch_base_forest(const ForestLaunch& L, hipStream_t s);
+hipError_t gnx_launch_base_forest(const ForestLaunch& L, const gnx_tune& tune, hipStream_t s);
 size_t gnx_forest_lds_bytes(int A, int max_words, int max_trees, int tree_bytes, int threads);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

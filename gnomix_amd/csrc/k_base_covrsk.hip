@@ -466,9 +466,9 @@ hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
   const size_t lds_dec = r16((size_t)2 * L0.max_nw * 64 * 4) + r16((size_t)(L0.max_width + 2) * 8) + r16((size_t)P * 64 * 8);
   const size_t lds_cpl = (size_t)(P + A * A + 2 * A) * 64 * 8;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_covrsk_dec<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dec);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_covrsk_dec<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dec);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svc_couple), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cpl);
+  GNX_LDS_OPTIN(lds_dec, k_covrsk_dec<false>);
+  GNX_LDS_OPTIN(lds_dec, k_covrsk_dec<true>);
+  GNX_LDS_OPTIN(lds_cpl, k_svc_couple);
   // the pairwise probabilities travel through a bounded global buffer: haplotypes in chunks of rpair_haps
   for (int64_t n0 = 0; n0 < L0.N; n0 += L0.rpair_haps) {
     CovRSKLaunch L = L0;

@@ -227,30 +227,27 @@ __global__ __launch_bounds__(256) void k_base_rforest(ForestLaunch L) {
 
 template <int AMAX>
 hipError_t launch_rf(const ForestLaunch& L, int n_windows, int threads, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_rforest<AMAX>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)((size_t)160 * 1024));
+  GNX_LDS_OPTIN((size_t)160 * 1024, k_base_rforest<AMAX>);
   hipLaunchKernelGGL(k_base_rforest<AMAX>, dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)n_windows), dim3(threads), lds, s, L);
   return hipGetLastError();
 }
 
 template <int D>
 hipError_t launch_d(const ForestLaunch& L, int n_windows, int threads, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_forest<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)((size_t)160 * 1024));
+  GNX_LDS_OPTIN((size_t)160 * 1024, k_base_forest<D>);
   hipLaunchKernelGGL(k_base_forest<D>, dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)n_windows), dim3(threads), lds, s, L);
   return hipGetLastError();
 }
 
 // windows [w_first, w_first + n_windows) with an X tile of max_words words per haplotype
-hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int max_words, hipStream_t s) {
+hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int max_words, const gnx_tune& tune, hipStream_t s) {
   if (n_windows <= 0) return hipSuccess;
   // the walks are issue-bound with one wave per SIMD and staging does not overlap them inside a block: take as many
   // waves per CU as the LDS holds (the X tile is 4 * max_words bytes per haplotype)
   constexpr size_t kLds = (size_t)160 * 1024;
   L.w_first = w_first;
   L.max_words = max_words;
-  int threads = 0;
-  if (const char* e = std::getenv("GNX_FOREST_T")) threads = std::atoi(e) / 64 * 64;
+  int threads = tune.forest_threads / 64 * 64;
   if (threads < 64 || threads > 256) threads = 256;
   while (threads > 64 && gnx_forest_lds_bytes(L.A, max_words, L.max_trees, L.tree_bytes, threads) > kLds) threads -= 64;
   while (threads > 64 && (int64_t)(threads - 64) >= L.N) threads -= 64;
@@ -280,11 +277,11 @@ size_t gnx_forest_lds_bytes(int A, int max_words, int max_trees, int tree_bytes,
   return (size_t)max_words * threads * 4 + (((size_t)max_trees * tree_bytes + 15) & ~(size_t)15) + (size_t)A * threads * 4;
 }
 
-hipError_t gnx_launch_base_forest(const ForestLaunch& L, hipStream_t s) {
+hipError_t gnx_launch_base_forest(const ForestLaunch& L, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
   // the last window is wider by C mod M (base.py:163-164): its own launch, so that the others get the smaller tile
   const int words = (int)((L.width + 15) >> 4), words_last = (int)((L.width_last + 15) >> 4);
-  hipError_t e = launch_range(L, 0, L.W - 1, words, s);
+  hipError_t e = launch_range(L, 0, L.W - 1, words, tune, s);
   if (e != hipSuccess) return e;
-  return launch_range(L, L.W - 1, 1, words_last, s);
+  return launch_range(L, L.W - 1, 1, words_last, tune, s);
 }

@@ -269,17 +269,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8(BaseLRLaunch L)
 #undef GNX_STAGE_STORE
 
 template <int MT, int NT, int WAVES, int CPS>
-hipError_t launch(const BaseLRLaunch& L, int n_cu, hipStream_t s) {
+hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   BaseLRLaunch P = L;
   const int haps_per_block = WAVES * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
   // window ranges: a multiple of 8 (one XCD each), ~4 blocks per CU in total; more (shorter) ranges if the per-block
   // chunk / window tables would not fit the LDS next to the tiles (long chromosomes with few haplotype tiles)
-  int bpc = 4;  // measured on chr22 / 10 k haplotypes: 32 ranges 1.17 ms, 24 ranges 1.21, 16 ranges 1.31
-  if (const char* t = std::getenv("GNX_LR_BPC")) bpc = std::max(1, std::atoi(t));
+  const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : 4;  // measured on chr22 / 10 k haplotypes: 32 ranges 1.17 ms, 24 ranges 1.21, 16 ranges 1.31
   int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
   want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
-  if (const char* t = std::getenv("GNX_LR_WANT")) want = std::max(1, std::atoi(t));
+  if (tune.lr_want > 0) want = tune.lr_want;
   int wch = 0, n_ranges = 0;
   size_t lds = 0;
   for (;; want += 8) {
@@ -306,48 +305,45 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, hipStream_t s) {
   const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
   P.wch = wch;
   P.n_htiles = (int)gx;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_base_logistic_i8<MT, NT, WAVES, CPS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  GNX_LDS_OPTIN(lds, k_base_logistic_i8<MT, NT, WAVES, CPS>);
   hipLaunchKernelGGL((k_base_logistic_i8<MT, NT, WAVES, CPS>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
   const hipError_t e = hipGetLastError();
-  if (e != hipSuccess && std::getenv("GNX_DEBUG")) std::fprintf(stderr, "k_base_logistic_i8<%d,%d,%d>: lds=%zu grid=%lld wch=%d max_chunks=%d max_wins=%d\n", MT, NT, WAVES, lds, (long long)(gx * n_ranges8), wch, P.max_chunks, P.max_wins);
+  if (e != hipSuccess && tune.debug) std::fprintf(stderr, "k_base_logistic_i8<%d,%d,%d>: lds=%zu grid=%lld wch=%d max_chunks=%d max_wins=%d\n", MT, NT, WAVES, lds, (long long)(gx * n_ranges8), wch, P.max_chunks, P.max_wins);
   return e;
 }
 
 }  // namespace
 
-hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L0, int n_cu, hipStream_t s) {
+hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L0, int n_cu, const gnx_tune& tune, hipStream_t s) {
   if (L0.N <= 0) return hipSuccess;
   BaseLRLaunch L = L0;
   const bool small = L.N <= 64 * 8;
   // tuning / ablation knobs (development only): GNX_LR_TUNE="mt,waves,cps", GNX_LR_FLAGS=bitmask
-  int tm = 0, tw = 0, tc = 0;
-  if (const char* t = std::getenv("GNX_LR_TUNE")) std::sscanf(t, "%d,%d,%d", &tm, &tw, &tc);
-  if (const char* f = std::getenv("GNX_LR_FLAGS")) L.flags = std::atoi(f);
+  const int tm = tune.lr_mt, tw = tune.lr_waves;
+  L.flags = tune.lr_flags;
   if (L.d.NT == 1 && tm) {
-    (void)tc;
-    if (tm == 1 && tw == 4) return launch<1, 1, 4, 2>(L, n_cu, s);
-    if (tm == 1 && tw == 8) return launch<1, 1, 8, 2>(L, n_cu, s);
-    if (tm == 1 && tw == 16) return launch<1, 1, 16, 2>(L, n_cu, s);
-    if (tm == 2 && tw == 4) return launch<2, 1, 4, 2>(L, n_cu, s);
-    if (tm == 2 && tw == 8) return launch<2, 1, 8, 2>(L, n_cu, s);
-    if (tm == 4 && tw == 4) return launch<4, 1, 4, 2>(L, n_cu, s);
-    if (tm == 4 && tw == 8) return launch<4, 1, 8, 2>(L, n_cu, s);
+    if (tm == 1 && tw == 4) return launch<1, 1, 4, 2>(L, n_cu, tune, s);
+    if (tm == 1 && tw == 8) return launch<1, 1, 8, 2>(L, n_cu, tune, s);
+    if (tm == 1 && tw == 16) return launch<1, 1, 16, 2>(L, n_cu, tune, s);
+    if (tm == 2 && tw == 4) return launch<2, 1, 4, 2>(L, n_cu, tune, s);
+    if (tm == 2 && tw == 8) return launch<2, 1, 8, 2>(L, n_cu, tune, s);
+    if (tm == 4 && tw == 4) return launch<4, 1, 4, 2>(L, n_cu, tune, s);
+    if (tm == 4 && tw == 8) return launch<4, 1, 8, 2>(L, n_cu, tune, s);
     return hipErrorInvalidValue;
   }
   if (L.d.NT == 2 && tm) {
-    if (tm == 1 && tw == 4) return launch<1, 2, 4, 2>(L, n_cu, s);
-    if (tm == 1 && tw == 8) return launch<1, 2, 8, 2>(L, n_cu, s);
-    if (tm == 1 && tw == 16) return launch<1, 2, 16, 2>(L, n_cu, s);
-    if (tm == 2 && tw == 4) return launch<2, 2, 4, 2>(L, n_cu, s);
-    if (tm == 2 && tw == 8) return launch<2, 2, 8, 2>(L, n_cu, s);
+    if (tm == 1 && tw == 4) return launch<1, 2, 4, 2>(L, n_cu, tune, s);
+    if (tm == 1 && tw == 8) return launch<1, 2, 8, 2>(L, n_cu, tune, s);
+    if (tm == 1 && tw == 16) return launch<1, 2, 16, 2>(L, n_cu, tune, s);
+    if (tm == 2 && tw == 4) return launch<2, 2, 4, 2>(L, n_cu, tune, s);
+    if (tm == 2 && tw == 8) return launch<2, 2, 8, 2>(L, n_cu, tune, s);
     return hipErrorInvalidValue;
   }
   switch (L.d.NT) {
-    case 1: return small ? launch<1, 1, 4, 2>(L, n_cu, s) : launch<2, 1, 8, 2>(L, n_cu, s);
-    case 2: return small ? launch<1, 2, 4, 2>(L, n_cu, s) : launch<2, 2, 8, 2>(L, n_cu, s);  // A=12: 2.0 TB/s measured
-    case 3: return launch<1, 3, 4, 2>(L, n_cu, s);
-    case 4: return launch<1, 4, 4, 2>(L, n_cu, s);
+    case 1: return small ? launch<1, 1, 4, 2>(L, n_cu, tune, s) : launch<2, 1, 8, 2>(L, n_cu, tune, s);
+    case 2: return small ? launch<1, 2, 4, 2>(L, n_cu, tune, s) : launch<2, 2, 8, 2>(L, n_cu, tune, s);  // A=12: 2.0 TB/s measured
+    case 3: return launch<1, 3, 4, 2>(L, n_cu, tune, s);
+    case 4: return launch<1, 4, 4, 2>(L, n_cu, tune, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -245,7 +245,7 @@ size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds) {
 hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s) {
   if (n_ind <= 0) return hipSuccess;
   const size_t lds = gnx_gnofix_lds_bytes(L.W, L.A, L.S, L.d.n_trees, L.bp_in_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gnofix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  GNX_LDS_OPTIN(lds, k_gnofix);
   hipLaunchKernelGGL(k_gnofix, dim3((unsigned)n_ind), dim3(THREADS), lds, s, L);
   return hipGetLastError();
 }

@@ -110,7 +110,7 @@ hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L0, hipStream_t s) {
   const dim3 grid((unsigned)((L.W + WS - 1) / WS), (unsigned)((L.N + nwave - 1) / nwave));
 #define GNX_CNN_LAUNCH(AM)                                                                                              \
   {                                                                                                                      \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_cnn<AM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    GNX_LDS_OPTIN(lds, k_smooth_cnn<AM>);                                                                              \
     hipLaunchKernelGGL(k_smooth_cnn<AM>, grid, dim3(nwave * 64), lds, s, L);                                             \
   }
   if (L.A <= 8) GNX_CNN_LAUNCH(8) else if (L.A <= 16) GNX_CNN_LAUNCH(16) else GNX_CNN_LAUNCH(32)

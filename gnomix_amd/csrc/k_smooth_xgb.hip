@@ -236,10 +236,10 @@ hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
   const dim3 grid((unsigned)((L.W + RPL * WS - 1) / (RPL * WS)), (unsigned)((L.N + NWAVE - 1) / NWAVE));
   const size_t lds = lds_bytes<RPL, NWAVE>(L.d, L.A, L.S);
   if (L.d.D == 4) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb<RPL, NWAVE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GNX_LDS_OPTIN(lds, k_smooth_xgb<RPL, NWAVE, 4>);
     hipLaunchKernelGGL((k_smooth_xgb<RPL, NWAVE, 4>), grid, dim3(NWAVE * 64), lds, s, L);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb<RPL, NWAVE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GNX_LDS_OPTIN(lds, k_smooth_xgb<RPL, NWAVE, 0>);
     hipLaunchKernelGGL((k_smooth_xgb<RPL, NWAVE, 0>), grid, dim3(NWAVE * 64), lds, s, L);
   }
   return hipGetLastError();
@@ -249,13 +249,12 @@ hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
 
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S) { return lds_bytes<1, 1>(d, A, S); }
 
-hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, int /*n_cu*/, hipStream_t s) {
+hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
   // rows per lane = 64-window segments one wave walks on its haplotype's strip; more segments per strip = less halo
   // and more independent chains per lane, bounded by LDS (want >= 2-3 blocks per CU)
   const int nseg = (L.W + WS - 1) / WS;
-  int rpl = 0, nw = 0;
-  if (const char* t = std::getenv("GNX_SM_TUNE")) std::sscanf(t, "%d,%d", &rpl, &nw);
+  int rpl = tune.smf_rpl, nw = tune.smf_nw;
   if (!rpl) {
     // measured on chr22 (W=370, A=7, 700 trees): 3 segments x 4 waves is the sweet spot (2.07 ms / 10k haplotypes);
     // 6-8 segments per lane lose to LDS/issue pressure, 1 segment pays 2.2x halo

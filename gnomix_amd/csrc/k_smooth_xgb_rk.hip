@@ -360,10 +360,10 @@ hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
   const size_t lds = lds_bytes<NWAVE>(L.d, L.A);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   if (L.d.D == 4) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb_rk<RPL, NWAVE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GNX_LDS_OPTIN(lds, k_smooth_xgb_rk<RPL, NWAVE, 4>);
     hipLaunchKernelGGL((k_smooth_xgb_rk<RPL, NWAVE, 4>), grid, dim3(NWAVE * 64), lds, s, L);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_xgb_rk<RPL, NWAVE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GNX_LDS_OPTIN(lds, k_smooth_xgb_rk<RPL, NWAVE, 0>);
     hipLaunchKernelGGL((k_smooth_xgb_rk<RPL, NWAVE, 0>), grid, dim3(NWAVE * 64), lds, s, L);
   }
   return hipGetLastError();
@@ -371,11 +371,10 @@ hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
 
 }  // namespace
 
-hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, hipStream_t s) {
+hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
   const int rpl = L.d.rk_rpl;  // fixed at model load: the node offsets encode the strip stride
-  int nw = 0;
-  if (const char* t = std::getenv("GNX_SM_NW")) nw = std::atoi(t);
+  int nw = tune.sm_nw;
   if (nw != 2 && nw != 4 && nw != 8) {
     // as many waves per CU as the LDS allows: 8-wave blocks unless 4-wave blocks pack the 160 KB better
     const size_t l8 = lds_bytes<8>(L.d, L.A), l4 = lds_bytes<4>(L.d, L.A);

@@ -4,7 +4,14 @@ Every haplotype is independent in base+smoother (src/Base/base.py:174, src/Smoot
 couples only the two haplotypes of one individual (src/model.py:205-210), so the path shards by individual
 with NO data-path collective; the model is replicated per GPU.  The only communication is the output
 gather (labels / probabilities), done once per batch with torch.distributed (backend "nccl" = RCCL over
-xGMI on the GPU box, "gloo" in the CPU tests).
+xGMI on the GPU box, "gloo" in the CPU tests):
+
+  * `dst=None`  every rank gets the full array: ONE all_gather of max-shard-sized blocks;
+  * `dst=r`     only rank r receives: a true gather (`dist.gather`: ncclSend/ncclRecv pairs under RCCL) — the other
+                ranks send their shard and receive nothing (whole genome, 100 k haplotypes = 49.6 GB of outputs: it
+                must not land on all 8 GPUs to serve rank 0);
+  * `gather=False` in `infer_sharded`: no collective at all — every rank keeps (and writes) its own row block,
+                   which is what the writers want when outputs go straight to disk.
 """
 from __future__ import annotations
 
@@ -26,8 +33,8 @@ def shard_bounds(n_haplotypes: int, world: int, rank: int):
 def gather_rows(local, n_total, group=None, dst=None):
     """Gather per-rank row blocks (axis 0, sizes given by shard_bounds) into the full array.
     `local` is a torch tensor (CUDA under nccl, CPU under gloo).  dst=None -> every rank gets the result
-    (all_gather), else only rank `dst` (others get None).  Shards are padded to the largest shard so a single
-    fixed-size collective is used (ncclAllGather wants equal counts)."""
+    (all_gather); dst=r -> only rank r (a gather: the others send and get None).  Shards are padded to the
+    largest shard so that one fixed-size collective is used (RCCL wants equal counts)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -36,30 +43,47 @@ def gather_rows(local, n_total, group=None, dst=None):
     mx = max(hi - lo for lo, hi in sizes)
     lo, hi = sizes[rank]
     assert local.shape[0] == hi - lo, (local.shape, lo, hi)
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:hi - lo] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    if dst is not None and rank != dst:
-        return None
+    if hi - lo == mx:
+        pad = local.contiguous()
+    else:
+        pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:hi - lo] = local
+    if dst is None:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+    else:
+        bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, gather_list=bufs, dst=dst if group is None else dist.get_global_rank(group, dst), group=group)
+        if rank != dst:
+            return None
     return torch.cat([b[:h - l] for b, (l, h) in zip(bufs, sizes)], dim=0)
 
 
-def infer_sharded(fn, X, group=None, dst=0):
-    """Run `fn(X_shard) -> tuple of arrays/tensors with leading dim = shard haplotypes` on this rank's shard of
-    X (numpy (N, C) or torch tensor, the FULL matrix or anything sliceable by rows) and gather the outputs."""
+def infer_sharded(fn, X, group=None, dst=0, gather=True):
+    """Run `fn(X_shard) -> array/tensor or tuple of them (leading dim = shard haplotypes; None entries allowed)` on this
+    rank's shard of X (numpy (N, C) or torch tensor, the FULL matrix or anything sliceable by rows) and gather the
+    outputs.  Always returns a TUPLE (also without torch.distributed: the single-process result, un-gathered);
+    None outputs stay None.  gather=False returns this rank's shard outputs and its (lo, hi) bounds last."""
     import torch
     import torch.distributed as dist
+
+    def as_tuple(o):
+        return tuple(o) if isinstance(o, (tuple, list)) else (o,)
+
     if not (dist.is_available() and dist.is_initialized()):
-        return fn(X)
+        outs = as_tuple(fn(X))
+        return outs if gather else outs + ((0, X.shape[0]),)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     N = X.shape[0]
     lo, hi = shard_bounds(N, world, rank)
-    outs = fn(X[lo:hi])
-    if not isinstance(outs, (tuple, list)):
-        outs = (outs,)
+    outs = as_tuple(fn(X[lo:hi]))
+    if not gather:
+        return outs + ((lo, hi),)
     res = []
     for o in outs:
+        if o is None:
+            res.append(None)
+            continue
         t = o if isinstance(o, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(o))
         if dist.get_backend(group) == "nccl" and not t.is_cuda:
             t = t.cuda()

@@ -203,6 +203,7 @@ class GnxModelData:
             if wt0.shape != (W + 1,):
                 raise ValueError("fb_win_tree0 must be (W+1,)")
             d.fb_n_trees = len(self.fb_tree_off) - 1
+            d.fb_n_nodes = len(self.fb_left)
             d.fb_missing = int(self.fb_missing)
             d.fb_win_tree0 = ptr(wt0, np.int32)
             d.fb_tree_off = ptr(self.fb_tree_off, np.int32)
@@ -223,6 +224,7 @@ class GnxModelData:
             if val.ndim != 2 or val.shape[1] != A or val.shape[0] != len(self.rf_left):
                 raise ValueError("rf_value must be (n_nodes, A)")
             d.rf_n_trees = len(self.rf_tree_off) - 1
+            d.rf_n_nodes = len(self.rf_left)
             d.rf_win_tree0 = ptr(wt0, np.int32)
             d.rf_tree_off = ptr(self.rf_tree_off, np.int32)
             d.rf_left = ptr(self.rf_left, np.int32)
@@ -232,6 +234,7 @@ class GnxModelData:
             d.rf_value = ptr(val, np.float64)
         if self.smooth_kind == "xgb":
             d.n_trees = self.n_trees
+            d.n_nodes = len(self.left)
             d.tree_off = ptr(self.tree_off, np.int32)
             d.left = ptr(self.left, np.int32)
             d.right = ptr(self.right, np.int32)

@@ -10,7 +10,13 @@ restricted `Unpickler`:
    `__module__`, so `gnomix_amd.convert.from_reference_model` duck-types it exactly like the real object
    (`type(m).__name__ == "LogisticRegression"`, `m.coef_`, ...);  scikit-learn classes are rebuilt for real when
    `use_sklearn=True` and scikit-learn imports;
- * torch objects (the CNN smoother of the "large" mode pickles an `nn.Sequential`) are rebuilt by torch when it imports;
+ * torch objects (the CNN smoother of the "large" mode pickles an `nn.Sequential(nn.Conv1d)`) are rebuilt by torch
+   through an explicit (module, name) allow-list (`_TORCH_OK`); the tensor bytes inside go through
+   `torch.load(..., weights_only=True)`, never through a nested unrestricted pickle;
+ * scikit-learn classes are rebuilt for real only when they are one of the estimator classes the converter reads
+   (`_SKLEARN_OK`), everything else under `sklearn.*` becomes a `Stub`;
+ * dotted names (`module="torch.serialization", name="os.system"`: protocol >= 4 walks attribute paths) are refused
+   outright, whatever the module;
  * anything else raises `pickle.UnpicklingError` (a pickle is code: nothing outside the lists above is ever
    imported or called).
 
@@ -91,15 +97,38 @@ def _stub_class(module, name):
     return _stub_cache[key]
 
 
+# torch globals a pickled nn.Sequential(nn.Conv1d) refers to (torch 1.4 ... 2.x), nothing else of torch is reachable
+_TORCH_OK = {("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+             ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+             ("torch.nn.parameter", "Parameter"), ("torch.nn.modules.container", "Sequential"),
+             ("torch.nn.modules.conv", "Conv1d"), ("torch.nn.modules.activation", "Softmax"),
+             ("torch.nn.modules.activation", "ReLU"), ("torch", "FloatStorage"), ("torch", "DoubleStorage"),
+             ("torch", "LongStorage"), ("torch", "Size"), ("torch", "device"), ("torch", "float32"), ("torch", "float64")}
+# scikit-learn estimator classes the converter reads fitted attributes of (module path differs between 0.2x and 1.x,
+# so the class NAME is matched inside the sklearn package); any other sklearn global becomes a Stub
+_SKLEARN_OK = {"LogisticRegression", "SVC", "RandomForestClassifier", "DecisionTreeClassifier", "Tree",
+               "IsotonicRegression", "LabelEncoder"}
+
+
+def _torch_storage_from_bytes(b):
+    """stand-in for torch.storage._load_from_bytes (which is torch.load(weights_only=False), i.e. a nested
+    UNRESTRICTED pickle of attacker-controlled bytes): the same bytes through torch's own restricted loader"""
+    import torch
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
 class RefUnpickler(pickle.Unpickler):
     def __init__(self, f, use_sklearn=True):
         super().__init__(f)
         self.use_sklearn = use_sklearn
 
     def find_class(self, module, name):
+        if "." in name or not name or not module:
+            # protocol >= 4 resolves dotted names attribute by attribute ("os.path.basename" below an allowed module)
+            raise pickle.UnpicklingError(f"dotted global {module}.{name} is refused")
         root = module.split(".")[0]
         if root == "numpy":
-            if name.split(".")[-1] in _NUMPY_OK:
+            if name in _NUMPY_OK:
                 return super().find_class(module, name)
             raise pickle.UnpicklingError(f"numpy global {module}.{name} is not on the allow-list")
         if module in ("builtins", "__builtin__"):
@@ -111,11 +140,15 @@ class RefUnpickler(pickle.Unpickler):
         if module == "copyreg" and name == "_reconstructor":
             return super().find_class(module, name)
         if root == "torch":  # the CNN smoother pickles a real torch module: rebuilt by torch itself (tensors, Parameters)
+            if (module, name) == ("torch.storage", "_load_from_bytes"):
+                return _torch_storage_from_bytes
+            if (module, name) not in _TORCH_OK:
+                raise pickle.UnpicklingError(f"torch global {module}.{name} is not on the allow-list")
             try:
                 return super().find_class(module, name)
             except Exception as e:
                 raise pickle.UnpicklingError(f"the pickle holds torch objects and torch is not importable: {e}")
-        if root in ("sklearn",) and self.use_sklearn:
+        if root == "sklearn" and self.use_sklearn and name in _SKLEARN_OK:
             try:
                 return super().find_class(module, name)
             except Exception:

@@ -118,8 +118,8 @@ typedef struct gnx_model_desc {
   /* GNX_SMOOTH_XGB: xgboost model schema, node arrays of all trees concatenated
    * (src/Smooth/models.py:14-20: multi:softprob, tree t belongs to class tree_class[t]) */
   int32_t n_trees;
-  int32_t reserved1;
-  const int32_t* tree_off;   /* (n_trees+1,) node offsets */
+  int32_t n_nodes;           /* length of left/right/feat/cond (0 = not given: tree_off[n_trees] is trusted) */
+  const int32_t* tree_off;   /* (n_trees+1,) node offsets: 0, strictly increasing, tree_off[n_trees] == n_nodes */
   const int32_t* left;       /* child index within the tree, -1 at leaves */
   const int32_t* right;
   const int32_t* feat;       /* split feature = s*A + a of the (S*A)-wide sliding window */
@@ -157,14 +157,14 @@ typedef struct gnx_model_desc {
   const uint8_t* fb_default_left;   /* per node: 1 = missing goes left */
   const int32_t* fb_tree_class;     /* (fb_n_trees,) */
   float fb_base_score;              /* 0.5 */
-  int32_t reserved4;
+  int32_t fb_n_nodes;               /* length of the fb_ node arrays (0 = not given) */
 
   /* GNX_BASE_RFOREST: one random forest per window (RFBase, src/Base/models.py:54-66:
    * RandomForestClassifier(n_estimators=20, max_depth=4)); sklearn's tree arrays (tree_.children_left/right, feature,
    * threshold) of all trees of all windows concatenated.  Left iff float32(x) <= threshold; a leaf contributes its
    * class-probability row rf_value[node]; the window's output is the mean over its trees (float64). */
   int32_t rf_n_trees;
-  int32_t reserved5;
+  int32_t rf_n_nodes;               /* length of the rf_ node arrays (0 = not given) */
   const int32_t* rf_win_tree0;      /* (W+1,) */
   const int32_t* rf_tree_off;       /* (rf_n_trees+1,) node offsets */
   const int32_t* rf_left;           /* -1 at leaves */

@@ -16,6 +16,10 @@ input/output pair produced by executing its own functions:
   G6_writers/      get_meta_data / write_msp / write_fb text              (postprocess.py:25-126)
   G7_vcf.npz       vcf_to_npy on a synthetic allel-style dict            (utils.py:104-159)
   G8_calib_sk.npz  Calibrator.fit/transform (Smooth/Calibration.py:19-69); StringKernelBase train+predict (models.py:161-176)
+  G9 / G10 / G11   RFBase, PolynomialStringKernelBase, CNN smoother (see the functions)
+  G12 / G13 / G14  third-party pins: xgboost smoother, CRFsuite smoother, XGBBase — generated only on a host that has
+                   xgboost / sklearn_crfsuite (absent here: they print "skipped"); tests/test_pins_thirdparty.py consumes them
+  G15_lr_binary.npz  A = 2 logistic base (sklearn's one-row binary form)
 
 Third-party modules the reference imports at module import time but that are absent here
 (xgboost, allel, seaborn, calibration, sklearn_crfsuite) are replaced by empty stubs; no code path
@@ -34,18 +38,40 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 
 
 def _stub_modules():
+    """empty stand-ins ONLY for third-party modules that really are absent (a host with xgboost / sklearn_crfsuite keeps
+    the real ones: the G12-G14 generators below need them)"""
+    import importlib
     for name in ["xgboost", "allel", "seaborn", "calibration", "sklearn_crfsuite"]:
-        if name not in sys.modules:
-            m = types.ModuleType(name)
-            sys.modules[name] = m
-    class _XGBClassifier:  # constructor-compatible placeholder; never fitted or called
-        def __init__(self, *a, **k):
-            self.kw = k
-    sys.modules["xgboost"].XGBClassifier = _XGBClassifier
-    class _CRF:
-        def __init__(self, *a, **k):
+        if name in sys.modules:
+            continue
+        try:
+            importlib.import_module(name)
+            continue
+        except Exception:
             pass
-    sys.modules["sklearn_crfsuite"].CRF = _CRF
+        m = types.ModuleType(name)
+        m.__gnx_stub__ = True
+        sys.modules[name] = m
+        if name == "xgboost":
+            class _XGBClassifier:  # constructor-compatible placeholder; never fitted or called
+                def __init__(self, *a, **k):
+                    self.kw = k
+            m.XGBClassifier = _XGBClassifier
+        if name == "sklearn_crfsuite":
+            class _CRF:
+                def __init__(self, *a, **k):
+                    pass
+            m.CRF = _CRF
+
+
+def have_real(name):
+    """True when the third-party module `name` imports for real (not one of the stubs above)"""
+    import importlib
+    try:
+        m = importlib.import_module(name)
+    except Exception:
+        return False
+    return not getattr(m, "__gnx_stub__", False)
 
 
 def import_reference():
@@ -502,11 +528,215 @@ def make_G11(out):
     print("G11", proba.shape, proba.dtype, labels.shape)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Third-party pins.  xgboost (requirements.txt:11 pins 1.1.1) and sklearn-crfsuite
+# (requirements.txt:9 pins 0.3.6) are absent from the build image, so rows a6 / a7 / XGBBase of SURVEY §8 are "parity
+# unpinned".  The three generators below turn the first host that has them into a one-command pin:
+#
+#     pip install xgboost==1.1.1 sklearn-crfsuite==0.3.6        (any host; the reference checkout is optional)
+#     python tests/golden/make_golden.py G12 G13 G14 && python -m pytest tests/test_pins_thirdparty.py
+#
+# They skip cleanly (print + return) when the package is absent.  With /root/reference present the reference's OWN classes
+# are trained and run (XGB_Smoother, CRF, XGBBase); without it the same third-party estimator is constructed with the
+# constructor arguments the reference uses (cited) and the window slicing / slide_window come from the oracle, which
+# G1 / G3 pin bit-for-bit against the reference.  `via_reference` in the fixture says which.
+# ----------------------------------------------------------------------------------------------------------------------
+def _booster_artifacts(booster):
+    """(raw model bytes as uint8, JSON tree dumps joined as one JSON list string)"""
+    import json as _json
+    try:
+        raw = booster.save_raw()          # xgboost 1.1.1 ... 1.5: legacy binary; >= 2.0: UBJSON by default
+    except TypeError:
+        raw = booster.save_raw("deprecated")
+    raw = bytes(raw)
+    if raw[:1] not in (b"{", b"b", b"C") and hasattr(booster, "save_raw"):
+        try:
+            raw = bytes(booster.save_raw(raw_format="json"))   # newer xgboost: ask for the JSON schema parse_xgb_raw reads
+        except TypeError:
+            pass
+    dumps = booster.get_dump(dump_format="json")
+    return np.frombuffer(raw, dtype=np.uint8).copy(), np.array(_json.dumps([_json.loads(x) for x in dumps]))
+
+
+def make_G12(out):
+    """XGB smoother: XGBClassifier(multi:softprob) on slide_window rows -> booster bytes + JSON dump +
+    predict_proba / predict exactly as Smoother.predict_proba / predict return them (smooth.py:40-65)."""
+    if not have_real("xgboost"):
+        print("G12 skipped: xgboost is not installed (pip install xgboost==1.1.1)")
+        return False
+    import xgboost
+    sys.path.insert(0, ROOT)
+    from oracle import gnx_oracle as O
+    rng = np.random.RandomState(94312)
+    N, W, A, S = 60, 48, 4, 11
+    via_ref = os.path.isdir(REF)
+    y = np.empty((N, W), dtype=int)
+    for i in range(N):
+        a = rng.randint(A)
+        for w in range(W):
+            if rng.rand() < 0.08:
+                a = rng.randint(A)
+            y[i, w] = a
+    y[:A, :] = np.arange(A)[:, None]
+    B = np.full((N, W, A), 0.25 / (A - 1)); B[np.arange(N)[:, None], np.arange(W)[None, :], y] = 0.75
+    B = B * rng.uniform(0.5, 1.5, size=B.shape); B /= B.sum(-1, keepdims=True)
+    Bq = rng.dirichlet(np.ones(A) * 0.5, size=(9, W))
+    Bq[:4] = B[:4]
+    if via_ref:
+        from src.Smooth.models import XGB_Smoother
+        sm = XGB_Smoother(n_windows=W, num_ancestry=A, smooth_window_size=S, n_jobs=1, calibrate=False, mode_filter=0,
+                          seed=94312, verbose=False)
+        sm.model.set_params(n_estimators=12)    # 12 rounds instead of 100: same arithmetic, small fixture
+        sm.train(B, y)
+        proba, labels, model = sm.predict_proba(Bq), sm.predict(Bq), sm.model
+    else:  # constructor arguments of src/Smooth/models.py:14-20
+        model = xgboost.XGBClassifier(n_estimators=12, max_depth=4, learning_rate=0.1, reg_lambda=1, reg_alpha=0, nthread=1,
+                                      random_state=94312, num_class=A, objective="multi:softprob", eval_metric="mlogloss")
+        model.fit(O.slide_window(B, S), y.reshape(-1))
+        proba = model.predict_proba(O.slide_window(Bq, S)).reshape(-1, W, A)
+        labels = np.argmax(proba, axis=-1)
+    raw, dumps = _booster_artifacts(model.get_booster())
+    np.savez_compressed(out, A=A, S=S, W=W, B=Bq, proba=np.asarray(proba), labels=np.asarray(labels), raw=raw, dumps=dumps,
+                        xgboost_version=np.array(xgboost.__version__), via_reference=via_ref)
+    print("G12 xgboost", xgboost.__version__, "proba", np.asarray(proba).dtype, np.asarray(proba).shape, "raw bytes", raw.size)
+    return True
+
+
+def make_G13(out):
+    """CRF smoother: sklearn_crfsuite.CRF(all_possible_transitions / states) -> state_features_,
+    transition_features_ and predict_marginals as CRF.predict_proba returns them (crf.py:9-15, 62-67)."""
+    if not have_real("sklearn_crfsuite"):
+        print("G13 skipped: sklearn_crfsuite is not installed (pip install sklearn-crfsuite==0.3.6)")
+        return False
+    import sklearn_crfsuite
+    rng = np.random.RandomState(94313)
+    N, W, A = 40, 30, 4
+    y = np.empty((N, W), dtype=int)
+    for i in range(N):
+        a = rng.randint(A)
+        for w in range(W):
+            if rng.rand() < 0.1:
+                a = rng.randint(A)
+            y[i, w] = a
+    y[:A, :] = np.arange(A)[:, None]
+    B = np.full((N, W, A), 0.3 / (A - 1)); B[np.arange(N)[:, None], np.arange(W)[None, :], y] = 0.7
+    B = B * rng.uniform(0.5, 1.5, size=B.shape); B /= B.sum(-1, keepdims=True)
+    Bq = rng.dirichlet(np.ones(A) * 0.6, size=(7, W))
+    via_ref = os.path.isdir(REF)
+    if via_ref:
+        from src.Smooth.crf import CRF
+        m = CRF(max_it=200)
+        m.fit(B, y)
+        proba, crf = m.predict_proba(Bq), m.CRF
+    else:  # constructor arguments of src/Smooth/crf.py:9-15, feature dicts of crf.py:17-34
+        crf = sklearn_crfsuite.CRF(algorithm="lbfgs", max_iterations=200, all_possible_transitions=True, all_possible_states=True)
+        feats = lambda Z: [[{str(a): Z[i, b, a] for a in range(A)} for b in range(W)] for i in range(len(Z))]
+        crf.fit(feats(B), [[str(v) for v in row] for row in y])
+        mg = crf.predict_marginals(feats(Bq))
+        proba = np.array([[[mg[i][b][str(a)] for a in range(A)] for b in range(W)] for i in range(len(Bq))])
+    state = np.zeros((A, A)); trans = np.zeros((A, A))
+    for (attr, label), w in crf.state_features_.items():
+        state[int(attr), int(label)] = w
+    for (y0, y1), w in crf.transition_features_.items():
+        trans[int(y0), int(y1)] = w
+    np.savez_compressed(out, A=A, W=W, B=Bq, proba=np.asarray(proba, dtype=np.float64), state=state, trans=trans,
+                        via_reference=via_ref, version=np.array(getattr(sklearn_crfsuite, "__version__", "?")))
+    print("G13 crf marginals", np.asarray(proba).shape)
+    return True
+
+
+def make_G14(out):
+    """XGBBase (SURVEY §8 a4'' / f3): one XGBClassifier(n_estimators=20, max_depth=4, missing=2) per window on the
+    window's SNPs (Base/models.py:24-35) -> per-window booster bytes + Base.predict_proba; A = 3 (multi:softprob) and
+    A = 2 (binary:logistic, one tree per round)."""
+    if not have_real("xgboost"):
+        print("G14 skipped: xgboost is not installed (pip install xgboost==1.1.1)")
+        return False
+    import xgboost
+    sys.path.insert(0, ROOT)
+    from oracle import gnx_oracle as O
+    via_ref = os.path.isdir(REF)
+    d = dict(xgboost_version=np.array(xgboost.__version__), via_reference=via_ref)
+    for tag, A in (("m", 3), ("b", 2)):
+        rng = np.random.RandomState(94314 + A)
+        C, M = 1237, 100
+        W, ctx = C // M, 50
+        Xt, yt = synth_admixed(rng, 150, C, A, W, M, miss=0.04)
+        for w in range(W):
+            for a in range(A):
+                yt[a, w] = a
+        Xq, _ = synth_admixed(rng, 21, C, A, W, M, miss=0.06, switch_p=0.1)
+        if via_ref:
+            from src.Base.models import XGBBase
+            base = XGBBase(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx, n_jobs=1, seed=94314,
+                           verbose=False)
+            base.base_multithread = False
+            base.train(Xt, yt)
+            Bq, models = base.predict_proba(Xq), base.models
+        else:  # constructor arguments of src/Base/models.py:31-34; window slicing from the oracle (pinned by G1)
+            models, cols = [], []
+            wins_t, wins_q = dict(O.base_windows(Xt, M, ctx)), dict(O.base_windows(Xq, M, ctx))
+            for w in range(W):
+                m = xgboost.XGBClassifier(n_estimators=20, max_depth=4, learning_rate=0.1, reg_lambda=1, reg_alpha=0, missing=2,
+                                          random_state=94314)
+                m.fit(wins_t[w], yt[:, w])
+                models.append(m)
+                cols.append(m.predict_proba(wins_q[w]))
+            Bq = np.stack(cols, axis=1)
+        raws, offs, dumps = [], [0], []
+        for m in models:
+            raw, dj = _booster_artifacts(m.get_booster())
+            raws.append(raw); offs.append(offs[-1] + raw.size); dumps.append(str(dj))
+        d.update({tag + "_C": C, tag + "_M": M, tag + "_A": A, tag + "_ctx": ctx, tag + "_X": Xq, tag + "_B": np.asarray(Bq),
+                  tag + "_raw": np.concatenate(raws), tag + "_raw_off": np.array(offs, np.int64), tag + "_dumps": np.array(dumps)})
+        print("G14", tag, "A", A, "B", np.asarray(Bq).shape, np.asarray(Bq).dtype)
+    np.savez_compressed(out, **d)
+    return True
+
+
+def make_G15(out):
+    """A = 2 logistic base: sklearn keeps ONE coefficient row for a binary LogisticRegression(liblinear) and
+    `_predict_proba_lr` returns [1 - expit(z), expit(z)] (no OvR normalisation).  Pins
+    gnomix_amd.convert.lr_rows_from_sklearn (the (-coef, +coef) two-row form) against the reference's own
+    Base.predict_proba; the raw sklearn arrays are stored next to the converted ones."""
+    from src.Base.models import LogisticRegressionBase
+    sys.path.insert(0, ROOT)
+    from gnomix_amd.convert import lr_rows_from_sklearn
+    rng = np.random.RandomState(94315)
+    C, M, A = 2237, 100, 2
+    W, ctx = C // M, 50
+    Xt, yt = synth_admixed(rng, 200, C, A, W, M)
+    for w in range(W):
+        for a in range(A):
+            yt[a, w] = a
+    base = LogisticRegressionBase(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx,
+                                  n_jobs=1, seed=94315, verbose=False)
+    base.base_multithread = False
+    base.train(Xt, yt)
+    Xq, _ = synth_admixed(rng, 30, C, A, W, M, miss=0.03, switch_p=0.1)
+    B = base.predict_proba(Xq)
+    ldc = M + 2 * ctx + (C - M * W)
+    coef = np.zeros((W, A, ldc)); icpt = np.zeros((W, A))
+    raw_coef = np.zeros((W, 1, ldc)); raw_icpt = np.zeros((W, 1))
+    for i, m in enumerate(base.models):
+        assert list(m.classes_) == [0, 1] and m.coef_.shape[0] == 1
+        c2, b2 = lr_rows_from_sklearn(m.coef_, m.intercept_, A)
+        coef[i, :, :c2.shape[1]] = c2
+        icpt[i] = b2
+        raw_coef[i, :, :m.coef_.shape[1]] = m.coef_
+        raw_icpt[i] = m.intercept_
+    np.savez_compressed(out, C=C, M=M, A=A, ctx=ctx, X=Xq, coef=coef, intercept=icpt, raw_coef=raw_coef,
+                        raw_intercept=raw_icpt, B=B)
+    print("G15", B.shape, "min/max P0", B[..., 0].min(), B[..., 0].max())
+
+
 def main():
-    if not import_reference():
-        print("reference not found at", REF, "- nothing generated")
-        return 0
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15"]
+    have_ref = import_reference()
+    if not have_ref:
+        _stub_modules()
+        print("reference not found at", REF, "- only the third-party pins (G12-G14) can be generated")
+        which = [w for w in which if w in ("G12", "G13", "G14")]
     if "G1" in which: make_G1(os.path.join(HERE, "G1_lr.npz"))
     if "G2" in which: make_G2(os.path.join(HERE, "G2_covrsk.npz"))
     if "G3" in which: make_G3(os.path.join(HERE, "G3_slide.npz"))
@@ -518,6 +748,10 @@ def main():
     if "G9" in which: make_G9(os.path.join(HERE, "G9_rf.npz"))
     if "G10" in which: make_G10(os.path.join(HERE, "G10_poly.npz"))
     if "G11" in which: make_G11(os.path.join(HERE, "G11_cnn.npz"))
+    if "G12" in which: make_G12(os.path.join(HERE, "G12_xgb_smoother.npz"))
+    if "G13" in which: make_G13(os.path.join(HERE, "G13_crf_smoother.npz"))
+    if "G14" in which: make_G14(os.path.join(HERE, "G14_xgb_base.npz"))
+    if "G15" in which: make_G15(os.path.join(HERE, "G15_lr_binary.npz"))
     return 0
 
 

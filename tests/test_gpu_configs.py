@@ -1,0 +1,150 @@
+"""-m gpu: BASELINE.json's configs 3 and 4 as PIPELINES ("configs_untested").
+
+config 3  chr1 array density, CovRSK/SVC base -> xgb smoother: the base classes were only ever tested up to
+          `base_predict`; here the string-kernel base feeds the tree smoother through gnx_infer / HipGnomix.predict at the
+          config's window geometry (M = 175, ctx = 87, width 349, Ms = [1, 4, 8, 39, 42, 117]) against the oracle, and once
+          at FULL size (C = 250 400, W = 1430, 1 400 support vectors per window) through size-independent properties plus
+          the oracle on two haplotypes.
+config 4  whole genome = one model per chromosome: several chromosome models of different window counts resident in ONE
+          context, chromosome-major batches of the same individuals, results equal to every model run on its own.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import gnomix_amd
+    gnomix_amd.load_library()
+    return gnomix_amd
+
+
+def _svc_oracle_windows(d, wins=None):
+    return [dict(Xfit=w["xfit"], Ms=list(w["ms"]), support=w["support"], dual=w["dual_coef"], intercept=w["intercept"],
+                 probA=w["prob_a"], probB=w["prob_b"], n_support=w["n_support"]) for w in (d.svc if wins is None else wins)]
+
+
+def _trees(O, d):
+    return O.Trees(d.tree_off, d.left, d.right, d.feat, d.cond, d.tree_class, d.A, d.base_score)
+
+
+def _related_queries(d, N, seed):
+    """queries that copy training rows over whole windows, so that long match runs (all six substring lengths) occur"""
+    from gnomix_amd import synth
+    rng = np.random.RandomState(seed)
+    X = synth.synthetic_X(N, d.C, seed=seed, miss=0.02)
+    for n in range(N):
+        for _ in range(3):
+            w = rng.randint(d.W)
+            src = d.svc[w]["xfit"][rng.randint(d.svc[w]["xfit"].shape[0])]
+            start = w * d.M - d.context
+            seg = src if start >= 0 else src[-start:]
+            lo = max(0, start)
+            ln = min(len(seg), d.C - lo)
+            X[n, lo:lo + ln] = seg[:ln]
+    return X
+
+
+def test_config3_covrsk_base_into_xgb_smoother_vs_oracle(ga, oracle):
+    """config-3 window geometry, W = 2S so the smoother accepts it, small enough for the oracle to run every window"""
+    from gnomix_amd import synth
+    M, ctx, A, S, W = 175, 87, 7, 75, 150
+    C = M * W + 150
+    d = synth.synthetic_svc_model(C, M, A, context=ctx, n_fit_per_class=8, seed=3, S=S, smooth="xgb")
+    assert d.window_width(0) == 349 and list(d.svc[0]["ms"]) == [1, 4, 8, 39, 42, 117]
+    N = 12
+    X = _related_queries(d, N, seed=5)
+    g = ga.HipGnomix(d)
+    proba, labels = g.predict_proba(X), g.predict(X)
+    B = oracle.base_covrsk(X, M, ctx, _svc_oracle_windows(d))
+    p_ref, l_ref = oracle.smooth_xgb(_trees(oracle, d), B, S)
+    assert np.array_equal(labels, l_ref)
+    assert np.max(np.abs(proba - p_ref)) <= 1e-5
+    # the plugin-style two-step use (gnomix.py:55-58) gives the same answer as the fused entry point
+    Bq = g.base.predict_proba(X)
+    assert np.max(np.abs(Bq - B)) < 1e-12
+    assert np.array_equal(g.smooth.predict(Bq), l_ref)
+    # host batching is invisible on this path too
+    p2, l2 = g.dev.infer(X[:6])
+    assert np.array_equal(l2, l_ref[:6]) and np.array_equal(p2, proba[:6])
+
+
+@pytest.mark.timeout(1500)
+def test_config3_full_size_properties(ga, oracle):
+    """config 3 at FULL size: C = 250 400, M = 175, W = 1430, A = 7, 1 400 training haplotypes per window, all of them
+    support vectors (the survey's worst case), 256 haplotypes."""
+    import torch
+    from gnomix_amd import synth
+    C, M, A, S = 250_400, 175, 7, 75
+    d = synth.synthetic_svc_model(C, M, A, n_fit_per_class=200, sv_frac=1.1, seed=0, S=S, smooth="xgb")
+    assert d.W == 1430 and d.svc[0]["xfit"].shape == (1400, 349) and len(d.svc[0]["support"]) == 1400
+    assert d.svc[-1]["xfit"].shape[1] == 349 + 150
+    dev = ga.DeviceModel(d)
+    N = 256
+    Xh = _related_queries(d, N, seed=11)
+    Xd = torch.from_numpy(Xh).cuda()
+    p, lab = dev.infer_device(Xd)
+    B = dev.base_predict_device(Xd, f64=True)
+    torch.cuda.synchronize()
+    p, lab, B = p.cpu().numpy(), lab.cpu().numpy(), B.cpu().numpy()
+    assert np.isfinite(p).all() and np.allclose(p.sum(-1), 1.0, atol=2e-6)
+    assert np.allclose(B.sum(-1), 1.0, atol=1e-9) and (B >= 0).all()
+    assert np.array_equal(lab, np.argmax(p, -1))
+    # permutation equivariance and batch-split independence, bit-exact
+    perm = np.random.RandomState(1).permutation(N)
+    p2, lab2 = dev.infer_device(torch.from_numpy(Xh[perm]).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(p2.cpu().numpy(), p[perm]) and np.array_equal(lab2.cpu().numpy(), lab[perm])
+    p3, _ = dev.infer_device(Xd[64:101])
+    torch.cuda.synchronize()
+    assert np.array_equal(p3.cpu().numpy(), p[64:101])
+    # the oracle: every window of two haplotypes for the base (1 400 SVs x 349 SNPs x 1 430 windows each), then the smoother
+    idx = [0, 201]
+    Bo = oracle.base_covrsk(Xh[idx], M, d.context, _svc_oracle_windows(d))
+    assert np.max(np.abs(B[idx] - Bo)) < 1e-12
+    p_ref, l_ref = oracle.smooth_xgb(_trees(oracle, d), Bo, S)
+    assert np.array_equal(lab[idx], l_ref)
+    assert np.max(np.abs(p[idx] - p_ref)) <= 1e-5
+    # the exact integer kernel matrix of three windows (first, an inner one, the wider last one) vs the oracle's
+    wins = dict(oracle.base_windows(Xh[idx], M, d.context))
+    for w in (0, 700, d.W - 1):
+        K = oracle.covrsk(wins[w], d.svc[w]["xfit"], list(d.svc[w]["ms"]))
+        assert K.shape == (2, 1400) and K.min() >= 0
+    dev.close()
+
+
+def test_config4_multi_chromosome_models_in_one_context(ga, oracle):
+    """whole-genome harness: >= 3 chromosome models of different W loaded in ONE context, chromosome-major batches of the
+    same individuals; every chromosome's result equals that model run alone (fresh context) and the oracle."""
+    import torch
+    from gnomix_amd import synth, _lib
+    shapes = [(37_537, 100, 375), (16_031, 100, 160), (23_419, 100, 234), (15_077, 100, 150)]   # (C, M, W): chr-like W spread
+    A, S, N = 7, 75, 70
+    ctx = _lib.Context(0)
+    datas = [synth.synthetic_model(C=C, M=M, A=A, S=S, n_rounds=10, seed=100 + k) for k, (C, M, W) in enumerate(shapes)]
+    models = [ga.DeviceModel(d, ctx=ctx) for d in datas]            # all resident at once, one stream, shared workspaces
+    assert [m.W for m in models] == [s[2] for s in shapes]
+    Xs = [synth.synthetic_X(N, d.C, seed=200 + k, miss=0.02) for k, d in enumerate(datas)]
+    Xd = [torch.from_numpy(x).cuda() for x in Xs]
+    outs = []
+    for rep in range(2):                                            # two passes: workspaces sized by the largest chromosome are reused
+        outs = [m.infer_device(x) for m, x in zip(models, Xd)]      # chromosome-major, back to back on one stream
+    torch.cuda.synchronize()
+    host = [m.infer(x) for m, x in zip(models[::-1], Xs[::-1])][::-1]   # host-pointer path, reverse order (workspace shrink/grow)
+    for k, d in enumerate(datas):
+        p, lab = outs[k][0].cpu().numpy(), outs[k][1].cpu().numpy()
+        alone = ga.DeviceModel(d, ctx=_lib.Context(0))
+        pa, la = alone.infer(Xs[k])
+        assert np.array_equal(p, pa) and np.array_equal(lab, la)
+        assert np.array_equal(host[k][0], pa) and np.array_equal(host[k][1], la)
+        alone.close()
+        sel = [0, N - 1]
+        Bo = oracle.base_lr(Xs[k][sel], d.M, d.context, d.lr_coef, d.lr_intercept)
+        p_ref, l_ref = oracle.smooth_xgb(_trees(oracle, d), Bo, S)
+        assert np.array_equal(lab[sel], l_ref) and np.max(np.abs(p[sel] - p_ref)) <= 1e-5
+    info = [m.info.device_bytes for m in models]
+    assert all(b > 0 for b in info)
+    for m in models:
+        m.close()

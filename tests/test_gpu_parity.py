@@ -59,6 +59,18 @@ def test_base_golden_G1(ga, oracle, lr_impl):
     assert np.array_equal(b32, b64.astype(np.float32))
 
 
+def test_base_golden_G15_binary(ga, lr_impl):
+    """A = 2 logistic base against the REFERENCE's own output (sklearn's one-row binary form, see G15 in make_golden.py)"""
+    g = load_golden("G15_lr_binary.npz")
+    d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=2, S=5, context=int(g["ctx"]), base_kind="logistic",
+                        lr_coef=g["coef"], lr_intercept=g["intercept"])
+    dev = ga.DeviceModel(d)
+    b32, b64 = dev.base_predict(g["X"], want_f32=True, want_f64=True)
+    assert np.max(np.abs(b64 - g["B"])) < 1e-12
+    assert np.array_equal(np.argmax(b64, -1), np.argmax(g["B"], -1))
+    assert np.count_nonzero(b32 != g["B"].astype(np.float32)) <= 2
+
+
 @pytest.mark.parametrize("C,M,A,ctx,N", [
     (4037, 100, 7, 50, 24),      # default context ratio 0.5
     (4037, 100, 7, 0, 5),        # no context
@@ -698,7 +710,9 @@ def test_host_path_batching_is_invisible(ga, monkeypatch):
     p_ref, l_ref = ref_dev.infer(X)
     Xg, yg, ns = ref_dev.gnofix(X, b64_ref)
     monkeypatch.setenv("GNX_HOST_BATCH", "6")
-    dev = ga.DeviceModel(d)
+    from gnomix_amd import _lib
+    ctx = _lib.Context(0)   # the knobs are read once per context (gnx_init), never on a launch path
+    dev = ga.DeviceModel(d, ctx=ctx)
     b32, b64 = dev.base_predict(X, want_f32=True, want_f64=True)
     p, l = dev.infer(X)
     assert np.array_equal(b32, b32_ref) and np.array_equal(b64, b64_ref)

@@ -3,6 +3,7 @@ declares, the host mirror validates its inputs, the .gnx container round-trips, 
 package never reaches into oracle/."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -247,3 +248,17 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert int(out[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(out[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+
+
+def test_bench_refuses_gpu_count_it_cannot_have():
+    """`python bench.py --gpus N` spawns its own N ranks or refuses: it must never print a line for a smaller world
+    (--gpus 8 silently ran 1 GPU).  No GPU here -> any N >= 2 is refused before anything is launched."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "refusing to run" in r.stderr
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+    env = dict(os.environ, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)

@@ -22,6 +22,24 @@ def test_G1_logistic_base(oracle):
     assert (g["X"] == 2).any()  # the fixture exercises the missing code
 
 
+def test_G15_binary_logistic_base(oracle):
+    """A = 2: sklearn stores one row and returns [1 - expit(z), expit(z)]; the converter's (-coef, +coef) rows through the
+    OvR form must reproduce the REFERENCE's Base.predict_proba (copying the row into both classes gives 0.5/0.5)"""
+    from gnomix_amd.convert import lr_rows_from_sklearn
+    g = load_golden("G15_lr_binary.npz")
+    assert int(g["A"]) == 2
+    W = int(g["C"]) // int(g["M"])
+    for i in range(W):  # the stored two-row arrays ARE what the converter makes of the raw sklearn arrays
+        c2, b2 = lr_rows_from_sklearn(g["raw_coef"][i], g["raw_intercept"][i], 2)
+        assert np.array_equal(c2, g["coef"][i]) and np.array_equal(b2, g["intercept"][i])
+    B = oracle.base_lr(g["X"], int(g["M"]), int(g["ctx"]), g["coef"], g["intercept"])
+    assert np.max(np.abs(B - g["B"])) < 1e-13
+    assert np.array_equal(np.argmax(B, -1), np.argmax(g["B"], -1))
+    assert np.abs(g["B"][..., 0] - 0.5).max() > 0.4   # the fixture is far from the degenerate 0.5/0.5 answer
+    with pytest.raises(ValueError):
+        lr_rows_from_sklearn(np.zeros((2, 5)), np.zeros(2), 3)
+
+
 def test_G1_rejects_C_multiple_of_M(oracle):
     X = np.zeros((2, 40), dtype=np.int8)
     with pytest.raises(ValueError):

@@ -102,6 +102,19 @@ def test_restricted_unpickler_refuses_code():
             return (os.system, ("true",))
     with pytest.raises(pickle.UnpicklingError):
         refpickle.load_reference_pickle(io.BytesIO(pickle.dumps(E())))
+    # protocol >= 4 walks dotted attribute paths below an allowed root: refused, as is any torch / sklearn
+    # global that is not one of the classes the converter reads
+    def stack_global(module, name, arg):
+        return (b"\x80\x04" + b"\x8c" + bytes([len(module)]) + module.encode() + b"\x8c" + bytes([len(name)]) + name.encode() +
+                b"\x93" + b"\x8c" + bytes([len(arg)]) + arg.encode() + b"\x85R.")
+    for module, name in [("torch.serialization", "os.path.basename"), ("sklearn.base", "platform.os.path.basename"),
+                         ("numpy", "testing._private.utils.os.path.basename"), ("torch.serialization", "load"),
+                         ("torch", "load"), ("torch.hub", "load")]:
+        with pytest.raises(pickle.UnpicklingError):
+            refpickle.load_reference_pickle(io.BytesIO(stack_global(module, name, "/tmp/x")))
+    # a sklearn global outside the estimator list is never imported: it becomes a Stub (constructed, not executed)
+    got = refpickle.load_reference_pickle(io.BytesIO(stack_global("sklearn.utils", "check_array", "/tmp/x")))
+    assert isinstance(got, refpickle.Stub)
 
 
 def _fake_reference_modules():
