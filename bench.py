@@ -107,6 +107,8 @@ def main():
             raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if rank != 0:
+        os.dup2(2, 1)   # only rank 0 owns stdout (see the end of main)
 
     cfg = dict(synth.CHR22)
     data = synth.synthetic_model(seed=0, n_rounds=100, **cfg)
@@ -238,10 +240,14 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         res["cpu_baseline"] = _cpu_baseline(args, data, X, out)
-    if rank == 0:
-        print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    # RCCL prints a version banner to STDOUT from a library destructor at process exit (after anything Python can
+    # print): point fd 1 at stderr from here on, on every rank, so the JSON line stays the last line of stdout
+    os.dup2(2, 1)
 
 
 def _e2e(model, X, steps, out_dev):

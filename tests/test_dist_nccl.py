@@ -70,6 +70,7 @@ def test_bench_force_dist_runs_the_rccl_path_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--haps", "512",
                         "--cpu-seconds", "0", "--e2e-steps", "0"], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-4000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("{"), r.stdout[-500:]   # the JSON line is the last line
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["dist_backend"] == "nccl" and line["value"] > 0
     assert isinstance(line["label_checksum"], int)
