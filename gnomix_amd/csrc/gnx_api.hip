@@ -7,6 +7,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <thread>
 #include <utility>
 
 #include "gnx_internal.h"
@@ -758,6 +759,7 @@ static void read_tune(gnx_tune& t) {
   if (const char* e = std::getenv("GNX_LR_TUNE")) std::sscanf(e, "%d,%d", &t.lr_mt, &t.lr_waves);
   t.lr_flags = geti("GNX_LR_FLAGS", 0);
   t.sm_nw = geti("GNX_SM_NW", 0);
+  t.sm_pair = geti("GNX_SM_PAIR", 1);
   if (const char* e = std::getenv("GNX_SM_TUNE")) std::sscanf(e, "%d,%d", &t.smf_rpl, &t.smf_nw);
   t.forest_threads = geti("GNX_FOREST_T", 0);
   if (const char* e = std::getenv("GNX_HOST_BATCH")) t.host_batch = std::atoll(e);
@@ -798,6 +800,12 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {ctx->ev_in[0], ctx->ev_in[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_out[0], ctx->ev_out[1]})
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
+  if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
+  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu})
+    if (b->p) (void)hipFree(b->p);
   for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal, &ctx->ws_marg})
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1157,32 +1165,185 @@ int gnx_smooth_predict(gnx_model* m, const void* B, int b_is_f64, int64_t N, flo
   return GNX_OK;
 }
 
+// ---- host-pointer inference: H2D of batch i+1, kernels of batch i and D2H of batch i-1 run on three streams ------------
+static int pipe_init(gnx_ctx* ctx) {
+  if (ctx->s_in) return GNX_OK;
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+  for (int b = 0; b < 2; ++b) {
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_in[b], hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_out[b], hipEventDisableTiming));
+  }
+  return GNX_OK;
+}
+
+// src = X (N, ld) int8, or with `packed` the 2-bit matrix (N, ld) of gnx_pack_x.  Batches alternate between the two halves of
+// the staging workspaces; with page-locked host memory (gnx_host_alloc) the three streams genuinely overlap, with pageable
+// memory the runtime's own staging serialises part of it (still correct).
+static int infer_host(gnx_model* m, const void* src, bool packed, int64_t N, int64_t ld, float* p32, double* p64, int32_t* lab) {
+  gnx_ctx* ctx = m->ctx;
+  const int64_t C = m->info.C;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t WA = (size_t)m->info.W * m->info.A, Wn = (size_t)m->info.W;
+  const int64_t row_bytes = packed ? (C + 3) / 4 : C;
+  // batch: whole individuals, ~1 GiB of staged input at most; when overlapping, at least ~4 batches so the pipeline fills
+  int64_t nb = ((int64_t)1 << 30) / std::max<int64_t>(ld, 1);
+  const bool overlap = ctx->tune.h2d_overlap != 0;
+  if (overlap && N >= 2048) nb = std::min<int64_t>(nb, std::max<int64_t>(512, (N + 3) / 4));
+  if (ctx->tune.host_batch > 0) nb = ctx->tune.host_batch;
+  nb = std::max<int64_t>(2, nb & ~(int64_t)1);
+  nb = std::min(N + (N & 1), nb);
+  const int nbuf = (overlap && N > nb) ? 2 : 1;
+  int rc;
+  if (nbuf == 2 && (rc = pipe_init(ctx)) != GNX_OK) return rc;
+  const int64_t ldx_dev = packed ? ((C + 15) / 16) * 16 : ld;  // unpacked rows get a 16-byte aligned stride
+  const size_t in_bytes = (((size_t)nb * ld + 64) + 255) & ~(size_t)255;
+  gnx_devbuf& wsin = packed ? ctx->ws_pk : ctx->ws_x;
+  if ((rc = ws_reserve(ctx, wsin, in_bytes * nbuf)) != GNX_OK) return rc;
+  if (packed && (rc = ws_reserve(ctx, ctx->ws_xu, (size_t)nb * ldx_dev + 256)) != GNX_OK) return rc;
+  const size_t p32_b = (nb * WA * 4 + 255) & ~(size_t)255, p64_b = (nb * WA * 8 + 255) & ~(size_t)255, lab_b = (nb * Wn * 4 + 255) & ~(size_t)255;
+  if ((rc = ws_reserve(ctx, ctx->ws_p32, p32_b * nbuf)) != GNX_OK) return rc;
+  if (p64 && (rc = ws_reserve(ctx, ctx->ws_p64, p64_b * nbuf)) != GNX_OK) return rc;
+  if (lab && (rc = ws_reserve(ctx, ctx->ws_lab, lab_b * nbuf)) != GNX_OK) return rc;
+  // the workspaces gnx_infer_dev grows (B, margins, last row) must not be reallocated while a copy stream is busy: size them now
+  {
+    const bool f64 = (m->info.smooth_kind == GNX_SMOOTH_CRF);
+    if ((rc = ws_reserve(ctx, f64 ? ctx->ws_b64 : ctx->ws_b32, nb * WA * (f64 ? 8 : 4))) != GNX_OK) return rc;
+  }
+  hipStream_t sc = ctx->stream, si = nbuf == 2 ? ctx->s_in : ctx->stream, so = nbuf == 2 ? ctx->s_out : ctx->stream;
+  const uint8_t* hsrc = (const uint8_t*)src;
+  const int64_t n_batches = (N + nb - 1) / nb;
+  auto issue_h2d = [&](int64_t i) -> int {
+    const int b = (int)(i % nbuf);
+    const int64_t n0 = i * nb, n = std::min(nb, N - n0);
+    if (nbuf == 2 && i >= 2) HIPCHK(ctx, hipStreamWaitEvent(si, ctx->ev_done[b], 0));  // kernels of batch i-2 have read this half
+    HIPCHK(ctx, hipMemcpyAsync((char*)wsin.p + (size_t)b * in_bytes, hsrc + (size_t)n0 * ld, (size_t)(n - 1) * ld + row_bytes,
+                               hipMemcpyHostToDevice, si));
+    if (nbuf == 2) HIPCHK(ctx, hipEventRecord(ctx->ev_in[b], si));
+    return GNX_OK;
+  };
+  if ((rc = issue_h2d(0)) != GNX_OK) return rc;
+  for (int64_t i = 0; i < n_batches; ++i) {
+    const int b = (int)(i % nbuf);
+    const int64_t n0 = i * nb, n = std::min(nb, N - n0);
+    if (nbuf == 2) {
+      HIPCHK(ctx, hipStreamWaitEvent(sc, ctx->ev_in[b], 0));
+      if (i >= 2) HIPCHK(ctx, hipStreamWaitEvent(sc, ctx->ev_out[b], 0));  // outputs of batch i-2 have left this half
+    }
+    const int8_t* dX = (const int8_t*)((char*)wsin.p + (size_t)b * in_bytes);
+    int64_t ldx = ld;
+    if (packed) {
+      HIPCHK(ctx, gnx_launch_unpack2((const uint8_t*)dX, n, ld, C, (int8_t*)ctx->ws_xu.p, ldx_dev, sc));
+      dX = (const int8_t*)ctx->ws_xu.p;
+      ldx = ldx_dev;
+    }
+    float* dp32 = (float*)((char*)ctx->ws_p32.p + (size_t)b * p32_b);
+    double* dp64 = p64 ? (double*)((char*)ctx->ws_p64.p + (size_t)b * p64_b) : nullptr;
+    int32_t* dlab = lab ? (int32_t*)((char*)ctx->ws_lab.p + (size_t)b * lab_b) : nullptr;
+    if ((rc = gnx_infer_dev(m, dX, n, ldx, dp32, dp64, dlab)) != GNX_OK) return rc;
+    if (nbuf == 2) HIPCHK(ctx, hipEventRecord(ctx->ev_done[b], sc));
+    // the next batch's input goes out BEFORE this batch's outputs are awaited (pageable D2H blocks the host thread)
+    if (i + 1 < n_batches && (rc = issue_h2d(i + 1)) != GNX_OK) return rc;
+    if (nbuf == 2) HIPCHK(ctx, hipStreamWaitEvent(so, ctx->ev_done[b], 0));
+    if (p32) HIPCHK(ctx, hipMemcpyAsync(p32 + n0 * WA, dp32, n * WA * 4, hipMemcpyDeviceToHost, so));
+    if (p64) HIPCHK(ctx, hipMemcpyAsync(p64 + n0 * WA, dp64, n * WA * 8, hipMemcpyDeviceToHost, so));
+    if (lab) HIPCHK(ctx, hipMemcpyAsync(lab + n0 * Wn, dlab, n * Wn * 4, hipMemcpyDeviceToHost, so));
+    if (nbuf == 2) HIPCHK(ctx, hipEventRecord(ctx->ev_out[b], so));
+    else HIPCHK(ctx, hipStreamSynchronize(sc));
+  }
+  if (nbuf == 2) {
+    HIPCHK(ctx, hipStreamSynchronize(so));
+    HIPCHK(ctx, hipStreamSynchronize(si));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(sc));
+  return GNX_OK;
+}
+
 int gnx_infer(gnx_model* m, const int8_t* X, int64_t N, int64_t ldx, float* p32, double* p64, int32_t* lab) {
   if (!m) return GNX_EINVAL;
   gnx_ctx* ctx = m->ctx;
   if (N < 0 || ldx < m->info.C || (N > 0 && !X)) return fail(ctx, GNX_EINVAL, "infer: bad X / N / ldx");
   if (N == 0) return GNX_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  const size_t WA = (size_t)m->info.W * m->info.A, Wn = (size_t)m->info.W;
-  const int64_t nb = hap_batch(m, N, ldx);
-  int rc;
-  if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)nb * ldx + 64)) != GNX_OK) return rc;
-  if ((rc = ws_reserve(ctx, ctx->ws_p32, nb * WA * 4)) != GNX_OK) return rc;
-  if (p64 && (rc = ws_reserve(ctx, ctx->ws_p64, nb * WA * 8)) != GNX_OK) return rc;
-  if (lab && (rc = ws_reserve(ctx, ctx->ws_lab, nb * Wn * 4)) != GNX_OK) return rc;
-  for (int64_t n0 = 0; n0 < N; n0 += nb) {
-    const int64_t n = std::min(nb, N - n0);
-    const size_t xbytes = (size_t)(n - 1) * ldx + m->info.C;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_x.p, X + n0 * ldx, xbytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = gnx_infer_dev(m, (const int8_t*)ctx->ws_x.p, n, ldx, (float*)ctx->ws_p32.p,
-                       p64 ? (double*)ctx->ws_p64.p : nullptr, lab ? (int32_t*)ctx->ws_lab.p : nullptr);
-    if (rc != GNX_OK) return rc;
-    if (p32) HIPCHK(ctx, hipMemcpyAsync(p32 + n0 * WA, ctx->ws_p32.p, n * WA * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (p64) HIPCHK(ctx, hipMemcpyAsync(p64 + n0 * WA, ctx->ws_p64.p, n * WA * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (lab) HIPCHK(ctx, hipMemcpyAsync(lab + n0 * Wn, ctx->ws_lab.p, n * Wn * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return infer_host(m, X, false, N, ldx, p32, p64, lab);
+}
+
+// ---- 2-bit packed input ------------------------------------------------------------------------------------------------
+int64_t gnx_packed_row_bytes(int64_t C) { return C <= 0 ? 0 : ((C + 15) / 16) * 4; }
+
+int gnx_pack_x(const int8_t* X, int64_t N, int64_t ldx, int64_t C, uint8_t* P, int64_t ldp, int n_threads) {
+  if (N < 0 || C <= 0 || ldx < C || ldp < (C + 3) / 4 || (N > 0 && (!X || !P))) return GNX_EINVAL;
+  if (N == 0) return GNX_OK;
+  int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+  nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, N / 16));
+  std::vector<int> bad((size_t)nt, 0);
+  auto work = [&](int t) {
+    const int64_t r0 = N * t / nt, r1 = N * (t + 1) / nt;
+    for (int64_t n = r0; n < r1; ++n) {
+      const int8_t* x = X + n * ldx;
+      uint8_t* p = P + n * ldp;
+      int64_t j = 0;
+      uint64_t flag = 0;
+      for (; j + 8 <= C; j += 8) {  // 8 SNPs -> 2 bytes
+        uint64_t v;
+        std::memcpy(&v, x + j, 8);
+        flag |= v & 0xFCFCFCFCFCFCFCFCull;
+        v |= v >> 6;                      // byte pairs: fields 0,1 in the low nibble of bytes 0, 2, 4, 6
+        v &= 0x000F000F000F000Full;
+        v |= v >> 12;                     // nibble pairs: one full byte in bytes 0 and 4
+        const uint16_t o = (uint16_t)((v & 0xFFu) | ((v >> 24) & 0xFF00u));
+        std::memcpy(p + (j >> 2), &o, 2);
+      }
+      for (; j < C; j += 4) {
+        uint8_t o = 0;
+        for (int k = 0; k < 4 && j + k < C; ++k) {
+          const uint8_t v = (uint8_t)x[j + k];
+          flag |= v & 0xFCu;
+          o |= (uint8_t)((v & 3u) << (2 * k));
+        }
+        p[j >> 2] = o;
+      }
+      for (int64_t b = (C + 3) / 4; b < std::min<int64_t>(ldp, gnx_packed_row_bytes(C)); ++b) p[b] = 0;  // canonical stride: zero tail
+      if (flag) bad[(size_t)t] = 1;
+    }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt);
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
   }
+  for (int b : bad)
+    if (b) return GNX_EINVAL;  // a value outside {0,1,2,3}: not representable in 2 bits
   return GNX_OK;
+}
+
+int gnx_unpack_x_dev(gnx_ctx* ctx, const uint8_t* dP, int64_t N, int64_t ldp, int64_t C, int8_t* dX, int64_t ldx) {
+  if (!ctx) return GNX_EINVAL;
+  if (N < 0 || C <= 0 || ldx < C || ldp < (C + 3) / 4 || (N > 0 && (!dP || !dX))) return fail(ctx, GNX_EINVAL, "unpack_x: bad arguments");
+  HIPCHK(ctx, gnx_launch_unpack2(dP, N, ldp, C, dX, ldx, ctx->stream));
+  return GNX_OK;
+}
+
+int gnx_infer_packed(gnx_model* m, const uint8_t* P, int64_t N, int64_t ldp, float* p32, double* p64, int32_t* lab) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (N < 0 || ldp < (m->info.C + 3) / 4 || (N > 0 && !P)) return fail(ctx, GNX_EINVAL, "infer_packed: bad P / N / ldp");
+  if (N == 0) return GNX_OK;
+  return infer_host(m, P, true, N, ldp, p32, p64, lab);
+}
+
+int gnx_infer_packed_dev(gnx_model* m, const uint8_t* dP, int64_t N, int64_t ldp, float* d_p32, double* d_p64, int32_t* d_lab) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (N < 0 || ldp < (m->info.C + 3) / 4 || (N > 0 && !dP)) return fail(ctx, GNX_EINVAL, "infer_packed: bad P / N / ldp");
+  if (N == 0) return GNX_OK;
+  const int64_t ldx = ((m->info.C + 15) / 16) * 16;
+  int rc = ws_reserve(ctx, ctx->ws_xu, (size_t)N * ldx + 256);
+  if (rc != GNX_OK) return rc;
+  HIPCHK(ctx, gnx_launch_unpack2(dP, N, ldp, m->info.C, (int8_t*)ctx->ws_xu.p, ldx, ctx->stream));
+  return gnx_infer_dev(m, (const int8_t*)ctx->ws_xu.p, N, ldx, d_p32, d_p64, d_lab);
 }
 
 int gnx_smooth_rows(gnx_model* m, const float* rows, int64_t R, float* proba) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct gnx_tune {
   int lr_mt = 0, lr_waves = 0;          // GNX_LR_TUNE="mt,waves": tile shape of the logistic pass
   int lr_flags = 0;                     // GNX_LR_FLAGS: ablation switches
   int sm_nw = 0;                        // GNX_SM_NW: waves per block of the rank smoother
+  int sm_pair = 1;                      // GNX_SM_PAIR=0: one tree at a time per lane in the rank smoother (default: two)
   int smf_rpl = 0, smf_nw = 0;          // GNX_SM_TUNE="rpl,nw": float smoother
   int forest_threads = 0;               // GNX_FOREST_T
   int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
@@ -53,6 +55,11 @@ struct gnx_ctx {
   int n_cu = 256;
   // grow-only device workspaces (host-pointer entry points stage through these)
   gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair, ws_y0, ws_cal, ws_marg;
+  // host-pointer pipeline (gnx_infer / gnx_infer_packed): copy-in and copy-out streams next to the compute stream, created on
+  // first use; buffers alternate between two halves of the staging workspaces
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+  gnx_devbuf ws_pk, ws_xu;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -323,6 +330,7 @@ size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width);
 hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
 size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
 hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
+hipError_t gnx_launch_unpack2(const uint8_t* P, int64_t N, int64_t ldp, int64_t C, int8_t* X, int64_t ldx, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);
 hipError_t gnx_launch_base_forest(const ForestLaunch& L, const gnx_tune& tune, hipStream_t s);

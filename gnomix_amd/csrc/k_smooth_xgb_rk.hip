@@ -159,19 +159,111 @@ __device__ __forceinline__ void step_sel_rk(uint32_t* j, uint32_t root, const ui
   }
 }
 
+// Level 0 for a fresh walk: j = 2 + (r >= rank field) straight from inline constants (v_addc_co_u32 VOP3: 1 + 1 + carry) —
+// no "j = 1" initialisation per tree and segment — and the level-1 node picked by the same mask.
+template <int R>
+__device__ __forceinline__ void step_first_rk(uint32_t* j, uint32_t root, const uint32_t* r, uint32_t lo, uint32_t hi, uint32_t* nxt) {
+  if constexpr (R == 1) {
+    uint64_t c0;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %[x0], %[lo], %[hi], %[c0]\n\t"
+        "v_addc_co_u32_e64 %[j0], %[c0], 1, 1, %[c0]"
+        : [j0] "=&v"(j[0]), [x0] "=&v"(nxt[0]), [c0] "=&s"(c0)
+        : [n] "v"(root), [r0] "v"(r[0]), [lo] "v"(lo), [hi] "v"(hi));
+  } else if constexpr (R == 2) {
+    uint64_t c0, c1;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c1], %[n], %[r1] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32 %[x0], %[lo], %[hi], %[c0]\n\t"
+        "v_cndmask_b32 %[x1], %[lo], %[hi], %[c1]\n\t"
+        "v_addc_co_u32_e64 %[j0], %[c0], 1, 1, %[c0]\n\t"
+        "v_addc_co_u32_e64 %[j1], %[c1], 1, 1, %[c1]"
+        : [j0] "=&v"(j[0]), [j1] "=&v"(j[1]), [x0] "=&v"(nxt[0]), [x1] "=&v"(nxt[1]), [c0] "=&s"(c0), [c1] "=&s"(c1)
+        : [n] "v"(root), [r0] "v"(r[0]), [r1] "v"(r[1]), [lo] "v"(lo), [hi] "v"(hi));
+  } else if constexpr (R == 3) {
+    uint64_t c0, c1, c2;
+    asm("v_cmp_le_u32_sdwa %[c0], %[n], %[r0] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c1], %[n], %[r1] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cmp_le_u32_sdwa %[c2], %[n], %[r2] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cndmask_b32 %[x0], %[lo], %[hi], %[c0]\n\t"
+        "v_cndmask_b32 %[x1], %[lo], %[hi], %[c1]\n\t"
+        "v_cndmask_b32 %[x2], %[lo], %[hi], %[c2]\n\t"
+        "v_addc_co_u32_e64 %[j0], %[c0], 1, 1, %[c0]\n\t"
+        "v_addc_co_u32_e64 %[j1], %[c1], 1, 1, %[c1]\n\t"
+        "v_addc_co_u32_e64 %[j2], %[c2], 1, 1, %[c2]"
+        : [j0] "=&v"(j[0]), [j1] "=&v"(j[1]), [j2] "=&v"(j[2]), [x0] "=&v"(nxt[0]), [x1] "=&v"(nxt[1]), [x2] "=&v"(nxt[2]),
+          [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
+        : [n] "v"(root), [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [lo] "v"(lo), [hi] "v"(hi));
+  } else if constexpr (R == 4) {
+    step_first_rk<2>(j, root, r, lo, hi, nxt);
+    step_first_rk<2>(j + 2, root, r + 2, lo, hi, nxt + 2);
+  } else if constexpr (R == 5) {
+    step_first_rk<3>(j, root, r, lo, hi, nxt);
+    step_first_rk<2>(j + 3, root, r + 3, lo, hi, nxt + 3);
+  } else {
+    static_assert(R == 6, "segments per strip");
+    step_first_rk<3>(j, root, r, lo, hi, nxt);
+    step_first_rk<3>(j + 3, root, r + 3, lo, hi, nxt + 3);
+  }
+}
+
+// TWO trees side by side for the R segments of a lane (D >= 2): 2R independent chains keep more LDS reads in flight per
+// wave, so the LDS pipe and the VALU overlap better; the leaves are still added in tree order (tb0 before tb1).
+template <int D, int R>
+__device__ __forceinline__ void walk_rk_pair(const uint8_t* tb0, const uint8_t* tb1, const uint8_t* rb, float* psum) {
+  static_assert(D >= 2, "pair walk needs the 16-byte tree top");
+  uint32_t j[2 * R], nd[2 * R], r[2 * R];
+  const uint4 top0 = *reinterpret_cast<const uint4*>(tb0);  // words 0..3: (unused, root, left child, right child)
+  const uint4 top1 = *reinterpret_cast<const uint4*>(tb1);
+#pragma unroll
+  for (int k = 0; k < R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (top0.y & 0xffffu));
+#pragma unroll
+  for (int k = 0; k < R; ++k) r[R + k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (top1.y & 0xffffu));
+  step_first_rk<R>(j, top0.y, r, top0.z, top0.w, nd);
+  step_first_rk<R>(j + R, top1.y, r + R, top1.z, top1.w, nd + R);
+#pragma unroll
+  for (int k = 0; k < 2 * R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + (k % R) * (WS * 2) + (nd[k] & 0xffffu));
+  step_rk<R>(j, nd, r);
+  step_rk<R>(j + R, nd + R, r + R);
+#pragma unroll
+  for (int d = 2; d < D; ++d) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) nd[k] = reinterpret_cast<const uint32_t*>(tb0)[j[k]];
+#pragma unroll
+    for (int k = 0; k < R; ++k) nd[R + k] = reinterpret_cast<const uint32_t*>(tb1)[j[R + k]];
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + (k % R) * (WS * 2) + (nd[k] & 0xffffu));
+    step_rk<R>(j, nd, r);
+    step_rk<R>(j + R, nd + R, r + R);
+  }
+  float l0[R], l1[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) l0[k] = reinterpret_cast<const float*>(tb0)[j[k]];
+#pragma unroll
+  for (int k = 0; k < R; ++k) l1[k] = reinterpret_cast<const float*>(tb1)[j[R + k]];
+#pragma unroll
+  for (int k = 0; k < R; ++k) psum[k] += l0[k];
+#pragma unroll
+  for (int k = 0; k < R; ++k) psum[k] += l1[k];
+}
+
 // D levels for the R segments of a lane: tb = the tree's 2^D node words + 2^D leaves (LDS), rb = the lane's origin in
 // its strip (LDS); segment k sits 64 windows = 128 bytes further
 template <int D, int R>
 __device__ __forceinline__ void walk_rk(const uint8_t* tb, const uint8_t* rb, float* psum) {
   uint32_t j[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) j[k] = 1;
   uint32_t nd[R], r[R];
+  if constexpr (D < 2) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) j[k] = 1;
+  }
   if constexpr (D >= 2) {
     const uint4 top = *reinterpret_cast<const uint4*>(tb);  // words 0..3: (unused, root, left child, right child)
 #pragma unroll
     for (int k = 0; k < R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (top.y & 0xffffu));
-    step_sel_rk<R>(j, top.y, r, top.z, top.w, nd);
+    step_first_rk<R>(j, top.y, r, top.z, top.w, nd);
 #pragma unroll
     for (int k = 0; k < R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (nd[k] & 0xffffu));
     step_rk<R>(j, nd, r);
@@ -199,7 +291,7 @@ __device__ __forceinline__ float walk_rk_rt(const uint8_t* tb, const uint8_t* rb
 }
 
 // One wave = one haplotype x RPL consecutive 64-window segments; NWAVE haplotypes per block.  DT = depth (0 = runtime).
-template <int RPL, int NWAVE, int DT>
+template <int RPL, int NWAVE, int DT, bool PAIR = false>
 __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int THREADS = NWAVE * 64;
@@ -304,7 +396,14 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
       cur_class = cls;
     }
     const int nt = L.d.rk_group_tree0[g + 1] - L.d.rk_group_tree0[g];
-    for (int t = 0; t < nt; ++t) {
+    int t = 0;
+    if constexpr (DT >= 2 && PAIR) {
+      for (; t + 1 < nt; t += 2) {
+        const uint8_t* tb = cur + (size_t)t * tree_bytes;
+        walk_rk_pair<DT, RPL>(tb, tb + tree_bytes, rowbase[0], psum);
+      }
+    }
+    for (; t < nt; ++t) {
       const uint8_t* tb = cur + (size_t)t * tree_bytes;
       if constexpr (DT > 0) walk_rk<DT, RPL>(tb, rowbase[0], psum);
       else {
@@ -355,11 +454,16 @@ size_t lds_bytes(const SmoothXGBDev& d, int A) {
 }
 
 template <int RPL, int NWAVE>
-hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
+hipError_t launch(const SmoothXGBLaunch& L, bool pair, hipStream_t s) {
   const dim3 grid((unsigned)((L.W + RPL * WS - 1) / (RPL * WS)), (unsigned)((L.N + NWAVE - 1) / NWAVE));
   const size_t lds = lds_bytes<NWAVE>(L.d, L.A);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
-  if (L.d.D == 4) {
+  if (L.d.D == 4 && pair && RPL <= 3) {
+    if constexpr (RPL <= 3) {
+      GNX_LDS_OPTIN(lds, k_smooth_xgb_rk<RPL, NWAVE, 4, true>);
+      hipLaunchKernelGGL((k_smooth_xgb_rk<RPL, NWAVE, 4, true>), grid, dim3(NWAVE * 64), lds, s, L);
+    }
+  } else if (L.d.D == 4) {
     GNX_LDS_OPTIN(lds, k_smooth_xgb_rk<RPL, NWAVE, 4>);
     hipLaunchKernelGGL((k_smooth_xgb_rk<RPL, NWAVE, 4>), grid, dim3(NWAVE * 64), lds, s, L);
   } else {
@@ -374,6 +478,7 @@ hipError_t launch(const SmoothXGBLaunch& L, hipStream_t s) {
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
   const int rpl = L.d.rk_rpl;  // fixed at model load: the node offsets encode the strip stride
+  const bool pair = tune.sm_pair != 0;  // two trees side by side per lane
   int nw = tune.sm_nw;
   if (nw != 2 && nw != 4 && nw != 8) {
     // as many waves per CU as the LDS allows: 8-wave blocks unless 4-wave blocks pack the 160 KB better
@@ -383,7 +488,7 @@ hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tu
     if (L.N < 8) nw = L.N < 3 ? 2 : 4;
   }
 #define GNX_SM_CASE(R_) \
-  if (rpl == R_) return nw == 8 ? launch<R_, 8>(L, s) : (nw == 4 ? launch<R_, 4>(L, s) : launch<R_, 2>(L, s));
+  if (rpl == R_) return nw == 8 ? launch<R_, 8>(L, pair, s) : (nw == 4 ? launch<R_, 4>(L, pair, s) : launch<R_, 2>(L, pair, s));
   GNX_SM_CASE(1) GNX_SM_CASE(2) GNX_SM_CASE(3) GNX_SM_CASE(4) GNX_SM_CASE(5) GNX_SM_CASE(6)
 #undef GNX_SM_CASE
   return hipErrorInvalidValue;

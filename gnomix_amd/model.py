@@ -332,17 +332,64 @@ class DeviceModel:
                                                    lab.ctypes.data if want_labels else None))
         return p, lab
 
-    def infer(self, X, want_proba=True, want_labels=True, proba_dtype=None):
+    def _outs(self, N, want_proba, want_labels, proba_dtype, out):
+        """output arrays of the host-pointer entry points; `out=(proba, labels)` lets the caller supply them (e.g. page-locked
+        arrays from Context.pinned_empty, reused across calls: D2H then runs at link rate instead of through pageable staging)"""
+        native64 = self.data.smooth_kind == "crf" or getattr(self, "calibrated", False)
+        pd = np.dtype(proba_dtype or (np.float64 if native64 else np.float32))
+        p = lab = None
+        if out is not None:
+            p, lab = out
+            if p is not None and (p.shape != (N, self.W, self.A) or p.dtype not in (np.float32, np.float64) or not p.flags.c_contiguous):
+                raise ValueError("out[0] must be a C-contiguous float32/float64 (N, W, A) array")
+            if lab is not None and (lab.shape != (N, self.W) or lab.dtype != np.int32 or not lab.flags.c_contiguous):
+                raise ValueError("out[1] must be a C-contiguous int32 (N, W) array")
+            if p is not None:
+                pd = p.dtype
+        if p is None and want_proba:
+            p = np.empty((N, self.W, self.A), pd)
+        if lab is None and want_labels:
+            lab = np.empty((N, self.W), np.int32)
+        return p, lab, pd
+
+    def infer(self, X, want_proba=True, want_labels=True, proba_dtype=None, out=None):
         X = self._x(X)
         N = X.shape[0]
-        native64 = self.data.smooth_kind == "crf" or getattr(self, "calibrated", False)
-        pd = proba_dtype or (np.float64 if native64 else np.float32)
-        p = np.empty((N, self.W, self.A), pd) if want_proba else None
-        lab = np.empty((N, self.W), np.int32) if want_labels else None
+        p, lab, pd = self._outs(N, want_proba, want_labels, proba_dtype, out)
+        want_proba, want_labels = p is not None, lab is not None
         p32 = p.ctypes.data if (want_proba and pd == np.float32) else None
         p64 = p.ctypes.data if (want_proba and pd == np.float64) else None
         self.ctx.check(self.lib.gnx_infer(self.h, X.ctypes.data, N, X.shape[1], p32, p64,
                                           lab.ctypes.data if want_labels else None))
+        return p, lab
+
+    # ---- 2-bit packed input (gnx_pack_x / gnx_infer_packed): a quarter of the bytes over the host link -------------
+    def pack_x(self, X, out=None, n_threads=0):
+        """int8 (N, C) {0,1,2} -> packed uint8 (N, gnx_packed_row_bytes(C)); `out` may be a page-locked array from
+        Context.pinned_empty.  Raises GnxError(-1) when X holds a value outside 0..3."""
+        X = self._x(X)
+        N = X.shape[0]
+        ldp = int(self.lib.gnx_packed_row_bytes(self.C))
+        if out is None:
+            out = self.ctx.pinned_empty((N, ldp), np.uint8)
+        if out.shape != (N, ldp) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be C-contiguous uint8 {(N, ldp)}")
+        rc = self.lib.gnx_pack_x(X.ctypes.data, N, X.shape[1], self.C, out.ctypes.data, ldp, int(n_threads))
+        if rc != _lib.GNX_OK:
+            raise _lib.GnxError(rc, "gnx_pack_x: a value outside {0, 1, 2, 3} cannot be packed in 2 bits")
+        return out
+
+    def infer_packed(self, P, N=None, want_proba=True, want_labels=True, proba_dtype=None, out=None):
+        P = np.ascontiguousarray(P, dtype=np.uint8)
+        if P.ndim != 2 or P.shape[1] < (self.C + 3) // 4:
+            raise ValueError(f"packed X must be (N, >= ceil(C/4) = {(self.C + 3) // 4}) uint8, got {P.shape}")
+        N = P.shape[0] if N is None else int(N)
+        p, lab, pd = self._outs(N, want_proba, want_labels, proba_dtype, out)
+        want_proba, want_labels = p is not None, lab is not None
+        p32 = p.ctypes.data if (want_proba and pd == np.float32) else None
+        p64 = p.ctypes.data if (want_proba and pd == np.float64) else None
+        self.ctx.check(self.lib.gnx_infer_packed(self.h, P.ctypes.data, N, P.shape[1], p32, p64,
+                                                 lab.ctypes.data if want_labels else None))
         return p, lab
 
     def smooth_rows(self, rows):

@@ -21,7 +21,8 @@
  *   - plain pointers and sizes only; the library never frees or keeps caller memory
  *     (gnx_model_load copies what it needs).
  *   - un-suffixed entry points take HOST pointers, are synchronous and stage through the context's
- *     device workspaces; *_dev entry points take DEVICE pointers (same device as the context), are
+ *     device workspaces (gnx_infer / gnx_infer_packed in batches, the copy-in of batch i+1, the kernels of
+ *     batch i and the copy-out of batch i-1 overlapped on three streams); *_dev entry points take DEVICE pointers (same device as the context), are
  *     asynchronous on the context stream (gnx_set_stream / gnx_synchronize) and never allocate
  *     when the workspace is already large enough.
  *   - one gnx_ctx per device; a context and its models are not thread-safe (the reference is
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 5
+#define GNX_ABI_VERSION 6
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -228,6 +229,25 @@ int gnx_infer(gnx_model* model, const int8_t* X, int64_t N, int64_t ldx, float* 
               int32_t* labels);
 int gnx_infer_dev(gnx_model* model, const int8_t* dX, int64_t N, int64_t ldx, float* d_proba_f32,
                   double* d_proba_f64, int32_t* d_labels);
+
+/* 2-bit packed haplotypes.  The reference's contract is int8 {0,1,2}, one byte per SNP (src/utils.py:153) and gnx_infer
+ * keeps accepting exactly that; whole genome it is 17.7 MB per haplotype, so the 63 GB/s host link bounds the host-pointer
+ * path at a few thousand haplotypes/s/GPU.  A caller that can hand over X as 2-bit fields moves a quarter of
+ * the bytes: SNP j of a row lives in bits 2*(j%4)..2*(j%4)+1 of byte j/4 (value = the int8 code, 0..3), rows ldp bytes apart
+ * (ldp >= ceil(C/4); gnx_packed_row_bytes(C) = the canonical stride, a multiple of 4, its tail zeroed by gnx_pack_x).
+ *   gnx_pack_x          host utility: int8 (N, ldx) -> packed (N, ldp) on n_threads host threads (<= 0: all cores, at most
+ *                       64); GNX_EINVAL if a value is outside 0..3.  Needs no context and no GPU.
+ *   gnx_infer_packed    gnx_infer on packed host input: batches are copied, widened on the device and run through the same
+ *                       kernels, H2D / kernels / D2H overlapped on three streams; results are bit-identical to gnx_infer's.
+ *   gnx_unpack_x_dev    the widening pass alone, on the context stream (device pointers).
+ *   gnx_infer_packed_dev  device-resident packed input. */
+int64_t gnx_packed_row_bytes(int64_t C);
+int gnx_pack_x(const int8_t* X, int64_t N, int64_t ldx, int64_t C, uint8_t* packed, int64_t ldp, int n_threads);
+int gnx_unpack_x_dev(gnx_ctx* ctx, const uint8_t* d_packed, int64_t N, int64_t ldp, int64_t C, int8_t* dX, int64_t ldx);
+int gnx_infer_packed(gnx_model* model, const uint8_t* packed, int64_t N, int64_t ldp, float* proba_f32, double* proba_f64,
+                     int32_t* labels);
+int gnx_infer_packed_dev(gnx_model* model, const uint8_t* d_packed, int64_t N, int64_t ldp, float* d_proba_f32,
+                         double* d_proba_f64, int32_t* d_labels);
 
 /* smoother.model.predict_proba on explicit rows (R, S*A) float32 -> (R, A) float32 (XGB only). */
 int gnx_smooth_rows(gnx_model* model, const float* rows, int64_t R, float* proba);

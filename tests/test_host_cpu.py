@@ -262,3 +262,32 @@ def test_bench_refuses_gpu_count_it_cannot_have():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], capture_output=True,
                        text=True, timeout=300, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_pack_x_roundtrip_and_validation():
+    """gnx_pack_x is a host-only utility (no context, no GPU): 4 SNPs per byte, SNP j in bits 2*(j%4).. of byte j/4"""
+    import gnomix_amd
+    lib = gnomix_amd.load_library()
+    rng = np.random.RandomState(0)
+    for Cn in (1, 3, 4, 5, 16, 17, 63, 64, 1001, 37_053):
+        N = 37
+        X = rng.randint(0, 3, size=(N, Cn)).astype(np.int8)
+        ldp = int(lib.gnx_packed_row_bytes(Cn))
+        assert ldp % 4 == 0 and ldp >= (Cn + 3) // 4
+        P = np.full((N, ldp), 255, np.uint8)
+        for threads in (1, 3):
+            assert lib.gnx_pack_x(X.ctypes.data, N, Cn, Cn, P.ctypes.data, ldp, threads) == 0
+            U = np.zeros((N, ldp * 4), np.int8)
+            for k in range(4):
+                U[:, k::4] = (P >> (2 * k)) & 3
+            assert np.array_equal(U[:, :Cn], X) and not U[:, Cn:].any()
+    Xs = np.zeros((4, 40), np.int8)                      # strided input rows (ldx > C)
+    Xs[:, :33] = rng.randint(0, 3, size=(4, 33))
+    P = np.zeros((4, 12), np.uint8)
+    assert lib.gnx_pack_x(Xs.ctypes.data, 4, 40, 33, P.ctypes.data, 12, 1) == 0
+    assert ((P[:, 8] >> 0) & 3).tolist() == Xs[:, 32].tolist()
+    X[5, 7] = 4                                           # not representable in 2 bits
+    assert lib.gnx_pack_x(X.ctypes.data, N, Cn, Cn, np.zeros((N, ldp), np.uint8).ctypes.data, ldp, 2) == gnomix_amd._lib.GNX_EINVAL
+    X[5, 7] = -1
+    assert lib.gnx_pack_x(X.ctypes.data, N, Cn, Cn, np.zeros((N, ldp), np.uint8).ctypes.data, ldp, 2) == gnomix_amd._lib.GNX_EINVAL
+    assert lib.gnx_pack_x(X.ctypes.data, N, Cn, Cn, P.ctypes.data, 3, 1) == gnomix_amd._lib.GNX_EINVAL   # ldp too small
