@@ -27,6 +27,10 @@ struct gnx_tune {
   int lr_bpc = 0, lr_want = 0;          // GNX_LR_BPC, GNX_LR_WANT: window ranges of the logistic pass
   int lr_mt = 0, lr_waves = 0;          // GNX_LR_TUNE="mt,waves": tile shape of the logistic pass
   int lr_flags = 0;                     // GNX_LR_FLAGS: ablation switches
+  int lr_dl = -1;                       // GNX_LR_DL: 1 = LDS-direct loads (k_base_logistic_i8_dl) always, 0 = never; default: for 2
+                                        // column tiles (A > 8 at the default context), where it measured 2.5 vs 3.1 ms (A = 12,
+                                        // chr22); with one column tile both kernels run at the same 1.14-1.16 ms
+  int lr_nbuf = 0;                      // GNX_LR_NBUF: ring slots of the LDS-direct kernel
   int sm_nw = 0;                        // GNX_SM_NW: waves per block of the rank smoother
   int sm_pair = 1;                      // GNX_SM_PAIR=0: one tree at a time per lane in the rank smoother (default: two)
   int smf_rpl = 0, smf_nw = 0;          // GNX_SM_TUNE="rpl,nw": float smoother
@@ -319,6 +323,7 @@ struct gnx_model {
 // kernel launchers (defined in the .hip files)
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,

@@ -40,18 +40,22 @@ def _lr_data(ga, C, M, A, ctx, seed):
 
 
 # ---------------------------------------------------------------- logistic base ------------------
-@pytest.fixture(params=["i8", "f64"])
+@pytest.fixture(params=["i8", "i8dl", "f64"])
 def lr_impl(request, monkeypatch):
-    """both arithmetic variants of the logistic pass: exact int8-limb fixed point (default) and f64 MFMA"""
-    monkeypatch.setenv("GNX_BASE_LR_IMPL", request.param)
-    return request.param
+    """every variant of the logistic pass on every geometry: exact int8-limb fixed point with register-staged loads
+    (k_base_logistic_i8), the same arithmetic with LDS-direct loads (k_base_logistic_i8_dl), and f64 MFMA.  Launch knobs are
+    read once per context, so each variant gets a context of its own."""
+    from gnomix_amd import _lib
+    monkeypatch.setenv("GNX_BASE_LR_IMPL", "f64" if request.param == "f64" else "i8")
+    monkeypatch.setenv("GNX_LR_DL", "1" if request.param == "i8dl" else "0")
+    return _lib.Context(0)
 
 
 def test_base_golden_G1(ga, oracle, lr_impl):
     g = load_golden("G1_lr.npz")
     d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=int(g["A"]), S=5, context=int(g["ctx"]), base_kind="logistic",
                         lr_coef=g["coef"], lr_intercept=g["intercept"])
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=lr_impl)
     b32, b64 = dev.base_predict(g["X"], want_f32=True, want_f64=True)
     assert np.max(np.abs(b64 - g["B"])) < 1e-12          # vs the REFERENCE's own output
     assert np.array_equal(np.argmax(b64, -1), np.argmax(g["B"], -1))
@@ -64,7 +68,7 @@ def test_base_golden_G15_binary(ga, lr_impl):
     g = load_golden("G15_lr_binary.npz")
     d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=2, S=5, context=int(g["ctx"]), base_kind="logistic",
                         lr_coef=g["coef"], lr_intercept=g["intercept"])
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=lr_impl)
     b32, b64 = dev.base_predict(g["X"], want_f32=True, want_f64=True)
     assert np.max(np.abs(b64 - g["B"])) < 1e-12
     assert np.array_equal(np.argmax(b64, -1), np.argmax(g["B"], -1))
@@ -87,7 +91,7 @@ def test_base_vs_oracle(ga, oracle, lr_impl, C, M, A, ctx, N):
     from gnomix_amd import synth
     d = _lr_data(ga, C, M, A, ctx, seed=C + A)
     X = synth.synthetic_X(N, C, seed=N, miss=0.03)
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=lr_impl)
     b32, b64 = dev.base_predict(X, want_f32=True, want_f64=True)
     ref = oracle.base_lr(X, M, ctx, d.lr_coef, d.lr_intercept)
     assert b64.shape == ref.shape
@@ -110,7 +114,7 @@ def test_base_transpose_detecting(ga, oracle, lr_impl):
     X = np.zeros((80, C), dtype=np.int8)
     for n in range(80):
         X[n, (n * 37) % C::(n + 3)] = 1 + (n % 2)
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=lr_impl)
     _, b64 = dev.base_predict(X)
     ref = oracle.base_lr(X, M, ctx, d.lr_coef, d.lr_intercept)
     assert np.max(np.abs(b64 - ref)) < 1e-13
