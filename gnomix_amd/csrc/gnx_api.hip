@@ -479,7 +479,7 @@ static int build_xgb(gnx_model* m, const gnx_model_desc* d) {
 // Forest trees use their own compact heap: 2^D node words (slot 0 unused) followed by 2^D float leaves.  A node word is
 // (SNP index within the window << 4) | left-mask, bit v of the mask = "a SNP of value v goes left": SNPs only take
 // the values 0..3, so `float(v) < threshold` and the missing code's default direction fold into 4 bits at load time.
-static void forest_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint32_t* nodes,
+static void forest_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint32_t off, uint32_t* nodes,
                         float* leaves) {
   const bool leaf = d->fb_left[o + nid] == -1;
   if (depth == D) {  // D is the ensemble's maximum depth: nid is a leaf here
@@ -495,11 +495,11 @@ static void forest_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_
       const bool left = (v == d->fb_missing) ? dl : ((float)v < thr);
       mask |= (left ? 1u : 0u) << v;
     }
-    word = ((uint32_t)d->fb_feat[o + nid] << 4) | mask;
+    word = (((uint32_t)d->fb_feat[o + nid] + off) << 4) | mask;  // off = window start mod 16 (the tile's words are anchored globally)
   }
   nodes[j] = word;
-  forest_fill(d, o, leaf ? nid : d->fb_left[o + nid], 2 * j, depth + 1, D, nodes, leaves);
-  forest_fill(d, o, leaf ? nid : d->fb_right[o + nid], 2 * j + 1, depth + 1, D, nodes, leaves);
+  forest_fill(d, o, leaf ? nid : d->fb_left[o + nid], 2 * j, depth + 1, D, off, nodes, leaves);
+  forest_fill(d, o, leaf ? nid : d->fb_right[o + nid], 2 * j + 1, depth + 1, D, off, nodes, leaves);
 }
 
 static int build_forest(gnx_model* m, const gnx_model_desc* d) {
@@ -538,7 +538,7 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
   if (D > 8) return fail(ctx, GNX_EUNSUPPORTED, "forest base: tree depth > 8");
   if (C < 16) return fail(ctx, GNX_EUNSUPPORTED, "forest base: fewer than 16 SNPs");
   const int tree_bytes = 8 << D;
-  const int max_words = (int)((M_ + rem + 15) / 16);
+  const int max_words = gnx_forest_ring_words(M_ + rem);
   if (gnx_forest_lds_bytes(A, max_words, max_trees, tree_bytes, 64) > (size_t)160 * 1024)
     return fail(ctx, GNX_EUNSUPPORTED, "forest base: one window's trees and SNPs exceed the 160 KB LDS");
 
@@ -554,7 +554,8 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
       for (int32_t t = t0; t < t1; ++t) {
         if (A > 2 && d->fb_tree_class[t] != c) continue;
         uint8_t* tb = packed.data() + k * tree_bytes;
-        forest_fill(d, d->fb_tree_off[t], 0, 1, 0, D, reinterpret_cast<uint32_t*>(tb), reinterpret_cast<float*>(tb + ((size_t)4 << D)));
+        forest_fill(d, d->fb_tree_off[t], 0, 1, 0, D, (uint32_t)((w * M) & 15), reinterpret_cast<uint32_t*>(tb),
+                    reinterpret_cast<float*>(tb + ((size_t)4 << D)));
         ++k;
       }
     }
@@ -572,7 +573,7 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
 // ------------------------------------------------------------------------------------------------
 // model preparation: random-forest base — sklearn tree arrays -> mask-node heaps + expanded leaf rows
 // ------------------------------------------------------------------------------------------------
-static void rf_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint32_t* nodes,
+static void rf_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, int D, uint32_t off, uint32_t* nodes,
                     double* leafval) {
   const bool leaf = d->rf_left[o + nid] == -1;
   if (depth == D) {
@@ -583,11 +584,11 @@ static void rf_fill(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j,
   if (!leaf) {
     uint32_t mask = 0;
     for (int v = 0; v < 4; ++v) mask |= (((double)(float)v <= d->rf_thr[o + nid]) ? 1u : 0u) << v;  // _tree.pyx: X[i, f] <= threshold
-    word = ((uint32_t)d->rf_feat[o + nid] << 4) | mask;
+    word = (((uint32_t)d->rf_feat[o + nid] + off) << 4) | mask;
   }
   nodes[j] = word;
-  rf_fill(d, o, leaf ? nid : d->rf_left[o + nid], 2 * j, depth + 1, D, nodes, leafval);
-  rf_fill(d, o, leaf ? nid : d->rf_right[o + nid], 2 * j + 1, depth + 1, D, nodes, leafval);
+  rf_fill(d, o, leaf ? nid : d->rf_left[o + nid], 2 * j, depth + 1, D, off, nodes, leafval);
+  rf_fill(d, o, leaf ? nid : d->rf_right[o + nid], 2 * j + 1, depth + 1, D, off, nodes, leafval);
 }
 
 static int build_rforest(gnx_model* m, const gnx_model_desc* d) {
@@ -619,14 +620,15 @@ static int build_rforest(gnx_model* m, const gnx_model_desc* d) {
   }
   if (D > 8) return fail(ctx, GNX_EUNSUPPORTED, "rforest base: tree depth > 8");
   const int tree_bytes = std::max(16, 4 << D);
-  const int max_words = (int)((M_ + rem + 15) / 16);
+  const int max_words = gnx_forest_ring_words(M_ + rem);
   if (gnx_forest_lds_bytes(A, max_words, max_trees, tree_bytes, 64) > (size_t)160 * 1024)
     return fail(ctx, GNX_EUNSUPPORTED, "rforest base: one window's trees and SNPs exceed the 160 KB LDS");
   std::vector<uint8_t> packed((size_t)d->rf_n_trees * tree_bytes, 0);
   std::vector<double> leafval((size_t)d->rf_n_trees * ((size_t)1 << D) * A, 0.0);
-  for (int32_t t = 0; t < d->rf_n_trees; ++t)
-    rf_fill(d, d->rf_tree_off[t], 0, 1, 0, D, reinterpret_cast<uint32_t*>(packed.data() + (size_t)t * tree_bytes),
-            leafval.data() + (size_t)t * ((size_t)1 << D) * A);
+  for (int64_t w = 0; w < W; ++w)
+    for (int32_t t = d->rf_win_tree0[w]; t < d->rf_win_tree0[w + 1]; ++t)
+      rf_fill(d, d->rf_tree_off[t], 0, 1, 0, D, (uint32_t)((w * M) & 15), reinterpret_cast<uint32_t*>(packed.data() + (size_t)t * tree_bytes),
+              leafval.data() + (size_t)t * ((size_t)1 << D) * A);
   std::vector<int32_t> win_tree0(d->rf_win_tree0, d->rf_win_tree0 + W + 1);
   int rc;
   if ((rc = dev_upload(m, packed, &m->forest.packed, 64)) != GNX_OK) return rc;
@@ -764,6 +766,8 @@ static void read_tune(gnx_tune& t) {
   t.sm_pair = geti("GNX_SM_PAIR", 1);
   if (const char* e = std::getenv("GNX_SM_TUNE")) std::sscanf(e, "%d,%d", &t.smf_rpl, &t.smf_nw);
   t.forest_threads = geti("GNX_FOREST_T", 0);
+  t.forest_wrun = geti("GNX_FOREST_WRUN", 0);
+  t.forest_flags = geti("GNX_FOREST_FLAGS", 0);
   if (const char* e = std::getenv("GNX_HOST_BATCH")) t.host_batch = std::atoll(e);
   t.h2d_overlap = geti("GNX_H2D_OVERLAP", 1);
   t.debug = std::getenv("GNX_DEBUG") != nullptr;
@@ -980,12 +984,12 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     L.width = m->info.M + 2 * m->info.ctx;
     L.width_last = L.width + (m->info.C - m->info.M * m->info.W);
     L.W = (int32_t)m->info.W; L.A = m->info.A; L.D = m->forest.D; L.tree_bytes = m->forest.tree_bytes;
-    L.max_trees = m->forest.max_trees; L.max_words = m->forest.max_words; L.missing = m->forest.missing;
+    L.max_trees = m->forest.max_trees; L.missing = m->forest.missing;
     L.base_score = m->forest.base_score;
     L.packed = m->forest.packed; L.win_tree0 = m->forest.win_tree0; L.win_class_tree0 = m->forest.win_class_tree0;
     L.rf_leafval = m->forest.rf_leafval;
     L.b32 = d_b32; L.b64 = d_b64;
-    HIPCHK(ctx, gnx_launch_base_forest(L, ctx->tune, ctx->stream));
+    HIPCHK(ctx, gnx_launch_base_forest(L, ctx->n_cu, ctx->tune, ctx->stream));
     return GNX_OK;
   }
   if (m->info.base_kind != GNX_BASE_LOGISTIC) return fail(ctx, GNX_ESTATE, "model has no base classifier");

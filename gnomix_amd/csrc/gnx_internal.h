@@ -35,6 +35,8 @@ struct gnx_tune {
   int sm_pair = 1;                      // GNX_SM_PAIR=0: one tree at a time per lane in the rank smoother (default: two)
   int smf_rpl = 0, smf_nw = 0;          // GNX_SM_TUNE="rpl,nw": float smoother
   int forest_threads = 0;               // GNX_FOREST_T
+  int forest_wrun = 0;                  // GNX_FOREST_WRUN: windows per block of the forest bases
+  int forest_flags = 0;                 // GNX_FOREST_FLAGS: ablation (1 = no walks, 2 = no register prefetch, 4 = no incremental staging)
   int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
   int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points
   bool debug = false;                   // GNX_DEBUG
@@ -271,8 +273,9 @@ struct CalibLaunch {
 };
 
 // ---- forest base (k_base_forest.hip) ------------------------------------------------------------------
-// Per tree: 2^D node words (heap slot 0 unused; (SNP index within the window << 4) | left-mask over the SNP values
-// 0..3) followed by 2^D float leaves.
+// Per tree: 2^D node words (heap slot 0 unused; (position << 4) | left-mask over the SNP values 0..3, position = SNP index
+// within the window + (window start mod 16): the tile's words are anchored on the padded chromosome coordinate)
+// followed by 2^D float leaves.
 struct ForestDev {
   const uint8_t* packed = nullptr;          // fb_n_trees * tree_bytes, per window class-major
   const int32_t* win_tree0 = nullptr;       // [W+1]
@@ -285,7 +288,9 @@ struct ForestDev {
 struct ForestLaunch {
   const int8_t* X;    // (N, ldx)
   int64_t N, ldx, C, ctx, M, width, width_last;
-  int32_t W, A, D, tree_bytes, max_trees, max_words, missing, w_first;
+  int32_t W, A, D, tree_bytes, max_trees, missing;
+  int32_t flags;  // development ablation switches (0 in production)
+  int32_t w_first, n_windows, wrun, ring;  // set by the launcher: window range of the grid, windows per block, ring slots
   float base_score;
   const uint8_t* packed;
   const int32_t* win_tree0;
@@ -338,6 +343,7 @@ hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
 hipError_t gnx_launch_unpack2(const uint8_t* P, int64_t N, int64_t ldp, int64_t C, int8_t* X, int64_t ldx, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);
-hipError_t gnx_launch_base_forest(const ForestLaunch& L, const gnx_tune& tune, hipStream_t s);
-size_t gnx_forest_lds_bytes(int A, int max_words, int max_trees, int tree_bytes, int threads);
+hipError_t gnx_launch_base_forest(const ForestLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+size_t gnx_forest_lds_bytes(int A, int ring_words, int max_trees, int tree_bytes, int threads);
+int gnx_forest_ring_words(int64_t width);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

@@ -6,17 +6,26 @@
 // multi:softprob for A >= 3, binary:logistic for A == 2).  No reference mode selects these bases (README.md:120-146
 // shows how to plug them in), they are the "forest-of-stumps" family of the north star.
 //
-// One thread = one haplotype of one window; a block = T = 64*waves haplotypes of that window.
-//  * staging: every wave reads ITS OWN 64 haplotypes' SNP bytes of the window straight from X (16 SNPs = one
-//    unaligned 16-byte load per lane, 8 lanes along a row = one 128-byte line, LB loads in flight per lane),
-//    squeezes them to 2 bits per SNP and stores them in LDS as xw[word][hap]: during the walks a lane's bank is then
-//    fixed by its haplotype, so lanes that sit on different split SNPs never conflict.  Reflect padding
-//    (base.py:146-151) only touches the first / last ctx SNPs of a row: those words take a per-byte path.
-//  * the window's trees sit next to the tile as compact heaps: one 32-bit word per node = (SNP index << 4) | left-mask
-//    (bit v = "value v goes left": SNPs only take the values 0..3, so the float compare and the missing code's
-//    default direction were folded into 4 bits by the loader), then the 2^D float leaves.  A lane walks TP trees at
-//    a time level by level (TP independent LDS chains), adds the leaves of each class in tree order (float32, as
-//    the restated predictor does), parks the margins in LDS and applies softmax / sigmoid in float32.
+// One thread = one haplotype of one window; a block = T = 64*waves haplotypes and a RUN of consecutive windows.
+//  * the SNPs live in LDS as 2-bit fields, 16 per word, xw[word slot][hap]: during the walks a lane's bank is fixed by its
+//    haplotype, so lanes that sit on different split SNPs never conflict.  Words are anchored on the PADDED chromosome
+//    coordinate (word g = padded SNPs 16g .. 16g+15) and kept in a power-of-two ring of slots (slot = g mod RING), so the
+//    half of a window that the next window shares (context: windows overlap by 2*ctx of M + 2*ctx SNPs, base.py:146-151)
+//    stays where it is: a block walks windows w, w+1, ... of its haplotypes and only fetches each window's NEW words —
+//    every byte of X is read about once instead of (M + 2 ctx) / M times.
+//  * those new words are fetched while the trees of the current window are walked: the loads are issued in four batches
+//    between tree groups (16 x 16-byte loads in flight per lane), squeezed to 2 bits per SNP into registers as they
+//    arrive, and stored into the ring slots the current window no longer needs after the block's barrier.  (One block
+//    fills the LDS, i.e. one wave per SIMD: nothing else would hide the HBM latency.)
+//  * staging proper: every wave reads ITS OWN 64 haplotypes' bytes straight from X (one unaligned 16-byte load per lane
+//    = one word, 8 lanes along a row = one 128-byte line).  Reflect padding only touches the first / last ctx SNPs of a
+//    row: those words take a per-byte path.
+//  * the window's trees sit next to the tile as compact heaps: one 32-bit word per node = (position << 4) | left-mask
+//    (position = SNP index within the window + the window start's offset inside its first word; bit v of the mask =
+//    "value v goes left": SNPs only take the values 0..3, so the float compare and the missing code's default direction
+//    were folded into 4 bits by the loader), then the 2^D float leaves.  A lane walks TP trees at a time level by level
+//    (TP independent LDS chains), adds the leaves of each class in tree order (float32, as the restated predictor does),
+//    parks the margins in LDS and applies softmax / sigmoid in float32.
 #include "gnx_internal.h"
 
 #include <cstdlib>
@@ -38,17 +47,34 @@ __device__ __forceinline__ uint32_t squeeze4(uint32_t d) {
   return (y | (y >> 12)) & 0xffu;
 }
 
-constexpr int TP = 8;  // trees walked concurrently per lane
+constexpr int TP = 16;  // trees walked concurrently per lane
 constexpr int LB = 16;  // 16-byte loads in flight per lane while staging
+constexpr int NPF = 4;  // prefetch batches per window (LB loads each): at most NPF*LB new words per haplotype row group
 
-// left iff bit v of the node's mask is set, v = the 2-bit SNP value
-__device__ __forceinline__ uint32_t step(uint32_t j, uint32_t nd, uint32_t xv) {
-  const uint32_t v = (xv >> ((nd >> 3) & 30u)) & 3u;
-  return 2 * j + (((nd >> v) & 1u) ^ 1u);
+// Node words as the walks read them from LDS.  The loader's word is (position << 4) | left-mask; while a window's trees are
+// copied into LDS every node word is rewritten FOR THAT WINDOW AND BLOCK SHAPE as
+//     (byte offset of the word's ring row) << 15 | (2 * field) << 4 | right-mask        right-mask = ~left-mask & 15
+// so that a level costs 7 VALU operations: node address, row offset (shift), + lane column, three bit-field extracts
+// (field shift, SNP value, direction), j = 2j + direction.
+__device__ __forceinline__ uint32_t node_for_window(uint32_t nd, uint32_t g0, uint32_t mask, int T) {
+  const uint32_t pos = nd >> 4;
+  const uint32_t slot = ((pos >> 4) + g0) & mask;
+  return ((slot * (uint32_t)T * 4u) << 15) | ((2u * (pos & 15u)) << 4) | (~nd & 15u);
 }
 
+__device__ __forceinline__ uint32_t step(uint32_t j, uint32_t nd, uint32_t xv) {
+  const uint32_t v = __builtin_amdgcn_ubfe(xv, __builtin_amdgcn_ubfe(nd, 4, 5), 2);  // the 2-bit SNP value
+  return 2 * j + __builtin_amdgcn_ubfe(nd, v, 1);                                     // + 1 iff value v goes right
+}
+
+// the tile as the walks see it: this lane's column of the ring (byte address), node words carry the row offset
+struct Tile {
+  const uint8_t* xcol;  // (const uint8_t*)(xw + haplotype)
+  __device__ __forceinline__ uint32_t word(uint32_t nd) const { return *reinterpret_cast<const uint32_t*>(xcol + (nd >> 15)); }
+};
+
 template <int D, int NT>
-__device__ __forceinline__ void walk(const uint8_t* tb, int tree_bytes, const uint32_t* xcol, int T, float* leaf) {
+__device__ __forceinline__ void walk(const uint8_t* tb, int tree_bytes, const Tile& tile, float* leaf) {
   uint32_t j[NT];
 #pragma unroll
   for (int k = 0; k < NT; ++k) j[k] = 1;
@@ -58,7 +84,7 @@ __device__ __forceinline__ void walk(const uint8_t* tb, int tree_bytes, const ui
 #pragma unroll
     for (int k = 0; k < NT; ++k) nd[k] = reinterpret_cast<const uint32_t*>(tb + k * tree_bytes)[j[k]];
 #pragma unroll
-    for (int k = 0; k < NT; ++k) xv[k] = xcol[(nd[k] >> 8) * T];
+    for (int k = 0; k < NT; ++k) xv[k] = tile.word(nd[k]);
 #pragma unroll
     for (int k = 0; k < NT; ++k) j[k] = step(j[k], nd[k], xv[k]);
   }
@@ -66,222 +92,355 @@ __device__ __forceinline__ void walk(const uint8_t* tb, int tree_bytes, const ui
   for (int k = 0; k < NT; ++k) leaf[k] = reinterpret_cast<const float*>(tb + k * tree_bytes)[j[k]];  // leaves follow the 2^D nodes
 }
 
-// Stage the calling wave's 64 haplotypes of window w: 8 haplotypes x 8 words per wave instruction.
-__device__ __forceinline__ void stage_window(const ForestLaunch& L, int w, int64_t width, uint32_t* xw, int T) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t C = L.C, ctx = L.ctx, Cp = C + 2 * ctx;
-  {
-    const int64_t s = (int64_t)w * L.M;  // padded coordinate of the window's first SNP
-    const int nw = (int)((width + 15) >> 4);
-    const int wsub = lane & 7, hsub = lane >> 3;
-    const int64_t cmax = C - 16;  // the model loader guarantees C >= 16
+// ---- staging ------------------------------------------------------------------------------------------------------
+// global word g = padded SNPs [16g, 16g+16) of a haplotype row; a lane stages (haplotype hb*8 + lane>>3 of its wave, words
+// g_first + 8u + (lane&7)): 8 lanes along a row cover 128 contiguous bytes.
+struct Stager {
+  const int8_t* X;      // copies of the launch fields (a reference to the kernel argument would force it into scratch)
+  int64_t N, ldx, C, ctx, cmax, blk0;
+  int T, wsub, hsub, wv;
+  __device__ __forceinline__ Stager(const int8_t* X_, int64_t N_, int64_t ldx_, int64_t C_, int64_t ctx_, int T_)
+      : X(X_), N(N_), ldx(ldx_), C(C_), ctx(ctx_), T(T_) {
+    const int lane = threadIdx.x & 63;
+    wsub = lane & 7; hsub = lane >> 3; wv = threadIdx.x >> 6;
+    cmax = C - 16;  // the model loader guarantees C >= 16
+    blk0 = (int64_t)blockIdx.x * T;
+  }
+  __device__ __forceinline__ const int8_t* row(int hb) const {
+    int64_t n = blk0 + wv * 64 + hb * 8 + hsub;
+    n = n < N ? n : N - 1;
+    return X + n * ldx;
+  }
+  __device__ __forceinline__ v4u load(const int8_t* r, int64_t g) const {  // unconditional, clamped address
+    int64_t c0 = 16 * g - ctx;
+    c0 = c0 < 0 ? 0 : (c0 > cmax ? cmax : c0);
+    v4u v;
+    __builtin_memcpy(&v, r + c0, 16);
+    return v;
+  }
+  __device__ __forceinline__ v4u load_inner(const int8_t* r, int64_t g) const {  // word known to lie inside the row: no clamp
+    v4u v;
+    __builtin_memcpy(&v, r + (16 * g - ctx), 16);
+    return v;
+  }
+  __device__ __forceinline__ uint32_t squeeze(const v4u& v, const int8_t* r, int64_t g) const {
+    const int64_t p0 = 16 * g;
+    uint32_t q = squeeze4(v.x) | (squeeze4(v.y) << 8) | (squeeze4(v.z) << 16) | (squeeze4(v.w) << 24);
+    if (p0 < ctx || p0 + 16 > ctx + C) {  // rare: the word touches the reflect padding / the row's end
+      q = 0;
+      for (int b = 0; b < 16; ++b) {
+        const int64_t p = p0 + b;
+        if (p < C + 2 * ctx) q |= ((uint32_t)(uint8_t)r[pad_src(p, C, ctx)] & 3u) << (2 * b);
+      }
+    }
+    return q;
+  }
+  // words [ga, gb) of the wave's 64 haplotypes -> ring, synchronously
+  __device__ void stage(uint32_t* xw, uint32_t mask, int64_t ga, int64_t gb) const {
     for (int hb = 0; hb < 8; ++hb) {
-      const int h = wv * 64 + hb * 8 + hsub;
-      int64_t n = (int64_t)blockIdx.x * T + h;
-      n = n < L.N ? n : L.N - 1;
-      const int8_t* row = L.X + n * L.ldx;
-      uint32_t* col = xw + h;
-      for (int wb = 0; wb < nw; wb += 8 * LB) {
+      const int8_t* r = row(hb);
+      uint32_t* col = xw + wv * 64 + hb * 8 + hsub;
+      for (int64_t gw = ga; gw < gb; gw += 8 * LB) {
         v4u v[LB];
 #pragma unroll
-        for (int u = 0; u < LB; ++u) {  // unconditional loads at clamped addresses: all LB are in flight together
-          int64_t c0 = s + 16 * (int64_t)(wb + 8 * u + wsub) - ctx;
-          c0 = c0 < 0 ? 0 : (c0 > cmax ? cmax : c0);
-          __builtin_memcpy(&v[u], row + c0, 16);
-        }
+        for (int u = 0; u < LB; ++u) v[u] = load(r, gw + 8 * u + wsub);
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
-          const int wd = wb + 8 * u + wsub;
-          const int64_t p0 = s + 16 * (int64_t)wd;
-          uint32_t q = squeeze4(v[u].x) | (squeeze4(v[u].y) << 8) | (squeeze4(v[u].z) << 16) | (squeeze4(v[u].w) << 24);
-          if (wd < nw && (p0 < ctx || p0 + 16 > ctx + C)) {  // rare: the word touches the reflect padding / the row's end
-            q = 0;
-            for (int b = 0; b < 16; ++b) {
-              const int64_t p = p0 + b;
-              if (p < Cp) q |= ((uint32_t)(uint8_t)row[pad_src(p, C, ctx)] & 3u) << (2 * b);
-            }
-          }
-          if (wd < nw) col[(size_t)wd * T] = q;
+          const int64_t g = gw + 8 * u + wsub;
+          if (g < gb) col[(size_t)((uint32_t)g & mask) * T] = squeeze(v[u], r, g);
         }
       }
     }
   }
+};
+
+// Register prefetch of the next window's new words [ga, gb) (at most 64, none of them touching the reflect padding: those
+// windows are staged synchronously).  Batch Q covers haplotype groups hb = 2Q, 2Q+1 of the wave, 8 words per lane each:
+// pf_issue<Q> puts LB loads in flight, pf_consume<Q> squeezes them into sq[Q*LB ..]; every register index is static.
+template <int Q>
+__device__ __forceinline__ void pf_issue(const Stager& st, int64_t ga, int64_t glast, v4u (&raw)[LB]) {
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int8_t* r = st.row(2 * Q + h2);
+#pragma unroll
+    for (int u = 0; u < LB / 2; ++u) raw[h2 * (LB / 2) + u] = st.load_inner(r, min(ga + 8 * u + st.wsub, glast));
+  }
+}
+template <int Q>
+__device__ __forceinline__ void pf_consume(const v4u (&raw)[LB], uint32_t (&sq)[NPF * LB]) {
+#pragma unroll
+  for (int k = 0; k < LB; ++k)
+    sq[Q * LB + k] = squeeze4(raw[k].x) | (squeeze4(raw[k].y) << 8) | (squeeze4(raw[k].z) << 16) | (squeeze4(raw[k].w) << 24);
+}
+// batch q goes out after the previous one was squeezed into its registers (q is block-uniform; q == NPF drains the last)
+#define GNX_PF_ADVANCE(q)                                                     \
+  switch (q) {                                                                \
+    case 0: pf_issue<0>(st, pf_ga, pf_gb - 1, raw); break;                               \
+    case 1: pf_consume<0>(raw, sq); pf_issue<1>(st, pf_ga, pf_gb - 1, raw); break;       \
+    case 2: pf_consume<1>(raw, sq); pf_issue<2>(st, pf_ga, pf_gb - 1, raw); break;       \
+    case 3: pf_consume<2>(raw, sq); pf_issue<3>(st, pf_ga, pf_gb - 1, raw); break;       \
+    default: pf_consume<3>(raw, sq); break;                                   \
+  }
+
+__device__ __forceinline__ void window_words(const ForestLaunch& L, int w, int64_t& g0, int64_t& g1) {
+  const int64_t s = (int64_t)w * L.M, width = (w == L.W - 1) ? L.width_last : L.width;
+  g0 = s >> 4;
+  g1 = ((s + width - 1) >> 4) + 1;
 }
 
-template <int D>
+// RF = false: boosted trees (XGBBase); RF = true: random forest (RFBase, src/Base/models.py:54-66): same tile and mask nodes
+// (mask bit v = "float32(v) <= threshold"); a leaf contributes its class-probability row (float64, expanded per heap slot in
+// global memory: 20 trees x 16 leaves x A doubles per window stay in L1/L2), the rows are added in estimator order and divided
+// by the tree count, as ForestClassifier.predict_proba does.
+template <int D, bool RF, int AMAX>
 __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, T = blockDim.x;
-  const int w = L.w_first + blockIdx.y;
   const int A = L.A, tree_bytes = L.tree_bytes;
-  const int64_t width = (w == L.W - 1) ? L.width_last : L.width;
-  const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
-
-  uint32_t* xw = reinterpret_cast<uint32_t*>(lds);                                    // [max_words][T]
-  uint8_t* tr = lds + (size_t)L.max_words * T * 4;                                    // trees of this window
+  const int Dr = RF ? L.D : D;  // the random-forest walk is depth-generic
+  const uint32_t mask = (uint32_t)L.ring - 1u;
+  uint32_t* xw = reinterpret_cast<uint32_t*>(lds);                                    // [ring][T]
+  uint8_t* tr = lds + (size_t)L.ring * T * 4;                                         // trees of the current window
   float* marg = reinterpret_cast<float*>(tr + (((size_t)L.max_trees * tree_bytes + 15) & ~(size_t)15)) + tid;  // [A][T]
 
-  stage_window(L, w, width, xw, T);
-  for (int e = tid; e < nt * tree_bytes / 16; e += T)
-    reinterpret_cast<uint4*>(tr)[e] = reinterpret_cast<const uint4*>(L.packed + (size_t)t0 * tree_bytes)[e];
-  __syncthreads();
-
-  // ---- walks: class-major packing per window, trees of class c contiguous and in model order ----------------
-  const uint32_t* xcol = xw + tid;
-  const int32_t* cls0 = L.win_class_tree0 + (size_t)w * (A + 1);  // [A+1] offsets relative to t0
-  const int n_groups = (A == 2) ? 1 : A;
-  for (int c = 0; c < n_groups; ++c) {
-    const int a0 = (A == 2) ? 0 : cls0[c], a1 = (A == 2) ? nt : cls0[c + 1];
-    float psum = 0.f;
-    int t = a0;
-    for (; t + TP <= a1; t += TP) {
-      float leaf[TP];
-      walk<D, TP>(tr + (size_t)t * tree_bytes, tree_bytes, xcol, T, leaf);
-#pragma unroll
-      for (int k = 0; k < TP; ++k) psum += leaf[k];  // tree order
-    }
-    for (; t < a1; ++t) {
-      float leaf[1];
-      walk<D, 1>(tr + (size_t)t * tree_bytes, tree_bytes, xcol, T, leaf);
-      psum += leaf[0];
-    }
-    marg[c * T] = psum;
-  }
+  const int wa = L.w_first + blockIdx.y * L.wrun, wb = min(L.w_first + L.n_windows, wa + L.wrun);
+  const Stager st(L.X, L.N, L.ldx, L.C, L.ctx, T);
+  int64_t g0, g1;
+  window_words(L, wa, g0, g1);
+  st.stage(xw, mask, g0, g1);
   const int64_t n = (int64_t)blockIdx.x * T + tid;
-  if (n >= L.N) return;
-  const size_t o = ((size_t)n * L.W + w) * A;
-  if (A == 2) {
-    const float margin = logf(L.base_score / (1.0f - L.base_score)) + marg[0];  // ProbToMargin of binary:logistic
-    const float p1 = 1.0f / (1.0f + (float)exp((double)(-margin)));
-    const float p[2] = {1.0f - p1, p1};
-    for (int a = 0; a < 2; ++a) {
-      if (L.b32) L.b32[o + a] = p[a];
-      if (L.b64) L.b64[o + a] = (double)p[a];
+
+  // a window's trees: uint4 pieces of the loader's records, node words rewritten for the window on their way into LDS
+  constexpr int TQ = 8;  // pieces per thread held in registers while the previous window is walked
+  const int words_per_tree = tree_bytes / 4, node_words = RF ? tree_bytes / 4 : (1 << D);
+  auto put_tree_piece = [&](int e, uint4 v, uint32_t gw0) {
+    const int wd = (e * 4) % words_per_tree;  // first word of the piece inside its tree (records are multiples of 16 bytes)
+    if (wd < node_words) v.x = node_for_window(v.x, gw0, mask, T);      // per word: a depth-1 record holds 2 node words
+    if (wd + 1 < node_words) v.y = node_for_window(v.y, gw0, mask, T);  // and its 2 leaves in ONE piece
+    if (wd + 2 < node_words) v.z = node_for_window(v.z, gw0, mask, T);
+    if (wd + 3 < node_words) v.w = node_for_window(v.w, gw0, mask, T);
+    reinterpret_cast<uint4*>(tr)[e] = v;
+  };
+  {
+    const int t0 = L.win_tree0[wa], np = (L.win_tree0[wa + 1] - t0) * tree_bytes / 16;
+    const uint4* src = reinterpret_cast<const uint4*>(L.packed + (size_t)t0 * tree_bytes);
+    for (int e = tid; e < np; e += T) put_tree_piece(e, src[e], (uint32_t)g0);
+  }
+
+  for (int w = wa; w < wb; ++w) {
+    const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
+    __syncthreads();  // tile + trees of window w complete
+    // the next window's trees travel through registers while this one is walked (when they fit TQ pieces per thread)
+    uint4 tq[TQ];
+    int np_next = 0;
+    const uint4* tsrc = nullptr;
+    if (w + 1 < wb) {
+      const int t1 = L.win_tree0[w + 1];
+      np_next = (L.win_tree0[w + 2] - t1) * tree_bytes / 16;
+      tsrc = reinterpret_cast<const uint4*>(L.packed + (size_t)t1 * tree_bytes);
     }
-    return;
+    const bool tpre = np_next > 0 && np_next <= TQ * T;
+    if (tpre) {
+#pragma unroll
+      for (int k = 0; k < TQ; ++k) tq[k] = tsrc[min(tid + k * T, np_next - 1)];
+    }
+
+    // the next window's new words: prefetched through registers when they fit NPF batches and none of them touches the
+    // reflect padding, else staged after the walks
+    v4u raw[LB];
+    uint32_t sq[NPF * LB];
+    int64_t ng0 = 0, ng1 = 0, pf_ga = 0, pf_gb = 0;
+    bool pre = false;
+    if (w + 1 < wb) {
+      window_words(L, w + 1, ng0, ng1);
+      pf_ga = ng0 > g1 ? ng0 : g1;
+      pf_gb = ng1;
+      pre = (pf_gb - pf_ga) <= 8 * (LB / 2) && 16 * pf_ga >= L.ctx && 16 * pf_gb <= L.ctx + L.C && !(L.flags & 2);
+    }
+    int stage_q = 0;  // batches issued so far
+    // called between tree groups: keep batch (progress * NPF) in flight
+#define GNX_PF_PUMP(done, total)                                              \
+  if (pre) {                                                                  \
+    const int want_ = min(NPF, ((done) * NPF) / max((total), 1) + 1);         \
+    while (stage_q < want_) { GNX_PF_ADVANCE(stage_q); ++stage_q; }           \
   }
-  float wmax = L.base_score + marg[0];
-  for (int a = 1; a < A; ++a) wmax = fmaxf(L.base_score + marg[a * T], wmax);
-  double wsum = 0.0;
-  for (int a = 0; a < A; ++a) {
-    const float e = (float)exp((double)((L.base_score + marg[a * T]) - wmax));
-    marg[a * T] = e;
-    wsum += (double)e;
+
+    const Tile tile{reinterpret_cast<const uint8_t*>(xw + tid)};
+    const size_t o = ((size_t)(n < L.N ? n : 0) * L.W + w) * A;
+    if constexpr (!RF) {
+      // ---- walks: class-major packing per window, trees of class c contiguous and in model order ----------------
+      const int32_t* cls0 = L.win_class_tree0 + (size_t)w * (A + 1);  // [A+1] offsets relative to t0
+      const int n_groups = (A == 2) ? 1 : A;
+      for (int c = 0; c < n_groups; ++c) {
+        const int a0 = (A == 2) ? 0 : cls0[c], a1 = (A == 2) ? nt : cls0[c + 1];
+        float psum = 0.f;
+        int t = a0;
+        for (; t + TP <= a1 && !(L.flags & 1); t += TP) {
+          GNX_PF_PUMP(t, nt)
+          float leaf[TP];
+          walk<D, TP>(tr + (size_t)t * tree_bytes, tree_bytes, tile, leaf);
+#pragma unroll
+          for (int k = 0; k < TP; ++k) psum += leaf[k];  // tree order
+        }
+        for (; t < a1 && !(L.flags & 1); ++t) {
+          float leaf[1];
+          walk<D, 1>(tr + (size_t)t * tree_bytes, tree_bytes, tile, leaf);
+          psum += leaf[0];
+        }
+        marg[c * T] = psum;
+      }
+      if (n < L.N) {
+        if (A == 2) {
+          const float margin = logf(L.base_score / (1.0f - L.base_score)) + marg[0];  // ProbToMargin of binary:logistic
+          const float p1 = 1.0f / (1.0f + (float)exp((double)(-margin)));
+          const float p[2] = {1.0f - p1, p1};
+          for (int a = 0; a < 2; ++a) {
+            if (L.b32) L.b32[o + a] = p[a];
+            if (L.b64) L.b64[o + a] = (double)p[a];
+          }
+        } else {
+          float wmax = L.base_score + marg[0];
+          for (int a = 1; a < A; ++a) wmax = fmaxf(L.base_score + marg[a * T], wmax);
+          double wsum = 0.0;
+          for (int a = 0; a < A; ++a) {
+            const float e = (float)exp((double)((L.base_score + marg[a * T]) - wmax));
+            marg[a * T] = e;
+            wsum += (double)e;
+          }
+          const float fs = (float)wsum;
+          for (int a = 0; a < A; ++a) {
+            const float p = marg[a * T] / fs;
+            if (L.b32) L.b32[o + a] = p;
+            if (L.b64) L.b64[o + a] = (double)p;
+          }
+        }
+      }
+    } else {
+      double acc[AMAX];
+#pragma unroll
+      for (int a = 0; a < AMAX; ++a) acc[a] = 0.0;
+      const size_t leaves = (size_t)1 << Dr;
+      for (int t = 0; t < nt; ++t) {
+        if ((t & 3) == 0) GNX_PF_PUMP(t, nt)
+        const uint32_t* nodes = reinterpret_cast<const uint32_t*>(tr + (size_t)t * tree_bytes);
+        uint32_t j = 1;
+        for (int d = 0; d < Dr; ++d) {
+          const uint32_t nd = nodes[j];
+          j = step(j, nd, tile.word(nd));
+        }
+        const double* v = L.rf_leafval + ((size_t)(t0 + t) * leaves + (j - (uint32_t)leaves)) * A;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a)
+          if (a < A) acc[a] += v[a];  // estimator order
+      }
+      if (n < L.N) {
+        const double cnt = (double)nt;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a)
+          if (a < A) {
+            const double p = acc[a] / cnt;
+            if (L.b64) L.b64[o + a] = p;
+            if (L.b32) L.b32[o + a] = (float)p;
+          }
+      }
+    }
+    if (w + 1 >= wb) break;
+    // drain the prefetch (batches the walks did not reach), then replace the words the next window no longer shares
+    if (pre)
+      while (stage_q <= NPF) { GNX_PF_ADVANCE(stage_q); ++stage_q; }
+    __syncthreads();  // every lane is done with window w's tile and trees
+    if (pre) {
+#pragma unroll
+      for (int q = 0; q < NPF; ++q)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int u = 0; u < LB / 2; ++u) {
+            const int64_t g = pf_ga + 8 * u + st.wsub;
+            if (g < pf_gb) xw[(size_t)((uint32_t)g & mask) * T + st.wv * 64 + (2 * q + h2) * 8 + st.hsub] = sq[q * LB + h2 * (LB / 2) + u];
+          }
+    } else if (!(L.flags & 4)) st.stage(xw, mask, ng0 > g1 ? ng0 : g1, ng1);
+    if (tpre) {
+#pragma unroll
+      for (int k = 0; k < TQ; ++k)
+        if (tid + k * T < np_next) put_tree_piece(tid + k * T, tq[k], (uint32_t)ng0);
+    } else {
+      for (int e = tid; e < np_next; e += T) put_tree_piece(e, tsrc[e], (uint32_t)ng0);
+    }
+    g0 = ng0;
+    g1 = ng1;
   }
-  const float fs = (float)wsum;
-  for (int a = 0; a < A; ++a) {
-    const float p = marg[a * T] / fs;
-    if (L.b32) L.b32[o + a] = p;
-    if (L.b64) L.b64[o + a] = (double)p;
-  }
+#undef GNX_PF_PUMP
 }
 
-// ---- random-forest variant (RFBase, src/Base/models.py:54-66) --------------------------------------------------------
-// Same tile, same mask nodes (mask bit v = "float32(v) <= threshold"); a leaf contributes its class-probability row
-// (float64, expanded per heap slot in global memory: 20 trees x 16 leaves x A doubles per window stay in L1/L2), the
-// rows are added in estimator order and divided by the tree count, as ForestClassifier.predict_proba does.
-template <int AMAX>
-__global__ __launch_bounds__(256) void k_base_rforest(ForestLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int tid = threadIdx.x, T = blockDim.x;
-  const int w = L.w_first + blockIdx.y;
-  const int A = L.A, D = L.D, tree_bytes = L.tree_bytes;
-  const int64_t width = (w == L.W - 1) ? L.width_last : L.width;
-  const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
-  uint32_t* xw = reinterpret_cast<uint32_t*>(lds);   // [max_words][T]
-  uint8_t* tr = lds + (size_t)L.max_words * T * 4;   // node words of this window's trees
-  stage_window(L, w, width, xw, T);
-  for (int e = tid; e < nt * tree_bytes / 16; e += T)
-    reinterpret_cast<uint4*>(tr)[e] = reinterpret_cast<const uint4*>(L.packed + (size_t)t0 * tree_bytes)[e];
-  __syncthreads();
-
-  const uint32_t* xcol = xw + tid;
-  double acc[AMAX];
-#pragma unroll
-  for (int a = 0; a < AMAX; ++a) acc[a] = 0.0;
-  const size_t leaves = (size_t)1 << D;
-  for (int t = 0; t < nt; ++t) {
-    const uint32_t* nodes = reinterpret_cast<const uint32_t*>(tr + (size_t)t * tree_bytes);
-    uint32_t j = 1;
-    for (int d = 0; d < D; ++d) {
-      const uint32_t nd = nodes[j];
-      j = step(j, nd, xcol[(nd >> 8) * T]);
-    }
-    const double* v = L.rf_leafval + ((size_t)(t0 + t) * leaves + (j - (uint32_t)leaves)) * A;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-      if (a < A) acc[a] += v[a];  // estimator order
-  }
-  const int64_t n = (int64_t)blockIdx.x * T + tid;
-  if (n >= L.N) return;
-  const size_t o = ((size_t)n * L.W + w) * A;
-  const double cnt = (double)nt;
-#pragma unroll
-  for (int a = 0; a < AMAX; ++a)
-    if (a < A) {
-      const double p = acc[a] / cnt;
-      if (L.b64) L.b64[o + a] = p;
-      if (L.b32) L.b32[o + a] = (float)p;
-    }
-}
-
-template <int AMAX>
-hipError_t launch_rf(const ForestLaunch& L, int n_windows, int threads, size_t lds, hipStream_t s) {
-  GNX_LDS_OPTIN((size_t)160 * 1024, k_base_rforest<AMAX>);
-  hipLaunchKernelGGL(k_base_rforest<AMAX>, dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)n_windows), dim3(threads), lds, s, L);
+template <int D, bool RF, int AMAX>
+hipError_t launch_k(const ForestLaunch& L, int threads, size_t lds, hipStream_t s) {
+  GNX_LDS_OPTIN((size_t)160 * 1024, k_base_forest<D, RF, AMAX>);
+  const int n_runs = (L.n_windows + L.wrun - 1) / L.wrun;
+  hipLaunchKernelGGL((k_base_forest<D, RF, AMAX>), dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)n_runs), dim3(threads), lds, s, L);
   return hipGetLastError();
 }
 
-template <int D>
-hipError_t launch_d(const ForestLaunch& L, int n_windows, int threads, size_t lds, hipStream_t s) {
-  GNX_LDS_OPTIN((size_t)160 * 1024, k_base_forest<D>);
-  hipLaunchKernelGGL(k_base_forest<D>, dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)n_windows), dim3(threads), lds, s, L);
-  return hipGetLastError();
-}
-
-// windows [w_first, w_first + n_windows) with an X tile of max_words words per haplotype
-hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int max_words, const gnx_tune& tune, hipStream_t s) {
+// windows [w_first, w_first + n_windows), all of padded width `width` (the last window of the chromosome goes alone)
+hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int64_t width, int n_cu, const gnx_tune& tune, hipStream_t s) {
   if (n_windows <= 0) return hipSuccess;
-  // the walks are issue-bound with one wave per SIMD and staging does not overlap them inside a block: take as many
-  // waves per CU as the LDS holds (the X tile is 4 * max_words bytes per haplotype)
   constexpr size_t kLds = (size_t)160 * 1024;
   L.w_first = w_first;
-  L.max_words = max_words;
+  L.n_windows = n_windows;
+  L.flags = tune.forest_flags;
+  // ring: a power of two of word slots that holds any window of this width whatever its start's offset inside a word
+  int ring = 16;
+  while (ring < (int)((width + 15 + 15) >> 4)) ring <<= 1;
+  L.ring = ring;
+  // one block fills the LDS (the tile is 4 * ring bytes per haplotype): as many haplotypes per block as fit
   int threads = tune.forest_threads / 64 * 64;
   if (threads < 64 || threads > 256) threads = 256;
-  while (threads > 64 && gnx_forest_lds_bytes(L.A, max_words, L.max_trees, L.tree_bytes, threads) > kLds) threads -= 64;
+  while (threads > 64 && gnx_forest_lds_bytes(L.A, ring, L.max_trees, L.tree_bytes, threads) > kLds) threads -= 64;
   while (threads > 64 && (int64_t)(threads - 64) >= L.N) threads -= 64;
-  const size_t lds = gnx_forest_lds_bytes(L.A, max_words, L.max_trees, L.tree_bytes, threads);
+  const size_t lds = gnx_forest_lds_bytes(L.A, ring, L.max_trees, L.tree_bytes, threads);
   if (lds > kLds) return hipErrorInvalidValue;
+  // windows per block: long runs re-use the shared half of every window (the first window of a run is staged in full),
+  // short runs fill the chip: ~5 blocks per CU, at most 12 windows (measured on chr22 / 10 k haplotypes, 140 trees per
+  // window: 8 -> 2.95 ms, 12 -> 2.64, 16 -> 2.73, 24 -> 2.73)
+  const int64_t tiles = (L.N + threads - 1) / threads;
+  int64_t wrun = tune.forest_wrun > 0 ? tune.forest_wrun : std::min<int64_t>(12, (tiles * n_windows) / ((int64_t)5 * n_cu));
+  wrun = std::max<int64_t>(1, wrun);
+  L.wrun = (int)std::min<int64_t>(wrun, n_windows);
   if (L.rf_leafval) {
-    if (L.A <= 8) return launch_rf<8>(L, n_windows, threads, lds, s);
-    if (L.A <= 16) return launch_rf<16>(L, n_windows, threads, lds, s);
-    return launch_rf<32>(L, n_windows, threads, lds, s);
+    if (L.A <= 8) return launch_k<1, true, 8>(L, threads, lds, s);
+    if (L.A <= 16) return launch_k<1, true, 16>(L, threads, lds, s);
+    return launch_k<1, true, 32>(L, threads, lds, s);
   }
   switch (L.D) {
-    case 1: return launch_d<1>(L, n_windows, threads, lds, s);
-    case 2: return launch_d<2>(L, n_windows, threads, lds, s);
-    case 3: return launch_d<3>(L, n_windows, threads, lds, s);
-    case 4: return launch_d<4>(L, n_windows, threads, lds, s);
-    case 5: return launch_d<5>(L, n_windows, threads, lds, s);
-    case 6: return launch_d<6>(L, n_windows, threads, lds, s);
-    case 7: return launch_d<7>(L, n_windows, threads, lds, s);
-    case 8: return launch_d<8>(L, n_windows, threads, lds, s);
+    case 1: return launch_k<1, false, 1>(L, threads, lds, s);
+    case 2: return launch_k<2, false, 1>(L, threads, lds, s);
+    case 3: return launch_k<3, false, 1>(L, threads, lds, s);
+    case 4: return launch_k<4, false, 1>(L, threads, lds, s);
+    case 5: return launch_k<5, false, 1>(L, threads, lds, s);
+    case 6: return launch_k<6, false, 1>(L, threads, lds, s);
+    case 7: return launch_k<7, false, 1>(L, threads, lds, s);
+    case 8: return launch_k<8, false, 1>(L, threads, lds, s);
     default: return hipErrorInvalidValue;
   }
 }
 
 }  // namespace
 
-size_t gnx_forest_lds_bytes(int A, int max_words, int max_trees, int tree_bytes, int threads) {
-  return (size_t)max_words * threads * 4 + (((size_t)max_trees * tree_bytes + 15) & ~(size_t)15) + (size_t)A * threads * 4;
+size_t gnx_forest_lds_bytes(int A, int ring_words, int max_trees, int tree_bytes, int threads) {
+  return (size_t)ring_words * threads * 4 + (((size_t)max_trees * tree_bytes + 15) & ~(size_t)15) + (size_t)A * threads * 4;
 }
 
-hipError_t gnx_launch_base_forest(const ForestLaunch& L, const gnx_tune& tune, hipStream_t s) {
+// word slots a window of `width` padded SNPs needs (power of two, any alignment of its first SNP inside a word)
+int gnx_forest_ring_words(int64_t width) {
+  int ring = 16;
+  while (ring < (int)((width + 15 + 15) >> 4)) ring <<= 1;
+  return ring;
+}
+
+hipError_t gnx_launch_base_forest(const ForestLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
-  // the last window is wider by C mod M (base.py:163-164): its own launch, so that the others get the smaller tile
-  const int words = (int)((L.width + 15) >> 4), words_last = (int)((L.width_last + 15) >> 4);
-  hipError_t e = launch_range(L, 0, L.W - 1, words, tune, s);
+  // the last window is wider by C mod M (base.py:163-164): its own launch, so that the others get the smaller ring
+  hipError_t e = launch_range(L, 0, L.W - 1, L.width, n_cu, tune, s);
   if (e != hipSuccess) return e;
-  return launch_range(L, L.W - 1, 1, words_last, tune, s);
+  return launch_range(L, L.W - 1, 1, L.width_last, n_cu, tune, s);
 }
