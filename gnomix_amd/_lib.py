@@ -14,7 +14,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 6
+GNX_ABI_VERSION = 7
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
@@ -62,6 +62,11 @@ class ModelDesc(C.Structure):
                 ("rf_value", C.c_void_p), ("cnn_weight", C.c_void_p), ("cnn_bias", C.c_void_p)]
 
 
+class TrainInfo(C.Structure):
+    _fields_ = [("newton_iterations", C.c_int32), ("cg_iterations", C.c_int32), ("n_problems", C.c_int32), ("reserved", C.c_int32),
+                ("worst_rel_gradient", C.c_double), ("objective_sum", C.c_double)]
+
+
 class ModelInfo(C.Structure):
     _fields_ = [("C", C.c_int64), ("M", C.c_int64), ("ctx", C.c_int64), ("W", C.c_int64), ("A", C.c_int32),
                 ("S", C.c_int32), ("base_kind", C.c_int32), ("smooth_kind", C.c_int32), ("n_trees", C.c_int32),
@@ -99,6 +104,10 @@ SYMBOLS = {
     "gnx_calibrate_rows": (C.c_int, [_VP, _VP, _I, _I64, _VP]),
     "gnx_gnofix": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
     "gnx_gnofix_dev": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
+    "gnx_train_logistic": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _I64, _I64, _I64, C.c_int32, C.c_double, C.c_double, C.c_int32, _VP, _I64, _VP,
+                                     C.POINTER(TrainInfo)]),
+    "gnx_train_logistic_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _I64, _I64, _I64, C.c_int32, C.c_double, C.c_double, C.c_int32, _VP, _I64,
+                                         _VP, C.POINTER(TrainInfo)]),
     "gnx_profile_enable": (C.c_int, [_VP, _I]),
     "gnx_profile_reset": (C.c_int, [_VP]),
     "gnx_profile_get": (C.c_int, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

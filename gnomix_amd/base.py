@@ -26,6 +26,19 @@ class HipBase:
         self.log_inference = False
         self.time = {}
 
+    def train(self, X, y, verbose=False):
+        """Base.train (base.py:104-127) for the logistic base: fits every window's LogisticRegression on the device and swaps
+        the device model for the freshly trained one.  X (N, C) int8, y (N, W) window labels."""
+        from .train import train_logistic_base
+        from .model import DeviceModel
+        if self.dev.data.base_kind not in (None, "logistic"):
+            raise NotImplementedError("on-device training is built for the logistic base (LogisticRegressionBase)")
+        t = time()
+        self.train_info = train_logistic_base(self.dev.data, X, y, ctx=self.dev.ctx)
+        self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)   # (a HipGnomix re-binds its smoother: HipGnomix.train_base)
+        self.time["train"] = time() - t
+        return self
+
     def predict_proba(self, X):
         """X (N, C) int8-like -> B (N, W, A) float64, as Base.predict_proba (base.py:129-180)."""
         t = time()

@@ -1489,6 +1489,42 @@ int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_
   return GNX_OK;
 }
 
+// ---- training --------------------------------------------------------------------------------------------
+int gnx_train_logistic_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ldx, const int32_t* dy, int64_t C, int64_t M, int64_t cx,
+                           int32_t A, double C_reg, double tol, int32_t max_iter, double* coef, int64_t ldc, double* intercept,
+                           gnx_train_info* info) {
+  if (!ctx) return GNX_EINVAL;
+  if (!ctx->usable) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
+  if (N <= 0 || !dX || !dy || !coef || !intercept) return fail(ctx, GNX_EINVAL, "train_logistic: bad X / y / outputs");
+  if (A < 2 || A > 32) return fail(ctx, GNX_EINVAL, "A (ancestries) must be in [2, 32]");
+  if (M <= 0 || C < M || cx < 0 || cx > C || ldx < C) return fail(ctx, GNX_EINVAL, "bad C / M / ctx / ldx");
+  if (C % M == 0) return fail(ctx, GNX_EINVAL, "C % M == 0: the reference's window slicing (base.py:158) requires a remainder");
+  if (ldc < M + 2 * cx + C % M) return fail(ctx, GNX_EINVAL, "train_logistic: ldc < M + 2*ctx + C % M");
+  if (!(C_reg > 0.0) || !(tol > 0.0)) return fail(ctx, GNX_EINVAL, "train_logistic: C_reg and tol must be positive");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int newton = max_iter > 0 ? std::min(max_iter, 200) : 100;
+  HIPCHK(ctx, gnx_train_lr_run(dX, N, ldx, dy, C, M, cx, A, C_reg, tol, newton, 250, coef, ldc, intercept, info, ctx->stream));
+  return GNX_OK;
+}
+
+int gnx_train_logistic(gnx_ctx* ctx, const int8_t* X, int64_t N, int64_t ldx, const int32_t* y, int64_t C, int64_t M, int64_t cx, int32_t A,
+                       double C_reg, double tol, int32_t max_iter, double* coef, int64_t ldc, double* intercept, gnx_train_info* info) {
+  if (!ctx) return GNX_EINVAL;
+  if (!ctx->usable) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
+  if (N <= 0 || !X || !y || M <= 0 || C < M || ldx < C) return fail(ctx, GNX_EINVAL, "train_logistic: bad X / y / geometry");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int64_t W = C / M;
+  int rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)N * ldx + 64)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_lab, (size_t)N * W * 4)) != GNX_OK) return rc;
+  for (int64_t i = 0; i < N * W; ++i)
+    if (y[i] < 0 || y[i] >= A) return fail(ctx, GNX_EINVAL, "train_logistic: label outside [0, A)");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ws_x.p, X, (size_t)(N - 1) * ldx + C, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lab.p, y, (size_t)N * W * 4, hipMemcpyHostToDevice, ctx->stream));
+  return gnx_train_logistic_dev(ctx, (const int8_t*)ctx->ws_x.p, N, ldx, (const int32_t*)ctx->ws_lab.p, C, M, cx, A, C_reg, tol, max_iter,
+                                coef, ldc, intercept, info);
+}
+
 // ---- profiling ---------------------------------------------------------------------------------------
 int gnx_profile_enable(gnx_ctx* ctx, int on) {
   if (!ctx) return GNX_EINVAL;

@@ -340,6 +340,9 @@ size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width);
 hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
 size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
 hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
+hipError_t gnx_train_lr_run(const int8_t* dX, int64_t N, int64_t ldx, const int32_t* dY, int64_t C, int64_t M, int64_t ctx, int A,
+                            double Creg, double tol, int max_newton, int max_cg, double* h_coef, int64_t ldc, double* h_icpt,
+                            gnx_train_info* info, hipStream_t st);
 hipError_t gnx_launch_unpack2(const uint8_t* P, int64_t N, int64_t ldp, int64_t C, int8_t* X, int64_t ldx, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
 hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);

@@ -40,6 +40,16 @@ class HipGnomix:
     def load(cls, path, **kw):
         return cls(GnxModelData.load(path), **kw)
 
+    def train_base(self, X, y):
+        """the base half of Gnomix.train (src/model.py:113, 155): fit the logistic base on the device, then re-bind base,
+        smoother and the fused path to the freshly loaded model"""
+        self.base.train(X, y)
+        self.dev = self.base.dev
+        self.smooth.dev = self.dev
+        if self.smooth.model is not None:
+            self.smooth.model.dev = self.dev
+        return self
+
     def predict(self, X):
         """labels (N, W) — base + smoother fused on the device, B never leaves HBM (model.py:169-173)"""
         _, lab = self.dev.infer(X, want_proba=False, want_labels=True)

@@ -12,6 +12,7 @@
  *   gnx_infer             <- Gnomix.predict_proba(X) / .predict(X)      src/model.py:169-179, gnomix.py:72
  *   gnx_smooth_rows       <- smoother.model.predict_proba(rows)         src/Gnofix/gnofix.py:157
  *   gnx_gnofix            <- Gnomix.phase(X, B) -> gnofix() per indiv.  src/model.py:188-214, src/Gnofix/gnofix.py:58-208
+ *   gnx_train_logistic    <- Base.train(X, y) of LogisticRegressionBase   src/Base/base.py:104-127, src/model.py:113,155
  *
  * Conventions
  *   - return 0 (GNX_OK) or a negative GNX_E* code; the message is kept per context (gnx_last_error).
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 6
+#define GNX_ABI_VERSION 7
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -264,6 +265,28 @@ int gnx_gnofix(gnx_model* model, int8_t* X, int64_t ldx, const double* B, int64_
                int32_t* Y, int32_t* n_switches);
 int gnx_gnofix_dev(gnx_model* model, int8_t* dX, int64_t ldx, const double* dB, int64_t n_ind, int32_t max_it,
                    int32_t* dY, int32_t* d_n_switches);
+
+/* Base.train for the logistic base (src/Base/base.py:104-127 -> per window
+ * LogisticRegression(penalty="l2", C=3., solver="liblinear", max_iter=1000).fit(X_w, y_w), src/Base/models.py:12-21; called
+ * twice by Gnomix.train, src/model.py:104-167): all W windows x A one-vs-rest problems (A == 2: one problem per window, as
+ * sklearn) of  min_w 1/2 w'w + C_reg sum_i log(1 + exp(-y_i w'[x_i, 1]))  minimised at once on the device, float64.
+ *   X (N, ldx) int8 {0,1,2}, y (N, W) int32 window labels in [0, A)  (rows = haplotypes)
+ *   tol: stop a problem when |grad| <= tol * |grad at w = 0| (liblinear stops at ~1e-4 scaled by the class balance; the
+ *        default 1e-9 converges to the optimum that the reference's solver approximates); max_iter bounds Newton steps
+ *   coef (W, A, ldc) / intercept (W, A): HOST outputs in exactly the layout gnx_model_desc.lr_coef / lr_intercept take
+ *        (A == 2: rows (-w, +w), see gnomix_amd.convert.lr_rows_from_sklearn); ldc >= M + 2 ctx + C % M
+ * The unsuffixed entry point takes host X / y and stages them; _dev takes device X / y (context's device). */
+typedef struct gnx_train_info {
+  int32_t newton_iterations, cg_iterations, n_problems, reserved;
+  double worst_rel_gradient; /* max over problems of |grad| / |grad at 0| on return */
+  double objective_sum;      /* sum over problems of the objective at the returned w */
+} gnx_train_info;
+int gnx_train_logistic(gnx_ctx* ctx, const int8_t* X, int64_t N, int64_t ldx, const int32_t* y, int64_t C, int64_t M,
+                       int64_t ctx_snps, int32_t A, double C_reg, double tol, int32_t max_iter, double* coef, int64_t ldc,
+                       double* intercept, gnx_train_info* info);
+int gnx_train_logistic_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ldx, const int32_t* dy, int64_t C, int64_t M,
+                           int64_t ctx_snps, int32_t A, double C_reg, double tol, int32_t max_iter, double* coef, int64_t ldc,
+                           double* intercept, gnx_train_info* info);
 
 /* per-kernel device time, measured with hipEvents on the context stream around every launch */
 int gnx_profile_enable(gnx_ctx* ctx, int on);

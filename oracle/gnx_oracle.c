@@ -59,10 +59,12 @@ int gnxo_base_lr(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t M, 
   if (rem == 0) return GNXO_EINVAL; /* base.py:158 relies on C % M != 0 (gnomix.py:124-125) */
   if (ldc < M_ + rem) return GNXO_EINVAL;
   double p[64];
-  for (int64_t n = 0; n < N; ++n) {
-    const int8_t* x = X + n * ldx;
-    for (int64_t i = 0; i < W; ++i) {
-      const int64_t start = i * M, len = (i == W - 1) ? M_ + rem : M_;
+  /* window-major: one window's coefficients (A x M_ doubles) stay in cache while every haplotype of the call goes through
+   * them; per (haplotype, window, class) the arithmetic and its order are what sklearn's decision_function + expit do */
+  for (int64_t i = 0; i < W; ++i) {
+    const int64_t start = i * M, len = (i == W - 1) ? M_ + rem : M_;
+    for (int64_t n = 0; n < N; ++n) {
+      const int8_t* x = X + n * ldx;
       double s = 0.0;
       for (int64_t a = 0; a < A; ++a) {
         const double* c = coef + (i * A + a) * ldc;

@@ -406,3 +406,60 @@ class OracleXGBSmoother:
 
     def predict(self, B):
         return np.argmax(self.predict_proba(B), axis=-1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# f4  Base.train for the logistic base (src/Base/base.py:104-127 -> sklearn LogisticRegression(penalty="l2", C=3.,
+#     solver="liblinear", max_iter=1000).fit per window, src/Base/models.py:12-21).  liblinear's primal L2R_LR problem per
+#     class (one-vs-rest; A == 2: one problem, positive class 1), bias = regularised extra feature of value 1:
+#         f(w) = 1/2 w'w + C sum_i log(1 + exp(-y_i w'x_i))
+#     f is strictly convex: the fit is its unique minimiser, which liblinear approximates to tol = 1e-4.  This restatement is
+#     a dense exact Newton method in numpy (small windows only: it factors the (width+1)^2 Hessian), run to 1e-12.
+# ----------------------------------------------------------------------------------------------------------------------
+def lr_objective(w, Xb, ypm, C_reg=3.0):
+    z = Xb @ w
+    return 0.5 * float(w @ w) + C_reg * float(np.sum(np.logaddexp(0.0, -ypm * z)))
+
+
+def _lr_fit_one(Xb, ypm, C_reg, tol=1e-12, max_it=100):
+    n = Xb.shape[1]
+    w = np.zeros(n)
+    g0 = None
+    for _ in range(max_it):
+        t = ypm * (Xb @ w)
+        sg = 1.0 / (1.0 + np.exp(-t))
+        g = w + C_reg * (Xb.T @ ((sg - 1.0) * ypm))
+        gn = float(np.linalg.norm(g))
+        if g0 is None:
+            g0 = gn
+        if gn <= tol * g0:
+            break
+        D = C_reg * sg * (1.0 - sg)
+        H = np.eye(n) + (Xb.T * D) @ Xb
+        s = -np.linalg.solve(H, g)
+        f0, a = lr_objective(w, Xb, ypm, C_reg), 1.0
+        while lr_objective(w + a * s, Xb, ypm, C_reg) - f0 > 0.01 * a * float(g @ s) and a > 1e-12:
+            a *= 0.5
+        w = w + a * s
+    return w
+
+
+def train_lr(X, y, M, ctx, A, C_reg=3.0):
+    """-> (coef (W, A, ldc), intercept (W, A)) in the layout of GnxModelData.lr_coef / lr_intercept (A == 2: rows -w, +w)"""
+    X = np.ascontiguousarray(X, dtype=np.int8)
+    N, Cn = X.shape
+    W = Cn // M
+    rem = Cn - M * W
+    ldc = M + 2 * ctx + rem
+    coef, icpt = np.zeros((W, A, ldc)), np.zeros((W, A))
+    for i, Xw in base_windows(X, M, ctx):
+        Xb = np.concatenate([Xw.astype(np.float64), np.ones((N, 1))], axis=1)
+        for a in ([1] if A == 2 else range(A)):
+            w = _lr_fit_one(Xb, np.where(y[:, i] == a, 1.0, -1.0), C_reg)
+            if A == 2:
+                coef[i, 0, :Xw.shape[1]], coef[i, 1, :Xw.shape[1]] = -w[:-1], w[:-1]
+                icpt[i] = [-w[-1], w[-1]]
+            else:
+                coef[i, a, :Xw.shape[1]] = w[:-1]
+                icpt[i, a] = w[-1]
+    return coef, icpt

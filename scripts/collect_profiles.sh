@@ -1,18 +1,49 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
-#   gpurun -- 'bash scripts/collect_profiles.sh'
-# then on the dev side:  python scripts/summarize_prof.py gpurun_out profiles r01c
-# One --kernel-trace --stats pass, then SEPARATE --pmc passes (counters only, never combined with sys/runtime traces),
-# as /opt/skills/guides/MI355X_MICROARCH.md prescribes for HBM traffic (FETCH_SIZE / WRITE_SIZE) on gfx950.
+# Collect the rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 3000 -- 'bash scripts/collect_profiles.sh [bench] [modes] [cf] [rf] [c5a] [c5b] [c3] [c4]'
+# (the script condenses the traces on the box: gpurun_out/prof_summary/ comes back; copy what is to be judged into profiles/)
+# Per workload: ONE --kernel-trace --stats pass, then SEPARATE --pmc passes (counters only, never combined with sys/runtime
+# traces), as /opt/skills/guides/MI355X_MICROARCH.md prescribes for HBM traffic (FETCH_SIZE / WRITE_SIZE) on gfx950.
+#   bench   = bench.py (config 2: logistic + xgb smoother)          modes = chr22 with the CRF and CNN smoothers
+#   cf / rf = chr22 with the boosted-tree / random-forest bases      c5a   = chr1 WGS, A = 12, logistic + CRF
+#   c5b     = Gnofix re-phasing loop                                  c3    = chr1 array, CovRSK/SVC base + xgb
+#   c4      = whole genome, 22 chromosome models (JSON only: scripts/bench_configs.py c4)
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
-BENCH="python bench.py --steps 3 --warmup 1 --cpu-seconds 0"
-mkdir -p gpurun_out
-rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq gpurun_out/prof_tc
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o stats -- python bench.py --steps 20 --warmup 3 --cpu-seconds 0 > gpurun_out/prof_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o c -- $BENCH > gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -o c -- $BENCH > gpurun_out/prof_write.log 2>&1
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/prof_sq -o c -- $BENCH > gpurun_out/prof_sq.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d gpurun_out/prof_tc -o c -- $BENCH > gpurun_out/prof_tc.log 2>&1
-find gpurun_out/prof_* -name "*.csv" | head -20
-tail -1 gpurun_out/prof_stats.log | cut -c1-200
+WHICH="${@:-bench modes cf rf c5a c5b c3 c4}"
+OUT=gpurun_out/prof
+mkdir -p $OUT
+SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU"
+TC="TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
+for cfg in $WHICH; do
+  if [ "$cfg" = "bench" ]; then
+    CMD="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-steps 0"
+    STATS="python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --e2e-steps 0"
+  elif [ "$cfg" = "c4" ]; then
+    python scripts/bench_configs.py c4 > $OUT/c4.log 2>&1
+    cp gpurun_out/bench_configs.json $OUT/c4.json
+    tail -1 $OUT/c4.log | cut -c1-300
+    continue
+  else
+    CMD="python scripts/bench_configs.py $cfg"
+    STATS="$CMD"
+  fi
+  rm -rf $OUT/$cfg; mkdir -p $OUT/$cfg
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$cfg/stats -o s -- $STATS > $OUT/$cfg/stats.log 2>&1
+  grep '"config"' $OUT/$cfg/stats.log | tail -2 > $OUT/$cfg/result.jsonl
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$cfg/fetch -o c -- $CMD > $OUT/$cfg/fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/$cfg/write -o c -- $CMD > $OUT/$cfg/write.log 2>&1
+  rocprofv3 --pmc $SQ --output-format csv -d $OUT/$cfg/sq -o c -- $CMD > $OUT/$cfg/sq.log 2>&1
+  if [ "$cfg" = "bench" ]; then
+    rocprofv3 --pmc $TC --output-format csv -d $OUT/$cfg/tc -o c -- $CMD > $OUT/$cfg/tc.log 2>&1
+  fi
+  # the raw traces are large: keep the per-kernel csv files only
+  find $OUT/$cfg -name "*.csv" | grep -v -e kernel_stats -e counter_collection | xargs -r rm -f
+  echo "$cfg done: $(find $OUT/$cfg -name '*.csv' | wc -l) csv files"
+done
+# the per-dispatch counter CSVs run to > 100 MB: condense them HERE and bring back only the summaries (gpurun merges at most
+# 64 MiB of gpurun_out/)
+python scripts/summarize_prof.py $OUT gpurun_out/prof_summary ${PROF_TAG:-r02} > gpurun_out/prof_summary.log 2>&1
+tail -3 gpurun_out/prof_summary.log | cut -c1-400
+rm -rf $OUT
+du -sh gpurun_out/prof_summary | tail -1

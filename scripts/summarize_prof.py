@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (gpurun_out/prof_*) into the small summaries kept under profiles/.
+"""Condense rocprofv3 CSV output (gpurun_out/prof/<workload>/<pass>/...) into the small summaries kept under profiles/.
 
-  python scripts/summarize_prof.py gpurun_out profiles r01
+  python scripts/summarize_prof.py gpurun_out/prof profiles r02
 
-writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, kernel names truncated),
-profiles/<tag>_pmc.json (per-kernel averages of every collected counter, one --pmc pass per group)
-and profiles/traffic_latest.json (HBM bytes per launch per kernel, FETCH_SIZE doubled as
+writes per workload   profiles/<tag>_<workload>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, names shortened)
+                      profiles/<tag>_<workload>_pmc.json           (per-kernel averages of every counter, one --pmc pass
+                                                                    per group; `derived` adds busy fractions and HBM bytes)
+                      profiles/<tag>_<workload>_result.jsonl       (the workload's own JSON line(s) from the stats pass)
+and profiles/traffic_latest.json (HBM bytes per launch of the two bench.py kernels: FETCH_SIZE doubled as
 MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on gfx950; KB -> bytes).
 """
 import collections
@@ -13,36 +15,39 @@ import csv
 import glob
 import json
 import os
+import re
+import shutil
 import sys
+
+N_CU, SIMD_PER_CU = 256, 4
 
 
 def short(name):
-    for k in ("k_base_logistic", "k_smooth_xgb", "k_smooth_rows", "k_base_covrsk", "k_smooth_crf", "k_gnofix"):
-        if k in name:
-            return name[name.index(k):][:40]
-    return name[:60]
+    m = re.search(r"(k_[a-z0-9_]+)(<[^>(]*>)?", name)
+    return (m.group(1) + (m.group(2) or ""))[:60] if m else name[:60]
 
 
-def main(src, dst, tag):
-    os.makedirs(dst, exist_ok=True)
-    ks = glob.glob(os.path.join(src, "prof_stats", "*kernel_stats.csv"))
+def one_workload(src, dst, tag, cfg):
+    ks = glob.glob(os.path.join(src, cfg, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    avg_ns = {}
     if ks:
         rows = list(csv.DictReader(open(ks[0])))
-        with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+        with open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w") as f:
             w = csv.writer(f)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
+                avg_ns[short(r["Name"])] = float(r["AverageNs"])
     pmc = collections.defaultdict(dict)
-    for d in sorted(glob.glob(os.path.join(src, "prof_*"))):
-        cc = glob.glob(os.path.join(d, "*counter_collection.csv"))
+    for d in sorted(glob.glob(os.path.join(src, cfg, "*"))):
+        cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if not cc:
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(cc[0])):
             n = r["Kernel_Name"]
-            if "k_" not in n or "anonymous" not in n:
+            if "k_" not in n:
                 continue
             agg[short(n)][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[short(n)]["_meta"] = [(r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"],
@@ -53,14 +58,51 @@ def main(src, dst, tag):
                     pmc[k]["vgpr,agpr,sgpr,lds,grid,wg"] = ",".join(vals[0])
                 else:
                     pmc[k][c] = {"avg_per_launch": sum(vals) / len(vals), "launches": len(vals), "pass": os.path.basename(d)}
-    json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
-    traffic = {}
     for k, v in pmc.items():
+        der = {}
+        t = avg_ns.get(k)
+        if t:
+            der["avg_ns_kernel_trace"] = t
+            cyc = t * 1e-9 * 2.4e9  # 2.4 GHz peak engine clock (MI355X_MICROARCH.md); counters summed over the chip
+            g = lambda c: v[c]["avg_per_launch"] if c in v else None
+            if g("SQ_LDS_IDX_ACTIVE") is not None:
+                der["lds_pipe_busy_frac"] = g("SQ_LDS_IDX_ACTIVE") / (N_CU * cyc)
+                if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
+                    der["lds_conflict_frac_of_active"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+            if g("SQ_ACTIVE_INST_VALU") is not None:      # quad-cycles (MI355X_MICROARCH.md §counters): x4 = cycles, per SIMD
+                der["valu_busy_frac"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (N_CU * SIMD_PER_CU * cyc)
+            if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+                der["mfma_busy_frac"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (N_CU * SIMD_PER_CU * cyc)
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            name = "k_base_logistic" if "k_base_logistic" in k else "k_smooth_xgb" if "k_smooth_xgb" in k else k
-            traffic[name] = (2.0 * v["FETCH_SIZE"]["avg_per_launch"] + v["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
-    json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
-    print(json.dumps(traffic))
+            der["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"]["avg_per_launch"] + v["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+            if t:
+                der["hbm_GBps"] = der["hbm_bytes_per_launch"] / (t * 1e-9) / 1e9
+        v["derived"] = der
+    if pmc:
+        json.dump(pmc, open(os.path.join(dst, f"{tag}_{cfg}_pmc.json"), "w"), indent=1, sort_keys=True)
+    res = os.path.join(src, cfg, "result.jsonl")
+    if os.path.exists(res) and os.path.getsize(res):
+        shutil.copy(res, os.path.join(dst, f"{tag}_{cfg}_result.jsonl"))
+    return pmc
+
+
+def main(src, dst, tag):
+    os.makedirs(dst, exist_ok=True)
+    for cfg in sorted(os.listdir(src)):
+        if not os.path.isdir(os.path.join(src, cfg)):
+            if cfg.endswith(".json"):
+                shutil.copy(os.path.join(src, cfg), os.path.join(dst, f"{tag}_{cfg}"))
+            continue
+        pmc = one_workload(src, dst, tag, cfg)
+        print(cfg, {k: {c: round(x, 3) for c, x in v.get("derived", {}).items()} for k, v in pmc.items()})
+        if cfg == "bench":
+            traffic = {"source": f"profiles/{tag}_bench_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"}
+            for k, v in pmc.items():
+                b = v.get("derived", {}).get("hbm_bytes_per_launch")
+                if b is not None:
+                    name = "k_base_logistic" if "k_base_logistic" in k else "k_smooth_xgb" if "k_smooth_xgb" in k else k
+                    traffic[name] = b
+            json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

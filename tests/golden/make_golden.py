@@ -20,6 +20,7 @@ input/output pair produced by executing its own functions:
   G12 / G13 / G14  third-party pins: xgboost smoother, CRFsuite smoother, XGBBase — generated only on a host that has
                    xgboost / sklearn_crfsuite (absent here: they print "skipped"); tests/test_pins_thirdparty.py consumes them
   G15_lr_binary.npz  A = 2 logistic base (sklearn's one-row binary form)
+  G16_lr_train.npz   LogisticRegressionBase.train (base.py:104-127): training data + the reference's fitted coefficients
 
 Third-party modules the reference imports at module import time but that are absent here
 (xgboost, allel, seaborn, calibration, sklearn_crfsuite) are replaced by empty stubs; no code path
@@ -730,8 +731,44 @@ def make_G15(out):
     print("G15", B.shape, "min/max P0", B[..., 0].min(), B[..., 0].max())
 
 
+def make_G16(out):
+    """Base.train of the logistic base: the reference's own LogisticRegressionBase.train (sklearn
+    LogisticRegression(penalty="l2", C=3., solver="liblinear", max_iter=1000) per window, base.py:104-127) on a small
+    problem, A = 3 (one-vs-rest) and A = 2 (sklearn's single-row binary form).  Stored: training data, the fitted
+    coefficients in the (W, A, ldc) layout, and Base.predict_proba of held-out haplotypes."""
+    from src.Base.models import LogisticRegressionBase
+    sys.path.insert(0, ROOT)
+    from gnomix_amd.convert import lr_rows_from_sklearn
+    d = {}
+    for tag, A in (("m", 3), ("b", 2)):
+        rng = np.random.RandomState(94316 + A)
+        C, M = 1237, 100
+        W, ctx = C // M, 50
+        Xt, yt = synth_admixed(rng, 160, C, A, W, M, miss=0.02)
+        for w in range(W):
+            for a in range(A):
+                yt[a, w] = a
+        base = LogisticRegressionBase(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx, n_jobs=1,
+                                      seed=94316, verbose=False)
+        base.base_multithread = False
+        base.train(Xt, yt)
+        Xq, _ = synth_admixed(rng, 20, C, A, W, M, miss=0.03, switch_p=0.1)
+        B = base.predict_proba(Xq)
+        ldc = M + 2 * ctx + (C - M * W)
+        coef = np.zeros((W, A, ldc)); icpt = np.zeros((W, A))
+        for i, m in enumerate(base.models):
+            assert list(m.classes_) == list(range(A))
+            c2, b2 = lr_rows_from_sklearn(m.coef_, m.intercept_, A)
+            coef[i, :, :c2.shape[1]] = c2
+            icpt[i] = b2
+        d.update({tag + "_C": C, tag + "_M": M, tag + "_A": A, tag + "_ctx": ctx, tag + "_Xt": Xt, tag + "_yt": yt.astype(np.int32),
+                  tag + "_coef": coef, tag + "_intercept": icpt, tag + "_Xq": Xq, tag + "_B": B})
+        print("G16", tag, "A", A, "coef", coef.shape, "|coef|max", np.abs(coef).max())
+    np.savez_compressed(out, **d)
+
+
 def main():
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16"]
     have_ref = import_reference()
     if not have_ref:
         _stub_modules()
@@ -752,6 +789,7 @@ def main():
     if "G13" in which: make_G13(os.path.join(HERE, "G13_crf_smoother.npz"))
     if "G14" in which: make_G14(os.path.join(HERE, "G14_xgb_base.npz"))
     if "G15" in which: make_G15(os.path.join(HERE, "G15_lr_binary.npz"))
+    if "G16" in which: make_G16(os.path.join(HERE, "G16_lr_train.npz"))
     return 0
 
 
