@@ -46,6 +46,8 @@ constexpr int FH = 2;    // haplotypes per thread in the forward product
 constexpr int FKC = 128;  // SNPs per LDS chunk of the weights
 
 // Z[n, w, p] = sum_k V[(w,p), k] * xp[n, w*M + k] + V[(w,p), ldw-1]          (ldw-1 = the bias element)
+// NP = compile-time bound of the per-window problem count (accumulators indexed by a run-time class would live in scratch)
+template <int NP>
 __global__ __launch_bounds__(128) void k_tr_forward(Geom g, const int8_t* __restrict__ X, const double* __restrict__ V,
                                                     double* __restrict__ Z) {
   __shared__ double vs[FKC * AMAX];
@@ -61,38 +63,65 @@ __global__ __launch_bounds__(128) void k_tr_forward(Geom g, const int8_t* __rest
     n[h] = ((int64_t)blockIdx.x * blockDim.x + tid) * FH + h;
     row[h] = X + (n[h] < g.N ? n[h] : g.N - 1) * g.ldx;
   }
-  double acc[FH][AMAX];
+  double acc[FH][NP];
 #pragma unroll
   for (int h = 0; h < FH; ++h)
 #pragma unroll
-    for (int p = 0; p < AMAX; ++p) acc[h][p] = 0.0;
-  const bool inner = start >= g.ctx && start + len <= g.ctx + g.C;  // no reflect padding inside this window
+    for (int p = 0; p < NP; ++p) acc[h][p] = 0.0;
+  // no reflect padding inside this window, and the 16-byte loads (which may overrun the window's end by < 16 bytes) stay
+  // inside the row
+  const bool inner = start >= g.ctx && start + ((len + 15) & ~15) <= g.ctx + g.C;
   for (int k0 = 0; k0 < len; k0 += FKC) {
     const int kc = min(FKC, len - k0);
     __syncthreads();
-    for (int e = tid; e < kc * npw; e += blockDim.x) {
+    for (int e = tid; e < kc * NP; e += blockDim.x) {
       const int p = e / kc, k = e - p * kc;
-      vs[k * AMAX + p] = Vw[(size_t)p * g.ldw + k0 + k];
+      vs[k * AMAX + p] = p < npw ? Vw[(size_t)p * g.ldw + k0 + k] : 0.0;
     }
     __syncthreads();
-    for (int k = 0; k < kc; ++k) {
-      double x[FH];
+    if (inner) {
+      // 16 SNPs per load: a lane streams ITS row (one 128-byte line serves 8 consecutive loads); bytes past the window's end
+      // (kc not a multiple of 16) are read but multiplied by nothing
+      for (int k = 0; k < kc; k += 16) {
+        uint32_t q[FH][4];
 #pragma unroll
-      for (int h = 0; h < FH; ++h) {
-        const int64_t pp = start + k0 + k;
-        x[h] = (double)row[h][inner ? pp - g.ctx : pad_src(pp, g.C, g.ctx)];
+        for (int h = 0; h < FH; ++h) __builtin_memcpy(q[h], row[h] + (start + k0 + k - g.ctx), 16);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          if (k + b < kc) {
+            double x[FH];
+#pragma unroll
+            for (int h = 0; h < FH; ++h) x[h] = (double)((q[h][b >> 2] >> (8 * (b & 3))) & 0xffu);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              const double v = vs[(k + b) * AMAX + p];   // rows of vs past npw hold zeros
+#pragma unroll
+              for (int h = 0; h < FH; ++h) acc[h][p] = fma(v, x[h], acc[h][p]);
+            }
+          }
+        }
       }
-      for (int p = 0; p < npw; ++p) {
-        const double v = vs[k * AMAX + p];
+    } else {
+      for (int k = 0; k < kc; ++k) {
+        double x[FH];
 #pragma unroll
-        for (int h = 0; h < FH; ++h) acc[h][p] = fma(v, x[h], acc[h][p]);
+        for (int h = 0; h < FH; ++h) x[h] = (double)row[h][pad_src(start + k0 + k, g.C, g.ctx)];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const double v = vs[k * AMAX + p];
+#pragma unroll
+          for (int h = 0; h < FH; ++h) acc[h][p] = fma(v, x[h], acc[h][p]);
+        }
       }
     }
   }
 #pragma unroll
   for (int h = 0; h < FH; ++h)
-    if (n[h] < g.N)
-      for (int p = 0; p < npw; ++p) Z[((size_t)n[h] * g.W + w) * npw + p] = acc[h][p] + Vw[(size_t)p * g.ldw + g.ldw - 1];
+    if (n[h] < g.N) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        if (p < npw) Z[((size_t)n[h] * g.W + w) * npw + p] = acc[h][p] + Vw[(size_t)p * g.ldw + g.ldw - 1];
+    }
 }
 
 constexpr int BK = 256;  // SNPs per block of the backward product (thread = SNP)
@@ -100,10 +129,10 @@ constexpr int BN = 32;   // haplotypes per LDS tile
 
 // G[(w,p), k] = sum_n xp[n, w*M + k]^(1 or 2) * R[n, w, p]  (k < len);   G[(w,p), ldw-1] = sum_n R[n, w, p]
 // SQUARE = true gives the diagonal of X'DX (the Jacobi preconditioner) from R = D.
-template <bool SQUARE>
+template <bool SQUARE, int NP>
 __global__ __launch_bounds__(BK) void k_tr_backward(Geom g, const int8_t* __restrict__ X, const double* __restrict__ R,
                                                     double* __restrict__ G) {
-  __shared__ uint8_t xt[BN][BK];
+  __shared__ __attribute__((aligned(16))) uint8_t xt[BN][BK];
   __shared__ double rs[BN][AMAX];
   const int w = blockIdx.y, tid = threadIdx.x;
   const int npw = g.npw;
@@ -112,35 +141,51 @@ __global__ __launch_bounds__(BK) void k_tr_backward(Geom g, const int8_t* __rest
   if (k0 >= len + 1) return;  // (the bias rides in the block that owns k == len)
   const int64_t start = (int64_t)w * g.M;
   const int k = k0 + tid;
-  double acc[AMAX];
+  // the whole BK-wide tile lies inside the window and inside the row: plain 16-byte loads (columns past the window's end or
+  // the bias column make the block take the per-byte path)
+  const bool tile_inner = k0 + BK <= len && start + k0 >= g.ctx && start + k0 + BK <= g.ctx + g.C;
+  double acc[NP];
 #pragma unroll
-  for (int p = 0; p < AMAX; ++p) acc[p] = 0.0;
+  for (int p = 0; p < NP; ++p) acc[p] = 0.0;
   for (int64_t n0 = 0; n0 < g.N; n0 += BN) {
     __syncthreads();
-    for (int e = tid; e < BN * BK; e += BK) {
-      const int r = e / BK, c = e - r * BK;
-      const int64_t n = n0 + r, pp = start + k0 + c;
-      uint8_t v = 0;
-      if (n < g.N && k0 + c < len) v = (uint8_t)X[n * g.ldx + pad_src(pp, g.C, g.ctx)];
-      else if (n < g.N && k0 + c == len) v = 1;  // the bias feature
-      xt[r][c] = v;
+    if (tile_inner) {  // 16 bytes per load, 16 lanes along a row
+      for (int e = tid; e < BN * (BK / 16); e += BK) {
+        const int r = e / (BK / 16), c = (e - r * (BK / 16)) * 16;
+        const int64_t n = n0 + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n < g.N) __builtin_memcpy(&v, X + n * g.ldx + (start + k0 + c - g.ctx), 16);
+        *reinterpret_cast<uint4*>(&xt[r][c]) = v;
+      }
+    } else {
+      for (int e = tid; e < BN * BK; e += BK) {
+        const int r = e / BK, c = e - r * BK;
+        const int64_t n = n0 + r, pp = start + k0 + c;
+        uint8_t v = 0;
+        if (n < g.N && k0 + c < len) v = (uint8_t)X[n * g.ldx + pad_src(pp, g.C, g.ctx)];
+        else if (n < g.N && k0 + c == len) v = 1;  // the bias feature
+        xt[r][c] = v;
+      }
     }
-    for (int e = tid; e < BN * npw; e += BK) {
-      const int r = e / npw, p = e - r * npw;
+    for (int e = tid; e < BN * NP; e += BK) {
+      const int r = e / NP, p = e - r * NP;
       const int64_t n = n0 + r;
-      rs[r][p] = n < g.N ? R[((size_t)n * g.W + w) * npw + p] : 0.0;
+      rs[r][p] = (n < g.N && p < npw) ? R[((size_t)n * g.W + w) * npw + p] : 0.0;
     }
     __syncthreads();
 #pragma unroll 4
     for (int r = 0; r < BN; ++r) {
       double x = (double)xt[r][tid];
       if (SQUARE) x *= x;
-      for (int p = 0; p < npw; ++p) acc[p] = fma(x, rs[r][p], acc[p]);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) acc[p] = fma(x, rs[r][p], acc[p]);
     }
   }
   if (k <= len) {
     const int kk = (k == len) ? g.ldw - 1 : k;
-    for (int p = 0; p < npw; ++p) G[((size_t)w * npw + p) * g.ldw + kk] = acc[p];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if (p < npw) G[((size_t)w * npw + p) * g.ldw + kk] = acc[p];
   }
 }
 
@@ -273,8 +318,14 @@ hipError_t gnx_train_lr_run(const int8_t* dX, int64_t N, int64_t ldx, const int3
   const dim3 fgrid((unsigned)((N + 128 * FH - 1) / (128 * FH)), (unsigned)W);
   const dim3 bgrid((unsigned)((g.len_last + 1 + BK - 1) / BK), (unsigned)W);
   const dim3 sgrid((unsigned)W, (unsigned)std::min<int64_t>(64, (N + 255) / 256));
-  auto forward = [&](const double* V, double* Zout) { hipLaunchKernelGGL(k_tr_forward, fgrid, dim3(128), 0, st, g, dX, V, Zout); };
-  auto backward = [&](const double* Rin, double* Gout) { hipLaunchKernelGGL(k_tr_backward<false>, bgrid, dim3(BK), 0, st, g, dX, Rin, Gout); };
+#define GNX_TR_NP(CALL)                                   \
+  if (npw <= 1) { CALL(1) } else if (npw <= 4) { CALL(4) } else if (npw <= 8) { CALL(8) } else if (npw <= 16) { CALL(16) } else { CALL(32) }
+#define GNX_TR_FWD(NP_) hipLaunchKernelGGL(k_tr_forward<NP_>, fgrid, dim3(128), 0, st, g, dX, V, Zout);
+#define GNX_TR_BWD(NP_) hipLaunchKernelGGL((k_tr_backward<false, NP_>), bgrid, dim3(BK), 0, st, g, dX, Rin, Gout);
+#define GNX_TR_BSQ(NP_) hipLaunchKernelGGL((k_tr_backward<true, NP_>), bgrid, dim3(BK), 0, st, g, dX, Rin, Gout);
+  auto forward = [&](const double* V, double* Zout) { GNX_TR_NP(GNX_TR_FWD) };
+  auto backward = [&](const double* Rin, double* Gout) { GNX_TR_NP(GNX_TR_BWD) };
+  auto backward_sq = [&](const double* Rin, double* Gout) { GNX_TR_NP(GNX_TR_BSQ) };
   auto vdot = [&](const double* a, const double* b, double* out) {
     hipLaunchKernelGGL(k_tr_vec<V_DOT>, dim3(P), dim3(256), 0, st, ldw, const_cast<double*>(a), b, nullptr, nullptr, nullptr, out, 1.0);
   };
@@ -321,7 +372,7 @@ hipError_t gnx_train_lr_run(const int8_t* dX, int64_t N, int64_t ldx, const int3
     if (n_act == 0) break;
     TRCHK(push_act(hact));
     // ---- preconditioned CG on H s = -g, H v = v + X'(D .* X v) ----
-    hipLaunchKernelGGL(k_tr_backward<true>, bgrid, dim3(BK), 0, st, g, dX, D.p, pre.p);
+    backward_sq(D.p, pre.p);
     hipLaunchKernelGGL(k_tr_vec<V_PRECOND>, dim3(P), dim3(256), 0, st, ldw, pre.p, pre.p, nullptr, nullptr, nullptr, nullptr, 1.0);
     TRCHK(hipMemsetAsync(s.p, 0, PV * sizeof(double), st));
     hipLaunchKernelGGL(k_tr_vec<V_COPY>, dim3(P), dim3(256), 0, st, ldw, r.p, grad.p, nullptr, nullptr, nullptr, nullptr, 1.0);
