@@ -28,6 +28,7 @@
 //    parks the margins in LDS and applies softmax / sigmoid in float32.
 #include "gnx_internal.h"
 
+#include <cstdint>
 #include <cstdlib>
 
 namespace {
@@ -399,11 +400,20 @@ hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int64_t widt
   while (threads > 64 && (int64_t)(threads - 64) >= L.N) threads -= 64;
   const size_t lds = gnx_forest_lds_bytes(L.A, ring, L.max_trees, L.tree_bytes, threads);
   if (lds > kLds) return hipErrorInvalidValue;
-  // windows per block: long runs re-use the shared half of every window (the first window of a run is staged in full),
-  // short runs fill the chip: ~5 blocks per CU, at most 12 windows (measured on chr22 / 10 k haplotypes, 140 trees per
-  // window: 8 -> 2.95 ms, 12 -> 2.64, 16 -> 2.73, 24 -> 2.73)
+  // windows per block: long runs re-use the shared half of every window (the first window of a run is staged in full, about
+  // two window-steps of work), short runs fill the chip.  Blocks run in rounds of one per CU, so the cost of a run length r
+  // is rounds(r) * (r + 2); measured on chr22 / 10 k haplotypes, 140 trees per window: r = 8 -> 2.95 ms, 11 -> 3.1,
+  // 12 -> 2.64, 16 -> 2.73, 24 -> 2.73 — the model's order
   const int64_t tiles = (L.N + threads - 1) / threads;
-  int64_t wrun = tune.forest_wrun > 0 ? tune.forest_wrun : std::min<int64_t>(12, (tiles * n_windows) / ((int64_t)5 * n_cu));
+  int64_t wrun = tune.forest_wrun;
+  if (wrun <= 0) {
+    int64_t best = INT64_MAX;
+    for (int64_t r = 1; r <= std::min<int64_t>(16, n_windows); ++r) {
+      const int64_t blocks = tiles * ((n_windows + r - 1) / r);
+      const int64_t cost = ((blocks + n_cu - 1) / n_cu) * (r + 2);
+      if (cost < best) { best = cost; wrun = r; }
+    }
+  }
   wrun = std::max<int64_t>(1, wrun);
   L.wrun = (int)std::min<int64_t>(wrun, n_windows);
   if (L.rf_leafval) {
