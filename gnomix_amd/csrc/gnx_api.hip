@@ -810,7 +810,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
   if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
-  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu})
+  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi})
     if (b->p) (void)hipFree(b->p);
   for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal, &ctx->ws_marg})
     if (b->p) (void)hipFree(b->p);
@@ -1075,13 +1075,13 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
   if (m->info.smooth_kind == GNX_SMOOTH_CRF) {
     const size_t n = (size_t)N * m->info.W * m->info.A;
     int rc;
-    double* alpha = d_p64;
-    if (!alpha) {
-      if ((rc = ws_reserve(ctx, ctx->ws_misc, n * sizeof(double))) != GNX_OK) return rc;
-      alpha = (double*)ctx->ws_misc.p;
-    }
+    // psi and the parked alphas live in context scratch with a padded tail (the scan's chunked loads may overrun the last row)
+    if ((rc = ws_reserve(ctx, ctx->ws_misc, n * sizeof(double) + 4096)) != GNX_OK) return rc;
+    double* alpha = (double*)ctx->ws_misc.p;
     if ((rc = ws_reserve(ctx, ctx->ws_scale, (size_t)N * m->info.W * sizeof(double))) != GNX_OK) return rc;
+    if ((rc = ws_reserve(ctx, ctx->ws_psi, n * sizeof(double) + 4096)) != GNX_OK) return rc;
     SmoothCRFLaunch L{};
+    L.psi = (double*)ctx->ws_psi.p;
     L.B = dB; L.b_is_f64 = b_is_f64; L.N = N; L.W = (int32_t)m->info.W; L.A = m->info.A;
     L.state = m->crf_state; L.etrans = m->crf_etrans;
     L.alpha = alpha; L.scale = (double*)ctx->ws_scale.p;

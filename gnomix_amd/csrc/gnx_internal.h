@@ -65,7 +65,7 @@ struct gnx_ctx {
   // first use; buffers alternate between two halves of the staging workspaces
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-  gnx_devbuf ws_pk, ws_xu;
+  gnx_devbuf ws_pk, ws_xu, ws_psi;
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -182,6 +182,7 @@ struct SmoothCRFLaunch {
   int32_t W, A;
   const double* state;    // device (A, A) theta[a][y]
   const double* etrans;   // device (A, A) exp(tau)[y'][y]
+  double* psi;            // (N, W, A) scratch: exp(theta'B) per window and label, computed once for both directions
   double* alpha;          // (N, W, A) scratch for the scaled forward variables (may alias proba64)
   double* scale;          // (N, W) scratch
   double* proba64;        // optional

@@ -4,20 +4,226 @@
 // sklearn_crfsuite.CRF.predict_marginals; CRFsuite semantics as restated in the CPU oracle: attributes
 // "0".."A-1" with values B[n,t,a], dense state weights theta[a][y] and transitions tau[y'][y]).
 //
-// One group of A lanes per haplotype (lane = label y), floor(64/A) haplotypes per wave; the chain is walked
-// forward (scaled alpha, parked in the output buffer) and backward (beta on the fly) in float64 with the
-// same left-to-right association as the oracle; cross-label terms travel by ds_bpermute shuffles.
-// The W-step recurrence is inherently sequential per haplotype: parallelism = haplotypes.  Memory latency is kept off that
-// chain (the base probabilities and, on the way back, the parked alphas and scales of the next PFD steps are requested
-// while the current PFD steps are computed); what remains per step is float64 VALU work: two exp, a division and
-// ~4A shuffles (measured: 17 ms per 25 000 haplotypes x 1431 windows x 12 classes with or without the prefetch).
+// The forward-backward recurrence is sequential over the W windows of a haplotype, so what decides the run time is the
+// LENGTH OF ONE STEP on its critical path.  Round 1 spread a haplotype over A lanes (lane = label) and paid ~7A float64
+// cross-lane shuffles (14A ds_bpermute) per step, plus an exp and a theta'B product twice per step (LDS pipe 56 % busy,
+// 16.6 ms for 25 000 haplotypes x 1431 windows x 12 labels).  Round 2:
+//   * k_crf_psi: psi_t(y) = exp(sum_a theta[a][y] B[t][a]) does not belong to the recurrence — one fully parallel pass
+//     (thread = (haplotype, window)) computes it once for both directions;
+//   * k_crf_scan: ONE LANE PER HAPLOTYPE holds the whole label vector in registers (alpha, beta: A doubles each): a step is
+//     A^2 multiply-adds against exp(tau) rows broadcast from LDS, no cross-lane traffic at all; the lane's rows of psi and of
+//     the parked alphas stream through an LDS ring filled by LDS-direct loads two chunks ahead, so HBM latency is off the chain.
+// Every sum keeps the oracle's left-to-right association (float64, no FMA contraction), so the marginals agree with it as before.
 #include "gnx_internal.h"
 
 namespace {
 
+template <int AT>
+__global__ __launch_bounds__(256) void k_crf_psi(SmoothCRFLaunch L) {
+  __shared__ double th[AT * AT];  // theta[a][y]
+  const int A = L.A;
+  for (int i = threadIdx.x; i < AT * AT; i += blockDim.x) {
+    const int a = i / AT, y = i - a * AT;
+    th[i] = (a < A && y < A) ? L.state[a * A + y] : 0.0;
+  }
+  __syncthreads();
+  const int64_t total = L.N * L.W;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  double b[AT];
+#pragma unroll
+  for (int a = 0; a < AT; ++a) {
+    if (a < A) b[a] = L.b_is_f64 ? reinterpret_cast<const double*>(L.B)[e * A + a] : (double)reinterpret_cast<const float*>(L.B)[e * A + a];
+    else b[a] = 0.0;
+  }
+#pragma unroll
+  for (int y = 0; y < AT; ++y) {
+    if (y < A) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < AT; ++a)
+        if (a < A) s += th[a * AT + y] * b[a];
+      L.psi[e * A + y] = exp(s);
+    }
+  }
+}
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// exp(tau): read from LDS once — the compiler keeps all 2 A^2 doubles (both orientations) in registers across the W steps (one
+// wave per SIMD: 512 VGPRs are there to be used; re-reading them per step put 2 A^2 LDS latencies on the chain: 40 ms vs 16 ms)
+__device__ __forceinline__ double ld_et(const double* p) { return *p; }
+
+// One lane per haplotype, one wave per block, A = AT exactly.  The lane's rows of psi (and, on the way back, of the parked
+// alphas) arrive through an LDS ring filled by `global_load_lds_dwordx4`: chunk c = the TC windows [c TC, (c+1) TC) of every
+// lane's row = TC*A doubles = PC 16-byte pieces per lane, piece p of all 64 lanes in ring slot bytes [p*1024, (p+1)*1024)
+// (LDS-direct loads write lane-linear, which is exactly "every lane its own row").  Two chunks are in flight while one is
+// computed and no register holds data on its way in, so HBM latency never sits on the W-step chain; the only waits are
+// `s_waitcnt vmcnt(loads of the youngest chunk)` (loads retire in order).
+template <int AT>
+__global__ __launch_bounds__(64) void k_crf_scan(SmoothCRFLaunch L) {
+  constexpr int TC = 4, NS = 3;
+  constexpr int PC = TC * AT / 2;              // 16-byte pieces per lane and chunk (TC * AT is even)
+  constexpr int SLOT = PC * 1024;              // bytes per ring slot and array
+  static_assert(2 * PC < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  double* et = reinterpret_cast<double*>(lds);  // exp(tau)[y'][y]
+  double* etT = et + AT * AT;                   // transposed: [y][y']
+  uint8_t* ring = lds + ((2 * AT * AT * 8 + 15) & ~15);  // [2 arrays][NS][SLOT]
+  const int W = L.W, lane = threadIdx.x;
+  for (int i = lane; i < AT * AT; i += 64) {
+    const int r = i / AT, c = i - r * AT;
+    et[r * AT + c] = L.etrans[r * AT + c];
+    etT[c * AT + r] = L.etrans[r * AT + c];
+  }
+  __syncthreads();
+  const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+  const bool active = n < L.N;
+  const int64_t nn = active ? n : L.N - 1;
+  const size_t row0 = (size_t)nn * W * AT;
+  const uint8_t* psi_row = reinterpret_cast<const uint8_t*>(L.psi + row0);
+  const uint8_t* alpha_row = reinterpret_cast<const uint8_t*>(L.alpha + row0);
+  double* alpha = L.alpha + row0;  // parked scaled alphas: always the context's scratch (its tail is padded: chunks may overrun a row)
+  double* scale = L.scale + (size_t)nn * W;
+  const int n_chunks = (W + TC - 1) / TC;
+  auto issue = [&](const uint8_t* rowp, int arr, int c) {  // unconditional, clamped chunk index: PC loads, always
+    const int cc = c < 0 ? 0 : (c > n_chunks - 1 ? n_chunks - 1 : c);
+    const uint8_t* src = rowp + (size_t)cc * (TC * AT * 8);
+    uint8_t* dst = ring + (size_t)(arr * NS + ((c % NS) + NS) % NS) * SLOT;
+#pragma unroll
+    for (int p = 0; p < PC; ++p) __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
+  };
+  auto slot_val = [&](int arr, int c, int idx) -> double {  // value idx (= step-in-chunk * AT + label) of this lane's chunk c
+    const uint8_t* base = ring + (size_t)(arr * NS + ((c % NS) + NS) % NS) * SLOT;
+    return *reinterpret_cast<const double*>(base + (idx >> 1) * 1024 + lane * 16 + (idx & 1) * 8);
+  };
+
+  // ---- forward: alpha_0 = psi_0, alpha_t(y) = psi_t(y) * sum_y' alpha_{t-1}(y') exp(tau)[y'][y], each alpha_t scaled to sum 1 ----
+  double ap[AT];
+#pragma unroll
+  for (int y = 0; y < AT; ++y) ap[y] = 0.0;
+  issue(psi_row, 0, 0);
+  issue(psi_row, 0, 1);
+  for (int c = 0; c < n_chunks; ++c) {
+    wait_vm<PC>();                 // chunk c has landed (at most the PC loads of chunk c+1 are still out)
+    issue(psi_row, 0, c + 2);      // into the slot chunk c-1 left
+#pragma unroll
+    for (int k = 0; k < TC; ++k) {
+      const int t = c * TC + k;
+      if (t < W) {
+        double pc[AT], v[AT];
+#pragma unroll
+        for (int y = 0; y < AT; ++y) pc[y] = slot_val(0, c, k * AT + y);
+        if (t == 0) {
+#pragma unroll
+          for (int y = 0; y < AT; ++y) v[y] = pc[y];
+        } else {
+          double acc[AT];
+#pragma unroll
+          for (int y = 0; y < AT; ++y) acc[y] = 0.0;
+#pragma unroll
+          for (int yp = 0; yp < AT; ++yp)
+#pragma unroll
+            for (int y = 0; y < AT; ++y) acc[y] += ap[yp] * ld_et(et + yp * AT + y);  // per y: y' = 0, 1, ... in order, as the oracle
+#pragma unroll
+          for (int y = 0; y < AT; ++y) v[y] = acc[y] * pc[y];
+        }
+        double sum = 0.0;
+#pragma unroll
+        for (int y = 0; y < AT; ++y) sum += v[y];
+        const double sc = (sum != 0.0) ? 1.0 / sum : 1.0;
+#pragma unroll
+        for (int y = 0; y < AT; ++y) ap[y] = v[y] * sc;
+        if (active) {
+#pragma unroll
+          for (int y = 0; y < AT; ++y) alpha[(size_t)t * AT + y] = ap[y];
+          scale[t] = sc;
+        }
+      }
+    }
+  }
+  wait_vm<0>();            // the stores of this lane's alphas / scales are done ...
+  __threadfence_block();   // ... before the backward pass reads them back
+
+  // ---- backward: beta_{W-1} = c_{W-1}, beta_t(y') = c_t sum_y exp(tau)[y'][y] psi_{t+1}(y) beta_{t+1}(y); marginal = alpha beta / c ----
+  double beta[AT], psin[AT];
+#pragma unroll
+  for (int y = 0; y < AT; ++y) { beta[y] = 0.0; psin[y] = 0.0; }
+  auto issue2 = [&](int c) { issue(psi_row, 0, c); issue(alpha_row, 1, c); };
+  issue2(n_chunks - 1);
+  issue2(n_chunks - 2);
+  for (int c = n_chunks - 1; c >= 0; --c) {
+    wait_vm<2 * PC>();
+    issue2(c - 2);
+    double scs[TC];
+#pragma unroll
+    for (int k = 0; k < TC; ++k) scs[k] = scale[min(c * TC + k, W - 1)];
+#pragma unroll
+    for (int k = TC - 1; k >= 0; --k) {
+      const int t = c * TC + k;
+      if (t < W) {
+        const double sct = scs[k];
+        if (t < W - 1) {
+          double acc[AT];
+#pragma unroll
+          for (int yp = 0; yp < AT; ++yp) acc[yp] = 0.0;
+#pragma unroll
+          for (int y = 0; y < AT; ++y)
+#pragma unroll
+            for (int yp = 0; yp < AT; ++yp) acc[yp] += ld_et(etT + y * AT + yp) * psin[y] * beta[y];  // per y': y = 0, 1, ... in order
+#pragma unroll
+          for (int yp = 0; yp < AT; ++yp) beta[yp] = acc[yp] * sct;
+        } else {
+#pragma unroll
+          for (int y = 0; y < AT; ++y) beta[y] = sct;
+        }
+        double m[AT];
+#pragma unroll
+        for (int y = 0; y < AT; ++y) {
+          psin[y] = slot_val(0, c, k * AT + y);  // psi_t, consumed by step t-1
+          m[y] = slot_val(1, c, k * AT + y) * beta[y] / sct;
+        }
+        int best = 0;  // argmax, first max wins
+        double bv = m[0];
+#pragma unroll
+        for (int y = 1; y < AT; ++y)
+          if (m[y] > bv) { bv = m[y]; best = y; }
+        if (active) {
+          const size_t o = row0 + (size_t)t * AT;
+#pragma unroll
+          for (int y = 0; y < AT; ++y) {
+            if (L.proba64) L.proba64[o + y] = m[y];
+            if (L.proba32) L.proba32[o + y] = (float)m[y];
+          }
+          if (L.labels) L.labels[(size_t)nn * W + t] = best;
+        }
+      }
+    }
+  }
+  wait_vm<0>();  // nothing of this block may still be writing LDS when it retires
+}
+
+template <int AT>
+hipError_t launch(const SmoothCRFLaunch& L, hipStream_t s) {
+  const int64_t total = L.N * L.W;
+  hipLaunchKernelGGL(k_crf_psi<AT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L);
+  constexpr size_t lds = ((2 * AT * AT * 8 + 15) & ~15) + (size_t)2 * 3 * (4 * AT / 2) * 1024;
+  GNX_LDS_OPTIN(lds, k_crf_scan<AT>);
+  hipLaunchKernelGGL(k_crf_scan<AT>, dim3((unsigned)((L.N + 63) / 64)), dim3(64), lds, s, L);
+  return hipGetLastError();
+}
+
+// ---- more than 8 labels: A lanes per haplotype (lane = label), cross-label terms by ds_bpermute shuffles -------------------------
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-__global__ __launch_bounds__(256) void k_smooth_crf(SmoothCRFLaunch L) {
+template <bool PRE>
+__global__ __launch_bounds__(256) void k_smooth_crf_lanes(SmoothCRFLaunch L) {
   extern __shared__ __attribute__((aligned(16))) double lds_d[];
   const int A = L.A, W = L.W;
   double* th = lds_d;           // theta[a][y]
@@ -36,11 +242,14 @@ __global__ __launch_bounds__(256) void k_smooth_crf(SmoothCRFLaunch L) {
   double* alpha = L.alpha + row0;       // (W, A) parked scaled alphas, overwritten by the marginals
   double* scale = L.scale + (size_t)nn * W;
 
+  // PRE: psi_t(y) comes from k_crf_psi's pass (it is not part of the recurrence: computed once for both directions, off the chain)
   auto loadB = [&](int t) -> double {
     const size_t idx = row0 + (size_t)t * A + y;
+    if (PRE) return L.psi[idx];
     return L.b_is_f64 ? reinterpret_cast<const double*>(L.B)[idx] : (double)reinterpret_cast<const float*>(L.B)[idx];
   };
   auto psi_of = [&](double myB) -> double {  // exp(sum_a theta[a][y] * B[t][a])
+    if (PRE) return myB;
     double s = 0.0;
     for (int a = 0; a < A; ++a) s += th[a * A + y] * shfl_d(myB, gbase + a);
     return exp(s);
@@ -140,15 +349,38 @@ __global__ __launch_bounds__(256) void k_smooth_crf(SmoothCRFLaunch L) {
   }
 }
 
+
 }  // namespace
+
+template <int AT>
+hipError_t launch_lanes_pre(const SmoothCRFLaunch& L, hipStream_t s) {
+  const int64_t total = L.N * L.W;
+  hipLaunchKernelGGL(k_crf_psi<AT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L);
+  const int G = 64 / L.A, waves = 4;
+  const int64_t per_block = (int64_t)G * waves;
+  hipLaunchKernelGGL(k_smooth_crf_lanes<true>, dim3((unsigned)((L.N + per_block - 1) / per_block)), dim3(64 * waves),
+                     (size_t)2 * L.A * L.A * sizeof(double), s, L);
+  return hipGetLastError();
+}
 
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
-  const int G = 64 / L.A;
-  const int waves = 4;
-  const int64_t per_block = (int64_t)G * waves;
-  const unsigned grid = (unsigned)((L.N + per_block - 1) / per_block);
-  const size_t lds = (size_t)2 * L.A * L.A * sizeof(double);
-  hipLaunchKernelGGL(k_smooth_crf, dim3(grid), dim3(64 * waves), lds, s, L);
-  return hipGetLastError();
+  if (!L.psi) return hipErrorInvalidValue;
+  // up to 8 labels: one lane per haplotype (k_crf_scan; chr22 / A = 7: 1.02 ms vs 1.26 ms).  More labels: the lane's A^2 products
+  // per step outgrow what one lane does between two windows (A = 12 measured 20 ms vs 16.6 ms) — A lanes per haplotype with the
+  // cross-label terms by shuffle, psi from the parallel pre-pass
+  switch (L.A) {
+    case 2: return launch<2>(L, s);
+    case 3: return launch<3>(L, s);
+    case 4: return launch<4>(L, s);
+    case 5: return launch<5>(L, s);
+    case 6: return launch<6>(L, s);
+    case 7: return launch<7>(L, s);
+    case 8: return launch<8>(L, s);
+    default: break;
+  }
+  if (L.A <= 12) return launch_lanes_pre<12>(L, s);
+  if (L.A <= 16) return launch_lanes_pre<16>(L, s);
+  if (L.A <= 24) return launch_lanes_pre<24>(L, s);
+  return launch_lanes_pre<32>(L, s);
 }
