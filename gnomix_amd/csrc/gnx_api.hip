@@ -767,6 +767,7 @@ static void read_tune(gnx_tune& t) {
   if (const char* e = std::getenv("GNX_SM_TUNE")) std::sscanf(e, "%d,%d", &t.smf_rpl, &t.smf_nw);
   t.forest_threads = geti("GNX_FOREST_T", 0);
   t.forest_wrun = geti("GNX_FOREST_WRUN", 0);
+  t.forest_halves = geti("GNX_FOREST_H", 0);
   t.forest_flags = geti("GNX_FOREST_FLAGS", 0);
   if (const char* e = std::getenv("GNX_HOST_BATCH")) t.host_batch = std::atoll(e);
   t.h2d_overlap = geti("GNX_H2D_OVERLAP", 1);

@@ -36,6 +36,7 @@ struct gnx_tune {
   int smf_rpl = 0, smf_nw = 0;          // GNX_SM_TUNE="rpl,nw": float smoother
   int forest_threads = 0;               // GNX_FOREST_T
   int forest_wrun = 0;                  // GNX_FOREST_WRUN: windows per block of the forest bases
+  int forest_halves = 0;                // GNX_FOREST_H=1: one wave group per tile (default: two for the boosted-tree base)
   int forest_flags = 0;                 // GNX_FOREST_FLAGS: ablation (1 = no walks, 2 = no register prefetch, 4 = no incremental staging)
   int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
   int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points

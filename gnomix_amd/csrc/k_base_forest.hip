@@ -99,11 +99,13 @@ __device__ __forceinline__ void walk(const uint8_t* tb, int tree_bytes, const Ti
 struct Stager {
   const int8_t* X;      // copies of the launch fields (a reference to the kernel argument would force it into scratch)
   int64_t N, ldx, C, ctx, cmax, blk0;
-  int T, wsub, hsub, wv;
-  __device__ __forceinline__ Stager(const int8_t* X_, int64_t N_, int64_t ldx_, int64_t C_, int64_t ctx_, int T_)
+  int T, wsub, hsub, wv, hb0, hbn;  // T haplotypes per block; this wave stages groups hb0 .. hb0+hbn-1 (8 haplotypes each) of its 64
+  __device__ __forceinline__ Stager(const int8_t* X_, int64_t N_, int64_t ldx_, int64_t C_, int64_t ctx_, int T_, int halves)
       : X(X_), N(N_), ldx(ldx_), C(C_), ctx(ctx_), T(T_) {
     const int lane = threadIdx.x & 63;
-    wsub = lane & 7; hsub = lane >> 3; wv = threadIdx.x >> 6;
+    const int hap = (int)threadIdx.x % T_, half = (int)threadIdx.x / T_;
+    wsub = lane & 7; hsub = lane >> 3; wv = hap >> 6;
+    hbn = 8 / halves; hb0 = half * hbn;
     cmax = C - 16;  // the model loader guarantees C >= 16
     blk0 = (int64_t)blockIdx.x * T;
   }
@@ -138,7 +140,7 @@ struct Stager {
   }
   // words [ga, gb) of the wave's 64 haplotypes -> ring, synchronously
   __device__ void stage(uint32_t* xw, uint32_t mask, int64_t ga, int64_t gb) const {
-    for (int hb = 0; hb < 8; ++hb) {
+    for (int hb = hb0; hb < hb0 + hbn; ++hb) {
       const int8_t* r = row(hb);
       uint32_t* col = xw + wv * 64 + hb * 8 + hsub;
       for (int64_t gw = ga; gw < gb; gw += 8 * LB) {
@@ -162,26 +164,27 @@ template <int Q>
 __device__ __forceinline__ void pf_issue(const Stager& st, int64_t ga, int64_t glast, v4u (&raw)[LB]) {
 #pragma unroll
   for (int h2 = 0; h2 < 2; ++h2) {
-    const int8_t* r = st.row(2 * Q + h2);
+    const int8_t* r = st.row(st.hb0 + 2 * Q + h2);
 #pragma unroll
     for (int u = 0; u < LB / 2; ++u) raw[h2 * (LB / 2) + u] = st.load_inner(r, min(ga + 8 * u + st.wsub, glast));
   }
 }
 template <int Q>
-__device__ __forceinline__ void pf_consume(const v4u (&raw)[LB], uint32_t (&sq)[NPF * LB]) {
+__device__ __forceinline__ void pf_consume(const v4u (&raw)[LB], uint32_t* sq) {
 #pragma unroll
   for (int k = 0; k < LB; ++k)
     sq[Q * LB + k] = squeeze4(raw[k].x) | (squeeze4(raw[k].y) << 8) | (squeeze4(raw[k].z) << 16) | (squeeze4(raw[k].w) << 24);
 }
-// batch q goes out after the previous one was squeezed into its registers (q is block-uniform; q == NPF drains the last)
-#define GNX_PF_ADVANCE(q)                                                     \
-  switch (q) {                                                                \
-    case 0: pf_issue<0>(st, pf_ga, pf_gb - 1, raw); break;                               \
-    case 1: pf_consume<0>(raw, sq); pf_issue<1>(st, pf_ga, pf_gb - 1, raw); break;       \
-    case 2: pf_consume<1>(raw, sq); pf_issue<2>(st, pf_ga, pf_gb - 1, raw); break;       \
-    case 3: pf_consume<2>(raw, sq); pf_issue<3>(st, pf_ga, pf_gb - 1, raw); break;       \
-    default: pf_consume<3>(raw, sq); break;                                   \
-  }
+// batch q goes out after the previous one was squeezed into its registers (q is block-uniform; q == NB drains the last);
+// NB = batches per wave = 4 (the wave stages all 8 haplotype groups of its 64) or 2 (two wave groups share them)
+template <int NB>
+__device__ __forceinline__ void pf_advance(const Stager& st, int q, int64_t ga, int64_t glast, v4u (&raw)[LB], uint32_t (&sq)[NB * LB]) {
+  if (q == 0) pf_issue<0>(st, ga, glast, raw);
+  else if (q == 1) { pf_consume<0>(raw, sq); if constexpr (NB > 1) pf_issue<1>(st, ga, glast, raw); }
+  else if (q == 2) { if constexpr (NB > 1) pf_consume<1>(raw, sq); if constexpr (NB > 2) pf_issue<2>(st, ga, glast, raw); }
+  else if (q == 3) { if constexpr (NB > 2) pf_consume<2>(raw, sq); if constexpr (NB > 3) pf_issue<3>(st, ga, glast, raw); }
+  else { if constexpr (NB > 3) pf_consume<3>(raw, sq); }
+}
 
 __device__ __forceinline__ void window_words(const ForestLaunch& L, int w, int64_t& g0, int64_t& g1) {
   const int64_t s = (int64_t)w * L.M, width = (w == L.W - 1) ? L.width_last : L.width;
@@ -193,26 +196,32 @@ __device__ __forceinline__ void window_words(const ForestLaunch& L, int w, int64
 // (mask bit v = "float32(v) <= threshold"); a leaf contributes its class-probability row (float64, expanded per heap slot in
 // global memory: 20 trees x 16 leaves x A doubles per window stay in L1/L2), the rows are added in estimator order and divided
 // by the tree count, as ForestClassifier.predict_proba does.
-template <int D, bool RF, int AMAX>
-__global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
+// H = wave groups per block: H = 2 puts 8 waves on a 256-haplotype tile — the tile is what fills the LDS, waves are free —
+// the two groups stage different haplotype groups, walk different classes of the SAME haplotypes (margins meet in LDS) and group
+// 0 writes the window's probabilities; two waves per SIMD overlap each other's LDS latencies and staging instructions.
+template <int D, bool RF, int AMAX, int H>
+__global__ __launch_bounds__(256 * H) void k_base_forest(ForestLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int tid = threadIdx.x, T = blockDim.x;
+  constexpr int NB = NPF / H;      // prefetch batches per wave
+  constexpr int TPW = TP / H;      // trees walked side by side per lane (two waves per SIMD need half the chains and registers)
+  const int tid = threadIdx.x, NTHR = blockDim.x, T = NTHR / H;
+  const int half = tid / T, hap = tid - half * T;
   const int A = L.A, tree_bytes = L.tree_bytes;
   const int Dr = RF ? L.D : D;  // the random-forest walk is depth-generic
   const uint32_t mask = (uint32_t)L.ring - 1u;
   uint32_t* xw = reinterpret_cast<uint32_t*>(lds);                                    // [ring][T]
   uint8_t* tr = lds + (size_t)L.ring * T * 4;                                         // trees of the current window
-  float* marg = reinterpret_cast<float*>(tr + (((size_t)L.max_trees * tree_bytes + 15) & ~(size_t)15)) + tid;  // [A][T]
+  float* marg = reinterpret_cast<float*>(tr + (((size_t)L.max_trees * tree_bytes + 15) & ~(size_t)15)) + hap;  // [A][T]
 
   const int wa = L.w_first + blockIdx.y * L.wrun, wb = min(L.w_first + L.n_windows, wa + L.wrun);
-  const Stager st(L.X, L.N, L.ldx, L.C, L.ctx, T);
+  const Stager st(L.X, L.N, L.ldx, L.C, L.ctx, T, H);
   int64_t g0, g1;
   window_words(L, wa, g0, g1);
   st.stage(xw, mask, g0, g1);
-  const int64_t n = (int64_t)blockIdx.x * T + tid;
+  const int64_t n = (int64_t)blockIdx.x * T + hap;
 
   // a window's trees: uint4 pieces of the loader's records, node words rewritten for the window on their way into LDS
-  constexpr int TQ = 8;  // pieces per thread held in registers while the previous window is walked
+  constexpr int TQ = 8 / H;  // pieces per thread held in registers while the previous window is walked
   const int words_per_tree = tree_bytes / 4, node_words = RF ? tree_bytes / 4 : (1 << D);
   auto put_tree_piece = [&](int e, uint4 v, uint32_t gw0) {
     const int wd = (e * 4) % words_per_tree;  // first word of the piece inside its tree (records are multiples of 16 bytes)
@@ -225,12 +234,12 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
   {
     const int t0 = L.win_tree0[wa], np = (L.win_tree0[wa + 1] - t0) * tree_bytes / 16;
     const uint4* src = reinterpret_cast<const uint4*>(L.packed + (size_t)t0 * tree_bytes);
-    for (int e = tid; e < np; e += T) put_tree_piece(e, src[e], (uint32_t)g0);
+    for (int e = tid; e < np; e += NTHR) put_tree_piece(e, src[e], (uint32_t)g0);
   }
 
   for (int w = wa; w < wb; ++w) {
     const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
-    __syncthreads();  // tile + trees of window w complete
+    __syncthreads();  // tile + trees of window w complete; everybody has read the previous window's margins
     // the next window's trees travel through registers while this one is walked (when they fit TQ pieces per thread)
     uint4 tq[TQ];
     int np_next = 0;
@@ -240,16 +249,16 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
       np_next = (L.win_tree0[w + 2] - t1) * tree_bytes / 16;
       tsrc = reinterpret_cast<const uint4*>(L.packed + (size_t)t1 * tree_bytes);
     }
-    const bool tpre = np_next > 0 && np_next <= TQ * T;
+    const bool tpre = np_next > 0 && np_next <= TQ * NTHR;
     if (tpre) {
 #pragma unroll
-      for (int k = 0; k < TQ; ++k) tq[k] = tsrc[min(tid + k * T, np_next - 1)];
+      for (int k = 0; k < TQ; ++k) tq[k] = tsrc[min(tid + k * NTHR, np_next - 1)];
     }
 
-    // the next window's new words: prefetched through registers when they fit NPF batches and none of them touches the
+    // the next window's new words: prefetched through registers when they fit the batches and none of them touches the
     // reflect padding, else staged after the walks
     v4u raw[LB];
-    uint32_t sq[NPF * LB];
+    uint32_t sq[NB * LB];
     int64_t ng0 = 0, ng1 = 0, pf_ga = 0, pf_gb = 0;
     bool pre = false;
     if (w + 1 < wb) {
@@ -259,29 +268,34 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
       pre = (pf_gb - pf_ga) <= 8 * (LB / 2) && 16 * pf_ga >= L.ctx && 16 * pf_gb <= L.ctx + L.C && !(L.flags & 2);
     }
     int stage_q = 0;  // batches issued so far
-    // called between tree groups: keep batch (progress * NPF) in flight
-#define GNX_PF_PUMP(done, total)                                              \
-  if (pre) {                                                                  \
-    const int want_ = min(NPF, ((done) * NPF) / max((total), 1) + 1);         \
-    while (stage_q < want_) { GNX_PF_ADVANCE(stage_q); ++stage_q; }           \
+    // called between tree groups: keep batch (progress * NB) in flight
+#define GNX_PF_PUMP(done, total)                                                                   \
+  if (pre) {                                                                                       \
+    const int want_ = min(NB, ((done) * NB) / max((total), 1) + 1);                                \
+    while (stage_q < want_) { pf_advance<NB>(st, stage_q, pf_ga, pf_gb - 1, raw, sq); ++stage_q; } \
   }
 
-    const Tile tile{reinterpret_cast<const uint8_t*>(xw + tid)};
+    const Tile tile{reinterpret_cast<const uint8_t*>(xw + hap)};
     const size_t o = ((size_t)(n < L.N ? n : 0) * L.W + w) * A;
+    double acc[AMAX];  // random forest only
     if constexpr (!RF) {
-      // ---- walks: class-major packing per window, trees of class c contiguous and in model order ----------------
+      // ---- walks: class-major packing per window, trees of class c contiguous and in model order; wave group h walks the
+      // classes [c_lo, c_hi) of its haplotypes ----------------
       const int32_t* cls0 = L.win_class_tree0 + (size_t)w * (A + 1);  // [A+1] offsets relative to t0
       const int n_groups = (A == 2) ? 1 : A;
-      for (int c = 0; c < n_groups; ++c) {
+      const int c_mid = (H == 1) ? n_groups : (n_groups + 1) / 2;
+      const int c_lo = half == 0 ? 0 : c_mid, c_hi = half == 0 ? c_mid : n_groups;
+      const int tr_lo = (A == 2) ? 0 : cls0[c_lo], tr_hi = (A == 2) ? (half == 0 ? nt : 0) : cls0[c_hi];
+      for (int c = c_lo; c < c_hi; ++c) {
         const int a0 = (A == 2) ? 0 : cls0[c], a1 = (A == 2) ? nt : cls0[c + 1];
         float psum = 0.f;
         int t = a0;
-        for (; t + TP <= a1 && !(L.flags & 1); t += TP) {
-          GNX_PF_PUMP(t, nt)
-          float leaf[TP];
-          walk<D, TP>(tr + (size_t)t * tree_bytes, tree_bytes, tile, leaf);
+        for (; t + TPW <= a1 && !(L.flags & 1); t += TPW) {
+          GNX_PF_PUMP(t - tr_lo, tr_hi - tr_lo)
+          float leaf[TPW];
+          walk<D, TPW>(tr + (size_t)t * tree_bytes, tree_bytes, tile, leaf);
 #pragma unroll
-          for (int k = 0; k < TP; ++k) psum += leaf[k];  // tree order
+          for (int k = 0; k < TPW; ++k) psum += leaf[k];  // tree order
         }
         for (; t < a1 && !(L.flags & 1); ++t) {
           float leaf[1];
@@ -290,34 +304,7 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
         }
         marg[c * T] = psum;
       }
-      if (n < L.N) {
-        if (A == 2) {
-          const float margin = logf(L.base_score / (1.0f - L.base_score)) + marg[0];  // ProbToMargin of binary:logistic
-          const float p1 = 1.0f / (1.0f + (float)exp((double)(-margin)));
-          const float p[2] = {1.0f - p1, p1};
-          for (int a = 0; a < 2; ++a) {
-            if (L.b32) L.b32[o + a] = p[a];
-            if (L.b64) L.b64[o + a] = (double)p[a];
-          }
-        } else {
-          float wmax = L.base_score + marg[0];
-          for (int a = 1; a < A; ++a) wmax = fmaxf(L.base_score + marg[a * T], wmax);
-          double wsum = 0.0;
-          for (int a = 0; a < A; ++a) {
-            const float e = (float)exp((double)((L.base_score + marg[a * T]) - wmax));
-            marg[a * T] = e;
-            wsum += (double)e;
-          }
-          const float fs = (float)wsum;
-          for (int a = 0; a < A; ++a) {
-            const float p = marg[a * T] / fs;
-            if (L.b32) L.b32[o + a] = p;
-            if (L.b64) L.b64[o + a] = (double)p;
-          }
-        }
-      }
     } else {
-      double acc[AMAX];
 #pragma unroll
       for (int a = 0; a < AMAX; ++a) acc[a] = 0.0;
       const size_t leaves = (size_t)1 << Dr;
@@ -334,7 +321,44 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
         for (int a = 0; a < AMAX; ++a)
           if (a < A) acc[a] += v[a];  // estimator order
       }
-      if (n < L.N) {
+    }
+    // batches the walks did not reach
+    if (pre)
+      while (stage_q <= NB) { pf_advance<NB>(st, stage_q, pf_ga, pf_gb - 1, raw, sq); ++stage_q; }
+    __syncthreads();  // every lane is done with window w's tile and trees; the margins of all classes are in LDS
+
+    // ---- the window's probabilities (wave group 0) ----
+    if (half == 0 && n < L.N) {
+      if constexpr (!RF) {
+        if (A == 2) {
+          const float margin = logf(L.base_score / (1.0f - L.base_score)) + marg[0];  // ProbToMargin of binary:logistic
+          const float p1 = 1.0f / (1.0f + (float)exp((double)(-margin)));
+          const float p[2] = {1.0f - p1, p1};
+          for (int a = 0; a < 2; ++a) {
+            if (L.b32) L.b32[o + a] = p[a];
+            if (L.b64) L.b64[o + a] = (double)p[a];
+          }
+        } else {
+          float wmax = L.base_score + marg[0];
+          for (int a = 1; a < A; ++a) wmax = fmaxf(L.base_score + marg[a * T], wmax);
+          double wsum = 0.0;
+          float ex[AMAX];
+#pragma unroll
+          for (int a = 0; a < AMAX; ++a)
+            if (a < A) {
+              ex[a] = (float)exp((double)((L.base_score + marg[a * T]) - wmax));
+              wsum += (double)ex[a];
+            }
+          const float fs = (float)wsum;
+#pragma unroll
+          for (int a = 0; a < AMAX; ++a)
+            if (a < A) {
+              const float p = ex[a] / fs;
+              if (L.b32) L.b32[o + a] = p;
+              if (L.b64) L.b64[o + a] = (double)p;
+            }
+        }
+      } else {
         const double cnt = (double)nt;
 #pragma unroll
         for (int a = 0; a < AMAX; ++a)
@@ -346,27 +370,25 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
       }
     }
     if (w + 1 >= wb) break;
-    // drain the prefetch (batches the walks did not reach), then replace the words the next window no longer shares
-    if (pre)
-      while (stage_q <= NPF) { GNX_PF_ADVANCE(stage_q); ++stage_q; }
-    __syncthreads();  // every lane is done with window w's tile and trees
+    // replace the words the next window no longer shares, and the trees
     if (pre) {
 #pragma unroll
-      for (int q = 0; q < NPF; ++q)
+      for (int q = 0; q < NB; ++q)
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
           for (int u = 0; u < LB / 2; ++u) {
             const int64_t g = pf_ga + 8 * u + st.wsub;
-            if (g < pf_gb) xw[(size_t)((uint32_t)g & mask) * T + st.wv * 64 + (2 * q + h2) * 8 + st.hsub] = sq[q * LB + h2 * (LB / 2) + u];
+            if (g < pf_gb)
+              xw[(size_t)((uint32_t)g & mask) * T + st.wv * 64 + (st.hb0 + 2 * q + h2) * 8 + st.hsub] = sq[q * LB + h2 * (LB / 2) + u];
           }
     } else if (!(L.flags & 4)) st.stage(xw, mask, ng0 > g1 ? ng0 : g1, ng1);
     if (tpre) {
 #pragma unroll
       for (int k = 0; k < TQ; ++k)
-        if (tid + k * T < np_next) put_tree_piece(tid + k * T, tq[k], (uint32_t)ng0);
+        if (tid + k * NTHR < np_next) put_tree_piece(tid + k * NTHR, tq[k], (uint32_t)ng0);
     } else {
-      for (int e = tid; e < np_next; e += T) put_tree_piece(e, tsrc[e], (uint32_t)ng0);
+      for (int e = tid; e < np_next; e += NTHR) put_tree_piece(e, tsrc[e], (uint32_t)ng0);
     }
     g0 = ng0;
     g1 = ng1;
@@ -374,12 +396,18 @@ __global__ __launch_bounds__(256) void k_base_forest(ForestLaunch L) {
 #undef GNX_PF_PUMP
 }
 
-template <int D, bool RF, int AMAX>
-hipError_t launch_k(const ForestLaunch& L, int threads, size_t lds, hipStream_t s) {
-  GNX_LDS_OPTIN((size_t)160 * 1024, k_base_forest<D, RF, AMAX>);
+template <int D, bool RF, int AMAX, int H>
+hipError_t launch_k(const ForestLaunch& L, int haps, size_t lds, hipStream_t s) {
+  GNX_LDS_OPTIN((size_t)160 * 1024, k_base_forest<D, RF, AMAX, H>);
   const int n_runs = (L.n_windows + L.wrun - 1) / L.wrun;
-  hipLaunchKernelGGL((k_base_forest<D, RF, AMAX>), dim3((unsigned)((L.N + threads - 1) / threads), (unsigned)n_runs), dim3(threads), lds, s, L);
+  hipLaunchKernelGGL((k_base_forest<D, RF, AMAX, H>), dim3((unsigned)((L.N + haps - 1) / haps), (unsigned)n_runs), dim3(haps * H), lds, s, L);
   return hipGetLastError();
+}
+
+template <int D>
+hipError_t launch_xgb(const ForestLaunch& L, int haps, size_t lds, bool two, hipStream_t s) {
+  if (L.A <= 8) return two ? launch_k<D, false, 8, 2>(L, haps, lds, s) : launch_k<D, false, 8, 1>(L, haps, lds, s);
+  return two ? launch_k<D, false, 32, 2>(L, haps, lds, s) : launch_k<D, false, 32, 1>(L, haps, lds, s);
 }
 
 // windows [w_first, w_first + n_windows), all of padded width `width` (the last window of the chromosome goes alone)
@@ -417,19 +445,21 @@ hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int64_t widt
   wrun = std::max<int64_t>(1, wrun);
   L.wrun = (int)std::min<int64_t>(wrun, n_windows);
   if (L.rf_leafval) {
-    if (L.A <= 8) return launch_k<1, true, 8>(L, threads, lds, s);
-    if (L.A <= 16) return launch_k<1, true, 16>(L, threads, lds, s);
-    return launch_k<1, true, 32>(L, threads, lds, s);
+    if (L.A <= 8) return launch_k<1, true, 8, 1>(L, threads, lds, s);
+    if (L.A <= 16) return launch_k<1, true, 16, 1>(L, threads, lds, s);
+    return launch_k<1, true, 32, 1>(L, threads, lds, s);
   }
+  // two wave groups per tile when there is more than one class group to split and the block stays within 1024 threads
+  const bool two = tune.forest_halves != 1 && L.A > 2 && threads * 2 <= 1024;
   switch (L.D) {
-    case 1: return launch_k<1, false, 1>(L, threads, lds, s);
-    case 2: return launch_k<2, false, 1>(L, threads, lds, s);
-    case 3: return launch_k<3, false, 1>(L, threads, lds, s);
-    case 4: return launch_k<4, false, 1>(L, threads, lds, s);
-    case 5: return launch_k<5, false, 1>(L, threads, lds, s);
-    case 6: return launch_k<6, false, 1>(L, threads, lds, s);
-    case 7: return launch_k<7, false, 1>(L, threads, lds, s);
-    case 8: return launch_k<8, false, 1>(L, threads, lds, s);
+    case 1: return launch_xgb<1>(L, threads, lds, two, s);
+    case 2: return launch_xgb<2>(L, threads, lds, two, s);
+    case 3: return launch_xgb<3>(L, threads, lds, two, s);
+    case 4: return launch_xgb<4>(L, threads, lds, two, s);
+    case 5: return launch_xgb<5>(L, threads, lds, two, s);
+    case 6: return launch_xgb<6>(L, threads, lds, two, s);
+    case 7: return launch_xgb<7>(L, threads, lds, two, s);
+    case 8: return launch_xgb<8>(L, threads, lds, two, s);
     default: return hipErrorInvalidValue;
   }
 }
