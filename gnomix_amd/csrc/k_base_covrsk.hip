@@ -283,7 +283,10 @@ __device__ __forceinline__ bool any_bit(const BitVec<NWT>& a) {
   return o != 0;
 }
 
-template <int NWT>
+// AT > 0: the class count is a compile-time constant — the class loop is unrolled, so the P pairwise decision sums live in
+// REGISTERS with static indices (per support vector the LDS version does 2(A-1) dependent read-modify-writes of [pair][lane]
+// doubles: ~2 LDS latencies on every iteration's critical path; VALU busy 57 % on config 3).  AT = 0: any A, sums in LDS.
+template <int NWT, int AT>
 __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int lane = threadIdx.x;
@@ -319,49 +322,74 @@ __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
   BitVec<NWT> valid;  // bit t set iff t < width
 #pragma unroll
   for (int i = 0; i < NWT; ++i) valid.w[i] = (i < NW - 1) ? 0xffffffffu : (i == NW - 1 ? ((width & 31) ? ((1u << (width & 31)) - 1u) : 0xffffffffu) : 0u);
-  for (int p = 0; p < P; ++p) dec[p * 64 + lane] = 0.0;
+  constexpr int PT = AT > 0 ? AT * (AT - 1) / 2 : 1;
+  double decr[PT];
+#pragma unroll
+  for (int p = 0; p < PT; ++p) decr[p] = 0.0;
+  if (AT == 0)
+    for (int p = 0; p < P; ++p) dec[p * 64 + lane] = 0.0;
 
   const double* dual = L.coef + win.coef_off;
-  for (int c = 0; c < A; ++c) {
-    for (int sv = win.cls_start[c]; sv < win.cls_start[c + 1]; ++sv) {
-      const uint32_t* yb = L.svbits + win.sv_off + (size_t)sv * 2 * NW;  // wave-uniform
-      BitVec<NWT> e;
+  // kernel value of the lane's query against support vector `sv` (wave-uniform): substring counts by AND-shift doubling
+  auto kernel_value = [&](int sv) -> uint32_t {
+    const uint32_t* yb = L.svbits + win.sv_off + (size_t)sv * 2 * NW;  // wave-uniform
+    BitVec<NWT> e;
 #pragma unroll
-      for (int i = 0; i < NWT; ++i) {
-        const uint32_t yl = (i < NW) ? yb[i] : 0u, yh = (i < NW) ? yb[NW + i] : 0u;
-        e.w[i] = ~((xl.w[i] ^ yl) | (xh.w[i] ^ yh)) & valid.w[i];
-      }
-      uint32_t K = pop(e);                                              // m = 1
-      const BitVec<NWT> r2 = band(e, shr<NWT, 1>(e));
-      const BitVec<NWT> r4 = band(r2, shr<NWT, 2>(r2));
-      if (n_ms > 1) K += pop(r4);                                       // m = 4
-      const BitVec<NWT> r8 = band(r4, shr<NWT, 4>(r4));
-      if (n_ms > 2) K += pop(r8);                                       // m = 8
-      if (n_ms > 3) {
-        const BitVec<NWT> r16 = band(r8, shr<NWT, 8>(r8));
-        const BitVec<NWT> r32 = band(r16, shr<NWT, 16>(r16));
-        if (__any(any_bit(r32))) {                                      // wave-uniform: some query has a run >= 32
-          K += pop(band(r32, shr<NWT, 31>(r8)));                        // m = 39 = [t,t+32) & [t+31,t+39)
-          if (n_ms > 4) K += pop(band(r32, shr<NWT, 26>(r16)));         // m = 42 = [t,t+32) & [t+26,t+42)
-          if (n_ms > 5) {
-            const BitVec<NWT> r64 = band(r32, shr<NWT, 32>(r32));
-            if (__any(any_bit(r64))) {
-              K += pop(band(r64, shr<NWT, 53>(r64)));                   // m = 117 = [t,t+64) & [t+53,t+117)
-              if (n_ms > 6) {
-                const BitVec<NWT> r128 = band(r64, shr<NWT, 64>(r64));
-                const BitVec<NWT> r256 = band(r128, shr<NWT, 128>(r128));
-                K += pop(band(r256, shr<NWT, 248>(r128)));              // m = 376 = [t,t+256) & [t+248,t+376)
-              }
+    for (int i = 0; i < NWT; ++i) {
+      const uint32_t yl = (i < NW) ? yb[i] : 0u, yh = (i < NW) ? yb[NW + i] : 0u;
+      e.w[i] = ~((xl.w[i] ^ yl) | (xh.w[i] ^ yh)) & valid.w[i];
+    }
+    uint32_t K = pop(e);                                              // m = 1
+    const BitVec<NWT> r2 = band(e, shr<NWT, 1>(e));
+    const BitVec<NWT> r4 = band(r2, shr<NWT, 2>(r2));
+    if (n_ms > 1) K += pop(r4);                                       // m = 4
+    const BitVec<NWT> r8 = band(r4, shr<NWT, 4>(r4));
+    if (n_ms > 2) K += pop(r8);                                       // m = 8
+    if (n_ms > 3) {
+      const BitVec<NWT> r16 = band(r8, shr<NWT, 8>(r8));
+      const BitVec<NWT> r32 = band(r16, shr<NWT, 16>(r16));
+      if (__any(any_bit(r32))) {                                      // wave-uniform: some query has a run >= 32
+        K += pop(band(r32, shr<NWT, 31>(r8)));                        // m = 39 = [t,t+32) & [t+31,t+39)
+        if (n_ms > 4) K += pop(band(r32, shr<NWT, 26>(r16)));         // m = 42 = [t,t+32) & [t+26,t+42)
+        if (n_ms > 5) {
+          const BitVec<NWT> r64 = band(r32, shr<NWT, 32>(r32));
+          if (__any(any_bit(r64))) {
+            K += pop(band(r64, shr<NWT, 53>(r64)));                   // m = 117 = [t,t+64) & [t+53,t+117)
+            if (n_ms > 6) {
+              const BitVec<NWT> r128 = band(r64, shr<NWT, 64>(r64));
+              const BitVec<NWT> r256 = band(r128, shr<NWT, 128>(r128));
+              K += pop(band(r256, shr<NWT, 248>(r128)));              // m = 376 = [t,t+256) & [t+248,t+376)
             }
           }
         }
       }
-      const double Kd = (double)K;
-      for (int o = 0; o < A; ++o) {
-        if (o == c) continue;
-        const int row = (o > c) ? o - 1 : o;
-        const int p = (o > c) ? pair_index(c, o, A) : pair_index(o, c, A);
-        dec[p * 64 + lane] += dual[(size_t)row * n_sv + sv] * Kd;
+    }
+    return K;
+  };
+  if constexpr (AT > 0) {
+#pragma unroll
+    for (int c = 0; c < AT; ++c) {
+      for (int sv = win.cls_start[c]; sv < win.cls_start[c + 1]; ++sv) {
+        const double Kd = (double)kernel_value(sv);
+#pragma unroll
+        for (int o = 0; o < AT; ++o) {
+          if (o == c) continue;
+          const int row = (o > c) ? o - 1 : o;
+          const int p = (o > c) ? (c * (2 * AT - c - 1) / 2 + (o - c - 1)) : (o * (2 * AT - o - 1) / 2 + (c - o - 1));
+          decr[p] += dual[(size_t)row * n_sv + sv] * Kd;   // libsvm's order: class-major, SV order inside a class
+        }
+      }
+    }
+  } else {
+    for (int c = 0; c < A; ++c) {
+      for (int sv = win.cls_start[c]; sv < win.cls_start[c + 1]; ++sv) {
+        const double Kd = (double)kernel_value(sv);
+        for (int o = 0; o < A; ++o) {
+          if (o == c) continue;
+          const int row = (o > c) ? o - 1 : o;
+          const int p = (o > c) ? pair_index(c, o, A) : pair_index(o, c, A);
+          dec[p * 64 + lane] += dual[(size_t)row * n_sv + sv] * Kd;
+        }
       }
     }
   }
@@ -371,10 +399,18 @@ __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
   const double min_prob = 1e-7;
   if (n < n_end) {
     double* out = L.rpair + (((size_t)(n - L.n_first)) * L.W + w) * P;
-    for (int p = 0; p < P; ++p) {
-      const double d = dec[p * 64 + lane] + icpt[p];
-      double v = sigmoid_predict(d, pA[p], pB[p]);
-      out[p] = fmin(fmax(v, min_prob), 1 - min_prob);
+    if constexpr (AT > 0) {
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const double v = sigmoid_predict(decr[p] + icpt[p], pA[p], pB[p]);
+        out[p] = fmin(fmax(v, min_prob), 1 - min_prob);
+      }
+    } else {
+      for (int p = 0; p < P; ++p) {
+        const double d = dec[p * 64 + lane] + icpt[p];
+        double v = sigmoid_predict(d, pA[p], pB[p]);
+        out[p] = fmin(fmax(v, min_prob), 1 - min_prob);
+      }
     }
   }
 }
@@ -483,7 +519,11 @@ hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
       const dim3 grid((unsigned)((L.n_count + 63) / 64), (unsigned)(w1 - w0));
       const size_t lds_fast = (size_t)P * 64 * 8;
       switch (key) {
-#define GNX_FAST_CASE(NWT_) case NWT_: hipLaunchKernelGGL(k_covrsk_dec_fast<NWT_>, grid, dim3(64), lds_fast, s, L); break;
+#define GNX_FAST_CASE(NWT_)                                                                                         \
+  case NWT_:                                                                                                        \
+    if (A == 7) hipLaunchKernelGGL((k_covrsk_dec_fast<NWT_, 7>), grid, dim3(64), lds_fast, s, L);                    \
+    else hipLaunchKernelGGL((k_covrsk_dec_fast<NWT_, 0>), grid, dim3(64), lds_fast, s, L);                          \
+    break;
         GNX_FAST_CASE(1) GNX_FAST_CASE(2) GNX_FAST_CASE(3) GNX_FAST_CASE(4) GNX_FAST_CASE(5) GNX_FAST_CASE(6) GNX_FAST_CASE(7)
         GNX_FAST_CASE(8) GNX_FAST_CASE(9) GNX_FAST_CASE(10) GNX_FAST_CASE(11) GNX_FAST_CASE(12) GNX_FAST_CASE(13)
         GNX_FAST_CASE(14) GNX_FAST_CASE(15) GNX_FAST_CASE(16)
