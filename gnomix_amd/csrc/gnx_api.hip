@@ -1321,9 +1321,16 @@ int gnx_pack_x(const int8_t* X, int64_t N, int64_t ldx, int64_t C, uint8_t* P, i
   };
   if (nt == 1) work(0);
   else {
+    // no exception crosses the ABI: a thread that cannot be started (resource limits) is run inline instead
     std::vector<std::thread> th;
     th.reserve((size_t)nt);
-    for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (int t = 0; t < nt; ++t) {
+      try {
+        th.emplace_back(work, t);
+      } catch (...) {
+        work(t);
+      }
+    }
     for (auto& t : th) t.join();
   }
   for (int b : bad)

@@ -18,10 +18,11 @@
 
 namespace {
 
-template <int AT>
+// EXACT: A == AT, so a row is a compile-time number of doubles and the loads / stores vectorise (2 doubles per access)
+template <int AT, bool EXACT>
 __global__ __launch_bounds__(256) void k_crf_psi(SmoothCRFLaunch L) {
   __shared__ double th[AT * AT];  // theta[a][y]
-  const int A = L.A;
+  const int A = EXACT ? AT : L.A;
   for (int i = threadIdx.x; i < AT * AT; i += blockDim.x) {
     const int a = i / AT, y = i - a * AT;
     th[i] = (a < A && y < A) ? L.state[a * A + y] : 0.0;
@@ -30,22 +31,28 @@ __global__ __launch_bounds__(256) void k_crf_psi(SmoothCRFLaunch L) {
   const int64_t total = L.N * L.W;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
-  double b[AT];
+  double b[AT], o[AT];
+  if (L.b_is_f64) {
+    const double* src = reinterpret_cast<const double*>(L.B) + e * A;
 #pragma unroll
-  for (int a = 0; a < AT; ++a) {
-    if (a < A) b[a] = L.b_is_f64 ? reinterpret_cast<const double*>(L.B)[e * A + a] : (double)reinterpret_cast<const float*>(L.B)[e * A + a];
-    else b[a] = 0.0;
+    for (int a = 0; a < AT; ++a) b[a] = (a < A) ? src[a] : 0.0;
+  } else {
+    const float* src = reinterpret_cast<const float*>(L.B) + e * A;
+#pragma unroll
+    for (int a = 0; a < AT; ++a) b[a] = (a < A) ? (double)src[a] : 0.0;
   }
 #pragma unroll
   for (int y = 0; y < AT; ++y) {
-    if (y < A) {
-      double s = 0.0;
+    double s = 0.0;
 #pragma unroll
-      for (int a = 0; a < AT; ++a)
-        if (a < A) s += th[a * AT + y] * b[a];
-      L.psi[e * A + y] = exp(s);
-    }
+    for (int a = 0; a < AT; ++a)
+      if (a < A) s += th[a * AT + y] * b[a];
+    o[y] = exp(s);
   }
+  double* dst = L.psi + e * A;
+#pragma unroll
+  for (int y = 0; y < AT; ++y)
+    if (y < A) dst[y] = o[y];
 }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(64) void k_crf_scan(SmoothCRFLaunch L) {
 template <int AT>
 hipError_t launch(const SmoothCRFLaunch& L, hipStream_t s) {
   const int64_t total = L.N * L.W;
-  hipLaunchKernelGGL(k_crf_psi<AT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L);
+  hipLaunchKernelGGL((k_crf_psi<AT, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L);
   constexpr size_t lds = ((2 * AT * AT * 8 + 15) & ~15) + (size_t)2 * 3 * (4 * AT / 2) * 1024;
   GNX_LDS_OPTIN(lds, k_crf_scan<AT>);
   hipLaunchKernelGGL(k_crf_scan<AT>, dim3((unsigned)((L.N + 63) / 64)), dim3(64), lds, s, L);
@@ -355,7 +362,8 @@ __global__ __launch_bounds__(256) void k_smooth_crf_lanes(SmoothCRFLaunch L) {
 template <int AT>
 hipError_t launch_lanes_pre(const SmoothCRFLaunch& L, hipStream_t s) {
   const int64_t total = L.N * L.W;
-  hipLaunchKernelGGL(k_crf_psi<AT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L);
+  if (L.A == AT) hipLaunchKernelGGL((k_crf_psi<AT, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L);
+  else hipLaunchKernelGGL((k_crf_psi<AT, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L);
   const int G = 64 / L.A, waves = 4;
   const int64_t per_block = (int64_t)G * waves;
   hipLaunchKernelGGL(k_smooth_crf_lanes<true>, dim3((unsigned)((L.N + per_block - 1) / per_block)), dim3(64 * waves),
