@@ -1013,7 +1013,7 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
   L.b32 = d_b32; L.b64 = d_b64;
   ProfScope ps(ctx, GNX_K_BASE_LOGISTIC);
   if (m->lr_i8) {
-    const bool dl = ctx->tune.lr_dl < 0 ? m->lr.NT == 2 : ctx->tune.lr_dl != 0;
+    const bool dl = ctx->tune.lr_dl < 0 ? m->lr.NT >= 2 : ctx->tune.lr_dl != 0;
     hipError_t e = dl ? gnx_launch_base_logistic_i8_dl(L, ctx->n_cu, ctx->tune, ctx->stream) : hipErrorNotSupported;
     if (e == hipErrorNotSupported) e = gnx_launch_base_logistic_i8(L, ctx->n_cu, ctx->tune, ctx->stream);  // > 2 column tiles
     HIPCHK(ctx, e);

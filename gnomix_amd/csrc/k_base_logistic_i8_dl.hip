@@ -252,7 +252,9 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
   // window ranges: a multiple of 8 (one XCD each), ~4 blocks per CU in total; more (shorter) ranges if the per-block tables
   // would not fit the LDS next to the ring
-  const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : 4;
+  // blocks per CU in total: 4 with one column tile; 2 with more (every range re-reads the digit planes of its first R windows
+  // and the planes are the larger share of the traffic there: A = 12, chr22, 16 k haplotypes: 2 -> 2.25 ms, 4 -> 2.39, 8 -> 2.40)
+  const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : (NT >= 2 ? 2 : 4);
   int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
   want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
   if (tune.lr_want > 0) want = tune.lr_want;
@@ -303,9 +305,19 @@ hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const
       return hipErrorNotSupported;
     case 2:
       if (small) { GNX_DL_TRY(1, 2, 4, 2) return hipErrorNotSupported; }
+      // 16 waves x 16 rows: 56 accumulator registers per wave, 4 waves per SIMD hide the operand reads (2.39 vs 2.56 ms for
+      // 8 waves x 32 rows at A = 12)
+      if (tune.lr_waves != 8 && tune.lr_mt != 2) GNX_DL_TRY(1, 2, 16, 2)
       if (tune.lr_mt != 1) GNX_DL_TRY(2, 2, 8, 2)
       if (nbuf != 2) GNX_DL_TRY(1, 2, 8, 3)
       GNX_DL_TRY(1, 2, 8, 2)
+      return hipErrorNotSupported;
+    case 3:  // 33 .. 48 class columns per SNP (e.g. A = 24 at the default context)
+      GNX_DL_TRY(1, 3, 8, 2)
+      GNX_DL_TRY(1, 3, 4, 2)
+      return hipErrorNotSupported;
+    case 4:  // 49 .. 64 class columns (A = 32): 112 accumulator registers per wave, no spill without the staging registers
+      GNX_DL_TRY(1, 4, 4, 2)
       return hipErrorNotSupported;
     default: return hipErrorNotSupported;
   }
