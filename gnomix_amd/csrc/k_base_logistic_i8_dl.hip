@@ -299,6 +299,7 @@ hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const
     case 1:
       if (small) { GNX_DL_TRY(1, 1, 4, 3) GNX_DL_TRY(1, 1, 4, 2) return hipErrorNotSupported; }
       if (tune.lr_waves == 16) { if (nbuf != 2) GNX_DL_TRY(1, 1, 16, 3) GNX_DL_TRY(1, 1, 16, 2) }
+      if (tune.lr_waves == 12) { GNX_DL_TRY(2, 1, 12, 2) }   // 384 rows per block: 2/3 of the plane bytes per X byte, ring depth 2
       if (nbuf != 2) GNX_DL_TRY(2, 1, 8, 3)
       GNX_DL_TRY(2, 1, 8, 2)
       GNX_DL_TRY(1, 1, 8, 3)

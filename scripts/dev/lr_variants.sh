@@ -1,6 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-.}"
-for v in "X=1" "GNX_LR_BPC=1" "GNX_LR_TUNE=2,8"; do
-  env $v TAG="$v" python scripts/dev/bench_a12.py 2>&1 | grep "A=12"
+for v in "GNX_LR_DL=0" "GNX_LR_DL=1" "GNX_LR_DL=1 GNX_LR_TUNE=2,12" "GNX_LR_DL=1 GNX_LR_TUNE=2,12 GNX_LR_BPC=3" "GNX_LR_DL=1 GNX_LR_TUNE=2,12 GNX_LR_BPC=6"; do
+  env $v TAG="$v" WHICH=base python scripts/dev/bench_kernels.py 2>&1 | grep base_logistic
 done
-A=20 TAG="A20" python scripts/dev/bench_anyA.py | tail -1
-A=20 GNX_LR_BPC=4 TAG="A20 bpc4" python scripts/dev/bench_anyA.py | tail -1
