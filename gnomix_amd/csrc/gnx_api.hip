@@ -771,7 +771,7 @@ static void read_tune(gnx_tune& t) {
   t.forest_flags = geti("GNX_FOREST_FLAGS", 0);
   if (const char* e = std::getenv("GNX_HOST_BATCH")) t.host_batch = std::atoll(e);
   t.h2d_overlap = geti("GNX_H2D_OVERLAP", 1);
-  t.debug = std::getenv("GNX_DEBUG") != nullptr;
+  t.debug = std::getenv("GNX_DEBUG") ? atoi(std::getenv("GNX_DEBUG")) : 0;
 }
 
 extern "C" {
@@ -1420,8 +1420,8 @@ static int gnofix_check(gnx_model* m, int64_t ldx, int64_t n_ind, int32_t max_it
   if (m->calibrate_on && m->calib_off)  // smoother.predict inside the loop would be calibrated (gnofix.py:80,190); the kernel's is not
     return fail(ctx, GNX_EUNSUPPORTED, "gnofix with calibrate=True is not built: switch calibration off for re-phasing");
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
-  *in_lds = gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, true) <= 150 * 1024;
-  if (gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, *in_lds) > 160 * 1024)
+  *in_lds = gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, m->xgb.tree_bytes, true) <= 150 * 1024;
+  if (gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, m->xgb.tree_bytes, *in_lds) > 160 * 1024)
     return fail(ctx, GNX_EUNSUPPORTED, "gnofix: model too large for the LDS working set (n_trees * 16 B + S*A*8 B)");
   return GNX_OK;
 }

@@ -40,7 +40,7 @@ struct gnx_tune {
   int forest_flags = 0;                 // GNX_FOREST_FLAGS: ablation (1 = no walks, 2 = no register prefetch, 4 = no incremental staging)
   int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
   int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points
-  bool debug = false;                   // GNX_DEBUG
+  int debug = 0;                        // GNX_DEBUG
 };
 
 // opt a kernel into its dynamic LDS size; a refusal is reported by the launcher instead of surfacing later as an
@@ -340,7 +340,7 @@ hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t
 hipError_t gnx_launch_covrsk(const CovRSKLaunch& L, hipStream_t s);
 size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width);
 hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
-size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds);
+size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, int tree_bytes, bool bp_in_lds);
 hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
 hipError_t gnx_train_lr_run(const int8_t* dX, int64_t N, int64_t ldx, const int32_t* dY, int64_t C, int64_t M, int64_t ctx, int A,
                             double Creg, double tol, int max_newton, int max_cg, double* h_coef, int64_t ldc, double* h_icpt,

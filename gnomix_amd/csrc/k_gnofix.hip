@@ -17,11 +17,24 @@
 //  * convergence (gnofix.py:108-113 compares whole X_m vectors) is tracked as a per-window signature
 //    parity & (block of SNPs differs between the two haplotypes), which is equal iff the X_m vectors are;
 //  * SNPs are swapped once at the end from the final parity (correct_phase_error applied cumulatively).
+// Round 2: nothing on the individual's critical path is left to one thread or to a window-by-window scan:
+//  * the next window whose labels change is found by ballot, THREADS windows at a time (the reference's `for w in range(1, W)`
+//    only ever acts on those);
+//  * a candidate's 4 x n_trees walks go NWALK_C per thread side by side (chains of dependent L2-latency loads: the 1200 trees,
+//    230 KB, stay in global memory), its softmax one (row, class) per lane;
+//  * after an accepted switch all threads classify the rows (swap / re-evaluate list by LDS atomic); the re-evaluation goes class
+//    by class with the class's trees staged in LDS, P lanes per row splitting them and handing the running float32 sum down the
+//    lanes in tree order (bit-identical to the sequential predictor);
+//  * the per-window "SNP blocks differ" flags stop at the first difference, the final SNP swap touches only windows of odd parity,
+//    a wave per window with the widest granule the row pitch allows;
+//  * the convergence history is compared one past sweep per thread.
+// -DGNX_GNOFIX_CLOCKS turns n_switches into per-phase clock counts (scripts/dev/gnofix_phases.py).
 #include "gnx_internal.h"
 
 namespace {
 
-constexpr int THREADS = 256;
+constexpr int THREADS = 512;   // one workgroup per CU (the strips fill its LDS); 8 waves with up to 256 VGPRs each
+constexpr int NWAVES = THREADS / 64;
 
 __device__ __forceinline__ int slide_src(int j, int W, int pad) {
   if (j < pad) return pad - 1 - j;
@@ -29,15 +42,88 @@ __device__ __forceinline__ int slide_src(int j, int W, int pad) {
   return W - 1 - (j - pad - W);
 }
 
-__device__ __forceinline__ void softmax_row(float* m, int A) {  // xgboost Softmax, in place
-  float wmax = m[0];
-  for (int a = 1; a < A; ++a) wmax = fmaxf(m[a], wmax);
-  double wsum = 0.0;
-  for (int a = 0; a < A; ++a) { m[a] = (float)exp((double)(m[a] - wmax)); wsum += (double)m[a]; }
-  const float fs = (float)wsum;
-  for (int a = 0; a < A; ++a) m[a] = m[a] / fs;
+// NW independent walks side by side (generic pointers: trees in global memory, rows in LDS or global); same arithmetic as gnx_walk
+template <int NW>
+__device__ __forceinline__ void walk_n(const uint8_t* const (&tb)[NW], const uint8_t* const (&row)[NW], int D, float (&out)[NW]) {
+  const uint32_t half = 1u << (D - 1);
+  uint32_t j[NW];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) j[k] = 1;
+  for (int d = 0; d < D - 1; ++d) {
+    uint2 nd[NW];
+    float fv[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) __builtin_memcpy(&nd[k], tb[k] + half * 16 + (j[k] - 1) * 8, 8);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) __builtin_memcpy(&fv[k], row[k] + nd[k].x, 4);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) j[k] = 2 * j[k] + ((fv[k] < __uint_as_float(nd[k].y)) ? 0u : 1u);
+  }
+  uint4 n4[NW];
+  float fv[NW];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) __builtin_memcpy(&n4[k], tb[k] + (j[k] - half) * 16, 16);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) __builtin_memcpy(&fv[k], row[k] + n4[k].x, 4);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) out[k] = (fv[k] < __uint_as_float(n4[k].y)) ? __uint_as_float(n4[k].z) : __uint_as_float(n4[k].w);
 }
 
+// ---- SNP ranges of the two haplotype rows, one wave per window.  The rows are ldx bytes apart, so a granule of G bytes (the largest
+// power of two <= 16 dividing ldx) is aligned in both once it is aligned in one; heads and tails go byte-wise. ----
+template <int G> struct granule;
+template <> struct granule<16> { using type = uint4; };
+template <> struct granule<8> { using type = uint2; };
+template <> struct granule<4> { using type = uint32_t; };
+template <> struct granule<1> { using type = uint8_t; };
+__device__ __forceinline__ bool neq(uint4 x, uint4 y) { return ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) != 0; }
+__device__ __forceinline__ bool neq(uint2 x, uint2 y) { return ((x.x ^ y.x) | (x.y ^ y.y)) != 0; }
+__device__ __forceinline__ bool neq(uint32_t x, uint32_t y) { return x != y; }
+__device__ __forceinline__ bool neq(uint8_t x, uint8_t y) { return x != y; }
+
+template <int G, bool SWAP>
+__device__ __forceinline__ bool snp_range(int8_t* a, int8_t* b, int64_t j0, int64_t j1, int ln) {
+  using V = typename granule<G>::type;
+  int64_t h = j0 + (int64_t)((0 - reinterpret_cast<uintptr_t>(a + j0)) & (uintptr_t)(G - 1));
+  if (h > j1) h = j1;
+  const int64_t nv = (j1 - h) / G, t0 = h + nv * G;
+  bool d = false;
+  auto bytes = [&](int64_t from, int64_t to) {
+    for (int64_t j = from + ln; j < to; j += 64) {
+      const int8_t x = a[j], y = b[j];
+      if (SWAP) { a[j] = y; b[j] = x; } else d |= x != y;
+    }
+  };
+  bytes(j0, h);
+  V* av = reinterpret_cast<V*>(a + h);
+  V* bv = reinterpret_cast<V*>(b + h);
+  for (int64_t k = ln; k < nv; k += 64) {
+    const V x = av[k], y = bv[k];
+    if (SWAP) { av[k] = y; bv[k] = x; } else d |= neq(x, y);
+  }
+  bytes(t0, j1);
+  return d;
+}
+template <bool SWAP>
+__device__ __forceinline__ bool snp_range_g(int g, int8_t* a, int8_t* b, int64_t j0, int64_t j1, int ln) {
+  switch (g) {
+    case 16: return snp_range<16, SWAP>(a, b, j0, j1, ln);
+    case 8: return snp_range<8, SWAP>(a, b, j0, j1, ln);
+    case 4: return snp_range<4, SWAP>(a, b, j0, j1, ln);
+    default: return snp_range<1, SWAP>(a, b, j0, j1, ln);
+  }
+}
+
+__host__ __device__ inline size_t gnofix_leafbuf_bytes(int n_trees, int tree_bytes) {
+  const size_t a = (size_t)4 * n_trees * 4, b = (size_t)8 * tree_bytes;  // at least 8 staged trees
+  return a > b ? a : b;
+}
+
+constexpr int NWALK = 4;   // re-evaluation: trees of one (row, class) side by side (LDS latency: 4 in flight are enough)
+constexpr int RE_PER = 52; // re-evaluation: most trees one lane walks per staged chunk (their leaves stay in registers)
+constexpr int NWALK_C = 10; // candidate: 4 rows x NT walks over the block (4 x 1200 = 4800 <= 10 x 512)
+
+template <bool SL>  // SL: the two padded strips live in LDS (else in global scratch: very long chromosomes)
 __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int W = L.W, A = L.A, S = L.S, pad = (S + 1) / 2, half = (S - 1) / 2;
@@ -48,19 +134,27 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
   // ---- carve LDS ----
   size_t off = 0;
   auto carve = [&](size_t bytes) { uint8_t* p = lds + off; off += (bytes + 15) & ~(size_t)15; return p; };
-  float* bp = L.bp_in_lds ? reinterpret_cast<float*>(carve((size_t)2 * Wp * A * 4))
-                          : L.bp_scratch + (size_t)ind * 2 * Wp * A;   // [2][Wp][A]
-  float* swrows = reinterpret_cast<float*>(carve((size_t)2 * F * 4));                // switched rows m', p'
-  float* leafbuf = reinterpret_cast<float*>(carve((size_t)4 * NT * 4));              // [4][NT]
+  float* bp;  // [2][Wp][A]
+  if constexpr (SL) bp = reinterpret_cast<float*>(carve((size_t)2 * Wp * A * 4));
+  else bp = L.bp_scratch + (size_t)ind * 2 * Wp * A;
+  float* swrows = reinterpret_cast<float*>(carve((size_t)2 * (S + 2) * A * 4));      // switched rows m', p' [2][F]; exp() of re-evaluated rows
+  float* leafbuf = reinterpret_cast<float*>(carve(gnofix_leafbuf_bytes(NT, L.d.tree_bytes)));  // [4][NT] leaves / staged trees
   float* marg = reinterpret_cast<float*>(carve((size_t)2 * (S + 2) * A * 4));        // margins of re-evaluated rows
   uint8_t* Y = carve((size_t)2 * W);                                                 // labels [2][W]
   uint32_t* par = reinterpret_cast<uint32_t*>(carve((size_t)NWD * 4));               // switch parity per window
   uint32_t* dif = reinterpret_cast<uint32_t*>(carve((size_t)NWD * 4));               // SNP block differs m vs p
   int* relist = reinterpret_cast<int*>(carve((size_t)W * 4));                        // rows to re-evaluate
-  int* flags = reinterpret_cast<int*>(carve(64));                                    // [0]=accept [1]=converged [2]=n_re
-  float* rowprob = reinterpret_cast<float*>(carve(64));
+  int* flags = reinterpret_cast<int*>(carve(128));                                   // [0]=accept [1]=converged [2]=n_re [4..4+NWAVES)=first change per wave
   uint32_t* hist = L.hist + (size_t)ind * L.max_it * NWD;
 
+#ifdef GNX_GNOFIX_CLOCKS  // development aid: per-phase shader clocks, individual i reports phase (i & 7) in n_switches (units of 64 clocks)
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+  const long long tstart = tprev;
+#define TICK(i) { __syncthreads(); const long long tn = clock64(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define TICK(i)
+#endif
   int8_t* Xm = L.X + (2 * ind) * L.ldx;
   int8_t* Xp = Xm + L.ldx;
   const int64_t C = L.C;
@@ -75,35 +169,72 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
   for (int e = tid; e < 2 * W; e += THREADS) Y[e] = (uint8_t)L.Y0[(size_t)2 * ind * W + e];
   for (int e = tid; e < NWD; e += THREADS) { par[e] = 0; dif[e] = 0; }
   __syncthreads();
-  for (int u = tid; u < W; u += THREADS) {
-    const int64_t j0 = (int64_t)u * ws, j1 = (u == W - 1) ? C : j0 + ws;
+  TICK(0)
+  const int wv = tid >> 6, ln = tid & 63;
+  const int gran = (L.ldx % 16 == 0) ? 16 : (L.ldx % 8 == 0) ? 8 : (L.ldx % 4 == 0) ? 4 : 1;
+  // "does this window's SNP block differ between the two haplotypes": four lanes per window, 64 bytes per step, stopping at the first
+  // difference (heterozygous sites are dense, so a window is normally decided by its first step; identical blocks read it all)
+  for (int u0 = wv * 16; u0 < W; u0 += NWAVES * 16) {
+    const int u = u0 + (ln >> 2), q = ln & 3;
+    const bool live = u < W;
+    const int64_t j0 = live ? (int64_t)u * ws : 0, j1 = !live ? 0 : (u == W - 1) ? C : j0 + ws;
     bool d = false;
-    for (int64_t j = j0; j < j1 && !d; ++j) d = Xm[j] != Xp[j];
-    if (d) atomicOr(&dif[u >> 5], 1u << (u & 31));
+    for (int64_t j = j0; ; j += 64) {
+      const int64_t a0 = j + q * 16, a1 = min(a0 + 16, j1);
+      if (!d && a0 < j1) {
+        if (gran >= 8 && a1 - a0 == 16 && ((reinterpret_cast<uintptr_t>(Xm + a0) & 7) == 0)) {
+          const uint2* xa = reinterpret_cast<const uint2*>(Xm + a0);
+          const uint2* xb = reinterpret_cast<const uint2*>(Xp + a0);
+          d = neq(xa[0], xb[0]) || neq(xa[1], xb[1]);
+        } else {
+          for (int64_t i = a0; i < a1; ++i) d |= Xm[i] != Xp[i];
+        }
+      }
+      const unsigned long long bal = __ballot(d);
+      d = ((bal >> (ln & ~3)) & 0xfull) != 0;  // the window's four lanes agree
+      if (__ballot(!d && j + 64 < j1) == 0) break;
+    }
+    if (d && q == 0) atomicOr(&dif[u >> 5], 1u << (u & 31));
   }
   __syncthreads();
+  TICK(1)
 
   auto row_ptr = [&](int h, int w) -> const float* { return bp + ((size_t)h * Wp + w) * A; };  // features of row (h,w)
 
   int n_switch = 0;
   for (int it = 0; it < L.max_it; ++it) {
     // ---- convergence: has this X_m been seen at the start of an earlier sweep? (gnofix.py:108-113) ----
-    if (tid == 0) {
-      int conv = 0;
-      for (int k = 0; k < it && !conv; ++k) {
-        bool same = true;
-        for (int q = 0; q < NWD && same; ++q) same = hist[(size_t)k * NWD + q] == (par[q] & dif[q]);
-        conv = same;
-      }
-      flags[1] = conv;
-      if (!conv) for (int q = 0; q < NWD; ++q) hist[(size_t)it * NWD + q] = par[q] & dif[q];
+    if (tid == 0) flags[1] = 0;
+    __syncthreads();
+    for (int k = tid; k < it; k += THREADS) {  // one past sweep per thread
+      bool same = true;
+      for (int q = 0; q < NWD && same; ++q) same = hist[(size_t)k * NWD + q] == (par[q] & dif[q]);
+      if (same) atomicOr(&flags[1], 1);
     }
+    for (int q = tid; q < NWD; q += THREADS) hist[(size_t)it * NWD + q] = par[q] & dif[q];  // (harmless when converged: never read again)
     __syncthreads();
     if (flags[1]) break;
 
-    for (int w = 1; w < W; ++w) {
-      // check(): "disc_smooth" (gnofix.py:32) — uniform across the block
-      if (Y[w] == Y[w - 1] && Y[W + w] == Y[W + w - 1]) continue;
+    // check(): "disc_smooth" (gnofix.py:32): the reference walks w = 1 .. W-1 and acts only where a label changes; the next such
+    // window at or after `from` is found THREADS windows at a time (labels of later windows may change while the sweep advances, so
+    // the search restarts after every candidate)
+    auto next_change = [&](int from) -> int {
+      for (int base = from; base < W; base += THREADS) {
+        const int wq = base + tid;
+        const bool hit = wq < W && (Y[wq] != Y[wq - 1] || Y[W + wq] != Y[W + wq - 1]);
+        const unsigned long long bal = __ballot(hit);
+        if ((tid & 63) == 0) flags[4 + (tid >> 6)] = bal ? base + (tid & ~63) + __builtin_ctzll(bal) : W;
+        __syncthreads();
+        int first = W;
+#pragma unroll
+        for (int k = 0; k < NWAVES; ++k) first = min(first, flags[4 + k]);
+        __syncthreads();
+        if (first < W) return first;
+      }
+      return W;
+    };
+    for (int w = next_change(1); w < W; w = next_change(w + 1)) {
+      TICK(2)
       const int center = min(max(w, half), W - 1 - half);
       const int lo = center - half;  // scope = windows [lo, lo+S)
       // switched rows: m' = [B0[lo:w], B1[w:hi]], p' = [B1[lo:w], B0[w:hi]]   (gnofix.py:144-153)
@@ -116,32 +247,65 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
       __syncthreads();
       // 4 rows x NT tree walks; rows 0,1 = original scope slices of the padded strips (unpadded window u
       // sits at padded index u+pad), rows 2,3 = switched copies
-      for (int e = tid; e < 4 * NT; e += THREADS) {
-        const int r = e & 3, t = e >> 2;
-        const float* row = (r < 2) ? (bp + ((size_t)r * Wp + pad + lo) * A) : (swrows + (size_t)(r - 2) * F);
-        leafbuf[(size_t)r * NT + t] = gnx_walk(L.d.packed + (size_t)t * L.d.tree_bytes, reinterpret_cast<const uint8_t*>(row), D);
+      for (int e0 = tid; e0 < 4 * NT; e0 += NWALK_C * THREADS) {
+        const uint8_t* tb[NWALK_C];
+        const uint8_t* rw[NWALK_C];
+        float lf[NWALK_C];
+#pragma unroll
+        for (int k = 0; k < NWALK_C; ++k) {
+          const int e = min(e0 + k * THREADS, 4 * NT - 1);  // clamped: the tail repeats the last walk and drops it
+          const int r = e & 3, t = e >> 2;
+          tb[k] = L.d.packed + (size_t)t * L.d.tree_bytes;
+          rw[k] = reinterpret_cast<const uint8_t*>((r < 2) ? (bp + ((size_t)r * Wp + pad + lo) * A) : (swrows + (size_t)(r - 2) * F));
+        }
+        walk_n<NWALK_C>(tb, rw, D, lf);
+#pragma unroll
+        for (int k = 0; k < NWALK_C; ++k) {
+          const int e = e0 + k * THREADS;
+          if (e < 4 * NT) leafbuf[(size_t)(e & 3) * NT + (e >> 2)] = lf[k];
+        }
       }
       __syncthreads();
       if (tid < 4 * A) {  // per (row, class): in-order float32 sum of that class's trees (class-major packing)
         const int r = tid / A, c = tid - r * A;
         float ps = 0.f;
-        for (int t = L.class_tree0[c]; t < L.class_tree0[c + 1]; ++t) ps += leafbuf[(size_t)r * NT + t];
+        const int t1 = L.class_tree0[c + 1];
+        int t = L.class_tree0[c];
+        for (; t + 8 <= t1; t += 8) {  // loads first, then the adds in tree order
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = leafbuf[(size_t)r * NT + t + k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ps += v[k];
+        }
+        for (; t < t1; ++t) ps += leafbuf[(size_t)r * NT + t];
         marg[r * A + c] = L.d.base_score + ps;
       }
       __syncthreads();
-      if (tid < 4) {
-        softmax_row(marg + tid * A, A);
-        float mx = marg[tid * A];
-        for (int a = 1; a < A; ++a) mx = fmaxf(mx, marg[tid * A + a]);
-        rowprob[tid] = mx;
+      // xgboost Softmax of the 4 rows, one (row, class) per lane: exp((double)(m - max)) -> float, in-order double sum, divide
+      float* ex = marg + 4 * A;
+      if (tid < 4 * A) {
+        const int r = tid / A;
+        float wmax = marg[r * A];
+        for (int a = 1; a < A; ++a) wmax = fmaxf(marg[r * A + a], wmax);
+        ex[tid] = (float)exp((double)(marg[tid] - wmax));
       }
       __syncthreads();
-      if (tid == 0) {
-        const float p_orig = fmaxf(rowprob[0], rowprob[1]);   // prob_comp="max" over hap and ancestry
-        const float p_sw = fmaxf(rowprob[2], rowprob[3]);
-        flags[0] = (p_sw * 0.5f > p_orig * 0.5f) ? 1 : 0;     // prior_switch_prob = 0.5 (gnofix.py:171)
+      if (tid < 64) {  // lanes 0..3 = rows; the decision is taken by lane 0
+        float mx = 0.f;
+        if (tid < 4) {
+          double wsum = 0.0;
+          for (int a = 0; a < A; ++a) wsum += (double)ex[tid * A + a];
+          const float fs = (float)wsum;
+          mx = ex[tid * A] / fs;
+          for (int a = 1; a < A; ++a) mx = fmaxf(mx, ex[tid * A + a] / fs);
+        }
+        const float p_orig = fmaxf(__shfl(mx, 0), __shfl(mx, 1));   // prob_comp="max" over hap and ancestry
+        const float p_sw = fmaxf(__shfl(mx, 2), __shfl(mx, 3));
+        if (tid == 0) flags[0] = (p_sw * 0.5f > p_orig * 0.5f) ? 1 : 0;  // prior_switch_prob = 0.5 (gnofix.py:171)
       }
       __syncthreads();
+      TICK(3)
       if (!flags[0]) continue;
 
       // ---- accept: swap the strips from window w on (incl. reflected pads), flip parity, relabel ----
@@ -167,85 +331,147 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
       // {slide_src(w'+s)} = [max(0,w'-pad) .. min(W-1,w'+S-1-pad)] plus reflections that stay inside it
       // except at the edges, where the reflected part can reach further: handled by the explicit min/max.
       int n_re = 0;
-      // (block-uniform scan; W iterations of trivial work per thread would be wasteful, so thread 0 lists rows)
-      if (tid == 0) {
-        for (int wr = 0; wr < W; ++wr) {
-          int mn = W, mx = -1;
-          // sources: j = wr .. wr+S-1
-          const int j0 = wr, j1 = wr + S - 1;
-          // interior part
-          const int a0 = max(j0, pad), a1 = min(j1, pad + W - 1);
-          if (a0 <= a1) { mn = min(mn, a0 - pad); mx = max(mx, a1 - pad); }
-          if (j0 < pad) { const int b1 = min(j1, pad - 1); mn = min(mn, pad - 1 - b1); mx = max(mx, pad - 1 - j0); }
-          if (j1 >= pad + W) { const int b0 = max(j0, pad + W); mn = min(mn, W - 1 - (j1 - pad - W)); mx = max(mx, W - 1 - (b0 - pad - W)); }
-          if (mn >= w) {  // pure swap
-            const uint8_t t0 = Y[wr];
-            Y[wr] = Y[W + wr];
-            Y[W + wr] = t0;
-          } else if (mx >= w) {
-            relist[n_re++] = wr;
-          }
+      if (tid == 0) flags[2] = 0;
+      __syncthreads();
+      for (int wr = tid; wr < W; wr += THREADS) {  // every row classified by its own thread; the order of `relist` is immaterial
+        int mn = W, mx = -1;
+        // sources: j = wr .. wr+S-1
+        const int j0 = wr, j1 = wr + S - 1;
+        // interior part
+        const int a0 = max(j0, pad), a1 = min(j1, pad + W - 1);
+        if (a0 <= a1) { mn = min(mn, a0 - pad); mx = max(mx, a1 - pad); }
+        if (j0 < pad) { const int b1 = min(j1, pad - 1); mn = min(mn, pad - 1 - b1); mx = max(mx, pad - 1 - j0); }
+        if (j1 >= pad + W) { const int b0 = max(j0, pad + W); mn = min(mn, W - 1 - (j1 - pad - W)); mx = max(mx, W - 1 - (b0 - pad - W)); }
+        if (mn >= w) {  // pure swap
+          const uint8_t t0 = Y[wr];
+          Y[wr] = Y[W + wr];
+          Y[W + wr] = t0;
+        } else if (mx >= w) {
+          relist[atomicAdd(&flags[2], 1)] = wr;
         }
-        flags[2] = n_re;
       }
       __syncthreads();
       n_re = flags[2];
-      // re-evaluate rows (h, relist[k]): thread = (row, class), in-order sum over the class's trees
+      TICK(4)
+      // re-evaluate rows (h, relist[k]) class by class: the class's trees are staged in LDS (leafbuf is idle here), P lanes share a
+      // row and split the staged trees, and the row's sum is taken in tree order by handing the running sum down those lanes
+      const int tree_bytes = L.d.tree_bytes, cap = min((int)(gnofix_leafbuf_bytes(NT, tree_bytes) / tree_bytes), 64 * RE_PER);
+      uint8_t* stage_t = reinterpret_cast<uint8_t*>(leafbuf);
       for (int base = 0; base < 2 * n_re; base += 2 * (S + 2)) {
         const int nrow = min(2 * (S + 2), 2 * n_re - base);
-        for (int e = tid; e < nrow * A; e += THREADS) {
-          const int rr = e / A, c = e - rr * A;
-          const int k = (base + rr) >> 1, h = (base + rr) & 1;
-          const float* row = row_ptr(h, relist[k]);
-          float ps = 0.f;
-          for (int t = L.class_tree0[c]; t < L.class_tree0[c + 1]; ++t)
-            ps += gnx_walk(L.d.packed + (size_t)t * L.d.tree_bytes, reinterpret_cast<const uint8_t*>(row), D);
-          marg[rr * A + c] = L.d.base_score + ps;
+        for (int c = 0; c < A; ++c) {
+          const int t0 = L.class_tree0[c], t1 = L.class_tree0[c + 1];
+          for (int ts = t0; ts < t1; ts += cap) {
+            const int n_st = min(cap, t1 - ts);
+            __syncthreads();
+            {
+              const uint4* src = reinterpret_cast<const uint4*>(L.d.packed + (size_t)ts * tree_bytes);
+              uint4* dst = reinterpret_cast<uint4*>(stage_t);
+              for (int q = tid; q < n_st * (tree_bytes / 16); q += THREADS) dst[q] = src[q];
+            }
+            __syncthreads();
+            int P = 1;
+            while (P * RE_PER < n_st) P *= 2;  // lanes per row (a power of two <= 64: the hand-down stays inside a wave)
+            const int per = (n_st + P - 1) / P;
+            const int n_task = nrow * P;
+            for (int e0 = 0; e0 < n_task; e0 += THREADS) {
+              const int e = e0 + tid;
+              const bool live = e < n_task;
+              const int rr = live ? e / P : 0, p = e & (P - 1);
+              const int k = (base + rr) >> 1, h = (base + rr) & 1;
+              const uint8_t* row = reinterpret_cast<const uint8_t*>(row_ptr(h, relist[k]));
+              const int lo_t = min(p * per, n_st), cnt = live ? min(per, n_st - lo_t) : 0;
+              float lf[RE_PER];
+#pragma unroll
+              for (int b = 0; b < RE_PER; b += NWALK) {
+                if (b < cnt) {
+                  const uint8_t* tb[NWALK];
+                  const uint8_t* rw[NWALK];
+                  float o[NWALK];
+#pragma unroll
+                  for (int i = 0; i < NWALK; ++i) { tb[i] = stage_t + (size_t)min(lo_t + b + i, n_st - 1) * tree_bytes; rw[i] = row; }
+                  walk_n<NWALK>(tb, rw, D, o);
+#pragma unroll
+                  for (int i = 0; i < NWALK; ++i) lf[b + i] = o[i];
+                }
+              }
+              float ps = (ts == t0) ? 0.f : marg[rr * A + c];  // (only lane p == 0 uses it)
+              for (int step = 0; step < P; ++step) {
+                const float up = __shfl_up(ps, 1);
+                if (p == step) {
+                  if (step > 0) ps = up;
+#pragma unroll
+                  for (int i = 0; i < RE_PER; ++i) if (i < cnt) ps += lf[i];  // tree order
+                }
+              }
+              if (live && p == P - 1) marg[rr * A + c] = ps;
+            }
+          }
+        }
+        __syncthreads();
+        for (int e = tid; e < nrow * A; e += THREADS) {  // margin -> exp(margin - row max), one (row, class) per thread
+          const int rr = e / A;
+          float wmax = L.d.base_score + marg[rr * A];
+          for (int a = 1; a < A; ++a) wmax = fmaxf(L.d.base_score + marg[rr * A + a], wmax);
+          swrows[e] = (float)exp((double)((L.d.base_score + marg[e]) - wmax));  // (swrows is idle here)
         }
         __syncthreads();
         for (int rr = tid; rr < nrow; rr += THREADS) {
-          softmax_row(marg + rr * A, A);
+          const float* m = swrows + rr * A;
+          double wsum = 0.0;
+          for (int a = 0; a < A; ++a) wsum += (double)m[a];
+          const float fs = (float)wsum;
           int best = 0;
-          float bv = marg[rr * A];
-          for (int a = 1; a < A; ++a) if (marg[rr * A + a] > bv) { bv = marg[rr * A + a]; best = a; }
+          float bv = m[0] / fs;
+          for (int a = 1; a < A; ++a) { const float v = m[a] / fs; if (v > bv) { bv = v; best = a; } }
           const int k = (base + rr) >> 1, h = (base + rr) & 1;
           Y[h * W + relist[k]] = (uint8_t)best;
         }
         __syncthreads();
       }
+      TICK(5)
     }
+    TICK(2)
   }
 
   // ---- outputs: labels, switch count, SNP swap from the final parity (phasing.py:188-198) ----
   for (int e = tid; e < 2 * W; e += THREADS) L.Yout[(size_t)2 * ind * W + e] = Y[e];
-  if (tid == 0 && L.n_switches) L.n_switches[ind] = n_switch;
-  for (int64_t j = tid; j < C; j += THREADS) {
-    int64_t u = j / ws;
-    if (u > W - 1) u = W - 1;
-    if ((par[u >> 5] >> (u & 31)) & 1u) {
-      const int8_t t0 = Xm[j];
-      Xm[j] = Xp[j];
-      Xp[j] = t0;
-    }
+  TICK(2)
+  for (int u = wv; u < W; u += NWAVES) {  // only the windows of odd parity are touched
+    if (!((par[u >> 5] >> (u & 31)) & 1u)) continue;
+    const int64_t j0 = (int64_t)u * ws, j1 = (u == W - 1) ? C : j0 + ws;
+    snp_range_g<true>(gran, Xm, Xp, j0, j1, ln);
   }
+  TICK(6)
+#ifdef GNX_GNOFIX_CLOCKS
+  tacc[7] = tprev - tstart;
+  if (tid == 0 && L.n_switches) L.n_switches[ind] = (int)(tacc[ind & 7] >> 6);
+#else
+  if (tid == 0 && L.n_switches) L.n_switches[ind] = n_switch;
+#endif
 }
 
 }  // namespace
 
-size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, bool bp_in_lds) {
-  const int pad = (S + 1) / 2, Wp = W + 2 * pad, F = S * A, NWD = (W + 31) / 32;
+size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, int tree_bytes, bool bp_in_lds) {
+  const int pad = (S + 1) / 2, Wp = W + 2 * pad, NWD = (W + 31) / 32;
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
   size_t t = 0;
   if (bp_in_lds) t += r16((size_t)2 * Wp * A * 4);
-  t += r16((size_t)2 * F * 4) + r16((size_t)4 * n_trees * 4) + r16((size_t)2 * (S + 2) * A * 4) + r16((size_t)2 * W) +
-       2 * r16((size_t)NWD * 4) + r16((size_t)W * 4) + 64 + 64;
+  t += r16((size_t)2 * (S + 2) * A * 4) + r16(gnofix_leafbuf_bytes(n_trees, tree_bytes)) + r16((size_t)2 * (S + 2) * A * 4) + r16((size_t)2 * W) +
+       2 * r16((size_t)NWD * 4) + r16((size_t)W * 4) + 128;
   return t;
 }
 
 hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s) {
   if (n_ind <= 0) return hipSuccess;
-  const size_t lds = gnx_gnofix_lds_bytes(L.W, L.A, L.S, L.d.n_trees, L.bp_in_lds);
-  GNX_LDS_OPTIN(lds, k_gnofix);
-  hipLaunchKernelGGL(k_gnofix, dim3((unsigned)n_ind), dim3(THREADS), lds, s, L);
+  const size_t lds = gnx_gnofix_lds_bytes(L.W, L.A, L.S, L.d.n_trees, L.d.tree_bytes, L.bp_in_lds != 0);
+  if (L.bp_in_lds) {
+    GNX_LDS_OPTIN(lds, k_gnofix<true>);
+    hipLaunchKernelGGL(k_gnofix<true>, dim3((unsigned)n_ind), dim3(THREADS), lds, s, L);
+  } else {
+    GNX_LDS_OPTIN(lds, k_gnofix<false>);
+    hipLaunchKernelGGL(k_gnofix<false>, dim3((unsigned)n_ind), dim3(THREADS), lds, s, L);
+  }
   return hipGetLastError();
 }

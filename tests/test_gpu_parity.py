@@ -470,6 +470,41 @@ def test_cli_end_to_end(ga, oracle, tmp_path, phase):
         assert os.path.exists(out + "/query_file_phased.vcf")
 
 
+@pytest.mark.parametrize("extra", [16, 4, 8, 13])  # row pitch: 16-, 4-, 8-byte and unaligned SNP granules
+def test_gnofix_wide_windows_and_equal_blocks(ga, oracle, extra):
+    """windows of several hundred SNPs: blocks that are identical between the two haplotypes (no contribution to the
+    convergence signature), blocks that differ only in their last SNP, and the vectorised SNP swap at every alignment"""
+    from gnomix_amd import synth
+    W, A, S, M = 96, 5, 11, 208
+    C = W * M + extra
+    d = ga.GnxModelData(C=C, M=M, A=A, S=S, context=0, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(3, A, S * A, seed=21, thr_lo=0.0, thr_hi=0.5, leaf_scale=1.0).items():
+        setattr(d, k, v)
+    dev = ga.DeviceModel(d)
+    T = _oracle_trees(oracle, d)
+    rng = np.random.RandomState(40 + extra)
+    n_ind = 3
+    X = rng.randint(0, 2, size=(2 * n_ind, C)).astype(np.int8)
+    for i in range(n_ind):
+        for u in range(W):
+            kind = rng.randint(4)
+            lo, hi = u * M, (u + 1) * M if u < W - 1 else C
+            if kind == 0:
+                X[2 * i + 1, lo:hi] = X[2 * i, lo:hi]
+            elif kind == 1:
+                X[2 * i + 1, lo:hi] = X[2 * i, lo:hi]
+                X[2 * i + 1, hi - 1] ^= 1
+    B = rng.dirichlet(np.ones(A) * 0.3, size=(2 * n_ind, W))
+    Xo, Y, nsw = dev.gnofix(X, B, max_it=8)
+    rows = lambda r: oracle.xgb_predict_proba(T, r)
+    labs = lambda b: oracle.smooth_xgb(T, b, S)[1]
+    for i in range(n_ind):
+        Xm, Xp, Ym, Yp, _, ns = oracle.gnofix(X[2 * i], X[2 * i + 1], B[2 * i:2 * i + 2], S, rows, labs, max_it=8)
+        assert np.array_equal(Xo[2 * i], Xm) and np.array_equal(Xo[2 * i + 1], Xp), i
+        assert np.array_equal(Y[2 * i], Ym) and np.array_equal(Y[2 * i + 1], Yp) and int(nsw[i]) == ns, i
+    assert int(nsw.sum()) > 0
+
+
 def test_gnofix_strips_in_global_scratch(ga, oracle):
     """an individual whose two padded strips exceed the LDS budget takes the global-scratch path"""
     from gnomix_amd import synth
