@@ -25,8 +25,8 @@
 //  * after an accepted switch all threads classify the rows (swap / re-evaluate list by LDS atomic); the re-evaluation goes class
 //    by class with the class's trees staged in LDS, P lanes per row splitting them and handing the running float32 sum down the
 //    lanes in tree order (bit-identical to the sequential predictor);
-//  * the per-window "SNP blocks differ" flags stop at the first difference, the final SNP swap touches only windows of odd parity,
-//    a wave per window with the widest granule the row pitch allows;
+//  * the per-window "SNP blocks differ" flags stop at the first difference; the final SNP swap touches only windows of odd parity,
+//    one byte range per run of such windows, unaligned 16-byte pieces;
 //  * the convergence history is compared one past sweep per thread.
 // -DGNX_GNOFIX_CLOCKS turns n_switches into per-phase clock counts (scripts/dev/gnofix_phases.py).
 #include "gnx_internal.h"
@@ -69,58 +69,24 @@ __device__ __forceinline__ void walk_n(const uint8_t* const (&tb)[NW], const uin
   for (int k = 0; k < NW; ++k) out[k] = (fv[k] < __uint_as_float(n4[k].y)) ? __uint_as_float(n4[k].z) : __uint_as_float(n4[k].w);
 }
 
-// ---- SNP ranges of the two haplotype rows, one wave per window.  The rows are ldx bytes apart, so a granule of G bytes (the largest
-// power of two <= 16 dividing ldx) is aligned in both once it is aligned in one; heads and tails go byte-wise. ----
-template <int G> struct granule;
-template <> struct granule<16> { using type = uint4; };
-template <> struct granule<8> { using type = uint2; };
-template <> struct granule<4> { using type = uint32_t; };
-template <> struct granule<1> { using type = uint8_t; };
-__device__ __forceinline__ bool neq(uint4 x, uint4 y) { return ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) != 0; }
-__device__ __forceinline__ bool neq(uint2 x, uint2 y) { return ((x.x ^ y.x) | (x.y ^ y.y)) != 0; }
-__device__ __forceinline__ bool neq(uint32_t x, uint32_t y) { return x != y; }
-__device__ __forceinline__ bool neq(uint8_t x, uint8_t y) { return x != y; }
+// ---- 16 SNPs of a haplotype row at any byte address (gfx950 global memory takes unaligned dwordx4; the rows of an individual are
+// ldx bytes apart with no alignment promise) ----
+struct __attribute__((packed, aligned(1))) snp16 { uint32_t x, y, z, w; };
+__device__ __forceinline__ snp16 ld16(const int8_t* p) { snp16 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st16(int8_t* p, const snp16& v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ bool neq(const snp16& a, const snp16& b) { return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) != 0; }
 
-template <int G, bool SWAP>
-__device__ __forceinline__ bool snp_range(int8_t* a, int8_t* b, int64_t j0, int64_t j1, int ln) {
-  using V = typename granule<G>::type;
-  int64_t h = j0 + (int64_t)((0 - reinterpret_cast<uintptr_t>(a + j0)) & (uintptr_t)(G - 1));
-  if (h > j1) h = j1;
-  const int64_t nv = (j1 - h) / G, t0 = h + nv * G;
-  bool d = false;
-  auto bytes = [&](int64_t from, int64_t to) {
-    for (int64_t j = from + ln; j < to; j += 64) {
-      const int8_t x = a[j], y = b[j];
-      if (SWAP) { a[j] = y; b[j] = x; } else d |= x != y;
-    }
-  };
-  bytes(j0, h);
-  V* av = reinterpret_cast<V*>(a + h);
-  V* bv = reinterpret_cast<V*>(b + h);
-  for (int64_t k = ln; k < nv; k += 64) {
-    const V x = av[k], y = bv[k];
-    if (SWAP) { av[k] = y; bv[k] = x; } else d |= neq(x, y);
-  }
-  bytes(t0, j1);
-  return d;
+__host__ __device__ inline size_t gnofix_swrows_bytes(int S, int A, bool strips_in_lds) {
+  const size_t a = (size_t)2 * (S + 2) * A * 4, b = (size_t)(strips_in_lds ? 2 : 4) * S * A * 4;
+  return a > b ? a : b;
 }
-template <bool SWAP>
-__device__ __forceinline__ bool snp_range_g(int g, int8_t* a, int8_t* b, int64_t j0, int64_t j1, int ln) {
-  switch (g) {
-    case 16: return snp_range<16, SWAP>(a, b, j0, j1, ln);
-    case 8: return snp_range<8, SWAP>(a, b, j0, j1, ln);
-    case 4: return snp_range<4, SWAP>(a, b, j0, j1, ln);
-    default: return snp_range<1, SWAP>(a, b, j0, j1, ln);
-  }
-}
-
 __host__ __device__ inline size_t gnofix_leafbuf_bytes(int n_trees, int tree_bytes) {
   const size_t a = (size_t)4 * n_trees * 4, b = (size_t)8 * tree_bytes;  // at least 8 staged trees
   return a > b ? a : b;
 }
 
-constexpr int NWALK = 4;   // re-evaluation: trees of one (row, class) side by side (LDS latency: 4 in flight are enough)
-constexpr int RE_PER = 52; // re-evaluation: most trees one lane walks per staged chunk (their leaves stay in registers)
+constexpr int NWALK = 4;   // re-evaluation: trees of one (row, class) walked side by side
+constexpr int RE_PER = 40; // re-evaluation: most trees one lane walks per staged chunk (their leaves stay in registers)
 constexpr int NWALK_C = 10; // candidate: 4 rows x NT walks over the block (4 x 1200 = 4800 <= 10 x 512)
 
 template <bool SL>  // SL: the two padded strips live in LDS (else in global scratch: very long chromosomes)
@@ -137,14 +103,18 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
   float* bp;  // [2][Wp][A]
   if constexpr (SL) bp = reinterpret_cast<float*>(carve((size_t)2 * Wp * A * 4));
   else bp = L.bp_scratch + (size_t)ind * 2 * Wp * A;
-  float* swrows = reinterpret_cast<float*>(carve((size_t)2 * (S + 2) * A * 4));      // switched rows m', p' [2][F]; exp() of re-evaluated rows
+  // candidate rows [2][F] (SL: the switched pair; the original pair is read from the strips) or [4][F] (strips in global memory:
+  // original pair + switched pair); also the exp() of re-evaluated rows
+  float* swrows = reinterpret_cast<float*>(carve(gnofix_swrows_bytes(S, A, SL)));
+  // strips in global memory: the slice of both strips that a group of re-evaluated rows reads, [2][SEGW][A]
+  const int SEGW = 2 * S + 2;
+  float* seg = SL ? nullptr : reinterpret_cast<float*>(carve((size_t)2 * SEGW * A * 4));
   float* leafbuf = reinterpret_cast<float*>(carve(gnofix_leafbuf_bytes(NT, L.d.tree_bytes)));  // [4][NT] leaves / staged trees
   float* marg = reinterpret_cast<float*>(carve((size_t)2 * (S + 2) * A * 4));        // margins of re-evaluated rows
-  uint8_t* Y = carve((size_t)2 * W);                                                 // labels [2][W]
+  uint8_t* Y = carve((size_t)2 * W + 16);                                                 // labels [2][W]
   uint32_t* par = reinterpret_cast<uint32_t*>(carve((size_t)NWD * 4));               // switch parity per window
   uint32_t* dif = reinterpret_cast<uint32_t*>(carve((size_t)NWD * 4));               // SNP block differs m vs p
-  int* relist = reinterpret_cast<int*>(carve((size_t)W * 4));                        // rows to re-evaluate
-  int* flags = reinterpret_cast<int*>(carve(128));                                   // [0]=accept [1]=converged [2]=n_re [4..4+NWAVES)=first change per wave
+  int* flags = reinterpret_cast<int*>(carve(128));                                   // [0]=accept [1]=converged [2],[3]=rows to re-evaluate [r0,r1) [4..4+NWAVES)=first change per wave
   uint32_t* hist = L.hist + (size_t)ind * L.max_it * NWD;
 
 #ifdef GNX_GNOFIX_CLOCKS  // development aid: per-phase shader clocks, individual i reports phase (i & 7) in n_switches (units of 64 clocks)
@@ -171,7 +141,6 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
   __syncthreads();
   TICK(0)
   const int wv = tid >> 6, ln = tid & 63;
-  const int gran = (L.ldx % 16 == 0) ? 16 : (L.ldx % 8 == 0) ? 8 : (L.ldx % 4 == 0) ? 4 : 1;
   // "does this window's SNP block differ between the two haplotypes": four lanes per window, 64 bytes per step, stopping at the first
   // difference (heterozygous sites are dense, so a window is normally decided by its first step; identical blocks read it all)
   for (int u0 = wv * 16; u0 < W; u0 += NWAVES * 16) {
@@ -182,10 +151,8 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
     for (int64_t j = j0; ; j += 64) {
       const int64_t a0 = j + q * 16, a1 = min(a0 + 16, j1);
       if (!d && a0 < j1) {
-        if (gran >= 8 && a1 - a0 == 16 && ((reinterpret_cast<uintptr_t>(Xm + a0) & 7) == 0)) {
-          const uint2* xa = reinterpret_cast<const uint2*>(Xm + a0);
-          const uint2* xb = reinterpret_cast<const uint2*>(Xp + a0);
-          d = neq(xa[0], xb[0]) || neq(xa[1], xb[1]);
+        if (a1 - a0 == 16) {
+          d = neq(ld16(Xm + a0), ld16(Xp + a0));
         } else {
           for (int64_t i = a0; i < a1; ++i) d |= Xm[i] != Xp[i];
         }
@@ -198,8 +165,6 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
   }
   __syncthreads();
   TICK(1)
-
-  auto row_ptr = [&](int h, int w) -> const float* { return bp + ((size_t)h * Wp + w) * A; };  // features of row (h,w)
 
   int n_switch = 0;
   for (int it = 0; it < L.max_it; ++it) {
@@ -238,15 +203,16 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
       const int center = min(max(w, half), W - 1 - half);
       const int lo = center - half;  // scope = windows [lo, lo+S)
       // switched rows: m' = [B0[lo:w], B1[w:hi]], p' = [B1[lo:w], B0[w:hi]]   (gnofix.py:144-153)
-      for (int e = tid; e < 2 * F; e += THREADS) {
-        const int r = e / F, f = e - r * F;
+      constexpr int R0 = SL ? 2 : 0;  // first row kept in swrows
+      for (int e = tid; e < (4 - R0) * F; e += THREADS) {
+        const int r = R0 + e / F, f = e % F;
         const int u = lo + f / A;
-        const int h = (u < w) ? r : (1 - r);
+        const int h = (r < 2) ? r : (u < w) ? (r - 2) : (3 - r);
         swrows[e] = bp[((size_t)h * Wp + pad + u) * A + (f % A)];
       }
       __syncthreads();
       // 4 rows x NT tree walks; rows 0,1 = original scope slices of the padded strips (unpadded window u
-      // sits at padded index u+pad), rows 2,3 = switched copies
+      // sits at padded index u+pad; copied to LDS when the strips are in global memory), rows 2,3 = switched copies
       for (int e0 = tid; e0 < 4 * NT; e0 += NWALK_C * THREADS) {
         const uint8_t* tb[NWALK_C];
         const uint8_t* rw[NWALK_C];
@@ -256,7 +222,8 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
           const int e = min(e0 + k * THREADS, 4 * NT - 1);  // clamped: the tail repeats the last walk and drops it
           const int r = e & 3, t = e >> 2;
           tb[k] = L.d.packed + (size_t)t * L.d.tree_bytes;
-          rw[k] = reinterpret_cast<const uint8_t*>((r < 2) ? (bp + ((size_t)r * Wp + pad + lo) * A) : (swrows + (size_t)(r - 2) * F));
+          if constexpr (SL) rw[k] = reinterpret_cast<const uint8_t*>((r < 2) ? (bp + ((size_t)r * Wp + pad + lo) * A) : (swrows + (size_t)(r - 2) * F));
+          else rw[k] = reinterpret_cast<const uint8_t*>(swrows + (size_t)r * F);
         }
         walk_n<NWALK_C>(tb, rw, D, lf);
 #pragma unroll
@@ -330,10 +297,11 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
       // rows that see windows on both sides of w: re-evaluate.  Row w' sees unpadded windows
       // {slide_src(w'+s)} = [max(0,w'-pad) .. min(W-1,w'+S-1-pad)] plus reflections that stay inside it
       // except at the edges, where the reflected part can reach further: handled by the explicit min/max.
-      int n_re = 0;
-      if (tid == 0) flags[2] = 0;
+      // (The rows to re-evaluate form one contiguous range [r0, r1): re-evaluating a row of that range that needed nothing, or one
+      // that was also swapped, just recomputes its label from the current strips.)
+      if (tid == 0) { flags[2] = W; flags[3] = 0; }
       __syncthreads();
-      for (int wr = tid; wr < W; wr += THREADS) {  // every row classified by its own thread; the order of `relist` is immaterial
+      for (int wr = tid; wr < W; wr += THREADS) {  // every row classified by its own thread
         int mn = W, mx = -1;
         // sources: j = wr .. wr+S-1
         const int j0 = wr, j1 = wr + S - 1;
@@ -347,18 +315,26 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
           Y[wr] = Y[W + wr];
           Y[W + wr] = t0;
         } else if (mx >= w) {
-          relist[atomicAdd(&flags[2], 1)] = wr;
+          atomicMin(&flags[2], wr);
+          atomicMax(&flags[3], wr + 1);
         }
       }
       __syncthreads();
-      n_re = flags[2];
+      const int r0 = flags[2], r1 = flags[3];
       TICK(4)
-      // re-evaluate rows (h, relist[k]) class by class: the class's trees are staged in LDS (leafbuf is idle here), P lanes share a
+      // re-evaluate rows (h, r0..r1-1), S+2 windows at a time, class by class: the class's trees are staged in LDS (leafbuf is idle here), P lanes share a
       // row and split the staged trees, and the row's sum is taken in tree order by handing the running sum down those lanes
       const int tree_bytes = L.d.tree_bytes, cap = min((int)(gnofix_leafbuf_bytes(NT, tree_bytes) / tree_bytes), 64 * RE_PER);
       uint8_t* stage_t = reinterpret_cast<uint8_t*>(leafbuf);
-      for (int base = 0; base < 2 * n_re; base += 2 * (S + 2)) {
-        const int nrow = min(2 * (S + 2), 2 * n_re - base);
+      for (int gb = r0; gb < r1; gb += S + 2) {
+        const int nwin = min(S + 2, r1 - gb), nrow = 2 * nwin;  // row rr = (window gb + (rr >> 1), haplotype rr & 1)
+        if constexpr (!SL) {  // the rows read padded windows [gb, gb + nwin + S - 1) of both strips
+          const int nj = nwin + S - 1;
+          for (int e = tid; e < 2 * nj * A; e += THREADS) {
+            const int h = e / (nj * A), r = e - h * nj * A;
+            seg[(size_t)h * SEGW * A + r] = bp[((size_t)h * Wp + gb) * A + r];
+          }
+        }
         for (int c = 0; c < A; ++c) {
           const int t0 = L.class_tree0[c], t1 = L.class_tree0[c + 1];
           for (int ts = t0; ts < t1; ts += cap) {
@@ -370,21 +346,24 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
               for (int q = tid; q < n_st * (tree_bytes / 16); q += THREADS) dst[q] = src[q];
             }
             __syncthreads();
-            int P = 1;
-            while (P * RE_PER < n_st) P *= 2;  // lanes per row (a power of two <= 64: the hand-down stays inside a wave)
+            // P lanes per row, rows never straddling a wave: the most lanes that still cover all rows in one pass of the block
+            // (at least enough for a lane's share of the staged trees to fit its registers)
+            int P = (n_st + RE_PER - 1) / RE_PER;
+            while (P < 64 && (P + 1) * 4 <= n_st && (nrow + 64 / (P + 1) - 1) / (64 / (P + 1)) <= NWAVES) ++P;
+            const int rpw = 64 / P;                      // rows per wave
             const int per = (n_st + P - 1) / P;
-            const int n_task = nrow * P;
-            for (int e0 = 0; e0 < n_task; e0 += THREADS) {
-              const int e = e0 + tid;
-              const bool live = e < n_task;
-              const int rr = live ? e / P : 0, p = e & (P - 1);
-              const int k = (base + rr) >> 1, h = (base + rr) & 1;
-              const uint8_t* row = reinterpret_cast<const uint8_t*>(row_ptr(h, relist[k]));
+            const int n_pass = (nrow + rpw * NWAVES - 1) / (rpw * NWAVES);
+            for (int pass = 0; pass < n_pass; ++pass) {
+              const int p = ln % P, rr_ = (pass * NWAVES + wv) * rpw + ln / P;
+              const bool live = ln < rpw * P && rr_ < nrow;
+              const int rr = live ? rr_ : 0;
+              const int k = rr >> 1, h = rr & 1;
+              const uint8_t* row = reinterpret_cast<const uint8_t*>(SL ? bp + ((size_t)h * Wp + gb + k) * A : seg + ((size_t)h * SEGW + k) * A);
               const int lo_t = min(p * per, n_st), cnt = live ? min(per, n_st - lo_t) : 0;
               float lf[RE_PER];
 #pragma unroll
               for (int b = 0; b < RE_PER; b += NWALK) {
-                if (b < cnt) {
+                if (b < per && b < cnt) {
                   const uint8_t* tb[NWALK];
                   const uint8_t* rw[NWALK];
                   float o[NWALK];
@@ -401,7 +380,7 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
                 if (p == step) {
                   if (step > 0) ps = up;
 #pragma unroll
-                  for (int i = 0; i < RE_PER; ++i) if (i < cnt) ps += lf[i];  // tree order
+                  for (int i = 0; i < RE_PER; ++i) if (i < per && i < cnt) ps += lf[i];  // tree order
                 }
               }
               if (live && p == P - 1) marg[rr * A + c] = ps;
@@ -424,8 +403,7 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
           int best = 0;
           float bv = m[0] / fs;
           for (int a = 1; a < A; ++a) { const float v = m[a] / fs; if (v > bv) { bv = v; best = a; } }
-          const int k = (base + rr) >> 1, h = (base + rr) & 1;
-          Y[h * W + relist[k]] = (uint8_t)best;
+          Y[(rr & 1) * W + gb + (rr >> 1)] = (uint8_t)best;
         }
         __syncthreads();
       }
@@ -437,10 +415,41 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
   // ---- outputs: labels, switch count, SNP swap from the final parity (phasing.py:188-198) ----
   for (int e = tid; e < 2 * W; e += THREADS) L.Yout[(size_t)2 * ind * W + e] = Y[e];
   TICK(2)
-  for (int u = wv; u < W; u += NWAVES) {  // only the windows of odd parity are touched
-    if (!((par[u >> 5] >> (u & 31)) & 1u)) continue;
-    const int64_t j0 = (int64_t)u * ws, j1 = (u == W - 1) ? C : j0 + ws;
-    snp_range_g<true>(gran, Xm, Xp, j0, j1, ln);
+  // Only windows of odd parity are touched; they come in a few long runs (every accepted switch flips "from w to the end"), so the
+  // block sweeps each run as one byte range, four 16-byte pieces per thread in flight for each row.
+  __syncthreads();                                  // Y is free from here: it takes the run starts
+  int* runs = reinterpret_cast<int*>(Y);            // <= W/2 starts, 2W bytes
+  if (tid == 0) flags[2] = 0;
+  __syncthreads();
+  auto flipped = [&](int u) { return ((par[u >> 5] >> (u & 31)) & 1u) != 0; };
+  for (int u = tid; u < W; u += THREADS)
+    if (flipped(u) && (u == 0 || !flipped(u - 1))) runs[atomicAdd(&flags[2], 1)] = u;
+  __syncthreads();
+  const int n_runs = flags[2];
+  for (int r = 0; r < n_runs; ++r) {
+    const int ua = runs[r];
+    int ub = ua + 1;
+    while (ub < W && flipped(ub)) ++ub;             // (block-uniform scan; runs are few)
+    const int64_t j0 = (int64_t)ua * ws, j1 = (ub == W) ? C : (int64_t)ub * ws;
+    const int64_t n16 = (j1 - j0) / 16;
+    for (int64_t k0 = 0; k0 < n16; k0 += 4 * THREADS) {
+      snp16 xa[4], xb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t k = k0 + q * THREADS + tid;
+        if (k < n16) { xa[q] = ld16(Xm + j0 + k * 16); xb[q] = ld16(Xp + j0 + k * 16); }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t k = k0 + q * THREADS + tid;
+        if (k < n16) { st16(Xm + j0 + k * 16, xb[q]); st16(Xp + j0 + k * 16, xa[q]); }
+      }
+    }
+    for (int64_t j = j0 + n16 * 16 + tid; j < j1; j += THREADS) {
+      const int8_t t0 = Xm[j];
+      Xm[j] = Xp[j];
+      Xp[j] = t0;
+    }
   }
   TICK(6)
 #ifdef GNX_GNOFIX_CLOCKS
@@ -458,8 +467,9 @@ size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, int tree_bytes, bo
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
   size_t t = 0;
   if (bp_in_lds) t += r16((size_t)2 * Wp * A * 4);
-  t += r16((size_t)2 * (S + 2) * A * 4) + r16(gnofix_leafbuf_bytes(n_trees, tree_bytes)) + r16((size_t)2 * (S + 2) * A * 4) + r16((size_t)2 * W) +
-       2 * r16((size_t)NWD * 4) + r16((size_t)W * 4) + 128;
+  t += r16(gnofix_swrows_bytes(S, A, bp_in_lds)) + (bp_in_lds ? 0 : r16((size_t)2 * (2 * S + 2) * A * 4)) +
+       r16(gnofix_leafbuf_bytes(n_trees, tree_bytes)) + r16((size_t)2 * (S + 2) * A * 4) + r16((size_t)2 * W + 16) +
+       2 * r16((size_t)NWD * 4) + 128;
   return t;
 }
 
