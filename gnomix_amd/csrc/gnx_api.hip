@@ -1426,9 +1426,8 @@ static int gnofix_check(gnx_model* m, int64_t ldx, int64_t n_ind, int32_t max_it
   return GNX_OK;
 }
 
-// device-resident batch: initial labels with the batched smoother kernel, then one workgroup per individual
-static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int64_t n, int32_t max_it, int32_t* dY,
-                          int32_t* dNs, bool in_lds) {
+// scratch of one device-resident batch of n individuals (grows only)
+static int gnofix_ws_reserve(gnx_model* m, int64_t n, int32_t max_it, bool in_lds, size_t* bp_off_out) {
   gnx_ctx* ctx = m->ctx;
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S, pad = (S + 1) / 2;
   const size_t WA = (size_t)W * A, NWD = (size_t)(W + 31) / 32;
@@ -1438,7 +1437,18 @@ static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* d
   size_t misc = (size_t)n * std::max(max_it, 1) * NWD * 4;
   const size_t bp_off = (misc + 255) & ~(size_t)255;
   if (!in_lds) misc = bp_off + (size_t)n * 2 * (W + 2 * pad) * A * 4;
-  if ((rc = ws_reserve(ctx, ctx->ws_misc, misc + 256)) != GNX_OK) return rc;
+  if (bp_off_out) *bp_off_out = bp_off;
+  return ws_reserve(ctx, ctx->ws_misc, misc + 256);
+}
+
+// device-resident batch: initial labels with the batched smoother kernel, then one workgroup per individual
+static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int64_t n, int32_t max_it, int32_t* dY,
+                          int32_t* dNs, bool in_lds) {
+  gnx_ctx* ctx = m->ctx;
+  const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
+  int rc;
+  size_t bp_off = 0;
+  if ((rc = gnofix_ws_reserve(m, n, max_it, in_lds, &bp_off)) != GNX_OK) return rc;
   int32_t* dY0 = (int32_t*)ctx->ws_y0.p;
   // initial labels = smoother.predict(B) for every haplotype at once (gnofix.py:80)
   rc = gnx_smooth_predict_dev(m, dB, 1, 2 * n, (float*)ctx->ws_p32.p, nullptr, dY0);
@@ -1473,27 +1483,64 @@ int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int W = (int)m->info.W;
   const size_t WA = (size_t)W * m->info.A;
-  // batches of individuals bound the staging workspaces (~1 GiB of X)
+  // Batches of whole individuals alternate between the two halves of the staging workspaces: X and B of batch i+1 go up, and X / labels
+  // of batch i-1 come back, while batch i is re-phased (three streams; page-locked host memory — gnx_host_alloc — makes the overlap
+  // real, pageable memory is still correct).  A batch is a multiple of the CU count (one workgroup per individual) near 1 GiB of X.
+  const int64_t cu = std::max(ctx->n_cu, 1);
   int64_t nb = std::max<int64_t>(1, (((int64_t)1 << 30) / std::max<int64_t>(ldx, 1)) / 2);
+  if (nb >= cu) nb -= nb % cu;
   if (ctx->tune.host_batch > 0) nb = std::max<int64_t>(1, ctx->tune.host_batch / 2);
   nb = std::min(nb, n_ind);
-  if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)2 * nb * ldx + 64)) != GNX_OK) return rc;
-  if ((rc = ws_reserve(ctx, ctx->ws_b64, (size_t)2 * nb * WA * 8)) != GNX_OK) return rc;
-  if ((rc = ws_reserve(ctx, ctx->ws_lab, (size_t)2 * nb * W * 4 + (size_t)nb * 4)) != GNX_OK) return rc;
-  for (int64_t i0 = 0; i0 < n_ind; i0 += nb) {
-    const int64_t n = std::min(nb, n_ind - i0);
-    int8_t* dX = (int8_t*)ctx->ws_x.p;
-    double* dB = (double*)ctx->ws_b64.p;
-    int32_t* dY = (int32_t*)ctx->ws_lab.p;
+  const int nbuf = (ctx->tune.h2d_overlap != 0 && n_ind > nb) ? 2 : 1;
+  if (nbuf == 2 && (rc = pipe_init(ctx)) != GNX_OK) return rc;
+  const size_t x_b = (((size_t)2 * nb * ldx + 64) + 255) & ~(size_t)255, b_b = ((size_t)2 * nb * WA * 8 + 255) & ~(size_t)255;
+  const size_t y_b = ((size_t)2 * nb * W * 4 + (size_t)nb * 4 + 255) & ~(size_t)255;
+  if ((rc = ws_reserve(ctx, ctx->ws_x, x_b * nbuf)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_b64, b_b * nbuf)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_lab, y_b * nbuf)) != GNX_OK) return rc;
+  // what a batch grows on the compute stream must not move while a copy stream is busy: size it now, with one individual run through
+  // the smoother so that its own workspaces exist at full size too
+  if ((rc = gnofix_ws_reserve(m, nb, max_it, in_lds, nullptr)) != GNX_OK) return rc;
+  hipStream_t sc = ctx->stream, si = nbuf == 2 ? ctx->s_in : ctx->stream, so = nbuf == 2 ? ctx->s_out : ctx->stream;
+  const int64_t n_batches = (n_ind + nb - 1) / nb;
+  auto issue_h2d = [&](int64_t i) -> int {
+    const int b = (int)(i % nbuf);
+    const int64_t i0 = i * nb, n = std::min(nb, n_ind - i0);
+    if (nbuf == 2 && i >= 2) HIPCHK(ctx, hipStreamWaitEvent(si, ctx->ev_out[b], 0));  // batch i-2 has left this half
+    HIPCHK(ctx, hipMemcpyAsync((char*)ctx->ws_x.p + (size_t)b * x_b, X + 2 * i0 * ldx, (size_t)(2 * n - 1) * ldx + m->info.C,
+                               hipMemcpyHostToDevice, si));
+    HIPCHK(ctx, hipMemcpyAsync((char*)ctx->ws_b64.p + (size_t)b * b_b, B + (size_t)2 * i0 * WA, (size_t)2 * n * WA * 8, hipMemcpyHostToDevice, si));
+    if (nbuf == 2) HIPCHK(ctx, hipEventRecord(ctx->ev_in[b], si));
+    return GNX_OK;
+  };
+  if ((rc = issue_h2d(0)) != GNX_OK) return rc;
+  for (int64_t i = 0; i < n_batches; ++i) {
+    const int b = (int)(i % nbuf);
+    const int64_t i0 = i * nb, n = std::min(nb, n_ind - i0);
+    int8_t* dX = (int8_t*)((char*)ctx->ws_x.p + (size_t)b * x_b);
+    double* dB = (double*)((char*)ctx->ws_b64.p + (size_t)b * b_b);
+    int32_t* dY = (int32_t*)((char*)ctx->ws_lab.p + (size_t)b * y_b);
     int32_t* dNs = dY + (size_t)2 * nb * W;
-    HIPCHK(ctx, hipMemcpyAsync(dX, X + 2 * i0 * ldx, (size_t)(2 * n - 1) * ldx + m->info.C, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(dB, B + (size_t)2 * i0 * WA, (size_t)2 * n * WA * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nbuf == 2) HIPCHK(ctx, hipStreamWaitEvent(sc, ctx->ev_in[b], 0));
     if ((rc = gnofix_run_dev(m, dX, ldx, dB, n, max_it, dY, dNs, in_lds)) != GNX_OK) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(X + 2 * i0 * ldx, dX, (size_t)(2 * n - 1) * ldx + m->info.C, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(Y + (size_t)2 * i0 * W, dY, (size_t)2 * n * W * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (n_switches) HIPCHK(ctx, hipMemcpyAsync(n_switches + i0, dNs, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (nbuf == 2) HIPCHK(ctx, hipEventRecord(ctx->ev_done[b], sc));
+    // (two halves: the next batch goes up before this one's results are awaited; one half: X is both input and output of it)
+    if (nbuf == 2 && i + 1 < n_batches && (rc = issue_h2d(i + 1)) != GNX_OK) return rc;
+    if (nbuf == 2) HIPCHK(ctx, hipStreamWaitEvent(so, ctx->ev_done[b], 0));
+    HIPCHK(ctx, hipMemcpyAsync(X + 2 * i0 * ldx, dX, (size_t)(2 * n - 1) * ldx + m->info.C, hipMemcpyDeviceToHost, so));
+    HIPCHK(ctx, hipMemcpyAsync(Y + (size_t)2 * i0 * W, dY, (size_t)2 * n * W * 4, hipMemcpyDeviceToHost, so));
+    if (n_switches) HIPCHK(ctx, hipMemcpyAsync(n_switches + i0, dNs, (size_t)n * 4, hipMemcpyDeviceToHost, so));
+    if (nbuf == 2) HIPCHK(ctx, hipEventRecord(ctx->ev_out[b], so));
+    else {
+      HIPCHK(ctx, hipStreamSynchronize(sc));
+      if (i + 1 < n_batches && (rc = issue_h2d(i + 1)) != GNX_OK) return rc;
+    }
   }
+  if (nbuf == 2) {
+    HIPCHK(ctx, hipStreamSynchronize(so));
+    HIPCHK(ctx, hipStreamSynchronize(si));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(sc));
   return GNX_OK;
 }
 

@@ -411,12 +411,26 @@ class DeviceModel:
                                                    out.ctypes.data))
         return out
 
-    def gnofix(self, X, B, max_it=50):
-        X = np.ascontiguousarray(X, dtype=np.int8).copy()
+    def gnofix(self, X, B, max_it=50, inplace=False, out=None):
+        """Re-phase individuals (rows 2i, 2i+1 of X and B).  Returns (X re-phased, labels i32 (2n, W), n_switches i32 (n,)).
+        `inplace=True` re-phases the caller's C-contiguous int8 X itself (what the C ABI does; no host copy of X — keep X, B
+        and `out=(Y, nsw)` in `ctx.pinned_empty` arrays and batches overlap on three streams); the default works on a copy."""
+        if inplace:
+            if not (isinstance(X, np.ndarray) and X.dtype == np.int8 and X.flags.c_contiguous and X.flags.writeable):
+                raise ValueError("gnofix(inplace=True) needs a writeable C-contiguous int8 array")
+        else:
+            X = np.array(X, dtype=np.int8, order="C", copy=True)
         B = np.ascontiguousarray(B, dtype=np.float64)
         n_ind = X.shape[0] // 2
-        Y = np.empty((2 * n_ind, self.W), np.int32)
-        nsw = np.empty((n_ind,), np.int32)
+        if out is not None:
+            Y, nsw = out
+            if Y.shape != (2 * n_ind, self.W) or Y.dtype != np.int32 or not Y.flags.c_contiguous:
+                raise ValueError("gnofix: out[0] must be C-contiguous int32 of shape (2n, W)")
+            if nsw.shape != (n_ind,) or nsw.dtype != np.int32 or not nsw.flags.c_contiguous:
+                raise ValueError("gnofix: out[1] must be C-contiguous int32 of shape (n,)")
+        else:
+            Y = np.empty((2 * n_ind, self.W), np.int32)
+            nsw = np.empty((n_ind,), np.int32)
         self.ctx.check(self.lib.gnx_gnofix(self.h, X.ctypes.data, X.shape[1], B.ctypes.data, n_ind, int(max_it),
                                            Y.ctypes.data, nsw.ctypes.data))
         return X, Y, nsw

@@ -87,6 +87,41 @@ def test_host_pipeline_overlapped_equals_serial(ga, monkeypatch):
     assert np.array_equal(p, p_ref) and np.array_equal(l, l_ref)
 
 
+def test_gnofix_host_pipeline_equals_one_batch(ga, monkeypatch):
+    """gnx_gnofix over several overlapped batches (both staging halves reused, pinned and pageable arrays, in place and on a
+    copy) == one batch"""
+    from gnomix_amd import synth, _lib
+    W, A, S, M = 70, 5, 11, 16
+    C = W * M + 5
+    d = ga.GnxModelData(C=C, M=M, A=A, S=S, context=0, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(3, A, S * A, seed=5, thr_lo=0.0, thr_hi=0.5, leaf_scale=1.0).items():
+        setattr(d, k, v)
+    rng = np.random.RandomState(12)
+    n_ind = 23
+    X = rng.randint(0, 2, size=(2 * n_ind, C)).astype(np.int8)
+    B = rng.dirichlet(np.ones(A) * 0.3, size=(2 * n_ind, W))
+    X_ref, Y_ref, ns_ref = ga.DeviceModel(d).gnofix(X, B, max_it=6)
+    assert int(ns_ref.sum()) > 0 and not np.array_equal(X_ref, X)
+    monkeypatch.setenv("GNX_HOST_BATCH", "10")            # 5 individuals per batch: 5 batches, the last one partial
+    ctx = _lib.Context(0)
+    dev = ga.DeviceModel(d, ctx=ctx)
+    Xo, Y, ns = dev.gnofix(X, B, max_it=6)
+    assert np.array_equal(Xo, X_ref) and np.array_equal(Y, Y_ref) and np.array_equal(ns, ns_ref)
+    Xp = ctx.pinned_empty(X.shape, np.int8); Xp[...] = X
+    Bp = ctx.pinned_empty(B.shape, np.float64); Bp[...] = B
+    Yp = ctx.pinned_empty(Y_ref.shape, np.int32); nsp = ctx.pinned_empty(ns_ref.shape, np.int32)
+    Xo, Y, ns = dev.gnofix(Xp, Bp, max_it=6, inplace=True, out=(Yp, nsp))
+    assert Xo is Xp and Y is Yp and ns is nsp
+    assert np.array_equal(Xp, X_ref) and np.array_equal(Yp, Y_ref) and np.array_equal(nsp, ns_ref)
+    with pytest.raises(ValueError):
+        dev.gnofix(X[:, ::-1], B, inplace=True)
+    with pytest.raises(ValueError):
+        dev.gnofix(X, B, out=(Yp[:-2], nsp))
+    monkeypatch.setenv("GNX_H2D_OVERLAP", "0")
+    Xo, Y, ns = ga.DeviceModel(d, ctx=_lib.Context(0)).gnofix(X, B, max_it=6)
+    assert np.array_equal(Xo, X_ref) and np.array_equal(Y, Y_ref) and np.array_equal(ns, ns_ref)
+
+
 def test_infer_packed_rejects_bad_arguments(ga):
     from gnomix_amd import synth
     d = synth.synthetic_model(C=1037, M=100, A=3, S=5, n_rounds=2)
