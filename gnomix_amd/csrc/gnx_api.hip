@@ -765,6 +765,7 @@ static void read_tune(gnx_tune& t) {
   t.sm_nw = geti("GNX_SM_NW", 0);
   t.sm_pair = geti("GNX_SM_PAIR", 1);
   if (const char* e = std::getenv("GNX_SM_TUNE")) std::sscanf(e, "%d,%d", &t.smf_rpl, &t.smf_nw);
+  if (const char* e = std::getenv("GNX_CRF_IMPL")) t.crf_impl = !std::strcmp(e, "scan") ? 1 : !std::strcmp(e, "row") ? 2 : !std::strcmp(e, "lanes") ? 3 : 0;
   t.forest_threads = geti("GNX_FOREST_T", 0);
   t.forest_wrun = geti("GNX_FOREST_WRUN", 0);
   t.forest_halves = geti("GNX_FOREST_H", 0);
@@ -1079,7 +1080,7 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     // psi and the parked alphas live in context scratch with a padded tail (the scan's chunked loads may overrun the last row)
     if ((rc = ws_reserve(ctx, ctx->ws_misc, n * sizeof(double) + 4096)) != GNX_OK) return rc;
     double* alpha = (double*)ctx->ws_misc.p;
-    if ((rc = ws_reserve(ctx, ctx->ws_scale, (size_t)N * m->info.W * sizeof(double))) != GNX_OK) return rc;
+    if ((rc = ws_reserve(ctx, ctx->ws_scale, (size_t)2 * N * m->info.W * sizeof(double))) != GNX_OK) return rc;  // (c_t, 1/c_t) pairs
     if ((rc = ws_reserve(ctx, ctx->ws_psi, n * sizeof(double) + 4096)) != GNX_OK) return rc;
     SmoothCRFLaunch L{};
     L.psi = (double*)ctx->ws_psi.p;
@@ -1088,7 +1089,7 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     L.alpha = alpha; L.scale = (double*)ctx->ws_scale.p;
     L.proba64 = d_p64; L.proba32 = d_p32; L.labels = d_lab;
     ProfScope ps(ctx, GNX_K_SMOOTH_CRF);
-    HIPCHK(ctx, gnx_launch_smooth_crf(L, ctx->stream));
+    HIPCHK(ctx, gnx_launch_smooth_crf(L, ctx->tune, ctx->stream));
     return GNX_OK;
   }
   if (m->info.smooth_kind == GNX_SMOOTH_CNN) {

@@ -34,6 +34,7 @@ struct gnx_tune {
   int sm_nw = 0;                        // GNX_SM_NW: waves per block of the rank smoother
   int sm_pair = 1;                      // GNX_SM_PAIR=0: one tree at a time per lane in the rank smoother (default: two)
   int smf_rpl = 0, smf_nw = 0;          // GNX_SM_TUNE="rpl,nw": float smoother
+  int crf_impl = 0;                     // GNX_CRF_IMPL=scan|row|lanes (default: row for up to 16 labels, lanes above)
   int forest_threads = 0;               // GNX_FOREST_T
   int forest_wrun = 0;                  // GNX_FOREST_WRUN: windows per block of the forest bases
   int forest_halves = 0;                // GNX_FOREST_H=1: one wave group per tile (default: two for the boosted-tree base)
@@ -185,7 +186,7 @@ struct SmoothCRFLaunch {
   const double* etrans;   // device (A, A) exp(tau)[y'][y]
   double* psi;            // (N, W, A) scratch: exp(theta'B) per window and label, computed once for both directions
   double* alpha;          // (N, W, A) scratch for the scaled forward variables (may alias proba64)
-  double* scale;          // (N, W) scratch
+  double* scale;          // (N, W, 2) scratch (the 9..16-label kernel parks (c_t, 1/c_t); the others use (N, W) of it)
   double* proba64;        // optional
   float* proba32;         // optional
   int32_t* labels;        // optional
@@ -346,7 +347,7 @@ hipError_t gnx_train_lr_run(const int8_t* dX, int64_t N, int64_t ldx, const int3
                             double Creg, double tol, int max_newton, int max_cg, double* h_coef, int64_t ldc, double* h_icpt,
                             gnx_train_info* info, hipStream_t st);
 hipError_t gnx_launch_unpack2(const uint8_t* P, int64_t N, int64_t ldp, int64_t C, int8_t* X, int64_t ldx, hipStream_t s);
-hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s);
+hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);
 hipError_t gnx_launch_base_forest(const ForestLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 size_t gnx_forest_lds_bytes(int A, int ring_words, int max_trees, int tree_bytes, int threads);

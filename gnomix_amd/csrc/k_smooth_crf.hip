@@ -357,6 +357,163 @@ __global__ __launch_bounds__(256) void k_smooth_crf_lanes(SmoothCRFLaunch L) {
 }
 
 
+// ---- 9..16 labels: one haplotype per 16-lane DPP row (lane = label) ---------------------------------------------------------------
+// A step of the lanes kernel above costs 60-85 LDS-pipe operations (every shuffle of a double is two ds_bpermute) on a strictly
+// dependent chain: ~9.6 k clocks per window at A = 12.  gfx950's double-precision ALU takes a DPP operand on v_fmac_f64 with
+// row_newbcast:i ("every lane of a 16-lane row reads lane i of its row"), so with one haplotype per row
+//     acc += alpha[i] * E[i][y]          is ONE instruction per label i (the coefficient E[i][y] sits in a register of lane y),
+// in label order, and a row sum is the same instruction against 1.0.  No LDS and no separate moves on the chain.  Differences to the
+// oracle's arithmetic, all inside the 1e-11 the tests allow on marginals (labels identical): the multiply-adds are fused, 1/sum is a
+// refined v_rcp_f64 instead of a division, and alpha*beta/c_t multiplies by the stored 1/c_t.
+template <int I>
+__device__ __forceinline__ void fmac_bcast(double& acc, double v, double c) {  // acc += (lane I of this row's v) * c
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(c), "n"(I));
+}
+template <int AT, int I = 0>
+__device__ __forceinline__ void row_dot(double& acc, double v, const double (&coef)[AT]) {
+  fmac_bcast<I>(acc, v, coef[I]);
+  if constexpr (I + 1 < AT) row_dot<AT, I + 1>(acc, v, coef);
+}
+template <int AT, int I = 0>
+__device__ __forceinline__ void row_sum(double& acc, double v) {
+  fmac_bcast<I>(acc, v, 1.0);
+  if constexpr (I + 1 < AT) row_sum<AT, I + 1>(acc, v);
+}
+// gfx9 wants two wait states between the VALU write of a VGPR and a DPP read of it; inline asm is opaque to the hazard recogniser
+__device__ __forceinline__ double dpp_ready(double v) {
+  asm volatile("s_nop 1" : "+v"(v));
+  return v;
+}
+template <int K>
+__device__ __forceinline__ double ror16(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x120 + K, 0xf, 0xf, false);  // row_ror:K
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x120 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int AT>  // labels padded to AT (12 or 16) inside the 16-lane row; padded coefficients are zero
+__global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
+  const int A = L.A, W = L.W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y = lane & 15;
+  const int64_t n = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 4 + (lane >> 4);
+  const bool label = y < A, active = label && n < L.N;
+  const int64_t nn = (n < L.N) ? n : 0;
+  const size_t row0 = (size_t)nn * W * A;
+  double* alpha = L.alpha + row0;
+  double* scale = L.scale + (size_t)nn * W * 2;  // [t] = (c_t, 1/c_t)
+
+  double Ef[AT], Eb[AT];  // forward: from label i to y; backward: from y to i
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+    const bool ok = label && i < A;
+    Ef[i] = ok ? L.etrans[i * A + y] : 0.0;
+    Eb[i] = ok ? L.etrans[y * A + i] : 0.0;
+  }
+
+  constexpr int PFD = 8;  // steps per software-pipeline stage (loads run one stage ahead: ~1 us of chain hides an HBM round trip)
+  auto clampt = [&](int t) { return t < 0 ? 0 : (t > W - 1 ? W - 1 : t); };
+  // loads are unconditional (a padding lane reads label 0's entry and drops it): a load under a divergent branch makes the compiler
+  // wait for ALL outstanding loads before the next use, which would put the prefetches of the next stage on the chain
+  const int yl = label ? y : 0;
+  auto loadP = [&](int t) -> double { const double v = L.psi[row0 + (size_t)t * A + yl]; return label ? v : 0.0; };
+
+  // ---- forward ----
+  double a_prev = 0.0;
+  double bn[PFD];
+#pragma unroll
+  for (int k = 0; k < PFD; ++k) bn[k] = loadP(clampt(k));
+  for (int t0 = 0; t0 < W; t0 += PFD) {
+    double bc[PFD];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) bc[k] = bn[k];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) bn[k] = loadP(clampt(t0 + PFD + k));  // unconditional, clamped: in flight during this stage
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) {
+      const int t = t0 + k;
+      if (t < W) {
+        double v = bc[k];
+        if (t > 0) {
+          double acc = 0.0;
+          row_dot<AT>(acc, dpp_ready(a_prev), Ef);
+          v = acc * bc[k];
+        }
+        double sum = 0.0;
+        row_sum<AT>(sum, dpp_ready(v));
+        const bool nz = sum != 0.0;
+        sum = nz ? sum : 1.0;
+        double sc = __builtin_amdgcn_rcp(sum);
+        sc = fma(fma(-sum, sc, 1.0), sc, sc);
+        sc = fma(fma(-sum, sc, 1.0), sc, sc);
+        sc = nz ? sc : 1.0;
+        a_prev = v * sc;
+        if (active) {
+          alpha[(size_t)t * A + y] = a_prev;
+          // every label lane writes the same pair and later reads back its OWN store
+          *reinterpret_cast<double2*>(scale + (size_t)t * 2) = make_double2(sc, sum);
+        }
+      }
+    }
+  }
+  __threadfence_block();
+
+  // ---- backward + marginals ----
+  auto loadS = [&](int t) -> double2 { return *reinterpret_cast<const double2*>(scale + (size_t)t * 2); };  // (rows beyond N: row 0's)
+  auto loadA = [&](int t) -> double { const double v = alpha[(size_t)t * A + yl]; return label ? v : 0.0; };
+  double beta = 0.0, psi_next = 0.0;
+  double an[PFD];
+  double2 sn[PFD];
+#pragma unroll
+  for (int k = 0; k < PFD; ++k) {
+    const int t = clampt(W - 1 - k);
+    bn[k] = loadP(t); an[k] = loadA(t); sn[k] = loadS(t);
+  }
+  for (int t0 = W - 1; t0 >= 0; t0 -= PFD) {
+    double bc[PFD], ac[PFD];
+    double2 scur[PFD];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) { bc[k] = bn[k]; ac[k] = an[k]; scur[k] = sn[k]; }
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) {
+      const int t = clampt(t0 - PFD - k);
+      bn[k] = loadP(t); an[k] = loadA(t); sn[k] = loadS(t);
+    }
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) {
+      const int t = t0 - k;
+      if (t >= 0) {
+        const double sct = scur[k].x;
+        // beta_t(y') = c_t * sum_y exp(tau)[y'][y] * psi_{t+1}(y) * beta_{t+1}(y)     (this lane: y' = y)
+        if (t < W - 1) {
+          double acc = 0.0;
+          row_dot<AT>(acc, dpp_ready(psi_next * beta), Eb);
+          beta = acc * sct;
+        } else {
+          beta = sct;
+        }
+        psi_next = bc[k];  // psi_t, consumed by step t-1
+        const double m = ac[k] * beta * scur[k].y;
+        // arg-max over the row, first maximum wins: the row maximum by rotations, then the lowest label that attains it
+        double mx = label ? m : -1.0;
+        mx = fmax(mx, ror16<8>(mx));
+        mx = fmax(mx, ror16<4>(mx));
+        mx = fmax(mx, ror16<2>(mx));
+        mx = fmax(mx, ror16<1>(mx));
+        const unsigned long long hit = __ballot(label && m == mx);
+        const int best = __builtin_ctz((unsigned)(hit >> (lane & 48)) & 0xffffu);
+        if (active) {
+          const size_t o = row0 + (size_t)t * A + y;
+          if (L.proba64) L.proba64[o] = m;          // may alias alpha: alpha[t] was read PFD steps ago at the latest
+          if (L.proba32) L.proba32[o] = (float)m;
+          if (L.labels && y == 0) L.labels[(size_t)nn * W + t] = best;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 template <int AT>
@@ -371,21 +528,48 @@ hipError_t launch_lanes_pre(const SmoothCRFLaunch& L, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, hipStream_t s) {
+static void launch_psi(const SmoothCRFLaunch& L, hipStream_t s) {
+  const dim3 grid((unsigned)((L.N * L.W + 255) / 256)), block(256);
+  switch (L.A) {
+    case 2: hipLaunchKernelGGL((k_crf_psi<2, true>), grid, block, 0, s, L); break;
+    case 3: hipLaunchKernelGGL((k_crf_psi<3, true>), grid, block, 0, s, L); break;
+    case 4: hipLaunchKernelGGL((k_crf_psi<4, true>), grid, block, 0, s, L); break;
+    case 5: hipLaunchKernelGGL((k_crf_psi<5, true>), grid, block, 0, s, L); break;
+    case 6: hipLaunchKernelGGL((k_crf_psi<6, true>), grid, block, 0, s, L); break;
+    case 7: hipLaunchKernelGGL((k_crf_psi<7, true>), grid, block, 0, s, L); break;
+    case 8: hipLaunchKernelGGL((k_crf_psi<8, true>), grid, block, 0, s, L); break;
+    case 12: hipLaunchKernelGGL((k_crf_psi<12, true>), grid, block, 0, s, L); break;
+    case 16: hipLaunchKernelGGL((k_crf_psi<16, true>), grid, block, 0, s, L); break;
+    default: hipLaunchKernelGGL((k_crf_psi<16, false>), grid, block, 0, s, L); break;  // 9..15 labels
+  }
+}
+
+hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
   if (!L.psi) return hipErrorInvalidValue;
-  // up to 8 labels: one lane per haplotype (k_crf_scan; chr22 / A = 7: 1.02 ms vs 1.26 ms).  More labels: the lane's A^2 products
-  // per step outgrow what one lane does between two windows (A = 12 measured 20 ms vs 16.6 ms) — A lanes per haplotype with the
-  // cross-label terms by shuffle, psi from the parallel pre-pass
-  switch (L.A) {
-    case 2: return launch<2>(L, s);
-    case 3: return launch<3>(L, s);
-    case 4: return launch<4>(L, s);
-    case 5: return launch<5>(L, s);
-    case 6: return launch<6>(L, s);
-    case 7: return launch<7>(L, s);
-    case 8: return launch<8>(L, s);
-    default: break;
+  // Up to 16 labels: one haplotype per 16-lane DPP row (k_smooth_crf_row16).  GNX_CRF_IMPL=scan keeps the round-2a kernel for up to 8
+  // labels (one lane per haplotype, LDS ring), =lanes the shuffle kernel (A lanes per haplotype), which also serves 17..32 labels.
+  const int impl = tune.crf_impl;  // 0 auto, 1 scan, 2 row, 3 lanes
+  if (L.A <= 16 && (impl == 0 || impl == 2 || (impl == 1 && L.A > 8))) {
+    launch_psi(L, s);
+    const int waves = 4;
+    const dim3 grid((unsigned)((L.N + 4 * waves - 1) / (4 * waves)));
+    if (L.A <= 8) hipLaunchKernelGGL(k_smooth_crf_row16<8>, grid, dim3(64 * waves), 0, s, L);
+    else if (L.A <= 12) hipLaunchKernelGGL(k_smooth_crf_row16<12>, grid, dim3(64 * waves), 0, s, L);
+    else hipLaunchKernelGGL(k_smooth_crf_row16<16>, grid, dim3(64 * waves), 0, s, L);
+    return hipGetLastError();
+  }
+  if (impl == 1) {
+    switch (L.A) {
+      case 2: return launch<2>(L, s);
+      case 3: return launch<3>(L, s);
+      case 4: return launch<4>(L, s);
+      case 5: return launch<5>(L, s);
+      case 6: return launch<6>(L, s);
+      case 7: return launch<7>(L, s);
+      case 8: return launch<8>(L, s);
+      default: break;
+    }
   }
   if (L.A <= 12) return launch_lanes_pre<12>(L, s);
   if (L.A <= 16) return launch_lanes_pre<16>(L, s);
