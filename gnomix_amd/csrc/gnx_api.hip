@@ -901,7 +901,14 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
       if (d->S <= 0 || d->S % 2 == 0) rc = fail(ctx, GNX_EINVAL, "S must be odd and positive (smooth.py:14)");
       else if (!d->cnn_weight || !d->cnn_bias) rc = fail(ctx, GNX_EINVAL, "cnn smoother: cnn_weight / cnn_bias is NULL");
       else {
-        std::vector<float> wv(d->cnn_weight, d->cnn_weight + (size_t)d->A * d->A * d->S), bv(d->cnn_bias, d->cnn_bias + d->A);
+        // torch's (out, in, k) -> [in][k][out padded to AP]: one tap's output weights are a contiguous, wave-uniform run that the
+        // kernel fetches with scalar loads; bias padded likewise
+        const int A = d->A, S = d->S, AP = gnx_cnn_ap(A);
+        std::vector<float> wv((size_t)A * S * AP, 0.f), bv((size_t)AP, 0.f);
+        for (int ao = 0; ao < A; ++ao)
+          for (int ai = 0; ai < A; ++ai)
+            for (int k = 0; k < S; ++k) wv[((size_t)ai * S + k) * AP + ao] = d->cnn_weight[((size_t)ao * A + ai) * S + k];
+        for (int ao = 0; ao < A; ++ao) bv[(size_t)ao] = d->cnn_bias[ao];
         if ((rc = dev_upload(m, wv, &m->cnn_weight)) == GNX_OK) rc = dev_upload(m, bv, &m->cnn_bias);
       }
       break;

@@ -197,9 +197,9 @@ struct SmoothCNNLaunch {
   const void* B;          // (N, W, A) float32 or float64 (cast to float32 as torch.tensor(B, dtype=torch.float) does)
   int32_t b_is_f64;
   int64_t N;
-  int32_t W, A, S, w_in_lds;
-  const float* weight;    // device (A_out, A_in, S)
-  const float* bias;      // device (A_out,)
+  int32_t W, A, S, reserved;
+  const float* weight;    // device [A_in][S][AP], AP = gnx_cnn_ap(A)
+  const float* bias;      // device (AP,)
   float* proba32;         // optional
   double* proba64;        // optional
   int32_t* labels;        // optional
@@ -318,8 +318,8 @@ struct gnx_model {
   // CRF
   const double* crf_state = nullptr;  // device (A,A)
   const double* crf_etrans = nullptr; // device (A,A) exp(trans)
-  const float* cnn_weight = nullptr;  // device (A, A, S)
-  const float* cnn_bias = nullptr;    // device (A,)
+  const float* cnn_weight = nullptr;  // device [A_in][S][AP] (transposed from torch's (out, in, k) at load), AP = gnx_cnn_ap(A)
+  const float* cnn_bias = nullptr;    // device (AP,)
   // calibrator
   const int32_t* calib_off = nullptr;
   const double* calib_x = nullptr;
@@ -348,6 +348,7 @@ hipError_t gnx_train_lr_run(const int8_t* dX, int64_t N, int64_t ldx, const int3
                             gnx_train_info* info, hipStream_t st);
 hipError_t gnx_launch_unpack2(const uint8_t* P, int64_t N, int64_t ldp, int64_t C, int8_t* X, int64_t ldx, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune, hipStream_t s);
+inline int gnx_cnn_ap(int A) { return A <= 8 ? 8 : A <= 16 ? 16 : 32; }  // output channels padded to the kernel's template width
 hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);
 hipError_t gnx_launch_base_forest(const ForestLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 size_t gnx_forest_lds_bytes(int A, int ring_words, int max_trees, int tree_bytes, int threads);

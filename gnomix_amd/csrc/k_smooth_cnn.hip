@@ -7,32 +7,27 @@
 // ignores it (any mode other than "circular" zero-pads), torch >= 1.5 refuses to construct the module.  Wherever the
 // reference's CNN runs it therefore ZERO-pads, and so does this kernel.
 //
-// One wave = 64 consecutive windows of one haplotype, lane = window; NWAVE haplotypes per block share the weights in LDS
-// ([a_in][s][a_out] so that a lane reads the A_out weights of one tap as a contiguous, wave-uniform run).  The padded
-// strip of the haplotype's base probabilities sits in LDS as [window][class] float32 (what torch.tensor(B, dtype=float)
-// holds).  Accumulation is float32, taps in (a_in, s) order; the result is compared with torch's own conv1d within the
-// north star's 1e-5 (the summation order of the backend's GEMM is not defined).
+// One wave = 64 consecutive windows of one haplotype, lane = window.  The padded strip of the haplotype's base probabilities
+// sits in LDS as [window][class] float32 (what torch.tensor(B, dtype=float) holds): the only per-lane operand of a tap.  A tap's
+// output weights are the same for every lane, so they come through the SCALAR cache straight into SGPRs (the loader stores the
+// weights as [a_in][tap][a_out padded]: one s_load per tap, no LDS, no VGPR), and the multiply-adds are v_pk_fma_f32 — two output
+// channels per instruction with the lane's probability splat over both halves.  Per tap: one ds_read_b32 and AP/2 packed FMAs
+// (round 1: three LDS reads and AP scalar FMAs).  Accumulation is float32, taps in (a_in, s) order, each channel's chain unchanged;
+// the result is compared with torch's own conv1d within the north star's 1e-5 (the summation order of the backend's GEMM is not defined).
 #include "gnx_internal.h"
 
 namespace {
 
 constexpr int WS = 64;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int AMAX>
+template <int AP>  // output channels padded to AP = gnx_cnn_ap(A)
 __global__ __launch_bounds__(256) void k_smooth_cnn(SmoothCNNLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int A = L.A, W = L.W, S = L.S, pad = (S - 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
   const int strip_w = WS + S - 1;
-  const bool wl = L.w_in_lds != 0;                               // weights that do not fit the LDS stay in global memory
-  const int AP = (A + 3) & ~3;                                   // weight rows padded to whole float4s (one tap = AP/4 LDS reads)
-  float* wgt = reinterpret_cast<float*>(lds);                   // [A_in][S][AP]
-  float* strip = wgt + (wl ? (size_t)A * S * AP : 0);            // [nwave][strip_w][A]
-  if (wl)
-    for (int e = tid; e < A * S * AP; e += blockDim.x) {
-      const int ai = e / (S * AP), r = e - ai * S * AP, s = r / AP, ao = r - s * AP;
-      wgt[e] = ao < A ? L.weight[((size_t)ao * A + ai) * S + s] : 0.f;  // torch layout (out, in, k)
-    }
+  float* strip = reinterpret_cast<float*>(lds);                  // [nwave][strip_w][A]
   const int64_t n = (int64_t)blockIdx.y * nwave + wave;
   const int w0 = blockIdx.x * WS;
   float* st = strip + (size_t)wave * strip_w * A;
@@ -49,29 +44,28 @@ __global__ __launch_bounds__(256) void k_smooth_cnn(SmoothCNNLaunch L) {
   }
   __syncthreads();
   const int w = w0 + lane;
-  float acc[AMAX];
+  const float* __restrict__ wt = L.weight;
+  f2 acc2[AP / 2];
 #pragma unroll
-  for (int y = 0; y < AMAX; ++y) acc[y] = (y < A) ? L.bias[y] : 0.f;
-  for (int ai = 0; ai < A; ++ai)
+  for (int q = 0; q < AP / 2; ++q) acc2[q] = f2{L.bias[2 * q], L.bias[2 * q + 1]};
+  for (int ai = 0; ai < A; ++ai) {
+    const float* xs = st + (size_t)lane * A + ai;
+    const float* wr = wt + (size_t)ai * S * AP;                  // wave-uniform
+#pragma unroll 5
     for (int s = 0; s < S; ++s) {
-      const float x = st[(size_t)(lane + s) * A + ai];
-      if (wl) {
-        const float4* wr = reinterpret_cast<const float4*>(wgt + ((size_t)ai * S + s) * AP);  // wave-uniform address
+      const float x = xs[s * A];
+      const f2 xx = f2{x, x};
 #pragma unroll
-        for (int q = 0; q < AMAX / 4; ++q)
-          if (4 * q < A) {
-            const float4 w4 = wr[q];
-            acc[4 * q + 0] = fmaf(x, w4.x, acc[4 * q + 0]);  // outputs past A accumulate zeros and are never read
-            acc[4 * q + 1] = fmaf(x, w4.y, acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(x, w4.z, acc[4 * q + 2]);
-            acc[4 * q + 3] = fmaf(x, w4.w, acc[4 * q + 3]);
-          }
-      } else {
-#pragma unroll
-        for (int y = 0; y < AMAX; ++y)
-          if (y < A) acc[y] = fmaf(x, L.weight[((size_t)y * A + ai) * S + s], acc[y]);
+      for (int q = 0; q < AP / 2; ++q) {
+        const f2 w2 = f2{wr[s * AP + 2 * q], wr[s * AP + 2 * q + 1]};
+        acc2[q] = __builtin_elementwise_fma(xx, w2, acc2[q]);     // outputs past A accumulate zeros and are never read
       }
     }
+  }
+  float acc[AP];
+#pragma unroll
+  for (int q = 0; q < AP / 2; ++q) { acc[2 * q] = acc2[q].x; acc[2 * q + 1] = acc2[q].y; }
+  constexpr int AMAX = AP;
   if (n >= L.N || w >= W) return;
   float mx = acc[0];
 #pragma unroll
@@ -97,14 +91,11 @@ __global__ __launch_bounds__(256) void k_smooth_cnn(SmoothCNNLaunch L) {
 
 }  // namespace
 
-hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L0, hipStream_t s) {
-  if (L0.N <= 0) return hipSuccess;
-  SmoothCNNLaunch L = L0;
+hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s) {
+  if (L.N <= 0) return hipSuccess;
   int nwave = 4;
-  const int AP = (L.A + 3) & ~3;
-  L.w_in_lds = ((size_t)L.A * L.S * AP * sizeof(float) <= (size_t)96 * 1024) ? 1 : 0;
-  auto lds_of = [&](int nw) { return ((L.w_in_lds ? (size_t)L.A * L.S * AP : 0) + (size_t)nw * (WS + L.S - 1) * L.A) * sizeof(float); };
-  while (nwave > 1 && lds_of(nwave) > (size_t)128 * 1024) nwave >>= 1;
+  auto lds_of = [&](int nw) { return (size_t)nw * (WS + L.S - 1) * L.A * sizeof(float); };
+  while (nwave > 1 && lds_of(nwave) > (size_t)64 * 1024) nwave >>= 1;
   const size_t lds = lds_of(nwave);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   const dim3 grid((unsigned)((L.W + WS - 1) / WS), (unsigned)((L.N + nwave - 1) / nwave));
