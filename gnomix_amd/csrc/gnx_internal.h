@@ -35,6 +35,7 @@ struct gnx_tune {
   int sm_pair = 1;                      // GNX_SM_PAIR=0: one tree at a time per lane in the rank smoother (default: two)
   int smf_rpl = 0, smf_nw = 0;          // GNX_SM_TUNE="rpl,nw": float smoother
   int crf_impl = 0;                     // GNX_CRF_IMPL=scan|row|lanes (default: row for up to 16 labels, lanes above)
+  int crf_flags = 0;                    // GNX_CRF_FLAGS bit 0: row kernel computes psi itself instead of reading the pre-pass's (slower)
   int forest_threads = 0;               // GNX_FOREST_T
   int forest_wrun = 0;                  // GNX_FOREST_WRUN: windows per block of the forest bases
   int forest_halves = 0;                // GNX_FOREST_H=1: one wave group per tile (default: two for the boosted-tree base)

@@ -392,7 +392,10 @@ __device__ __forceinline__ double ror16(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int AT>  // labels padded to AT (12 or 16) inside the 16-lane row; padded coefficients are zero
+// FUSE (GNX_CRF_FLAGS=1, not the default): psi_t(y) = exp(sum_a theta[a][y] B[t][a]) computed here from the prefetched B row, off the
+// chain, in both directions — no psi pass and no psi buffer (a third less HBM traffic).  Measured: chr22 / A = 7 0.57 ms against
+// 0.09 + 0.38 ms, chr1 / A = 12 5.71 against 5.65 ms: two float64 exp per window cost the issue slots the saved bytes would buy.
+template <int AT, bool FUSE>  // labels padded to AT (8, 12 or 16) inside the 16-lane row; padded coefficients are zero
 __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
   const int A = L.A, W = L.W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -404,12 +407,13 @@ __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
   double* alpha = L.alpha + row0;
   double* scale = L.scale + (size_t)nn * W * 2;  // [t] = (c_t, 1/c_t)
 
-  double Ef[AT], Eb[AT];  // forward: from label i to y; backward: from y to i
+  double Ef[AT], Eb[AT], Th[FUSE ? AT : 1];  // forward: from label i to y; backward: from y to i; theta[i][y]
 #pragma unroll
   for (int i = 0; i < AT; ++i) {
     const bool ok = label && i < A;
     Ef[i] = ok ? L.etrans[i * A + y] : 0.0;
     Eb[i] = ok ? L.etrans[y * A + i] : 0.0;
+    if constexpr (FUSE) Th[i] = ok ? L.state[i * A + y] : 0.0;
   }
 
   constexpr int PFD = 8;  // steps per software-pipeline stage (loads run one stage ahead: ~1 us of chain hides an HBM round trip)
@@ -417,7 +421,22 @@ __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
   // loads are unconditional (a padding lane reads label 0's entry and drops it): a load under a divergent branch makes the compiler
   // wait for ALL outstanding loads before the next use, which would put the prefetches of the next stage on the chain
   const int yl = label ? y : 0;
-  auto loadP = [&](int t) -> double { const double v = L.psi[row0 + (size_t)t * A + yl]; return label ? v : 0.0; };
+  auto loadP = [&](int t) -> double {  // psi, or with FUSE the base probability it is computed from
+    const size_t idx = row0 + (size_t)t * A + yl;
+    double v;
+    if constexpr (FUSE) v = L.b_is_f64 ? reinterpret_cast<const double*>(L.B)[idx] : (double)reinterpret_cast<const float*>(L.B)[idx];
+    else v = L.psi[idx];
+    return label ? v : 0.0;
+  };
+  auto psi_of = [&](double b) -> double {
+    if constexpr (FUSE) {
+      double sdot = 0.0;
+      row_dot<AT>(sdot, dpp_ready(b), Th);
+      return label ? exp(sdot) : 0.0;
+    } else {
+      return b;
+    }
+  };
 
   // ---- forward ----
   double a_prev = 0.0;
@@ -434,11 +453,12 @@ __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
     for (int k = 0; k < PFD; ++k) {
       const int t = t0 + k;
       if (t < W) {
-        double v = bc[k];
+        const double psi = psi_of(bc[k]);
+        double v = psi;
         if (t > 0) {
           double acc = 0.0;
           row_dot<AT>(acc, dpp_ready(a_prev), Ef);
-          v = acc * bc[k];
+          v = acc * psi;
         }
         double sum = 0.0;
         row_sum<AT>(sum, dpp_ready(v));
@@ -493,7 +513,7 @@ __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
         } else {
           beta = sct;
         }
-        psi_next = bc[k];  // psi_t, consumed by step t-1
+        psi_next = psi_of(bc[k]);  // psi_t, consumed by step t-1
         const double m = ac[k] * beta * scur[k].y;
         // arg-max over the row, first maximum wins: the row maximum by rotations, then the lowest label that attains it
         double mx = label ? m : -1.0;
@@ -551,12 +571,18 @@ hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune,
   // labels (one lane per haplotype, LDS ring), =lanes the shuffle kernel (A lanes per haplotype), which also serves 17..32 labels.
   const int impl = tune.crf_impl;  // 0 auto, 1 scan, 2 row, 3 lanes
   if (L.A <= 16 && (impl == 0 || impl == 2 || (impl == 1 && L.A > 8))) {
-    launch_psi(L, s);
     const int waves = 4;
     const dim3 grid((unsigned)((L.N + 4 * waves - 1) / (4 * waves)));
-    if (L.A <= 8) hipLaunchKernelGGL(k_smooth_crf_row16<8>, grid, dim3(64 * waves), 0, s, L);
-    else if (L.A <= 12) hipLaunchKernelGGL(k_smooth_crf_row16<12>, grid, dim3(64 * waves), 0, s, L);
-    else hipLaunchKernelGGL(k_smooth_crf_row16<16>, grid, dim3(64 * waves), 0, s, L);
+    if (!(tune.crf_flags & 1)) {  // default: psi from the separate pass (GNX_CRF_FLAGS=1 fuses it: measured slower, see below)
+      launch_psi(L, s);
+      if (L.A <= 8) hipLaunchKernelGGL((k_smooth_crf_row16<8, false>), grid, dim3(64 * waves), 0, s, L);
+      else if (L.A <= 12) hipLaunchKernelGGL((k_smooth_crf_row16<12, false>), grid, dim3(64 * waves), 0, s, L);
+      else hipLaunchKernelGGL((k_smooth_crf_row16<16, false>), grid, dim3(64 * waves), 0, s, L);
+    } else {
+      if (L.A <= 8) hipLaunchKernelGGL((k_smooth_crf_row16<8, true>), grid, dim3(64 * waves), 0, s, L);
+      else if (L.A <= 12) hipLaunchKernelGGL((k_smooth_crf_row16<12, true>), grid, dim3(64 * waves), 0, s, L);
+      else hipLaunchKernelGGL((k_smooth_crf_row16<16, true>), grid, dim3(64 * waves), 0, s, L);
+    }
     return hipGetLastError();
   }
   if (impl == 1) {
