@@ -267,7 +267,7 @@ def test_full_size_properties_chr22(ga, oracle):
 
 
 # ---------------------------------------------------------------- crf smoother ----------------------
-@pytest.mark.parametrize("impl", ["", "scan", "lanes"])   # default = one haplotype per DPP row up to 16 labels
+@pytest.mark.parametrize("impl", ["", "scan", "lanes", "fused"])   # default = one haplotype per DPP row up to 16 labels
 @pytest.mark.parametrize("N,W,A", [(5, 40, 7), (70, 370, 7), (33, 150, 12), (9, 97, 2), (1, 30, 3), (40, 64, 16), (21, 83, 9), (6, 51, 20)])
 def test_crf_vs_oracle(ga, oracle, monkeypatch, N, W, A, impl):
     from gnomix_amd import _lib
@@ -277,7 +277,10 @@ def test_crf_vs_oracle(ga, oracle, monkeypatch, N, W, A, impl):
     trans = rng.standard_normal((A, A)) * 0.5 + 3 * np.eye(A)
     d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=75, context=5, smooth_kind="crf", crf_state=state, crf_trans=trans)
     if impl:
-        monkeypatch.setenv("GNX_CRF_IMPL", impl)   # read once, at gnx_init
+        if impl == "fused":
+            monkeypatch.setenv("GNX_CRF_FLAGS", "1")   # the row kernel computes psi itself
+        else:
+            monkeypatch.setenv("GNX_CRF_IMPL", impl)   # read once, at gnx_init
         dev = ga.DeviceModel(d, ctx=_lib.Context(0))
     else:
         dev = ga.DeviceModel(d)
