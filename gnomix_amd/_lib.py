@@ -14,7 +14,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 7
+GNX_ABI_VERSION = 8
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
@@ -67,6 +67,12 @@ class TrainInfo(C.Structure):
                 ("worst_rel_gradient", C.c_double), ("objective_sum", C.c_double)]
 
 
+class GbtParams(C.Structure):
+    _fields_ = [("n_rounds", C.c_int32), ("max_depth", C.c_int32), ("max_bin", C.c_int32), ("reserved", C.c_int32),
+                ("eta", C.c_double), ("lam", C.c_double), ("gamma", C.c_double), ("min_child_weight", C.c_double),
+                ("base_score", C.c_double)]
+
+
 class ModelInfo(C.Structure):
     _fields_ = [("C", C.c_int64), ("M", C.c_int64), ("ctx", C.c_int64), ("W", C.c_int64), ("A", C.c_int32),
                 ("S", C.c_int32), ("base_kind", C.c_int32), ("smooth_kind", C.c_int32), ("n_trees", C.c_int32),
@@ -108,6 +114,8 @@ SYMBOLS = {
                                      C.POINTER(TrainInfo)]),
     "gnx_train_logistic_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _I64, _I64, _I64, C.c_int32, C.c_double, C.c_double, C.c_int32, _VP, _I64,
                                          _VP, C.POINTER(TrainInfo)]),
+    "gnx_train_gbt": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
+    "gnx_train_gbt_dev": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
     "gnx_profile_enable": (C.c_int, [_VP, _I]),
     "gnx_profile_reset": (C.c_int, [_VP]),
     "gnx_profile_get": (C.c_int, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -1589,6 +1589,54 @@ int gnx_train_logistic(gnx_ctx* ctx, const int8_t* X, int64_t N, int64_t ldx, co
                                 coef, ldc, intercept, info);
 }
 
+// ---- training the tree smoother ---------------------------------------------------------------------------------
+static int gbt_check(gnx_ctx* ctx, const void* B, const int32_t* y, int64_t N, int32_t W, int32_t A, int32_t S, const gnx_gbt_params* P,
+                     const void* o1, const void* o2, const void* o3, const void* o4, const void* o5, const void* o6, const void* o7) {
+  if (!ctx->usable) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
+  if (N <= 0 || !B || !y || !P || !o1 || !o2 || !o3 || !o4 || !o5 || !o6 || !o7) return fail(ctx, GNX_EINVAL, "train_gbt: bad B / y / params / outputs");
+  if (A < 2 || A > 32) return fail(ctx, GNX_EINVAL, "A (ancestries) must be in [2, 32]");
+  if (S <= 0 || S % 2 == 0) return fail(ctx, GNX_EINVAL, "S must be odd and positive (smooth.py:14)");
+  if (W < 2 * S) return fail(ctx, GNX_EINVAL, "Smoother size to large for given window size. ");  // src/Smooth/models.py:13
+  if (P->n_rounds < 1 || P->n_rounds > 100000 || P->max_depth < 1 || P->max_depth > 5 || P->max_bin < 2 || P->max_bin > 256)
+    return fail(ctx, GNX_EINVAL, "train_gbt: n_rounds >= 1, 1 <= max_depth <= 5, 2 <= max_bin <= 256");
+  if (!(P->eta > 0.0) || !(P->lambda >= 0.0) || !(P->gamma >= 0.0) || !(P->min_child_weight >= 0.0))
+    return fail(ctx, GNX_EINVAL, "train_gbt: eta > 0, lambda / gamma / min_child_weight >= 0");
+  if ((int64_t)N * W >= ((int64_t)1 << 31)) return fail(ctx, GNX_EINVAL, "train_gbt: N * W must stay below 2^31 rows");
+  return GNX_OK;
+}
+
+int gnx_train_gbt_dev(gnx_ctx* ctx, const void* dB, int32_t b_is_f64, const int32_t* dy, int64_t N, int32_t W, int32_t A, int32_t S,
+                      const gnx_gbt_params* P, int32_t* tree_off, int32_t* tree_class, int32_t* left, int32_t* right, int32_t* feat,
+                      float* cond, int64_t* n_nodes, double* loss) {
+  if (!ctx) return GNX_EINVAL;
+  int rc = gbt_check(ctx, dB, dy, N, W, A, S, P, tree_off, tree_class, left, right, feat, cond, n_nodes);
+  if (rc != GNX_OK) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, gnx_train_gbt_run(dB, b_is_f64, dy, N, W, A, S, *P, tree_off, tree_class, left, right, feat, cond, n_nodes, loss, ctx->n_cu,
+                                ctx->stream));
+  return GNX_OK;
+}
+
+int gnx_train_gbt(gnx_ctx* ctx, const void* B, int32_t b_is_f64, const int32_t* y, int64_t N, int32_t W, int32_t A, int32_t S,
+                  const gnx_gbt_params* P, int32_t* tree_off, int32_t* tree_class, int32_t* left, int32_t* right, int32_t* feat,
+                  float* cond, int64_t* n_nodes, double* loss) {
+  if (!ctx) return GNX_EINVAL;
+  int rc = gbt_check(ctx, B, y, N, W, A, S, P, tree_off, tree_class, left, right, feat, cond, n_nodes);
+  if (rc != GNX_OK) return rc;
+  for (int64_t i = 0; i < N * W; ++i)
+    if (y[i] < 0 || y[i] >= A) return fail(ctx, GNX_EINVAL, "train_gbt: label outside [0, A)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = (size_t)N * W * A * (b_is_f64 ? 8 : 4), ny = (size_t)N * W * 4;
+  gnx_devbuf& wsB = b_is_f64 ? ctx->ws_b64 : ctx->ws_b32;
+  if ((rc = ws_reserve(ctx, wsB, nb)) != GNX_OK) return rc;
+  if ((rc = ws_reserve(ctx, ctx->ws_lab, ny)) != GNX_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(wsB.p, B, nb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lab.p, y, ny, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, gnx_train_gbt_run(wsB.p, b_is_f64, (const int32_t*)ctx->ws_lab.p, N, W, A, S, *P, tree_off, tree_class, left, right, feat, cond,
+                                n_nodes, loss, ctx->n_cu, ctx->stream));
+  return GNX_OK;
+}
+
 // ---- profiling ---------------------------------------------------------------------------------------
 int gnx_profile_enable(gnx_ctx* ctx, int on) {
   if (!ctx) return GNX_EINVAL;

@@ -349,6 +349,9 @@ hipError_t gnx_train_lr_run(const int8_t* dX, int64_t N, int64_t ldx, const int3
                             gnx_train_info* info, hipStream_t st);
 hipError_t gnx_launch_unpack2(const uint8_t* P, int64_t N, int64_t ldp, int64_t C, int8_t* X, int64_t ldx, hipStream_t s);
 hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, int64_t N, int32_t W, int32_t A, int32_t S,
+                             const gnx_gbt_params& P, int32_t* tree_off, int32_t* tree_class, int32_t* left, int32_t* right,
+                             int32_t* feat, float* cond, int64_t* n_nodes_out, double* loss_out, int n_cu, hipStream_t s);
 inline int gnx_cnn_ap(int A) { return A <= 8 ? 8 : A <= 16 ? 16 : 32; }  // output channels padded to the kernel's template width
 hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);
 hipError_t gnx_launch_base_forest(const ForestLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);

@@ -50,6 +50,25 @@ class HipGnomix:
             self.smooth.model.dev = self.dev
         return self
 
+    def train_smoother(self, B, y, **kw):
+        """the smoother half of Gnomix.train (src/model.py:116-117): fit the tree smoother on the device, re-bind everything"""
+        self.smooth.train(B, y, **kw)
+        self.dev = self.smooth.dev
+        self.base.dev = self.dev
+        return self
+
+    def train(self, data, retrain_base=True, verbose=False, **smoother_kw):
+        """Gnomix.train (src/model.py:104-167) on the device: base on train1, smoother on the base's probabilities of train2,
+        base again on all the data.  data = ((X_t1, y_t1), (X_t2, y_t2), (X_v, y_v)) with X_v possibly None."""
+        (X_t1, y_t1), (X_t2, y_t2), (X_v, y_v) = data
+        self.train_base(X_t1, y_t1)
+        B_t2 = self.base.predict_proba(X_t2)
+        self.train_smoother(B_t2, y_t2, **smoother_kw)
+        if retrain_base:
+            parts = [(X_t1, y_t1), (X_t2, y_t2)] + ([(X_v, y_v)] if X_v is not None else [])
+            self.train_base(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+        return self
+
     def predict(self, X):
         """labels (N, W) — base + smoother fused on the device, B never leaves HBM (model.py:169-173)"""
         _, lab = self.dev.infer(X, want_proba=False, want_labels=True)

@@ -46,6 +46,24 @@ class HipSmoother:
         self._calibrate = on
         self.dev.set_calibrate(bool(on))
 
+    def train(self, B, y, **kw):
+        """Smoother.train (smooth.py:28-38) for the tree smoother: gradient boosting on the device with the reference's
+        XGBClassifier arguments (Smooth/models.py:14-20), then the device model is swapped for the freshly trained one.
+        B (N, W, A) base probabilities of the smoother's training haplotypes, y (N, W) labels."""
+        from .train import train_gbt_smoother
+        from .model import DeviceModel
+        y = np.asarray(y)
+        assert len(np.unique(y)) == self.A, "Smoother training data does not include all populations"   # smooth.py:30
+        if self.dev.data.smooth_kind not in (None, "xgb"):
+            raise NotImplementedError("on-device training is built for the tree smoother (XGB_Smoother)")
+        t = time()
+        self.train_loss = train_gbt_smoother(self.dev.data, B, y.reshape(np.asarray(B).shape[0], -1), ctx=self.dev.ctx, **kw)
+        self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)   # (a HipGnomix re-binds base and fused path: HipGnomix.train_smoother)
+        self.gnofix = True
+        self.model = _RowModel(self.dev)
+        self.time["train"] = time() - t
+        return self
+
     def predict_proba(self, B):
         """B (N, W, A) -> (N, W, A): float32 for the xgb smoother, float64 for crf (smooth.py:40-56)."""
         t = time()

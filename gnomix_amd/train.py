@@ -1,4 +1,9 @@
-"""Training the per-window logistic base on the device: the device side of `Base.train` for
+"""Training on the device.
+
+Tree smoother: `Smoother.train` of `XGB_Smoother` (reference src/Smooth/smooth.py:28-38, src/Smooth/models.py:14-20, called
+from Gnomix.train, src/model.py:117) — gnx_train_gbt, histogram gradient boosting with fixed-point sums (k_train_gbt.hip).
+
+Logistic base: the device side of `Base.train` for
 `LogisticRegressionBase` (reference src/Base/base.py:104-127, src/Base/models.py:12-21, called from Gnomix.train,
 src/model.py:113 and :155).  gnx_train_logistic minimises liblinear's L2-regularised logistic objective for all
 W windows x A one-vs-rest problems at once (k_train_lr.hip); this module is the ctypes call and the glue that turns the
@@ -48,3 +53,54 @@ def lr_objective(coef_row, intercept, Xw, ypm, C_reg=3.0):
     tests and for judging a fit against the reference's (the bias is a regularised feature: intercept_scaling = 1)"""
     z = Xw.astype(np.float64) @ coef_row + intercept
     return 0.5 * (float(coef_row @ coef_row) + float(intercept) ** 2) + C_reg * float(np.sum(np.logaddexp(0.0, -ypm * z)))
+
+
+def train_gbt_arrays(B, y, S, n_rounds=100, max_depth=4, learning_rate=0.1, reg_lambda=1.0, gamma=0.0, min_child_weight=1.0,
+                     max_bin=256, base_score=0.5, ctx=None, device=0):
+    """B (N, W, A) base probabilities of the smoother's training haplotypes (float32 / float64; a CUDA tensor stays on the
+    device), y (N, W) labels -> (dict of tree arrays as GnxModelData takes them, losses (n_rounds + 1,)).  Defaults are the
+    reference's XGBClassifier arguments (src/Smooth/models.py:14-20)."""
+    ctx = ctx or _lib.default_context(device)
+    on_dev = hasattr(B, "is_cuda") and B.is_cuda
+    if on_dev:
+        import torch
+        assert B.is_contiguous() and B.dtype in (torch.float32, torch.float64)
+        N, W, A = B.shape
+        is64 = B.dtype == torch.float64
+        y = y if (hasattr(y, "is_cuda") and y.is_cuda) else torch.as_tensor(np.ascontiguousarray(y, dtype=np.int32), device=B.device)
+        assert y.dtype == torch.int32 and y.is_contiguous() and tuple(y.shape) == (N, W)
+        b_ptr, y_ptr, fn = B.data_ptr(), y.data_ptr(), ctx.lib.gnx_train_gbt_dev
+        ctx.set_stream(torch.cuda.current_stream(ctx.device).cuda_stream)
+    else:
+        B = np.ascontiguousarray(B)
+        if B.dtype != np.float64:
+            B = np.ascontiguousarray(B, dtype=np.float32)
+        N, W, A = B.shape
+        is64 = B.dtype == np.float64
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        if y.shape != (N, W):
+            raise ValueError(f"y must be (N, W) = ({N}, {W}), got {y.shape}")
+        b_ptr, y_ptr, fn = B.ctypes.data, y.ctypes.data, ctx.lib.gnx_train_gbt
+    T = int(n_rounds) * int(A)
+    tree_off = np.zeros(T + 1, np.int32); tree_class = np.zeros(T, np.int32)
+    left = np.zeros(T * 63, np.int32); right = np.zeros(T * 63, np.int32); feat = np.zeros(T * 63, np.int32)
+    cond = np.zeros(T * 63, np.float32); loss = np.zeros(int(n_rounds) + 1, np.float64)
+    nn = C.c_int64(0)
+    P = _lib.GbtParams(int(n_rounds), int(max_depth), int(max_bin), 0, float(learning_rate), float(reg_lambda), float(gamma),
+                       float(min_child_weight), float(base_score))
+    ctx.check(fn(ctx.h, b_ptr, int(is64), y_ptr, int(N), int(W), int(A), int(S), C.byref(P), tree_off.ctypes.data, tree_class.ctypes.data,
+                 left.ctypes.data, right.ctypes.data, feat.ctypes.data, cond.ctypes.data, C.addressof(nn), loss.ctypes.data))
+    n = nn.value
+    trees = dict(tree_off=tree_off, left=left[:n].copy(), right=right[:n].copy(), feat=feat[:n].copy(), cond=cond[:n].copy(),
+                 tree_class=tree_class)
+    return trees, loss
+
+
+def train_gbt_smoother(data: GnxModelData, B, y, **kw) -> np.ndarray:
+    """fit the tree smoother of `data` in place (smooth_kind "xgb", tree arrays, base_score) -> losses per round"""
+    trees, loss = train_gbt_arrays(B, y, data.S, **kw)
+    data.smooth_kind = "xgb"
+    for k, v in trees.items():
+        setattr(data, k, v)
+    data.base_score = float(kw.get("base_score", 0.5))
+    return loss

@@ -13,6 +13,7 @@
  *   gnx_smooth_rows       <- smoother.model.predict_proba(rows)         src/Gnofix/gnofix.py:157
  *   gnx_gnofix            <- Gnomix.phase(X, B) -> gnofix() per indiv.  src/model.py:188-214, src/Gnofix/gnofix.py:58-208
  *   gnx_train_logistic    <- Base.train(X, y) of LogisticRegressionBase   src/Base/base.py:104-127, src/model.py:113,155
+ *   gnx_train_gbt         <- Smoother.train(B, y) of XGB_Smoother         src/Smooth/smooth.py:28-38, src/model.py:137
  *
  * Conventions
  *   - return 0 (GNX_OK) or a negative GNX_E* code; the message is kept per context (gnx_last_error).
@@ -43,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 7
+#define GNX_ABI_VERSION 8
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -287,6 +288,36 @@ int gnx_train_logistic(gnx_ctx* ctx, const int8_t* X, int64_t N, int64_t ldx, co
 int gnx_train_logistic_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ldx, const int32_t* dy, int64_t C, int64_t M,
                            int64_t ctx_snps, int32_t A, double C_reg, double tol, int32_t max_iter, double* coef, int64_t ldc,
                            double* intercept, gnx_train_info* info);
+
+/* ---- training the tree smoother: Smoother.train of XGB_Smoother (src/Smooth/smooth.py:28-38, src/Smooth/models.py:14-20:
+ *      XGBClassifier(n_estimators=100, max_depth=4, learning_rate=0.1, reg_lambda=1, objective='multi:softprob').fit(slide_window(B), y))
+ * Second-order gradient boosting of A regression trees per round on the softmax objective, in the histogram form (<= max_bin
+ * quantile bins per class column; gradient sums in fixed point, so the trees do not depend on scheduling and equal the CPU
+ * oracle's bit for bit).  xgboost itself is a third-party fitter outside the reference tree: this entry point reproduces the
+ * algorithm the call asks for, not xgboost's floating-point trajectory.
+ *   B (N, W, A) base probabilities (what Base.predict_proba returned for the smoother's training haplotypes), float32 or float64
+ *   y (N, W) int32 labels in [0, A);  W >= 2 S, S odd
+ *   outputs (HOST, caller-allocated): tree_off[T+1], tree_class[T], left / right / feat (int32) and cond (float32) with room for
+ *     63 T nodes, T = n_rounds * A — exactly the arrays gnx_model_desc takes (a leaf has left = right = -1 and its value in cond;
+ *     tree t belongs to class t % A); *n_nodes = nodes written; loss[n_rounds + 1] (optional) = mean log loss before each round
+ *     and after the last. */
+typedef struct gnx_gbt_params {
+  int32_t n_rounds;          /* 100  (n_estimators) */
+  int32_t max_depth;         /* 4, at most 5 */
+  int32_t max_bin;           /* 256, at most 256 */
+  int32_t reserved;
+  double eta;                /* 0.1  (learning_rate) */
+  double lambda;             /* 1.0  (reg_lambda) */
+  double gamma;              /* 0.0  (min_split_loss) */
+  double min_child_weight;   /* 1.0 */
+  double base_score;         /* 0.5 */
+} gnx_gbt_params;
+int gnx_train_gbt(gnx_ctx* ctx, const void* B, int32_t b_is_f64, const int32_t* y, int64_t N, int32_t W, int32_t A, int32_t S,
+                  const gnx_gbt_params* params, int32_t* tree_off, int32_t* tree_class, int32_t* left, int32_t* right,
+                  int32_t* feat, float* cond, int64_t* n_nodes, double* loss);
+int gnx_train_gbt_dev(gnx_ctx* ctx, const void* dB, int32_t b_is_f64, const int32_t* dy, int64_t N, int32_t W, int32_t A, int32_t S,
+                      const gnx_gbt_params* params, int32_t* tree_off, int32_t* tree_class, int32_t* left, int32_t* right,
+                      int32_t* feat, float* cond, int64_t* n_nodes, double* loss);
 
 /* per-kernel device time, measured with hipEvents on the context stream around every launch */
 int gnx_profile_enable(gnx_ctx* ctx, int on);

@@ -604,3 +604,229 @@ int gnxo_smooth_cnn(const double* B, int64_t N, int64_t W, int64_t A, int64_t S,
     }
   return GNXO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * f4  Training the tree smoother (src/Smooth/smooth.py:28-38 Smoother.train ->
+ *     src/Smooth/models.py:14-20 XGBClassifier(n_estimators=100, max_depth=4, learning_rate=0.1,
+ *     reg_lambda=1, reg_alpha=0, objective='multi:softprob', num_class=A).fit(slide_window(B), y))
+ *
+ *     xgboost itself is absent (third party, see a6), so there is no arithmetic to be bit-equal
+ *     to; what is restated here is the ALGORITHM the call asks for — second-order gradient
+ *     boosting of A one-vs-rest regression trees per round on the softmax objective
+ *     (g = p - 1[y=c], h = max(2p(1-p), 1e-16); split gain GL^2/(HL+l) + GR^2/(HR+l) - G^2/(H+l);
+ *     leaf -eta*G/(H+l); min_child_weight on H) — in the histogram form (tree_method="hist":
+ *     <= 256 quantile bins per feature) with every sum held in fixed point, so that the HIP
+ *     trainer (k_train_gbt.hip) and this port produce IDENTICAL trees, bit for bit.  The spec,
+ *     shared with the device code by construction and checked by tests/test_train_gbt.py:
+ *       - features of row (n,w): slide_window's f = s*A + a  ->  float32(B)[n, src(w+s), a]
+ *       - cuts of class column a: bucket(v) = clamp(int(v*65536), 0, 65535); the k-th cut
+ *         (k = 1..max_bin-1) is (u+1)/65536 for the first bucket u whose cumulative count reaches
+ *         k*N*W/max_bin; duplicates dropped; bin(v) = #{cuts <= v}; "bin <= j" <=> v < cut[j]
+ *       - p = softmax(F) through gnx_det_exp (plain IEEE operations in a fixed order), g and h
+ *         rounded to multiples of 2^-30 and summed as int64
+ *       - best split of a node: largest gain, ties to the lowest feature, then the lowest bin;
+ *         taken if gain > max(gamma, 1e-6) and both children have H >= min_child_weight
+ * ------------------------------------------------------------------------------------------ */
+static double gnx_det_exp(double x) { /* x <= 0 */
+  if (!(x > -745.0)) return 0.0;
+  const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  const double kf = rint(x * LOG2E);
+  const double r = (x - kf * LN2_HI) - kf * LN2_LO;
+  double p = 1.0 / 6227020800.0;
+  p = p * r + 1.0 / 479001600.0;
+  p = p * r + 1.0 / 39916800.0;
+  p = p * r + 1.0 / 3628800.0;
+  p = p * r + 1.0 / 362880.0;
+  p = p * r + 1.0 / 40320.0;
+  p = p * r + 1.0 / 5040.0;
+  p = p * r + 1.0 / 720.0;
+  p = p * r + 1.0 / 120.0;
+  p = p * r + 1.0 / 24.0;
+  p = p * r + 1.0 / 6.0;
+  p = p * r + 0.5;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  return ldexp(p, (int)kf);
+}
+
+#define GBT_FIX 1073741824.0 /* 2^30 */
+#define GBT_MAXNODES 63      /* heap positions of a tree of depth <= 5 */
+
+typedef struct {
+  int32_t n_rounds, max_depth, max_bin, reserved;
+  double eta, lambda, gamma, min_child_weight, base_score;
+} gnxo_gbt_params;
+
+/* Outputs (caller-allocated): tree_off[T+1], tree_class[T], and node arrays of capacity T*63: left, right, feat (int32),
+ * cond (float32: threshold of an internal node, value of a leaf).  T = n_rounds*A.  Returns the number of nodes or < 0.
+ * loss_out[r] (optional) = mean multi-class log loss BEFORE round r's trees (r = 0..n_rounds), from the same p. */
+int64_t gnxo_train_gbt(const void* B, int is_f64, const int32_t* y, int64_t N, int64_t W, int64_t A, int64_t S,
+                       const gnxo_gbt_params* P, int32_t* tree_off, int32_t* tree_class, int32_t* left, int32_t* right,
+                       int32_t* feat, float* cond, double* loss_out) {
+  const int64_t pad = (S + 1) / 2, Wp = W + 2 * pad, R = N * W, F = S * A;
+  const int D = P->max_depth, MB = P->max_bin;
+  if (N <= 0 || W < 2 * S || A < 2 || S < 1 || (S & 1) == 0 || D < 1 || D > 5 || MB < 2 || MB > 256 || P->n_rounds < 1) return GNXO_EINVAL;
+  float* Bf = (float*)malloc((size_t)R * A * sizeof(float));
+  uint8_t* Bq = (uint8_t*)malloc((size_t)N * Wp * A);
+  uint32_t* cnt = (uint32_t*)calloc((size_t)65536, sizeof(uint32_t));
+  float* cuts = (float*)malloc((size_t)A * 256 * sizeof(float));
+  int32_t* ncut = (int32_t*)calloc((size_t)A, sizeof(int32_t));
+  uint8_t* lut = (uint8_t*)malloc((size_t)65536);
+  float* Fm = (float*)malloc((size_t)R * A * sizeof(float));
+  int64_t* gq = (int64_t*)malloc((size_t)R * A * sizeof(int64_t));
+  int64_t* hq = (int64_t*)malloc((size_t)R * A * sizeof(int64_t));
+  uint8_t* pos = (uint8_t*)malloc((size_t)R);
+  int64_t* hist = (int64_t*)malloc((size_t)32 * F * 256 * 2 * sizeof(int64_t)); /* [node of level][f][bin][g,h] */
+  if (!Bf || !Bq || !cnt || !cuts || !ncut || !lut || !Fm || !gq || !hq || !pos || !hist) return GNXO_ENOMEM;
+  for (int64_t i = 0; i < R * A; ++i) Bf[i] = is_f64 ? (float)((const double*)B)[i] : ((const float*)B)[i];
+  /* cuts and quantised, reflect-padded strips */
+  for (int64_t a = 0; a < A; ++a) {
+    memset(cnt, 0, 65536 * sizeof(uint32_t));
+    for (int64_t i = 0; i < R; ++i) {
+      const float v = Bf[i * A + a];
+      int b = (v > 0.0f) ? (int)(v * 65536.0f) : 0;
+      if (v >= 1.0f) b = 65535; /* also keeps the float -> int conversion in range */
+      cnt[b]++;
+    }
+    int k = 1, nc = 0;
+    uint64_t cum = 0;
+    for (int u = 0; u < 65536 && k < MB; ++u) {
+      cum += cnt[u];
+      int hit = 0;
+      while (k < MB && cum >= (uint64_t)k * (uint64_t)R / (uint64_t)MB) { ++k; hit = 1; }
+      if (hit && u < 65535) cuts[a * 256 + nc++] = (float)(u + 1) / 65536.0f;
+    }
+    ncut[a] = nc;
+    int c = 0;
+    for (int u = 0; u < 65536; ++u) { /* bin = #{cuts <= v} = #{cuts*65536 <= bucket} */
+      while (c < nc && (int)(cuts[a * 256 + c] * 65536.0f) <= u) ++c;
+      lut[u] = (uint8_t)c;
+    }
+    for (int64_t n = 0; n < N; ++n)
+      for (int64_t j = 0; j < Wp; ++j) {
+        const float v = Bf[(n * W + slide_src(j, W, pad)) * A + a];
+        int b = (v > 0.0f) ? (int)(v * 65536.0f) : 0;
+        if (v >= 1.0f) b = 65535;
+        Bq[(n * Wp + j) * A + a] = lut[b];
+      }
+  }
+  for (int64_t i = 0; i < R * A; ++i) Fm[i] = (float)P->base_score;
+  int64_t nn = 0;
+  int32_t t = 0;
+  tree_off[0] = 0;
+  for (int r = 0; r <= P->n_rounds; ++r) {
+    /* gradients of the round (one softmax per row for all A trees) */
+    double loss = 0.0;
+    for (int64_t i = 0; i < R; ++i) {
+      float m = Fm[i * A];
+      for (int64_t c = 1; c < A; ++c) m = Fm[i * A + c] > m ? Fm[i * A + c] : m;
+      double e[64], sum = 0.0;
+      for (int64_t c = 0; c < A; ++c) { e[c] = gnx_det_exp((double)(Fm[i * A + c] - m)); sum += e[c]; }
+      for (int64_t c = 0; c < A; ++c) {
+        const double p = e[c] / sum;
+        const double g = p - (y[i] == c ? 1.0 : 0.0);
+        double h = 2.0 * p * (1.0 - p);
+        if (h < 1e-16) h = 1e-16;
+        gq[c * R + i] = (int64_t)llrint(g * GBT_FIX);
+        hq[c * R + i] = (int64_t)llrint(h * GBT_FIX);
+      }
+      const double py = e[y[i]] / sum;
+      loss -= log(py > 1e-300 ? py : 1e-300);
+    }
+    if (loss_out) loss_out[r] = loss / (double)R;
+    if (r == P->n_rounds) break;
+    for (int64_t c = 0; c < A; ++c, ++t) {
+      int64_t nG[GBT_MAXNODES], nH[GBT_MAXNODES];
+      int32_t nF[GBT_MAXNODES], nB[GBT_MAXNODES], st[GBT_MAXNODES]; /* st: 0 unused, 1 open, 2 internal, 3 leaf */
+      float nV[GBT_MAXNODES];
+      memset(st, 0, sizeof(st));
+      const int64_t* g = gq + c * R;
+      const int64_t* h = hq + c * R;
+      nG[0] = 0; nH[0] = 0;
+      for (int64_t i = 0; i < R; ++i) { nG[0] += g[i]; nH[0] += h[i]; pos[i] = 0; }
+      st[0] = 1;
+      for (int d = 0; d < D; ++d) {
+        const int base = (1 << d) - 1, nl = 1 << d;
+        int any = 0;
+        for (int k = 0; k < nl; ++k) any |= st[base + k] == 1;
+        if (!any) break;
+        memset(hist, 0, (size_t)nl * F * 256 * 2 * sizeof(int64_t));
+        for (int64_t n = 0; n < N; ++n)
+          for (int64_t w = 0; w < W; ++w) {
+            const int64_t i = n * W + w;
+            const int k = (int)pos[i] - base;
+            if (k < 0 || k >= nl || st[pos[i]] != 1) continue;
+            const uint8_t* q = Bq + (n * Wp + w) * A; /* feature f = s*A + a is q[f] */
+            int64_t* hk = hist + (size_t)k * F * 512;
+            for (int64_t f = 0; f < F; ++f) { hk[(f * 256 + q[f]) * 2] += g[i]; hk[(f * 256 + q[f]) * 2 + 1] += h[i]; }
+          }
+        for (int k = 0; k < nl; ++k) {
+          const int node = base + k;
+          if (st[node] != 1) continue;
+          const double Gd = (double)nG[node] / GBT_FIX, Hd = (double)nH[node] / GBT_FIX;
+          const double root_term = Gd * Gd / (Hd + P->lambda);
+          double best = P->gamma > 1e-6 ? P->gamma : 1e-6;
+          int bf = -1, bb = -1;
+          int64_t bGL = 0, bHL = 0;
+          for (int64_t f = 0; f < F; ++f) {
+            const int nc = ncut[f % A];
+            int64_t GL = 0, HL = 0;
+            const int64_t* hf = hist + ((size_t)k * F + f) * 512;
+            for (int j = 0; j < nc; ++j) { /* bins 0..j left, threshold cut[j] */
+              GL += hf[j * 2];
+              HL += hf[j * 2 + 1];
+              const double gl = (double)GL / GBT_FIX, hl = (double)HL / GBT_FIX;
+              const double gr = (double)(nG[node] - GL) / GBT_FIX, hr = (double)(nH[node] - HL) / GBT_FIX;
+              if (hl < P->min_child_weight || hr < P->min_child_weight) continue;
+              const double gain = (gl * gl / (hl + P->lambda) + gr * gr / (hr + P->lambda)) - root_term;
+              if (gain > best) { best = gain; bf = (int)f; bb = j; bGL = GL; bHL = HL; }
+            }
+          }
+          if (bf >= 0) {
+            st[node] = 2; nF[node] = bf; nB[node] = bb;
+            const int l = 2 * node + 1, rr = 2 * node + 2;
+            st[l] = 1; st[rr] = 1;
+            nG[l] = bGL; nH[l] = bHL; nG[rr] = nG[node] - bGL; nH[rr] = nH[node] - bHL;
+          } else {
+            st[node] = 3;
+          }
+        }
+        for (int64_t n = 0; n < N; ++n)
+          for (int64_t w = 0; w < W; ++w) {
+            const int64_t i = n * W + w;
+            const int node = pos[i];
+            if (node < base || st[node] != 2) continue;
+            const uint8_t q = Bq[(n * Wp + w) * A + nF[node]];
+            pos[i] = (uint8_t)(q <= nB[node] ? 2 * node + 1 : 2 * node + 2);
+          }
+      }
+      /* leaves, emitted tree (nodes in heap order), margins */
+      int32_t idx[GBT_MAXNODES];
+      int32_t cntn = 0;
+      for (int node = 0; node < GBT_MAXNODES; ++node) {
+        if (st[node] == 1) st[node] = 3;
+        if (st[node] == 3) {
+          const double Gd = (double)nG[node] / GBT_FIX, Hd = (double)nH[node] / GBT_FIX;
+          nV[node] = (float)(P->eta * (-Gd / (Hd + P->lambda)));
+        }
+        if (st[node] >= 2) idx[node] = cntn++;
+      }
+      for (int node = 0; node < GBT_MAXNODES; ++node) {
+        if (st[node] < 2) continue;
+        const int64_t o = nn + idx[node];
+        if (st[node] == 2) {
+          left[o] = idx[2 * node + 1]; right[o] = idx[2 * node + 2]; feat[o] = nF[node];
+          cond[o] = cuts[(nF[node] % A) * 256 + nB[node]];
+        } else {
+          left[o] = -1; right[o] = -1; feat[o] = 0; cond[o] = nV[node];
+        }
+      }
+      nn += cntn;
+      tree_off[t + 1] = (int32_t)nn;
+      tree_class[t] = (int32_t)c;
+      for (int64_t i = 0; i < R; ++i) Fm[i * A + c] += nV[pos[i]];
+    }
+  }
+  free(Bf); free(Bq); free(cnt); free(cuts); free(ncut); free(lut); free(Fm); free(gq); free(hq); free(pos); free(hist);
+  return nn;
+}

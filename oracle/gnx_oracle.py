@@ -463,3 +463,37 @@ def train_lr(X, y, M, ctx, A, C_reg=3.0):
                 coef[i, a, :Xw.shape[1]] = w[:-1]
                 icpt[i, a] = w[-1]
     return coef, icpt
+
+
+# ------------------------------------------------------------------------------------------------
+# f4 training the tree smoother (histogram gradient boosting, fixed-point sums: see gnx_oracle.c)
+# ------------------------------------------------------------------------------------------------
+class _CGbtParams(C.Structure):
+    _fields_ = [("n_rounds", C.c_int32), ("max_depth", C.c_int32), ("max_bin", C.c_int32), ("reserved", C.c_int32),
+                ("eta", C.c_double), ("lam", C.c_double), ("gamma", C.c_double), ("min_child_weight", C.c_double),
+                ("base_score", C.c_double)]
+
+
+def train_gbt(B, y, S, n_rounds=100, max_depth=4, eta=0.1, lam=1.0, gamma=0.0, min_child_weight=1.0, max_bin=256,
+              base_score=0.5):
+    """Smoother.train of XGB_Smoother (src/Smooth/smooth.py:28-38, src/Smooth/models.py:14-20) in the histogram form.
+    B (N, W, A) base probabilities, y (N, W) labels.  Returns (Trees, losses (n_rounds+1,))."""
+    B = np.ascontiguousarray(B)
+    is64 = B.dtype == np.float64
+    if not is64:
+        B = np.ascontiguousarray(B, dtype=np.float32)
+    N, W, A = B.shape
+    y = np.ascontiguousarray(y, dtype=np.int32).reshape(N, W)
+    T = n_rounds * A
+    tree_off = np.zeros(T + 1, np.int32); tree_class = np.zeros(T, np.int32)
+    left = np.zeros(T * 63, np.int32); right = np.zeros(T * 63, np.int32); feat = np.zeros(T * 63, np.int32)
+    cond = np.zeros(T * 63, np.float32); loss = np.zeros(n_rounds + 1, np.float64)
+    P = _CGbtParams(n_rounds, max_depth, max_bin, 0, eta, lam, gamma, min_child_weight, base_score)
+    fn = lib().gnxo_train_gbt
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(_CGbtParams)] + [C.c_void_p] * 7
+    nn = fn(_p(B), int(is64), _p(y), N, W, A, S, C.byref(P), _p(tree_off), _p(tree_class), _p(left), _p(right), _p(feat),
+            _p(cond), _p(loss))
+    if nn < 0:
+        raise ValueError(f"oracle train_gbt failed with code {nn}")
+    return Trees(tree_off, left[:nn].copy(), right[:nn].copy(), feat[:nn].copy(), cond[:nn].copy(), tree_class, A, base_score), loss
