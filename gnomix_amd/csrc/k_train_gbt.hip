@@ -134,35 +134,50 @@ __global__ __launch_bounds__(256) void k_gbt_grad(const float* Fm, const int32_t
 }
 
 // histograms of one level for all classes: block = (feature group, class, row slice); LDS [feature][node of level][bin] (g, h)
-__global__ __launch_bounds__(256) void k_gbt_hist(const uint8_t* Bq, const long long* gq, const long long* hq, const uint8_t* pos,
+constexpr int HIST_T = 1024;  // one block per CU (its histogram fills the LDS): 16 waves keep enough row loads in flight
+__global__ __launch_bounds__(HIST_T) void k_gbt_hist(const uint8_t* Bq, const long long* gq, const long long* hq, const uint8_t* pos,
                                                    const int32_t* st, long long* part, int d, int fpb, int n_slices, Geom G) {
   extern __shared__ __attribute__((aligned(16))) long long sh[];
   const int nl = 1 << d, base = nl - 1;
   const int f0 = blockIdx.x * fpb, c = blockIdx.y, slice = blockIdx.z;
   const int nf = min(fpb, G.F - f0);
-  for (int e = threadIdx.x; e < fpb * nl * 512; e += 256) sh[e] = 0;
+  // two planes, [feature][node][bin] of g and the same of h: 8-byte cells, so the 64 lanes of an atomic spread over 32 bank pairs
+  // (16-byte (g, h) cells would leave 16: a 4-way conflict at best)
+  const int cells = fpb * nl * 256;
+  unsigned long long* shg = reinterpret_cast<unsigned long long*>(sh);
+  unsigned long long* shh = shg + cells;
+  for (int e = threadIdx.x; e < 2 * cells; e += HIST_T) sh[e] = 0;
   __syncthreads();
   const int64_t r0 = G.R * slice / n_slices, r1 = G.R * (slice + 1) / n_slices;
   const uint8_t* posc = pos + (size_t)c * G.R;
   const int32_t* stc = st + c * MAXN;
-  for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+  for (int64_t i = r0 + threadIdx.x; i < r1; i += HIST_T) {
     const int node = posc[i], k = node - base;
     if (k < 0 || k >= nl || stc[node] != 1) continue;
     const int64_t n = i / G.W;
     const int w = (int)(i - n * G.W);
     const unsigned long long g = (unsigned long long)gq[(size_t)c * G.R + i], h = (unsigned long long)hq[(size_t)c * G.R + i];
     const uint8_t* q = Bq + ((size_t)n * G.Wp + w) * G.A + f0;
-    for (int fi = 0; fi < nf; ++fi) {
-      unsigned long long* cell = reinterpret_cast<unsigned long long*>(sh) + ((size_t)(fi * nl + k) * 256 + q[fi]) * 2;
-      atomicAdd(cell, g);
-      atomicAdd(cell + 1, h);
+    for (int f4 = 0; f4 < nf; f4 += 4) {  // four bins per (unaligned) dword load; bytes past the block's features are not used
+      uint32_t qv;
+      __builtin_memcpy(&qv, q + f4, 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (f4 + u < nf) {
+          const int cell = ((f4 + u) * nl + k) * 256 + (int)((qv >> (8 * u)) & 0xffu);
+          atomicAdd(shg + cell, g);
+          atomicAdd(shh + cell, h);
+        }
+      }
     }
   }
   __syncthreads();
   // part[slice][c][k][f][bin][2]
-  for (int e = threadIdx.x; e < nf * nl * 512; e += 256) {
-    const int fi = e / (nl * 512), r = e - fi * nl * 512, k = r / 512, b2 = r - k * 512;
-    part[((((size_t)slice * G.A + c) * nl + k) * G.F + (f0 + fi)) * 512 + b2] = sh[e];
+  for (int e = threadIdx.x; e < nf * nl * 256; e += HIST_T) {
+    const int fi = e / (nl * 256), r = e - fi * nl * 256, k = r / 256, b = r - k * 256;
+    long long* dst = part + ((((size_t)slice * G.A + c) * nl + k) * G.F + (f0 + fi)) * 512 + b * 2;
+    dst[0] = (long long)shg[e];
+    dst[1] = (long long)shh[e];
   }
 }
 
@@ -171,27 +186,27 @@ struct Best {
   int f, j;
   long long GL, HL;
 };
-__device__ __forceinline__ bool better(const Best& a, const Best& b) {  // a beats b: larger gain, then lower feature, then lower bin
-  if (a.gain != b.gain) return a.gain > b.gain;
-  if (a.f != b.f) return a.f < b.f;
-  return a.j < b.j;
-}
+constexpr int SPLIT_CHUNKS = 16;// the features of a node are searched by this many blocks; k_gbt_split_pick takes the best of them
 
-// best split of every open node of the level: grid (node of level, class); a wave per feature, lanes over the bins
-__global__ __launch_bounds__(256) void k_gbt_split(const long long* part, const int32_t* ncut, long long* nG, long long* nH, int32_t* nF,
-                                                    int32_t* nB, int32_t* st, int d, int n_slices, double lambda, double gamma, double mcw, Geom G) {
-  __shared__ Best wbest[4];
+// best split of every open node of the level: grid (node of level, class, feature chunk); a wave per feature, lanes over the bins
+__global__ __launch_bounds__(256) void k_gbt_split(const long long* part, const int32_t* ncut, const long long* nG, const long long* nH,
+                                                    const int32_t* st, Best* cand, int d, int n_slices, double lambda, double gamma, double mcw, Geom G) {
   const int nl = 1 << d, base = nl - 1;
   const int k = blockIdx.x, c = blockIdx.y, node = base + k;
   if (st[c * MAXN + node] != 1) return;
+  const int fchunk = (G.F + SPLIT_CHUNKS - 1) / SPLIT_CHUNKS, fbeg = blockIdx.z * fchunk, fend = min(G.F, fbeg + fchunk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long Gn = nG[c * MAXN + node], Hn = nH[c * MAXN + node];
   const double Gd = (double)Gn / FIX, Hd = (double)Hn / FIX;
   const double root_term = Gd * Gd / (Hd + lambda);
-  Best best;
-  best.gain = gamma > 1e-6 ? gamma : 1e-6;
-  best.f = -1; best.j = -1; best.GL = 0; best.HL = 0;
-  for (int f = wave; f < G.F; f += 4) {
+  // the running best as scalars (see k_gbt_split_pick: no struct selects); a candidate exists iff bf >= 0
+  double bg = gamma > 1e-6 ? gamma : 1e-6;
+  int bf = -1, bj = -1;
+  long long bGL = 0, bHL = 0;
+  auto beats = [](double g1, int f1, int j1, double g2, int f2, int j2) {  // larger gain, then lower feature, then lower bin
+    return g1 > g2 || (g1 == g2 && (f1 < f2 || (f1 == f2 && j1 < j2)));
+  };
+  for (int f = fbeg + wave; f < fend; f += 4) {
     const int nc = ncut[f % G.A];
     long long g4[4], h4[4];
 #pragma unroll
@@ -219,32 +234,59 @@ __global__ __launch_bounds__(256) void k_gbt_split(const long long* part, const 
       const double gr = (double)(Gn - GL) / FIX, hr = (double)(Hn - HL) / FIX;
       if (hl < mcw || hr < mcw) continue;
       const double gain = (gl * gl / (hl + lambda) + gr * gr / (hr + lambda)) - root_term;
-      Best cand{gain, f, j, GL, HL};
-      if (gain > best.gain || (best.f >= 0 && better(cand, best))) best = cand;
+      if (bf < 0 ? gain > bg : beats(gain, f, j, bg, bf, bj)) { bg = gain; bf = f; bj = j; bGL = GL; bHL = HL; }
     }
   }
-  // wave reduction (a candidate only counts if it exists: f >= 0)
+  // wave reduction, then the four waves through LDS
   for (int o = 32; o > 0; o >>= 1) {
-    Best ot;
-    ot.gain = __shfl_down(best.gain, o); ot.f = __shfl_down(best.f, o); ot.j = __shfl_down(best.j, o);
-    ot.GL = __shfl_down(best.GL, o); ot.HL = __shfl_down(best.HL, o);
-    if (ot.f >= 0 && (best.f < 0 || better(ot, best))) best = ot;
+    const double tg = __shfl_down(bg, o);
+    const int tf = __shfl_down(bf, o), tj = __shfl_down(bj, o);
+    const long long tGL = __shfl_down(bGL, o), tHL = __shfl_down(bHL, o);
+    if (tf >= 0 && (bf < 0 || beats(tg, tf, tj, bg, bf, bj))) { bg = tg; bf = tf; bj = tj; bGL = tGL; bHL = tHL; }
   }
-  if (lane == 0) wbest[wave] = best;
+  __shared__ double wg[4];
+  __shared__ int wf[4], wj[4];
+  __shared__ long long wGL[4], wHL[4];
+  if (lane == 0) { wg[wave] = bg; wf[wave] = bf; wj[wave] = bj; wGL[wave] = bGL; wHL[wave] = bHL; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    Best b = wbest[0];
-    for (int w = 1; w < 4; ++w)
-      if (wbest[w].f >= 0 && (b.f < 0 || better(wbest[w], b))) b = wbest[w];
-    const int o = c * MAXN;
-    if (b.f >= 0) {
-      st[o + node] = 2; nF[o + node] = b.f; nB[o + node] = b.j;
-      const int l = 2 * node + 1, r = 2 * node + 2;
-      st[o + l] = 1; st[o + r] = 1;
-      nG[o + l] = b.GL; nH[o + l] = b.HL; nG[o + r] = Gn - b.GL; nH[o + r] = Hn - b.HL;
-    } else {
-      st[o + node] = 3;
-    }
+    int bw = -1;
+    for (int w = 0; w < 4; ++w)
+      if (wf[w] >= 0 && (bw < 0 || beats(wg[w], wf[w], wj[w], wg[bw], wf[bw], wj[bw]))) bw = w;
+    Best* dst = cand + ((size_t)c * nl + k) * SPLIT_CHUNKS + blockIdx.z;
+    dst->gain = bw >= 0 ? wg[bw] : 0.0;
+    dst->f = bw >= 0 ? wf[bw] : -1;
+    dst->j = bw >= 0 ? wj[bw] : -1;
+    dst->GL = bw >= 0 ? wGL[bw] : 0;
+    dst->HL = bw >= 0 ? wHL[bw] : 0;
+  }
+}
+
+__global__ void k_gbt_split_pick(const Best* cand, long long* nG, long long* nH, int32_t* nF, int32_t* nB, int32_t* st, int d, int A) {
+  const int nl = 1 << d, base = nl - 1;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= A * nl) return;
+  const int c = e / nl, k = e - c * nl, node = base + k, o = c * MAXN;
+  if (st[o + node] != 1) return;
+  // (scalars and an index, not struct copies: hipcc 7.2 mixed the fields of two `Best` values in the select it built for `b = t`)
+  const Best* cq = cand + (size_t)e * SPLIT_CHUNKS;
+  int bi = -1, bf = -1, bj = -1;
+  double bg = 0.0;
+  for (int q = 0; q < SPLIT_CHUNKS; ++q) {
+    const double tg = cq[q].gain;
+    const int tf = cq[q].f, tj = cq[q].j;
+    if (tf < 0) continue;
+    if (bi < 0 || tg > bg || (tg == bg && (tf < bf || (tf == bf && tj < bj)))) { bi = q; bg = tg; bf = tf; bj = tj; }
+  }
+  if (bi >= 0) {
+    const long long GL = cq[bi].GL, HL = cq[bi].HL;
+    const long long Gn = nG[o + node], Hn = nH[o + node];
+    st[o + node] = 2; nF[o + node] = bf; nB[o + node] = bj;
+    const int l = 2 * node + 1, r = 2 * node + 2;
+    st[o + l] = 1; st[o + r] = 1;
+    nG[o + l] = GL; nH[o + l] = HL; nG[o + r] = Gn - GL; nH[o + r] = Hn - HL;
+  } else {
+    st[o + node] = 3;
   }
 }
 
@@ -302,7 +344,7 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
   G.N = N; G.W = W; G.A = A; G.S = S; G.pad = (S + 1) / 2; G.Wp = W + 2 * G.pad; G.F = S * A; G.R = N * (int64_t)W;
   const int D = P.max_depth, T = P.n_rounds * A;
   const int64_t RA = G.R * A;
-  DevBuf bBf, bCnt, bLut, bBq, bFm, bG, bH, bPos, bPart, bTab, bNcut, bLoss;
+  DevBuf bBf, bCnt, bLut, bBq, bFm, bG, bH, bPos, bPart, bTab, bNcut, bLoss, bCand;
   GBT_HIP(bBf.alloc((size_t)RA * 4));
   GBT_HIP(bCnt.alloc((size_t)A * 65536 * 4));
   GBT_HIP(bLut.alloc((size_t)A * 65536));
@@ -313,6 +355,7 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
   GBT_HIP(bPos.alloc((size_t)RA));
   GBT_HIP(bNcut.alloc((size_t)A * 4));
   GBT_HIP(bLoss.alloc((size_t)(P.n_rounds + 1) * 8));
+  GBT_HIP(bCand.alloc((size_t)A * 32 * SPLIT_CHUNKS * sizeof(Best)));
   // node tables of every tree: [T][63] x {G, H (int64), F, B, st (int32), V (float)}
   const size_t tab_n = (size_t)T * MAXN;
   GBT_HIP(bTab.alloc(tab_n * (8 + 8 + 4 + 4 + 4 + 4)));
@@ -402,10 +445,11 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
     else hipLaunchKernelGGL(k_gbt_grad<32>, dim3(gR), dim3(256), 0, s, bFm.as<float>(), dy, bG.as<long long>(), bH.as<long long>(), rG, rH, bLoss.as<long long>() + r, bPos.as<uint8_t>(), rS, G);
     for (int d = 0; d < D; ++d) {
       const int nl = 1 << d, fg = (G.F + fpb[d] - 1) / fpb[d];
-      hipLaunchKernelGGL(k_gbt_hist, dim3((unsigned)fg, (unsigned)A, (unsigned)nsl[d]), dim3(256), (size_t)fpb[d] * nl * 512 * 8, s, bBq.as<uint8_t>(),
+      hipLaunchKernelGGL(k_gbt_hist, dim3((unsigned)fg, (unsigned)A, (unsigned)nsl[d]), dim3(HIST_T), (size_t)fpb[d] * nl * 512 * 8, s, bBq.as<uint8_t>(),
                          bG.as<long long>(), bH.as<long long>(), bPos.as<uint8_t>(), rS, bPart.as<long long>(), d, fpb[d], nsl[d], G);
-      hipLaunchKernelGGL(k_gbt_split, dim3((unsigned)nl, (unsigned)A), dim3(256), 0, s, bPart.as<long long>(), bNcut.as<int32_t>(), rG, rH, rF, rB,
-                         rS, d, nsl[d], P.lambda, P.gamma, P.min_child_weight, G);
+      hipLaunchKernelGGL(k_gbt_split, dim3((unsigned)nl, (unsigned)A, SPLIT_CHUNKS), dim3(256), 0, s, bPart.as<long long>(), bNcut.as<int32_t>(), rG,
+                         rH, rS, bCand.as<Best>(), d, nsl[d], P.lambda, P.gamma, P.min_child_weight, G);
+      hipLaunchKernelGGL(k_gbt_split_pick, dim3((unsigned)((A * nl + 63) / 64)), dim3(64), 0, s, bCand.as<Best>(), rG, rH, rF, rB, rS, d, A);
       hipLaunchKernelGGL(k_gbt_partition, dim3(gR, (unsigned)A), dim3(256), 0, s, bBq.as<uint8_t>(), bPos.as<uint8_t>(), rS, rF, rB, d, G);
     }
     hipLaunchKernelGGL(k_gbt_close, dim3((unsigned)((A * MAXN + 255) / 256)), dim3(256), 0, s, rG, rH, rS, rV, A, P.eta, P.lambda);

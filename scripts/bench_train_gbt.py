@@ -35,6 +35,8 @@ t0 = time.perf_counter()
 trees_d, loss_d = train.train_gbt_arrays(Bd, yd, S)
 res["gpu_device_tensors"] = {"seconds": time.perf_counter() - t0, "identical_to_host_run": bool(all(np.array_equal(trees[k], trees_d[k]) for k in trees))}
 try:
+    if cpu_rounds <= 0:
+        raise ImportError
     from sklearn.ensemble import HistGradientBoostingClassifier
     sys.path.insert(0, ROOT)
     pad = (S + 1) // 2
