@@ -42,6 +42,7 @@ struct gnx_tune {
   int forest_flags = 0;                 // GNX_FOREST_FLAGS: ablation (1 = no walks, 2 = no register prefetch, 4 = no incremental staging)
   int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
   int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points
+  int lr_lds_pad = 0, sm_lds_pad = 0;   // GNX_LDS_PAD="lr,sm": extra dynamic LDS bytes (occupancy experiments: scripts/dev/overlap_probe.py)
   int debug = 0;                        // GNX_DEBUG
 };
 

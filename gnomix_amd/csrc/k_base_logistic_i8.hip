@@ -302,6 +302,7 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
     if (lds <= (size_t)160 * 1024 || wch == 4) break;
   }
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  lds = std::min(lds + (size_t)std::max(tune.lr_lds_pad, 0), (size_t)160 * 1024);
   const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
   P.wch = wch;
   P.n_htiles = (int)gx;

@@ -454,10 +454,11 @@ size_t lds_bytes(const SmoothXGBDev& d, int A) {
 }
 
 template <int RPL, int NWAVE>
-hipError_t launch(const SmoothXGBLaunch& L, bool pair, hipStream_t s) {
+hipError_t launch(const SmoothXGBLaunch& L, bool pair, int lds_pad, hipStream_t s) {
   const dim3 grid((unsigned)((L.W + RPL * WS - 1) / (RPL * WS)), (unsigned)((L.N + NWAVE - 1) / NWAVE));
-  const size_t lds = lds_bytes<NWAVE>(L.d, L.A);
+  size_t lds = lds_bytes<NWAVE>(L.d, L.A);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  lds = std::min(lds + (size_t)std::max(lds_pad, 0), (size_t)160 * 1024);
   if (L.d.D == 4 && pair && RPL <= 3) {
     if constexpr (RPL <= 3) {
       GNX_LDS_OPTIN(lds, k_smooth_xgb_rk<RPL, NWAVE, 4, true>);
@@ -488,7 +489,7 @@ hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tu
     if (L.N < 8) nw = L.N < 3 ? 2 : 4;
   }
 #define GNX_SM_CASE(R_) \
-  if (rpl == R_) return nw == 8 ? launch<R_, 8>(L, pair, s) : (nw == 4 ? launch<R_, 4>(L, pair, s) : launch<R_, 2>(L, pair, s));
+  if (rpl == R_) return nw == 8 ? launch<R_, 8>(L, pair, tune.sm_lds_pad, s) : (nw == 4 ? launch<R_, 4>(L, pair, tune.sm_lds_pad, s) : launch<R_, 2>(L, pair, tune.sm_lds_pad, s));
   GNX_SM_CASE(1) GNX_SM_CASE(2) GNX_SM_CASE(3) GNX_SM_CASE(4) GNX_SM_CASE(5) GNX_SM_CASE(6)
 #undef GNX_SM_CASE
   return hipErrorInvalidValue;
