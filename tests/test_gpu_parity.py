@@ -268,7 +268,7 @@ def test_full_size_properties_chr22(ga, oracle):
 
 # ---------------------------------------------------------------- crf smoother ----------------------
 @pytest.mark.parametrize("impl", ["", "scan", "lanes", "fused"])   # default = one haplotype per DPP row up to 16 labels
-@pytest.mark.parametrize("N,W,A", [(5, 40, 7), (70, 370, 7), (33, 150, 12), (9, 97, 2), (1, 30, 3), (40, 64, 16), (21, 83, 9), (6, 51, 20)])
+@pytest.mark.parametrize("N,W,A", [(5, 40, 7), (70, 370, 7), (33, 150, 12), (9, 97, 2), (1, 30, 3), (40, 64, 16), (21, 83, 9), (12, 70, 14), (6, 51, 20), (3, 5, 11), (130, 33, 4)])
 def test_crf_vs_oracle(ga, oracle, monkeypatch, N, W, A, impl):
     from gnomix_amd import _lib
     rng = np.random.RandomState(N + W)
