@@ -39,6 +39,17 @@ class HipBase:
         self.time["train"] = time() - t
         return self
 
+    def evaluate(self, X=None, y=None, B=None):
+        """(accuracy %, balanced accuracy %) rounded to two decimals, from SNPs or from base probabilities (base.py:214-228)"""
+        from .metrics import accuracy_pair
+        if X is not None:
+            y_pred = self.predict(X)
+        elif B is not None:
+            y_pred = np.argmax(B, axis=-1)
+        else:
+            raise ValueError("Need either SNP input or estimated probabilities to evaluate.")
+        return accuracy_pair(y, y_pred)
+
     def predict_proba(self, X):
         """X (N, C) int8-like -> B (N, W, A) float64, as Base.predict_proba (base.py:129-180)."""
         t = time()

@@ -57,16 +57,39 @@ class HipGnomix:
         self.base.dev = self.dev
         return self
 
-    def train(self, data, retrain_base=True, verbose=False, **smoother_kw):
+    def conf_matrix(self, y, y_pred):
+        from .metrics import confusion
+        return confusion(y, y_pred)
+
+    def train(self, data, retrain_base=True, evaluate=True, verbose=False, **smoother_kw):
         """Gnomix.train (src/model.py:104-167) on the device: base on train1, smoother on the base's probabilities of train2,
-        base again on all the data.  data = ((X_t1, y_t1), (X_t2, y_t2), (X_v, y_v)) with X_v possibly None."""
+        the reference's accuracies / confusion matrices, base again on all the data.
+        data = ((X_t1, y_t1), (X_t2, y_t2), (X_v, y_v)) with X_v possibly None."""
+        from time import time
+        t0 = time()
         (X_t1, y_t1), (X_t2, y_t2), (X_v, y_v) = data
         self.train_base(X_t1, y_t1)
         B_t2 = self.base.predict_proba(X_t2)
         self.train_smoother(B_t2, y_t2, **smoother_kw)
+        if evaluate:   # src/model.py:127-151
+            Acc, CM = {}, {}
+            B_t1 = self.base.predict_proba(X_t1)
+            y_t1_pred = self.smooth.predict(B_t1)
+            y_t2_pred = self.smooth.predict(B_t2)
+            Acc["base_train_acc"], Acc["base_train_acc_bal"] = self.base.evaluate(X=None, y=y_t1, B=B_t1)
+            Acc["smooth_train_acc"], Acc["smooth_train_acc_bal"] = self.smooth.evaluate(B=None, y=y_t2, y_pred=y_t2_pred)
+            CM["train"] = self.conf_matrix(y=y_t1, y_pred=y_t1_pred)
+            if X_v is not None:
+                B_v = self.base.predict_proba(X_v)
+                y_v_pred = self.smooth.predict(B_v)
+                Acc["base_val_acc"], Acc["base_val_acc_bal"] = self.base.evaluate(X=None, y=y_v, B=B_v)
+                Acc["smooth_val_acc"], Acc["smooth_val_acc_bal"] = self.smooth.evaluate(B=None, y=y_v, y_pred=y_v_pred)
+                CM["val"] = self.conf_matrix(y=y_v, y_pred=y_v_pred)
+            self.accuracies, self.Confusion_Matrices = Acc, CM
         if retrain_base:
             parts = [(X_t1, y_t1), (X_t2, y_t2)] + ([(X_v, y_v)] if X_v is not None else [])
             self.train_base(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+        self.time["training"] = round(time() - t0, 2)
         return self
 
     def predict(self, X):

@@ -64,6 +64,15 @@ class HipSmoother:
         self.time["train"] = time() - t
         return self
 
+    def evaluate(self, B=None, y=None, y_pred=None):
+        """(accuracy %, balanced accuracy %) rounded to two decimals (smooth.py:67-79)"""
+        from .metrics import accuracy_pair
+        if B is not None:
+            y_pred = self.predict(B)
+        elif y_pred is None:
+            raise ValueError("Need either Base probabilities or y predictions.")
+        return accuracy_pair(y, y_pred)
+
     def predict_proba(self, B):
         """B (N, W, A) -> (N, W, A): float32 for the xgb smoother, float64 for crf (smooth.py:40-56)."""
         t = time()

@@ -291,3 +291,21 @@ def test_pack_x_roundtrip_and_validation():
     X[5, 7] = -1
     assert lib.gnx_pack_x(X.ctypes.data, N, Cn, Cn, np.zeros((N, ldp), np.uint8).ctypes.data, ldp, 2) == gnomix_amd._lib.GNX_EINVAL
     assert lib.gnx_pack_x(X.ctypes.data, N, Cn, Cn, P.ctypes.data, 3, 1) == gnomix_amd._lib.GNX_EINVAL   # ldp too small
+
+
+def test_metrics_equal_sklearn():
+    """the scores and the confusion matrix of the reference's evaluate() / conf_matrix() (sklearn.metrics) in numpy"""
+    skm = pytest.importorskip("sklearn.metrics")
+    import warnings
+    from gnomix_amd.metrics import accuracy_pair, confusion
+    rng = np.random.RandomState(0)
+    for _ in range(10):
+        y = rng.randint(0, 5, 800)
+        yp = np.where(rng.rand(800) < 0.7, y, rng.randint(0, 6, 800))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = (round(skm.accuracy_score(y, yp) * 100, 2), round(skm.balanced_accuracy_score(y, yp) * 100, 2))
+            cm = skm.confusion_matrix(y, yp)
+        assert accuracy_pair(y.reshape(20, 40), yp.reshape(20, 40)) == ref
+        got, labels = confusion(y, yp)
+        assert np.array_equal(got, cm) and labels == sorted(set(y) | set(yp))
