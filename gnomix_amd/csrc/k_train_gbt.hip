@@ -11,8 +11,9 @@
 //     order are exact: the result does not depend on scheduling, and the CPU oracle (gnxo_train_gbt under oracle/)
 //     produces IDENTICAL trees — that is the parity test of this path (tests/test_train_gbt.py);
 //   * all A trees of a round grow together, level by level: one histogram launch (block = a group of features x one class
-//     x a slice of the rows, its 128 KB of LDS holding [feature][node][bin] sums), one split search (a wave per feature:
-//     prefix sums over the bins, gains in float64, ties to the lowest feature then the lowest bin), one partition pass;
+//     x a slice of the rows, its 128 KB of LDS holding [feature][node][bin] sums) that visits only the rows of the SMALLER child of
+//     every split (the sibling's histogram is parent - built, exact in int64), one split search (a wave per feature: prefix sums
+//     over the bins, gains in float64, ties to the lowest feature then the lowest bin), one partition pass;
 //   * the softmax goes through det_exp (plain IEEE operations in a fixed order) because the oracle must reproduce p exactly.
 // The trees come back in the layout gnx_model_desc takes (tree_off / left / right / feat / cond / tree_class), thresholds on
 // the 1/65536 grid, so the trained smoother runs on k_smooth_xgb_rk like any other.
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void k_gbt_grad(const float* Fm, const int32_t
 // histograms of one level for all classes: block = (feature group, class, row slice); LDS [feature][node of level][bin] (g, h)
 constexpr int HIST_T = 1024;  // one block per CU (its histogram fills the LDS): 16 waves keep enough row loads in flight
 __global__ __launch_bounds__(HIST_T) void k_gbt_hist(const uint8_t* Bq, const long long* gq, const long long* hq, const uint8_t* pos,
-                                                   const int32_t* st, long long* part, int d, int fpb, int n_slices, Geom G) {
+                                                   const int32_t* st, const int32_t* build, long long* part, int d, int fpb, int n_slices, Geom G) {
   extern __shared__ __attribute__((aligned(16))) long long sh[];
   const int nl = 1 << d, base = nl - 1;
   const int f0 = blockIdx.x * fpb, c = blockIdx.y, slice = blockIdx.z;
@@ -151,9 +152,10 @@ __global__ __launch_bounds__(HIST_T) void k_gbt_hist(const uint8_t* Bq, const lo
   const int64_t r0 = G.R * slice / n_slices, r1 = G.R * (slice + 1) / n_slices;
   const uint8_t* posc = pos + (size_t)c * G.R;
   const int32_t* stc = st + c * MAXN;
+  const int32_t* bldc = build + c * MAXN;
   for (int64_t i = r0 + threadIdx.x; i < r1; i += HIST_T) {
     const int node = posc[i], k = node - base;
-    if (k < 0 || k >= nl || stc[node] != 1) continue;
+    if (k < 0 || k >= nl || stc[node] != 1 || !bldc[node]) continue;  // (the sibling of a built node is derived: parent - built)
     const int64_t n = i / G.W;
     const int w = (int)(i - n * G.W);
     const unsigned long long g = (unsigned long long)gq[(size_t)c * G.R + i], h = (unsigned long long)hq[(size_t)c * G.R + i];
@@ -190,11 +192,14 @@ constexpr int SPLIT_CHUNKS = 16;// the features of a node are searched by this m
 
 // best split of every open node of the level: grid (node of level, class, feature chunk); a wave per feature, lanes over the bins
 __global__ __launch_bounds__(256) void k_gbt_split(const long long* part, const int32_t* ncut, const long long* nG, const long long* nH,
-                                                    const int32_t* st, Best* cand, int d, int n_slices, double lambda, double gamma, double mcw, Geom G) {
+                                                    const int32_t* st, const int32_t* build, const long long* Hprev, long long* Hcur, Best* cand, int d,
+                                                    int n_slices, double lambda, double gamma, double mcw, Geom G) {
   const int nl = 1 << d, base = nl - 1;
   const int k = blockIdx.x, c = blockIdx.y, node = base + k;
   if (st[c * MAXN + node] != 1) return;
   const int fchunk = (G.F + SPLIT_CHUNKS - 1) / SPLIT_CHUNKS, fbeg = blockIdx.z * fchunk, fend = min(G.F, fbeg + fchunk);
+  const bool built = build[c * MAXN + node] != 0;
+  const int ks = built ? k : (k ^ 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long Gn = nG[c * MAXN + node], Hn = nH[c * MAXN + node];
   const double Gd = (double)Gn / FIX, Hd = (double)Hn / FIX;
@@ -212,9 +217,19 @@ __global__ __launch_bounds__(256) void k_gbt_split(const long long* part, const 
 #pragma unroll
     for (int q = 0; q < 4; ++q) { g4[q] = 0; h4[q] = 0; }
     for (int s = 0; s < n_slices; ++s) {
-      const long long* src = part + ((((size_t)s * G.A + c) * nl + k) * G.F + f) * 512 + lane * 8;
+      const long long* src = part + ((((size_t)s * G.A + c) * nl + ks) * G.F + f) * 512 + lane * 8;
 #pragma unroll
       for (int q = 0; q < 4; ++q) { g4[q] += src[q * 2]; h4[q] += src[q * 2 + 1]; }
+    }
+    if (!built) {  // sibling subtraction: this node's histogram = its parent's - its (built) sibling's, exact in int64
+      const long long* par = Hprev + (((size_t)c * (nl >> 1) + (k >> 1)) * G.F + f) * 512 + lane * 8;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { g4[q] = par[q * 2] - g4[q]; h4[q] = par[q * 2 + 1] - h4[q]; }
+    }
+    {
+      long long* dst = Hcur + (((size_t)c * nl + k) * G.F + f) * 512 + lane * 8;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dst[q * 2] = g4[q]; dst[q * 2 + 1] = h4[q]; }
     }
     // inclusive prefix over the 256 bins: inside the lane, then across lanes
 #pragma unroll
@@ -291,16 +306,38 @@ __global__ void k_gbt_split_pick(const Best* cand, long long* nG, long long* nH,
 }
 
 __global__ __launch_bounds__(256) void k_gbt_partition(const uint8_t* Bq, uint8_t* pos, const int32_t* st, const int32_t* nF, const int32_t* nB,
-                                                        int d, Geom G) {
+                                                        int32_t* cnt, int d, Geom G) {
+  __shared__ int lc[64];
+  if (threadIdx.x < 64) lc[threadIdx.x] = 0;
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
-  if (i >= G.R) return;
-  const int node = pos[(size_t)c * G.R + i];
-  if (node < (1 << d) - 1 || st[c * MAXN + node] != 2) return;
-  const int64_t n = i / G.W;
-  const int w = (int)(i - n * G.W);
-  const uint8_t q = Bq[((size_t)n * G.Wp + w) * G.A + nF[c * MAXN + node]];
-  pos[(size_t)c * G.R + i] = (uint8_t)(q <= nB[c * MAXN + node] ? 2 * node + 1 : 2 * node + 2);
+  if (i < G.R) {
+    const int node = pos[(size_t)c * G.R + i];
+    if (node >= (1 << d) - 1 && st[c * MAXN + node] == 2) {
+      const int64_t n = i / G.W;
+      const int w = (int)(i - n * G.W);
+      const uint8_t q = Bq[((size_t)n * G.Wp + w) * G.A + nF[c * MAXN + node]];
+      const int child = q <= nB[c * MAXN + node] ? 2 * node + 1 : 2 * node + 2;
+      pos[(size_t)c * G.R + i] = (uint8_t)child;
+      atomicAdd(&lc[child], 1);  // rows per child: the smaller child of a pair gets its histogram built, the other derived
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < MAXN && lc[threadIdx.x]) atomicAdd(&cnt[c * MAXN + threadIdx.x], lc[threadIdx.x]);
+}
+
+// which child of every node split at level d gets its histogram built at level d + 1 (the one with fewer rows; ties: the left)
+__global__ void k_gbt_choose(const int32_t* st, const int32_t* cnt, int32_t* build, int d, int A) {
+  const int nl = 1 << d, base = nl - 1;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= A * nl) return;
+  const int c = e / nl, node = base + (e - c * nl), o = c * MAXN;
+  if (st[o + node] != 2) return;
+  const int l = 2 * node + 1, r = 2 * node + 2;
+  const bool left = cnt[o + l] <= cnt[o + r];
+  build[o + l] = left ? 1 : 0;
+  build[o + r] = left ? 0 : 1;
 }
 
 __global__ void k_gbt_close(const long long* nG, const long long* nH, int32_t* st, float* nV, int A, double eta, double lambda) {
@@ -344,7 +381,7 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
   G.N = N; G.W = W; G.A = A; G.S = S; G.pad = (S + 1) / 2; G.Wp = W + 2 * G.pad; G.F = S * A; G.R = N * (int64_t)W;
   const int D = P.max_depth, T = P.n_rounds * A;
   const int64_t RA = G.R * A;
-  DevBuf bBf, bCnt, bLut, bBq, bFm, bG, bH, bPos, bPart, bTab, bNcut, bLoss, bCand;
+  DevBuf bBf, bCnt, bLut, bBq, bFm, bG, bH, bPos, bPart, bTab, bNcut, bLoss, bCand, bRows, bLev;
   GBT_HIP(bBf.alloc((size_t)RA * 4));
   GBT_HIP(bCnt.alloc((size_t)A * 65536 * 4));
   GBT_HIP(bLut.alloc((size_t)A * 65536));
@@ -417,6 +454,13 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
     part_entries = std::max(part_entries, (size_t)ns * A * nl * G.F * 512);
   }
   GBT_HIP(bPart.alloc(part_entries * 8));
+  // rows per node and "build this node's histogram" flags of the round's trees; the level's summed histograms, this level's and the
+  // previous one's (a derived node reads its parent's)
+  GBT_HIP(bRows.alloc((size_t)2 * A * MAXN * 4));
+  int32_t* dCnt = bRows.as<int32_t>();
+  int32_t* dBuild = dCnt + (size_t)A * MAXN;
+  const size_t lev_entries = (size_t)A * ((size_t)1 << (D - 1)) * G.F * 512;
+  GBT_HIP(bLev.alloc(2 * lev_entries * 8));
   GNX_LDS_OPTIN((size_t)HIST_ENTRIES * 16, k_gbt_hist);
 
   const unsigned gR = (unsigned)((G.R + 255) / 256);
@@ -443,14 +487,19 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
     if (A <= 8) hipLaunchKernelGGL(k_gbt_grad<8>, dim3(gR), dim3(256), 0, s, bFm.as<float>(), dy, bG.as<long long>(), bH.as<long long>(), rG, rH, bLoss.as<long long>() + r, bPos.as<uint8_t>(), rS, G);
     else if (A <= 16) hipLaunchKernelGGL(k_gbt_grad<16>, dim3(gR), dim3(256), 0, s, bFm.as<float>(), dy, bG.as<long long>(), bH.as<long long>(), rG, rH, bLoss.as<long long>() + r, bPos.as<uint8_t>(), rS, G);
     else hipLaunchKernelGGL(k_gbt_grad<32>, dim3(gR), dim3(256), 0, s, bFm.as<float>(), dy, bG.as<long long>(), bH.as<long long>(), rG, rH, bLoss.as<long long>() + r, bPos.as<uint8_t>(), rS, G);
+    GBT_HIP(hipMemsetAsync(dCnt, 0, (size_t)A * MAXN * 4, s));
+    GBT_HIP(hipMemsetAsync(dBuild, 0xff, (size_t)A * MAXN * 4, s));  // (the roots are built; children are decided by k_gbt_choose)
     for (int d = 0; d < D; ++d) {
       const int nl = 1 << d, fg = (G.F + fpb[d] - 1) / fpb[d];
+      long long* Hcur = bLev.as<long long>() + (size_t)(d & 1) * lev_entries;
+      const long long* Hprev = bLev.as<long long>() + (size_t)((d & 1) ^ 1) * lev_entries;
       hipLaunchKernelGGL(k_gbt_hist, dim3((unsigned)fg, (unsigned)A, (unsigned)nsl[d]), dim3(HIST_T), (size_t)fpb[d] * nl * 512 * 8, s, bBq.as<uint8_t>(),
-                         bG.as<long long>(), bH.as<long long>(), bPos.as<uint8_t>(), rS, bPart.as<long long>(), d, fpb[d], nsl[d], G);
+                         bG.as<long long>(), bH.as<long long>(), bPos.as<uint8_t>(), rS, dBuild, bPart.as<long long>(), d, fpb[d], nsl[d], G);
       hipLaunchKernelGGL(k_gbt_split, dim3((unsigned)nl, (unsigned)A, SPLIT_CHUNKS), dim3(256), 0, s, bPart.as<long long>(), bNcut.as<int32_t>(), rG,
-                         rH, rS, bCand.as<Best>(), d, nsl[d], P.lambda, P.gamma, P.min_child_weight, G);
+                         rH, rS, dBuild, Hprev, Hcur, bCand.as<Best>(), d, nsl[d], P.lambda, P.gamma, P.min_child_weight, G);
       hipLaunchKernelGGL(k_gbt_split_pick, dim3((unsigned)((A * nl + 63) / 64)), dim3(64), 0, s, bCand.as<Best>(), rG, rH, rF, rB, rS, d, A);
-      hipLaunchKernelGGL(k_gbt_partition, dim3(gR, (unsigned)A), dim3(256), 0, s, bBq.as<uint8_t>(), bPos.as<uint8_t>(), rS, rF, rB, d, G);
+      hipLaunchKernelGGL(k_gbt_partition, dim3(gR, (unsigned)A), dim3(256), 0, s, bBq.as<uint8_t>(), bPos.as<uint8_t>(), rS, rF, rB, dCnt, d, G);
+      if (d + 1 < D) hipLaunchKernelGGL(k_gbt_choose, dim3((unsigned)((A * nl + 63) / 64)), dim3(64), 0, s, rS, dCnt, dBuild, d, A);
     }
     hipLaunchKernelGGL(k_gbt_close, dim3((unsigned)((A * MAXN + 255) / 256)), dim3(256), 0, s, rG, rH, rS, rV, A, P.eta, P.lambda);
     hipLaunchKernelGGL(k_gbt_margin, dim3(gRA), dim3(256), 0, s, bFm.as<float>(), bPos.as<uint8_t>(), rV, G);
