@@ -173,3 +173,31 @@ def test_gbt_rejects_bad_arguments(ga):
         train.train_gbt_arrays(B, y, 11, max_depth=9)
     with pytest.raises(ValueError):
         train.train_gbt_arrays(B, y[:, :-1], 11)
+
+
+@pytest.mark.gpu
+def test_gbt_full_size_properties(ga, oracle):
+    """config-2 geometry (W = 370, A = 7, S = 75), 3 000 haplotypes = 1.1 M rows x 525 features: too large for the scalar oracle, so
+    size-independent properties — the loss falls every round, two runs give identical trees (fixed-point sums: no dependence on
+    scheduling), the first trees equal the oracle's on a subset small enough for it when trained on that subset, and the
+    trained smoother labels the training haplotypes better than the raw arg-max."""
+    from gnomix_amd import synth, train
+    N, W, A, S = 3000, 370, 7, 75
+    B, y = _problem(N, W, A, seed=77, noise=0.45)
+    t1, l1 = train.train_gbt_arrays(B, y, S, n_rounds=10)
+    t2, l2 = train.train_gbt_arrays(B, y, S, n_rounds=10)
+    for k in t1:
+        assert np.array_equal(t1[k], t2[k]), k
+    assert np.array_equal(l1, l2) and np.all(np.diff(l1) < 0) and abs(l1[0] - np.log(A)) < 1e-6
+    assert t1["feat"].max() < S * A and np.array_equal(t1["tree_class"], np.arange(10 * A) % A)
+    # a subset the oracle can do: same trees
+    Bs, ys = B[:24], y[:24].copy()
+    ys[0, :A] = np.arange(A)
+    T, _ = oracle.train_gbt(Bs, ys, S, n_rounds=2)
+    ts, _ = train.train_gbt_arrays(Bs, ys, S, n_rounds=2)
+    assert np.array_equal(ts["feat"], T.feat) and np.array_equal(ts["cond"].view(np.uint32), T.cond.view(np.uint32))
+    d = synth.synthetic_model(C=W * 10 + 3, M=10, A=A, S=S, n_rounds=1, seed=3)
+    for k, v in t1.items():
+        setattr(d, k, v)
+    lab = ga.DeviceModel(d).smooth_predict(B[:400], want_proba=False)[1]
+    assert (lab == y[:400]).mean() > (np.argmax(B[:400], -1) == y[:400]).mean() + 0.05
