@@ -57,7 +57,7 @@ class HipSmoother:
         if self.dev.data.smooth_kind not in (None, "xgb"):
             raise NotImplementedError("on-device training is built for the tree smoother (XGB_Smoother)")
         t = time()
-        self.train_loss = train_gbt_smoother(self.dev.data, B, y.reshape(np.asarray(B).shape[0], -1), ctx=self.dev.ctx, **kw)
+        self.train_loss = train_gbt_smoother(self.dev.data, B, y.reshape(B.shape[0], -1), ctx=self.dev.ctx, **kw)
         self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)   # (a HipGnomix re-binds base and fused path: HipGnomix.train_smoother)
         self.gnofix = True
         self.model = _RowModel(self.dev)
