@@ -1,0 +1,53 @@
+# run the GPU fuzz tests (tests/test_gpu_fuzz.py) over seeds beyond the ones the suite pins:  python scripts/dev/extended_fuzz.py 1000 1040
+import os, sys, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pytest
+from oracle import gnx_oracle as O
+O.build()
+import test_gpu_fuzz as F
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+for name in ("test_random_geometry_vs_oracle", "test_random_geometry_tree_bases_vs_oracle", "test_random_gnofix_vs_oracle", "test_random_covrsk_vs_oracle"):
+    fn = getattr(F, name)
+    fn = getattr(fn, "__wrapped__", fn)
+    ok = skipped = 0
+    for seed in range(lo, hi):
+        try:
+            fn(O, seed); ok += 1
+        except pytest.skip.Exception:
+            skipped += 1
+        except Exception:
+            bad += 1
+            print("FAIL", name, seed); traceback.print_exc(limit=3)
+    print(name, "ok", ok, "skipped", skipped)
+
+# the tree-smoother trainer against the oracle's on random small problems (trees must be identical, bit for bit)
+import numpy as np
+from gnomix_amd import train
+import test_train_gbt as TG
+ok = 0
+for seed in range(lo, hi):
+    rng = np.random.RandomState(seed)
+    A = int(rng.choice([2, 3, 4, 5, 7, 9, 12])); S = int(rng.choice([3, 5, 9, 15, 31])); W = int(rng.randint(2 * S, 2 * S + 40)); N = int(rng.randint(4, 40))
+    kw = dict(n_rounds=int(rng.randint(1, 6)), max_depth=int(rng.randint(1, 6)), max_bin=int(rng.choice([2, 7, 32, 256])),
+              gamma=float(rng.choice([0.0, 0.3])), min_child_weight=float(rng.choice([0.0, 1.0, 4.0])), reg_lambda=float(rng.choice([0.0, 1.0, 10.0])),
+              learning_rate=float(rng.choice([0.1, 0.5, 1.0])), base_score=float(rng.choice([0.5, 0.0])))
+    B, y = TG._problem(N, W, A, seed=seed, noise=float(rng.choice([0.1, 0.5, 1.0])))
+    if rng.rand() < 0.3:
+        B = np.round(B, 2); B /= B.sum(-1, keepdims=True)      # heavy ties: few distinct values per class column
+    if rng.rand() < 0.5:
+        B = B.astype(np.float32)
+    okw = dict(kw); okw["lam"] = okw.pop("reg_lambda"); okw["eta"] = okw.pop("learning_rate")
+    try:
+        T, lref = O.train_gbt(B, y, S, **okw)
+        t, l = train.train_gbt_arrays(B, y, S, **kw)
+        assert np.array_equal(t["tree_off"], T.tree_off) and np.array_equal(t["feat"], T.feat) and np.array_equal(t["left"], T.left)
+        assert np.array_equal(t["cond"].view(np.uint32), T.cond.view(np.uint32)) and np.allclose(l, lref, atol=1e-6, rtol=0)
+        ok += 1
+    except Exception:
+        bad += 1
+        print("FAIL gbt", seed, dict(N=N, W=W, A=A, S=S), kw); traceback.print_exc(limit=2)
+print("gbt trainer vs oracle ok", ok)
+print("failures:", bad)
+sys.exit(1 if bad else 0)

@@ -102,7 +102,7 @@ def test_random_gnofix_vs_oracle(oracle, seed):
     max_it = int(rng.choice([1, 3, 6, 50]))
     d = gnomix_amd.GnxModelData(C=C, M=M, A=A, S=S, context=0, smooth_kind="xgb")
     trained = seed % 3 == 0   # a smoother that behaves like a trained one (few switches) or a chaotic random one (many)
-    trees = synth.synthetic_smoothing_trees(6, A, S, seed=seed, reach=min(8, (S - 1) // 2)) if trained else \
+    trees = synth.synthetic_smoothing_trees(6, A, S, seed=seed, reach=min(8, S - 1 - (S + 1) // 2)) if trained else \
         synth.synthetic_trees(int(rng.randint(2, 7)), A, S * A, seed=seed, thr_lo=0.0, thr_hi=0.6, leaf_scale=1.0)
     for k, v in trees.items():
         setattr(d, k, v)
