@@ -114,6 +114,7 @@ SYMBOLS = {
                                      C.POINTER(TrainInfo)]),
     "gnx_train_logistic_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _I64, _I64, _I64, C.c_int32, C.c_double, C.c_double, C.c_int32, _VP, _I64,
                                          _VP, C.POINTER(TrainInfo)]),
+    "gnx_fit_isotonic_f32": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP]),
     "gnx_train_gbt": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
     "gnx_train_gbt_dev": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
     "gnx_profile_enable": (C.c_int, [_VP, _I]),

@@ -1638,6 +1638,61 @@ int gnx_train_gbt(gnx_ctx* ctx, const void* B, int32_t b_is_f64, const int32_t* 
   return GNX_OK;
 }
 
+// ---- fitting one isotonic map of the calibrator (host arithmetic: a sort and two linear passes over a few thousand points) -------
+// sklearn.isotonic.IsotonicRegression(out_of_bounds="clip").fit(x, y) as the reference's Calibrator.fit calls it per class
+// (src/Smooth/Calibration.py:55) on float32 probabilities: sort by (x, y); merge x closer than float32's resolution (1e-6) to the
+// first x of their group, y = float32 running mean; pool adjacent violators (block means in float64, as scipy's PAVA behind
+// sklearn >= 1.4 does, result cast to float32); drop interior points whose y equals both neighbours'.
+int gnx_fit_isotonic_f32(const float* x, const float* y, int64_t n, float* x_thr, float* y_thr, int64_t* n_thr) {
+  if (n <= 0 || !x || !y || !x_thr || !y_thr || !n_thr) return GNX_EINVAL;
+  try {
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return x[a] < x[b] || (x[a] == x[b] && y[a] < y[b]); });
+    // _make_unique (sklearn/_isotonic.pyx), float32 throughout
+    std::vector<float> ux, uy, uw;
+    const float eps = 1e-6f;  // np.finfo(np.float32).resolution
+    float cx = x[order[0]], cy = 0.f, cw = 0.f;
+    for (int64_t j = 0; j < n; ++j) {
+      const float xv = x[order[(size_t)j]], yv = y[order[(size_t)j]];
+      if (xv - cx >= eps) {
+        ux.push_back(cx); uw.push_back(cw); uy.push_back(cy / cw);
+        cx = xv; cw = 1.f; cy = yv * 1.f;
+      } else {
+        cw += 1.f;
+        cy += yv * 1.f;
+      }
+    }
+    ux.push_back(cx); uw.push_back(cw); uy.push_back(cy / cw);
+    // pool adjacent violators on (uy, uw): blocks as (weighted sum, weight, first index), means in float64
+    const size_t m = ux.size();
+    std::vector<double> bs(m), bw(m);
+    std::vector<size_t> b0(m);
+    size_t nb = 0;
+    for (size_t i = 0; i < m; ++i) {
+      bs[nb] = (double)uw[i] * (double)uy[i]; bw[nb] = (double)uw[i]; b0[nb] = i; ++nb;
+      while (nb > 1 && bs[nb - 2] / bw[nb - 2] > bs[nb - 1] / bw[nb - 1]) {
+        bs[nb - 2] += bs[nb - 1]; bw[nb - 2] += bw[nb - 1]; --nb;
+      }
+    }
+    std::vector<float> fy(m);
+    for (size_t b = 0; b < nb; ++b) {
+      const float v = (float)(bs[b] / bw[b]);
+      const size_t e = (b + 1 < nb) ? b0[b + 1] : m;
+      for (size_t i = b0[b]; i < e; ++i) fy[i] = v;
+    }
+    int64_t k = 0;
+    for (size_t i = 0; i < m; ++i) {
+      const bool keep = (i == 0 || i + 1 == m) ? true : (fy[i] != fy[i - 1] || fy[i] != fy[i + 1]);
+      if (keep) { x_thr[k] = ux[i]; y_thr[k] = fy[i]; ++k; }
+    }
+    *n_thr = k;
+  } catch (...) {
+    return GNX_ENOMEM;
+  }
+  return GNX_OK;
+}
+
 // ---- profiling ---------------------------------------------------------------------------------------
 int gnx_profile_enable(gnx_ctx* ctx, int on) {
   if (!ctx) return GNX_EINVAL;

@@ -71,6 +71,10 @@ class HipGnomix:
         self.train_base(X_t1, y_t1)
         B_t2 = self.base.predict_proba(X_t2)
         self.train_smoother(B_t2, y_t2, **smoother_kw)
+        if self.calibrate:   # src/model.py:119-124: balanced w.r.t. the train1 class distribution
+            self.smooth.train_calibrator(self.base.predict_proba(X_t1), y_t1)
+            self.dev = self.smooth.dev
+            self.base.dev = self.dev
         if evaluate:   # src/model.py:127-151
             Acc, CM = {}, {}
             B_t1 = self.base.predict_proba(X_t1)

@@ -64,6 +64,26 @@ class HipSmoother:
         self.time["train"] = time() - t
         return self
 
+    def train_calibrator(self, B, y, frac=0.05):
+        """Smoother.train_calibrator (smooth.py:81-92): uncalibrated probabilities of a random `frac` of the haplotypes (numpy's
+        global generator, as the reference), one isotonic map per class (gnomix_amd.calibrate), device model re-loaded with them"""
+        from .calibrate import fit_calibrator
+        from .model import DeviceModel
+        B = np.asarray(B)
+        y = np.asarray(y)
+        calibrate = self.calibrate
+        self.calibrate = False
+        idxs = np.random.choice(len(B), int(frac * len(B)), replace=False)
+        proba = self.predict_proba(B[idxs]).reshape(-1, self.A)
+        for k, v in fit_calibrator(proba, y[idxs].reshape(-1), self.A).items():
+            setattr(self.dev.data, k, v)
+        self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)   # (a HipGnomix re-binds: HipGnomix.train)
+        if self.model is not None:
+            self.model.dev = self.dev
+        self.calibrator = True
+        self.calibrate = calibrate
+        return self
+
     def evaluate(self, B=None, y=None, y_pred=None):
         """(accuracy %, balanced accuracy %) rounded to two decimals (smooth.py:67-79)"""
         from .metrics import accuracy_pair

@@ -319,6 +319,12 @@ int gnx_train_gbt_dev(gnx_ctx* ctx, const void* dB, int32_t b_is_f64, const int3
                       const gnx_gbt_params* params, int32_t* tree_off, int32_t* tree_class, int32_t* left, int32_t* right,
                       int32_t* feat, float* cond, int64_t* n_nodes, double* loss);
 
+/* ---- one isotonic map of the calibrator: Calibrator.fit (src/Smooth/Calibration.py:43-55) fits, per class i,
+ *      sklearn IsotonicRegression(out_of_bounds='clip') on (proba[:, i], y == class i) with float32 probabilities.
+ * Host arithmetic (no context, no device): x, y (n,) float32 in any order -> thresholds x_thr / y_thr (caller-allocated, n each),
+ * *n_thr of them; they go into gnx_model_desc.calib_x / calib_y (as float64) with calib_is_f32 = 1. */
+int gnx_fit_isotonic_f32(const float* x, const float* y, int64_t n, float* x_thr, float* y_thr, int64_t* n_thr);
+
 /* per-kernel device time, measured with hipEvents on the context stream around every launch */
 int gnx_profile_enable(gnx_ctx* ctx, int on);
 int gnx_profile_reset(gnx_ctx* ctx);

@@ -309,3 +309,35 @@ def test_metrics_equal_sklearn():
         assert accuracy_pair(y.reshape(20, 40), yp.reshape(20, 40)) == ref
         got, labels = confusion(y, yp)
         assert np.array_equal(got, cm) and labels == sorted(set(y) | set(yp))
+
+
+def test_isotonic_fit_equals_the_references_calibrator():
+    """gnx_fit_isotonic_f32 (host arithmetic in the library) vs golden G8: the thresholds the REFERENCE's Calibrator.fit produced
+    on the same (regenerated) inputs, bit for bit; plus random problems against scikit-learn when it is installed"""
+    from conftest import load_golden
+    from gnomix_amd import calibrate
+    g = load_golden("G8_calib_sk.npz")
+    rng = np.random.RandomState(8)                       # make_golden.py: make_G8 draws these first
+    A = int(g["A"])
+    proba_fit = rng.dirichlet(np.ones(A) * 0.5, size=3000).astype(np.float32)
+    y = np.array([rng.choice(A, p=p / p.sum()) for p in proba_fit.astype(np.float64) ** 0.7])
+    d = calibrate.fit_calibrator(proba_fit, y, A)
+    assert d["calib_is_f32"] is True
+    for i in range(A):
+        sl = slice(d["calib_off"][i], d["calib_off"][i + 1])
+        assert np.array_equal(d["calib_x"][sl], g["x%d" % i]) and np.array_equal(d["calib_y"][sl], g["y%d" % i]), i
+    with pytest.raises(ValueError):
+        calibrate.fit_calibrator(proba_fit, np.zeros_like(y), A)
+    iso = pytest.importorskip("sklearn.isotonic")
+    for seed in range(12):
+        r = np.random.RandomState(seed)
+        n = int(r.randint(1, 400))
+        x = r.beta(0.3, 0.3, size=n).astype(np.float32)
+        if seed % 3 == 0:
+            x = np.round(x, 2)                             # heavy ties
+        if seed % 4 == 0:
+            x[: n // 2] += np.float32(3e-7) * r.randint(0, 3, size=n // 2)   # values closer than float32's resolution
+        t = (r.rand(n) < x).astype(np.float32)
+        m = iso.IsotonicRegression(out_of_bounds="clip").fit(x, t)
+        xt, yt = calibrate.fit_isotonic(x, t)
+        assert np.array_equal(xt, m.X_thresholds_) and np.array_equal(yt, m.y_thresholds_), seed

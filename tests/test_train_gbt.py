@@ -159,6 +159,13 @@ def test_gnomix_train_end_to_end(ga, oracle):
     assert g.accuracies['smooth_val_acc'] > 80 and g.accuracies['smooth_val_acc'] > g.accuracies['base_val_acc'] + 3, g.accuracies
     assert g.predict(v[0]).shape == v[1].shape
     assert np.all(np.diff(g.smooth.train_loss) < 0)
+    # the calibrated variant (config `calibrate: True`): Gnomix.train also fits the isotonic maps on train1 (src/model.py:119-124)
+    gc = ga.HipGnomix(d, calibrate=True)
+    np.random.seed(5)
+    gc.train((t1, t2, v), n_rounds=8, evaluate=False)
+    assert gc.dev.data.calib_off is not None and gc.smooth.calibrator
+    pc = gc.predict_proba(v[0][:6])
+    assert np.allclose(pc.sum(-1), 1.0, atol=1e-6)
 
 
 @pytest.mark.gpu
@@ -201,3 +208,34 @@ def test_gbt_full_size_properties(ga, oracle):
         setattr(d, k, v)
     lab = ga.DeviceModel(d).smooth_predict(B[:400], want_proba=False)[1]
     assert (lab == y[:400]).mean() > (np.argmax(B[:400], -1) == y[:400]).mean() + 0.05
+
+
+@pytest.mark.gpu
+def test_train_calibrator_end_to_end(ga, oracle):
+    """Smoother.train_calibrator (smooth.py:81-92) on the device model: the maps fitted by gnx_fit_isotonic_f32 on the smoother's own
+    probabilities equal scikit-learn's on the same rows, the re-loaded model applies them (k_calibrate == the reference's transform
+    arithmetic, pinned by G8 elsewhere), rows still sum to one, and Gnomix.train(calibrate=True) runs the whole sequence."""
+    iso = pytest.importorskip("sklearn.isotonic")
+    from gnomix_amd import synth
+    N, W, A, S = 120, 60, 4, 11
+    B, y = _problem(N, W, A, seed=21)
+    d = synth.synthetic_model(C=W * 10 + 3, M=10, A=A, S=S, n_rounds=2, seed=3)
+    sm = ga.HipSmoother(ga.DeviceModel(d))
+    sm.train(B, y, n_rounds=5)
+    raw = sm.predict_proba(B)
+    np.random.seed(11)
+    idxs = np.random.choice(N, int(0.25 * N), replace=False)
+    np.random.seed(11)
+    sm.train_calibrator(B, y, frac=0.25)
+    data = sm.dev.data
+    assert data.calib_is_f32 and len(data.calib_off) == A + 1
+    for i in range(A):
+        m = iso.IsotonicRegression(out_of_bounds="clip").fit(raw[idxs].reshape(-1, A)[:, i], (y[idxs].reshape(-1) == i).astype(float))
+        sl = slice(data.calib_off[i], data.calib_off[i + 1])
+        assert np.array_equal(data.calib_x[sl], m.X_thresholds_.astype(np.float64)) and np.array_equal(data.calib_y[sl], m.y_thresholds_.astype(np.float64))
+    assert np.array_equal(sm.predict_proba(B), raw)                      # calibrate flag still off
+    sm.calibrate = True
+    cal = sm.predict_proba(B)
+    assert cal.shape == raw.shape and np.allclose(cal.sum(-1), 1.0, atol=1e-6) and not np.array_equal(cal, raw)
+    ref = sm.dev.calibrate_rows(raw.reshape(-1, A)).reshape(raw.shape)
+    assert np.array_equal(cal, ref)
