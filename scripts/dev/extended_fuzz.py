@@ -29,7 +29,7 @@ import test_train_gbt as TG
 ok = 0
 for seed in range(lo, hi):
     rng = np.random.RandomState(seed)
-    A = int(rng.choice([2, 3, 4, 5, 7, 9, 12])); S = int(rng.choice([3, 5, 9, 15, 31])); W = int(rng.randint(2 * S, 2 * S + 40)); N = int(rng.randint(4, 40))
+    A = int(rng.choice([2, 3, 4, 5, 7, 9, 12])); S = int(rng.choice([3, 5, 9, 15, 31])); W = int(rng.randint(max(2 * S, A), max(2 * S, A) + 40)); N = int(rng.randint(4, 40))
     kw = dict(n_rounds=int(rng.randint(1, 6)), max_depth=int(rng.randint(1, 6)), max_bin=int(rng.choice([2, 7, 32, 256])),
               gamma=float(rng.choice([0.0, 0.3])), min_child_weight=float(rng.choice([0.0, 1.0, 4.0])), reg_lambda=float(rng.choice([0.0, 1.0, 10.0])),
               learning_rate=float(rng.choice([0.1, 0.5, 1.0])), base_score=float(rng.choice([0.5, 0.0])))
