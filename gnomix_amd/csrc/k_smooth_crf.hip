@@ -13,7 +13,11 @@
 //   * k_crf_scan: ONE LANE PER HAPLOTYPE holds the whole label vector in registers (alpha, beta: A doubles each): a step is
 //     A^2 multiply-adds against exp(tau) rows broadcast from LDS, no cross-lane traffic at all; the lane's rows of psi and of
 //     the parked alphas stream through an LDS ring filled by LDS-direct loads two chunks ahead, so HBM latency is off the chain.
-// Every sum keeps the oracle's left-to-right association (float64, no FMA contraction), so the marginals agree with it as before.
+//   * k_smooth_crf_row16 (the default up to 16 labels, further down): ONE HAPLOTYPE PER 16-LANE DPP ROW, the cross-label sums as
+//     v_fmac_f64 with a row_newbcast DPP operand — no LDS and no shuffles on the chain; k_crf_scan (<= 8 labels) and
+//     k_smooth_crf_lanes (any label count; the only kernel for 17..32) stay selectable with GNX_CRF_IMPL and serve as cross-checks.
+// k_crf_scan / k_smooth_crf_lanes keep the oracle's left-to-right association (float64, no FMA contraction); the row kernel fuses
+// its multiply-adds (marginals within 1e-11 of the oracle's, labels identical).
 #include "gnx_internal.h"
 
 namespace {
