@@ -40,6 +40,11 @@ class HipGnomix:
     def load(cls, path, **kw):
         return cls(GnxModelData.load(path), **kw)
 
+    def save(self, path):
+        """write the model (base, smoother, calibrator, metadata) as a .gnx archive: what Gnomix.save pickles (src/model.py:100-102)"""
+        self.dev.data.save(path)
+        return path
+
     def train_base(self, X, y):
         """the base half of Gnomix.train (src/model.py:113, 155): fit the logistic base on the device, then re-bind base,
         smoother and the fused path to the freshly loaded model"""

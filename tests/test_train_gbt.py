@@ -159,6 +159,12 @@ def test_gnomix_train_end_to_end(ga, oracle):
     assert g.accuracies['smooth_val_acc'] > 80 and g.accuracies['smooth_val_acc'] > g.accuracies['base_val_acc'] + 3, g.accuracies
     assert g.predict(v[0]).shape == v[1].shape
     assert np.all(np.diff(g.smooth.train_loss) < 0)
+    # a trained model survives save / load
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        path = g.save(os.path.join(td, "trained.gnx"))
+        g2 = ga.HipGnomix.load(path)
+        assert np.array_equal(g2.predict(v[0][:10]), g.predict(v[0][:10]))
     # the calibrated variant (config `calibrate: True`): Gnomix.train also fits the isotonic maps on train1 (src/model.py:119-124)
     gc = ga.HipGnomix(d, calibrate=True)
     np.random.seed(5)
