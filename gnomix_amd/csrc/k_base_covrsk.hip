@@ -269,9 +269,11 @@ __device__ __forceinline__ BitVec<NWT> band(const BitVec<NWT>& a, const BitVec<N
 
 template <int NWT>
 __device__ __forceinline__ uint32_t pop(const BitVec<NWT>& a) {
+  // v_bcnt_u32_b32 adds its count to an accumulator operand: NWT instructions (hipcc's own lowering of `c += __popc(w)` is a tree of
+  // bcnt(w, 0) and v_add3: NWT + NWT/2)
   uint32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < NWT; ++i) c += __popc(a.w[i]);
+  for (int i = 0; i < NWT; ++i) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c) : "v"(a.w[i]));
   return c;
 }
 
@@ -293,7 +295,10 @@ __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
   const int w = L.w_first + blockIdx.y;
   const int A = L.A, P = A * (A - 1) / 2;
   const SvcWinDev win = L.win[w];
-  const int NW = win.nw, width = win.width, n_sv = win.n_sv, n_ms = win.n_ms;
+  // the launcher groups windows by their word count and instantiates NWT = that count: a compile-time NW lets the support vector's
+  // words arrive as a few wide scalar loads instead of one guarded s_load_dword per word
+  constexpr int NW = NWT;
+  const int width = win.width, n_sv = win.n_sv, n_ms = win.n_ms;
   double* dec = reinterpret_cast<double*>(lds);  // [pair][lane]
 
   const int64_t n = L.n_first + (int64_t)blockIdx.x * 64 + lane;
@@ -478,6 +483,76 @@ __global__ __launch_bounds__(64) void k_svc_couple(CovRSKLaunch L) {
 #undef PP
 }
 
+// The same iteration with a compile-time class count: r, Q, Qp and p live in REGISTERS with static indices (the generic kernel
+// keeps them in LDS as [index][thread]: every one of the ~k^2 operands of an iteration is an LDS round trip on the lane's
+// critical path).  Identical operations in identical order -> identical results.
+template <int AT>
+__global__ __launch_bounds__(64) void k_svc_couple_reg(CovRSKLaunch L) {
+  constexpr int k = AT, P = AT * (AT - 1) / 2;
+  const int lane = threadIdx.x;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t total = L.n_count * L.W;
+  const int64_t ic = idx < total ? idx : total - 1;
+  const double* in = L.rpair + (size_t)ic * P;
+  double rr[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) rr[p] = in[p];
+  const int max_iter = k > 100 ? k : 100;
+  const double eps = 0.005 / k;
+  // R[i][j] = r_ij (i < j from the pairwise pass, j < i as 1 - r_ji): the full matrix in registers, every index static
+  double R[AT][AT], Q[AT][AT], Qp[AT], pr[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int j = 0; j < AT; ++j)
+      R[i][j] = (i < j) ? rr[i * (2 * AT - i - 1) / 2 + (j - i - 1)] : (i > j) ? 1.0 - rr[j * (2 * AT - j - 1) / 2 + (i - j - 1)] : 0.0;
+#pragma unroll
+  for (int t = 0; t < k; ++t) {
+    pr[t] = 1.0 / k;
+    double qtt = 0.0;
+#pragma unroll
+    for (int j = 0; j < k; ++j)
+      if (j != t) qtt += R[j][t] * R[j][t];   // (j < t first, then j > t: libsvm's order)
+    Q[t][t] = qtt;
+#pragma unroll
+    for (int j = 0; j < k; ++j)
+      if (j > t) { Q[t][j] = -R[j][t] * R[t][j]; Q[j][t] = Q[t][j]; }
+  }
+  for (int iter = 0; iter < max_iter; ++iter) {
+    double pQp = 0.0;
+#pragma unroll
+    for (int t = 0; t < k; ++t) {
+      double q = 0.0;
+#pragma unroll
+      for (int j = 0; j < k; ++j) q += Q[t][j] * pr[j];
+      Qp[t] = q;
+      pQp += pr[t] * q;
+    }
+    double max_error = 0.0;
+#pragma unroll
+    for (int t = 0; t < k; ++t) { const double e = fabs(Qp[t] - pQp); if (e > max_error) max_error = e; }
+    if (max_error < eps) break;
+#pragma unroll
+    for (int t = 0; t < k; ++t) {
+      const double diff = (-Qp[t] + pQp) / Q[t][t];
+      pr[t] += diff;
+      pQp = (pQp + diff * (diff * Q[t][t] + 2 * Qp[t])) / (1 + diff) / (1 + diff);
+#pragma unroll
+      for (int j = 0; j < k; ++j) { Qp[j] = (Qp[j] + diff * Q[t][j]) / (1 + diff); pr[j] /= (1 + diff); }
+    }
+  }
+  if (idx < total) {
+    const int64_t nl = idx / L.W, w = idx - nl * L.W;
+    const size_t o = ((size_t)(L.n_first + nl) * L.W + w) * AT;
+#pragma unroll
+    for (int a = 0; a < AT; ++a) {
+      const double v = pr[a];
+      if (L.b64) L.b64[o + a] = v;
+      if (L.b32) L.b32[o + a] = (float)v;
+    }
+  }
+}
+
 }  // namespace
 
 size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width) {
@@ -534,7 +609,9 @@ hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
       w0 = w1;
     }
     const int64_t total = L.n_count * L.W;
-    hipLaunchKernelGGL(k_svc_couple, dim3((unsigned)((total + 63) / 64)), dim3(64), lds_cpl, s, L);
+    if (A == 7) hipLaunchKernelGGL(k_svc_couple_reg<7>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, L);
+    else if (A == 3) hipLaunchKernelGGL(k_svc_couple_reg<3>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, L);
+    else hipLaunchKernelGGL(k_svc_couple, dim3((unsigned)((total + 63) / 64)), dim3(64), lds_cpl, s, L);
   }
   return hipGetLastError();
 }
