@@ -812,6 +812,9 @@ void gnx_ctx_free(gnx_ctx* ctx) {
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : {ctx->ev_in[0], ctx->ev_in[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_out[0], ctx->ev_out[1]})
     if (e) (void)hipEventDestroy(e);
+  if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
+  for (auto e : ctx->ev_aux)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
   if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
   for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi})
@@ -985,6 +988,11 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
       L.rpair = (double*)ctx->ws_rpair.p;
       L.rpair_haps = haps;
     }
+    if (!ctx->s_aux) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+      for (int b = 0; b < 2; ++b) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_aux[b], hipEventDisableTiming));
+    }
+    L.aux = ctx->s_aux; L.ev_fork = ctx->ev_aux[0]; L.ev_join = ctx->ev_aux[1]; L.n_cu = ctx->n_cu;
     HIPCHK(ctx, gnx_launch_covrsk(L, ctx->stream));
     return GNX_OK;
   }

@@ -67,6 +67,9 @@ struct gnx_ctx {
   gnx_devbuf ws_x, ws_b32, ws_b64, ws_p32, ws_p64, ws_lab, ws_misc, ws_scale, ws_bits, ws_lastrow, ws_rpair, ws_y0, ws_cal, ws_marg;
   // host-pointer pipeline (gnx_infer / gnx_infer_packed): copy-in and copy-out streams next to the compute stream, created on
   // first use; buffers alternate between two halves of the staging workspaces
+  // side stream of the CovRSK base: window groups too small to fill the chip (the wider last window) run beside the main grid
+  hipStream_t s_aux = nullptr;
+  hipEvent_t ev_aux[2] = {nullptr, nullptr};
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   gnx_devbuf ws_pk, ws_xu, ws_psi;
@@ -244,6 +247,9 @@ struct CovRSKLaunch {
   int64_t n_first, n_count; // chunk being processed (set by the launcher)
   int32_t w_first;          // first window of the grid (set by the launcher)
   const int32_t* host_fast_nw;  // HOST pointer: per-window fast-path word count (launcher only)
+  hipStream_t aux;              // optional side stream + two events (launcher only): small window groups overlap the main grid
+  hipEvent_t ev_fork, ev_join;
+  int32_t n_cu;
 };
 
 // ---- gnofix (k_gnofix.hip) ----------------------------------------------------------------------------

@@ -571,7 +571,7 @@ hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t
   return hipGetLastError();
 }
 
-hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
+hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s0) {
   if (L0.N <= 0) return hipSuccess;
   const int A = L0.A, P = A * (A - 1) / 2;
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
@@ -585,13 +585,23 @@ hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
     CovRSKLaunch L = L0;
     L.n_first = n0;
     L.n_count = (L0.N - n0 < L0.rpair_haps) ? L0.N - n0 : L0.rpair_haps;
-    // consecutive windows with the same (fast-path word count) go in one grid
+    // consecutive windows with the same (fast-path word count) go in one grid.  A grid that cannot fill the chip (the one wider last
+    // window: a dozen waves walking 1 400 support vectors, 1.5 ms at 1 % VALU) goes to the side stream, next to the main grid
+    const bool fork = L0.aux != nullptr;
+    bool forked = false;
+    if (fork) (void)hipEventRecord(L0.ev_fork, s0);  // the side stream may start once this chunk's buffers are free
     for (int w0 = 0; w0 < L.W;) {
       const int key = L0.host_fast_nw[w0];
       int w1 = w0 + 1;
       while (w1 < L.W && L0.host_fast_nw[w1] == key) ++w1;
       L.w_first = w0;
       const dim3 grid((unsigned)((L.n_count + 63) / 64), (unsigned)(w1 - w0));
+      const bool small = fork && (int64_t)grid.x * grid.y < (int64_t)4 * std::max(L0.n_cu, 1) && w1 - w0 < L.W;
+      hipStream_t s = s0;
+      if (small) {
+        if (!forked) { (void)hipStreamWaitEvent(L0.aux, L0.ev_fork, 0); forked = true; }
+        s = L0.aux;
+      }
       const size_t lds_fast = (size_t)P * 64 * 8;
       switch (key) {
 #define GNX_FAST_CASE(NWT_)                                                                                         \
@@ -609,6 +619,8 @@ hipError_t gnx_launch_covrsk(const CovRSKLaunch& L0, hipStream_t s) {
       w0 = w1;
     }
     const int64_t total = L.n_count * L.W;
+    hipStream_t s = s0;
+    if (forked) { (void)hipEventRecord(L0.ev_join, L0.aux); (void)hipStreamWaitEvent(s0, L0.ev_join, 0); }
     if (A == 7) hipLaunchKernelGGL(k_svc_couple_reg<7>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, L);
     else if (A == 3) hipLaunchKernelGGL(k_svc_couple_reg<3>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, L);
     else hipLaunchKernelGGL(k_svc_couple, dim3((unsigned)((total + 63) / 64)), dim3(64), lds_cpl, s, L);
