@@ -36,12 +36,28 @@ __global__ __launch_bounds__(256) void k_pack_bits(const int8_t* X, int64_t N, i
   const int64_t Cp = C + 2 * ctx;
   const int8_t* x = X + n * ldx;
   uint32_t lo = 0, hi = 0;
-  for (int b = 0; b < 32; ++b) {
-    const int64_t p = wd * 32 + b;
-    if (p < Cp) {
-      const uint32_t v = (uint32_t)(uint8_t)x[pad_src(p, C, ctx)];
-      lo |= (v & 1u) << b;
-      hi |= ((v >> 1) & 1u) << b;
+  const int64_t p0 = wd * 32;
+  if (p0 >= ctx && p0 + 32 <= ctx + C) {
+    // interior word: 32 consecutive SNPs = 32 consecutive bytes (any alignment); bit k of every byte of a 64-bit group is
+    // gathered into one byte by the multiply (the eight partial products land on distinct bits: no carries)
+    const int8_t* src = x + (p0 - ctx);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned long long v;
+      __builtin_memcpy(&v, src + 8 * q, 8);
+      const unsigned long long b0 = ((v & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56;
+      const unsigned long long b1 = (((v >> 1) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56;
+      lo |= (uint32_t)b0 << (8 * q);
+      hi |= (uint32_t)b1 << (8 * q);
+    }
+  } else {
+    for (int b = 0; b < 32; ++b) {
+      const int64_t p = p0 + b;
+      if (p < Cp) {
+        const uint32_t v = (uint32_t)(uint8_t)x[pad_src(p, C, ctx)];
+        lo |= (v & 1u) << b;
+        hi |= ((v >> 1) & 1u) << b;
+      }
     }
   }
   planes[(n * 2 + 0) * nwp + wd] = lo;
