@@ -352,14 +352,18 @@ __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
 
   const double* dual = L.coef + win.coef_off;
   // kernel value of the lane's query against support vector `sv` (wave-uniform): substring counts by AND-shift doubling
-  auto kernel_value = [&](int sv) -> uint32_t {
-    const uint32_t* yb = L.svbits + win.sv_off + (size_t)sv * 2 * NW;  // wave-uniform
+  struct SvWords { uint32_t w[2 * NWT]; };  // a support vector's two bit-planes: wave-uniform, i.e. scalar registers
+  auto load_sv = [&](int sv) -> SvWords {
+    const uint32_t* yb = L.svbits + win.sv_off + (size_t)sv * 2 * NW;
+    SvWords y;
+#pragma unroll
+    for (int i = 0; i < 2 * NWT; ++i) y.w[i] = yb[i];
+    return y;
+  };
+  auto kernel_value_of = [&](const SvWords& y) -> uint32_t {
     BitVec<NWT> e;
 #pragma unroll
-    for (int i = 0; i < NWT; ++i) {
-      const uint32_t yl = (i < NW) ? yb[i] : 0u, yh = (i < NW) ? yb[NW + i] : 0u;
-      e.w[i] = ~((xl.w[i] ^ yl) | (xh.w[i] ^ yh)) & valid.w[i];
-    }
+    for (int i = 0; i < NWT; ++i) e.w[i] = ~((xl.w[i] ^ y.w[i]) | (xh.w[i] ^ y.w[NW + i])) & valid.w[i];
     uint32_t K = pop(e);                                              // m = 1
     const BitVec<NWT> r2 = band(e, shr<NWT, 1>(e));
     const BitVec<NWT> r4 = band(r2, shr<NWT, 2>(r2));
@@ -387,11 +391,18 @@ __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
     }
     return K;
   };
+  auto kernel_value = [&](int sv) -> uint32_t { return kernel_value_of(load_sv(sv)); };
   if constexpr (AT > 0) {
 #pragma unroll
     for (int c = 0; c < AT; ++c) {
-      for (int sv = win.cls_start[c]; sv < win.cls_start[c + 1]; ++sv) {
-        const double Kd = (double)kernel_value(sv);
+      // the NEXT support vector's words are requested before this one is evaluated (index clamped: always a valid address), so the
+      // scalar-load latency is not paid at the top of every trip
+      const int sv_end = win.cls_start[c + 1];
+      SvWords ycur = load_sv(min(win.cls_start[c], n_sv - 1));
+      for (int sv = win.cls_start[c]; sv < sv_end; ++sv) {
+        const SvWords ynext = load_sv(min(sv + 1, n_sv - 1));
+        const double Kd = (double)kernel_value_of(ycur);
+        ycur = ynext;
 #pragma unroll
         for (int o = 0; o < AT; ++o) {
           if (o == c) continue;
