@@ -398,9 +398,17 @@ __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
       // the NEXT support vector's words are requested before this one is evaluated (index clamped: always a valid address), so the
       // scalar-load latency is not paid at the top of every trip
       const int sv_end = win.cls_start[c + 1];
+      auto load_dual = [&](int sv, double (&d)[AT - 1]) {  // the vector's AT-1 dual coefficients (rows of the classes other than c)
+#pragma unroll
+        for (int r = 0; r < AT - 1; ++r) d[r] = dual[(size_t)r * n_sv + sv];
+      };
       SvWords ycur = load_sv(min(win.cls_start[c], n_sv - 1));
+      double dcur[AT - 1];
+      load_dual(min(win.cls_start[c], n_sv - 1), dcur);
       for (int sv = win.cls_start[c]; sv < sv_end; ++sv) {
         const SvWords ynext = load_sv(min(sv + 1, n_sv - 1));
+        double dnext[AT - 1];
+        load_dual(min(sv + 1, n_sv - 1), dnext);
         const double Kd = (double)kernel_value_of(ycur);
         ycur = ynext;
 #pragma unroll
@@ -408,8 +416,10 @@ __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
           if (o == c) continue;
           const int row = (o > c) ? o - 1 : o;
           const int p = (o > c) ? (c * (2 * AT - c - 1) / 2 + (o - c - 1)) : (o * (2 * AT - o - 1) / 2 + (c - o - 1));
-          decr[p] += dual[(size_t)row * n_sv + sv] * Kd;   // libsvm's order: class-major, SV order inside a class
+          decr[p] += dcur[row] * Kd;   // libsvm's order: class-major, SV order inside a class
         }
+#pragma unroll
+        for (int r = 0; r < AT - 1; ++r) dcur[r] = dnext[r];
       }
     }
   } else {
