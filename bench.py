@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline core-seconds budget scale (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="host-pointer (PCIe-inclusive) passes at N=1 (0 = skip)")
+    ap.add_argument("--vcf-reps", type=int, default=2, help="file-to-file passes (VCF text in, .msp/.fb out) at N=1 (0 = skip)")
+    ap.add_argument("--vcf-dir", default="", help="where the synthetic VCF and the outputs go (default: /dev/shm when it has room, else a temp dir)")
     ap.add_argument("--seed", type=int, default=94305)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -238,6 +240,13 @@ def main():
         except Exception as e:  # the headline line must still print
             res["e2e"] = {"error": repr(e)}
 
+    # ---- file to file: synthetic phased VCF -> .msp / .fb through the command line's own run_inference (never `value`) ----
+    if rank == 0 and world == 1 and args.vcf_reps > 0:
+        try:
+            res["e2e_vcf"] = _e2e_vcf(args, model, data, X, out)
+        except Exception as e:
+            res["e2e_vcf"] = {"error": repr(e)}
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         res["cpu_baseline"] = _cpu_baseline(args, data, X, out)
     if dist is not None:
@@ -285,6 +294,86 @@ def _e2e(model, X, steps, out_dev):
     res["e2e_haplotypes_per_s"] = max(v["haplotypes_per_s"] for v in res.values() if isinstance(v, dict) and "haplotypes_per_s" in v)
     res["note"] = "host pointers in and out (page-locked arrays), probabilities f32 + labels i32 out, PCIe both ways included; never `value`"
     return res
+
+
+def _e2e_vcf(args, model, data, X, out_dev):
+    """`north_star`: "throughput on synthetic phased VCFs".  The batch of the headline run is written as a phased VCF (GT-only
+    records, '.' for missing calls; outside the timed region), then gnomix_amd.cli.run_inference — the command line's own
+    function — takes it from TEXT to query_results.msp / .fb: native parse on every host core -> 2-bit rows over PCIe -> X built
+    in HBM -> base + smoother -> native formatting.  Also timed: the whole command line as a fresh process."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    from gnomix_amd import HipGnomix, cli, synth, vcfio
+    N, C = X.shape
+    ns = N // 2
+    rng = np.random.RandomState(7)
+    data.snp_pos = (16_050_000 + np.cumsum(rng.randint(1, 180, size=C))).astype(np.int64)
+    data.snp_ref = rng.choice(list("ACGT"), size=C)
+    data.snp_alt = rng.choice(list("ACGT"), size=C)
+    data.gen_map_pos = np.array([16_000_000, 30_000_000, 52_000_000])
+    data.gen_map_cm = np.array([0.0, 31.5, 74.1])
+    need = 4 * ns * C + (64 << 20) + N * model.W * model.A * 14
+    root = args.vcf_dir
+    if not root:
+        root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need else tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="gnx_e2e_", dir=root)
+    try:
+        ctx = model.ctx
+        # X (HBM) -> variant-major 2-bit rows -> text
+        ldg = (N + 15) // 16 * 4
+        cols = torch.arange(C, dtype=torch.int32, device=X.device)
+        Gd = torch.zeros((C, ldg), dtype=torch.uint8, device=X.device)
+        model._bind_torch_stream()
+        ctx.check(ctx.lib.gnx_x_to_gt2_dev(ctx.h, X.data_ptr(), N, X.stride(0), 0, cols.data_ptr(), C, Gd.data_ptr(), ldg))
+        torch.cuda.synchronize()
+        G = Gd.cpu().numpy()
+        del Gd
+        vcf_path = os.path.join(work, "query.vcf")
+        t0 = time.perf_counter()
+        synth.write_vcf_gt2(vcf_path, G, ns, data.snp_pos, data.snp_ref, data.snp_alt, chrom="22")
+        t_gen = time.perf_counter() - t0
+        vcf_bytes = os.path.getsize(vcf_path)
+        del G
+        gm = HipGnomix(data, ctx=ctx)
+        base_args = {"query_file": vcf_path, "chm": "22", "output_basename": work, "phase": False}
+        reps = []
+        for r in range(args.vcf_reps):
+            T = {}
+            t0 = time.perf_counter()
+            cli.run_inference(base_args, gm, verbose=False, timings=T)
+            T["total"] = time.perf_counter() - t0
+            reps.append(T)
+        best = min(reps, key=lambda t: t["total"])
+        msp = open(os.path.join(work, "query_results.msp")).read().split("\n")[2:2 + model.W]
+        lab_file = np.stack([np.array(ln.split("\t")[6:], dtype=np.int32) for ln in msp], axis=1)
+        same = bool(np.array_equal(lab_file, out_dev[1].cpu().numpy()))
+        fb_bytes = os.path.getsize(os.path.join(work, "query_results.fb"))
+        msp_bytes = os.path.getsize(os.path.join(work, "query_results.msp"))
+        res = {"haplotypes_per_s": N / best["total"], "seconds": best["total"], "stages_s": {k: round(v, 4) for k, v in best.items()},
+               "first_pass_s": round(reps[0]["total"], 4), "vcf_GB": vcf_bytes / 1e9, "parse_GBps": vcf_bytes / best["read_vcf"] / 1e9,
+               "write_MBps": (fb_bytes + msp_bytes) / (best["write_fb"] + best["write_msp"]) / 1e6, "fb_MB": fb_bytes / 1e6,
+               "host_threads": len(os.sched_getaffinity(0)), "vcf_written_s": round(t_gen, 3), "dir": root,
+               "msp_labels_equal_device_path": same,
+               "note": "chr22 x %d samples as VCF TEXT in, query_results.msp + .fb out, through gnomix_amd.cli.run_inference; best of %d passes in "
+                       "this process (first_pass_s includes page-locked allocations and the worker pool's start); never `value`" % (ns, len(reps))}
+        # the whole command line as a fresh process: interpreter + library + gnx_init + model load + the above
+        try:
+            mp = os.path.join(work, "model.gnx")
+            data.save(mp)
+            outdir = os.path.join(work, "cli")
+            t0 = time.perf_counter()
+            rc = subprocess.call([sys.executable, os.path.join(ROOT, "gnomix.py"), vcf_path, outdir, "22", "False", mp],
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, cwd=work)
+            dt = time.perf_counter() - t0
+            same_cli = rc == 0 and open(os.path.join(outdir, "query_results.msp")).read() == open(os.path.join(work, "query_results.msp")).read()
+            res["cli_process"] = {"wall_s": round(dt, 3), "haplotypes_per_s": N / dt, "rc": rc, "msp_identical": bool(same_cli)}
+        except Exception as e:
+            res["cli_process"] = {"error": repr(e)}
+        return res
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def _cpu_baseline(args, data, X, out_dev):

@@ -73,6 +73,13 @@ class GbtParams(C.Structure):
                 ("base_score", C.c_double)]
 
 
+class VcfInfo(C.Structure):
+    _fields_ = [("n_variants", C.c_int64), ("n_samples", C.c_int64), ("ldg", C.c_int64), ("file_bytes", C.c_int64),
+                ("text_bytes", C.c_int64), ("n_fast_lines", C.c_int64), ("n_general_lines", C.c_int64), ("n_overflow", C.c_int64),
+                ("seconds_load", C.c_double), ("seconds_index", C.c_double), ("seconds_parse", C.c_double),
+                ("n_threads", C.c_int32), ("compression", C.c_int32), ("region_fallback", C.c_int32), ("gt2_pinned", C.c_int32)]
+
+
 class ModelInfo(C.Structure):
     _fields_ = [("C", C.c_int64), ("M", C.c_int64), ("ctx", C.c_int64), ("W", C.c_int64), ("A", C.c_int32),
                 ("S", C.c_int32), ("base_kind", C.c_int32), ("smooth_kind", C.c_int32), ("n_trees", C.c_int32),
@@ -117,12 +124,37 @@ SYMBOLS = {
     "gnx_fit_isotonic_f32": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP]),
     "gnx_train_gbt": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
     "gnx_train_gbt_dev": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
+    # include/gnomix_io.h: the file side
+    "gnx_io_last_error": (C.c_char_p, []),
+    "gnx_vcf_read": (C.c_int, [_VP, C.c_char_p, C.c_char_p, _I, C.POINTER(_VP)]),
+    "gnx_vcf_free": (None, [_VP]),
+    "gnx_vcf_get_info": (C.c_int, [_VP, C.POINTER(VcfInfo)]),
+    "gnx_vcf_gt2": (_VP, [_VP]),
+    "gnx_vcf_pos": (_VP, [_VP]),
+    "gnx_vcf_qual": (_VP, [_VP]),
+    "gnx_vcf_strings": (C.c_int, [_VP, _I, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_I64)]),
+    "gnx_vcf_gt_int8": (C.c_int, [_VP, _VP, _I]),
+    "gnx_gt2_to_x_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),
+    "gnx_x_to_gt2_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),
+    "gnx_infer_gt2": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _VP, _VP, _VP]),
+    "gnx_phase_gt2": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, C.c_int32, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP]),
+    "gnx_write_msp": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I64, _I64, _I64, _I]),
+    "gnx_write_fb": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I, _I64, _I64, _I64, _I]),
+    "gnx_write_vcf_gt2": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I64, _I64, _I64, _I, _I]),
+    "gnx_write_phased_vcf": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I]),
+    "gnx_format_floats": (C.c_int, [_VP, _I, _I64, _VP, _VP]),
     "gnx_profile_enable": (C.c_int, [_VP, _I]),
     "gnx_profile_reset": (C.c_int, [_VP]),
     "gnx_profile_get": (C.c_int, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None
+
+
+def io_check(rc):
+    """return code of a context-free entry point of include/gnomix_io.h -> GnxError with the thread's message"""
+    if rc != GNX_OK:
+        raise GnxError(rc, load().gnx_io_last_error().decode(errors="replace"))
 
 
 def load():

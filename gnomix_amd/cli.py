@@ -40,38 +40,57 @@ def load_model(path_to_model, device=0, verbose=True):
     return HipGnomix(from_reference_model(ref_model), device=device)
 
 
-def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False):
-    """gnomix.py:37-100 with the HIP model behind the same calls"""
+def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False, timings=None):
+    """gnomix.py:37-100 with the HIP model behind the same steps.  The query never becomes an (N, C) host matrix: the library
+    parses the text into 2-bit rows (gnx_vcf_read), `column_map` keeps vcf_to_npy's bookkeeping (SNP intersection, REF flips,
+    absent SNPs) as one int32 per model SNP, the GPU builds X and runs base + smoother (or Gnofix) on it, and the library
+    formats .msp / .fb / the phased VCF.  `timings` (a dict) receives the seconds of each stage."""
+    from time import perf_counter as clock
     from . import postprocess as pp
     from . import vcfio
     query_file, chm, output_path = base_args["query_file"], base_args["chm"], base_args["output_basename"]
+    T = timings if timings is not None else {}
     if verbose:
         print("Loading and processing query file...")
-    vcf = vcfio.read_vcf(query_file, chm=chm)
-    X, vcf_idx, fmt_idx = vcfio.vcf_to_npy(vcf, model.snp_pos, model.snp_ref, return_idx=True, verbose=verbose)
+    t0 = clock()
+    vcf = vcfio.read_vcf(query_file, chm=chm, ctx=model.dev.ctx)
+    assert vcf is not None, "No SNPs of specified chromosome found in query file."
+    T["read_vcf"] = clock() - t0
+    t0 = clock()
+    src, vcf_idx, fmt_idx = vcfio.column_map(vcf, model.snp_pos, model.snp_ref, verbose=verbose)
+    N = 2 * vcf.n_samples
+    T["column_map"] = clock() - t0
     if verbose:
         print("Inferring ancestry on query data...")
-    B = model.base.predict_proba(X)
+    t0 = clock()
+    out = (model.dev.ctx.pinned_empty((N, model.W, model.A), model.dev.proba_dtype()), model.dev.ctx.pinned_empty((N, model.W), np.int32))
     if not base_args["phase"]:
-        proba = model.smooth.predict_proba(B)
-        labels = np.argmax(proba, axis=-1)
+        proba, labels = model.dev.infer_gt2(vcf.gt2, N, src, out=out)
+        T["infer"] = clock() - t0
     else:
-        X_phased, labels = model.phase(X, B=B)
+        assert model.smooth is not None, "Smoother is not trained, returning original haplotypes"
+        assert model.smooth.gnofix, "Type of Smoother ({}) does not currently support re-phasing".format(model.smooth)
+        G_phased, proba, labels, _ = model.dev.phase_gt2(vcf.gt2, N, src, out_cols=fmt_idx, out=out)
+        T["phase"] = clock() - t0
         if verbose:
             print("Writing phased SNPs to disk...")
-        upd = {"variants/REF": np.asarray(model.snp_ref)[fmt_idx],
-               "variants/ALT": np.asarray(model.snp_alt)[fmt_idx].reshape(len(fmt_idx), 1)}
-        vcf_ph = vcfio.update_vcf(vcf, mask=vcf_idx, Updates=upd)
-        vcfio.npy_to_vcf(vcf_ph, X_phased[:, fmt_idx], output_path + "/" + "query_file_phased",
-                         headers=vcfio.read_headers(query_file))
-        proba = model.predict_proba(X_phased)
+        t0 = clock()
+        rows = np.asarray(vcf_idx) if vcf.rows is None else np.asarray(vcf.rows)[vcf_idx]
+        vcfio.write_phased_vcf(vcf, rows, G_phased, output_path + "/" + "query_file_phased", ref=np.asarray(model.snp_ref)[fmt_idx],
+                               alt=np.asarray(model.snp_alt)[fmt_idx], headers=vcf.meta_header)
+        T["write_vcf"] = clock() - t0
     if verbose:
         print("Saving results...")
+    t0 = clock()
     gm_pos, gm_cm = model.data.gen_map_pos, model.data.gen_map_cm
     meta = pp.get_meta_data(chm, model.snp_pos, vcf["variants/POS"], model.W, model.M, gm_pos, gm_cm)
     out_prefix = output_path + "/" + "query_results"
-    pp.write_msp(out_prefix, meta, labels, model.population_order, vcf["samples"])
-    pp.write_fb(out_prefix, meta, proba, model.population_order, vcf["samples"])
+    samples = vcf["samples"]
+    pp.write_msp(out_prefix, meta, labels, model.population_order, samples)
+    T["write_msp"] = clock() - t0
+    t0 = clock()
+    pp.write_fb(out_prefix, meta, proba, model.population_order, samples)
+    T["write_fb"] = clock() - t0
     if snp_level:
         pp.msp_to_lai(out_prefix + ".msp", vcf["variants/POS"], out_prefix + ".lai")
     if bed_file_output:

@@ -15,10 +15,11 @@
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
-static int fail(gnx_ctx* ctx, int code, const std::string& msg) {
+int gnx_fail(gnx_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   return code;
 }
+static inline int fail(gnx_ctx* ctx, int code, const std::string& msg) { return gnx_fail(ctx, code, msg); }
 
 #define HIPCHK(ctx, expr)                                                                      \
   do {                                                                                         \
@@ -27,6 +28,8 @@ static int fail(gnx_ctx* ctx, int code, const std::string& msg) {
       return fail((ctx), GNX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
   } while (0)
 
+static int ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes);
+int gnx_ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes) { return ws_reserve(ctx, b, bytes); }
 static int ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes) {
   if (bytes <= b.cap) return GNX_OK;
   if (b.p) {
@@ -817,7 +820,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
   if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
-  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi})
+  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi, &ctx->ws_gt2, &ctx->ws_src, &ctx->ws_gt2o})
     if (b->p) (void)hipFree(b->p);
   for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal, &ctx->ws_marg})
     if (b->p) (void)hipFree(b->p);
@@ -1725,3 +1728,5 @@ int gnx_profile_get(gnx_ctx* ctx, int kid, double* total_ms, int64_t* launches) 
 }
 
 }  // extern "C"
+
+int gnx_pipe_init(gnx_ctx* ctx) { return pipe_init(ctx); }

@@ -73,6 +73,7 @@ struct gnx_ctx {
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   gnx_devbuf ws_pk, ws_xu, ws_psi;
+  gnx_devbuf ws_gt2, ws_src, ws_gt2o;  // file path (gnx_api_vcf.hip): variant-major 2-bit genotypes, column map, phased rows
   // profiling
   bool prof = false;
   std::vector<gnx_prof_pair> prof_pending;
@@ -336,7 +337,16 @@ struct gnx_model {
   bool calib_f32 = false;
 };
 
+// shared with gnx_api_vcf.hip (defined in gnx_api.hip)
+int gnx_fail(gnx_ctx* ctx, int code, const std::string& msg);
+int gnx_ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes);
+int gnx_pipe_init(gnx_ctx* ctx);
+
 // kernel launchers (defined in the .hip files)
+hipError_t gnx_launch_gt2_to_x(const uint8_t* G, int64_t V, int64_t ldg, int64_t n0, int64_t N, const int32_t* src, int64_t C,
+                               int8_t* X, int64_t ldx, hipStream_t s);
+hipError_t gnx_launch_x_to_gt2(const int8_t* X, int64_t N, int64_t ldx, int64_t n0, const int32_t* cols, int64_t V, uint8_t* G,
+                               int64_t ldg, hipStream_t s);
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);

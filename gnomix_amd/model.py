@@ -332,6 +332,11 @@ class DeviceModel:
                                                    lab.ctypes.data if want_labels else None))
         return p, lab
 
+    def proba_dtype(self):
+        """dtype of the probabilities this model's smoother returns: float64 for CRF and for calibrated output, else float32"""
+        native64 = self.data.smooth_kind == "crf" or getattr(self, "calibrated", False)
+        return np.dtype(np.float64 if native64 else np.float32)
+
     def _outs(self, N, want_proba, want_labels, proba_dtype, out):
         """output arrays of the host-pointer entry points; `out=(proba, labels)` lets the caller supply them (e.g. page-locked
         arrays from Context.pinned_empty, reused across calls: D2H then runs at link rate instead of through pageable staging)"""
@@ -384,6 +389,8 @@ class DeviceModel:
         if P.ndim != 2 or P.shape[1] < (self.C + 3) // 4:
             raise ValueError(f"packed X must be (N, >= ceil(C/4) = {(self.C + 3) // 4}) uint8, got {P.shape}")
         N = P.shape[0] if N is None else int(N)
+        if N < 0 or N > P.shape[0]:
+            raise ValueError(f"infer_packed: N = {N} but the packed matrix has {P.shape[0]} rows")
         p, lab, pd = self._outs(N, want_proba, want_labels, proba_dtype, out)
         want_proba, want_labels = p is not None, lab is not None
         p32 = p.ctypes.data if (want_proba and pd == np.float32) else None
@@ -391,6 +398,52 @@ class DeviceModel:
         self.ctx.check(self.lib.gnx_infer_packed(self.h, P.ctypes.data, N, P.shape[1], p32, p64,
                                                  lab.ctypes.data if want_labels else None))
         return p, lab
+
+    # ---- the file path: parsed VCF rows (variant-major 2-bit, include/gnomix_io.h) straight to the outputs --------------------
+    def _gt2_args(self, G, N, src):
+        G = np.asarray(G)
+        if G.dtype != np.uint8 or G.ndim != 2 or not G.flags.c_contiguous:
+            raise ValueError("G must be a C-contiguous uint8 (n_variants, ldg) array of 2-bit genotype rows")
+        N = int(N)
+        if N < 0 or G.shape[1] < (N + 3) // 4:
+            raise ValueError(f"G rows hold {4 * G.shape[1]} haplotypes, fewer than N = {N}")
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        if src.shape != (self.C,):
+            raise ValueError(f"src must be (C={self.C},) int32 (vcfio.column_map), got {src.shape}")
+        return G, N, src
+
+    def infer_gt2(self, G, N, src, want_proba=True, want_labels=True, proba_dtype=None, out=None):
+        """vcf_to_npy + predict_proba + argmax of gnomix.py:49-58 on the parsed query: G (n_variants, ldg) the reader's 2-bit
+        rows (VcfData.gt2), N = 2 * samples, src = vcfio.column_map(...)[0].  The (N, C) matrix exists only in HBM."""
+        G, N, src = self._gt2_args(G, N, src)
+        p, lab, pd = self._outs(N, want_proba, want_labels, proba_dtype, out)
+        want_proba, want_labels = p is not None, lab is not None
+        p32 = p.ctypes.data if (want_proba and pd == np.float32) else None
+        p64 = p.ctypes.data if (want_proba and pd == np.float64) else None
+        self.ctx.check(self.lib.gnx_infer_gt2(self.h, G.ctypes.data, G.shape[0], G.shape[1], N, src.ctypes.data, p32, p64,
+                                              lab.ctypes.data if want_labels else None))
+        return p, lab
+
+    def phase_gt2(self, G, N, src, out_cols=None, max_it=50, want_proba=True, proba_dtype=None, out=None):
+        """gnomix.py:60-72 (phase=True) on the parsed query: Gnofix on every individual, then predict_proba of the re-phased
+        haplotypes.  -> (G_phased or None, proba, labels (N, W) int32, n_switches (N/2,) int32); G_phased (len(out_cols), ldg)
+        holds X_phased[:, out_cols] as 2-bit rows for the phased VCF."""
+        G, N, src = self._gt2_args(G, N, src)
+        if N % 2:
+            raise ValueError("phase_gt2: N = 2 * individuals")
+        p, lab, pd = self._outs(N, want_proba, True, proba_dtype, out)
+        p32 = p.ctypes.data if (p is not None and pd == np.float32) else None
+        p64 = p.ctypes.data if (p is not None and pd == np.float64) else None
+        nsw = np.empty((N // 2,), np.int32)
+        Go = cols = None
+        if out_cols is not None:
+            cols = np.ascontiguousarray(out_cols, dtype=np.int32)
+            Go = np.zeros((len(cols), G.shape[1]), np.uint8)
+        self.ctx.check(self.lib.gnx_phase_gt2(self.h, G.ctypes.data, G.shape[0], G.shape[1], N, src.ctypes.data, int(max_it),
+                                              cols.ctypes.data if cols is not None else None, len(cols) if cols is not None else 0,
+                                              Go.ctypes.data if Go is not None else None, G.shape[1], p32, p64, lab.ctypes.data,
+                                              nsw.ctypes.data))
+        return Go, p, lab, nsw
 
     def smooth_rows(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float32)
@@ -421,6 +474,10 @@ class DeviceModel:
         else:
             X = np.array(X, dtype=np.int8, order="C", copy=True)
         B = np.ascontiguousarray(B, dtype=np.float64)
+        if X.ndim != 2 or X.shape[1] != self.C or X.shape[0] % 2:
+            raise ValueError(f"gnofix: X must be (2n, C={self.C}), got {X.shape}")
+        if B.shape != (X.shape[0], self.W, self.A):
+            raise ValueError(f"gnofix: B must be (2n={X.shape[0]}, W={self.W}, A={self.A}), got {B.shape}")
         n_ind = X.shape[0] // 2
         if out is not None:
             Y, nsw = out

@@ -1,12 +1,16 @@
 """Writers on the output side of the hot path: window metadata, .msp, .fb (+ .lai, .bed).
 
 Mirrors the reference's src/postprocess.py:25-210 byte for byte (pinned by tests/golden/G6_writers, produced by
-running the reference's own get_meta_data / write_msp / write_fb).  numpy only; no pandas needed."""
+running the reference's own get_meta_data / write_msp / write_fb).  The two big tables (.msp labels, .fb probabilities) are
+formatted and written by the library (include/gnomix_io.h: gnx_write_msp / gnx_write_fb, all host cores); the window
+metadata (W rows) is plain numpy.  No pandas needed."""
 from __future__ import annotations
 
 import os
 
 import numpy as np
+
+from . import _lib
 
 
 def _fmt(v):
@@ -59,38 +63,50 @@ def _meta_strings(meta):
     return [[_fmt(meta[c][i]) for c in META_COLUMNS] for i in range(n)]
 
 
-def write_msp(msp_prefix, meta_data, pred_labels, populations, query_samples):
-    """<prefix>.msp (postprocess.py:84-98): pred_labels (N, W) ints, haplotype columns sample.0 / sample.1"""
-    rows = _meta_strings(meta_data)
-    lab = np.asarray(pred_labels)
-    with open(msp_prefix + ".msp", "w") as f:
-        f.write("#Subpopulation order/codes: ")
-        f.write("\t".join([str(pop) + "=" + str(i) for i, pop in enumerate(populations)]) + "\n")
-        f.write("#" + "\t".join(META_COLUMNS) + "\t")
-        f.write("\t".join([str(s) for q in query_samples for s in (str(q) + ".0", str(q) + ".1")]) + "\n")
-        for l, r in enumerate(rows):
-            f.write("\t".join(r + [str(v) for v in lab[:, l]]))
-            f.write("\n")
+def _blob(rows):
+    enc = [r.encode() for r in rows]
+    off = np.zeros(len(enc) + 1, np.int64)
+    if enc:
+        np.cumsum([len(e) for e in enc], out=off[1:])
+    return b"".join(enc), off
 
 
-def write_fb(fb_prefix, meta_data, proba, ancestry, query_samples):
-    """<prefix>.fb (postprocess.py:100-126): proba (N, W, A); float32 values are printed with their shortest repr"""
+def write_msp(msp_prefix, meta_data, pred_labels, populations, query_samples, n_threads=0):
+    """<prefix>.msp (postprocess.py:84-98): pred_labels (N, W) ints, haplotype columns sample.0 / sample.1.  The header and
+    the W metadata prefixes are built here; the N x W label text is produced by the library on all host cores."""
+    rows = ["\t".join(r) for r in _meta_strings(meta_data)]
+    lab = np.ascontiguousarray(pred_labels, dtype=np.int32)
+    head = "#Subpopulation order/codes: " + "\t".join([str(pop) + "=" + str(i) for i, pop in enumerate(populations)]) + "\n"
+    head += "#" + "\t".join(META_COLUMNS) + "\t"
+    head += "\t".join([str(s) for q in query_samples for s in (str(q) + ".0", str(q) + ".1")]) + "\n"
+    head = head.encode()
+    pb, po = _blob(rows)
+    if lab.ndim != 2 or lab.shape[1] != len(rows):
+        raise ValueError(f"pred_labels must be (N, W={len(rows)}), got {lab.shape}")
+    _lib.io_check(_lib.load().gnx_write_msp((msp_prefix + ".msp").encode(), head, len(head), pb, po.ctypes.data, lab.ctypes.data,
+                                            lab.shape[0], lab.shape[1], lab.shape[1], int(n_threads)))
+
+
+def write_fb(fb_prefix, meta_data, proba, ancestry, query_samples, n_threads=0):
+    """<prefix>.fb (postprocess.py:100-126): proba (N, W, A); every value is printed as pandas' to_csv prints a float column
+    (numpy's shortest round-trip text of the array's dtype) — by the library, W rows in parallel."""
     proba = np.asarray(proba)
+    if proba.dtype not in (np.float32, np.float64):
+        proba = proba.astype(np.float64)
+    proba = np.ascontiguousarray(proba)
     n_rows = len(meta_data["spos"])
+    if proba.ndim != 3 or proba.shape[1] != n_rows:
+        raise ValueError(f"proba must be (N, W={n_rows}, A), got {proba.shape}")
     se = np.stack([np.asarray(meta_data["spos"]).astype(int), np.asarray(meta_data["epos"]).astype(int)], axis=1)
     pp = np.round(np.mean(se, axis=1)).astype(int)
     gp = np.mean(np.stack([np.asarray(meta_data["sgpos"], dtype=float), np.asarray(meta_data["egpos"], dtype=float)], 1), axis=1)
     header = ["chromosome", "physical position", "genetic_position", "genetic_marker_index"]
     header += [":::".join([str(q), h, str(a)]) for q in query_samples for h in ["hap1", "hap2"] for a in ancestry]
-    fb_prob = np.swapaxes(proba, 1, 2).reshape(-1, n_rows).T  # (W, N*A)
-    with open(fb_prefix + ".fb", "w") as f:
-        f.write("#reference_panel_population:\t")
-        f.write("\t".join([str(a) for a in ancestry]) + "\n")
-        f.write("\t".join(header) + "\n")
-        for r in range(n_rows):
-            vals = [str(meta_data["chm"][r]), str(pp[r]), _fmt(np.float64(gp[r])), "."]
-            vals += [_fmt(v) for v in fb_prob[r]]
-            f.write("\t".join(vals) + "\n")
+    head = ("#reference_panel_population:\t" + "\t".join([str(a) for a in ancestry]) + "\n" + "\t".join(header) + "\n").encode()
+    rows = ["\t".join([str(meta_data["chm"][r]), str(pp[r]), _fmt(np.float64(gp[r])), "."]) for r in range(n_rows)]
+    pb, po = _blob(rows)
+    _lib.io_check(_lib.load().gnx_write_fb((fb_prefix + ".fb").encode(), head, len(head), pb, po.ctypes.data, proba.ctypes.data,
+                                           int(proba.dtype == np.float64), proba.shape[0], n_rows, proba.shape[2], int(n_threads)))
 
 
 def msp_to_lai(msp_file, positions, lai_file=None):

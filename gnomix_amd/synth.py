@@ -277,3 +277,25 @@ def synthetic_phased_individuals(n_ind, W, A, seed=0, mean_segments=3, phase_err
             bm, bp = np.concatenate([bm[:s], bp[s:]]), np.concatenate([bp[:s], bm[s:]])
         B[2 * i], B[2 * i + 1] = bm, bp
     return B
+
+
+def write_vcf_gt2(path, G, n_samples, pos, ref, alt, chrom="22", samples=None, missing_as_dot=True, n_threads=0):
+    """A synthetic phased query VCF ("throughput on synthetic phased VCFs", BASELINE.json): G (n_variants, ldg) variant-major
+    2-bit rows (include/gnomix_io.h; vcfio.pack_gt2 makes them from an (N, V) matrix, DeviceModel / gnx_x_to_gt2_dev from X in
+    HBM), one record per variant `chrom pos . ref alt . PASS . GT a|b ...`; the text is produced by the library's VCF writer."""
+    import ctypes as C
+    from . import _lib
+    G = np.ascontiguousarray(G, np.uint8)
+    V = G.shape[0]
+    names = samples if samples is not None else ["S%d" % i for i in range(n_samples)]
+    head = ("##fileformat=VCFv4.2\n##source=gnomix_amd.synth\n##contig=<ID=%s>\n" % chrom +
+            '##FORMAT=<ID=GT,Number=1,Type=String,Description="Phased Genotype">\n' +
+            "#" + "\t".join(["CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"] + [str(s) for s in names]) + "\n").encode()
+    pre = [("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT" % (chrom, p, r, a)).encode() for p, r, a in zip(np.asarray(pos).tolist(), ref, alt)]
+    off = np.zeros(V + 1, np.int64)
+    if V:
+        np.cumsum([len(e) for e in pre], out=off[1:])
+    blob = b"".join(pre)
+    _lib.io_check(_lib.load().gnx_write_vcf_gt2(str(path).encode(), head, len(head), blob, off.ctypes.data, G.ctypes.data, V, G.shape[1],
+                                                int(n_samples), int(bool(missing_as_dot)), int(n_threads)))
+    return str(path)

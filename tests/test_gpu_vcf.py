@@ -1,0 +1,157 @@
+"""-m gpu: the file path on the device (include/gnomix_io.h): gt2 <-> X kernels against their numpy statement, and the
+pipelines  parsed VCF -> outputs  against the reference's own sequence vcf_to_npy -> predict_proba / phase
+(gnomix.py:48-72) run through the int8 entry points.  Bar: bit-identical (integers and the same kernels behind both)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import gnomix_amd
+    gnomix_amd.load_library()
+    return gnomix_amd
+
+
+def _rows(rng, V, N, p3=0.02):
+    """random variant-major 2-bit rows with a canonical stride; tail fields zero"""
+    code = rng.choice(4, size=(V, N), p=[0.45, 0.45, 0.1 - p3, p3]).astype(np.uint8)
+    ldg = (N + 15) // 16 * 4
+    pad = np.zeros((V, ldg * 4), np.uint8)
+    pad[:, :N] = code
+    q = pad.reshape(V, ldg, 4)
+    return (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8), code
+
+
+def _x_from(code, src):
+    """numpy statement of k_gt2_to_x (= vcf_to_npy's fill / flip / missing rule, src/utils.py:125-151)"""
+    N = code.shape[1]
+    X = np.full((N, len(src)), 2, np.int8)
+    have = src >= 0
+    v, flip = src[have] & 0x3FFFFFFF, (src[have] >> 30) & 1
+    c = code[v].T.astype(np.int8)
+    X[:, have] = np.where(c >= 2, 2, np.where(flip[None, :] == 1, 1 - c, c))
+    return X
+
+
+@pytest.mark.parametrize("V,N,C,ldx_extra,n0", [(300, 70, 257, 0, 0), (64, 1030, 64, 0, 0), (500, 2100, 1037, 27, 0), (200, 48, 130, 62, 16),
+                                                (200, 52, 131, 5, 4), (90, 6, 1, 0, 0), (1500, 4096 + 20, 300, 212, 1024)])
+def test_gt2_to_x_and_back(ga, V, N, C, ldx_extra, n0):
+    import torch
+    from gnomix_amd import _lib
+    rng = np.random.default_rng(V * N + C)
+    G, code = _rows(rng, V, N)
+    src = rng.integers(0, V, C).astype(np.int32)
+    src |= (rng.random(C) < 0.2).astype(np.int32) << 30
+    src[rng.random(C) < 0.15] = -1
+    ctx = _lib.default_context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ldg = G.shape[1]
+    n = N - n0
+    ldx = (C + ldx_extra) if ldx_extra else (C + 63) // 64 * 64
+    Gd = torch.from_numpy(G).cuda()
+    sd = torch.from_numpy(src).cuda()
+    Xd = torch.full((n * ldx + 64,), 9, dtype=torch.int8, device="cuda")
+    base = Xd.data_ptr() + (0 if ldx % 16 == 0 else 3)      # a misaligned buffer takes the byte-store variant
+    ctx.check(ctx.lib.gnx_gt2_to_x_dev(ctx.h, Gd.data_ptr(), V, ldg, n0, n, sd.data_ptr(), C, base, ldx))
+    torch.cuda.synchronize()
+    off = base - Xd.data_ptr()
+    got = Xd[off:off + n * ldx].cpu().numpy().reshape(n, ldx)
+    want = _x_from(code, src)[n0:]
+    assert np.array_equal(got[:, :C], want)
+    assert (got[:, C:] == 9).all() and (Xd[off + n * ldx:].cpu().numpy() == 9).all()      # nothing outside [0, C) of a row
+    # the way back: columns `cols` of X as 2-bit rows
+    cols = np.sort(rng.choice(C, max(1, C // 2), replace=False)).astype(np.int32)
+    cd = torch.from_numpy(cols).cuda()
+    Go = torch.zeros((len(cols), ldg), dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.gnx_x_to_gt2_dev(ctx.h, base, n, ldx, n0, cd.data_ptr(), len(cols), Go.data_ptr(), ldg))
+    torch.cuda.synchronize()
+    Gh = Go.cpu().numpy()
+    back = np.stack([(Gh[:, h // 4] >> (2 * (h % 4))) & 3 for h in range(N)], axis=0).astype(np.int8)     # (N, len(cols))
+    assert np.array_equal(back[n0:], want[:, cols]) and not back[:n0].any()
+    # argument checks
+    assert ctx.lib.gnx_gt2_to_x_dev(ctx.h, Gd.data_ptr(), V, ldg, 2, n, sd.data_ptr(), C, base, ldx) == _lib.GNX_EINVAL
+    assert ctx.lib.gnx_gt2_to_x_dev(ctx.h, Gd.data_ptr(), V, ldg, 0, 4 * ldg + 1, sd.data_ptr(), C, base, ldx) == _lib.GNX_EINVAL
+    ctx.reset_stream()
+
+
+def _query(tmp_path, d, n_ind, rng, drop=200, flip_frac=0.05, miss=0.02):
+    """a model with SNP metadata + a query VCF that lacks `drop` model SNPs, has extra SNPs of its own, REF mismatches and
+    missing calls; returns (vcf path, the matrix the reference's vcf_to_npy builds from it)"""
+    from gnomix_amd import synth, vcfio
+    d.snp_pos = np.sort(rng.choice(np.arange(10_000, 9_000_000), size=d.C, replace=False))
+    d.snp_ref = rng.choice(list("ACGT"), size=d.C)
+    d.snp_alt = rng.choice(list("ACGT"), size=d.C)
+    keep = np.sort(rng.choice(d.C, size=d.C - drop, replace=False))
+    extra = np.setdiff1d(rng.choice(np.arange(10_000, 9_000_000), size=300), d.snp_pos)
+    qpos = np.concatenate([d.snp_pos[keep], extra])
+    qref = np.concatenate([d.snp_ref[keep], rng.choice(list("ACGT"), len(extra))])
+    fl = rng.random(len(keep)) < flip_frac
+    qref[:len(keep)][fl] = np.where(qref[:len(keep)][fl] == "A", "C", "A")
+    order = np.argsort(qpos)
+    Xq = synth.synthetic_X(2 * n_ind, len(qpos), seed=int(rng.integers(1 << 30)), miss=miss)
+    p = synth.write_vcf_gt2(str(tmp_path / "q.vcf"), vcfio.pack_gt2(Xq[:, order]), n_ind, qpos[order], qref[order], ["N"] * len(qpos), chrom="22")
+    return p
+
+
+@pytest.mark.parametrize("C,M,A,S,n_ind,smooth", [(6037, 100, 7, 21, 35, "xgb"), (4112, 100, 4, 11, 17, "xgb"), (3001, 50, 12, 75, 4, "crf"),
+                                                  (2049, 64, 3, 9, 64, "cnn")])
+def test_infer_gt2_equals_vcf_to_npy_then_infer(ga, tmp_path, monkeypatch, C, M, A, S, n_ind, smooth):
+    from gnomix_amd import synth, vcfio, _lib
+    rng = np.random.default_rng(C)
+    d = synth.synthetic_model(C=C, M=M, A=A, S=S, n_rounds=6, seed=C, smooth=smooth)
+    p = _query(tmp_path, d, n_ind, rng)
+    dev = ga.DeviceModel(d)
+    vcf = vcfio.read_vcf(p, chm="22", ctx=dev.ctx)
+    assert vcf.info.gt2_pinned == 1 and vcf.info.n_fast_lines == vcf.n_variants
+    X, vi, fi = vcfio.vcf_to_npy(vcf, d.snp_pos, d.snp_ref, return_idx=True, verbose=False)      # the reference's route
+    assert (X == 2).any() and X.shape == (2 * n_ind, C)
+    p_ref, l_ref = dev.infer(X)
+    src, vi2, fi2 = vcfio.column_map(vcf, d.snp_pos, d.snp_ref, verbose=False)
+    assert np.array_equal(vi, vi2) and np.array_equal(fi, fi2) and (src >> 30 == 1).any()
+    pr, lb = dev.infer_gt2(vcf.gt2, 2 * n_ind, src)
+    assert pr.dtype == p_ref.dtype and np.array_equal(pr, p_ref) and np.array_equal(lb, l_ref)
+    # several haplotype batches through both output halves, pageable genotype rows, labels only
+    monkeypatch.setenv("GNX_HOST_BATCH", "12")
+    ctx = _lib.Context(0)
+    dev2 = ga.DeviceModel(d, ctx=ctx)
+    pr2, lb2 = dev2.infer_gt2(np.array(vcf.gt2), 2 * n_ind, src)
+    assert np.array_equal(pr2, p_ref) and np.array_equal(lb2, l_ref)
+    none, lb3 = dev2.infer_gt2(vcf.gt2, 2 * n_ind, src, want_proba=False)
+    assert none is None and np.array_equal(lb3, l_ref)
+    bad = src.copy()
+    bad[0] = vcf.n_variants
+    with pytest.raises(_lib.GnxError):
+        dev.infer_gt2(vcf.gt2, 2 * n_ind, bad)
+    ctx.close()
+
+
+@pytest.mark.parametrize("C,M,A,n_ind,batch", [(16037, 100, 4, 9, 0), (9037, 60, 5, 14, 8)])
+def test_phase_gt2_equals_the_int8_route(ga, tmp_path, monkeypatch, C, M, A, n_ind, batch):
+    """gnomix.py:60-72: B = base.predict_proba(X); X_phased, labels = model.phase(X, B); proba = model.predict_proba(X_phased)"""
+    from gnomix_amd import synth, vcfio, _lib
+    rng = np.random.default_rng(C)
+    d = synth.synthetic_model(C=C, M=M, A=A, S=75, n_rounds=8, seed=11)
+    p = _query(tmp_path, d, n_ind, rng)
+    if batch:
+        monkeypatch.setenv("GNX_HOST_BATCH", str(batch))
+    ctx = _lib.Context(0)
+    dev = ga.DeviceModel(d, ctx=ctx)
+    vcf = vcfio.read_vcf(p, chm="22", ctx=ctx)
+    X, vi, fi = vcfio.vcf_to_npy(vcf, d.snp_pos, d.snp_ref, return_idx=True, verbose=False)
+    _, B = dev.base_predict(X)
+    Xp, Y, nsw = dev.gnofix(X, B)
+    p_ref, _ = dev.infer(Xp)
+    src, _, _ = vcfio.column_map(vcf, d.snp_pos, d.snp_ref, verbose=False)
+    Go, pr, lab, ns2 = dev.phase_gt2(vcf.gt2, 2 * n_ind, src, out_cols=fi)
+    assert np.array_equal(lab, Y) and np.array_equal(ns2, nsw) and np.array_equal(pr, p_ref)
+    back = np.stack([(Go[:, h // 4] >> (2 * (h % 4))) & 3 for h in range(2 * n_ind)], axis=0).astype(np.int8)
+    assert np.array_equal(back, Xp[:, fi])
+    assert nsw.sum() >= 0 and Go.shape == (len(fi), vcf.gt2.shape[1])
+    # a smoother that cannot re-phase is refused like src/model.py:194
+    dc = synth.synthetic_model(C=2049, M=64, A=3, S=9, n_rounds=2, seed=1, smooth="crf")
+    devc = ga.DeviceModel(dc, ctx=ctx)
+    with pytest.raises(_lib.GnxError):
+        devc.phase_gt2(np.zeros((10, 4), np.uint8), 4, np.full(2049, -1, np.int32))
+    ctx.close()

@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     import ctypes
     from gnomix_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "gnomix_hip.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include")))
+                  if f.endswith(".h"))
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)   # prototypes only: comments mention entry points in prose
     declared = set(re.findall(r"\b(gnx_[a-z_0-9]+)\s*\(", hdr))
     declared -= {"gnx_ctx", "gnx_model"}
     assert declared, "no prototypes parsed"
@@ -232,8 +234,9 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     import ctypes as C
     import subprocess
     from gnomix_amd import _lib
-    structs = {"gnx_model_desc": _lib.ModelDesc, "gnx_svc_window": _lib.SvcWindow, "gnx_model_info": _lib.ModelInfo}
-    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "gnomix_hip.h"', 'int main(void) {']
+    structs = {"gnx_model_desc": _lib.ModelDesc, "gnx_svc_window": _lib.SvcWindow, "gnx_model_info": _lib.ModelInfo,
+               "gnx_vcf_info": _lib.VcfInfo, "gnx_train_info": _lib.TrainInfo}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "gnomix_hip.h"', '#include "gnomix_io.h"', 'int main(void) {']
     for cname, ct in structs.items():
         src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
         for fname, _ in ct._fields_:

@@ -1,0 +1,333 @@
+"""The file side of the hot path on the CPU (-m "not gpu"): the library's VCF reader against the pure-Python mirror
+(oracle/vcf_text.py), its number formatting against numpy's own `.astype(str)` (what the reference's writers print through
+pandas), the .msp / .fb / phased-VCF writers against line-by-line Python restatements of src/postprocess.py:84-126 and
+src/utils.py:247-329, and vcfio.column_map against the reference-pinned vcf_to_npy (G7)."""
+import gzip
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from gnomix_amd import _lib, postprocess as pp, vcfio
+from oracle import vcf_text
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- VCF text generator covering what real files contain ---------------------------------------------------------------------
+def _vcf_text(rng, nv, ns, general_every=0, crlf=False, chroms=("22",), big_allele=0.01, haploid=0.03, unphased=0.2, miss=0.03):
+    nl = "\r\n" if crlf else "\n"
+    lines = ["##fileformat=VCFv4.2", "##contig=<ID=22>", '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("S%d" % i for i in range(ns))]
+    pos = np.sort(rng.choice(10 ** 7, nv, replace=False))
+    for v in range(nv):
+        g = rng.integers(0, 2, (ns, 2))
+        ms = rng.random((ns, 2)) < miss
+        general = general_every and v % general_every == 0
+        flds = []
+        for s in range(ns):
+            a = ["." if ms[s, h] else str(g[s, h] + (rng.integers(2, 140) if general and rng.random() < big_allele else 0)) for h in range(2)]
+            if general:
+                sep = "/" if rng.random() < unphased else "|"
+                f = a[0] if rng.random() < haploid else a[0] + sep + a[1]
+                flds.append(f + ":%d:0.5" % rng.integers(0, 99) if v % 2 else "7:" + f)
+            else:
+                flds.append(a[0] + ("/" if rng.random() < unphased * 0.1 else "|") + a[1])
+        fmt = ("GT:DP:GQ" if v % 2 else "DP:GT") if general else "GT"
+        alt = "T" if v % 7 else "T,G,C,A"
+        qual = "." if v % 5 == 0 else "%.2f" % (rng.random() * 100)
+        lines.append("\t".join([chroms[v % len(chroms)], str(pos[v]), "rs%d" % v if v % 11 else ".", "ACGT"[v % 4] if v % 13 else "ACG", alt, qual,
+                                "PASS", "AC=1;AN=2", fmt] + flds))
+    return nl.join(lines) + nl
+
+
+def _bgzf(data, block=3000):
+    """BGZF as bgzip writes it: gzip members with a BC extra field, raw deflate payload, crc32 + isize, empty EOF block"""
+    out = bytearray()
+    for o in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if o is None else data[o:o + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(payload) + 8 - 1
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+        out += payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    return bytes(out)
+
+
+def _same(a, b):
+    for k in ["calldata/GT", "variants/POS", "variants/CHROM", "variants/ID", "variants/REF", "variants/ALT", "samples"]:
+        assert np.array_equal(a[k], b[k]), k
+    qa, qb = a["variants/QUAL"], b["variants/QUAL"]
+    assert qa.dtype == np.float32 and np.array_equal(np.isnan(qa), np.isnan(qb)) and np.array_equal(qa[~np.isnan(qa)], qb[~np.isnan(qb)])
+
+
+@pytest.mark.parametrize("case", [
+    dict(nv=40, ns=1), dict(nv=97, ns=3, general_every=3), dict(nv=200, ns=8, crlf=True), dict(nv=150, ns=37, general_every=2, crlf=True),
+    dict(nv=300, ns=33, chroms=("22", "21", "22", "X")), dict(nv=64, ns=129, general_every=5), dict(nv=500, ns=16, miss=0.5)])
+@pytest.mark.parametrize("container", ["plain", "gzip", "bgzf"])
+def test_reader_equals_python_mirror(tmp_path, case, container):
+    rng = np.random.default_rng(hash(str(case)) % 2 ** 32)
+    txt = _vcf_text(rng, **case).encode()
+    p = str(tmp_path / ("q.vcf" + ("" if container == "plain" else ".gz")))
+    if container == "plain":
+        open(p, "wb").write(txt)
+    elif container == "gzip":
+        with gzip.open(p, "wb") as f:
+            f.write(txt[:len(txt) // 2])
+        with gzip.open(p, "ab") as f:           # two members: what `cat a.gz b.gz` produces
+            f.write(txt[len(txt) // 2:])
+    else:
+        open(p, "wb").write(_bgzf(txt))
+    for chm in (None, "22", "7"):
+        for nt in (1, 5):
+            a = vcfio.read_vcf(p, chm=chm, n_threads=nt)
+            b = vcf_text.read_vcf(p, chm=chm)
+            _same(a, b)
+            assert a.info.compression == {"plain": 0, "gzip": 1, "bgzf": 2}[container]
+            assert a.info.region_fallback == int(chm == "7")
+            assert a.info.n_fast_lines + a.info.n_general_lines == a.info.n_variants
+    assert vcfio.read_headers(p) == "".join(ln + "\n" for ln in txt.decode().replace("\r\n", "\n").split("\n") if ln.startswith("##")) or case.get("crlf")
+    # the 2-bit rows: codes of calldata/GT
+    a = vcfio.read_vcf(p)
+    gt = a["calldata/GT"].reshape(a.info.n_variants, -1)
+    code = np.where(gt < 0, 2, np.where(gt > 1, 3, gt)).astype(np.uint8)
+    G = a.gt2
+    got = np.stack([(G[:, h // 4] >> (2 * (h % 4))) & 3 for h in range(gt.shape[1])], axis=1)
+    assert np.array_equal(got, code)
+    used = (gt.shape[1] + 3) // 4
+    assert not G[:, used:].any() and (gt.shape[1] % 4 == 0 or not (G[:, used - 1] >> (2 * (gt.shape[1] % 4))).any())
+
+
+def test_reader_fast_path_takes_plain_gt_files(tmp_path):
+    rng = np.random.default_rng(5)
+    for ns in (1, 2, 7, 8, 9, 15, 16, 17, 40, 41):
+        p = str(tmp_path / f"f{ns}.vcf")
+        open(p, "w").write(_vcf_text(rng, 50, ns, unphased=0.0))
+        a = vcfio.read_vcf(p, n_threads=2)
+        assert a.info.n_fast_lines == 50 and a.info.n_general_lines == 0
+        _same(a, vcf_text.read_vcf(p))
+    # the same records without a final newline, and with every fixed-width record broken in one place
+    p = str(tmp_path / "nonl.vcf")
+    txt = _vcf_text(rng, 30, 12, unphased=0.0)
+    open(p, "w").write(txt.rstrip("\n"))
+    _same(vcfio.read_vcf(p), vcf_text.read_vcf(p))
+    lines = txt.rstrip("\n").split("\n")
+    for k, bad in enumerate(["1", "0:1", "10|1", "0|"]):
+        t = lines[4 + k].split("\t")
+        t[9 + k] = bad
+        lines[4 + k] = "\t".join(t)
+    open(p, "w").write("\n".join(lines) + "\n")
+    a = vcfio.read_vcf(p)
+    assert a.info.n_general_lines >= 3
+    _same(a, vcf_text.read_vcf(p))
+
+
+def test_reader_errors_are_reported_not_swallowed(tmp_path):
+    p = str(tmp_path / "bad.vcf")
+    head = "##x\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\n"
+    for body, what in [("22\t1\t.\tA\tC\t.\t.\t.\tGT\t0|1\n", "fewer sample"), ("22\t1\t.\tA\tC\t.\t.\t.\tGT\t0|1\t0|0\t1|1\n", "more sample"),
+                       ("22\tx\t.\tA\tC\t.\t.\t.\tGT\t0|1\t0|0\n", "POS"), ("22\t5\t.\tA\n", "fewer than 10")]:
+        open(p, "w").write(head + body)
+        with pytest.raises(_lib.GnxError) as e:
+            vcfio.read_vcf(p)
+        assert what in str(e.value)
+    with pytest.raises(_lib.GnxError):
+        vcfio.read_vcf(str(tmp_path / "absent.vcf"))
+    open(p, "w").write("##only meta\n")
+    with pytest.raises(_lib.GnxError):
+        vcfio.read_vcf(p)
+    open(p, "wb").write(b"\x1f\x8b\x08\x00garbage-not-deflate")
+    with pytest.raises(_lib.GnxError):
+        vcfio.read_vcf(p)
+    open(p, "w").write(head)
+    assert vcfio.read_vcf(p) is None   # "No data found in vcf file" (src/utils.py:70-71)
+
+
+# ---- numbers ----------------------------------------------------------------------------------------------------------------------
+def test_float_text_equals_numpy():
+    rng = np.random.default_rng(0)
+    f32 = [rng.integers(0, 2 ** 32, 400_000, dtype=np.uint64).astype(np.uint32).view(np.float32),      # every exponent
+           rng.random(400_000, dtype=np.float32), (rng.random(100_000) * 1e-3).astype(np.float32),
+           np.float32(10.0) ** rng.integers(-12, 20, 50_000).astype(np.float32), np.arange(0, 70000, dtype=np.float32),
+           np.array([0, -0.0, 1, 1e-4, 9.9999e-5, 9.999999e-5, 1e16, 9.9999998e15, 1e-45, 3.4028235e38, np.inf, -np.inf, 0.1, 0.14285715, 1 / 3,
+                     16777216, 1e-5, 123456.79, 0.001, 1e15, 5e-324], dtype=np.float32)]
+    for a in f32:
+        a = a[~np.isnan(a)]
+        assert vcfio._format_floats(a) == a.astype(str).tolist()
+    f64 = [rng.integers(0, 2 ** 63, 300_000, dtype=np.uint64).view(np.float64), rng.random(300_000), rng.random(100_000) * 1e-4,
+           10.0 ** rng.integers(-300, 300, 50_000), rng.random(100_000).astype(np.float32).astype(np.float64),
+           np.array([0, -0.0, 1e-4, 9.999999999999999e-5, 1e16, 9999999999999998.0, 5e-324, 1.7976931348623157e308, np.inf, 0.1, 1 / 3, 2 ** 53, 1e22, 1e23])]
+    for a in f64:
+        a = a[~np.isnan(a)]
+        assert vcfio._format_floats(a) == a.astype(str).tolist()
+    assert vcfio._format_floats(np.array([np.nan], np.float32)) == ["nan"]
+
+
+# ---- writers --------------------------------------------------------------------------------------------------------------------------
+def _py_msp(meta, labels, populations, samples):
+    rows = pp._meta_strings(meta)
+    out = "#Subpopulation order/codes: " + "\t".join([str(p) + "=" + str(i) for i, p in enumerate(populations)]) + "\n"
+    out += "#" + "\t".join(pp.META_COLUMNS) + "\t" + "\t".join([str(s) for q in samples for s in (str(q) + ".0", str(q) + ".1")]) + "\n"
+    lab = np.asarray(labels)
+    for l, r in enumerate(rows):       # src/postprocess.py:95-97: np.concatenate([meta, pred_labels.T], 1).astype(str), tab-joined
+        out += "\t".join(r + [str(v) for v in lab[:, l]]) + "\n"
+    return out
+
+
+def _py_fb(meta, proba, ancestry, samples):
+    n_rows = len(meta["spos"])
+    se = np.stack([np.asarray(meta["spos"]).astype(int), np.asarray(meta["epos"]).astype(int)], axis=1)
+    ppos = np.round(np.mean(se, axis=1)).astype(int)
+    gp = np.mean(np.stack([np.asarray(meta["sgpos"], dtype=float), np.asarray(meta["egpos"], dtype=float)], 1), axis=1)
+    header = ["chromosome", "physical position", "genetic_position", "genetic_marker_index"]
+    header += [":::".join([str(q), h, str(a)]) for q in samples for h in ["hap1", "hap2"] for a in ancestry]
+    fb = np.swapaxes(proba, 1, 2).reshape(-1, n_rows).T       # src/postprocess.py:115: (W, N*A)
+    txt = fb.astype(str)                                       # what DataFrame.to_csv prints for a float column
+    out = "#reference_panel_population:\t" + "\t".join(str(a) for a in ancestry) + "\n" + "\t".join(header) + "\n"
+    for r in range(n_rows):
+        vals = [str(meta["chm"][r]), str(ppos[r]), str(np.float64(gp[r])), "."] + ["" if t == "nan" else t for t in txt[r]]
+        out += "\t".join(vals) + "\n"
+    return out
+
+
+@pytest.mark.parametrize("N,W,A,dtype", [(2, 3, 2, np.float32), (14, 41, 7, np.float32), (6, 150, 12, np.float64), (500, 9, 3, np.float32)])
+def test_msp_fb_writers_equal_the_python_restatement(tmp_path, N, W, A, dtype):
+    rng = np.random.default_rng(N * W)
+    M = 10
+    model_pos = np.sort(rng.choice(10 ** 6, W * M + 3, replace=False))
+    meta = pp.get_meta_data("22", model_pos, model_pos[::2], W, M, np.array([0, 10 ** 6]), np.array([0.0, 3.3]))
+    labels = rng.integers(0, A, (N, W))
+    if A > 10:
+        labels[0, 0] = 11
+    proba = rng.random((N, W, A)).astype(dtype)
+    proba /= proba.sum(-1, keepdims=True)
+    proba[0, 0, 0] = 1e-7
+    proba[1, W - 1, A - 1] = 1.0
+    proba[0, 1, 1] = 0.0
+    proba[1, 0, 0] = np.nan
+    samples, pops = ["I%d" % i for i in range(N // 2)], ["P%d" % a for a in range(A)]
+    for nt in (1, 7):
+        for env in ("", "1"):       # mapped output file, and the pwrite route
+            os.environ["GNX_IO_NO_MMAP"] = env
+            if not env:
+                del os.environ["GNX_IO_NO_MMAP"]
+            out = str(tmp_path / f"o{nt}{env}")
+            pp.write_msp(out, meta, labels, pops, samples, n_threads=nt)
+            pp.write_fb(out, meta, proba, pops, samples, n_threads=nt)
+            assert open(out + ".msp").read() == _py_msp(meta, labels, pops, samples)
+            assert open(out + ".fb").read() == _py_fb(meta, proba, pops, samples)
+    os.environ.pop("GNX_IO_NO_MMAP", None)
+
+
+def _py_npy_to_vcf(data, npy, headers, names):
+    """src/utils.py:283-329 line by line: one "m|p" string per sample and variant, pandas to_csv with tabs"""
+    out = headers + "##fileformat=VCFv4.1\n##source=gnomix.py\n" + '##FORMAT=<ID=GT,Number=1,Type=String,Description="Phased Genotype">\n'
+    out += "#" + "\t".join(["CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"] + list(names)) + "\n"
+    alt = data["variants/ALT"]
+    for v in range(npy.shape[1]):
+        q = data["variants/QUAL"][v]
+        row = [str(data["variants/CHROM"][v]), str(data["variants/POS"][v]), str(data["variants/ID"][v]), str(data["variants/REF"][v]),
+               str(alt[v, 0]), "" if np.isnan(q) else str(np.float32(q)), "PASS", ".", "GT"]
+        row += [str(npy[2 * i, v]) + "|" + str(npy[2 * i + 1, v]) for i in range(npy.shape[0] // 2)]
+        out += "\t".join(row) + "\n"
+    return out
+
+
+@pytest.mark.parametrize("ns", [1, 2, 5, 64, 131])
+def test_phased_vcf_writers(tmp_path, ns):
+    rng = np.random.default_rng(ns)
+    p = str(tmp_path / "q.vcf")
+    open(p, "w").write(_vcf_text(rng, 120, ns, general_every=4))
+    d = vcfio.read_vcf(p)
+    nv = d.n_variants
+    X = rng.integers(0, 3, (2 * ns, nv)).astype(np.int8)
+    names = list(d["samples"])
+    want = _py_npy_to_vcf(d, X, d.meta_header, names)
+    out = vcfio.npy_to_vcf(d, X, str(tmp_path / "a"), headers=vcfio.read_headers(p))
+    assert open(out).read() == want
+    # the file path: a row subset, the model's alleles, 2-bit rows
+    rows = np.sort(rng.choice(nv, nv // 2, replace=False))
+    ref, alt = rng.choice(list("ACGT"), len(rows)), rng.choice(["A", "CT", "G"], len(rows))
+    upd = vcfio.update_vcf(d, mask=rows, Updates={"variants/REF": ref, "variants/ALT": alt.reshape(-1, 1)})
+    assert upd.n_variants == len(rows) and np.array_equal(upd["variants/POS"], d["variants/POS"][rows])
+    want = _py_npy_to_vcf(upd, X[:, rows], d.meta_header, names)
+    G = vcfio.pack_gt2(X[:, rows])
+    out = vcfio.write_phased_vcf(d, rows, G, str(tmp_path / "b"), ref=ref, alt=alt, headers=d.meta_header, n_threads=3)
+    assert open(out).read() == want
+    # and what comes back through the reader is the matrix that went in
+    back = vcfio.read_vcf(out)
+    assert np.array_equal(back["calldata/GT"].reshape(len(rows), -1).T, X[:, rows])
+
+
+def test_synthetic_vcf_roundtrip_with_missing_as_dot(tmp_path):
+    from gnomix_amd import synth
+    rng = np.random.default_rng(3)
+    ns, nv = 21, 300
+    X = rng.integers(0, 3, (2 * ns, nv)).astype(np.int8)
+    pos = np.sort(rng.choice(10 ** 6, nv, replace=False))
+    p = synth.write_vcf_gt2(str(tmp_path / "s.vcf"), vcfio.pack_gt2(X), ns, pos, rng.choice(list("ACGT"), nv), rng.choice(list("ACGT"), nv), chrom="22")
+    txt = open(p).read()
+    assert ".|" in txt or "|." in txt
+    d = vcfio.read_vcf(p, chm="22")
+    assert d.info.n_fast_lines == nv
+    assert np.array_equal(vcfio.vcf_to_npy(d, verbose=False), X)
+    assert np.array_equal(d["variants/POS"], pos)
+
+
+# ---- column map == vcf_to_npy -------------------------------------------------------------------------------------------------------
+def _apply_map(G, N, src):
+    """numpy statement of k_gt2_to_x: X[n, c] from the 2-bit rows and the column map"""
+    C = len(src)
+    X = np.full((N, C), 2, np.int8)
+    have = src >= 0
+    v = src[have] & 0x3FFFFFFF
+    flip = (src[have] >> 30) & 1
+    codes = np.stack([(G[v, h // 4] >> (2 * (h % 4))) & 3 for h in range(N)], axis=0).astype(np.int8)   # (N, n_have)
+    codes = np.where(codes >= 2, 2, np.where(flip[None, :] == 1, 1 - codes, codes))
+    X[:, have] = codes
+    return X
+
+
+def test_column_map_reproduces_vcf_to_npy_G7(tmp_path):
+    """the reference's own vcf_to_npy output (golden G7) through VCF text, the native reader and the column map"""
+    from gnomix_amd import synth
+    g = np.load(os.path.join(ROOT, "tests", "golden", "G7_vcf.npz"), allow_pickle=False)
+    gt = g["gt"]
+    nv, ns, _ = gt.shape
+    code = np.where(gt < 0, 2, np.where(gt > 1, 3, gt)).astype(np.uint8).reshape(nv, 2 * ns)
+    p = synth.write_vcf_gt2(str(tmp_path / "g7.vcf"), vcfio.pack_gt2(code.T), ns, g["vcf_pos"], g["vcf_ref"], ["N"] * nv, chrom="22",
+                            missing_as_dot=True)
+    d = vcfio.read_vcf(p, chm="22")
+    src, vi, fi = vcfio.column_map(d, g["model_pos"], g["model_ref"], verbose=False)
+    assert np.array_equal(vi, g["vcf_idx"]) and np.array_equal(fi, g["fmt_idx"])
+    X = _apply_map(d.gt2, 2 * ns, src)
+    want = g["X"].copy()
+    assert np.array_equal(X, want)
+
+
+def test_column_map_random_cases_against_vcf_to_npy(tmp_path, capsys):
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        nv, ns, C = 400, 9, 350
+        p = str(tmp_path / "q.vcf")
+        txt = _vcf_text(rng, nv, ns, general_every=3 if trial % 2 else 0, chroms=("22", "22", "21"))
+        if trial >= 4:   # a repeated position: np.intersect1d keeps the first occurrence
+            ls = txt.split("\n")
+            t = ls[10].split("\t")
+            t[1] = ls[9].split("\t")[1]
+            ls[10] = "\t".join(t)
+            txt = "\n".join(ls)
+        open(p, "w").write(txt)
+        d = vcfio.read_vcf(p, chm="22")
+        qpos = d["variants/POS"]
+        model_pos = np.sort(np.unique(np.concatenate([rng.choice(qpos, min(C - 60, len(qpos) - 30), replace=False), rng.choice(10 ** 7, 60)])))
+        model_ref = rng.choice(list("ACGT"), len(model_pos))
+        want, vi, fi = vcfio.vcf_to_npy(d, model_pos, model_ref, return_idx=True, verbose=True)
+        msg_ref = capsys.readouterr().out
+        src, vi2, fi2 = vcfio.column_map(d, model_pos, model_ref, verbose=True)
+        assert capsys.readouterr().out == msg_ref              # the reference's progress messages, word for word
+        assert np.array_equal(vi, vi2) and np.array_equal(fi, fi2)
+        assert np.array_equal(_apply_map(d.gt2, 2 * ns, src), want)
+        assert (src >> 30 == 1).any() and (src == -1).any()
