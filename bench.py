@@ -364,11 +364,16 @@ def _e2e_vcf(args, model, data, X, out_dev):
             data.save(mp)
             outdir = os.path.join(work, "cli")
             t0 = time.perf_counter()
-            rc = subprocess.call([sys.executable, os.path.join(ROOT, "gnomix.py"), vcf_path, outdir, "22", "False", mp],
-                                 stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, cwd=work)
+            env = dict(os.environ, GNX_CLI_TIMING="1")
+            env.pop("GNX_NO_TORCH", None)
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "gnomix.py"), vcf_path, outdir, "22", "False", mp],
+                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=work, env=env, text=True)
+            rc = pr.returncode
             dt = time.perf_counter() - t0
+            stages = [ln for ln in pr.stderr.splitlines() if ln.startswith("gnomix_amd timings")]
             same_cli = rc == 0 and open(os.path.join(outdir, "query_results.msp")).read() == open(os.path.join(work, "query_results.msp")).read()
-            res["cli_process"] = {"wall_s": round(dt, 3), "haplotypes_per_s": N / dt, "rc": rc, "msp_identical": bool(same_cli)}
+            res["cli_process"] = {"wall_s": round(dt, 3), "haplotypes_per_s": N / dt, "rc": rc, "msp_identical": bool(same_cli),
+                                  "stages": stages[-1] if stages else None}
         except Exception as e:
             res["cli_process"] = {"error": repr(e)}
         return res

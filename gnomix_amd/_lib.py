@@ -76,7 +76,7 @@ class GbtParams(C.Structure):
 class VcfInfo(C.Structure):
     _fields_ = [("n_variants", C.c_int64), ("n_samples", C.c_int64), ("ldg", C.c_int64), ("file_bytes", C.c_int64),
                 ("text_bytes", C.c_int64), ("n_fast_lines", C.c_int64), ("n_general_lines", C.c_int64), ("n_overflow", C.c_int64),
-                ("seconds_load", C.c_double), ("seconds_index", C.c_double), ("seconds_parse", C.c_double),
+                ("seconds_load", C.c_double), ("seconds_parse", C.c_double), ("seconds_alloc", C.c_double), ("seconds_merge", C.c_double),
                 ("n_threads", C.c_int32), ("compression", C.c_int32), ("region_fallback", C.c_int32), ("gt2_pinned", C.c_int32)]
 
 
@@ -166,12 +166,14 @@ def load():
         raise GnxLibraryError(
             f"{SO_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py` or "
             f"`make -C gnomix_amd/csrc`).  gnomix_amd has no CPU fallback.")
-    try:
-        # torch (when installed) ships its own libamdhip64 with the same SONAME; importing it first makes
-        # this library and torch share ONE HIP runtime, so device pointers/streams are interchangeable.
-        import torch  # noqa: F401
-    except Exception:
-        pass
+    if not os.environ.get("GNX_NO_TORCH"):
+        try:
+            # torch (when installed) ships its own libamdhip64 with the same SONAME; importing it first makes
+            # this library and torch share ONE HIP runtime, so device pointers/streams are interchangeable.
+            # The command line never touches torch and sets GNX_NO_TORCH (its import alone costs over a second).
+            import torch  # noqa: F401
+        except Exception:
+            pass
     try:
         lib = C.CDLL(SO_PATH)
     except OSError as e:

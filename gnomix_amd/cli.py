@@ -100,6 +100,8 @@ def run_inference(base_args, model, snp_level=False, bed_file_output=False, verb
 
 def main(argv=None):
     argv = list(sys.argv if argv is None else argv)
+    if "torch" not in sys.modules:
+        os.environ.setdefault("GNX_NO_TORCH", "1")   # the command line needs no torch: do not pay for its import
     if len(argv) in (8, 9):
         print("Training mode is not part of this build.\n" + USAGE)
         return 2
@@ -117,7 +119,10 @@ def main(argv=None):
         with open("./config.yaml") as f:
             config = yaml.safe_load(f) or config
     print("Launching in pre-trained mode...")
+    from time import perf_counter as clock
+    t_load = clock()
     model = load_model(base_args["path_to_model"])
+    t_load = clock() - t_load
     model.n_cores = (config.get("model") or {}).get("n_cores")            # gnomix.py:365-367
     model.calibrate = (config.get("model") or {}).get("calibrate")
     model.smooth.calibrate = model.calibrate
@@ -125,8 +130,11 @@ def main(argv=None):
     if base_args["query_file"]:
         print("Launching inference...")
         inf = config.get("inference") or {}
+        T = {"load_model": t_load}
         run_inference(base_args, model, snp_level=bool(inf.get("snp_level_inference")),
-                      bed_file_output=bool(inf.get("bed_file_output")), verbose=True)
+                      bed_file_output=bool(inf.get("bed_file_output")), verbose=True, timings=T)
+        if os.environ.get("GNX_CLI_TIMING"):
+            sys.stderr.write("gnomix_amd timings (s): " + ", ".join("%s %.3f" % kv for kv in T.items()) + "\n")
     return 0
 
 

@@ -46,11 +46,18 @@ def get_meta_data(chm, model_pos, query_pos, n_wind, wind_size, gen_map_pos, gen
     sgpos = np.round(interp(spos), 5)
     egpos = np.round(interp(epos), 5)
     n_snps = np.zeros_like(epos)
-    q = 0
-    for w in range(n_wind - 1):
-        while q < len(query_pos) and query_pos[q] <= epos[w]:
-            n_snps[w] += 1
-            q += 1
+    if len(query_pos) < 2 or bool(np.all(query_pos[1:] >= query_pos[:-1])):
+        # the reference's running pointer (postprocess.py:56-62) on sorted positions = counts between successive window ends
+        # (the pointer never moves backwards: a window end below its predecessor adds nothing)
+        cut = np.maximum.accumulate(np.searchsorted(query_pos, epos[:n_wind - 1], side="right")) if n_wind > 1 else np.zeros(0, int)
+        n_snps[:n_wind - 1] = np.diff(np.concatenate([[0], cut]))
+        q = int(cut[-1]) if n_wind > 1 else 0
+    else:
+        q = 0
+        for w in range(n_wind - 1):
+            while q < len(query_pos) and query_pos[q] <= epos[w]:
+                n_snps[w] += 1
+                q += 1
     n_snps[n_wind - 1] = len(query_pos) - q
     return {"chm": [chm] * n_wind, "spos": spos, "epos": epos, "sgpos": sgpos, "egpos": egpos, "n snps": n_snps}
 

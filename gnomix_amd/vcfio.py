@@ -175,7 +175,17 @@ def read_vcf(vcf_file, chm=None, fields=None, verbose=False, ctx=None, n_threads
 def snp_intersection(pos1, pos2, verbose=False):
     """indices of the common positions in both arrays (src/utils.py:83-102)"""
     assert len(pos2) != 0, "No SNPs of specified chromosome found in query file."
-    inter, idx1, idx2 = np.intersect1d(pos1, pos2, return_indices=True)
+    pos1, pos2 = np.asarray(pos1), np.asarray(pos2)
+    if (pos1.ndim == pos2.ndim == 1 and pos1.dtype.kind in "iu" and pos2.dtype.kind in "iu" and len(pos1) > 0
+            and bool(np.all(pos1[1:] > pos1[:-1])) and bool(np.all(pos2[1:] > pos2[:-1]))):
+        # both strictly increasing (a model's SNPs and a sorted VCF without repeated positions): np.intersect1d's answer
+        # without its two sorts — a binary search of one list in the other
+        k = np.minimum(np.searchsorted(pos2, pos1), len(pos2) - 1)
+        hit = pos2[k] == pos1
+        idx1, idx2 = np.nonzero(hit)[0], k[hit]
+        inter = pos1[idx1]
+    else:
+        inter, idx1, idx2 = np.intersect1d(pos1, pos2, return_indices=True)
     if verbose:
         print("- Number of SNPs from model:", len(pos1))
         print("- Number of SNPs from file:", len(pos2))

@@ -45,9 +45,10 @@ typedef struct gnx_vcf_info {
   int64_t n_fast_lines;   /* records taken by the fixed-width "a|b" path */
   int64_t n_general_lines;
   int64_t n_overflow;     /* alleles >= 2 kept in the side list */
-  double seconds_load;    /* open / mmap / decompress */
-  double seconds_index;   /* line index + region filter */
-  double seconds_parse;   /* fields + genotypes */
+  double seconds_load;    /* open / inflate / header */
+  double seconds_parse;   /* read + fields + genotypes, all chunks */
+  double seconds_alloc;   /* the (page-locked) genotype matrix */
+  double seconds_merge;   /* chunk columns -> final arrays */
   int32_t n_threads;
   int32_t compression;    /* 0 plain text, 1 gzip (one stream: serial inflate), 2 BGZF (blocks inflated in parallel) */
   int32_t region_fallback; /* 1: `region` matched no record and the whole file was used (src/utils.py:72-78) */

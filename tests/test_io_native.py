@@ -87,7 +87,8 @@ def test_reader_equals_python_mirror(tmp_path, case, container):
             _same(a, b)
             assert a.info.compression == {"plain": 0, "gzip": 1, "bgzf": 2}[container]
             assert a.info.region_fallback == int(chm == "7")
-            assert a.info.n_fast_lines + a.info.n_general_lines == a.info.n_variants
+            n_parsed = a.info.n_fast_lines + a.info.n_general_lines      # every record is parsed, the region selects afterwards
+            assert n_parsed >= a.info.n_variants and (chm == "22" or n_parsed == a.info.n_variants)
     assert vcfio.read_headers(p) == "".join(ln + "\n" for ln in txt.decode().replace("\r\n", "\n").split("\n") if ln.startswith("##")) or case.get("crlf")
     # the 2-bit rows: codes of calldata/GT
     a = vcfio.read_vcf(p)
