@@ -102,7 +102,9 @@ class GnxModelData:
         return 0 if self.tree_off is None else len(self.tree_off) - 1
 
     # ---- persistence -------------------------------------------------------------------------------
-    def save(self, path):
+    def save(self, path, compress=False):
+        """a flat .gnx (npz) archive.  Stored uncompressed by default: logistic weights are float64 noise to a compressor (the
+        chr22 model shrinks by a few percent) and inflating them costs the command line 0.6 s of its ~1.4 s; load reads both."""
         d = {"gnx_version": GNX_FILE_VERSION}
         for k, v in self.__dict__.items():
             if v is None or k in ("svc", "extra"):
@@ -117,7 +119,7 @@ class GnxModelData:
                 for kk, vv in w.items():
                     d[f"svc{i}_{kk}"] = np.asarray(vv)
         with open(path, "wb") as f:
-            np.savez_compressed(f, **d)
+            (np.savez_compressed if compress else np.savez)(f, **d)
 
     @classmethod
     def load(cls, path):

@@ -236,7 +236,12 @@ def column_map(vcf_data, snp_pos_fmt, snp_ref_fmt=None, verbose=True):
         if isinstance(vcf_data, VcfData) and "variants/REF" not in vcf_data._over:
             qref = vcf_data.fixed_bytes(2)[rows]
             mref = np.asarray(snp_ref_fmt)[fmt_idx]
-            mref = np.char.encode(mref.astype(str), "utf-8") if mref.dtype.kind != "S" else mref
+            if mref.dtype.kind == "U" and mref.dtype.itemsize:
+                w = mref.dtype.itemsize // 4
+                u = np.ascontiguousarray(mref).view(np.uint32).reshape(len(mref), w)      # UCS-4 code points
+                mref = u.astype(np.uint8).view("S%d" % w).reshape(len(mref)) if (u < 128).all() else np.char.encode(mref, "utf-8")
+            elif mref.dtype.kind != "S":
+                mref = np.char.encode(mref.astype(str), "utf-8")
             swap = qref != mref
         else:
             swap = vcf_data["variants/REF"][vcf_idx] != np.asarray(snp_ref_fmt)[fmt_idx]

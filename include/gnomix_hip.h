@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 8
+#define GNX_ABI_VERSION 9
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
