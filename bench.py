@@ -39,6 +39,18 @@ N_CU, CLK_GHZ = 256, 2.4   # MI355X_MICROARCH.md: 256 CUs, 2.4 GHz peak engine c
 LDS_PEAK_NODE_STEPS = N_CU * CLK_GHZ * 1e9 * 32
 
 
+def kernel_src_sha16():
+    """identity of the kernel sources a counter file was collected from / this run executes (there is no .git on the GPU box)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gnomix_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -67,7 +79,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--haps", type=int, default=10000, help="haplotypes per GPU per step")
+    ap.add_argument("--haps", type=int, default=10000, help="haplotypes per GPU per pass")
+    ap.add_argument("--passes", type=int, default=20, help="passes over the resident batch per step: a step is `passes` x `haps` haplotypes, so "
+                    "that the 20 steps the driver asks for time > 1 s of device work instead of 57 ms")
+    ap.add_argument("--trained", type=int, default=1, help="also time the smoother on a gnx_train_gbt-trained ensemble (N=1, rank 0)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline core-seconds budget scale (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="host-pointer (PCIe-inclusive) passes at N=1 (0 = skip)")
@@ -127,14 +142,17 @@ def main():
         torch.cuda.synchronize()
 
     out = None
+    P = max(1, args.passes)
     for _ in range(args.warmup):
-        out = model.infer_device(X)
+        for _ in range(P):
+            out = model.infer_device(X)
     barrier()
     ctx.profile_reset()
     ctx.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = model.infer_device(X)
+        for _ in range(P):
+            out = model.infer_device(X)
     barrier()
     t1 = time.perf_counter()
     ctx.profile_enable(False)
@@ -215,23 +233,31 @@ def main():
                     "traffic": traffic,
                     "note": "algorithmic bytes/launch = %d B/haplotype x %d haplotypes (SURVEY.md 8d)" % (bytes_base, N)}
 
-    hps = world * N * args.steps / dt
+    hps = world * N * P * args.steps / dt
     res = {
         "metric": "haplotypes/sec (+ windows/sec) chr22 7-ancestry inference",
         "value": hps, "unit": "haplotypes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "passes_per_step": P, "ms_per_pass": dt / args.steps / P * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8 x 7-digit fixed-point weights -> exact i32/i64 logits, f64 sigmoid (logistic base); f32 (tree smoother)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: chr22-like C=370500 M=1000 ctx=500 W=370 A=7 S=75, logistic base + xgb smoother "
-                               "(100 rounds x 7 trees, depth<=4), %d synthetic haplotypes per GPU resident in HBM" % N,
-                   "haplotypes_per_gpu": N, "sharding": "haplotypes across ranks, no data-path collective",
+                               "(100 rounds x 7 trees of depth<=4 with UNIFORM RANDOM features and thresholds: the divergence / LDS-conflict worst "
+                               "case, see trained_ensemble), %d synthetic haplotypes per GPU resident in HBM, a step = %d passes over them" % (N, P),
+                   "haplotypes_per_gpu": N, "haplotypes_per_step_per_gpu": N * P, "sharding": "haplotypes across ranks, no data-path collective",
                    "dist_backend": backend},
         "windows_per_s": hps * W,
         "roofline": roofline, "kernels": kernels, "label_checksum": lab_sum,
     }
     if counters:
+        sha = kernel_src_sha16()
         res["counters"] = {"source": counters.get("source", "profiles/traffic_latest.json"), "hbm_bytes_per_launch": {
-            k: v for k, v in counters.items() if isinstance(v, (int, float))}}
+            k: v for k, v in counters.items() if isinstance(v, (int, float))},
+            "collected_at_kernel_src": counters.get("kernel_src_sha16"), "this_run_kernel_src": sha,
+            "stale": counters.get("kernel_src_sha16") != sha}
+        if res["counters"]["stale"]:
+            roofline["traffic"] = None        # never print a counter next to times of other kernels
+            roofline["traffic_note"] = "profiles/traffic_latest.json was collected from other kernel sources: rerun scripts/collect_profiles.sh"
 
     # ---- PCIe-inclusive rate: host pointers in, labels + probabilities out (never `value`) ----------------------------
     if rank == 0 and world == 1 and args.e2e_steps > 0:
@@ -239,6 +265,12 @@ def main():
             res["e2e"] = _e2e(model, X, args.e2e_steps, out)
         except Exception as e:  # the headline line must still print
             res["e2e"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and args.trained:
+        try:
+            res["trained_ensemble"] = _trained_ensemble(ctx, data, avg_sm * 1e3)
+        except Exception as e:
+            res["trained_ensemble"] = {"error": repr(e)}
 
     # ---- file to file: synthetic phased VCF -> .msp / .fb through the command line's own run_inference (never `value`) ----
     if rank == 0 and world == 1 and args.vcf_reps > 0:
@@ -294,6 +326,51 @@ def _e2e(model, X, steps, out_dev):
     res["e2e_haplotypes_per_s"] = max(v["haplotypes_per_s"] for v in res.values() if isinstance(v, dict) and "haplotypes_per_s" in v)
     res["note"] = "host pointers in and out (page-locked arrays), probabilities f32 + labels i32 out, PCIe both ways included; never `value`"
     return res
+
+
+def _trained_ensemble(ctx, data, bench_ms):
+    """The tree smoother alone on an ensemble TRAINED by gnx_train_gbt (same size: 100 rounds x A trees, depth 4) and on inputs
+    with ancestry tracts, next to the bench's uniform-random trees on the same inputs.  Random trees and unstructured inputs send
+    neighbouring lanes to unrelated nodes (worst case for divergence and LDS bank conflicts); the headline `value` keeps them."""
+    import numpy as np
+    import torch
+    import gnomix_amd
+    from gnomix_amd import synth, train, _lib
+    W, A, S = data.C // data.M, data.A, data.S
+    N = 10000
+    rng = np.random.RandomState(3)
+
+    def noisy(Bc, sd):
+        B = np.clip(Bc + rng.normal(0, sd, Bc.shape), 1e-4, None)
+        return B / B.sum(-1, keepdims=True)
+    Bt = synth.synthetic_phased_individuals(500, W, A, seed=5, phase_errors=0, noise=0.02)
+    yt = np.argmax(Bt, -1).astype(np.int32)
+    trees, _ = train.train_gbt_arrays(noisy(Bt, 0.45), yt, S, ctx=ctx)
+    Bq = noisy(synth.synthetic_phased_individuals(N // 2, W, A, seed=9, phase_errors=0, noise=0.02), 0.45).astype(np.float32)
+    Bd = torch.from_numpy(Bq).cuda()
+    d_tr = synth.synthetic_model(C=data.C, M=data.M, A=A, S=S, n_rounds=1, seed=1)
+    for k, v in trees.items():
+        setattr(d_tr, k, v)
+    out = {}
+    for name, d in (("random_trees_tract_inputs_ms", data), ("trained_trees_tract_inputs_ms", d_tr)):
+        m = gnomix_amd.DeviceModel(d, ctx=ctx)
+        m.smooth_predict_device(Bd)
+        torch.cuda.synchronize()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(10):
+            m.smooth_predict_device(Bd)
+        torch.cuda.synchronize()
+        ctx.profile_enable(False)
+        ms, n = ctx.profile_get(_lib.K_SMOOTH_XGB)
+        out[name] = ms / max(n, 1)
+        if d is not data:
+            out["trained_nodes"] = int(len(d.left))
+            m.close()
+    out["random_trees_bench_inputs_ms"] = bench_ms
+    out["random_nodes"] = int(len(data.left))
+    out["note"] = "k_smooth_xgb average launch, %d haplotypes x %d windows; tract inputs = synthetic admixed individuals + noise" % (N, W)
+    return out
 
 
 def _e2e_vcf(args, model, data, X, out_dev):
@@ -382,6 +459,11 @@ def _e2e_vcf(args, model, data, X, out_dev):
 
 
 def _cpu_baseline(args, data, X, out_dev):
+    """The oracle's C restatement on every host core, with the work cut the way a CPU wants it: the logistic base by WINDOWS (a
+    core keeps a window's A x M_ float64 weights in its cache and runs the whole sample through them — cutting by haplotypes
+    makes every core stream all 41 MB of weights from DRAM, which is what round 2's 1 288 haplotypes/s on 256 threads measured),
+    the tree smoother by haplotypes (the 90 KB of trees stay in every core's L2).  Beside it the reference's own arithmetic for
+    the base: one BLAS product per window (sklearn's predict_proba), numpy's BLAS threads."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import gnx_oracle as O
@@ -393,37 +475,47 @@ def _cpu_baseline(args, data, X, out_dev):
         avail = os.cpu_count() or 1
     cores = max(1, args.cpu_threads or avail)
     Xh = X.cpu().numpy()
-    # one core alone first (also sizes the sample): the port is scalar C, haplotypes are independent, so every core runs
-    # a disjoint slice through it from a thread pool (ctypes releases the GIL; every call owns its scratch)
+    W = data.C // data.M
+    # one core alone first (also sizes the sample)
     c0 = time.perf_counter()
     B4 = O.base_lr(Xh[:4], data.M, data.context, data.lr_coef, data.lr_intercept)
     c1 = time.perf_counter()
     O.smooth_xgb(T, B4, data.S)
     c2 = time.perf_counter()
     per = (c2 - c0) / 4
-    # bounded sample: ~cpu_seconds of wall time per core at most, never more than the batch
-    n_s = int(min(Xh.shape[0], max(2 * cores, cores * args.cpu_seconds / max(per, 1e-6))))
-    n_s -= n_s % cores
-    chunk = n_s // cores
-    sl = [slice(i * chunk, (i + 1) * chunk) for i in range(cores)]
+    # bounded sample: ~cpu_seconds of wall time with every core busy, never more than the batch
+    n_s = int(min(Xh.shape[0], max(cores, cores * args.cpu_seconds / max(per, 1e-6))))
+    n_s = max(cores, n_s - n_s % cores) if n_s >= cores else n_s
+    Xs = np.ascontiguousarray(Xh[:n_s])
+    B = np.empty((n_s, W, data.A), np.float64)
+    chunk = max(1, n_s // cores)
+    sl = [slice(i, min(n_s, i + chunk)) for i in range(0, n_s, chunk)]
     with ThreadPoolExecutor(max_workers=cores) as pool:
         c0 = time.perf_counter()
-        Bs = list(pool.map(lambda s: O.base_lr(Xh[s], data.M, data.context, data.lr_coef, data.lr_intercept), sl))
+        list(pool.map(lambda w: O.base_lr_windows(Xs, data.M, data.context, data.lr_coef, data.lr_intercept, w, w + 1, B), range(W)))
         c1 = time.perf_counter()
-        parts = list(pool.map(lambda b: O.smooth_xgb(T, b, data.S), Bs))
+        parts = list(pool.map(lambda s_: O.smooth_xgb(T, B[s_], data.S), sl))
         c2 = time.perf_counter()
     l_ref = np.concatenate([p[1] for p in parts])
     same = bool((out_dev[1][:n_s].cpu().numpy() == l_ref).all())
     t_base, t_sm = c1 - c0, c2 - c1
+    # the reference's arithmetic for the base leg: BLAS, window by window, on a sample sized for a few seconds
+    n_b = int(min(n_s, 2000))
+    c0 = time.perf_counter()
+    Bb = O.base_lr_blas(Xs[:n_b], data.M, data.context, data.lr_coef, data.lr_intercept)
+    t_blas = time.perf_counter() - c0
+    blas_err = float(np.abs(Bb - B[:n_b]).max())
     return {"value": n_s / (t_base + t_sm), "unit": "haplotypes/s", "cores": cores, "kind": "port",
             "base_lr_haplotypes_per_s": n_s / t_base, "smooth_xgb_haplotypes_per_s": n_s / t_sm,
-            "one_core_haplotypes_per_s": 1.0 / per,
+            "one_core_haplotypes_per_s": 1.0 / per, "parallel_efficiency": (n_s / (t_base + t_sm)) / (cores / per),
+            "base_lr_blas": {"haplotypes_per_s": n_b / t_blas, "sample": n_b, "max_abs_diff_vs_port": blas_err,
+                             "note": "numpy: Xw.astype(float64) @ coef.T per window (what sklearn's predict_proba does), BLAS threads as configured"},
             "sample": "%d haplotypes of the same workload through oracle/gnx_oracle.c — the SCALAR C port of the reference's "
-                      "algorithm, not the reference — on %d threads x %d haplotypes (host reports %d cores, %d usable): logistic "
-                      "base %.2f s, tree smoother %.2f s wall; labels identical to the GPU's on the sample: %s.  Context "
-                      "(BASELINE.md 2, the reference itself, 8 cores of the survey container): base 815 haplotypes/s, "
+                      "algorithm, not the reference — on %d threads (host reports %d cores, %d usable): logistic base by windows "
+                      "(370 tasks) %.2f s, tree smoother by haplotypes %.2f s wall; labels identical to the GPU's on the sample: %s.  "
+                      "Context (BASELINE.md 2, the reference itself, 8 cores of the survey container): base 815 haplotypes/s, "
                       "slide_window 225 haplotypes/s (xgboost itself absent there)" %
-                      (n_s, cores, chunk, os.cpu_count() or 0, avail, t_base, t_sm, same)}
+                      (n_s, cores, os.cpu_count() or 0, avail, t_base, t_sm, same)}
 
 
 if __name__ == "__main__":

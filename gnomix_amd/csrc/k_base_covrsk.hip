@@ -423,8 +423,11 @@ __global__ __launch_bounds__(64) void k_covrsk_dec_fast(CovRSKLaunch L) {
       }
     }
   } else {
+    // class bounds straight from the window table (wave-uniform scalar loads): indexing the private COPY of the window with a
+    // run-time class put its cls_start[36] in scratch (208 B per lane on every generic-A instance)
+    const int32_t* cls_start = L.win[w].cls_start;
     for (int c = 0; c < A; ++c) {
-      for (int sv = win.cls_start[c]; sv < win.cls_start[c + 1]; ++sv) {
+      for (int sv = cls_start[c]; sv < cls_start[c + 1]; ++sv) {
         const double Kd = (double)kernel_value(sv);
         for (int o = 0; o < A; ++o) {
           if (o == c) continue;

@@ -45,18 +45,31 @@ __global__ __launch_bounds__(256) void k_crf_psi(SmoothCRFLaunch L) {
 #pragma unroll
     for (int a = 0; a < AT; ++a) b[a] = (a < A) ? (double)src[a] : 0.0;
   }
-#pragma unroll
-  for (int y = 0; y < AT; ++y) {
-    double s = 0.0;
-#pragma unroll
-    for (int a = 0; a < AT; ++a)
-      if (a < A) s += th[a * AT + y] * b[a];
-    o[y] = exp(s);
-  }
   double* dst = L.psi + e * A;
+  if constexpr (EXACT) {
 #pragma unroll
-  for (int y = 0; y < AT; ++y)
-    if (y < A) dst[y] = o[y];
+    for (int y = 0; y < AT; ++y) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < AT; ++a) s += th[a * AT + y] * b[a];
+      o[y] = exp(s);
+    }
+#pragma unroll
+    for (int y = 0; y < AT; ++y) dst[y] = o[y];
+  } else {
+    // run-time label count below the template bound (17..32 labels, or 9..15 through the 16-wide instance): one label at a
+    // time, stored as it is ready.  Fully unrolled, AT inlined exp() bodies and the o[] vector cost 52 B .. 6 KB of scratch per
+    // lane; the sums run over a = 0..A-1 in the same order either way.
+    (void)o;
+#pragma unroll 1
+    for (int y = 0; y < A; ++y) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < AT; ++a)
+        if (a < A) s += th[a * AT + y] * b[a];
+      dst[y] = exp(s);
+    }
+  }
 }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;

@@ -22,6 +22,7 @@ class HipSmoother:
 
     def __init__(self, device_model, calibrate=None, mode_filter=0, n_jobs=None, seed=None, verbose=False):
         d = device_model.data
+        self._calibrate = None
         self.dev = device_model
         self.W = d.C // d.M
         self.A = d.A
@@ -36,6 +37,17 @@ class HipSmoother:
         self.gnofix = d.smooth_kind == "xgb"   # only XGB_Smoother sets it (Smooth/models.py:12)
         self.model = _RowModel(device_model) if d.smooth_kind == "xgb" else None
         self.time = {}
+
+    @property
+    def dev(self):
+        return self._dev
+
+    @dev.setter
+    def dev(self, m):
+        """every (re)binding of the device model — training builds fresh ones — carries the calibrate switch over: a new
+        gnx_model starts with calibration off (the reference keeps calibrating after Gnomix.train's base retrain, model.py:119-167)"""
+        self._dev = m
+        m.set_calibrate(bool(self._calibrate))
 
     @property
     def calibrate(self):
@@ -69,6 +81,10 @@ class HipSmoother:
         global generator, as the reference), one isotonic map per class (gnomix_amd.calibrate), device model re-loaded with them"""
         from .calibrate import fit_calibrator
         from .model import DeviceModel
+        if self.dev.data.smooth_kind != "xgb":
+            # Calibrator.fit on a float64 smoother (CRF) fits sklearn's isotonic maps on float64 inputs without the float32
+            # tie merging gnx_fit_isotonic_f32 reproduces: not built, and not silently approximated
+            raise NotImplementedError("train_calibrator is built for the tree smoother (float32 probabilities)")
         B = np.asarray(B)
         y = np.asarray(y)
         calibrate = self.calibrate

@@ -37,8 +37,16 @@ def train_logistic_arrays(X, y, M, context, A, C_reg=3.0, tol=1e-9, max_iter=100
     info = _lib.TrainInfo()
     ctx.check(ctx.lib.gnx_train_logistic(ctx.h, X.ctypes.data, N, X.shape[1], y.ctypes.data, Cn, int(M), int(context), int(A),
                                          float(C_reg), float(tol), int(max_iter), coef.ctypes.data, ldc, icpt.ctypes.data, C.byref(info)))
-    return coef, icpt, dict(newton_iterations=info.newton_iterations, cg_iterations=info.cg_iterations, n_problems=info.n_problems,
-                            worst_rel_gradient=info.worst_rel_gradient, objective_sum=info.objective_sum)
+    out = dict(newton_iterations=info.newton_iterations, cg_iterations=info.cg_iterations, n_problems=info.n_problems,
+               worst_rel_gradient=info.worst_rel_gradient, objective_sum=info.objective_sum)
+    # the library bounds the Newton steps (at most 200 whatever max_iter says: include/gnomix_hip.h) and returns what it has: a
+    # window that did not get near liblinear's own stopping level (1e-4) must not pass as a trained model silently
+    if info.worst_rel_gradient > max(float(tol), 1e-4):
+        import warnings
+        warnings.warn("gnx_train_logistic stopped after %d Newton steps with |grad| / |grad(0)| = %.3g on its worst window "
+                      "(tol %.3g): the logistic base is not converged" % (info.newton_iterations, info.worst_rel_gradient, tol),
+                      RuntimeWarning, stacklevel=2)
+    return coef, icpt, out
 
 
 def train_logistic_base(data: GnxModelData, X, y, **kw) -> dict:
@@ -82,9 +90,12 @@ def train_gbt_arrays(B, y, S, n_rounds=100, max_depth=4, learning_rate=0.1, reg_
             raise ValueError(f"y must be (N, W) = ({N}, {W}), got {y.shape}")
         b_ptr, y_ptr, fn = B.ctypes.data, y.ctypes.data, ctx.lib.gnx_train_gbt
     T = int(n_rounds) * int(A)
+    if not 1 <= int(max_depth) <= 5:
+        raise ValueError("max_depth must be 1..5 (include/gnomix_hip.h: gnx_gbt_params)")
+    per_tree = 2 ** (int(max_depth) + 1) - 1     # a complete tree of that depth; the header promises room for 63 T at the limit 5
     tree_off = np.zeros(T + 1, np.int32); tree_class = np.zeros(T, np.int32)
-    left = np.zeros(T * 63, np.int32); right = np.zeros(T * 63, np.int32); feat = np.zeros(T * 63, np.int32)
-    cond = np.zeros(T * 63, np.float32); loss = np.zeros(int(n_rounds) + 1, np.float64)
+    left = np.zeros(T * per_tree, np.int32); right = np.zeros(T * per_tree, np.int32); feat = np.zeros(T * per_tree, np.int32)
+    cond = np.zeros(T * per_tree, np.float32); loss = np.zeros(int(n_rounds) + 1, np.float64)
     nn = C.c_int64(0)
     P = _lib.GbtParams(int(n_rounds), int(max_depth), int(max_bin), 0, float(learning_rate), float(reg_lambda), float(gamma),
                        float(min_child_weight), float(base_score))

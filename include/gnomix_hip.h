@@ -273,7 +273,9 @@ int gnx_gnofix_dev(gnx_model* model, int8_t* dX, int64_t ldx, const double* dB, 
  * sklearn) of  min_w 1/2 w'w + C_reg sum_i log(1 + exp(-y_i w'[x_i, 1]))  minimised at once on the device, float64.
  *   X (N, ldx) int8 {0,1,2}, y (N, W) int32 window labels in [0, A)  (rows = haplotypes)
  *   tol: stop a problem when |grad| <= tol * |grad at w = 0| (liblinear stops at ~1e-4 scaled by the class balance; the
- *        default 1e-9 converges to the optimum that the reference's solver approximates); max_iter bounds Newton steps
+ *        default 1e-9 converges to the optimum that the reference's solver approximates); max_iter bounds Newton steps and is
+ *        itself clamped to 200 (a Newton-CG run takes 10-20); GNX_OK is returned even when a problem has not reached tol —
+ *        check info.worst_rel_gradient
  *   coef (W, A, ldc) / intercept (W, A): HOST outputs in exactly the layout gnx_model_desc.lr_coef / lr_intercept take
  *        (A == 2: rows (-w, +w), see gnomix_amd.convert.lr_rows_from_sklearn); ldc >= M + 2 ctx + C % M
  * The unsuffixed entry point takes host X / y and stages them; _dev takes device X / y (context's device). */
@@ -298,7 +300,7 @@ int gnx_train_logistic_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ld
  *   B (N, W, A) base probabilities (what Base.predict_proba returned for the smoother's training haplotypes), float32 or float64
  *   y (N, W) int32 labels in [0, A);  W >= 2 S, S odd
  *   outputs (HOST, caller-allocated): tree_off[T+1], tree_class[T], left / right / feat (int32) and cond (float32) with room for
- *     63 T nodes, T = n_rounds * A — exactly the arrays gnx_model_desc takes (a leaf has left = right = -1 and its value in cond;
+ *     (2^(max_depth+1) - 1) T nodes (63 T at the limit max_depth = 5), T = n_rounds * A — exactly the arrays gnx_model_desc takes (a leaf has left = right = -1 and its value in cond;
  *     tree t belongs to class t % A); *n_nodes = nodes written; loss[n_rounds + 1] (optional) = mean log loss before each round
  *     and after the last. */
 typedef struct gnx_gbt_params {

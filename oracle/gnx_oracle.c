@@ -52,16 +52,21 @@ int64_t gnxo_pad_src(int64_t p, int64_t C, int64_t ctx) { return pad_src(p, C, c
  * coef is (W, A, ldc) row-major, ldc >= M_+rem, entries beyond a window's width ignored.
  * B is (N, W, A) float64.
  * ---------------------------------------------------------------------------------------- */
-int gnxo_base_lr(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t M, int64_t ctx,
-                 int64_t A, const double* coef, int64_t ldc, const double* intercept, double* B) {
+/* windows [w0, w1) only: B keeps its (N, W, A) shape and the other windows are left untouched.  This is how the CPU baseline
+ * of bench.py spreads the work over the host's cores: a core owns a few WINDOWS (A x M_ doubles of weights that stay in its
+ * cache) and runs every haplotype of the sample through them — splitting the haplotypes instead makes every core stream all
+ * of the chromosome's weights (41 MB at chr22) from DRAM. */
+int gnxo_base_lr_range(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t M, int64_t ctx,
+                       int64_t A, const double* coef, int64_t ldc, const double* intercept, int64_t w0, int64_t w1, double* B) {
   if (M <= 0 || C < M || ctx < 0 || ctx > C || A <= 0 || A > 64) return GNXO_EINVAL;
   const int64_t W = C / M, rem = C - M * W, M_ = M + 2 * ctx;
   if (rem == 0) return GNXO_EINVAL; /* base.py:158 relies on C % M != 0 (gnomix.py:124-125) */
   if (ldc < M_ + rem) return GNXO_EINVAL;
+  if (w0 < 0 || w1 > W || w0 > w1) return GNXO_EINVAL;
   double p[64];
   /* window-major: one window's coefficients (A x M_ doubles) stay in cache while every haplotype of the call goes through
    * them; per (haplotype, window, class) the arithmetic and its order are what sklearn's decision_function + expit do */
-  for (int64_t i = 0; i < W; ++i) {
+  for (int64_t i = w0; i < w1; ++i) {
     const int64_t start = i * M, len = (i == W - 1) ? M_ + rem : M_;
     for (int64_t n = 0; n < N; ++n) {
       const int8_t* x = X + n * ldx;
@@ -78,6 +83,12 @@ int gnxo_base_lr(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t M, 
     }
   }
   return GNXO_OK;
+}
+
+int gnxo_base_lr(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t M, int64_t ctx,
+                 int64_t A, const double* coef, int64_t ldc, const double* intercept, double* B) {
+  if (M <= 0 || C < M) return GNXO_EINVAL;
+  return gnxo_base_lr_range(X, N, ldx, C, M, ctx, A, coef, ldc, intercept, 0, C / M, B);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -68,6 +68,39 @@ def base_lr(X, M, ctx, coef, intercept):
     return B
 
 
+def base_lr_windows(X, M, ctx, coef, intercept, w0, w1, B):
+    """windows [w0, w1) of base_lr into a caller-owned B (N, W, A) float64: the unit of work bench.py's CPU baseline hands
+    to a host thread (a window's weights stay in that core's cache)."""
+    N, Cn = X.shape
+    W, A, ldc = coef.shape
+    assert X.dtype == np.int8 and X.flags.c_contiguous and B.shape == (N, W, A) and B.dtype == np.float64 and B.flags.c_contiguous
+    rc = lib().gnxo_base_lr_range(_p(X), C.c_int64(N), C.c_int64(Cn), C.c_int64(Cn), C.c_int64(M), C.c_int64(ctx), C.c_int64(A),
+                                  _p(coef), C.c_int64(ldc), _p(intercept), C.c_int64(w0), C.c_int64(w1), _p(B))
+    _chk(rc, "base_lr_windows")
+    return B
+
+
+def base_lr_blas(X, M, ctx, coef, intercept, w0=0, w1=None, out=None):
+    """The same step through the host's BLAS, window by window, the way the reference computes it: sklearn's
+    LogisticRegression.predict_proba of an OvR model = expit(X_w.astype(float64) @ coef_.T + intercept_), normalised
+    (src/Base/models.py:12-21 through src/Base/base.py:146-180; reflect padding of base.py:41-44).  Summation order is the
+    BLAS library's, so values differ from base_lr in the last bits (tests allow 1e-12)."""
+    X = np.asarray(X)
+    N, Cn = X.shape
+    W, A, ldc = coef.shape
+    rem = Cn - M * W
+    M_ = M + 2 * ctx
+    w1 = W if w1 is None else w1
+    B = np.empty((N, W, A), np.float64) if out is None else out
+    Xp = np.concatenate([X[:, :ctx][:, ::-1], X, X[:, Cn - ctx:][:, ::-1]], axis=1) if ctx else X
+    for i in range(w0, w1):
+        lo, n = (i * M, M_) if i < W - 1 else (Xp.shape[1] - (M_ + rem), M_ + rem)
+        z = Xp[:, lo:lo + n].astype(np.float64) @ coef[i, :, :n].T + intercept[i]
+        p = 1.0 / (1.0 + np.exp(-z))
+        B[:, i, :] = p / p.sum(axis=1, keepdims=True)
+    return B
+
+
 # ------------------------------------------------------------------------------------------------
 # a5 slide_window
 # ------------------------------------------------------------------------------------------------

@@ -102,6 +102,10 @@ def main(src, dst, tag):
                 if b is not None:
                     name = "k_base_logistic" if "k_base_logistic" in k else "k_smooth_xgb" if "k_smooth_xgb" in k else k
                     traffic[name] = b
+            # stamp: the kernel sources these counters were collected from (bench.py prints counters.stale when its own differ)
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import kernel_src_sha16
+            traffic["kernel_src_sha16"] = kernel_src_sha16()
             json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 
 

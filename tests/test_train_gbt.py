@@ -172,6 +172,15 @@ def test_gnomix_train_end_to_end(ga, oracle):
     assert gc.dev.data.calib_off is not None and gc.smooth.calibrator
     pc = gc.predict_proba(v[0][:6])
     assert np.allclose(pc.sum(-1), 1.0, atol=1e-6)
+    # ... and the FINAL model (base refitted last, src/model.py:153-167) still calibrates: every re-binding of the device
+    # model carries the switch over (it used to come back uncalibrated float32)
+    assert gc.smooth.calibrate and gc.dev.calibrated and pc.dtype == np.float64
+    gc.smooth.calibrate = False
+    raw = gc.predict_proba(v[0][:6])
+    gc.smooth.calibrate = True
+    assert raw.dtype == np.float32 and not np.allclose(raw, pc, atol=1e-4)
+    want = gc.dev.calibrate_rows(raw.reshape(-1, A)).reshape(raw.shape)
+    assert np.allclose(pc, want, atol=1e-12) and np.array_equal(gc.predict_proba(v[0][:6]), pc)
 
 
 @pytest.mark.gpu
