@@ -90,9 +90,8 @@ def train_gbt_arrays(B, y, S, n_rounds=100, max_depth=4, learning_rate=0.1, reg_
             raise ValueError(f"y must be (N, W) = ({N}, {W}), got {y.shape}")
         b_ptr, y_ptr, fn = B.ctypes.data, y.ctypes.data, ctx.lib.gnx_train_gbt
     T = int(n_rounds) * int(A)
-    if not 1 <= int(max_depth) <= 5:
-        raise ValueError("max_depth must be 1..5 (include/gnomix_hip.h: gnx_gbt_params)")
-    per_tree = 2 ** (int(max_depth) + 1) - 1     # a complete tree of that depth; the header promises room for 63 T at the limit 5
+    # a complete tree of that depth (the library rejects depths outside 1..5 itself: include/gnomix_hip.h, gnx_gbt_params)
+    per_tree = 2 ** (min(max(int(max_depth), 1), 5) + 1) - 1
     tree_off = np.zeros(T + 1, np.int32); tree_class = np.zeros(T, np.int32)
     left = np.zeros(T * per_tree, np.int32); right = np.zeros(T * per_tree, np.int32); feat = np.zeros(T * per_tree, np.int32)
     cond = np.zeros(T * per_tree, np.float32); loss = np.zeros(int(n_rounds) + 1, np.float64)
