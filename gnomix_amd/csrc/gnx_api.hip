@@ -412,6 +412,44 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
   if ((rc = dev_upload(m, group_class, &m->xgb.rk_group_class)) != GNX_OK) return rc;
   m->xgb.rk_K = K; m->xgb.rk_steps = steps; m->xgb.rk_stride = stride; m->xgb.rk_tree_bytes = tree_bytes;
   m->xgb.rk_n_groups = (int32_t)group_class.size(); m->xgb.rk_max_group = G; m->xgb.rk_rpl = rpl;
+  // measured (chr22, 10 000 haplotypes, MI355X): rk 1.83 ms; h64 2.22 ms + 0.23 ms of rank pre-pass — conflict-free, and slower
+  // (DESIGN.md 4.2b): the rank kernel stays the default, h64 is what GNX_SMOOTH_IMPL=h64 selects
+  m->xgb.impl = (impl && std::string(impl) == "h64") ? 2 : 1;
+  // ---- the same trees for k_smooth_xgb_h64 (lane = haplotype): 8-byte nodes {slot byte offset, rank field} ------------------
+  if ((size_t)S * A * 128 < ((size_t)1 << 31)) {
+    const int tb8 = ((12 << D) + 15) & ~15;
+    const int G8 = std::max(1, 4096 / tb8);  // a group = one 16-byte piece per thread of the smallest block (256 threads)
+    std::vector<int32_t> g8_tree0, g8_class;
+    {
+      int in_group = 0, cur = -1;
+      for (size_t k = 0; k < order.size(); ++k) {
+        const int c = d->tree_class[order[k]];
+        if (c != cur || in_group == G8) { g8_tree0.push_back((int32_t)k); g8_class.push_back(c); in_group = 0; cur = c; }
+        ++in_group;
+      }
+      g8_tree0.push_back((int32_t)order.size());
+    }
+    std::vector<uint8_t> p8(order.size() * (size_t)tb8, 0);
+    std::vector<uint32_t> nodes((size_t)1 << D);
+    std::vector<float> leaves((size_t)1 << D);
+    for (size_t k = 0; k < order.size(); ++k) {
+      std::fill(nodes.begin(), nodes.end(), 0u);
+      tree_fill_rk(d, d->tree_off[order[k]], 0, 1, 0, D, U, stride, nodes.data(), leaves.data());  // (field << 16) | strip offset
+      uint32_t* o8 = reinterpret_cast<uint32_t*>(p8.data() + k * tb8);
+      for (uint32_t j = 1; j < (1u << D); ++j) {
+        const uint32_t off16 = nodes[j] & 0xffffu, field = nodes[j] >> 16;
+        // the rank layout's byte offset (a * stride + s) * 2 back to (s, a); an early leaf's word (offset 0) reads slot 0
+        const uint32_t h = off16 / 2, a = h / (uint32_t)stride, sidx = h - a * (uint32_t)stride;
+        o8[2 * j] = (sidx * (uint32_t)A + a) * 128u;
+        o8[2 * j + 1] = field;
+      }
+      memcpy(p8.data() + k * tb8 + ((size_t)8 << D), leaves.data(), sizeof(float) << D);
+    }
+    if ((rc = dev_upload(m, p8, &m->xgb.h8_packed, 64)) != GNX_OK) return rc;
+    if ((rc = dev_upload(m, g8_tree0, &m->xgb.h8_group_tree0)) != GNX_OK) return rc;
+    if ((rc = dev_upload(m, g8_class, &m->xgb.h8_group_class)) != GNX_OK) return rc;
+    m->xgb.h8_tree_bytes = tb8; m->xgb.h8_n_groups = (int32_t)g8_class.size(); m->xgb.h8_max_group = G8;
+  }
   return GNX_OK;
 }
 
@@ -564,8 +602,18 @@ static int build_forest(gnx_model* m, const gnx_model_desc* d) {
     }
     for (int c = (A == 2 ? 1 : A); c <= A; ++c) ct[c] = t1 - t0;
   }
+  // k_base_forest2's node words: the loader words above, baked for their window (first word, ring size) at load time
+  std::vector<uint32_t> nodes2((size_t)d->fb_n_trees << D, 0);
+  for (int64_t w = 0; w < W; ++w) {
+    const uint32_t ring = (uint32_t)gnx_forest_ring_words(w == W - 1 ? M_ + rem : M_), g0 = (uint32_t)((w * M) >> 4);
+    for (int32_t t = win_tree0[(size_t)w]; t < win_tree0[(size_t)w + 1]; ++t) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(packed.data() + (size_t)t * tree_bytes);
+      for (uint32_t j = 1; j < (1u << D); ++j) nodes2[((size_t)t << D) + j] = gnx_forest2_node(src[j], g0, ring);
+    }
+  }
   int rc;
   if ((rc = dev_upload(m, packed, &m->forest.packed, 64)) != GNX_OK) return rc;
+  if ((rc = dev_upload(m, nodes2, &m->forest.nodes2, 64)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, win_tree0, &m->forest.win_tree0)) != GNX_OK) return rc;
   if ((rc = dev_upload(m, wct, &m->forest.win_class_tree0)) != GNX_OK) return rc;
   m->forest.D = D; m->forest.tree_bytes = tree_bytes; m->forest.max_trees = max_trees; m->forest.max_words = max_words;
@@ -775,6 +823,7 @@ static void read_tune(gnx_tune& t) {
   t.forest_wrun = geti("GNX_FOREST_WRUN", 0);
   t.forest_halves = geti("GNX_FOREST_H", 0);
   t.forest_flags = geti("GNX_FOREST_FLAGS", 0);
+  t.forest_impl = geti("GNX_FOREST_IMPL", 0);
   if (const char* e = std::getenv("GNX_HOST_BATCH")) t.host_batch = std::atoll(e);
   t.h2d_overlap = geti("GNX_H2D_OVERLAP", 1);
   t.debug = std::getenv("GNX_DEBUG") ? atoi(std::getenv("GNX_DEBUG")) : 0;
@@ -820,7 +869,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
   if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
-  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi, &ctx->ws_gt2, &ctx->ws_src, &ctx->ws_gt2o})
+  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi, &ctx->ws_gt2, &ctx->ws_src, &ctx->ws_gt2o, &ctx->ws_rank})
     if (b->p) (void)hipFree(b->p);
   for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal, &ctx->ws_marg})
     if (b->p) (void)hipFree(b->p);
@@ -1011,7 +1060,12 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     L.packed = m->forest.packed; L.win_tree0 = m->forest.win_tree0; L.win_class_tree0 = m->forest.win_class_tree0;
     L.rf_leafval = m->forest.rf_leafval;
     L.b32 = d_b32; L.b64 = d_b64;
-    HIPCHK(ctx, gnx_launch_base_forest(L, ctx->n_cu, ctx->tune, ctx->stream));
+    // boosted trees: the two-blocks-per-CU kernel wherever its 128-haplotype tile fits the LDS; random forest and GNX_FOREST_IMPL=1:
+    // the 256-haplotype kernel
+    const bool v2 = !L.rf_leafval && m->forest.nodes2 && ctx->tune.forest_impl != 1 &&
+                    gnx_forest2_lds_bytes(L.A, gnx_forest_ring_words(L.width_last), L.max_trees, L.D) <= (size_t)160 * 1024;
+    if (v2) HIPCHK(ctx, gnx_launch_base_forest2(L, m->forest.nodes2, ctx->n_cu, ctx->tune, ctx->stream));
+    else HIPCHK(ctx, gnx_launch_base_forest(L, ctx->n_cu, ctx->tune, ctx->stream));
     return GNX_OK;
   }
   if (m->info.base_kind != GNX_BASE_LOGISTIC) return fail(ctx, GNX_ESTATE, "model has no base classifier");
@@ -1084,13 +1138,18 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     L.B = dB; L.b_is_f64 = b_is_f64; L.N = N;
     L.W = (int32_t)m->info.W; L.A = m->info.A; L.S = m->info.S;
     L.d = m->xgb; L.proba = d_p32; L.proba64 = d_p64; L.labels = d_lab;
+    const bool h64 = m->xgb.rk_packed && m->xgb.impl != 1 && gnx_smooth_h64_waves(m->xgb, m->info.A, m->info.S) > 0;
+    if (m->xgb.impl == 2 && !h64) return fail(ctx, GNX_EUNSUPPORTED, "GNX_SMOOTH_IMPL=h64: the model's strip does not fit the LDS");
     if (m->xgb.rk_packed) {
-      int rc = ws_reserve(ctx, ctx->ws_marg, n * sizeof(float));
+      const size_t n_pad = (size_t)((N + 63) / 64 * 64) * m->info.W * m->info.A;   // h64 parks whole 64-haplotype lines
+      int rc = ws_reserve(ctx, ctx->ws_marg, n_pad * sizeof(float));
       if (rc != GNX_OK) return rc;
       L.marg = (float*)ctx->ws_marg.p;
+      if (h64 && (rc = ws_reserve(ctx, ctx->ws_rank, gnx_smooth_h64_rank_bytes(N, L.W, L.A, L.S))) != GNX_OK) return rc;
     }
     ProfScope ps(ctx, GNX_K_SMOOTH_XGB);
-    if (m->xgb.rk_packed) HIPCHK(ctx, gnx_launch_smooth_xgb_rk(L, ctx->tune, ctx->stream));
+    if (h64) HIPCHK(ctx, gnx_launch_smooth_xgb_h64(L, (uint16_t*)ctx->ws_rank.p, ctx->tune, ctx->stream));
+    else if (m->xgb.rk_packed) HIPCHK(ctx, gnx_launch_smooth_xgb_rk(L, ctx->tune, ctx->stream));
     else HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->tune, ctx->stream));
     return GNX_OK;
   }

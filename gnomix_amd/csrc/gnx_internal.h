@@ -39,6 +39,8 @@ struct gnx_tune {
   int forest_threads = 0;               // GNX_FOREST_T
   int forest_wrun = 0;                  // GNX_FOREST_WRUN: windows per block of the forest bases
   int forest_halves = 0;                // GNX_FOREST_H=1: one wave group per tile (default: two for the boosted-tree base)
+  int forest_impl = 0;                  // GNX_FOREST_IMPL=1: k_base_forest (256-haplotype tile, register prefetch) for the boosted-tree
+                                        // base too; default 2: k_base_forest2 (two blocks per CU) wherever its tile fits
   int forest_flags = 0;                 // GNX_FOREST_FLAGS: ablation (1 = no walks, 2 = no register prefetch, 4 = no incremental staging)
   int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
   int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points
@@ -73,6 +75,7 @@ struct gnx_ctx {
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   gnx_devbuf ws_pk, ws_xu, ws_psi;
+  gnx_devbuf ws_rank;  // k_smooth_ranks -> k_smooth_xgb_h64
   gnx_devbuf ws_gt2, ws_src, ws_gt2o;  // file path (gnx_api_vcf.hip): variant-major 2-bit genotypes, column map, phased rows
   // profiling
   bool prof = false;
@@ -141,6 +144,13 @@ struct SmoothXGBDev {
   const int32_t* rk_group_class = nullptr;
   int32_t rk_K = 0, rk_steps = 0, rk_stride = 0, rk_tree_bytes = 0, rk_n_groups = 0, rk_max_group = 0;
   int32_t rk_rpl = 0;                    // 64-window segments per strip the node offsets were laid out for
+  // lane = haplotype copy for k_smooth_xgb_h64 (same ranks, rk_thr / rk_lut): per tree 2^D nodes of 8 bytes {byte offset of the
+  // feature's slot = (s * A + a) * 128, rank field} (heap slot 0 unused) followed by 2^D float leaves, padded to 16 bytes
+  const uint8_t* h8_packed = nullptr;
+  const int32_t* h8_group_tree0 = nullptr;
+  const int32_t* h8_group_class = nullptr;
+  int32_t h8_tree_bytes = 0, h8_n_groups = 0, h8_max_group = 0;
+  int32_t impl = 0;                      // 0 auto (h64 where its strip fits the LDS, else rk), 1 rk, 2 h64 (GNX_SMOOTH_IMPL at model load)
 };
 
 constexpr int GNX_RK_RPL_MAX = 6;  // most 64-window segments per strip the rank kernel is instantiated for
@@ -295,6 +305,7 @@ struct ForestDev {
   int32_t D = 0, tree_bytes = 0, max_trees = 0, max_words = 0, missing = 2;
   float base_score = 0.5f;
   const double* rf_leafval = nullptr;       // random forest: [tree][2^D heap leaf][A] class-probability rows
+  const uint32_t* nodes2 = nullptr;         // k_base_forest2: [tree][2^D] node words baked per window (ring slot byte offset | field | right-mask)
 };
 
 struct ForestLaunch {
@@ -352,6 +363,9 @@ hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, const gn
 hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_launch_smooth_xgb_h64(const SmoothXGBLaunch& L, uint16_t* Rk, const gnx_tune& tune, hipStream_t s);
+int gnx_smooth_h64_waves(const SmoothXGBDev& d, int A, int S);            // 0: the strip does not fit the LDS
+size_t gnx_smooth_h64_rank_bytes(int64_t N, int W, int A, int S);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);
 hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwp,
@@ -373,5 +387,8 @@ inline int gnx_cnn_ap(int A) { return A <= 8 ? 8 : A <= 16 ? 16 : 32; }  // outp
 hipError_t gnx_launch_smooth_cnn(const SmoothCNNLaunch& L, hipStream_t s);
 hipError_t gnx_launch_base_forest(const ForestLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 size_t gnx_forest_lds_bytes(int A, int ring_words, int max_trees, int tree_bytes, int threads);
+hipError_t gnx_launch_base_forest2(const ForestLaunch& L, const uint32_t* nodes2, int n_cu, const gnx_tune& tune, hipStream_t s);
+size_t gnx_forest2_lds_bytes(int A, int ring_words, int max_trees, int D);
+uint32_t gnx_forest2_node(uint32_t loader_word, uint32_t g0, uint32_t ring);
 int gnx_forest_ring_words(int64_t width);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

@@ -1,0 +1,269 @@
+// k_base_forest2.hip — the boosted-tree window base (XGBBase, reference src/Base/models.py:24-35) with TWO blocks per CU.
+//
+// Same contract, tile and walk as k_base_forest.hip (2-bit SNP fields in an LDS ring anchored on the padded chromosome
+// coordinate, mask nodes, margins per class in float32 in tree order, softmax / sigmoid as the restated predictor).  What
+// round 2's kernel paid for: one 256-haplotype tile filled the LDS, so ONE block (two waves per SIMD) had to hide the HBM
+// latency of its own staging with a hand-rolled register prefetch — 64 raw + 32 squeezed + 16 tree registers next to 8 walk
+// chains: 256 VGPRs + 54 spilled + 148 SGPR spills, 312 B of scratch per lane (scripts/scratch_audit.py) — and rewrote every
+// node word for the window and block shape on its way into LDS.  Here
+//   * a tile is 128 haplotypes (64 KB of ring) and only the NODE words of the window's trees go to LDS (64 B per depth-4 tree;
+//     the leaves, read once per walk, come from global memory / L1): 76 KB per block -> two blocks per CU, 16 waves, and the
+//     staging of one block runs under the walks of the other.  Staging is synchronous and simple: no prefetch registers.
+//   * node words are baked per window at model load (ring slot byte offset << 15 | 2 * field << 4 | right-mask: the word the
+//     walk consumes), a window's nodes are a straight copy.
+//   * four wave groups share a tile and split the classes (margins meet in LDS), group 0 writes the probabilities.
+// The random-forest base keeps k_base_forest.hip (its float64 class rows are summed over ALL trees in estimator order by one
+// lane per haplotype: nothing to split between wave groups).
+#include "gnx_internal.h"
+
+namespace {
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+constexpr int T2 = 128;   // haplotypes per tile
+constexpr int H2 = 4;     // wave groups per tile
+constexpr int NTHR2 = T2 * H2;
+constexpr int TPW2 = 8;   // trees walked side by side per lane
+constexpr int LB2 = 6;    // 16-byte loads in flight per lane while staging (16 waves per CU: ~100 KB in flight; 8 spills 6 VGPRs)
+
+__device__ __forceinline__ int64_t pad_src2(int64_t p, int64_t C, int64_t ctx) {
+  if (p < ctx) return ctx - 1 - p;
+  if (p < ctx + C) return p - ctx;
+  return C - 1 - (p - ctx - C);
+}
+__device__ __forceinline__ uint32_t squeeze4b(uint32_t d) {  // 4 SNP bytes (values 0..3) -> 8 bits
+  const uint32_t x = d & 0x03030303u;
+  const uint32_t y = x | (x >> 6);
+  return (y | (y >> 12)) & 0xffu;
+}
+__device__ __forceinline__ uint32_t step2(uint32_t j, uint32_t nd, uint32_t xv) {
+  const uint32_t v = __builtin_amdgcn_ubfe(xv, __builtin_amdgcn_ubfe(nd, 4, 5), 2);  // the 2-bit SNP value
+  return 2 * j + __builtin_amdgcn_ubfe(nd, v, 1);                                     // + 1 iff value v goes right
+}
+
+// NT trees side by side: nodes in LDS (stride 2^D words), the lane's ring column xcol, leaves from the loader's records
+template <int D, int NT>
+__device__ __forceinline__ void walk2(const uint32_t* nodes, const uint8_t* xcol, const uint8_t* rec, int tree_bytes, float* leaf) {
+  uint32_t j[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) j[k] = 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    uint32_t nd[NT], xv[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) nd[k] = nodes[(k << D) + j[k]];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) xv[k] = *reinterpret_cast<const uint32_t*>(xcol + (nd[k] >> 15));
+#pragma unroll
+    for (int k = 0; k < NT; ++k) j[k] = step2(j[k], nd[k], xv[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) leaf[k] = reinterpret_cast<const float*>(rec + (size_t)k * tree_bytes)[j[k]];  // leaves follow the 2^D node words
+}
+
+__device__ __forceinline__ void window_words2(const ForestLaunch& L, int w, int64_t& g0, int64_t& g1) {
+  const int64_t s = (int64_t)w * L.M, width = (w == L.W - 1) ? L.width_last : L.width;
+  g0 = s >> 4;
+  g1 = ((s + width - 1) >> 4) + 1;
+}
+
+template <int D>
+// (HIP reads the second launch bound as waves per SIMD: two 8-wave blocks per CU = 4, i.e. at most 128 VGPRs)
+__global__ __launch_bounds__(NTHR2, 4) void k_base_forest2(ForestLaunch L, const uint32_t* __restrict__ nodes2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = tid / T2, hap = tid - half * T2;
+  const int A = L.A, tree_bytes = L.tree_bytes;
+  const uint32_t ring = (uint32_t)L.ring;
+  uint32_t* xw = reinterpret_cast<uint32_t*>(lds);                                   // [ring][T2]
+  uint32_t* nlds = xw + (size_t)ring * T2;                                           // node words of the current window
+  float* marg = reinterpret_cast<float*>(nlds + ((size_t)L.max_trees << D)) + hap;   // [A][T2]
+
+  const int wa = L.w_first + blockIdx.y * L.wrun, wb = min(L.w_first + L.n_windows, wa + L.wrun);
+  const int64_t blk0 = (int64_t)blockIdx.x * T2;
+  const int64_t n = blk0 + hap;
+  const int64_t C = L.C, ctx = L.ctx, cmax = C - 16;
+  const int wsub = lane & 7, hsub = lane >> 3;
+
+  // words [ga, gb) of the tile's 128 haplotypes -> ring.  A wave-task = 8 haplotypes x 8 consecutive words (8 lanes along a row
+  // cover 128 contiguous bytes); tasks are dealt to the 8 waves round robin, LB2 loads in flight per lane.
+  auto stage = [&](int64_t ga, int64_t gb) {
+    const int wgroups = (int)((gb - ga + 7) >> 3);
+    const int ntask = wgroups * (T2 / 8);
+    // task i -> (word, haplotype of the tile, row); recomputed where it is needed instead of being kept across the loads:
+    // the registers belong to the bytes in flight (two blocks per CU need the kernel inside 128 VGPRs)
+    auto task = [&](int i, int64_t& g, int& hp) {
+      const int hg = i % (T2 / 8), wg = i / (T2 / 8);
+      g = ga + 8 * wg + wsub;
+      hp = hg * 8 + hsub;
+    };
+    auto rowp = [&](int hp) -> const int8_t* {
+      int64_t nn = blk0 + hp;
+      nn = nn < L.N ? nn : L.N - 1;
+      return L.X + nn * L.ldx;
+    };
+    for (int i0 = wave; i0 < ntask; i0 += 8 * LB2) {
+      v4u v[LB2];
+#pragma unroll
+      for (int u = 0; u < LB2; ++u) {
+        int64_t g;
+        int hp;
+        task(min(i0 + 8 * u, ntask - 1), g, hp);  // clamped: loads stay unconditional
+        g = min(g, gb - 1);
+        int64_t c0 = 16 * g - ctx;
+        c0 = c0 < 0 ? 0 : (c0 > cmax ? cmax : c0);
+        __builtin_memcpy(&v[u], rowp(hp) + c0, 16);
+      }
+#pragma unroll
+      for (int u = 0; u < LB2; ++u) {
+        const int i = i0 + 8 * u;
+        int64_t g;
+        int hp;
+        task(min(i, ntask - 1), g, hp);
+        if (i >= ntask || g >= gb) continue;
+        const int64_t p0 = 16 * g;
+        uint32_t q = squeeze4b(v[u].x) | (squeeze4b(v[u].y) << 8) | (squeeze4b(v[u].z) << 16) | (squeeze4b(v[u].w) << 24);
+        if (p0 < ctx || p0 + 16 > ctx + C) {  // rare: the word touches the reflect padding / the row's end
+          const int8_t* row = rowp(hp);
+          q = 0;
+          for (int b = 0; b < 16; ++b) {
+            const int64_t p = p0 + b;
+            if (p < C + 2 * ctx) q |= ((uint32_t)(uint8_t)row[pad_src2(p, C, ctx)] & 3u) << (2 * b);
+          }
+        }
+        xw[(size_t)((uint32_t)g & (ring - 1u)) * T2 + hp] = q;  // ring: a power of two
+      }
+    }
+  };
+
+  int64_t g0, g1, pg1 = 0;
+  for (int w = wa; w < wb; ++w) {
+    window_words2(L, w, g0, g1);
+    // the window's new words (all of them for the first window of the run) and its node words
+    stage(w == wa ? g0 : (g0 > pg1 ? g0 : pg1), g1);
+    pg1 = g1;
+    const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(nodes2 + ((size_t)t0 << D));
+      const int np = D >= 2 ? (nt << D) / 4 : 0;  // 16-byte pieces (a tree = 2^D words; stumps are copied word by word below)
+      for (int e = tid; e < np; e += NTHR2) reinterpret_cast<uint4*>(nlds)[e] = src[e];
+      for (int e = np * 4 + tid; e < (nt << D); e += NTHR2) nlds[e] = nodes2[((size_t)t0 << D) + e];
+    }
+    __syncthreads();  // tile + nodes of window w complete; everybody has read the previous window's margins
+
+    const uint8_t* xcol = reinterpret_cast<const uint8_t*>(xw + hap);
+    const int32_t* cls0 = L.win_class_tree0 + (size_t)w * (A + 1);  // [A+1] offsets relative to t0
+    const int n_groups = (A == 2) ? 1 : A;
+    const int c_lo = (half * n_groups) / H2, c_hi = ((half + 1) * n_groups) / H2;
+    const uint8_t* rec0 = L.packed + (size_t)t0 * tree_bytes;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const int a0 = (A == 2) ? 0 : cls0[c], a1 = (A == 2) ? nt : cls0[c + 1];
+      float psum = 0.f;
+      int t = a0;
+      for (; t + TPW2 <= a1; t += TPW2) {
+        float leaf[TPW2];
+        walk2<D, TPW2>(nlds + ((size_t)t << D), xcol, rec0 + (size_t)t * tree_bytes, tree_bytes, leaf);
+#pragma unroll
+        for (int k = 0; k < TPW2; ++k) psum += leaf[k];  // tree order
+      }
+      for (; t < a1; ++t) {
+        float leaf[1];
+        walk2<D, 1>(nlds + ((size_t)t << D), xcol, rec0 + (size_t)t * tree_bytes, tree_bytes, leaf);
+        psum += leaf[0];
+      }
+      marg[c * T2] = psum;
+    }
+    __syncthreads();  // every lane is done with window w's tile and nodes; the margins of all classes are in LDS
+
+    if (half == 0 && n < L.N) {
+      const size_t o = ((size_t)n * L.W + w) * A;
+      if (A == 2) {
+        const float margin = logf(L.base_score / (1.0f - L.base_score)) + marg[0];  // ProbToMargin of binary:logistic
+        const float p1 = 1.0f / (1.0f + (float)exp((double)(-margin)));
+        const float p[2] = {1.0f - p1, p1};
+        for (int a = 0; a < 2; ++a) {
+          if (L.b32) L.b32[o + a] = p[a];
+          if (L.b64) L.b64[o + a] = (double)p[a];
+        }
+      } else {
+        float wmax = L.base_score + marg[0];
+        for (int a = 1; a < A; ++a) wmax = fmaxf(L.base_score + marg[a * T2], wmax);
+        // exp evaluated twice per class (sum, then output) instead of A values kept in registers across the loop: the
+        // kernel has to stay inside 128 VGPRs for two blocks per CU, and this epilogue is ~1 % of a window's work
+        double wsum = 0.0;
+        for (int a = 0; a < A; ++a) wsum += (double)(float)exp((double)((L.base_score + marg[a * T2]) - wmax));
+        const float fs = (float)wsum;
+        for (int a = 0; a < A; ++a) {
+          const float p = (float)exp((double)((L.base_score + marg[a * T2]) - wmax)) / fs;
+          if (L.b32) L.b32[o + a] = p;
+          if (L.b64) L.b64[o + a] = (double)p;
+        }
+      }
+    }
+    // (the next iteration's staging rewrites ring slots and node words every lane is done with; the margins are rewritten
+    //  only behind the next iteration's first barrier, after group 0 has read them)
+  }
+}
+
+template <int D>
+hipError_t launch2_d(const ForestLaunch& L, const uint32_t* nodes2, size_t lds, hipStream_t s) {
+  GNX_LDS_OPTIN(lds, k_base_forest2<D>);
+  const int n_runs = (L.n_windows + L.wrun - 1) / L.wrun;
+  hipLaunchKernelGGL((k_base_forest2<D>), dim3((unsigned)((L.N + T2 - 1) / T2), (unsigned)n_runs), dim3(NTHR2), lds, s, L, nodes2);
+  return hipGetLastError();
+}
+
+hipError_t launch_range2(ForestLaunch L, const uint32_t* nodes2, int w_first, int n_windows, int64_t width, int n_cu, const gnx_tune& tune,
+                         hipStream_t s) {
+  if (n_windows <= 0) return hipSuccess;
+  L.w_first = w_first;
+  L.n_windows = n_windows;
+  L.ring = gnx_forest_ring_words(width);
+  const size_t lds = gnx_forest2_lds_bytes(L.A, L.ring, L.max_trees, L.D);
+  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  const int per_cu = lds <= (size_t)80 * 1024 ? 2 : 1;
+  // windows per block: as k_base_forest — long runs re-use the shared half of every window (the first window of a run is staged
+  // in full: about two window-steps), short runs fill the chip; blocks run in rounds of per_cu per CU
+  const int64_t tiles = (L.N + T2 - 1) / T2;
+  int64_t wrun = tune.forest_wrun;
+  if (wrun <= 0) {
+    int64_t best = INT64_MAX;
+    for (int64_t r = 1; r <= std::min<int64_t>(24, n_windows); ++r) {
+      const int64_t blocks = tiles * ((n_windows + r - 1) / r);
+      const int64_t cost = ((blocks + (int64_t)n_cu * per_cu - 1) / ((int64_t)n_cu * per_cu)) * (r + 1);
+      if (cost < best) { best = cost; wrun = r; }
+    }
+  }
+  L.wrun = (int)std::min<int64_t>(std::max<int64_t>(1, wrun), n_windows);
+  switch (L.D) {
+    case 1: return launch2_d<1>(L, nodes2, lds, s);
+    case 2: return launch2_d<2>(L, nodes2, lds, s);
+    case 3: return launch2_d<3>(L, nodes2, lds, s);
+    case 4: return launch2_d<4>(L, nodes2, lds, s);
+    case 5: return launch2_d<5>(L, nodes2, lds, s);
+    case 6: return launch2_d<6>(L, nodes2, lds, s);
+    case 7: return launch2_d<7>(L, nodes2, lds, s);
+    case 8: return launch2_d<8>(L, nodes2, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+size_t gnx_forest2_lds_bytes(int A, int ring_words, int max_trees, int D) {
+  return (size_t)ring_words * T2 * 4 + (((size_t)max_trees << D) * 4 + 15 & ~(size_t)15) + (size_t)A * T2 * 4;
+}
+
+// node word of k_base_forest2 for a loader word (position << 4 | left-mask) of a window whose first word is g0, in a ring of
+// `ring` word slots (a power of two): (byte offset of the slot's row of 128 haplotypes) << 15 | (2 * field) << 4 | right-mask
+uint32_t gnx_forest2_node(uint32_t nd, uint32_t g0, uint32_t ring) {
+  const uint32_t pos = nd >> 4;
+  const uint32_t slot = ((pos >> 4) + g0) & (ring - 1u);
+  return ((slot * (uint32_t)T2 * 4u) << 15) | ((2u * (pos & 15u)) << 4) | (~nd & 15u);
+}
+
+hipError_t gnx_launch_base_forest2(const ForestLaunch& L, const uint32_t* nodes2, int n_cu, const gnx_tune& tune, hipStream_t s) {
+  if (L.N <= 0) return hipSuccess;
+  hipError_t e = launch_range2(L, nodes2, 0, L.W - 1, L.width, n_cu, tune, s);
+  if (e != hipSuccess) return e;
+  return launch_range2(L, nodes2, L.W - 1, 1, L.width_last, n_cu, tune, s);
+}

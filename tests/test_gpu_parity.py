@@ -689,6 +689,18 @@ def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S
         pr, lr = ga.DeviceModel(d).smooth_predict(B)
         assert np.array_equal(pf, pr, equal_nan=True), rpl
         assert np.array_equal(lf, lr), rpl
+    # lane = haplotype kernel (k_smooth_ranks + k_smooth_xgb_h64): same ranks, same leaf order -> the same bits
+    monkeypatch.setenv("GNX_SMOOTH_IMPL", "h64")
+    monkeypatch.delenv("GNX_RK_RPL")
+    for nw in ("16", "8", "4"):
+        monkeypatch.setenv("GNX_SM_NW", nw)
+        from gnomix_amd import _lib
+        ctx = _lib.Context(0)                                                 # GNX_SM_NW is read at gnx_init
+        ph, lh = ga.DeviceModel(d, ctx=ctx).smooth_predict(B)
+        assert np.array_equal(pf, ph, equal_nan=True), nw
+        assert np.array_equal(lf, lh), nw
+        ctx.close()
+    monkeypatch.delenv("GNX_SM_NW")
     finite = np.isfinite(B).all(axis=(1, 2))                                  # oracle as the third opinion
     T = _oracle_trees(oracle, d)
     p_ref, l_ref = oracle.smooth_xgb(T, B[finite], S)
