@@ -121,8 +121,9 @@ __global__ __launch_bounds__(64) void k_covrsk_dec(CovRSKLaunch L) {
   const uint32_t tail_mask = (width & 31) ? ((1u << (width & 31)) - 1u) : 0xffffffffu;
   const double* dual = L.coef + win.coef_off;  // (A-1, n_sv)
 
+  const int32_t* cls_start = L.win[w].cls_start;  // from the table, not from the private copy: a run-time index would put it in scratch
   for (int c = 0; c < A; ++c) {
-    for (int sv = win.cls_start[c]; sv < win.cls_start[c + 1]; ++sv) {
+    for (int sv = cls_start[c]; sv < cls_start[c + 1]; ++sv) {
       const uint32_t* yb = L.svbits + win.sv_off + (size_t)sv * 2 * NW;  // wave-uniform -> scalar loads
       double Kd;
       if constexpr (POLY) {

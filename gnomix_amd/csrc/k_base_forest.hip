@@ -138,8 +138,9 @@ struct Stager {
     }
     return q;
   }
-  // words [ga, gb) of the wave's 64 haplotypes -> ring, synchronously
-  __device__ void stage(uint32_t* xw, uint32_t mask, int64_t ga, int64_t gb) const {
+  // words [ga, gb) of the wave's 64 haplotypes -> ring, synchronously.  (Inlined: as an out-of-line member the object it is
+  // called on has to live in memory, i.e. 104 B of scratch per lane in every instance of the kernel.)
+  __device__ __forceinline__ void stage(uint32_t* xw, uint32_t mask, int64_t ga, int64_t gb) const {
     for (int hb = hb0; hb < hb0 + hbn; ++hb) {
       const int8_t* r = row(hb);
       uint32_t* col = xw + wv * 64 + hb * 8 + hsub;
@@ -221,7 +222,9 @@ __global__ __launch_bounds__(256 * H) void k_base_forest(ForestLaunch L) {
   const int64_t n = (int64_t)blockIdx.x * T + hap;
 
   // a window's trees: uint4 pieces of the loader's records, node words rewritten for the window on their way into LDS
-  constexpr int TQ = 8 / H;  // pieces per thread held in registers while the previous window is walked
+  // pieces per thread held in registers while the previous window is walked (random forest: 2 — its float64 class sums and the
+  // word prefetch already fill the 512 registers of a lane; with 8 the kernel spilled 12 VGPRs)
+  constexpr int TQ = RF ? 2 : 8 / H;
   const int words_per_tree = tree_bytes / 4, node_words = RF ? tree_bytes / 4 : (1 << D);
   auto put_tree_piece = [&](int e, uint4 v, uint32_t gw0) {
     const int wd = (e * 4) % words_per_tree;  // first word of the piece inside its tree (records are multiples of 16 bytes)

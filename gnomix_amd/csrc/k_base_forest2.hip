@@ -19,45 +19,54 @@
 namespace {
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-constexpr int T2 = 128;   // haplotypes per tile
+#ifndef GNX_F2_T
+#define GNX_F2_T 128
+#endif
+constexpr int T2 = GNX_F2_T;   // haplotypes per tile (128: two blocks per CU at chr22's window width; 64: three)
 constexpr int H2 = 4;     // wave groups per tile
-constexpr int NTHR2 = T2 * H2;
-constexpr int TPW2 = 8;   // trees walked side by side per lane
-constexpr int LB2 = 6;    // 16-byte loads in flight per lane while staging (16 waves per CU: ~100 KB in flight; 8 spills 6 VGPRs)
+constexpr int NTHR2 = T2 * H2, NWV2 = NTHR2 / 64;
+constexpr int WPS2 = T2 == 128 ? 4 : 3;  // waves per SIMD the kernel is compiled for (HIP's second launch bound): 128 / 170 VGPRs
+#ifndef GNX_F2_TPW
+#define GNX_F2_TPW 10
+#endif
+constexpr int TPW2 = GNX_F2_TPW;  // trees walked side by side per lane (XGBBase: 20 rounds -> 20 trees per class = two batches)
+constexpr int LB2 = 4;    // 16-byte loads in flight per lane while staging (16 waves per CU: 64 KB in flight; more spills registers)
 
 __device__ __forceinline__ int64_t pad_src2(int64_t p, int64_t C, int64_t ctx) {
   if (p < ctx) return ctx - 1 - p;
   if (p < ctx + C) return p - ctx;
   return C - 1 - (p - ctx - C);
 }
-__device__ __forceinline__ uint32_t squeeze4b(uint32_t d) {  // 4 SNP bytes (values 0..3) -> 8 bits
-  const uint32_t x = d & 0x03030303u;
-  const uint32_t y = x | (x >> 6);
-  return (y | (y >> 12)) & 0xffu;
-}
 __device__ __forceinline__ uint32_t step2(uint32_t j, uint32_t nd, uint32_t xv) {
   const uint32_t v = __builtin_amdgcn_ubfe(xv, __builtin_amdgcn_ubfe(nd, 4, 5), 2);  // the 2-bit SNP value
   return 2 * j + __builtin_amdgcn_ubfe(nd, v, 1);                                     // + 1 iff value v goes right
 }
 
-// NT trees side by side: nodes in LDS (stride 2^D words), the lane's ring column xcol, leaves from the loader's records
+// NT trees side by side, trees t .. t + NT - 1 of the window clamped to t_last (a short last batch walks its last tree more
+// than once; the caller ignores those leaves): nodes in LDS (2^D words per tree), the lane's ring column xcol, leaves from the
+// loader's records in global memory.  The leaf loads are ISSUED here and awaited where the caller adds them up.
 template <int D, int NT>
-__device__ __forceinline__ void walk2(const uint32_t* nodes, const uint8_t* xcol, const uint8_t* rec, int tree_bytes, float* leaf) {
+__device__ __forceinline__ void walk2(const uint32_t* nodes, const uint8_t* xcol, const uint8_t* rec, int tree_bytes, int t, int t_last,
+                                      float* leaf) {
   uint32_t j[NT];
+  int tk[NT];
 #pragma unroll
-  for (int k = 0; k < NT; ++k) j[k] = 1;
+  for (int k = 0; k < NT; ++k) {
+    j[k] = 1;
+    tk[k] = min(t + k, t_last);
+  }
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     uint32_t nd[NT], xv[NT];
 #pragma unroll
-    for (int k = 0; k < NT; ++k) nd[k] = nodes[(k << D) + j[k]];
+    for (int k = 0; k < NT; ++k) nd[k] = nodes[(tk[k] << D) + j[k]];
 #pragma unroll
     for (int k = 0; k < NT; ++k) xv[k] = *reinterpret_cast<const uint32_t*>(xcol + (nd[k] >> 15));
 #pragma unroll
     for (int k = 0; k < NT; ++k) j[k] = step2(j[k], nd[k], xv[k]);
   }
 #pragma unroll
-  for (int k = 0; k < NT; ++k) leaf[k] = reinterpret_cast<const float*>(rec + (size_t)k * tree_bytes)[j[k]];  // leaves follow the 2^D node words
+  for (int k = 0; k < NT; ++k) leaf[k] = reinterpret_cast<const float*>(rec + (size_t)tk[k] * tree_bytes)[j[k]];  // leaves follow the 2^D node words
 }
 
 __device__ __forceinline__ void window_words2(const ForestLaunch& L, int w, int64_t& g0, int64_t& g1) {
@@ -68,7 +77,7 @@ __device__ __forceinline__ void window_words2(const ForestLaunch& L, int w, int6
 
 template <int D>
 // (HIP reads the second launch bound as waves per SIMD: two 8-wave blocks per CU = 4, i.e. at most 128 VGPRs)
-__global__ __launch_bounds__(NTHR2, 4) void k_base_forest2(ForestLaunch L, const uint32_t* __restrict__ nodes2) {
+__global__ __launch_bounds__(NTHR2, WPS2) void k_base_forest2(ForestLaunch L, const uint32_t* __restrict__ nodes2) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = tid / T2, hap = tid - half * T2;
@@ -82,55 +91,63 @@ __global__ __launch_bounds__(NTHR2, 4) void k_base_forest2(ForestLaunch L, const
   const int64_t blk0 = (int64_t)blockIdx.x * T2;
   const int64_t n = blk0 + hap;
   const int64_t C = L.C, ctx = L.ctx, cmax = C - 16;
-  const int wsub = lane & 7, hsub = lane >> 3;
+  const int wsub = lane & 7, hsub = lane >> 3;  // 8 consecutive lanes along a row: 128 contiguous bytes per haplotype
 
-  // words [ga, gb) of the tile's 128 haplotypes -> ring.  A wave-task = 8 haplotypes x 8 consecutive words (8 lanes along a row
-  // cover 128 contiguous bytes); tasks are dealt to the 8 waves round robin, LB2 loads in flight per lane.
-  auto stage = [&](int64_t ga, int64_t gb) {
-    const int wgroups = (int)((gb - ga + 7) >> 3);
-    const int ntask = wgroups * (T2 / 8);
-    // task i -> (word, haplotype of the tile, row); recomputed where it is needed instead of being kept across the loads:
-    // the registers belong to the bytes in flight (two blocks per CU need the kernel inside 128 VGPRs)
-    auto task = [&](int i, int64_t& g, int& hp) {
-      const int hg = i % (T2 / 8), wg = i / (T2 / 8);
-      g = ga + 8 * wg + wsub;
-      hp = hg * 8 + hsub;
-    };
-    auto rowp = [&](int hp) -> const int8_t* {
-      int64_t nn = blk0 + hp;
-      nn = nn < L.N ? nn : L.N - 1;
-      return L.X + nn * L.ldx;
-    };
-    for (int i0 = wave; i0 < ntask; i0 += 8 * LB2) {
-      v4u v[LB2];
+  // words [ga, gb) of the tile's haplotypes -> ring.  A wave owns RPW groups of 8 haplotypes for the whole kernel (their row
+  // pointers are computed once), a load instruction covers 8 haplotypes x 8 consecutive words, LB2 loads in flight per lane.
+  // 16 SNP bytes become one 32-bit word with four v_dot4_u32_u8 against the weights (1, 4, 16, 64): the staging of a window costs
+  // about as many VALU instructions as a third of its walks (the shift-and-or squeeze of k_base_forest cost as many as all of
+  // them, so staging one block could not hide under the walks of the other).  The ring is [word slot][haplotype]: lanes that
+  // store different words of ONE haplotype hit one bank (8-way conflicted stores); shapes that avoid it fetch rows in 32- or
+  // 64-byte pieces and measured slower (2 x 32: 1.95 ms, 4 x 16: 1.72 ms against 1.61 ms for this 8 x 8 shape, chr22 / 10 000
+  // haplotypes): the fetch pattern decides, not the store conflicts.
+  constexpr int RPW = (T2 / 8) / NWV2;  // haplotype groups per wave (2)
+  const int8_t* rowp[RPW];
+  int hpw[RPW];
 #pragma unroll
-      for (int u = 0; u < LB2; ++u) {
-        int64_t g;
-        int hp;
-        task(min(i0 + 8 * u, ntask - 1), g, hp);  // clamped: loads stay unconditional
-        g = min(g, gb - 1);
+  for (int r = 0; r < RPW; ++r) {
+    hpw[r] = (wave * RPW + r) * 8 + hsub;
+    int64_t nn = blk0 + hpw[r];
+    nn = nn < L.N ? nn : L.N - 1;
+    rowp[r] = L.X + nn * L.ldx;
+  }
+  auto squeeze16 = [](const v4u& v) -> uint32_t {
+    constexpr uint32_t M = 0x03030303u, K = 0x40100401u;  // bytes (1, 4, 16, 64): b0 + 4 b1 + 16 b2 + 64 b3
+    const uint32_t q0 = __builtin_amdgcn_udot4(v.x & M, K, 0u, false), q1 = __builtin_amdgcn_udot4(v.y & M, K, 0u, false);
+    const uint32_t q2 = __builtin_amdgcn_udot4(v.z & M, K, 0u, false), q3 = __builtin_amdgcn_udot4(v.w & M, K, 0u, false);
+    return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+  };
+  auto stage = [&](int64_t ga, int64_t gb) {
+    constexpr int WB = LB2 / RPW;  // word groups (8 words each) per batch
+    for (int64_t gw = ga; gw < gb; gw += 8 * WB) {
+      v4u v[WB * RPW];
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int64_t g = min(gw + 8 * u + wsub, gb - 1);  // clamped: loads stay unconditional
         int64_t c0 = 16 * g - ctx;
         c0 = c0 < 0 ? 0 : (c0 > cmax ? cmax : c0);
-        __builtin_memcpy(&v[u], rowp(hp) + c0, 16);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) __builtin_memcpy(&v[u * RPW + r], rowp[r] + c0, 16);
       }
 #pragma unroll
-      for (int u = 0; u < LB2; ++u) {
-        const int i = i0 + 8 * u;
-        int64_t g;
-        int hp;
-        task(min(i, ntask - 1), g, hp);
-        if (i >= ntask || g >= gb) continue;
+      for (int u = 0; u < WB; ++u) {
+        const int64_t g = gw + 8 * u + wsub;
+        if (g >= gb) continue;
         const int64_t p0 = 16 * g;
-        uint32_t q = squeeze4b(v[u].x) | (squeeze4b(v[u].y) << 8) | (squeeze4b(v[u].z) << 16) | (squeeze4b(v[u].w) << 24);
-        if (p0 < ctx || p0 + 16 > ctx + C) {  // rare: the word touches the reflect padding / the row's end
-          const int8_t* row = rowp(hp);
-          q = 0;
-          for (int b = 0; b < 16; ++b) {
-            const int64_t p = p0 + b;
-            if (p < C + 2 * ctx) q |= ((uint32_t)(uint8_t)row[pad_src2(p, C, ctx)] & 3u) << (2 * b);
+        const bool edge = p0 < ctx || p0 + 16 > ctx + C;  // rare: the word touches the reflect padding / the row's end
+        uint32_t* dst = xw + (size_t)((uint32_t)g & (ring - 1u)) * T2;  // ring: a power of two
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          uint32_t q = squeeze16(v[u * RPW + r]);
+          if (edge) {
+            q = 0;
+            for (int b = 0; b < 16; ++b) {
+              const int64_t p = p0 + b;
+              if (p < C + 2 * ctx) q |= ((uint32_t)(uint8_t)rowp[r][pad_src2(p, C, ctx)] & 3u) << (2 * b);
+            }
           }
+          dst[hpw[r]] = q;
         }
-        xw[(size_t)((uint32_t)g & (ring - 1u)) * T2 + hp] = q;  // ring: a power of two
       }
     }
   };
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(NTHR2, 4) void k_base_forest2(ForestLaunch L, const
   for (int w = wa; w < wb; ++w) {
     window_words2(L, w, g0, g1);
     // the window's new words (all of them for the first window of the run) and its node words
-    stage(w == wa ? g0 : (g0 > pg1 ? g0 : pg1), g1);
+    if (w == wa || !(L.flags & 4)) stage(w == wa ? g0 : (g0 > pg1 ? g0 : pg1), g1);  // (flags: development ablation switches)
     pg1 = g1;
     const int t0 = L.win_tree0[w], nt = L.win_tree0[w + 1] - t0;
     {
@@ -155,20 +172,32 @@ __global__ __launch_bounds__(NTHR2, 4) void k_base_forest2(ForestLaunch L, const
     const int n_groups = (A == 2) ? 1 : A;
     const int c_lo = (half * n_groups) / H2, c_hi = ((half + 1) * n_groups) / H2;
     const uint8_t* rec0 = L.packed + (size_t)t0 * tree_bytes;
-    for (int c = c_lo; c < c_hi; ++c) {
+    for (int c = c_lo; c < c_hi && !(L.flags & 1); ++c) {
       const int a0 = (A == 2) ? 0 : cls0[c], a1 = (A == 2) ? nt : cls0[c + 1];
+      constexpr int TPW = D <= 4 ? TPW2 : (D <= 6 ? TPW2 - 2 : TPW2 - 4);
+      // batches of TPW trees (10 up to depth 4, fewer for deeper trees: registers), two per trip: the leaves of a batch (global memory: an L1 / L2 round trip) are added up only
+      // after the NEXT batch has been walked, in tree order all the same (A, B, A', B', ...)
       float psum = 0.f;
-      int t = a0;
-      for (; t + TPW2 <= a1; t += TPW2) {
-        float leaf[TPW2];
-        walk2<D, TPW2>(nlds + ((size_t)t << D), xcol, rec0 + (size_t)t * tree_bytes, tree_bytes, leaf);
+      float lA[TPW], lB[TPW];
+      int nB = 0;
+      for (int t = a0; t < a1; t += 2 * TPW) {
+        const int nA = min(TPW, a1 - t);
+        walk2<D, TPW>(nlds, xcol, rec0, tree_bytes, t, a1 - 1, lA);
+        if (nB) {
 #pragma unroll
-        for (int k = 0; k < TPW2; ++k) psum += leaf[k];  // tree order
+          for (int k = 0; k < TPW; ++k)
+            if (k < nB) psum += lB[k];
+        }
+        nB = max(0, min(TPW, a1 - (t + TPW)));
+        if (nB) walk2<D, TPW>(nlds, xcol, rec0, tree_bytes, t + TPW, a1 - 1, lB);
+#pragma unroll
+        for (int k = 0; k < TPW; ++k)
+          if (k < nA) psum += lA[k];
       }
-      for (; t < a1; ++t) {
-        float leaf[1];
-        walk2<D, 1>(nlds + ((size_t)t << D), xcol, rec0 + (size_t)t * tree_bytes, tree_bytes, leaf);
-        psum += leaf[0];
+      if (nB) {
+#pragma unroll
+        for (int k = 0; k < TPW; ++k)
+          if (k < nB) psum += lB[k];
       }
       marg[c * T2] = psum;
     }
@@ -187,13 +216,17 @@ __global__ __launch_bounds__(NTHR2, 4) void k_base_forest2(ForestLaunch L, const
       } else {
         float wmax = L.base_score + marg[0];
         for (int a = 1; a < A; ++a) wmax = fmaxf(L.base_score + marg[a * T2], wmax);
-        // exp evaluated twice per class (sum, then output) instead of A values kept in registers across the loop: the
-        // kernel has to stay inside 128 VGPRs for two blocks per CU, and this epilogue is ~1 % of a window's work
+        // the exponentials are parked in the lane's own margin slots (LDS) between the two loops instead of in A registers: the
+        // kernel has to stay inside 128 VGPRs for two blocks per CU
         double wsum = 0.0;
-        for (int a = 0; a < A; ++a) wsum += (double)(float)exp((double)((L.base_score + marg[a * T2]) - wmax));
+        for (int a = 0; a < A; ++a) {
+          const float e = (float)exp((double)((L.base_score + marg[a * T2]) - wmax));
+          marg[a * T2] = e;
+          wsum += (double)e;
+        }
         const float fs = (float)wsum;
         for (int a = 0; a < A; ++a) {
-          const float p = (float)exp((double)((L.base_score + marg[a * T2]) - wmax)) / fs;
+          const float p = marg[a * T2] / fs;
           if (L.b32) L.b32[o + a] = p;
           if (L.b64) L.b64[o + a] = (double)p;
         }
@@ -218,9 +251,12 @@ hipError_t launch_range2(ForestLaunch L, const uint32_t* nodes2, int w_first, in
   L.w_first = w_first;
   L.n_windows = n_windows;
   L.ring = gnx_forest_ring_words(width);
+  L.flags = tune.forest_flags;
+  L.n_cu = std::max(n_cu, 1);
+  L.skew = tune.forest_skew >= 0 ? tune.forest_skew : 4;  // ~14 us at 2.4 GHz: one staging phase of a 128-haplotype tile
   const size_t lds = gnx_forest2_lds_bytes(L.A, L.ring, L.max_trees, L.D);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
-  const int per_cu = lds <= (size_t)80 * 1024 ? 2 : 1;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(4 * WPS2) / NWV2));
   // windows per block: as k_base_forest — long runs re-use the shared half of every window (the first window of a run is staged
   // in full: about two window-steps), short runs fill the chip; blocks run in rounds of per_cu per CU
   const int64_t tiles = (L.N + T2 - 1) / T2;

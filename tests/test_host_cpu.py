@@ -344,3 +344,13 @@ def test_isotonic_fit_equals_the_references_calibrator():
         m = iso.IsotonicRegression(out_of_bounds="clip").fit(x, t)
         xt, yt = calibrate.fit_isotonic(x, t)
         assert np.array_equal(xt, m.X_thresholds_) and np.array_equal(yt, m.y_thresholds_), seed
+
+
+def test_no_default_dispatch_kernel_carries_scratch():
+    """scripts/scratch_audit.py --check: the code objects' metadata of libgnomix_hip.so (no GPU needed) must show
+    .private_segment_fixed_size == 0 for every kernel a default dispatch reaches — a kernel with scratch is a correctness-only
+    kernel (the forest bases, k_crf_psi, k_calibrate and the generic CovRSK instances spilled)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "scratch_audit.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "0 of those on a default dispatch" in r.stdout
