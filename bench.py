@@ -51,6 +51,29 @@ def kernel_src_sha16():
     return h.hexdigest()[:16]
 
 
+def usable_cpus():
+    """(logical CPUs this process may be scheduled on, CPUs' worth of time its cgroup allows — None when unlimited).  The GPU boxes of
+    this project show 256 CPUs and a quota of 16 (cpu.max "1600000 100000"): threads beyond the quota are throttled, not run."""
+    try:
+        shown = len(os.sched_getaffinity(0))
+    except AttributeError:
+        shown = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = -(-int(q) // int(per))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = -(-q // per)
+        except Exception:
+            pass
+    return shown, quota
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -431,7 +454,7 @@ def _e2e_vcf(args, model, data, X, out_dev):
         res = {"haplotypes_per_s": N / best["total"], "seconds": best["total"], "stages_s": {k: round(v, 4) for k, v in best.items()},
                "first_pass_s": round(reps[0]["total"], 4), "vcf_GB": vcf_bytes / 1e9, "parse_GBps": vcf_bytes / best["read_vcf"] / 1e9,
                "write_MBps": (fb_bytes + msp_bytes) / (best["write_fb"] + best["write_msp"]) / 1e6, "fb_MB": fb_bytes / 1e6,
-               "host_threads": len(os.sched_getaffinity(0)), "vcf_written_s": round(t_gen, 3), "dir": root,
+               "host_cpus_shown": usable_cpus()[0], "host_cpu_quota": usable_cpus()[1], "vcf_written_s": round(t_gen, 3), "dir": root,
                "msp_labels_equal_device_path": same,
                "note": "chr22 x %d samples as VCF TEXT in, query_results.msp + .fb out, through gnomix_amd.cli.run_inference; best of %d passes in "
                        "this process (first_pass_s includes page-locked allocations and the worker pool's start); never `value`" % (ns, len(reps))}
@@ -469,11 +492,8 @@ def _cpu_baseline(args, data, X, out_dev):
     from oracle import gnx_oracle as O
     O.build()
     T = O.Trees(data.tree_off, data.left, data.right, data.feat, data.cond, data.tree_class, data.A, data.base_score)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, args.cpu_threads or avail)
+    avail, quota = usable_cpus()
+    cores = max(1, args.cpu_threads or min(avail, quota or avail))   # one thread per CPU the cgroup lets run
     Xh = X.cpu().numpy()
     W = data.C // data.M
     # one core alone first (also sizes the sample)
@@ -511,11 +531,11 @@ def _cpu_baseline(args, data, X, out_dev):
             "base_lr_blas": {"haplotypes_per_s": n_b / t_blas, "sample": n_b, "max_abs_diff_vs_port": blas_err,
                              "note": "numpy: Xw.astype(float64) @ coef.T per window (what sklearn's predict_proba does), BLAS threads as configured"},
             "sample": "%d haplotypes of the same workload through oracle/gnx_oracle.c — the SCALAR C port of the reference's "
-                      "algorithm, not the reference — on %d threads (host reports %d cores, %d usable): logistic base by windows "
+                      "algorithm, not the reference — on %d threads (host shows %d CPUs, %d schedulable, cgroup CPU quota %s): logistic base by windows "
                       "(370 tasks) %.2f s, tree smoother by haplotypes %.2f s wall; labels identical to the GPU's on the sample: %s.  "
                       "Context (BASELINE.md 2, the reference itself, 8 cores of the survey container): base 815 haplotypes/s, "
                       "slide_window 225 haplotypes/s (xgboost itself absent there)" %
-                      (n_s, cores, os.cpu_count() or 0, avail, t_base, t_sm, same)}
+                      (n_s, cores, os.cpu_count() or 0, avail, quota, t_base, t_sm, same)}
 
 
 if __name__ == "__main__":

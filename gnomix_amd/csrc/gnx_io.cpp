@@ -50,15 +50,49 @@ int gnx_io_threads(int requested) {
   int n = 0;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
   if (n <= 0) n = (int)std::thread::hardware_concurrency();
+  const int q = gnx_io_cpu_quota();
+  if (q > 0) n = std::min(n, q);
   return std::max(1, std::min(n, 512));
 }
 
-// threads for work that streams memory (pread + parse, format + write): on the 2 x 64-core host of an MI355X box the
-// reader peaks at 32 workers (79 GB/s of text; 18 GB/s with 256: they fight over the memory system and the page cache) and
-// the writers at 16-64 (scripts/dev/vcf_io_probe.py), so "all cores" is capped unless the caller or GNX_IO_THREADS says otherwise
+// CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cfs quota), rounded up; 0: no limit.  The GPU
+// boxes of this project show 256 logical CPUs and a quota of 16: threads beyond the quota are throttled, not run — the same
+// sha256 loop finishes 26 thread-equivalents with 32 threads and 13 with 256.
+int gnx_io_cpu_quota() {
+  static const int cached = [] {
+    long long quota = -1, period = 100000;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+      fclose(f);
+    } else {
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+      }
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(g, "%lld", &period) != 1) period = 100000;
+        fclose(g);
+      }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (int)((quota + period - 1) / period);
+  }();
+  return cached;
+}
+
+// threads for work that streams memory (pread + parse, format + write).  Measured on an MI355X box (2 x 64 cores shown, CPU
+// quota 16): the reader peaks at 32 workers — 79 GB/s of text, 60 GB/s with 16, 18 GB/s with 256 — and the writers at 16-64
+// (scripts/dev/vcf_io_probe.py): these workers spend part of their time in page-cache copies and faults, so twice the quota
+// keeps the allowed CPUs busy; without a quota 32 is where one file stops scaling.
 int gnx_io_stream_threads(int requested) {
   if (requested > 0 || getenv("GNX_IO_THREADS")) return gnx_io_threads(requested);
-  return std::min(gnx_io_threads(0), 32);
+  const int q = gnx_io_cpu_quota();
+  cpu_set_t set;
+  int n = 0;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (int)std::thread::hardware_concurrency();
+  return std::max(1, std::min(std::min(n, 32), q > 0 ? 2 * q : 32));
 }
 
 namespace {

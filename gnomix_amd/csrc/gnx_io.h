@@ -21,6 +21,7 @@ int gnx_io_fail(int code, const std::string& msg);  // sets the thread's message
 // process-wide worker pool: fn(tid) runs once on each of n workers (the caller is worker 0); returns when all are done
 int gnx_io_threads(int requested);         // <= 0: every core this process may run on (GNX_IO_THREADS overrides)
 int gnx_io_stream_threads(int requested);  // <= 0: the same, capped where memory streaming stops scaling
+int gnx_io_cpu_quota();                    // CPUs the container's cgroup allows (0: unlimited)
 void gnx_io_parallel(int n_workers, const std::function<void(int)>& fn);
 double gnx_io_now();
 

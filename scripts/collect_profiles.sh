@@ -17,8 +17,8 @@ SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CY
 TC="TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
 for cfg in $WHICH; do
   if [ "$cfg" = "bench" ]; then
-    CMD="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-steps 0"
-    STATS="python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --e2e-steps 0"
+    CMD="python bench.py --steps 3 --warmup 1 --passes 1 --cpu-seconds 0 --e2e-steps 0 --vcf-reps 0 --trained 0"
+    STATS="python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --e2e-steps 0 --vcf-reps 0 --trained 0"
   elif [ "$cfg" = "c4" ]; then
     python scripts/bench_configs.py c4 > $OUT/c4.log 2>&1
     cp gpurun_out/bench_configs.json $OUT/c4.json
@@ -43,7 +43,7 @@ for cfg in $WHICH; do
 done
 # the per-dispatch counter CSVs run to > 100 MB: condense them HERE and bring back only the summaries (gpurun merges at most
 # 64 MiB of gpurun_out/)
-python scripts/summarize_prof.py $OUT gpurun_out/prof_summary ${PROF_TAG:-r02} > gpurun_out/prof_summary.log 2>&1
+python scripts/summarize_prof.py $OUT gpurun_out/prof_summary ${PROF_TAG:-r03} > gpurun_out/prof_summary.log 2>&1
 tail -3 gpurun_out/prof_summary.log | cut -c1-400
 rm -rf $OUT
 du -sh gpurun_out/prof_summary | tail -1
