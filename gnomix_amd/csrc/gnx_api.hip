@@ -1065,7 +1065,13 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     // the 256-haplotype kernel
     const bool v2 = !L.rf_leafval && m->forest.nodes2 && ctx->tune.forest_impl != 1 &&
                     gnx_forest2_lds_bytes(L.A, gnx_forest_ring_words(L.width_last), L.max_trees, L.D) <= (size_t)160 * 1024;
-    if (v2) HIPCHK(ctx, gnx_launch_base_forest2(L, m->forest.nodes2, ctx->n_cu, ctx->tune, ctx->stream));
+    if (v2) {
+      if (!ctx->s_aux) {  // the one wider last window (a grid of N / 128 blocks) runs beside the main grid on a side stream
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_aux[b], hipEventDisableTiming));
+      }
+      HIPCHK(ctx, gnx_launch_base_forest2(L, m->forest.nodes2, ctx->n_cu, ctx->tune, ctx->stream, ctx->s_aux, ctx->ev_aux[0], ctx->ev_aux[1]));
+    }
     else HIPCHK(ctx, gnx_launch_base_forest(L, ctx->n_cu, ctx->tune, ctx->stream));
     return GNX_OK;
   }

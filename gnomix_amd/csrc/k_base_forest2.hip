@@ -297,9 +297,21 @@ uint32_t gnx_forest2_node(uint32_t nd, uint32_t g0, uint32_t ring) {
   return ((slot * (uint32_t)T2 * 4u) << 15) | ((2u * (pos & 15u)) << 4) | (~nd & 15u);
 }
 
-hipError_t gnx_launch_base_forest2(const ForestLaunch& L, const uint32_t* nodes2, int n_cu, const gnx_tune& tune, hipStream_t s) {
+hipError_t gnx_launch_base_forest2(const ForestLaunch& L, const uint32_t* nodes2, int n_cu, const gnx_tune& tune, hipStream_t s,
+                                   hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
   if (L.N <= 0) return hipSuccess;
-  hipError_t e = launch_range2(L, nodes2, 0, L.W - 1, L.width, n_cu, tune, s);
-  if (e != hipSuccess) return e;
+  // The last window is wider by C mod M (base.py:163-164): its own launch with the larger ring — N / 128 blocks, a fraction of the
+  // chip — on the side stream beside the main grid (they write disjoint windows of B): fork after whatever produced X, join before
+  // whatever reads B.
+  const bool side = aux && ev_fork && ev_join && L.W > 1;
+  hipError_t e;
+  if (side) {
+    if ((e = hipEventRecord(ev_fork, s)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e;
+    if ((e = launch_range2(L, nodes2, L.W - 1, 1, L.width_last, n_cu, tune, aux)) != hipSuccess) return e;
+    if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e;
+  }
+  if ((e = launch_range2(L, nodes2, 0, L.W - 1, L.width, n_cu, tune, s)) != hipSuccess) return e;
+  if (side) return hipStreamWaitEvent(s, ev_join, 0);
   return launch_range2(L, nodes2, L.W - 1, 1, L.width_last, n_cu, tune, s);
 }
