@@ -332,3 +332,45 @@ def test_column_map_random_cases_against_vcf_to_npy(tmp_path, capsys):
         assert np.array_equal(vi, vi2) and np.array_equal(fi, fi2)
         assert np.array_equal(_apply_map(d.gt2, 2 * ns, src), want)
         assert (src >> 30 == 1).any() and (src == -1).any()
+
+
+def test_reader_survives_mutated_files(tmp_path):
+    """robustness: random truncations, byte flips, deleted / duplicated spans of a valid file either parse or raise GnxError —
+    and whenever the Python mirror can read the mutant too, both agree"""
+    rng = np.random.default_rng(99)
+    base = _vcf_text(rng, 60, 11, general_every=3).encode()
+    p = str(tmp_path / "m.vcf")
+    n_ok = n_err = 0
+    for trial in range(250):
+        b = bytearray(base)
+        kind = trial % 5
+        if kind == 0:
+            b = b[:rng.integers(1, len(b))]
+        elif kind == 1:
+            for _ in range(rng.integers(1, 6)):
+                b[rng.integers(0, len(b))] = rng.choice(list(b"\t\n|/.:0123456789xG#"))
+        elif kind == 2:
+            i = rng.integers(0, len(b) - 40)
+            del b[i:i + rng.integers(1, 40)]
+        elif kind == 3:
+            i = rng.integers(0, len(b) - 40)
+            b[i:i] = b[i:i + rng.integers(1, 40)]
+        else:
+            b = b.replace(b"\t", b" ", 1) if trial % 2 else b + b"\n\n#junk\n22\t5\n"
+        open(p, "wb").write(bytes(b))
+        try:
+            a = vcfio.read_vcf(p, chm="22", n_threads=3)
+        except _lib.GnxError:
+            n_err += 1
+            continue
+        n_ok += 1
+        if a is None:
+            continue
+        assert a["calldata/GT"].shape[0] == len(a["variants/POS"]) == a.n_variants
+        try:
+            m = vcf_text.read_vcf(p, chm="22")
+        except Exception:
+            continue
+        if m is not None and len(m["variants/POS"]) == a.n_variants:
+            assert np.array_equal(a["calldata/GT"], m["calldata/GT"]) and np.array_equal(a["variants/POS"], m["variants/POS"])
+    assert n_ok > 20 and n_err > 20
