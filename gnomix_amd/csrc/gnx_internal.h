@@ -31,6 +31,7 @@ struct gnx_tune {
                                         // column tiles (A > 8 at the default context), where it measured 2.5 vs 3.1 ms (A = 12,
                                         // chr22); with one column tile both kernels run at the same 1.14-1.16 ms
   int lr_nbuf = 0;                      // GNX_LR_NBUF: ring slots of the LDS-direct kernel
+  int lr_w512 = 0;                      // GNX_LR_W512=1: 512 rows per block, 64-SNP steps (k_base_logistic_i8_w512)
   int lr_ws = 0, lr_ws_pw = 2;          // GNX_LR_WS=1: wave-specialised kernel (k_base_logistic_i8_ws); GNX_LR_WS_PW: producer waves (2, 4)
   int sm_nw = 0;                        // GNX_SM_NW: waves per block of the rank smoother
   int sm_pair = 1;                      // GNX_SM_PAIR=0: one tree at a time per lane in the rank smoother (default: two)
@@ -364,6 +365,7 @@ hipError_t gnx_launch_x_to_gt2(const int8_t* X, int64_t N, int64_t ldx, int64_t 
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_launch_base_logistic_i8_w512(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_ws(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);

@@ -7,8 +7,10 @@ N = int(os.environ.get("N", 10000))
 d = synth.synthetic_model(seed=0, n_rounds=2, **synth.CHR22)
 X = synth.synthetic_X_device(N, d.C, torch.device("cuda", 0), seed=94305)
 ref = None
-for name, env in (("i8", {}), ("i8_dl", {"GNX_LR_DL": "1"}), ("i8_ws pw2", {"GNX_LR_WS": "1"}), ("i8_ws pw4", {"GNX_LR_WS": "1", "GNX_LR_WS_PW": "4"})):
-    for k in ("GNX_LR_DL", "GNX_LR_WS", "GNX_LR_WS_PW"):
+for name, env in (("i8", {}), ("i8_dl", {"GNX_LR_DL": "1"}), ("i8_ws pw2", {"GNX_LR_WS": "1"}), ("i8_ws pw4", {"GNX_LR_WS": "1", "GNX_LR_WS_PW": "4"}),
+                  ("i8_w512", {"GNX_LR_W512": "1"}), ("i8_w512 bpc3", {"GNX_LR_W512": "1", "GNX_LR_BPC": "3"}), ("i8_w512 bpc4", {"GNX_LR_W512": "1", "GNX_LR_BPC": "4"}),
+                  ("i8_w512 nbuf2", {"GNX_LR_W512": "1", "GNX_LR_NBUF": "2"})):
+    for k in ("GNX_LR_DL", "GNX_LR_WS", "GNX_LR_WS_PW", "GNX_LR_W512", "GNX_LR_BPC", "GNX_LR_NBUF"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ctx = _lib.Context(0)

@@ -40,7 +40,7 @@ def _lr_data(ga, C, M, A, ctx, seed):
 
 
 # ---------------------------------------------------------------- logistic base ------------------
-@pytest.fixture(params=["i8", "i8dl", "i8ws", "f64"])
+@pytest.fixture(params=["i8", "i8dl", "i8ws", "i8w512", "f64"])
 def lr_impl(request, monkeypatch):
     """every variant of the logistic pass on every geometry: exact int8-limb fixed point with register-staged loads
     (k_base_logistic_i8), the same arithmetic with LDS-direct loads (k_base_logistic_i8_dl), with LDS-direct loads issued by
@@ -50,6 +50,7 @@ def lr_impl(request, monkeypatch):
     monkeypatch.setenv("GNX_BASE_LR_IMPL", "f64" if request.param == "f64" else "i8")
     monkeypatch.setenv("GNX_LR_DL", "1" if request.param == "i8dl" else "0")
     monkeypatch.setenv("GNX_LR_WS", "1" if request.param == "i8ws" else "0")
+    monkeypatch.setenv("GNX_LR_W512", "1" if request.param == "i8w512" else "0")   # 512 rows per block, 64-SNP steps
     return _lib.Context(0)
 
 
