@@ -138,9 +138,12 @@ struct Stager {
     }
     return q;
   }
-  // words [ga, gb) of the wave's 64 haplotypes -> ring, synchronously.  (Inlined: as an out-of-line member the object it is
-  // called on has to live in memory, i.e. 104 B of scratch per lane in every instance of the kernel.)
-  __device__ __forceinline__ void stage(uint32_t* xw, uint32_t mask, int64_t ga, int64_t gb) const {
+  // words [ga, gb) of the wave's 64 haplotypes -> ring, synchronously.  Two spellings of one body: as an out-of-line member the
+  // object it is called on has to live in memory (104 B of scratch per lane), inlined everywhere the file takes four times as
+  // long to compile (35 kernel instances).  The random-forest instances — the default dispatch of that base — inline it; the
+  // boosted-tree instances are the fallback behind k_base_forest2 and keep the call.
+  __device__ void stage(uint32_t* xw, uint32_t mask, int64_t ga, int64_t gb) const { stage_inl(xw, mask, ga, gb); }
+  __device__ __forceinline__ void stage_inl(uint32_t* xw, uint32_t mask, int64_t ga, int64_t gb) const {
     for (int hb = hb0; hb < hb0 + hbn; ++hb) {
       const int8_t* r = row(hb);
       uint32_t* col = xw + wv * 64 + hb * 8 + hsub;
@@ -218,7 +221,8 @@ __global__ __launch_bounds__(256 * H) void k_base_forest(ForestLaunch L) {
   const Stager st(L.X, L.N, L.ldx, L.C, L.ctx, T, H);
   int64_t g0, g1;
   window_words(L, wa, g0, g1);
-  st.stage(xw, mask, g0, g1);
+  if constexpr (RF) st.stage_inl(xw, mask, g0, g1);
+  else st.stage(xw, mask, g0, g1);
   const int64_t n = (int64_t)blockIdx.x * T + hap;
 
   // a window's trees: uint4 pieces of the loader's records, node words rewritten for the window on their way into LDS
@@ -385,7 +389,10 @@ __global__ __launch_bounds__(256 * H) void k_base_forest(ForestLaunch L) {
             if (g < pf_gb)
               xw[(size_t)((uint32_t)g & mask) * T + st.wv * 64 + (st.hb0 + 2 * q + h2) * 8 + st.hsub] = sq[q * LB + h2 * (LB / 2) + u];
           }
-    } else if (!(L.flags & 4)) st.stage(xw, mask, ng0 > g1 ? ng0 : g1, ng1);
+    } else if (!(L.flags & 4)) {
+      if constexpr (RF) st.stage_inl(xw, mask, ng0 > g1 ? ng0 : g1, ng1);
+      else st.stage(xw, mask, ng0 > g1 ? ng0 : g1, ng1);
+    }
     if (tpre) {
 #pragma unroll
       for (int k = 0; k < TQ; ++k)
