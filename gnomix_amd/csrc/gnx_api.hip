@@ -345,7 +345,7 @@ static void tree_fill_rk(const gnx_model_desc* d, int32_t o, int32_t nid, uint32
 }
 
 static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector<int32_t>& order, int D) {
-  const char* impl = std::getenv("GNX_SMOOTH_IMPL");  // "rk" (default: 16-bit ranks) or "f32" (float features)
+  const char* impl = std::getenv("GNX_SMOOTH_IMPL");  // default: 16-bit ranks with pointer nodes; "rk" heap-index nodes, "h64" lane = haplotype, "f32" float features
   if (impl && std::string(impl) == "f32") return GNX_OK;
   const int A = d->A, S = d->S;
   std::vector<float> U;
@@ -414,7 +414,46 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
   m->xgb.rk_n_groups = (int32_t)group_class.size(); m->xgb.rk_max_group = G; m->xgb.rk_rpl = rpl;
   // measured (chr22, 10 000 haplotypes, MI355X): rk 1.83 ms; h64 2.22 ms + 0.23 ms of rank pre-pass — conflict-free, and slower
   // (DESIGN.md 4.2b): the rank kernel stays the default, h64 is what GNX_SMOOTH_IMPL=h64 selects
-  m->xgb.impl = (impl && std::string(impl) == "h64") ? 2 : 1;
+  // (round 3, same inputs: rk 1.83 ms, pointer nodes 1.78 ms, bit-identical: default where the shape allows, "rk" = heap-index nodes)
+  m->xgb.impl = (impl && std::string(impl) == "h64") ? 2 : (impl && std::string(impl) == "rk") ? 1 : 3;
+  // ---- the same trees with pointer nodes (k_smooth_xgb_rk<.., PTR>): the walk keeps the ADDRESS of its node, no heap index ---
+  if (D >= 2 && D <= 6) {
+    const int tbp = 12 << D;
+    const int Gp = std::max(2, (4096 / tbp) & ~1);  // even: trees are walked in pairs
+    std::vector<int32_t> gp_tree0, gp_class;
+    {
+      int in_group = 0, cur = -1;
+      for (size_t k = 0; k < order.size(); ++k) {
+        const int c = d->tree_class[order[k]];
+        if (c != cur || in_group == Gp) { gp_tree0.push_back((int32_t)k); gp_class.push_back(c); in_group = 0; cur = c; }
+        ++in_group;
+      }
+      gp_tree0.push_back((int32_t)order.size());
+    }
+    std::vector<uint8_t> pp(order.size() * (size_t)tbp, 0);
+    std::vector<uint32_t> nodes((size_t)1 << D);
+    std::vector<float> leaves((size_t)1 << D);
+    size_t g = 0;
+    for (size_t k = 0; k < order.size(); ++k) {
+      while ((size_t)gp_tree0[g + 1] <= k) ++g;
+      const uint32_t base = (uint32_t)(k - (size_t)gp_tree0[g]) * (uint32_t)tbp;  // the tree's first byte inside its group
+      std::fill(nodes.begin(), nodes.end(), 0u);
+      tree_fill_rk(d, d->tree_off[order[k]], 0, 1, 0, D, U, stride, nodes.data(), leaves.data());
+      uint32_t* o = reinterpret_cast<uint32_t*>(pp.data() + k * tbp);
+      auto kids = [&](uint32_t j) {
+        const uint32_t l = 2 * j < (1u << D) ? base + 8u * (2 * j) : base + (8u << D) + 4u * (2 * j - (1u << D));
+        const uint32_t step = 2 * j < (1u << D) ? 8u : 4u;
+        return l | ((l + step) << 16);
+      };
+      for (uint32_t j = 2; j < (1u << D); ++j) { o[2 * j] = nodes[j]; o[2 * j + 1] = kids(j); }
+      o[0] = nodes[2]; o[1] = nodes[3]; o[2] = nodes[1]; o[3] = kids(2);
+      memcpy(pp.data() + k * tbp + ((size_t)8 << D), leaves.data(), sizeof(float) << D);
+    }
+    if ((rc = dev_upload(m, pp, &m->xgb.rp_packed, 64)) != GNX_OK) return rc;
+    if ((rc = dev_upload(m, gp_tree0, &m->xgb.rp_group_tree0)) != GNX_OK) return rc;
+    if ((rc = dev_upload(m, gp_class, &m->xgb.rp_group_class)) != GNX_OK) return rc;
+    m->xgb.rp_tree_bytes = tbp; m->xgb.rp_n_groups = (int32_t)gp_class.size(); m->xgb.rp_max_group = Gp;
+  }
   // ---- the same trees for k_smooth_xgb_h64 (lane = haplotype): 8-byte nodes {slot byte offset, rank field} ------------------
   if ((size_t)S * A * 128 < ((size_t)1 << 31)) {
     const int tb8 = ((12 << D) + 15) & ~15;
@@ -1150,7 +1189,7 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     L.B = dB; L.b_is_f64 = b_is_f64; L.N = N;
     L.W = (int32_t)m->info.W; L.A = m->info.A; L.S = m->info.S;
     L.d = m->xgb; L.proba = d_p32; L.proba64 = d_p64; L.labels = d_lab;
-    const bool h64 = m->xgb.rk_packed && m->xgb.impl != 1 && gnx_smooth_h64_waves(m->xgb, m->info.A, m->info.S) > 0;
+    const bool h64 = m->xgb.rk_packed && m->xgb.impl == 2 && gnx_smooth_h64_waves(m->xgb, m->info.A, m->info.S) > 0;
     if (m->xgb.impl == 2 && !h64) return fail(ctx, GNX_EUNSUPPORTED, "GNX_SMOOTH_IMPL=h64: the model's strip does not fit the LDS");
     if (m->xgb.rk_packed) {
       const size_t n_pad = (size_t)((N + 63) / 64 * 64) * m->info.W * m->info.A;   // h64 parks whole 64-haplotype lines

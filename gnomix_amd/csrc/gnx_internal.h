@@ -153,7 +153,15 @@ struct SmoothXGBDev {
   const int32_t* h8_group_tree0 = nullptr;
   const int32_t* h8_group_class = nullptr;
   int32_t h8_tree_bytes = 0, h8_n_groups = 0, h8_max_group = 0;
-  int32_t impl = 0;                      // 0 auto (h64 where its strip fits the LDS, else rk), 1 rk, 2 h64 (GNX_SMOOTH_IMPL at model load)
+  // pointer-node copy for k_smooth_xgb_rk<.., PTR> (same strip, ranks and offsets as rk_*): per tree 2^D slots of 8 bytes
+  // {w0 = rank field << 16 | strip offset, w1 = address of the left child | address of the right child << 16} (addresses relative
+  // to the staging group's first byte; children of the last level = the leaves) followed by 2^D float leaves; slot 0 carries
+  // {w0 of node 2, w0 of node 3}, the root slot {w0 of the root, w1 of node 2}: the tree's first 16 bytes are levels 0 and 1
+  const uint8_t* rp_packed = nullptr;
+  const int32_t* rp_group_tree0 = nullptr;
+  const int32_t* rp_group_class = nullptr;
+  int32_t rp_tree_bytes = 0, rp_n_groups = 0, rp_max_group = 0;
+  int32_t impl = 0;                      // 1 rk, 2 h64, 3 rk with pointer nodes (GNX_SMOOTH_IMPL at model load)
 };
 
 constexpr int GNX_RK_RPL_MAX = 6;  // most 64-window segments per strip the rank kernel is instantiated for

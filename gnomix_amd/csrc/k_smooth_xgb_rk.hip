@@ -280,6 +280,100 @@ __device__ __forceinline__ void walk_rk(const uint8_t* tb, const uint8_t* rb, fl
   for (int k = 0; k < R; ++k) psum[k] += reinterpret_cast<const float*>(tb)[j[k]];
 }
 
+// ---- pointer nodes (PTR variant): the walk carries the LDS ADDRESS of its node instead of a heap index -----------------------
+// A node is 8 bytes {w0 = rank field << 16 | strip offset, w1 = address of the left child | address of the right child << 16}
+// (ds_read_b64 occupies the LDS array for the same 2 cycles as ds_read_b32), so a level is rank address (v_add_u32_sdwa),
+// compare (v_cmp_le_u32_sdwa -> vcc) and v_cndmask_b32_sdwa picking a half of w1: 3 VALU instead of 4 — no node address, no
+// heap index — and the last level's "children" are the leaves' own addresses (no leaf address either).
+// (the low 32 bits of a generic pointer into the LDS are its LDS address; reading through an address_space(3) pointer made from
+// the integer gives `ds_read vdst, p` with nothing added)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(3))) T* lds_at(uint32_t a) {
+  return (const __attribute__((address_space(3))) T*)(uintptr_t)a;
+}
+#else
+template <typename T>
+__device__ const T* lds_at(uint32_t a);  // host pass: declaration only
+#endif
+__device__ __forceinline__ uint32_t step_ptr(uint32_t w0, uint32_t w1, uint32_t r) {
+  uint32_t p;
+  asm("v_cmp_le_u32_sdwa vcc, %[n], %[r] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+      "v_cndmask_b32_sdwa %[p], %[w], %[w], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+      : [p] "=v"(p)
+      : [n] "v"(w0), [r] "v"(r), [w] "v"(w1)
+      : "vcc");
+  return p;
+}
+// level 0: the level-1 node {w0, w1} is one of two wave-uniform candidates, picked by the root's compare
+__device__ __forceinline__ void first_ptr(uint32_t root, uint32_t r, uint32_t l0, uint32_t r0, uint32_t l1, uint32_t r1, uint32_t& w0,
+                                          uint32_t& w1) {
+  asm("v_cmp_le_u32_sdwa vcc, %[n], %[r] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+      "v_cndmask_b32 %[x], %[l0], %[r0], vcc\n\t"
+      "v_cndmask_b32 %[y], %[l1], %[r1], vcc"
+      : [x] "=&v"(w0), [y] "=&v"(w1)
+      : [n] "v"(root), [r] "v"(r), [l0] "v"(l0), [r0] "v"(r0), [l1] "v"(l1), [r1] "v"(r1)
+      : "vcc");
+}
+
+// TWO trees side by side for the R segments of a lane (node addresses = LDS addresses).
+template <int D, int R>
+__device__ __forceinline__ void walk_rp_pair(const uint8_t* tb0, const uint8_t* tb1, const uint8_t* rb, float* psum) {
+  static_assert(D >= 2, "the 16-byte tree top holds levels 0 and 1");
+  uint32_t w0[2 * R], w1[2 * R], r[2 * R], p[2 * R];
+  const uint4 top0 = *reinterpret_cast<const uint4*>(tb0);  // {w0 of node 2, w0 of node 3, w0 of the root, w1 of node 2}
+  const uint4 top1 = *reinterpret_cast<const uint4*>(tb1);
+  constexpr uint32_t SIB = (D == 2 ? 8u : 16u) * 0x10001u;  // node 3's children sit right behind node 2's
+  const uint32_t k0 = top0.w + SIB, k1 = top1.w + SIB;
+#pragma unroll
+  for (int k = 0; k < R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (top0.z & 0xffffu));
+#pragma unroll
+  for (int k = 0; k < R; ++k) r[R + k] = *reinterpret_cast<const uint16_t*>(rb + k * (WS * 2) + (top1.z & 0xffffu));
+#pragma unroll
+  for (int k = 0; k < R; ++k) first_ptr(top0.z, r[k], top0.x, top0.y, top0.w, k0, w0[k], w1[k]);
+#pragma unroll
+  for (int k = 0; k < R; ++k) first_ptr(top1.z, r[R + k], top1.x, top1.y, top1.w, k1, w0[R + k], w1[R + k]);
+#pragma unroll
+  for (int k = 0; k < 2 * R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + (k % R) * (WS * 2) + (w0[k] & 0xffffu));
+#pragma unroll
+  for (int k = 0; k < 2 * R; ++k) p[k] = step_ptr(w0[k], w1[k], r[k]);
+#pragma unroll
+  for (int d = 2; d < D; ++d) {
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) {
+      const uint2 nd = *lds_at<uint2>(p[k]);
+      w0[k] = nd.x;
+      w1[k] = nd.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) r[k] = *reinterpret_cast<const uint16_t*>(rb + (k % R) * (WS * 2) + (w0[k] & 0xffffu));
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) p[k] = step_ptr(w0[k], w1[k], r[k]);
+  }
+  float lf[2 * R];
+#pragma unroll
+  for (int k = 0; k < 2 * R; ++k) lf[k] = *lds_at<float>(p[k]);
+#pragma unroll
+  for (int k = 0; k < R; ++k) psum[k] += lf[k];  // tree order: tb0 before tb1
+#pragma unroll
+  for (int k = 0; k < R; ++k) psum[k] += lf[R + k];
+}
+
+// one tree (the odd tail of a group)
+template <int D>
+__device__ __forceinline__ float walk_rp_one(const uint8_t* tb, const uint8_t* rb) {
+  const uint32_t root = reinterpret_cast<const uint32_t*>(tb)[2];
+  uint32_t r = *reinterpret_cast<const uint16_t*>(rb + (root & 0xffffu));
+  uint32_t p = (uint32_t)(uintptr_t)tb + ((r < (root >> 16)) ? 16u : 24u);  // nodes 2 and 3 keep their own slots
+#pragma unroll
+  for (int d = 1; d < D; ++d) {
+    const uint2 nd = *lds_at<uint2>(p);
+    r = *reinterpret_cast<const uint16_t*>(rb + (nd.x & 0xffffu));
+    p = (r < (nd.x >> 16)) ? (nd.y & 0xffffu) : (nd.y >> 16);
+  }
+  return *lds_at<float>(p);
+}
+
 __device__ __forceinline__ float walk_rk_rt(const uint8_t* tb, const uint8_t* rb, int D) {
   uint32_t j = 1;
   for (int d = 0; d < D; ++d) {
@@ -291,17 +385,21 @@ __device__ __forceinline__ float walk_rk_rt(const uint8_t* tb, const uint8_t* rb
 }
 
 // One wave = one haplotype x RPL consecutive 64-window segments; NWAVE haplotypes per block.  DT = depth (0 = runtime).
-template <int RPL, int NWAVE, int DT, bool PAIR = false>
+template <int RPL, int NWAVE, int DT, bool PAIR = false, bool PTR = false>
 __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L) {
+  static_assert(!PTR || (PAIR && DT >= 2), "pointer nodes: pair walks of a compile-time depth");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int THREADS = NWAVE * 64;
   const int A = L.A, W = L.W, S = L.S, pad = (S + 1) / 2;
   const int D = DT ? DT : L.d.D;
-  const int tree_bytes = L.d.rk_tree_bytes;
+  const int tree_bytes = PTR ? L.d.rp_tree_bytes : L.d.rk_tree_bytes;
+  const int32_t* const group_tree0 = PTR ? L.d.rp_group_tree0 : L.d.rk_group_tree0;
+  const int32_t* const group_class = PTR ? L.d.rp_group_class : L.d.rk_group_class;
+  const uint8_t* const packed = PTR ? L.d.rp_packed : L.d.rk_packed;
   const int stride = L.d.rk_stride;              // halfwords per class row (>= RPL*64 + S - 1)
   const int strip_w = RPL * WS + S - 1;          // padded windows held per haplotype
   const int strip_bytes = A * stride * 2;
-  const int buf_bytes = L.d.rk_max_group * tree_bytes;  // multiple of 16
+  const int buf_bytes = (PTR ? L.d.rp_max_group : L.d.rk_max_group) * tree_bytes;  // multiple of 16
   uint8_t* strip = lds;                          // [NWAVE][A][stride] u16
   uint8_t* tbuf0 = lds + (((size_t)NWAVE * strip_bytes + 15) & ~(size_t)15);
   uint8_t* tbuf1 = tbuf0 + buf_bytes;
@@ -351,22 +449,28 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
   }
 
   // ---- tree groups through the double-buffered LDS window ----
-  const int ng = L.d.rk_n_groups;
+  const int ng = PTR ? L.d.rp_n_groups : L.d.rk_n_groups;
   constexpr int MAXV = (8192 / 16 + THREADS - 1) / THREADS;  // 16-byte staging pieces per thread (buf <= 8 KB)
   uint4 stg[MAXV];
   const int nv = (buf_bytes / 16 + THREADS - 1) / THREADS;
   // unconditional clamped loads: no branch around a load, so hipcc keeps its waits counted
 #define GNX_G_LOAD(g)                                                                               \
   {                                                                                                 \
-    const int t0_ = L.d.rk_group_tree0[g], t1_ = L.d.rk_group_tree0[(g) + 1];                       \
+    const int t0_ = group_tree0[g], t1_ = group_tree0[(g) + 1];                                     \
     const int last_ = (t1_ - t0_) * tree_bytes / 16 - 1;                                            \
-    const uint4* src_ = reinterpret_cast<const uint4*>(L.d.rk_packed + (size_t)t0_ * tree_bytes);   \
+    const uint4* src_ = reinterpret_cast<const uint4*>(packed + (size_t)t0_ * tree_bytes);          \
     _Pragma("unroll") for (int v = 0; v < MAXV; ++v) if (v < nv) stg[v] = src_[min(v * THREADS + tid, last_)]; \
   }
 #define GNX_G_STORE(dst)                                                                            \
   {                                                                                                 \
     _Pragma("unroll") for (int v = 0; v < MAXV; ++v) {                                              \
       const int e_ = v * THREADS + tid;                                                             \
+      if constexpr (PTR) { /* child addresses: relative to the group -> relative to the block's LDS origin */ \
+        const int pc_ = (e_ * 16 % tree_bytes) >> 4;                                                \
+        const uint32_t add_ = pc_ < (1 << (DT - 1)) ? (uint32_t)(uintptr_t)(dst) * 0x10001u : 0u;   \
+        stg[v].w += add_;                                                                           \
+        stg[v].y += pc_ ? add_ : 0u;                                                                \
+      }                                                                                             \
       if (v < nv && e_ * 16 < buf_bytes) *reinterpret_cast<uint4*>((dst) + (size_t)e_ * 16) = stg[v]; \
     }                                                                                               \
   }
@@ -379,14 +483,14 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
   GNX_G_STORE(tbuf0);
   __syncthreads();
 
-  int cur_class = L.d.rk_group_class[0];
+  int cur_class = group_class[0];
   for (int g = 0; g < ng; ++g) {
     uint8_t* cur = (g & 1) ? tbuf1 : tbuf0;
     uint8_t* nxt = (g & 1) ? tbuf0 : tbuf1;
     const int gn = min(g + 1, ng - 1);  // clamped: the last iteration re-fetches its own group
     GNX_G_LOAD(gn);
 
-    const int cls = L.d.rk_group_class[g];
+    const int cls = group_class[g];
     if (cls != cur_class) {  // class finished: park its margin (base_score + psum), class-major = full cache lines
 #pragma unroll
       for (int k = 0; k < RPL; ++k) {
@@ -395,17 +499,21 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
       }
       cur_class = cls;
     }
-    const int nt = L.d.rk_group_tree0[g + 1] - L.d.rk_group_tree0[g];
+    const int nt = group_tree0[g + 1] - group_tree0[g];
     int t = 0;
     if constexpr (DT >= 2 && PAIR) {
       for (; t + 1 < nt; t += 2) {
         const uint8_t* tb = cur + (size_t)t * tree_bytes;
-        walk_rk_pair<DT, RPL>(tb, tb + tree_bytes, rowbase[0], psum);
+        if constexpr (PTR) walk_rp_pair<DT, RPL>(tb, tb + tree_bytes, rowbase[0], psum);
+        else walk_rk_pair<DT, RPL>(tb, tb + tree_bytes, rowbase[0], psum);
       }
     }
     for (; t < nt; ++t) {
       const uint8_t* tb = cur + (size_t)t * tree_bytes;
-      if constexpr (DT > 0) walk_rk<DT, RPL>(tb, rowbase[0], psum);
+      if constexpr (PTR) {
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) psum[k] += walk_rp_one<DT>(tb, rowbase[k]);
+      } else if constexpr (DT > 0) walk_rk<DT, RPL>(tb, rowbase[0], psum);
       else {
 #pragma unroll
         for (int k = 0; k < RPL; ++k) psum[k] += walk_rk_rt(tb, rowbase[k], D);
@@ -448,18 +556,25 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
 }
 
 template <int NWAVE>
-size_t lds_bytes(const SmoothXGBDev& d, int A) {
+size_t lds_bytes(const SmoothXGBDev& d, int A, bool ptr = false) {
   const size_t strip = (size_t)NWAVE * A * d.rk_stride * 2;
-  return ((strip + 15) & ~(size_t)15) + 2 * (size_t)d.rk_max_group * d.rk_tree_bytes;
+  return ((strip + 15) & ~(size_t)15) + 2 * (ptr ? (size_t)d.rp_max_group * d.rp_tree_bytes : (size_t)d.rk_max_group * d.rk_tree_bytes);
 }
 
 template <int RPL, int NWAVE>
 hipError_t launch(const SmoothXGBLaunch& L, bool pair, int lds_pad, hipStream_t s) {
   const dim3 grid((unsigned)((L.W + RPL * WS - 1) / (RPL * WS)), (unsigned)((L.N + NWAVE - 1) / NWAVE));
-  size_t lds = lds_bytes<NWAVE>(L.d, L.A);
+  // pointer nodes: depth 4, pair walks, and every node address must fit 16 bits
+  const bool ptr = L.d.impl == 3 && L.d.rp_packed && L.d.D == 4 && pair && RPL <= 3 && lds_bytes<NWAVE>(L.d, L.A, true) <= 65536;
+  size_t lds = lds_bytes<NWAVE>(L.d, L.A, ptr);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   lds = std::min(lds + (size_t)std::max(lds_pad, 0), (size_t)160 * 1024);
-  if (L.d.D == 4 && pair && RPL <= 3) {
+  if (ptr) {
+    if constexpr (RPL <= 3) {
+      GNX_LDS_OPTIN(lds, k_smooth_xgb_rk<RPL, NWAVE, 4, true, true>);
+      hipLaunchKernelGGL((k_smooth_xgb_rk<RPL, NWAVE, 4, true, true>), grid, dim3(NWAVE * 64), lds, s, L);
+    }
+  } else if (L.d.D == 4 && pair && RPL <= 3) {
     if constexpr (RPL <= 3) {
       GNX_LDS_OPTIN(lds, k_smooth_xgb_rk<RPL, NWAVE, 4, true>);
       hipLaunchKernelGGL((k_smooth_xgb_rk<RPL, NWAVE, 4, true>), grid, dim3(NWAVE * 64), lds, s, L);

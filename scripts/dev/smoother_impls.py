@@ -9,7 +9,7 @@ rng = np.random.RandomState(1)
 B = rng.dirichlet(np.ones(A) * 0.5, size=(N, W)).astype(np.float32)
 Bd = torch.from_numpy(B).cuda()
 ref = None
-for impl in ("rk", "h64", "f32"):
+for impl in os.environ.get("IMPLS", "rk,rp,h64,f32").split(","):
     os.environ["GNX_SMOOTH_IMPL"] = impl
     m = gnomix_amd.DeviceModel(d)
     p, l = m.smooth_predict_device(Bd); torch.cuda.synchronize()

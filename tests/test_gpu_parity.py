@@ -662,7 +662,8 @@ def test_forest_base_rejects_bad_models(ga):
 
 
 # ---------------------------------------------------------------- rank-quantised smoother vs float smoother --------
-@pytest.mark.parametrize("W,A,S,rounds,depth", [(370, 7, 75, 12, 4), (131, 3, 31, 6, 5), (160, 12, 75, 4, 2), (500, 5, 75, 8, 4)])
+@pytest.mark.parametrize("W,A,S,rounds,depth", [(370, 7, 75, 12, 4), (131, 3, 31, 6, 5), (160, 12, 75, 4, 2), (500, 5, 75, 8, 4),
+                                                 (200, 4, 31, 7, 4), (700, 7, 75, 23, 4)])
 def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S, rounds, depth):
     """k_smooth_xgb_rk replaces every `p < threshold` by a 16-bit rank compare: outputs must be BIT-identical to the
     float kernel, including probabilities that sit exactly on a threshold (p == thr goes right), just below / above
@@ -688,6 +689,14 @@ def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S
     pf, lf = ga.DeviceModel(d).smooth_predict(B)
     monkeypatch.setenv("GNX_SMOOTH_IMPL", "rk")
     for rpl in ("1", "2", "3", "4", "5", "6"):
+        monkeypatch.setenv("GNX_RK_RPL", rpl)
+        pr, lr = ga.DeviceModel(d).smooth_predict(B)
+        assert np.array_equal(pf, pr, equal_nan=True), rpl
+        assert np.array_equal(lf, lr), rpl
+    # pointer nodes (k_smooth_xgb_rk<.., PTR>: depth 4 and <= 3 segments per strip, other shapes run the plain rank kernel);
+    # 7 and 23 rounds leave an odd tree at the end of a staging group (the single-tree walk)
+    monkeypatch.setenv("GNX_SMOOTH_IMPL", "rp")
+    for rpl in ("1", "2", "3", "4"):
         monkeypatch.setenv("GNX_RK_RPL", rpl)
         pr, lr = ga.DeviceModel(d).smooth_predict(B)
         assert np.array_equal(pf, pr, equal_nan=True), rpl
