@@ -454,10 +454,23 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
     if ((rc = dev_upload(m, gp_class, &m->xgb.rp_group_class)) != GNX_OK) return rc;
     m->xgb.rp_tree_bytes = tbp; m->xgb.rp_n_groups = (int32_t)gp_class.size(); m->xgb.rp_max_group = Gp;
   }
-  // ---- the same trees for k_smooth_xgb_h64 (lane = haplotype): 8-byte nodes {slot byte offset, rank field} ------------------
-  if ((size_t)S * A * 128 < ((size_t)1 << 31)) {
-    const int tb8 = ((12 << D) + 15) & ~15;
-    const int G8 = std::max(1, 4096 / tb8);  // a group = one 16-byte piece per thread of the smallest block (256 threads)
+  // ---- the same trees for k_smooth_xgb_h64 (lane = haplotype): pointer nodes whose w0 carries the feature's SLOT s * A + a --------
+  if (D >= 2 && D <= 6 && (size_t)S * A < 65536) {
+    const int tb8 = 12 << D;
+    // a staging group = as many trees of one class as the LDS holds beside the 16-wave strip (two buffers): one block per CU means
+    // nothing covers a block barrier, so there should be few of them (chr22 / A = 7: a class = 100 trees = one group, 7 barriers
+    // instead of 35); a multiple of the trees walked side by side, at most 32 KB (staging registers)
+    int G8 = std::max(4, (4096 / tb8) & ~3);
+    {
+      const size_t strip16 = (size_t)(16 * 3 + S - 1) * A * 128;
+      if (strip16 + 2 * (size_t)G8 * tb8 <= (size_t)160 * 1024) {
+        int per_class = 0;
+        std::vector<int> cnt(A, 0);
+        for (size_t k = 0; k < order.size(); ++k) per_class = std::max(per_class, ++cnt[d->tree_class[order[k]]]);
+        const int fit = (int)((((size_t)160 * 1024 - strip16) / 2) / tb8) & ~3;
+        G8 = std::max(G8, std::min({fit, (32768 / tb8) & ~3, (per_class + 3) & ~3}));
+      }
+    }
     std::vector<int32_t> g8_tree0, g8_class;
     {
       int in_group = 0, cur = -1;
@@ -471,17 +484,25 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
     std::vector<uint8_t> p8(order.size() * (size_t)tb8, 0);
     std::vector<uint32_t> nodes((size_t)1 << D);
     std::vector<float> leaves((size_t)1 << D);
+    size_t g = 0;
     for (size_t k = 0; k < order.size(); ++k) {
+      while ((size_t)g8_tree0[g + 1] <= k) ++g;
+      const uint32_t base = (uint32_t)(k - (size_t)g8_tree0[g]) * (uint32_t)tb8;
       std::fill(nodes.begin(), nodes.end(), 0u);
       tree_fill_rk(d, d->tree_off[order[k]], 0, 1, 0, D, U, stride, nodes.data(), leaves.data());  // (field << 16) | strip offset
-      uint32_t* o8 = reinterpret_cast<uint32_t*>(p8.data() + k * tb8);
       for (uint32_t j = 1; j < (1u << D); ++j) {
-        const uint32_t off16 = nodes[j] & 0xffffu, field = nodes[j] >> 16;
         // the rank layout's byte offset (a * stride + s) * 2 back to (s, a); an early leaf's word (offset 0) reads slot 0
-        const uint32_t h = off16 / 2, a = h / (uint32_t)stride, sidx = h - a * (uint32_t)stride;
-        o8[2 * j] = (sidx * (uint32_t)A + a) * 128u;
-        o8[2 * j + 1] = field;
+        const uint32_t h = (nodes[j] & 0xffffu) / 2, a = h / (uint32_t)stride, sidx = h - a * (uint32_t)stride;
+        nodes[j] = (nodes[j] & 0xffff0000u) | (sidx * (uint32_t)A + a);
       }
+      uint32_t* o = reinterpret_cast<uint32_t*>(p8.data() + k * tb8);
+      auto kids = [&](uint32_t j) {
+        const uint32_t l = 2 * j < (1u << D) ? base + 8u * (2 * j) : base + (8u << D) + 4u * (2 * j - (1u << D));
+        const uint32_t step = 2 * j < (1u << D) ? 8u : 4u;
+        return l | ((l + step) << 16);
+      };
+      for (uint32_t j = 2; j < (1u << D); ++j) { o[2 * j] = nodes[j]; o[2 * j + 1] = kids(j); }
+      o[0] = nodes[2]; o[1] = nodes[3]; o[2] = nodes[1]; o[3] = kids(2);
       memcpy(p8.data() + k * tb8 + ((size_t)8 << D), leaves.data(), sizeof(float) << D);
     }
     if ((rc = dev_upload(m, p8, &m->xgb.h8_packed, 64)) != GNX_OK) return rc;

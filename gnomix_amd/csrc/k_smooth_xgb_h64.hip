@@ -119,115 +119,98 @@ __global__ __launch_bounds__(256) void k_smooth_ranks(SmoothXGBLaunch L, uint16_
 }
 
 // ---- the walk ---------------------------------------------------------------------------------------------------------------
-// one level for three chains: j = 2j + (r >= field)   (v_cmp_le_u32 field, r -> mask; v_addc j, j, j, mask)
-__device__ __forceinline__ void step3(uint32_t* j, const uint32_t* f, const uint32_t* r) {
-  uint64_t c0, c1, c2;
-  asm("v_cmp_le_u32_e64 %[c0], %[f0], %[r0]\n\t"
-      "v_cmp_le_u32_e64 %[c1], %[f1], %[r1]\n\t"
-      "v_cmp_le_u32_e64 %[c2], %[f2], %[r2]\n\t"
-      "v_addc_co_u32 %[j0], %[c0], %[j0], %[j0], %[c0]\n\t"
-      "v_addc_co_u32 %[j1], %[c1], %[j1], %[j1], %[c1]\n\t"
-      "v_addc_co_u32 %[j2], %[c2], %[j2], %[j2], %[c2]"
-      : [j0] "+v"(j[0]), [j1] "+v"(j[1]), [j2] "+v"(j[2]), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
-      : [f0] "v"(f[0]), [r0] "v"(r[0]), [f1] "v"(f[1]), [r1] "v"(r[1]), [f2] "v"(f[2]), [r2] "v"(r[2]));
+// Pointer nodes (as k_smooth_xgb_rk's PTR variant): 8 bytes {w0 = rank field << 16 | slot (s * A + a), w1 = LDS address of the left
+// child | of the right child << 16}; the last level's children are the leaves.  A level = rank address (v_mad_u32_u16: slot * 128 +
+// the lane's strip origin), compare (v_cmp_le_u32_sdwa -> vcc), v_cndmask_b32_sdwa picking a half of w1: 3 VALU, 2 LDS reads.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(3))) T* lds_at(uint32_t a) {
+  return (const __attribute__((address_space(3))) T*)(uintptr_t)a;
 }
-// level 0 of a fresh walk: j = 2 + (r >= root field); the level-1 node {offset, field} picked by the same mask
-__device__ __forceinline__ void first3(uint32_t* j, uint32_t field, const uint32_t* r, uint32_t lo_off, uint32_t lo_f, uint32_t hi_off,
-                                       uint32_t hi_f, uint32_t* noff, uint32_t* nf) {
-  uint64_t c0, c1, c2;
-  asm("v_cmp_le_u32_e64 %[c0], %[fd], %[r0]\n\t"
-      "v_cmp_le_u32_e64 %[c1], %[fd], %[r1]\n\t"
-      "v_cmp_le_u32_e64 %[c2], %[fd], %[r2]\n\t"
-      "v_cndmask_b32 %[o0], %[lo], %[ho], %[c0]\n\t"
-      "v_cndmask_b32 %[o1], %[lo], %[ho], %[c1]\n\t"
-      "v_cndmask_b32 %[o2], %[lo], %[ho], %[c2]\n\t"
-      "v_cndmask_b32 %[g0], %[lf], %[hf], %[c0]\n\t"
-      "v_cndmask_b32 %[g1], %[lf], %[hf], %[c1]\n\t"
-      "v_cndmask_b32 %[g2], %[lf], %[hf], %[c2]\n\t"
-      "v_addc_co_u32_e64 %[j0], %[c0], 1, 1, %[c0]\n\t"
-      "v_addc_co_u32_e64 %[j1], %[c1], 1, 1, %[c1]\n\t"
-      "v_addc_co_u32_e64 %[j2], %[c2], 1, 1, %[c2]"
-      : [j0] "=&v"(j[0]), [j1] "=&v"(j[1]), [j2] "=&v"(j[2]), [o0] "=&v"(noff[0]), [o1] "=&v"(noff[1]), [o2] "=&v"(noff[2]),
-        [g0] "=&v"(nf[0]), [g1] "=&v"(nf[1]), [g2] "=&v"(nf[2]), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
-      : [fd] "v"(field), [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [lo] "v"(lo_off), [ho] "v"(hi_off), [lf] "v"(lo_f), [hf] "v"(hi_f));
+#else
+template <typename T>
+__device__ const T* lds_at(uint32_t a);  // host pass: declaration only
+#endif
+__device__ __forceinline__ uint32_t step_ptr(uint32_t w0, uint32_t w1, uint32_t r) {
+  uint32_t p;
+  asm("v_cmp_le_u32_sdwa vcc, %[n], %[r] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+      "v_cndmask_b32_sdwa %[p], %[w], %[w], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+      : [p] "=v"(p)
+      : [n] "v"(w0), [r] "v"(r), [w] "v"(w1)
+      : "vcc");
+  return p;
+}
+__device__ __forceinline__ void first_ptr(uint32_t root, uint32_t r, uint32_t l0, uint32_t r0, uint32_t l1, uint32_t r1, uint32_t& w0,
+                                          uint32_t& w1) {
+  asm("v_cmp_le_u32_sdwa vcc, %[n], %[r] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+      "v_cndmask_b32 %[x], %[l0], %[r0], vcc\n\t"
+      "v_cndmask_b32 %[y], %[l1], %[r1], vcc"
+      : [x] "=&v"(w0), [y] "=&v"(w1)
+      : [n] "v"(root), [r] "v"(r), [l0] "v"(l0), [r0] "v"(r0), [l1] "v"(l1), [r1] "v"(r1)
+      : "vcc");
+}
+// LDS address of the rank a node asks for: slot * 128 + the lane's origin for the window (rb, an LDS address)
+__device__ __forceinline__ uint32_t rank_at(uint32_t w0, uint32_t rb) {
+  uint32_t a;
+  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(a) : "v"(w0), "s"(128u), "v"(rb));
+  return a;
 }
 
-__device__ __forceinline__ uint32_t ld_rank(const uint8_t* p) { return *reinterpret_cast<const uint16_t*>(p); }
-
-// TWO trees (tb0, tb1) side by side for the RW windows of a lane, depth D >= 2.  rb[k] = the lane's origin in the strip for
-// window k (slot of padded position w_k, class 0, + the haplotype's bytes); a node's offset is (s * A + a) * 128.
-template <int D>
-__device__ __forceinline__ void walk_pair(const uint8_t* tb0, const uint8_t* tb1, const uint8_t* const* rb, float* psum) {
-  uint32_t j[2 * RW], off[2 * RW], f[2 * RW], r[2 * RW];
-  const uint2 root0 = *reinterpret_cast<const uint2*>(tb0 + 8), root1 = *reinterpret_cast<const uint2*>(tb1 + 8);
-  const uint4 kid0 = *reinterpret_cast<const uint4*>(tb0 + 16), kid1 = *reinterpret_cast<const uint4*>(tb1 + 16);
+// NT trees (tb, tb + tree_bytes, ...) side by side for the RW windows of a lane: NT * RW independent chains.  rb[k] = LDS address
+// of the lane's halfword in slot (padded position w_k, class 0).
+template <int D, int NT>
+__device__ __forceinline__ void walk_n(const uint8_t* tb, int tree_bytes, const uint32_t* rb, float* psum) {
+  static_assert(D >= 2, "the 16-byte tree top holds levels 0 and 1");
+  constexpr int NC = NT * RW;
+  uint32_t w0[NC], w1[NC], r[NC], p[NC];
+  uint4 top[NT];  // {w0 of node 2, w0 of node 3, w0 of the root, w1 of node 2}
 #pragma unroll
-  for (int k = 0; k < RW; ++k) r[k] = ld_rank(rb[k] + root0.x);
+  for (int t = 0; t < NT; ++t) top[t] = *reinterpret_cast<const uint4*>(tb + t * tree_bytes);
+  constexpr uint32_t SIB = (D == 2 ? 8u : 16u) * 0x10001u;  // node 3's children sit right behind node 2's
 #pragma unroll
-  for (int k = 0; k < RW; ++k) r[RW + k] = ld_rank(rb[k] + root1.x);
-  first3(j, root0.y, r, kid0.x, kid0.y, kid0.z, kid0.w, off, f);
-  first3(j + RW, root1.y, r + RW, kid1.x, kid1.y, kid1.z, kid1.w, off + RW, f + RW);
+  for (int c = 0; c < NC; ++c) r[c] = *lds_at<uint16_t>(rank_at(top[c / RW].z, rb[c % RW]));
 #pragma unroll
-  for (int k = 0; k < 2 * RW; ++k) r[k] = ld_rank(rb[k % RW] + off[k]);
-  step3(j, f, r);
-  step3(j + RW, f + RW, r + RW);
+  for (int c = 0; c < NC; ++c)
+    first_ptr(top[c / RW].z, r[c], top[c / RW].x, top[c / RW].y, top[c / RW].w, top[c / RW].w + SIB, w0[c], w1[c]);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) r[c] = *lds_at<uint16_t>(rank_at(w0[c], rb[c % RW]));
+#pragma unroll
+  for (int c = 0; c < NC; ++c) p[c] = step_ptr(w0[c], w1[c], r[c]);
 #pragma unroll
   for (int d = 2; d < D; ++d) {
 #pragma unroll
-    for (int k = 0; k < RW; ++k) {
-      const uint2 nd = reinterpret_cast<const uint2*>(tb0)[j[k]];
-      off[k] = nd.x;
-      f[k] = nd.y;
+    for (int c = 0; c < NC; ++c) {
+      const uint2 nd = *lds_at<uint2>(p[c]);
+      w0[c] = nd.x;
+      w1[c] = nd.y;
     }
 #pragma unroll
-    for (int k = 0; k < RW; ++k) {
-      const uint2 nd = reinterpret_cast<const uint2*>(tb1)[j[RW + k]];
-      off[RW + k] = nd.x;
-      f[RW + k] = nd.y;
-    }
+    for (int c = 0; c < NC; ++c) r[c] = *lds_at<uint16_t>(rank_at(w0[c], rb[c % RW]));
 #pragma unroll
-    for (int k = 0; k < 2 * RW; ++k) r[k] = ld_rank(rb[k % RW] + off[k]);
-    step3(j, f, r);
-    step3(j + RW, f + RW, r + RW);
+    for (int c = 0; c < NC; ++c) p[c] = step_ptr(w0[c], w1[c], r[c]);
   }
-  float l0[RW], l1[RW];
-  const float* lf0 = reinterpret_cast<const float*>(tb0 + ((size_t)8 << D)) - (1 << D);  // leaf of heap index j (2^D <= j < 2^(D+1))
-  const float* lf1 = reinterpret_cast<const float*>(tb1 + ((size_t)8 << D)) - (1 << D);
+  float lf[NC];
 #pragma unroll
-  for (int k = 0; k < RW; ++k) l0[k] = lf0[j[k]];
+  for (int c = 0; c < NC; ++c) lf[c] = *lds_at<float>(p[c]);
 #pragma unroll
-  for (int k = 0; k < RW; ++k) l1[k] = lf1[j[RW + k]];
+  for (int t = 0; t < NT; ++t)  // tree order
 #pragma unroll
-  for (int k = 0; k < RW; ++k) psum[k] += l0[k];   // tree order: tb0 before tb1
-#pragma unroll
-  for (int k = 0; k < RW; ++k) psum[k] += l1[k];
-}
-
-// one tree, any depth (the tail of an odd group, depth-1 ensembles, run-time depths)
-__device__ __forceinline__ float walk_one(const uint8_t* tb, const uint8_t* rb, int D) {
-  uint32_t j = 1;
-  for (int d = 0; d < D; ++d) {
-    const uint2 nd = reinterpret_cast<const uint2*>(tb)[j];
-    const uint32_t r = ld_rank(rb + nd.x);
-    j = 2 * j + ((r < nd.y) ? 0u : 1u);
-  }
-  return (reinterpret_cast<const float*>(tb + ((size_t)8 << D)) - (1 << D))[j];
+    for (int k = 0; k < RW; ++k) psum[k] += lf[t * RW + k];
 }
 
 // NWAVE waves = NWAVE * RW windows of HB haplotypes per block.  DT = depth (0: run time).
-template <int NWAVE, int DT>
+template <int NWAVE, int DT, int NT>
 __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_h64(SmoothXGBLaunch L, const uint16_t* __restrict__ Rk) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int THREADS = NWAVE * 64, WPB = NWAVE * RW;
   const int A = L.A, W = L.W, S = L.S, pad = (S + 1) / 2, J = W + 2 * pad;
-  const int D = DT ? DT : L.d.D;
   const int tree_bytes = L.d.h8_tree_bytes;
   const int P = WPB + S - 1;                                  // padded window positions held
   const int strip_bytes = P * A * 128;
   const int buf_bytes = L.d.h8_max_group * tree_bytes;        // multiple of 16
-  uint8_t* strip = lds;
-  uint8_t* tbuf0 = lds + strip_bytes;
+  uint8_t* tbuf0 = lds;                                      // the trees first: node addresses must fit 16 bits
   uint8_t* tbuf1 = tbuf0 + buf_bytes;
+  uint8_t* strip = tbuf1 + buf_bytes;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t hb = blockIdx.y;
   const int w0 = blockIdx.x * WPB;
@@ -241,13 +224,13 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_h64(SmoothXGBLaunch L
   }
 
   const int64_t n = hb * HB + lane;
-  const uint8_t* rb[RW];
+  uint32_t rb[RW];
   bool valid[RW];
   const int hoff = hap_off(lane);
 #pragma unroll
   for (int k = 0; k < RW; ++k) {
     const int wl = wave * RW + k;
-    rb[k] = strip + (size_t)wl * A * 128 + hoff;
+    rb[k] = (uint32_t)(uintptr_t)strip + (uint32_t)(wl * A * 128 + hoff);
     valid[k] = (n < L.N) && (w0 + wl < W);
   }
   // margins parked class-major, [class][haplotype block][window][64 lanes]: whole 256-byte lines
@@ -256,7 +239,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_h64(SmoothXGBLaunch L
 
   // ---- tree groups through the double-buffered LDS window ----
   const int ng = L.d.h8_n_groups;
-  constexpr int MAXV = (4096 / 16 + THREADS - 1) / THREADS;  // a group is at most 4 KB (model loader): one piece per thread
+  constexpr int MAXV = (32768 / 16 + THREADS - 1) / THREADS;  // a group is at most 32 KB (model loader)
   uint4 stg[MAXV];
   const int nv = (buf_bytes / 16 + THREADS - 1) / THREADS;
 #define GNX_G_LOAD(g)                                                                               \
@@ -270,6 +253,11 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_h64(SmoothXGBLaunch L
   {                                                                                                 \
     _Pragma("unroll") for (int v = 0; v < MAXV; ++v) {                                              \
       const int e_ = v * THREADS + tid;                                                             \
+      /* child addresses: relative to the group -> LDS addresses */                                 \
+      const int pc_ = (e_ * 16 % tree_bytes) >> 4;                                                  \
+      const uint32_t add_ = pc_ < (1 << (DT - 1)) ? (uint32_t)(uintptr_t)(dst) * 0x10001u : 0u;     \
+      stg[v].w += add_;                                                                             \
+      stg[v].y += pc_ ? add_ : 0u;                                                                  \
       if (v < nv && e_ * 16 < buf_bytes) *reinterpret_cast<uint4*>((dst) + (size_t)e_ * 16) = stg[v]; \
     }                                                                                               \
   }
@@ -298,17 +286,8 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_h64(SmoothXGBLaunch L
     }
     const int nt = L.d.h8_group_tree0[g + 1] - L.d.h8_group_tree0[g];
     int t = 0;
-    if constexpr (DT >= 2) {
-      for (; t + 1 < nt; t += 2) {
-        const uint8_t* tb = cur + (size_t)t * tree_bytes;
-        walk_pair<DT>(tb, tb + tree_bytes, rb, psum);
-      }
-    }
-    for (; t < nt; ++t) {
-      const uint8_t* tb = cur + (size_t)t * tree_bytes;
-#pragma unroll
-      for (int k = 0; k < RW; ++k) psum[k] += walk_one(tb, rb[k], D);
-    }
+    for (; t + NT <= nt; t += NT) walk_n<DT, NT>(cur + (size_t)t * tree_bytes, tree_bytes, rb, psum);
+    for (; t < nt; ++t) walk_n<DT, 1>(cur + (size_t)t * tree_bytes, tree_bytes, rb, psum);
     GNX_G_STORE(nxt);
     __syncthreads();
   }
@@ -346,17 +325,28 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_h64(SmoothXGBLaunch L
   }
 }
 
-template <int NWAVE>
-hipError_t launch_h64(const SmoothXGBLaunch& L, const uint16_t* Rk, size_t lds, hipStream_t s) {
+template <int NWAVE, int DT>
+hipError_t launch_h64_d(const SmoothXGBLaunch& L, const uint16_t* Rk, size_t lds, int nt, hipStream_t s) {
   const dim3 grid((unsigned)((L.W + NWAVE * RW - 1) / (NWAVE * RW)), (unsigned)((L.N + HB - 1) / HB));
-  if (L.d.D == 4) {
-    GNX_LDS_OPTIN(lds, k_smooth_xgb_h64<NWAVE, 4>);
-    hipLaunchKernelGGL((k_smooth_xgb_h64<NWAVE, 4>), grid, dim3(NWAVE * 64), lds, s, L, Rk);
+  if (nt == 2) {
+    GNX_LDS_OPTIN(lds, k_smooth_xgb_h64<NWAVE, DT, 2>);
+    hipLaunchKernelGGL((k_smooth_xgb_h64<NWAVE, DT, 2>), grid, dim3(NWAVE * 64), lds, s, L, Rk);
   } else {
-    GNX_LDS_OPTIN(lds, k_smooth_xgb_h64<NWAVE, 0>);
-    hipLaunchKernelGGL((k_smooth_xgb_h64<NWAVE, 0>), grid, dim3(NWAVE * 64), lds, s, L, Rk);
+    GNX_LDS_OPTIN(lds, k_smooth_xgb_h64<NWAVE, DT, 4>);
+    hipLaunchKernelGGL((k_smooth_xgb_h64<NWAVE, DT, 4>), grid, dim3(NWAVE * 64), lds, s, L, Rk);
   }
   return hipGetLastError();
+}
+template <int NWAVE>
+hipError_t launch_h64(const SmoothXGBLaunch& L, const uint16_t* Rk, size_t lds, int nt, hipStream_t s) {
+  switch (L.d.D) {
+    case 2: return launch_h64_d<NWAVE, 2>(L, Rk, lds, nt, s);
+    case 3: return launch_h64_d<NWAVE, 3>(L, Rk, lds, nt, s);
+    case 4: return launch_h64_d<NWAVE, 4>(L, Rk, lds, nt, s);
+    case 5: return launch_h64_d<NWAVE, 5>(L, Rk, lds, nt, s);
+    case 6: return launch_h64_d<NWAVE, 6>(L, Rk, lds, nt, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 size_t lds_need(const SmoothXGBDev& d, int A, int S, int nwave) {
@@ -390,5 +380,6 @@ hipError_t gnx_launch_smooth_xgb_h64(const SmoothXGBLaunch& L, uint16_t* Rk, con
     if (e != hipSuccess) return e;
   }
   const size_t lds = lds_need(L.d, L.A, L.S, nw);
-  return nw == 16 ? launch_h64<16>(L, Rk, lds, s) : nw == 8 ? launch_h64<8>(L, Rk, lds, s) : launch_h64<4>(L, Rk, lds, s);
+  const int nt = tune.sm_pair == 2 ? 2 : 4;  // trees side by side per lane (GNX_SM_PAIR=2: two)
+  return nw == 16 ? launch_h64<16>(L, Rk, lds, nt, s) : nw == 8 ? launch_h64<8>(L, Rk, lds, nt, s) : launch_h64<4>(L, Rk, lds, nt, s);
 }
