@@ -40,11 +40,34 @@ def load_model(path_to_model, device=0, verbose=True):
     return HipGnomix(from_reference_model(ref_model), device=device)
 
 
-def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False, timings=None):
+class _Prefetch:
+    """`fn()` on a worker thread (the library calls release the GIL); result() re-raises what it raised"""
+
+    def __init__(self, fn):
+        import threading
+        self._out = self._err = None
+
+        def work():
+            try:
+                self._out = fn()
+            except BaseException as e:   # noqa: BLE001 - handed to the caller
+                self._err = e
+        self._t = threading.Thread(target=work, daemon=True)
+        self._t.start()
+
+    def result(self):
+        self._t.join()
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+
+def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False, timings=None, query=None):
     """gnomix.py:37-100 with the HIP model behind the same steps.  The query never becomes an (N, C) host matrix: the library
     parses the text into 2-bit rows (gnx_vcf_read), `column_map` keeps vcf_to_npy's bookkeeping (SNP intersection, REF flips,
     absent SNPs) as one int32 per model SNP, the GPU builds X and runs base + smoother (or Gnofix) on it, and the library
-    formats .msp / .fb / the phased VCF.  `timings` (a dict) receives the seconds of each stage."""
+    formats .msp / .fb / the phased VCF.  `timings` (a dict) receives the seconds of each stage; `query` = a _Prefetch of
+    vcfio.read_vcf started earlier (the command line parses the query while the GPU runtime starts and the model loads)."""
     from time import perf_counter as clock
     from . import postprocess as pp
     from . import vcfio
@@ -53,7 +76,7 @@ def run_inference(base_args, model, snp_level=False, bed_file_output=False, verb
     if verbose:
         print("Loading and processing query file...")
     t0 = clock()
-    vcf = vcfio.read_vcf(query_file, chm=chm, ctx=model.dev.ctx)
+    vcf = query.result() if query is not None else vcfio.read_vcf(query_file, chm=chm, ctx=model.dev.ctx)
     assert vcf is not None, "No SNPs of specified chromosome found in query file."
     T["read_vcf"] = clock() - t0
     t0 = clock()
@@ -98,8 +121,21 @@ def run_inference(base_args, model, snp_level=False, bed_file_output=False, verb
     return out_prefix
 
 
+def _since_process_start():
+    """seconds since this process was created (Linux: /proc/self/stat field 22 against /proc/uptime)"""
+    try:
+        with open("/proc/self/stat") as f:
+            start_ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return up - start_ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return float("nan")
+
+
 def main(argv=None):
     argv = list(sys.argv if argv is None else argv)
+    t_startup = _since_process_start() if os.environ.get("GNX_CLI_TIMING") else None
     if "torch" not in sys.modules:
         os.environ.setdefault("GNX_NO_TORCH", "1")   # the command line needs no torch: do not pay for its import
     if len(argv) in (8, 9):
@@ -120,6 +156,12 @@ def main(argv=None):
             config = yaml.safe_load(f) or config
     print("Launching in pre-trained mode...")
     from time import perf_counter as clock
+    query = None
+    if base_args["query_file"] and os.environ.get("GNX_CLI_PREFETCH", "1") != "0":
+        # neither needs the other: the host's threads parse the text (into pageable memory, no GPU context yet) while this
+        # thread starts the GPU runtime (~0.16 s), reads the model and builds its device tables (~0.15 s)
+        from . import vcfio
+        query = _Prefetch(lambda: vcfio.read_vcf(base_args["query_file"], chm=base_args["chm"], ctx=None))
     t_load = clock()
     model = load_model(base_args["path_to_model"])
     t_load = clock() - t_load
@@ -131,9 +173,12 @@ def main(argv=None):
         print("Launching inference...")
         inf = config.get("inference") or {}
         T = {"load_model": t_load}
+        if t_startup is not None:
+            T = {"interpreter_and_imports": t_startup, "load_model": t_load}
         run_inference(base_args, model, snp_level=bool(inf.get("snp_level_inference")),
-                      bed_file_output=bool(inf.get("bed_file_output")), verbose=True, timings=T)
+                      bed_file_output=bool(inf.get("bed_file_output")), verbose=True, timings=T, query=query)
         if os.environ.get("GNX_CLI_TIMING"):
+            T["since_process_start"] = _since_process_start()
             sys.stderr.write("gnomix_amd timings (s): " + ", ".join("%s %.3f" % kv for kv in T.items()) + "\n")
     return 0
 
