@@ -14,7 +14,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 9
+GNX_ABI_VERSION = 10
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
@@ -73,6 +73,11 @@ class GbtParams(C.Structure):
                 ("base_score", C.c_double)]
 
 
+class CnnParams(C.Structure):
+    _fields_ = [("epochs", C.c_int32), ("batch", C.c_int32), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double), ("log_eps", C.c_double)]
+
+
 class VcfInfo(C.Structure):
     _fields_ = [("n_variants", C.c_int64), ("n_samples", C.c_int64), ("ldg", C.c_int64), ("file_bytes", C.c_int64),
                 ("text_bytes", C.c_int64), ("n_fast_lines", C.c_int64), ("n_general_lines", C.c_int64), ("n_overflow", C.c_int64),
@@ -123,6 +128,7 @@ SYMBOLS = {
                                          _VP, C.POINTER(TrainInfo)]),
     "gnx_fit_isotonic_f32": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP]),
     "gnx_train_gbt": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
+    "gnx_train_cnn": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnnParams), _VP, _VP, _VP, _VP]),
     "gnx_train_gbt_dev": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
     # include/gnomix_io.h: the file side
     "gnx_io_last_error": (C.c_char_p, []),

@@ -294,7 +294,7 @@ __device__ __forceinline__ const __attribute__((address_space(3))) T* lds_at(uin
 }
 #else
 template <typename T>
-__device__ const T* lds_at(uint32_t a);  // host pass: declaration only
+__device__ const T* lds_at(uint32_t) { return nullptr; }  // host pass: never called
 #endif
 __device__ __forceinline__ uint32_t step_ptr(uint32_t w0, uint32_t w1, uint32_t r) {
   uint32_t p;

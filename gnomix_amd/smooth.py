@@ -62,12 +62,18 @@ class HipSmoother:
         """Smoother.train (smooth.py:28-38) for the tree smoother: gradient boosting on the device with the reference's
         XGBClassifier arguments (Smooth/models.py:14-20), then the device model is swapped for the freshly trained one.
         B (N, W, A) base probabilities of the smoother's training haplotypes, y (N, W) labels."""
-        from .train import train_gbt_smoother
+        from .train import train_gbt_smoother, train_cnn_smoother
         from .model import DeviceModel
         y = np.asarray(y)
         assert len(np.unique(y)) == self.A, "Smoother training data does not include all populations"   # smooth.py:30
+        if self.dev.data.smooth_kind == "cnn":   # CNN_Smoother: CNN.fit (Smooth/cnn.py:104-118) on the device
+            t = time()
+            self.train_loss = train_cnn_smoother(self.dev.data, B, y.reshape(np.asarray(B).shape[0], -1), ctx=self.dev.ctx, **kw)
+            self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)
+            self.time["train"] = time() - t
+            return self
         if self.dev.data.smooth_kind not in (None, "xgb"):
-            raise NotImplementedError("on-device training is built for the tree smoother (XGB_Smoother)")
+            raise NotImplementedError("on-device training is built for the tree and the convolutional smoother (XGB_Smoother, CNN_Smoother)")
         t = time()
         self.train_loss = train_gbt_smoother(self.dev.data, B, y.reshape(B.shape[0], -1), ctx=self.dev.ctx, **kw)
         self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)   # (a HipGnomix re-binds base and fused path: HipGnomix.train_smoother)

@@ -114,3 +114,52 @@ def train_gbt_smoother(data: GnxModelData, B, y, **kw) -> np.ndarray:
         setattr(data, k, v)
     data.base_score = float(kw.get("base_score", 0.5))
     return loss
+
+
+def cnn_init(A, S, seed=None):
+    """nn.Conv1d(A, A, S)'s default initialisation (torch.nn.modules.conv._ConvNd.reset_parameters): kaiming_uniform_(a = sqrt 5)
+    on the weight and uniform(+-1/sqrt(fan_in)) on the bias are both uniform(+-1/sqrt(A * S)); numpy's generator, not torch's"""
+    rng = np.random.RandomState(seed)
+    bound = 1.0 / np.sqrt(A * S)
+    return (rng.uniform(-bound, bound, size=(A, A, S)).astype(np.float32), rng.uniform(-bound, bound, size=A).astype(np.float32))
+
+
+def train_cnn_arrays(B, y, S, weight=None, bias=None, max_ep=250, batch_size=128, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, log_eps=1e-8,
+                     shuffle=True, seed=None, order=None, ctx=None, device=0):
+    """CNN.fit (src/Smooth/cnn.py:104-118) on the device: B (N, W, A) base probabilities, y (N, W) labels -> (weight (A, A, S),
+    bias (A,), per-epoch mean batch loss).  `weight` / `bias` = initial parameters (default: cnn_init(A, S, seed));
+    `order` (max_ep, N) = the rows' order in every epoch (default: a fresh permutation per epoch when `shuffle`, as the
+    reference's DataLoader(shuffle=True), drawn from numpy's RandomState(seed))."""
+    ctx = ctx or _lib.default_context(device)
+    B = np.ascontiguousarray(B)
+    if B.dtype != np.float64:
+        B = np.ascontiguousarray(B, dtype=np.float32)
+    N, W, A = B.shape
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    if y.shape != (N, W):
+        raise ValueError(f"y must be (N, W) = ({N}, {W}), got {y.shape}")
+    if weight is None or bias is None:
+        weight, bias = cnn_init(A, S, seed)
+    weight = np.array(weight, dtype=np.float32, order="C")
+    bias = np.array(bias, dtype=np.float32, order="C")
+    if weight.shape != (A, A, S) or bias.shape != (A,):
+        raise ValueError(f"weight / bias must be ({A}, {A}, {S}) / ({A},), got {weight.shape} / {bias.shape}")
+    if order is None and shuffle:
+        rng = np.random.RandomState(None if seed is None else seed + 1)
+        order = np.stack([rng.permutation(N) for _ in range(int(max_ep))]) if max_ep > 0 else np.zeros((0, N), np.int64)
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        if order.shape != (int(max_ep), N):
+            raise ValueError(f"order must be (max_ep, N) = ({int(max_ep)}, {N}), got {order.shape}")
+    loss = np.zeros(max(int(max_ep), 1), np.float64)
+    P = _lib.CnnParams(int(max_ep), int(batch_size), float(lr), float(betas[0]), float(betas[1]), float(eps), float(log_eps))
+    ctx.check(ctx.lib.gnx_train_cnn(ctx.h, B.ctypes.data, int(B.dtype == np.float64), y.ctypes.data, int(N), int(W), int(A), int(S), C.byref(P),
+                                    order.ctypes.data if order is not None else None, weight.ctypes.data, bias.ctypes.data, loss.ctypes.data))
+    return weight, bias, loss[:int(max_ep)]
+
+
+def train_cnn_smoother(data: GnxModelData, B, y, **kw) -> np.ndarray:
+    """fit the convolutional smoother of `data` in place (smooth_kind "cnn", cnn_weight / cnn_bias) -> losses per epoch"""
+    w, b, loss = train_cnn_arrays(B, y, data.S if data.S % 2 else data.S - 1, **kw)
+    data.smooth_kind, data.cnn_weight, data.cnn_bias = "cnn", w, b
+    return loss

@@ -14,6 +14,7 @@
  *   gnx_gnofix            <- Gnomix.phase(X, B) -> gnofix() per indiv.  src/model.py:188-214, src/Gnofix/gnofix.py:58-208
  *   gnx_train_logistic    <- Base.train(X, y) of LogisticRegressionBase   src/Base/base.py:104-127, src/model.py:113,155
  *   gnx_train_gbt         <- Smoother.train(B, y) of XGB_Smoother         src/Smooth/smooth.py:28-38, src/model.py:137
+ *   gnx_train_cnn         <- Smoother.train(B, y) of CNN_Smoother         src/Smooth/cnn.py:104-118, src/Smooth/models.py:35-42
  *
  * Conventions
  *   - return 0 (GNX_OK) or a negative GNX_E* code; the message is kept per context (gnx_last_error).
@@ -44,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 9
+#define GNX_ABI_VERSION 10
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -320,6 +321,24 @@ int gnx_train_gbt(gnx_ctx* ctx, const void* B, int32_t b_is_f64, const int32_t* 
 int gnx_train_gbt_dev(gnx_ctx* ctx, const void* dB, int32_t b_is_f64, const int32_t* dy, int64_t N, int32_t W, int32_t A, int32_t S,
                       const gnx_gbt_params* params, int32_t* tree_off, int32_t* tree_class, int32_t* left, int32_t* right,
                       int32_t* feat, float* cond, int64_t* n_nodes, double* loss);
+
+/* ---- training the convolutional smoother: CNN.fit (src/Smooth/cnn.py:104-118) as Smoother.train calls it for CNN_Smoother
+ *      (src/Smooth/smooth.py:28-38, src/Smooth/models.py:35-42).  nn.Conv1d(A, A, S, padding = (S-1)/2) with zero padding,
+ *      loss = NLLLoss(log(softmax + log_eps), y) averaged over the batch's rows x windows (cnn.py:57-75), torch.optim.Adam
+ *      (cnn.py:32), mini-batches of `batch` rows in the order `order` gives for each epoch (the DataLoader's shuffle, cnn.py:172;
+ *      NULL = 0 .. N-1 every epoch).  All arithmetic float32.
+ *      B (N, W, A) float32 / float64 and y (N, W) on the host; weight (A, A, S) and bias (A) hold the initial parameters on
+ *      entry (torch's default: uniform(+-1/sqrt(A*S))) and the trained ones on return; loss (epochs) receives each epoch's mean
+ *      batch loss (the number cnn.py:120 prints) or may be NULL. */
+typedef struct gnx_cnn_params {
+  int32_t epochs;            /* 250  (max_ep) */
+  int32_t batch;             /* 128  (DataLoader batch_size) */
+  double lr;                 /* 1e-3 (Adam) */
+  double beta1, beta2, eps;  /* 0.9, 0.999, 1e-8 (Adam defaults) */
+  double log_eps;            /* 1e-8 (cnn.py:73) */
+} gnx_cnn_params;
+int gnx_train_cnn(gnx_ctx* ctx, const void* B, int32_t b_is_f64, const int32_t* y, int64_t N, int32_t W, int32_t A, int32_t S,
+                  const gnx_cnn_params* params, const int64_t* order, float* weight, float* bias, double* loss);
 
 /* ---- one isotonic map of the calibrator: Calibrator.fit (src/Smooth/Calibration.py:43-55) fits, per class i,
  *      sklearn IsotonicRegression(out_of_bounds='clip') on (proba[:, i], y == class i) with float32 probabilities.

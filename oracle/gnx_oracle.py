@@ -276,6 +276,55 @@ def smooth_cnn(B, weight, bias):
     return proba, labels
 
 
+def cnn_fit(B, y, weight, bias, epochs, batch=128, order=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, log_eps=1e-8):
+    """CNN.fit (reference src/Smooth/cnn.py:104-118) restated in float32 numpy: Conv1d(A, A, S, zero padding (S-1)//2)
+    (cnn.py:37-39; zero padding: see smooth_cnn / tests/golden/make_golden.py G11), loss = NLLLoss(log(softmax + 1e-8), y) with
+    mean reduction (cnn.py:57-75), torch.optim.Adam's single-tensor step (exp_avg, exp_avg_sq, bias corrections in Python floats,
+    denom = sqrt(v) / sqrt(bc2) + eps, p -= lr / bc1 * m / denom), mini-batches of `batch` rows in the order `order[ep]`
+    (None: 0 .. N-1).  Pinned by G17 (the reference's own CNN.fit run under torch).  -> weight, bias, per-epoch mean batch loss"""
+    f32 = np.float32
+    Bt = np.ascontiguousarray(np.transpose(np.asarray(B), (0, 2, 1)), dtype=f32)           # as_torch_tensor: (N, A, W) float
+    y = np.asarray(y)
+    N, A, W = Bt.shape
+    w = np.array(weight, dtype=f32)
+    b = np.array(bias, dtype=f32)
+    S = w.shape[2]
+    pad = (S - 1) // 2
+    Bp = np.zeros((N, A, W + 2 * pad), f32)
+    Bp[:, :, pad:pad + W] = Bt
+    mw, vw, mb, vb = np.zeros_like(w), np.zeros_like(w), np.zeros_like(b), np.zeros_like(b)
+    b1, b2 = float(betas[0]), float(betas[1])
+    t = 0
+    losses = np.zeros(int(epochs), np.float64)
+    for ep in range(int(epochs)):
+        rows = np.arange(N) if order is None else np.asarray(order[ep])
+        nbat = (N + batch - 1) // batch
+        for k in range(nbat):
+            idx = rows[k * batch:(k + 1) * batch]
+            nb = len(idx)
+            V = np.lib.stride_tricks.sliding_window_view(Bp[idx], S, axis=2)              # (nb, A_in, W, S)
+            z = np.einsum("nawk,cak->ncw", V, w, optimize=True).astype(f32) + b[None, :, None]
+            z = z - z.max(axis=1, keepdims=True)
+            e = np.exp(z, dtype=f32)
+            p = e / e.sum(axis=1, keepdims=True, dtype=f32)
+            py = np.take_along_axis(p, y[idx][:, None, :].astype(np.int64), axis=1)[:, 0, :]   # (nb, W)
+            losses[ep] += float(np.mean(-np.log(py + f32(log_eps), dtype=f32), dtype=np.float64)) / nbat
+            k_ = (py / (py + f32(log_eps)) / f32(nb * W)).astype(f32)
+            onehot = (np.arange(A)[None, :, None] == y[idx][:, None, :]).astype(f32)
+            g = (k_[:, None, :] * (p - onehot)).astype(f32)                                  # dL/dlogit (nb, A_out, W)
+            gw = np.einsum("ncw,nawk->cak", g, V, optimize=True).astype(f32)
+            gb = g.sum(axis=(0, 2), dtype=f32)
+            t += 1
+            step = lr / (1.0 - b1 ** t)
+            bc2s = np.sqrt(1.0 - b2 ** t)
+            for prm, grd, m_, v_ in ((w, gw, mw, vw), (b, gb, mb, vb)):
+                m_ *= f32(b1); m_ += grd * f32(1.0 - b1)
+                v_ *= f32(b2); v_ += (grd * grd) * f32(1.0 - b2)
+                denom = np.sqrt(v_) / f32(bc2s) + f32(eps)
+                prm -= f32(step) * (m_ / denom)
+    return w, b, losses
+
+
 def cov_sample(M, alpha=0.6, beta=1.0, seed=37):
     """CovSample (string_kernel.py:80-89): legacy MT19937 stream, one draw per m in 2..M."""
     rs = np.random.RandomState(seed)  # == np.random.seed(seed); np.random.rand() draws

@@ -21,6 +21,7 @@ input/output pair produced by executing its own functions:
                    xgboost / sklearn_crfsuite (absent here: they print "skipped"); tests/test_pins_thirdparty.py consumes them
   G15_lr_binary.npz  A = 2 logistic base (sklearn's one-row binary form)
   G16_lr_train.npz   LogisticRegressionBase.train (base.py:104-127): training data + the reference's fitted coefficients
+  G17_cnn_train.npz  CNN.fit (Smooth/cnn.py:104-118): data, initial and trained Conv1d parameters, the DataLoader's row order
 
 Third-party modules the reference imports at module import time but that are absent here
 (xgboost, allel, seaborn, calibration, sklearn_crfsuite) are replaced by empty stubs; no code path
@@ -768,7 +769,7 @@ def make_G16(out):
 
 
 def main():
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17"]
     have_ref = import_reference()
     if not have_ref:
         _stub_modules()
@@ -790,7 +791,66 @@ def main():
     if "G14" in which: make_G14(os.path.join(HERE, "G14_xgb_base.npz"))
     if "G15" in which: make_G15(os.path.join(HERE, "G15_lr_binary.npz"))
     if "G16" in which: make_G16(os.path.join(HERE, "G16_lr_train.npz"))
+    if "G17" in which: make_G17(os.path.join(HERE, "G17_cnn_train.npz"))
     return 0
+
+
+def make_G17(out):
+    """CNN.fit (src/Smooth/cnn.py:104-118) as Smoother.train runs it for CNN_Smoother: the reference's own class, optimiser and
+    data generator under torch; the layer is constructed with zero padding as in G11.  LAIDataset.__getitem__ is wrapped only to
+    RECORD the order in which the shuffling DataLoader visits the rows (300 rows = batches of 128, 128, 44 per epoch)."""
+    import torch
+    from torch import nn
+    real_conv = nn.Conv1d
+
+    class Conv1dOldTorch(real_conv):
+        def __init__(self, *a, padding_mode="zeros", **k):
+            super().__init__(*a, padding_mode="zeros" if padding_mode == "reflection" else padding_mode, **k)
+
+    from src.Smooth import cnn as ref_cnn
+    torch.manual_seed(170017)
+    torch.set_num_threads(1)
+    A, S, W, N, EP = 4, 9, 50, 300, 12
+    nn.Conv1d = Conv1dOldTorch
+    try:
+        model = ref_cnn.CNN(num_classes=A, num_features=S)
+    finally:
+        nn.Conv1d = real_conv
+    w0 = model.smoothNet[0].weight.detach().numpy().copy()
+    b0 = model.smoothNet[0].bias.detach().numpy().copy()
+    rng = np.random.RandomState(170017)
+    # tract-structured labels and base probabilities that lean towards them: something a smoother can learn
+    y = np.zeros((N, W), np.int64)
+    for n in range(N):
+        pos = 0
+        while pos < W:
+            ln = rng.randint(4, 20)
+            y[n, pos:pos + ln] = rng.randint(A)
+            pos += ln
+    B = rng.dirichlet(np.ones(A) * 0.6, size=(N, W))
+    B[np.arange(N)[:, None], np.arange(W)[None, :], y] += 0.8 * rng.random_sample((N, W))
+    B = (B / B.sum(-1, keepdims=True)).astype(np.float32)
+    visited = []
+    real_get = ref_cnn.LAIDataset.__getitem__
+
+    def logging_get(self, index):
+        visited.append(int(index))
+        return real_get(self, index)
+
+    ref_cnn.LAIDataset.__getitem__ = logging_get
+    try:
+        model.fit(B, y, max_ep=EP)
+    finally:
+        ref_cnn.LAIDataset.__getitem__ = real_get
+    order = np.asarray(visited, np.int64).reshape(EP, N)
+    assert all(sorted(r) == list(range(N)) for r in order.tolist())
+    w1 = model.smoothNet[0].weight.detach().numpy().copy()
+    b1 = model.smoothNet[0].bias.detach().numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        proba = model.predict_proba(B[:16])
+    np.savez_compressed(out, A=A, S=S, W=W, epochs=EP, B=B, y=y.astype(np.int32), order=order, w0=w0, b0=b0, w1=w1, b1=b1, proba16=proba)
+    print("G17", "moved", float(np.abs(w1 - w0).max()), "train acc", float((np.argmax(model.predict_proba(B), -1) == y).mean()))
 
 
 if __name__ == "__main__":
