@@ -78,6 +78,15 @@ class CnnParams(C.Structure):
                 ("eps", C.c_double), ("log_eps", C.c_double)]
 
 
+class CrfParams(C.Structure):
+    _fields_ = [("c1", C.c_double), ("c2", C.c_double), ("epsilon", C.c_double), ("max_iterations", C.c_int32), ("memory", C.c_int32)]
+
+
+class CrfInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("evaluations", C.c_int32), ("objective", C.c_double), ("grad_norm", C.c_double),
+                ("converged", C.c_int32), ("reserved", C.c_int32)]
+
+
 class VcfInfo(C.Structure):
     _fields_ = [("n_variants", C.c_int64), ("n_samples", C.c_int64), ("ldg", C.c_int64), ("file_bytes", C.c_int64),
                 ("text_bytes", C.c_int64), ("n_fast_lines", C.c_int64), ("n_general_lines", C.c_int64), ("n_overflow", C.c_int64),
@@ -128,6 +137,7 @@ SYMBOLS = {
                                          _VP, C.POINTER(TrainInfo)]),
     "gnx_fit_isotonic_f32": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP]),
     "gnx_train_gbt": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
+    "gnx_train_crf": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.POINTER(CrfParams), _VP, _VP, C.POINTER(CrfInfo)]),
     "gnx_train_cnn": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnnParams), _VP, _VP, _VP, _VP]),
     "gnx_train_gbt_dev": (C.c_int, [_VP, _VP, C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GbtParams)] + [_VP] * 8),
     # include/gnomix_io.h: the file side

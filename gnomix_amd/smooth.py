@@ -62,7 +62,7 @@ class HipSmoother:
         """Smoother.train (smooth.py:28-38) for the tree smoother: gradient boosting on the device with the reference's
         XGBClassifier arguments (Smooth/models.py:14-20), then the device model is swapped for the freshly trained one.
         B (N, W, A) base probabilities of the smoother's training haplotypes, y (N, W) labels."""
-        from .train import train_gbt_smoother, train_cnn_smoother
+        from .train import train_gbt_smoother, train_cnn_smoother, train_crf_smoother
         from .model import DeviceModel
         y = np.asarray(y)
         assert len(np.unique(y)) == self.A, "Smoother training data does not include all populations"   # smooth.py:30
@@ -72,8 +72,12 @@ class HipSmoother:
             self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)
             self.time["train"] = time() - t
             return self
-        if self.dev.data.smooth_kind not in (None, "xgb"):
-            raise NotImplementedError("on-device training is built for the tree and the convolutional smoother (XGB_Smoother, CNN_Smoother)")
+        if self.dev.data.smooth_kind == "crf":   # CRF_Smoother: CRFsuite's objective, L-BFGS with device evaluations
+            t = time()
+            self.train_info = train_crf_smoother(self.dev.data, B, y.reshape(np.asarray(B).shape[0], -1), ctx=self.dev.ctx, **kw)
+            self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)
+            self.time["train"] = time() - t
+            return self
         t = time()
         self.train_loss = train_gbt_smoother(self.dev.data, B, y.reshape(B.shape[0], -1), ctx=self.dev.ctx, **kw)
         self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)   # (a HipGnomix re-binds base and fused path: HipGnomix.train_smoother)

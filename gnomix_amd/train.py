@@ -163,3 +163,34 @@ def train_cnn_smoother(data: GnxModelData, B, y, **kw) -> np.ndarray:
     w, b, loss = train_cnn_arrays(B, y, data.S if data.S % 2 else data.S - 1, **kw)
     data.smooth_kind, data.cnn_weight, data.cnn_bias = "cnn", w, b
     return loss
+
+
+def train_crf_arrays(B, y, c2=1.0, epsilon=1e-8, max_iterations=10000, memory=10, state0=None, trans0=None, ctx=None, device=0):
+    """CRF.fit (src/Smooth/crf.py:51-58) on the device: B (N, W, A) base probabilities (the attributes' values), y (N, W) labels ->
+    (state (A, A) [attribute][label], trans (A, A) [from][to], info dict).  Minimises CRFsuite's L2-regularised negative
+    log-likelihood (c1 = 0, c2 = 1 as sklearn_crfsuite.CRF's defaults) from zeros, like CRFsuite, to a tighter tolerance."""
+    ctx = ctx or _lib.default_context(device)
+    B = np.ascontiguousarray(B)
+    if B.dtype != np.float64:
+        B = np.ascontiguousarray(B, dtype=np.float32)
+    N, W, A = B.shape
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    if y.shape != (N, W):
+        raise ValueError(f"y must be (N, W) = ({N}, {W}), got {y.shape}")
+    state = np.zeros((A, A), np.float64) if state0 is None else np.array(state0, dtype=np.float64, order="C")
+    trans = np.zeros((A, A), np.float64) if trans0 is None else np.array(trans0, dtype=np.float64, order="C")
+    if state.shape != (A, A) or trans.shape != (A, A):
+        raise ValueError(f"state0 / trans0 must be ({A}, {A})")
+    P = _lib.CrfParams(0.0, float(c2), float(epsilon), int(max_iterations), int(memory))
+    info = _lib.CrfInfo()
+    ctx.check(ctx.lib.gnx_train_crf(ctx.h, B.ctypes.data, int(B.dtype == np.float64), y.ctypes.data, int(N), int(W), int(A), C.byref(P),
+                                    state.ctypes.data, trans.ctypes.data, C.byref(info)))
+    return state, trans, {"iterations": info.iterations, "evaluations": info.evaluations, "objective": info.objective,
+                          "grad_norm": info.grad_norm, "converged": bool(info.converged)}
+
+
+def train_crf_smoother(data: GnxModelData, B, y, **kw) -> dict:
+    """fit the CRF smoother of `data` in place (smooth_kind "crf", crf_state / crf_trans) -> info"""
+    st, tr, info = train_crf_arrays(B, y, **kw)
+    data.smooth_kind, data.crf_state, data.crf_trans = "crf", st, tr
+    return info

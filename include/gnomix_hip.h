@@ -14,6 +14,7 @@
  *   gnx_gnofix            <- Gnomix.phase(X, B) -> gnofix() per indiv.  src/model.py:188-214, src/Gnofix/gnofix.py:58-208
  *   gnx_train_logistic    <- Base.train(X, y) of LogisticRegressionBase   src/Base/base.py:104-127, src/model.py:113,155
  *   gnx_train_gbt         <- Smoother.train(B, y) of XGB_Smoother         src/Smooth/smooth.py:28-38, src/model.py:137
+ *   gnx_train_crf         <- Smoother.train(B, y) of CRF_Smoother         src/Smooth/crf.py:51-58, src/Smooth/models.py:27-32
  *   gnx_train_cnn         <- Smoother.train(B, y) of CNN_Smoother         src/Smooth/cnn.py:104-118, src/Smooth/models.py:35-42
  *
  * Conventions
@@ -339,6 +340,27 @@ typedef struct gnx_cnn_params {
 } gnx_cnn_params;
 int gnx_train_cnn(gnx_ctx* ctx, const void* B, int32_t b_is_f64, const int32_t* y, int64_t N, int32_t W, int32_t A, int32_t S,
                   const gnx_cnn_params* params, const int64_t* order, float* weight, float* bias, double* loss);
+
+/* ---- training the linear-chain CRF smoother: CRF.fit (src/Smooth/crf.py:51-58: sklearn_crfsuite.CRF(algorithm="lbfgs",
+ *      max_iterations=10000, all_possible_transitions=True, all_possible_states=True)) as Smoother.train calls it for
+ *      CRF_Smoother (src/Smooth/smooth.py:28-38, src/Smooth/models.py:27-32).  Minimises CRFsuite's objective
+ *      f = - sum log p(y | x) + c2 |w|^2 over state (attribute, label) and transition (from, to) weights — the arrays
+ *      gnx_model_desc.crf_state / crf_trans take — by L-BFGS with every evaluation on the device (k_train_crf.hip).
+ *      state / trans (A, A) hold the starting point on entry (CRFsuite starts from zeros) and the fit on return. */
+typedef struct gnx_crf_params {
+  double c1;                 /* 0.0  (L1: only 0 is built) */
+  double c2;                 /* 1.0  (L2, CRFsuite's default) */
+  double epsilon;            /* 1e-8: stop when |g| / max(1, |w|) < epsilon (CRFsuite: 1e-5) */
+  int32_t max_iterations;    /* 10000 (crf.py:7) */
+  int32_t memory;            /* 10: L-BFGS pairs kept (CRFsuite: 6) */
+} gnx_crf_params;
+typedef struct gnx_crf_info {
+  int32_t iterations, evaluations;
+  double objective, grad_norm;
+  int32_t converged, reserved;
+} gnx_crf_info;
+int gnx_train_crf(gnx_ctx* ctx, const void* B, int32_t b_is_f64, const int32_t* y, int64_t N, int32_t W, int32_t A,
+                  const gnx_crf_params* params, double* state, double* trans, gnx_crf_info* info);
 
 /* ---- one isotonic map of the calibrator: Calibrator.fit (src/Smooth/Calibration.py:43-55) fits, per class i,
  *      sklearn IsotonicRegression(out_of_bounds='clip') on (proba[:, i], y == class i) with float32 probabilities.

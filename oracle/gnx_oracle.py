@@ -276,6 +276,51 @@ def smooth_cnn(B, weight, bias):
     return proba, labels
 
 
+def crf_objective(B, y, state, trans, c2=1.0):
+    """CRFsuite's training objective for the reference's CRF smoother (src/Smooth/crf.py:9-15, 51-54: lbfgs, c1 = 0, c2 = 1,
+    all possible state and transition features; CRFsuite crf1d_encode.c / train_lbfgs.c restated, log-space forward-backward):
+        f = - sum_n log p(y_n | x_n) + c2 |w|^2,   score(y | x) = sum_t sum_a state[a][y_t] x[t][a] + sum_{t>=1} trans[y_{t-1}][y_t]
+    -> f, df/dstate (A, A) [attribute][label], df/dtrans (A, A) [from][to]; float64.  The model is the one smooth_crf evaluates."""
+    from scipy.special import logsumexp
+    X = np.asarray(B, dtype=np.float64)
+    y = np.asarray(y).astype(np.int64)
+    state = np.asarray(state, dtype=np.float64)
+    trans = np.asarray(trans, dtype=np.float64)
+    N, W, A = X.shape
+    s = X @ state                                                     # (N, W, A) state scores
+    la = np.empty_like(s)
+    lb = np.zeros_like(s)
+    la[:, 0] = s[:, 0]
+    for t in range(1, W):
+        la[:, t] = s[:, t] + logsumexp(la[:, t - 1][:, :, None] + trans[None], axis=1)
+    for t in range(W - 2, -1, -1):
+        lb[:, t] = logsumexp(trans[None] + (s[:, t + 1] + lb[:, t + 1])[:, None, :], axis=2)
+    logz = logsumexp(la[:, W - 1], axis=1)
+    score = np.take_along_axis(s, y[:, :, None], axis=2)[:, :, 0].sum(1) + trans[y[:, :-1], y[:, 1:]].sum(1)
+    marg = np.exp(la + lb - logz[:, None, None])
+    onehot = (np.arange(A)[None, None, :] == y[:, :, None]).astype(np.float64)
+    g_state = np.einsum("nta,ntl->al", X, marg - onehot)
+    g_trans = np.zeros((A, A))
+    for t in range(1, W):
+        g_trans += np.exp(la[:, t - 1][:, :, None] + trans[None] + (s[:, t] + lb[:, t])[:, None, :] - logz[:, None, None]).sum(0)
+    np.subtract.at(g_trans, (y[:, :-1].ravel(), y[:, 1:].ravel()), 1.0)
+    f = float(np.sum(logz - score) + c2 * (np.sum(state * state) + np.sum(trans * trans)))
+    return f, g_state + 2.0 * c2 * state, g_trans + 2.0 * c2 * trans
+
+
+def crf_fit(B, y, c2=1.0, gtol=1e-10, max_iterations=10000):
+    """the minimiser of crf_objective from zeros (CRFsuite's starting point) by scipy's L-BFGS-B run to a tight gradient tolerance:
+    an optimiser that shares nothing with the device's -> state, trans, f"""
+    from scipy.optimize import minimize
+    A = np.asarray(B).shape[2]
+
+    def fg(w):
+        f, gs, gt = crf_objective(B, y, w[:A * A].reshape(A, A), w[A * A:].reshape(A, A), c2)
+        return f, np.concatenate([gs.ravel(), gt.ravel()])
+    r = minimize(fg, np.zeros(2 * A * A), jac=True, method="L-BFGS-B", options=dict(maxiter=max_iterations, maxfun=10 * max_iterations, gtol=gtol, ftol=1e-16, maxcor=20))
+    return r.x[:A * A].reshape(A, A), r.x[A * A:].reshape(A, A), float(r.fun)
+
+
 def cnn_fit(B, y, weight, bias, epochs, batch=128, order=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, log_eps=1e-8):
     """CNN.fit (reference src/Smooth/cnn.py:104-118) restated in float32 numpy: Conv1d(A, A, S, zero padding (S-1)//2)
     (cnn.py:37-39; zero padding: see smooth_cnn / tests/golden/make_golden.py G11), loss = NLLLoss(log(softmax + 1e-8), y) with

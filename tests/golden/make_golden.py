@@ -641,7 +641,8 @@ def make_G13(out):
         state[int(attr), int(label)] = w
     for (y0, y1), w in crf.transition_features_.items():
         trans[int(y0), int(y1)] = w
-    np.savez_compressed(out, A=A, W=W, B=Bq, proba=np.asarray(proba, dtype=np.float64), state=state, trans=trans,
+    # Bt / yt = the training set: the fit itself is the pin of the trainer (gnx_train_crf, tests/test_pins_thirdparty.py)
+    np.savez_compressed(out, A=A, W=W, B=Bq, proba=np.asarray(proba, dtype=np.float64), state=state, trans=trans, Bt=B, yt=y.astype(np.int32),
                         via_reference=via_ref, version=np.array(getattr(sklearn_crfsuite, "__version__", "?")))
     print("G13 crf marginals", np.asarray(proba).shape)
     return True

@@ -235,7 +235,8 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     import subprocess
     from gnomix_amd import _lib
     structs = {"gnx_model_desc": _lib.ModelDesc, "gnx_svc_window": _lib.SvcWindow, "gnx_model_info": _lib.ModelInfo,
-               "gnx_vcf_info": _lib.VcfInfo, "gnx_train_info": _lib.TrainInfo}
+               "gnx_vcf_info": _lib.VcfInfo, "gnx_train_info": _lib.TrainInfo, "gnx_cnn_params": _lib.CnnParams,
+               "gnx_crf_params": _lib.CrfParams, "gnx_crf_info": _lib.CrfInfo}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "gnomix_hip.h"', '#include "gnomix_io.h"', 'int main(void) {']
     for cname, ct in structs.items():
         src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

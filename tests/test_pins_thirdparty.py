@@ -86,6 +86,25 @@ def check_crf_smoother(O, g, hip=None):
         assert np.array_equal(lh, np.argmax(ref, -1))
 
 
+def check_crf_trainer(O, g, hip=None):
+    """G13's training set: CRFsuite's own fit (libLBFGS stopped at its epsilon / delta / max_iterations) against the oracle's
+    objective and the minimiser the oracle (and the device) find: never worse than CRFsuite's, and as close as CRFsuite's
+    stopping error allows"""
+    if "Bt" not in g.files:
+        pytest.skip("G13 was generated before the training set was recorded: regenerate it")
+    Bt, yt = g["Bt"], g["yt"]
+    f_ref = O.crf_objective(Bt, yt, g["state"], g["trans"])[0]
+    st, tr, f = O.crf_fit(Bt, yt)
+    assert f <= f_ref * (1 + 1e-12)
+    assert (f_ref - f) / f_ref < 1e-3
+    assert np.max(np.abs(st - g["state"])) < 5e-2 and np.max(np.abs(tr - g["trans"])) < 5e-2
+    if hip is not None:
+        from gnomix_amd.train import train_crf_arrays
+        sd, td, info = train_crf_arrays(Bt, yt)
+        assert info["converged"] and info["objective"] <= f_ref * (1 + 1e-12)
+        assert np.max(np.abs(sd - st)) < 1e-5 and np.max(np.abs(td - tr)) < 1e-5
+
+
 def check_xgb_base(O, g, hip=None):
     """G14: per-window XGBClassifier(missing=2) — multi:softprob (A = 3) and binary:logistic (A = 2)"""
     from gnomix_amd import convert, refpickle
@@ -122,6 +141,10 @@ def test_pin_G13_crfsuite_smoother_vs_oracle(oracle):
     check_crf_smoother(oracle, _load("G13_crf_smoother.npz"))
 
 
+def test_pin_G13_crfsuite_fit_vs_oracle(oracle):
+    check_crf_trainer(oracle, _load("G13_crf_smoother.npz"))
+
+
 def test_pin_G14_xgboost_base_vs_oracle(oracle):
     check_xgb_base(oracle, _load("G14_xgb_base.npz"))
 
@@ -130,6 +153,12 @@ def test_pin_G14_xgboost_base_vs_oracle(oracle):
 def test_pin_G12_xgboost_smoother_vs_hip(oracle):
     import gnomix_amd
     check_xgb_smoother(oracle, _load("G12_xgb_smoother.npz"), hip=gnomix_amd)
+
+
+@pytest.mark.gpu
+def test_pin_G13_crfsuite_fit_vs_hip(oracle):
+    import gnomix_amd
+    check_crf_trainer(oracle, _load("G13_crf_smoother.npz"), hip=gnomix_amd)
 
 
 @pytest.mark.gpu
