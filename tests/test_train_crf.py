@@ -117,3 +117,49 @@ def test_train_crf_rejects_bad_arguments():
     st = np.zeros((3, 3)); tr = np.zeros((3, 3))
     rc = ctx.lib.gnx_train_crf(ctx.h, B.ctypes.data, 1, y.ctypes.data, 4, 10, 3, C.byref(P), st.ctypes.data, tr.ctypes.data, None)
     assert rc != 0 and b"c1" in ctx.lib.gnx_last_error(ctx.h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["crf", "cnn"])
+def test_gnomix_train_end_to_end_fast_and_large_modes(kind):
+    """Gnomix.train (src/model.py:104-167) with the smoothers of the reference's "fast" (CRF) and "large" (CNN) modes: logistic base on
+    train1, smoother on the base's probabilities of train2, base again on everything — all on the device; the smoother beats its
+    base on held-out admixed haplotypes, and the trained model survives save / load"""
+    import os
+    import tempfile
+    import gnomix_amd as ga
+    from gnomix_amd.train import cnn_init
+    A, M, W, S = 3, 40, 30, 7
+    C = M * W + 13
+    rng = np.random.RandomState(4)
+    freq = np.clip(rng.uniform(0.2, 0.8, size=(1, C)) + rng.normal(0, 0.13, size=(A, C)), 0.02, 0.98)
+
+    def haplotypes(n, seed):
+        r = np.random.RandomState(seed)
+        y = np.zeros((n, W), np.int32)
+        for i in range(n):
+            cuts = np.sort(r.choice(np.arange(3, W - 3), size=2, replace=False))
+            a = r.randint(A)
+            for lo, hi in zip([0, *cuts], [*cuts, W]):
+                y[i, lo:hi] = a
+                a = (a + 1 + r.randint(A - 1)) % A
+        ysnp = np.concatenate([np.repeat(y, M, axis=1), np.repeat(y[:, -1:], C - M * W, axis=1)], axis=1)
+        X = (r.uniform(size=(n, C)) < freq[ysnp, np.arange(C)[None, :]]).astype(np.int8)
+        return X, y
+
+    t1, t2, v = haplotypes(120, 1), haplotypes(80, 2), haplotypes(40, 3)
+    d = ga.GnxModelData(C=C, M=M, A=A, S=S, context=M // 2, smooth_kind=kind)
+    d.base_kind, d.lr_coef, d.lr_intercept = "logistic", np.zeros((W, A, M + 2 * (M // 2) + C - M * W)), np.zeros((W, A))
+    if kind == "crf":
+        d.crf_state, d.crf_trans = np.zeros((A, A)), np.zeros((A, A))
+        kw = {}
+    else:
+        d.cnn_weight, d.cnn_bias = cnn_init(A, S, seed=0)
+        kw = dict(max_ep=150, seed=1)
+    g = ga.HipGnomix(d)
+    g.train((t1, t2, v), **kw)
+    assert g.accuracies["smooth_val_acc"] > 80 and g.accuracies["smooth_val_acc"] > g.accuracies["base_val_acc"] + 3, g.accuracies
+    assert g.predict(v[0]).shape == v[1].shape
+    with tempfile.TemporaryDirectory() as td:
+        g2 = ga.HipGnomix.load(g.save(os.path.join(td, "trained.gnx")))
+        assert np.array_equal(g2.predict(v[0][:10]), g.predict(v[0][:10]))
