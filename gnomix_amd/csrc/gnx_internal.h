@@ -365,6 +365,31 @@ int gnx_fail(gnx_ctx* ctx, int code, const std::string& msg);
 int gnx_ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes);
 int gnx_pipe_init(gnx_ctx* ctx);
 
+// model preparation (gnx_model_build.hip), called by gnx_model_load
+int gnx_build_lr(gnx_model* m, const gnx_model_desc* d);
+int gnx_build_covrsk(gnx_model* m, const gnx_model_desc* d);
+int gnx_build_forest(gnx_model* m, const gnx_model_desc* d);
+int gnx_build_rforest(gnx_model* m, const gnx_model_desc* d);
+int gnx_build_xgb(gnx_model* m, const gnx_model_desc* d);
+int gnx_build_crf(gnx_model* m, const gnx_model_desc* d);
+
+// a host vector as a device array owned by the model (freed with it), followed by pad_bytes + 16 zero bytes
+template <typename T>
+inline int gnx_dev_upload(gnx_model* m, const std::vector<T>& h, const T** out, size_t pad_bytes = 0) {
+  gnx_ctx* ctx = m->ctx;
+  void* p = nullptr;
+  const size_t bytes = h.size() * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes + pad_bytes + 16);
+  if (e != hipSuccess) return gnx_fail(ctx, GNX_ENOMEM, std::string("hipMalloc model: ") + hipGetErrorString(e));
+  m->dev_allocs.push_back(p);
+  m->info.device_bytes += (int64_t)(bytes + pad_bytes + 16);
+  if (bytes && (e = hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess) return gnx_fail(ctx, GNX_EHIP, std::string("hipMemcpy model: ") + hipGetErrorString(e));
+  if ((e = hipMemset((char*)p + bytes, 0, pad_bytes + 16)) != hipSuccess) return gnx_fail(ctx, GNX_EHIP, std::string("hipMemset model: ") + hipGetErrorString(e));
+  *out = (const T*)p;
+  return GNX_OK;
+}
+
+
 // kernel launchers (defined in the .hip files)
 hipError_t gnx_launch_gt2_to_x(const uint8_t* G, int64_t V, int64_t ldg, int64_t n0, int64_t N, const int32_t* src, int64_t C,
                                int8_t* X, int64_t ldx, hipStream_t s);
