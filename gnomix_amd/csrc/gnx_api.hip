@@ -98,6 +98,7 @@ static void read_tune(gnx_tune& t) {
   if (const char* e = std::getenv("GNX_LR_TUNE")) std::sscanf(e, "%d,%d", &t.lr_mt, &t.lr_waves);
   t.lr_flags = geti("GNX_LR_FLAGS", 0);
   t.lr_dl = geti("GNX_LR_DL", -1);
+  t.lr_flat = geti("GNX_LR_FLAT", -1);
   t.lr_ws = geti("GNX_LR_WS", 0);
   t.lr_w512 = geti("GNX_LR_W512", 0);
   t.lr_ws_pw = geti("GNX_LR_WS_PW", 2);
@@ -387,6 +388,7 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     const bool dl = ctx->tune.lr_dl < 0 ? m->lr.NT >= 2 : ctx->tune.lr_dl != 0;
     hipError_t e = ctx->tune.lr_ws ? gnx_launch_base_logistic_i8_ws(L, ctx->n_cu, ctx->tune, ctx->stream) : hipErrorNotSupported;
     if (e == hipErrorNotSupported && ctx->tune.lr_w512) e = gnx_launch_base_logistic_i8_w512(L, ctx->n_cu, ctx->tune, ctx->stream);
+    if (e == hipErrorNotSupported && ctx->tune.lr_flat > 0 && m->lr.V8F) e = gnx_launch_base_logistic_i8_fl(L, ctx->n_cu, ctx->tune, ctx->stream);
     if (e == hipErrorNotSupported && dl) e = gnx_launch_base_logistic_i8_dl(L, ctx->n_cu, ctx->tune, ctx->stream);
     if (e == hipErrorNotSupported) e = gnx_launch_base_logistic_i8(L, ctx->n_cu, ctx->tune, ctx->stream);  // > 2 column tiles
     HIPCHK(ctx, e);

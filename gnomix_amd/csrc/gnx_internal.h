@@ -31,6 +31,7 @@ struct gnx_tune {
                                         // column tiles (A > 8 at the default context), where it measured 2.5 vs 3.1 ms (A = 12,
                                         // chr22); with one column tile both kernels run at the same 1.14-1.16 ms
   int lr_nbuf = 0;                      // GNX_LR_NBUF: ring slots of the LDS-direct kernel
+  int lr_flat = -1;                     // GNX_LR_FLAT: 1 = flat column tiles (k_base_logistic_i8_fl) wherever built, 0 = never
   int lr_w512 = 0;                      // GNX_LR_W512=1: 512 rows per block, 64-SNP steps (k_base_logistic_i8_w512)
   int lr_ws = 0, lr_ws_pw = 2;          // GNX_LR_WS=1: wave-specialised kernel (k_base_logistic_i8_ws); GNX_LR_WS_PW: producer waves (2, 4)
   int sm_nw = 0;                        // GNX_SM_NW: waves per block of the rank smoother
@@ -94,6 +95,7 @@ struct gnx_ctx {
 struct BaseLRDev {
   const double* V = nullptr;        // f64 path: [n_chunks][16 steps][NT][64 lanes]
   const int8_t* V8 = nullptr;       // i8 path: [n_chunks][NT][7 limbs][64 lanes][16 bytes] balanced base-256 digits
+  const int8_t* V8F = nullptr;      // i8 path, flat column tiles (k_base_logistic_i8_fl): [n_chunks][NF][64 lanes][16 bytes], column q = slot * 7 + limb
   const double* wscale = nullptr;   // i8 path: [W] 2^-f_w
   const double* icpt = nullptr;     // [W][A]
   const int32_t* chunk_j0 = nullptr;     // [n_chunks] first real SNP of the chunk
@@ -104,6 +106,7 @@ struct BaseLRDev {
   int32_t n_chunks = 0;
   int32_t R = 0;   // windows simultaneously active = column slots
   int32_t NT = 0;  // 16-column tiles
+  int32_t NF = 0;  // flat column tiles of V8F (0: not built)
   int32_t max_piece_chunks = 0;  // longest piece, in chunks
 };
 
@@ -400,6 +403,7 @@ hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, const gn
 hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_w512(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_ws(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_launch_base_logistic_i8_fl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_h64(const SmoothXGBLaunch& L, uint16_t* Rk, const gnx_tune& tune, hipStream_t s);

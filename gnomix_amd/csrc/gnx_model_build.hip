@@ -159,6 +159,23 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
             }
           }
     if ((rc = gnx_dev_upload(m, V8, &m->lr.V8, 64)) != GNX_OK) return rc;
+    // flat column tiles for k_base_logistic_i8_fl: column q = slot * 7 + limb, ceil(NC * 7 / 16) tiles instead of NT * 7
+    // (A = 12 at the default context: 11 instead of 14); an experiment that measured slower (see the kernel's header): built only
+    // when GNX_LR_FLAT=1 asks for it at model load
+    const int NF = (int)((NC * 7 + 15) / 16);
+    if (NF < NT * 7 && NF >= 8 && NF <= 11 && A <= 16 && std::getenv("GNX_LR_FLAT") && std::atoi(std::getenv("GNX_LR_FLAT")) > 0) {
+      std::vector<int8_t> V8F(n_chunks * (size_t)NF * 64 * 16, 0);
+      for (size_t c = 0; c < n_chunks; ++c)
+        for (int ft = 0; ft < NF; ++ft)
+          for (int ln = 0; ln < 64; ++ln) {
+            const int q = ft * 16 + (ln & 15), slot = q / 7, l = q - 7 * slot;
+            if (slot >= NC) continue;
+            const int8_t* src = &V8[(((c * NT + (size_t)(slot / 16)) * 7 + (size_t)l) * 64 + (size_t)((ln & ~15) + slot % 16)) * 16];
+            std::copy(src, src + 16, &V8F[((c * NF + (size_t)ft) * 64 + (size_t)ln) * 16]);
+          }
+      if ((rc = gnx_dev_upload(m, V8F, &m->lr.V8F, 64)) != GNX_OK) return rc;
+      m->lr.NF = NF;
+    }
     if ((rc = gnx_dev_upload(m, wscale, &m->lr.wscale)) != GNX_OK) return rc;
   } else if ((rc = gnx_dev_upload(m, V, &m->lr.V)) != GNX_OK) return rc;
   if ((rc = gnx_dev_upload(m, icpt, &m->lr.icpt)) != GNX_OK) return rc;

@@ -40,7 +40,7 @@ def _lr_data(ga, C, M, A, ctx, seed):
 
 
 # ---------------------------------------------------------------- logistic base ------------------
-@pytest.fixture(params=["i8", "i8dl", "i8ws", "i8w512", "f64"])
+@pytest.fixture(params=["i8", "i8dl", "i8fl", "i8ws", "i8w512", "f64"])
 def lr_impl(request, monkeypatch):
     """every variant of the logistic pass on every geometry: exact int8-limb fixed point with register-staged loads
     (k_base_logistic_i8), the same arithmetic with LDS-direct loads (k_base_logistic_i8_dl), with LDS-direct loads issued by
@@ -49,6 +49,7 @@ def lr_impl(request, monkeypatch):
     from gnomix_amd import _lib
     monkeypatch.setenv("GNX_BASE_LR_IMPL", "f64" if request.param == "f64" else "i8")
     monkeypatch.setenv("GNX_LR_DL", "1" if request.param == "i8dl" else "0")
+    monkeypatch.setenv("GNX_LR_FLAT", "1" if request.param == "i8fl" else "0")      # flat column tiles where the model has them (8..13 tiles)
     monkeypatch.setenv("GNX_LR_WS", "1" if request.param == "i8ws" else "0")
     monkeypatch.setenv("GNX_LR_W512", "1" if request.param == "i8w512" else "0")   # 512 rows per block, 64-SNP steps
     return _lib.Context(0)
@@ -83,7 +84,9 @@ def test_base_golden_G15_binary(ga, lr_impl):
     (4037, 100, 7, 0, 5),        # no context
     (2531, 100, 3, 30, 70),      # ratio 0.3: windows end mid-piece
     (1999, 64, 2, 32, 130),      # M multiple of 64
-    (3001, 100, 12, 50, 33),     # A=12: 24 columns -> 2 MFMA column tiles
+    (3001, 100, 12, 50, 33),     # A=12: 24 columns -> 2 MFMA column tiles (flat: 11 tiles instead of 14)
+    (2201, 100, 9, 50, 600),     # A=9: 18 slots -> 8 flat tiles instead of 14; more rows than one block
+    (1801, 60, 7, 45, 50),       # ratio 0.75: R = 3 windows per SNP, 21 slots -> 10 flat tiles
     (1503, 100, 16, 50, 9),      # A=16
     (2777, 100, 5, 120, 40),     # ratio 1.2: 4 windows per SNP, left/right reflection reaches window 1
     (1237, 50, 7, 25, 600),      # more haplotypes than one 64-row wave tile; exercises MT=4 kernels
