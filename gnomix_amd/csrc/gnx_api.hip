@@ -114,7 +114,6 @@ static void read_tune(gnx_tune& t) {
   t.forest_halves = geti("GNX_FOREST_H", 0);
   t.forest_flags = geti("GNX_FOREST_FLAGS", 0);
   t.forest_impl = geti("GNX_FOREST_IMPL", 0);
-  t.forest_skew = geti("GNX_FOREST_SKEW", -1);
   if (const char* e = std::getenv("GNX_HOST_BATCH")) t.host_batch = std::atoll(e);
   t.h2d_overlap = geti("GNX_H2D_OVERLAP", 1);
   t.debug = std::getenv("GNX_DEBUG") ? atoi(std::getenv("GNX_DEBUG")) : 0;

@@ -44,7 +44,6 @@ struct gnx_tune {
   int forest_halves = 0;                // GNX_FOREST_H=1: one wave group per tile (default: two for the boosted-tree base)
   int forest_impl = 0;                  // GNX_FOREST_IMPL=1: k_base_forest (256-haplotype tile, register prefetch) for the boosted-tree
                                         // base too; default 2: k_base_forest2 (two blocks per CU) wherever its tile fits
-  int forest_skew = -1;                 // GNX_FOREST_SKEW: k_base_forest2's phase skew in s_sleep(127) units (-1: built-in)
   int forest_flags = 0;                 // GNX_FOREST_FLAGS: ablation (1 = no walks, 2 = no register prefetch, 4 = no incremental staging)
   int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
   int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points
@@ -335,7 +334,6 @@ struct ForestLaunch {
   const double* rf_leafval;  // non-NULL selects the random-forest kernel
   float* b32;
   double* b64;
-  int32_t n_cu, skew;        // k_base_forest2 (set by its launcher): CU count, start delay of the second block of a CU's pair (s_sleep 127 units)
 };
 
 struct gnx_model {

@@ -252,8 +252,6 @@ hipError_t launch_range2(ForestLaunch L, const uint32_t* nodes2, int w_first, in
   L.n_windows = n_windows;
   L.ring = gnx_forest_ring_words(width);
   L.flags = tune.forest_flags;
-  L.n_cu = std::max(n_cu, 1);
-  L.skew = tune.forest_skew >= 0 ? tune.forest_skew : 4;  // ~14 us at 2.4 GHz: one staging phase of a 128-haplotype tile
   const size_t lds = gnx_forest2_lds_bytes(L.A, L.ring, L.max_trees, L.D);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(4 * WPS2) / NWV2));
