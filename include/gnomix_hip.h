@@ -300,7 +300,9 @@ int gnx_train_logistic_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ld
  * oracle's bit for bit).  xgboost itself is a third-party fitter outside the reference tree: this entry point reproduces the
  * algorithm the call asks for, not xgboost's floating-point trajectory.
  *   B (N, W, A) base probabilities (what Base.predict_proba returned for the smoother's training haplotypes), float32 or float64
- *   y (N, W) int32 labels in [0, A);  W >= 2 S, S odd
+ *   y (N, W) int32 labels in [0, A);  W >= 2 S, S odd.  gnx_train_gbt rejects labels outside the range; gnx_train_gbt_dev (arrays
+ *     already in HBM) does not read them back to check: a row whose label is outside [0, A) counts as belonging to no class
+ *     (labels are only ever compared, never used as an index)
  *   outputs (HOST, caller-allocated): tree_off[T+1], tree_class[T], left / right / feat (int32) and cond (float32) with room for
  *     (2^(max_depth+1) - 1) T nodes (63 T at the limit max_depth = 5), T = n_rounds * A — exactly the arrays gnx_model_desc takes (a leaf has left = right = -1 and its value in cond;
  *     tree t belongs to class t % A); *n_nodes = nodes written; loss[n_rounds + 1] (optional) = mean log loss before each round
