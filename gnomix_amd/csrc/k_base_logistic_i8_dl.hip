@@ -191,7 +191,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8_dl(BaseLRLaunch
                 for (int r = 0; r < 4; ++r) acc[mt][nt][l][r] = mine ? 0 : acc[mt][nt][l][r];
             }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zb is wave-private: LDS ops of one wave complete in order
-          if (w >= wa && w < wb) {
+          if (w >= wa && w < wb && (L.flags & 8)) {
+            // ABLATION (GNX_LR_FLAGS=8, timing only): raw logits (z + intercept) instead of probabilities, i.e. the flush without
+            // its float64 exps and divisions.  A = 12, chr22: 2.24 -> 2.05 ms — the epilogue's arithmetic is 8 % of this kernel;
+            // moving it into the next kernel's pre-pass would move ~1 ms of VALU work per 25 000 chr1 haplotypes with it
+            const int ne = MT * 16 * A;
+            const double* ic = tab_ic + (w - wt0) * A;
+            for (int e = lane; e < ne; e += 64) {
+              const int rl = e / A, a = e - rl * A;
+              const int64_t n = n0 + rl;
+              if (n < L.N) {
+                const size_t o = ((size_t)n * W + w) * A + a;
+                if (L.b64) L.b64[o] = zb[e] + ic[a];
+                if (L.b32) L.b32[o] = (float)(zb[e] + ic[a]);
+              }
+            }
+          } else if (w >= wa && w < wb) {
             // sigmoid, normaliser and division for the wave's MT*16 rows x A classes, spread over ALL 64 lanes (one lane per
             // row left half the wave idle through 7 double-precision exps and divisions); per element the arithmetic and
             // the class order of the row sum are unchanged
@@ -248,6 +263,7 @@ size_t lds_need(int A, int max_chunks, int max_wins) {
 template <int MT, int NT, int WAVES, int NBUF>
 hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   BaseLRLaunch P = L;
+  P.flags = L.flags | (tune.lr_flags & 8);  // bit 3: ablation, raw logits instead of probabilities (GNX_LR_FLAGS=8, timing only)
   const int haps_per_block = WAVES * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
   // window ranges: a multiple of 8 (one XCD each), ~4 blocks per CU in total; more (shorter) ranges if the per-block tables
