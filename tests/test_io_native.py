@@ -101,9 +101,13 @@ def test_reader_equals_python_mirror(tmp_path, case, container):
     assert not G[:, used:].any() and (gt.shape[1] % 4 == 0 or not (G[:, used - 1] >> (2 * (gt.shape[1] % 4))).any())
 
 
-def test_reader_fast_path_takes_plain_gt_files(tmp_path):
+@pytest.mark.parametrize("simd", ["scalar", "avx2", "avx512"])
+def test_reader_fast_path_takes_plain_gt_files(tmp_path, monkeypatch, simd):
+    """the fixed-width genotype path in its three widths (GNX_IO_SIMD narrows the choice; a CPU without the wider unit runs the next
+    one down): sample counts around the 8- and 16-sample steps and their tails"""
+    monkeypatch.setenv("GNX_IO_SIMD", simd)
     rng = np.random.default_rng(5)
-    for ns in (1, 2, 7, 8, 9, 15, 16, 17, 40, 41):
+    for ns in (1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 40, 41, 64, 65, 130):
         p = str(tmp_path / f"f{ns}.vcf")
         open(p, "w").write(_vcf_text(rng, 50, ns, unphased=0.0))
         a = vcfio.read_vcf(p, n_threads=2)
