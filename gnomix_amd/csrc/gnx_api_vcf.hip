@@ -19,12 +19,10 @@ static void* alloc_plain(void*, size_t bytes) { return malloc(bytes); }
 static void free_plain(void*, void* p) { free(p); }
 static void* alloc_pinned(void* user, size_t bytes) {
   gnx_ctx* ctx = (gnx_ctx*)user;
-  void* p = nullptr;
   if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-  return p;
+  return gnx_pin_alloc(bytes);  // (released buffers of the same size are reused: gnx_api.hip)
 }
-static void free_pinned(void*, void* p) { (void)hipHostFree(p); }
+static void free_pinned(void*, void* p) { gnx_pin_free(p); }
 
 int gnx_vcf_read(gnx_ctx* ctx, const char* path, const char* region, int n_threads, gnx_vcf** out) {
   if (ctx && ctx->usable) {

@@ -365,6 +365,8 @@ struct gnx_model {
 int gnx_fail(gnx_ctx* ctx, int code, const std::string& msg);
 int gnx_ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes);
 int gnx_pipe_init(gnx_ctx* ctx);
+void* gnx_pin_alloc(size_t bytes);  // page-locked host memory through the process-wide reuse list (gnx_api.hip); NULL on failure
+void gnx_pin_free(void* p);
 
 // model preparation (gnx_model_build.hip), called by gnx_model_load
 int gnx_build_lr(gnx_model* m, const gnx_model_desc* d);
