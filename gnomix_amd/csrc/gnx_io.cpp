@@ -181,6 +181,105 @@ static inline char* put_int(char* o, int64_t v) {
   return r.ptr;
 }
 
+// ---- float32 -> the shortest decimal that reads back as the same float (then the closest one, then the even one): Schubfach
+// (R. Giulietti, "The Schubfach way to render doubles", 2020), binary32 instance.  v = c * 2^q -> f * 10^e in a few 64-bit
+// multiplications and no loop; the same digits numpy's Dragon4 "unique" mode and Ryu print (tests: millions of values against numpy).
+// kG1[k + 31] = floor(10^k * 2^-r) >> 63 with r = floor(log2 10^k) - 125, k = -31 .. 45 (126-bit constants, upper 63 bits).
+static const uint64_t kG1[77] = {
+    0x40e7599625a1fe7aull, 0x51212ffbaf0a7e18ull, 0x65697bfa9acd1d9full, 0x7ec3daf941806506ull,
+    0x4f3a68dbc8f03f24ull, 0x63090312bb2c4eedull, 0x7bcb43d769f762a8ull, 0x4d5f0a66a23a9da9ull,
+    0x60b6cd004ac94513ull, 0x78e480405d7b9658ull, 0x4b8ed0283a6d3df7ull, 0x5e72843249088d75ull,
+    0x760f253edb4ab0d2ull, 0x49c97747490eae83ull, 0x5c3bd5191b525a24ull, 0x734aca5f6226f0adull,
+    0x480ebe7b9d58566cull, 0x5a126e1a84ae6c07ull, 0x709709a125da0709ull, 0x465e6604b7a84465ull,
+    0x57f5ff85e592557full, 0x6df37f675ef6eadfull, 0x44b82fa09b5a52cbull, 0x55e63b88c230e77eull,
+    0x6b5fca6af2bd215eull, 0x431bde82d7b634daull, 0x53e2d6238da3c211ull, 0x68db8bac710cb295ull,
+    0x4189374bc6a7ef9dull, 0x51eb851eb851eb85ull, 0x6666666666666666ull, 0x4000000000000000ull,
+    0x5000000000000000ull, 0x6400000000000000ull, 0x7d00000000000000ull, 0x4e20000000000000ull,
+    0x61a8000000000000ull, 0x7a12000000000000ull, 0x4c4b400000000000ull, 0x5f5e100000000000ull,
+    0x7735940000000000ull, 0x4a817c8000000000ull, 0x5d21dba000000000ull, 0x746a528800000000ull,
+    0x48c2739500000000ull, 0x5af3107a40000000ull, 0x71afd498d0000000ull, 0x470de4df82000000ull,
+    0x58d15e1762800000ull, 0x6f05b59d3b200000ull, 0x4563918244f40000ull, 0x56bc75e2d6310000ull,
+    0x6c6b935b8bbd4000ull, 0x43c33c1937564800ull, 0x54b40b1f852bda00ull, 0x69e10de76676d080ull,
+    0x422ca8b0a00a4250ull, 0x52b7d2dcc80cd2e4ull, 0x6765c793fa10079dull, 0x409f9cbc7c4a04c2ull,
+    0x50c783eb9b5c85f2ull, 0x64f964e68233a76full, 0x7e37be2022c0914bull, 0x4ee2d6d415b85aceull,
+    0x629b8c891b267182ull, 0x7b426fab61f00de3ull, 0x4d0985cb1d3608aeull, 0x604be73de4838ad9ull,
+    0x785ee10d5da46d90ull, 0x4b3b4ca85a86c47aull, 0x5e0a1fd271287598ull, 0x758ca7c70d7292feull,
+    0x4977e8dc68679bdfull, 0x5bd5e313828182d6ull, 0x72cb5bd86321e38cull, 0x47bf19673df52e37ull,
+    0x59aedfc10d7279c5ull,
+};
+static inline int64_t sf_flog10pow2(int64_t e) { return (e * 661971961083LL) >> 41; }
+static inline int64_t sf_flog10_three_quarters_pow2(int64_t e) { return (e * 661971961083LL - 274743187321LL) >> 41; }
+static inline int64_t sf_flog2pow10(int64_t e) { return (e * 913124641741LL) >> 38; }
+static inline uint32_t sf_rop(uint64_t g, uint64_t cp) {
+  const uint64_t x1 = (uint64_t)(((unsigned __int128)g * cp) >> 64);
+  return (uint32_t)((x1 >> 31) | (((x1 & 0xffffffffull) + 0xffffffffull) >> 32));
+}
+// bits of a positive, finite, non-zero float -> f (no trailing zeros), e: the value prints as the digits of f times 10^e
+static inline void f32_shortest(uint32_t bits, uint32_t& f_out, int& e_out) {
+  const uint32_t t = bits & 0x7fffffu, bq = bits >> 23;
+  const int64_t q = bq ? (int64_t)bq - 150 : -149;
+  const uint64_t c = bq ? (0x800000u | t) : t;
+  const uint32_t out = (uint32_t)(c & 1);
+  const uint64_t cb = c << 2, cbr = cb + 2;
+  uint64_t cbl;
+  int64_t k;
+  if (c != 0x800000u || q == -149) {
+    cbl = cb - 2;
+    k = sf_flog10pow2(q);
+  } else {  // a power of two: the gap below is half the gap above
+    cbl = cb - 1;
+    k = sf_flog10_three_quarters_pow2(q);
+  }
+  const int h = (int)(q + sf_flog2pow10(-k) + 33);
+  const uint64_t g = kG1[-k + 31] + 1;
+  const uint32_t vb = sf_rop(g, cb << h), vbl = sf_rop(g, cbl << h), vbr = sf_rop(g, cbr << h);
+  const uint32_t s = vb >> 2;
+  uint32_t f;
+  bool done = false;
+  if (s >= 100) {
+    const uint32_t sp10 = 10 * (s / 10), tp10 = sp10 + 10;
+    const bool upin = vbl + out <= (sp10 << 2), wpin = (tp10 << 2) + out <= vbr;
+    if (upin != wpin) {
+      f = upin ? sp10 : tp10;
+      done = true;
+    }
+  }
+  if (!done) {
+    const uint32_t t1 = s + 1;
+    const bool uin = vbl + out <= (s << 2), win = (t1 << 2) + out <= vbr;
+    if (uin != win) f = uin ? s : t1;
+    else {
+      const int32_t cmp = (int32_t)vb - (int32_t)((s + t1) << 1);
+      f = (cmp < 0 || (cmp == 0 && (s & 1) == 0)) ? s : t1;
+    }
+  }
+  int e = (int)k;
+  while (f % 10 == 0) {  // f > 0
+    f /= 10;
+    ++e;
+  }
+  f_out = f;
+  e_out = e;
+}
+
+// decimal digits of f (1 <= f < 10^9) into d (16 bytes are the caller's), two at a time from the end; returns their number
+static const char kD2[] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263"
+    "646566676869707172737475767778798081828384858687888990919293949596979899";
+static inline int f32_digits(uint32_t f, char* d) {
+  const int nd = f >= 100000000u ? 9 : f >= 10000000u ? 8 : f >= 1000000u ? 7 : f >= 100000u ? 6 : f >= 10000u ? 5 : f >= 1000u ? 4 : f >= 100u ? 3 : f >= 10u ? 2 : 1;
+  char* p = d + nd;
+  while (f >= 100) {
+    const uint32_t r = f % 100;
+    f /= 100;
+    p -= 2;
+    memcpy(p, kD2 + 2 * r, 2);
+  }
+  if (f >= 10) memcpy(p - 2, kD2 + 2 * f, 2);
+  else p[-1] = (char)('0' + f);
+  return nd;
+}
+
 // numpy's str() of a float scalar (scalartypes.c.src: *_either): shortest round-trip digits (Dragon4, unique mode = what
 // Ryu's shortest gives), positional when 1e-4 <= |x| < 1e16 (at least one digit after the point), else scientific with a
 // two-digit exponent.  Writes at most 32 characters, returns the end.
@@ -203,22 +302,35 @@ static inline char* put_float(char* o, T v) {
     memcpy(o, "0.0", 3);
     return o + 3;
   }
-  char sc[40];
-  auto r = std::to_chars(sc, sc + 40, v, std::chars_format::scientific);  // d[.ddd]e[+-]XX
-  // digits
+  // digits dig[0 .. k) and the exponent e of the first one (d.ddd x 10^e)
   char dig[24];
-  int k = 0;
-  const char* p = sc;
-  while (p < r.ptr && *p != 'e') {
-    if (*p != '.') dig[k++] = *p;
+  int k = 0, e = 0;
+  if constexpr (sizeof(T) == 4) {
+    uint32_t bits, f;
+    memcpy(&bits, &v, 4);
+    int e10;
+    f32_shortest(bits, f, e10);
+    k = f32_digits(f, dig);
+    e = e10 + k - 1;
+    if (e < 0 && e >= -4 && v >= 1e-4f && (double)v >= 1e-4) {  // 1e-4 <= v < 1 (numpy's rule reads the VALUE, not the digits: float32(1e-4) prints 1e-04): "0." + (-e - 1) zeros + digits — nearly every probability; fixed-size stores only
+      memcpy(o, "0.000000", 8);
+      memcpy(o + 1 - e, dig, 16);  // (the caller's buffer has 32 characters per number)
+      return o + 1 - e + k;
+    }
+  } else {
+    char sc[40];
+    auto r = std::to_chars(sc, sc + 40, v, std::chars_format::scientific);  // d[.ddd]e[+-]XX
+    const char* p = sc;
+    while (p < r.ptr && *p != 'e') {
+      if (*p != '.') dig[k++] = *p;
+      ++p;
+    }
+    ++p;  // 'e'
+    const bool eneg = (*p == '-');
     ++p;
+    while (p < r.ptr) e = e * 10 + (*p++ - '0');
+    if (eneg) e = -e;
   }
-  ++p;  // 'e'
-  const bool eneg = (*p == '-');
-  ++p;
-  int e = 0;
-  while (p < r.ptr) e = e * 10 + (*p++ - '0');
-  if (eneg) e = -e;
   const double av = (double)v;
   if (av >= 1e-4 && av < 1e16) {
     if (e >= 0) {
@@ -401,10 +513,12 @@ extern "C" int gnx_write_fb(const char* path, const char* head, int64_t head_len
                             int is_f64, int64_t N, int64_t W, int64_t A, int n_threads) {
   if (N < 0 || W < 0 || A < 0 || (W > 0 && (!pb || !po)) || (N > 0 && W > 0 && A > 0 && !proba)) return io_fail(GNX_EINVAL, "write_fb: bad arguments");
   const size_t per = is_f64 ? 26 : 17;
+  // (re-laying (N, W, A) window-major first, so that a line reads one contiguous run, was measured: 0.082-0.086 s against 0.074-0.080 s
+  //  for chr22 x 10 000 haplotypes — the strided reads are not what bounds this writer)
   return write_blocks(path, head, head_len, W, gnx_io_stream_threads(n_threads), (W > 0 ? po[W] - po[0] : 0) + W * (N * A * (int64_t)per + 2),
                       [&](int64_t w, std::vector<char>& buf) {
     const size_t plen = (size_t)(po[w + 1] - po[w]);
-    buf.resize(plen + (size_t)N * (size_t)A * per + 2);
+    buf.resize(plen + (size_t)N * (size_t)A * per + 2 + 32);  // + 32: put_float<float> stores 16 digit bytes whatever their number
     char* o = buf.data();
     memcpy(o, pb + po[w], plen);
     o += plen;
@@ -474,7 +588,7 @@ extern "C" int gnx_write_vcf_gt2(const char* path, const char* head, int64_t hea
   return write_blocks(path, head, head_len, (V + kVcfBlock - 1) / kVcfBlock, gnx_io_stream_threads(n_threads), (V > 0 ? po[V] - po[0] : 0) + V * (ns * 4 + 10),
                       [&](int64_t blk, std::vector<char>& buf) {
     const int64_t v0 = blk * kVcfBlock, v1 = std::min(V, v0 + kVcfBlock);
-    buf.resize((size_t)(po[v1] - po[v0]) + (size_t)(v1 - v0) * ((size_t)ns * 4 + 10));
+    buf.resize((size_t)(po[v1] - po[v0]) + (size_t)(v1 - v0) * ((size_t)ns * 4 + 10) + 32);
     char* o = buf.data();
     for (int64_t v = v0; v < v1; ++v) {
       const size_t plen = (size_t)(po[v + 1] - po[v]);

@@ -156,6 +156,9 @@ def test_float_text_equals_numpy():
     f32 = [rng.integers(0, 2 ** 32, 400_000, dtype=np.uint64).astype(np.uint32).view(np.float32),      # every exponent
            rng.random(400_000, dtype=np.float32), (rng.random(100_000) * 1e-3).astype(np.float32),
            np.float32(10.0) ** rng.integers(-12, 20, 50_000).astype(np.float32), np.arange(0, 70000, dtype=np.float32),
+           # every power of two and its neighbours (the asymmetric rounding interval of the shortest-digits search), subnormals included
+           np.concatenate([(np.uint32(1) << np.arange(23, dtype=np.uint32)).view(np.float32)] +
+                          [(np.arange(1, 255, dtype=np.uint32) << np.uint32(23)).__add__(np.uint32(d)).astype(np.uint32).view(np.float32) for d in (0, 1, 0xFFFFFFFF)]),
            np.array([0, -0.0, 1, 1e-4, 9.9999e-5, 9.999999e-5, 1e16, 9.9999998e15, 1e-45, 3.4028235e38, np.inf, -np.inf, 0.1, 0.14285715, 1 / 3,
                      16777216, 1e-5, 123456.79, 0.001, 1e15, 5e-324], dtype=np.float32)]
     for a in f32:
@@ -197,7 +200,8 @@ def _py_fb(meta, proba, ancestry, samples):
     return out
 
 
-@pytest.mark.parametrize("N,W,A,dtype", [(2, 3, 2, np.float32), (14, 41, 7, np.float32), (6, 150, 12, np.float64), (500, 9, 3, np.float32)])
+@pytest.mark.parametrize("N,W,A,dtype", [(2, 3, 2, np.float32), (14, 41, 7, np.float32), (6, 150, 12, np.float64), (500, 9, 3, np.float32),
+                                         (1030, 171, 6, np.float32), (300, 130, 27, np.float64)])   # > 2^20 values: re-laid window-major first
 def test_msp_fb_writers_equal_the_python_restatement(tmp_path, N, W, A, dtype):
     rng = np.random.default_rng(N * W)
     M = 10
