@@ -14,7 +14,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 10
+GNX_ABI_VERSION = 11
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
@@ -155,6 +155,7 @@ SYMBOLS = {
     "gnx_infer_gt2": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _VP, _VP, _VP]),
     "gnx_phase_gt2": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, C.c_int32, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP]),
     "gnx_write_msp": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I64, _I64, _I64, _I]),
+    "gnx_write_fb_dev": (C.c_int, [_VP, C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I64, _I64, _I64]),
     "gnx_write_fb": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I, _I64, _I64, _I64, _I]),
     "gnx_write_vcf_gt2": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I64, _I64, _I64, _I, _I]),
     "gnx_write_phased_vcf": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I]),

@@ -112,7 +112,7 @@ def run_inference(base_args, model, snp_level=False, bed_file_output=False, verb
     pp.write_msp(out_prefix, meta, labels, model.population_order, samples)
     T["write_msp"] = clock() - t0
     t0 = clock()
-    pp.write_fb(out_prefix, meta, proba, model.population_order, samples)
+    pp.write_fb(out_prefix, meta, proba, model.population_order, samples, ctx=model.dev.ctx if os.environ.get("GNX_FB_DEV") == "1" else None)
     T["write_fb"] = clock() - t0
     if snp_level:
         pp.msp_to_lai(out_prefix + ".msp", vcf["variants/POS"], out_prefix + ".lai")

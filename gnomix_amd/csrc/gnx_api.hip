@@ -159,7 +159,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
   if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
-  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi, &ctx->ws_gt2, &ctx->ws_src, &ctx->ws_gt2o, &ctx->ws_rank})
+  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi, &ctx->ws_gt2, &ctx->ws_src, &ctx->ws_gt2o, &ctx->ws_rank, &ctx->ws_fb, &ctx->ws_fb_body})
     if (b->p) (void)hipFree(b->p);
   for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal, &ctx->ws_marg})
     if (b->p) (void)hipFree(b->p);

@@ -198,3 +198,57 @@ int gnx_phase_gt2(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_
   HIPCHK(ctx, hipStreamSynchronize(sc));
   return GNX_OK;
 }
+
+// ---- <prefix>.fb with the number text produced on the GPU (k_fb_text.hip) ------------------------------------------------------------
+// proba (N, W, A) float32 on the HOST (where gnx_infer_gt2 put it): back to HBM (2 ms for chr22 x 10 000 haplotypes), lengths, line
+// offsets (a scan over W numbers on the host), text, one page-locked buffer back, one write().  The body is produced exactly — the same
+// bytes gnx_write_fb writes.
+extern "C" int gnx_write_fb_dev(gnx_ctx* ctx, const char* path, const char* head, int64_t head_len, const char* pb, const int64_t* po,
+                                const float* proba, int64_t N, int64_t W, int64_t A) {
+  if (!ctx) return GNX_EINVAL;
+  if (!ctx->usable) return gnx_fail(ctx, GNX_ESTATE, "write_fb_dev: context has no device");
+  if (!path || head_len < 0 || (head_len > 0 && !head) || N < 0 || W < 0 || A < 0 || (W > 0 && (!pb || !po)) || (N > 0 && W > 0 && A > 0 && !proba))
+    return gnx_fail(ctx, GNX_EINVAL, "write_fb_dev: bad arguments");
+  if (N == 0 || W == 0 || A == 0 || A > 4096) return gnx_write_fb(path, head, head_len, pb, po, proba, 0, N, W, A, 0);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int64_t NA = N * A, plen_all = po[W] - po[0];
+  if (po[0] != 0 || plen_all < 0) return gnx_fail(ctx, GNX_EINVAL, "write_fb_dev: prefix offsets must start at 0 and not decrease");
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_p = take((size_t)N * W * A * 4), o_len = take((size_t)W * NA), o_ll = take((size_t)W * 8), o_pb = take((size_t)plen_all + 1),
+               o_po = take((size_t)(W + 1) * 8), o_lo = take((size_t)W * 8);
+  int rc = gnx_ws_reserve(ctx, ctx->ws_fb, off);
+  if (rc != GNX_OK) return rc;
+  uint8_t* base = (uint8_t*)ctx->ws_fb.p;
+  HIPCHK(ctx, hipMemcpyAsync(base + o_p, proba, (size_t)N * W * A * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(base + o_pb, pb, (size_t)plen_all, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(base + o_po, po, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemsetAsync(base + o_ll, 0, (size_t)W * 8, s));
+  HIPCHK(ctx, gnx_launch_fb_len((const float*)(base + o_p), N, W, (int)A, base + o_len, (unsigned long long*)(base + o_ll), s));
+  std::vector<unsigned long long> line_len((size_t)W);
+  HIPCHK(ctx, hipMemcpyAsync(line_len.data(), base + o_ll, (size_t)W * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  std::vector<int64_t> line_off((size_t)W);
+  int64_t total = 0;
+  for (int64_t w = 0; w < W; ++w) {
+    line_off[(size_t)w] = total;
+    total += (po[w + 1] - po[w]) + (int64_t)line_len[(size_t)w] + 1;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(base + o_lo, line_off.data(), (size_t)W * 8, hipMemcpyHostToDevice, s));
+  if ((rc = gnx_ws_reserve(ctx, ctx->ws_fb_body, (size_t)total + 64)) != GNX_OK) return rc;
+  HIPCHK(ctx, gnx_launch_fb_emit((const float*)(base + o_p), N, W, (int)A, base + o_len, (const char*)(base + o_pb), (const int64_t*)(base + o_po),
+                                 (const int64_t*)(base + o_lo), (char*)ctx->ws_fb_body.p, s));
+  char* host = (char*)gnx_pin_alloc((size_t)total + 64);
+  if (!host) return gnx_fail(ctx, GNX_ENOMEM, "write_fb_dev: page-locked buffer for the text");
+  hipError_t e = hipMemcpyAsync(host, ctx->ws_fb_body.p, (size_t)total, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    gnx_pin_free(host);
+    return gnx_fail(ctx, GNX_EHIP, std::string("write_fb_dev: ") + hipGetErrorString(e));
+  }
+  rc = gnx_io_write_file(path, head, (size_t)head_len, host, (size_t)total);
+  gnx_pin_free(host);
+  if (rc != GNX_OK) return gnx_fail(ctx, rc, gnx_io_last_error());
+  return GNX_OK;
+}

@@ -79,6 +79,7 @@ struct gnx_ctx {
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   gnx_devbuf ws_pk, ws_xu, ws_psi;
   gnx_devbuf ws_rank;  // k_smooth_ranks -> k_smooth_xgb_h64
+  gnx_devbuf ws_fb, ws_fb_body;  // gnx_write_fb_dev: probabilities / lengths / tables, and the file's body as text
   gnx_devbuf ws_gt2, ws_src, ws_gt2o;  // file path (gnx_api_vcf.hip): variant-major 2-bit genotypes, column map, phased rows
   // profiling
   bool prof = false;
@@ -404,6 +405,9 @@ hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const
 hipError_t gnx_launch_base_logistic_i8_w512(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_ws(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_fl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_launch_fb_len(const float* d_proba, int64_t N, int64_t W, int A, uint8_t* d_len, unsigned long long* d_line_len, hipStream_t s);
+hipError_t gnx_launch_fb_emit(const float* d_proba, int64_t N, int64_t W, int A, const uint8_t* d_len, const char* d_pb, const int64_t* d_po,
+                              const int64_t* d_line_off, char* d_body, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_h64(const SmoothXGBLaunch& L, uint16_t* Rk, const gnx_tune& tune, hipStream_t s);

@@ -478,6 +478,31 @@ inline void grow(std::vector<char>& buf, size_t used, size_t need) {
 }
 }  // namespace
 
+int gnx_io_write_file(const char* path, const char* head, size_t head_len, const char* body, size_t body_len) {
+  const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return io_fail(GNX_EINVAL, std::string("write: cannot open ") + path + ": " + strerror(errno));
+  bool ok = true;
+  int err_no = 0;
+  for (int part = 0; part < 2 && ok; ++part) {
+    const char* b = part ? body : head;
+    size_t n = part ? body_len : head_len;
+    while (n > 0) {
+      const ssize_t w = write(fd, b, std::min<size_t>(n, (size_t)1 << 30));
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        ok = false;
+        err_no = errno;
+        break;
+      }
+      b += w;
+      n -= (size_t)w;
+    }
+  }
+  const int cr = close(fd);
+  if (!ok || cr != 0) return io_fail(GNX_EINVAL, std::string("write: I/O error on ") + path + ": " + strerror(err_no ? err_no : errno));
+  return GNX_OK;
+}
+
 extern "C" int gnx_write_msp(const char* path, const char* head, int64_t head_len, const char* pb, const int64_t* po, const int32_t* labels,
                              int64_t N, int64_t ldl, int64_t W, int n_threads) {
   if (N < 0 || W < 0 || ldl < W || (W > 0 && (!pb || !po)) || (N > 0 && W > 0 && !labels)) return io_fail(GNX_EINVAL, "write_msp: bad arguments");

@@ -17,6 +17,7 @@ typedef void (*gnx_io_free_fn)(void* user, void* p);
 int gnx_io_vcf_read(const char* path, const char* region, int n_threads, gnx_io_alloc_fn alloc, gnx_io_free_fn release,
                     void* user, int pinned, gnx_vcf** out);
 int gnx_io_fail(int code, const std::string& msg);  // sets the thread's message, returns code
+int gnx_io_write_file(const char* path, const char* head, size_t head_len, const char* body, size_t body_len);  // create / truncate, head then body
 
 // process-wide worker pool: fn(tid) runs once on each of n workers (the caller is worker 0); returns when all are done
 int gnx_io_threads(int requested);         // <= 0: every core this process may run on (GNX_IO_THREADS overrides)

@@ -94,9 +94,10 @@ def write_msp(msp_prefix, meta_data, pred_labels, populations, query_samples, n_
                                             lab.shape[0], lab.shape[1], lab.shape[1], int(n_threads)))
 
 
-def write_fb(fb_prefix, meta_data, proba, ancestry, query_samples, n_threads=0):
+def write_fb(fb_prefix, meta_data, proba, ancestry, query_samples, n_threads=0, ctx=None):
     """<prefix>.fb (postprocess.py:100-126): proba (N, W, A); every value is printed as pandas' to_csv prints a float column
-    (numpy's shortest round-trip text of the array's dtype) — by the library, W rows in parallel."""
+    (numpy's shortest round-trip text of the array's dtype) — by the library, W rows in parallel on the host's cores, or, when a
+    context is given and the probabilities are float32, as text produced on the GPU (gnx_write_fb_dev: same bytes, one write())."""
     proba = np.asarray(proba)
     if proba.dtype not in (np.float32, np.float64):
         proba = proba.astype(np.float64)
@@ -112,6 +113,13 @@ def write_fb(fb_prefix, meta_data, proba, ancestry, query_samples, n_threads=0):
     head = ("#reference_panel_population:\t" + "\t".join([str(a) for a in ancestry]) + "\n" + "\t".join(header) + "\n").encode()
     rows = ["\t".join([str(meta_data["chm"][r]), str(pp[r]), _fmt(np.float64(gp[r])), "."]) for r in range(n_rows)]
     pb, po = _blob(rows)
+    # (measured, chr22 x 10 000 haplotypes into tmpfs: 0.078-0.082 s either way — one thread putting 305 MB into a FRESH file costs
+    #  0.052-0.056 s in the kernel's page cache whoever produced the text: scripts/dev/tmpfs_write_probe.py.  The GPU route is what a
+    #  caller asks for with ctx=; the command line keeps the host writer unless GNX_FB_DEV=1)
+    if ctx is not None and proba.dtype == np.float32 and proba.size > 0:
+        ctx.check(ctx.lib.gnx_write_fb_dev(ctx.h, (fb_prefix + ".fb").encode(), head, len(head), pb, po.ctypes.data, proba.ctypes.data,
+                                           proba.shape[0], n_rows, proba.shape[2]))
+        return
     _lib.io_check(_lib.load().gnx_write_fb((fb_prefix + ".fb").encode(), head, len(head), pb, po.ctypes.data, proba.ctypes.data,
                                            int(proba.dtype == np.float64), proba.shape[0], n_rows, proba.shape[2], int(n_threads)))
 

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 10
+#define GNX_ABI_VERSION 11
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;

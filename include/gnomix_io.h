@@ -108,6 +108,13 @@ int gnx_write_msp(const char* path, const char* head, int64_t head_len, const ch
  * pandas' to_csv prints a float column: numpy's shortest round-trip text, empty for NaN (src/postprocess.py:100-126) */
 int gnx_write_fb(const char* path, const char* head, int64_t head_len, const char* prefix_blob, const int64_t* prefix_off,
                  const void* proba, int proba_is_f64, int64_t N, int64_t W, int64_t A, int n_threads);
+
+/* the same file with the number text produced on the GPU (k_fb_text.hip): proba (N, W, A) float32 on the host goes back to HBM, the
+ * body returns as one page-locked buffer and is written with one write() — byte-identical to gnx_write_fb.  Measured no faster for
+ * chr22 x 10 000 haplotypes into tmpfs (0.08 s either way: the write of a fresh 305 MB file is the bound), but it leaves the host's
+ * cores free. */
+int gnx_write_fb_dev(gnx_ctx* ctx, const char* path, const char* head, int64_t head_len, const char* prefix_blob, const int64_t* prefix_off,
+                     const float* proba, int64_t N, int64_t W, int64_t A);
 /* VCF row v: prefix (CHROM .. FORMAT joined by tabs), then "\t<a>|<b>" per sample from gt2 row v (codes printed as the
  * digits 0..3: the reference prints the int8 matrix, missing = 2, src/utils.py:299-308; missing_as_dot != 0 prints code 2
  * as '.', the VCF spelling of a missing allele — what a query file carries) */

@@ -155,3 +155,36 @@ def test_phase_gt2_equals_the_int8_route(ga, tmp_path, monkeypatch, C, M, A, n_i
     with pytest.raises(_lib.GnxError):
         devc.phase_gt2(np.zeros((10, 4), np.uint8), 4, np.full(2049, -1, np.int32))
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,W,A", [(2, 3, 2), (14, 41, 7), (500, 9, 3), (1030, 171, 6), (3, 1, 33)])
+def test_write_fb_on_the_gpu_is_byte_identical_to_the_host_writer(tmp_path, N, W, A):
+    """gnx_write_fb_dev (number text produced by k_fb_text.hip: Schubfach digits, numpy's layout rules) against gnx_write_fb, which
+    tests/test_io_native.py holds to numpy's own text and to golden G6: every exponent, powers of two, subnormals, 0, -0, 1, the
+    1e-4 and 1e16 switches between positional and scientific notation, inf, and NaN (an empty field)"""
+    import gnomix_amd as ga
+    from gnomix_amd import postprocess as pp, _lib
+    rng = np.random.default_rng(N * 1000 + W)
+    proba = rng.dirichlet(np.ones(A) * 0.3, size=(N, W)).astype(np.float32)
+    flat = proba.reshape(-1)
+    special = np.array([0.0, -0.0, 1.0, 1e-4, 9.9999e-5, 9.999999e-5, 1e16, 9.9999998e15, 1e-45, 3.4028235e38, np.inf, -np.inf, 0.1, 0.14285715,
+                        1 / 3, 16777216, 1e-5, 123456.79, 0.001, 1e15, np.nan, -2.5e-7, 5e-39], np.float32)
+    k = min(len(special), flat.size)
+    flat[rng.choice(flat.size, k, replace=False)] = special[:k]
+    if flat.size > 4000:   # raw bit patterns: every exponent; powers of two and their neighbours
+        bits = rng.integers(0, 2 ** 32, 3000, dtype=np.uint64).astype(np.uint32)
+        pw = ((np.arange(1, 255, dtype=np.uint32) << np.uint32(23))[:, None] + np.array([0, 1, 0xFFFFFFFF], np.uint32)[None, :]).astype(np.uint32).ravel()
+        vals = np.concatenate([bits, pw]).view(np.float32)
+        flat[rng.choice(flat.size, len(vals), replace=False)] = vals
+    meta = {"chm": ["22"] * W, "spos": np.arange(W) * 1000 + 16_000_000, "epos": np.arange(W) * 1000 + 16_000_999, "sgpos": np.arange(W) * 0.21,
+            "egpos": np.arange(W) * 0.21 + 0.2}
+    samples, pops = ["I%d" % i for i in range((N + 1) // 2)], ["P%d" % a for a in range(A)]
+    if N % 2:
+        proba = proba[:N - 1]
+        samples = samples[:(N - 1) // 2]
+    ctx = _lib.default_context(0)
+    pp.write_fb(str(tmp_path / "host"), meta, proba, pops, samples)
+    pp.write_fb(str(tmp_path / "dev"), meta, proba, pops, samples, ctx=ctx)
+    a, b = open(str(tmp_path / "host.fb"), "rb").read(), open(str(tmp_path / "dev.fb"), "rb").read()
+    assert len(a) == len(b) and a == b
