@@ -427,10 +427,9 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
     L.packed = m->forest.packed; L.win_tree0 = m->forest.win_tree0; L.win_class_tree0 = m->forest.win_class_tree0;
     L.rf_leafval = m->forest.rf_leafval;
     L.b32 = d_b32; L.b64 = d_b64;
-    // boosted trees: the two-blocks-per-CU kernel wherever its 128-haplotype tile fits the LDS; random forest and GNX_FOREST_IMPL=1:
-    // the 256-haplotype kernel
-    const bool v2 = !L.rf_leafval && m->forest.nodes2 && ctx->tune.forest_impl != 1 &&
-                    gnx_forest2_lds_bytes(L.A, gnx_forest_ring_words(L.width_last), L.max_trees, L.D) <= (size_t)160 * 1024;
+    // the two-blocks-per-CU kernel wherever its 128-haplotype tile fits the LDS (both tree bases); GNX_FOREST_IMPL=1: the 256-haplotype kernel
+    const bool v2 = m->forest.nodes2 && ctx->tune.forest_impl != 1 && (!L.rf_leafval || L.A <= 32) &&
+                    gnx_forest2_lds_bytes(L.A, gnx_forest_ring_words(L.width_last), L.max_trees, L.D, L.rf_leafval != nullptr) <= (size_t)160 * 1024;
     if (v2) {
       if (!ctx->s_aux) {  // the one wider last window (a grid of N / 128 blocks) runs beside the main grid on a side stream
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));

@@ -436,7 +436,7 @@ hipError_t gnx_launch_base_forest(const ForestLaunch& L, int n_cu, const gnx_tun
 size_t gnx_forest_lds_bytes(int A, int ring_words, int max_trees, int tree_bytes, int threads);
 hipError_t gnx_launch_base_forest2(const ForestLaunch& L, const uint32_t* nodes2, int n_cu, const gnx_tune& tune, hipStream_t s,
                                    hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
-size_t gnx_forest2_lds_bytes(int A, int ring_words, int max_trees, int D);
+size_t gnx_forest2_lds_bytes(int A, int ring_words, int max_trees, int D, bool rf = false);
 uint32_t gnx_forest2_node(uint32_t loader_word, uint32_t g0, uint32_t ring);
 int gnx_forest_ring_words(int64_t width);
 size_t gnx_smooth_xgb_lds_bytes(const SmoothXGBDev& d, int A, int S);

@@ -682,6 +682,17 @@ int gnx_build_rforest(gnx_model* m, const gnx_model_desc* d) {
   int rc;
   if ((rc = gnx_dev_upload(m, packed, &m->forest.packed, 64)) != GNX_OK) return rc;
   if ((rc = gnx_dev_upload(m, leafval, &m->forest.rf_leafval)) != GNX_OK) return rc;
+  {  // k_base_forest2's node words, baked per window as for the boosted-tree base (a record holds nothing but its 2^D node words)
+    std::vector<uint32_t> nodes2((size_t)d->rf_n_trees << D, 0);
+    for (int64_t w = 0; w < W; ++w) {
+      const uint32_t ring = (uint32_t)gnx_forest_ring_words(w == W - 1 ? M_ + rem : M_), g0 = (uint32_t)((w * M) >> 4);
+      for (int32_t t = d->rf_win_tree0[w]; t < d->rf_win_tree0[w + 1]; ++t) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(packed.data() + (size_t)t * tree_bytes);
+        for (uint32_t j = 1; j < (1u << D); ++j) nodes2[((size_t)t << D) + j] = gnx_forest2_node(src[j], g0, ring);
+      }
+    }
+    if ((rc = gnx_dev_upload(m, nodes2, &m->forest.nodes2, 64)) != GNX_OK) return rc;
+  }
   if ((rc = gnx_dev_upload(m, win_tree0, &m->forest.win_tree0)) != GNX_OK) return rc;
   m->forest.D = D; m->forest.tree_bytes = tree_bytes; m->forest.max_trees = max_trees; m->forest.max_words = max_words;
   return GNX_OK;

@@ -12,8 +12,9 @@
 //   * node words are baked per window at model load (ring slot byte offset << 15 | 2 * field << 4 | right-mask: the word the
 //     walk consumes), a window's nodes are a straight copy.
 //   * four wave groups share a tile and split the classes (margins meet in LDS), group 0 writes the probabilities.
-// The random-forest base keeps k_base_forest.hip (its float64 class rows are summed over ALL trees in estimator order by one
-// lane per haplotype: nothing to split between wave groups).
+// The random-forest base runs here too (RF = true, round 3 close): its float64 class rows are summed in estimator order PER CLASS,
+// so the four wave groups split the classes (each walks all 20 trees: 80 walks per haplotype and window against the boosted
+// base's 140) — 2.84 ms in k_base_forest (one wave per SIMD, 506 VGPRs, nothing busy) -> see the launcher's note.
 #include "gnx_internal.h"
 
 namespace {
@@ -69,13 +70,39 @@ __device__ __forceinline__ void walk2(const uint32_t* nodes, const uint8_t* xcol
   for (int k = 0; k < NT; ++k) leaf[k] = reinterpret_cast<const float*>(rec + (size_t)tk[k] * tree_bytes)[j[k]];  // leaves follow the 2^D node words
 }
 
+// the same walk for the random-forest base: the heap index of the leaf (2^D <= j < 2^(D+1)); its class row lives in global memory
+template <int D, int NT>
+__device__ __forceinline__ void walk2_idx(const uint32_t* nodes, const uint8_t* xcol, int t, int t_last, uint32_t* j) {
+  int tk[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    j[k] = 1;
+    tk[k] = min(t + k, t_last);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    uint32_t nd[NT], xv[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) nd[k] = nodes[(tk[k] << D) + j[k]];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) xv[k] = *reinterpret_cast<const uint32_t*>(xcol + (nd[k] >> 15));
+#pragma unroll
+    for (int k = 0; k < NT; ++k) j[k] = step2(j[k], nd[k], xv[k]);
+  }
+}
+
 __device__ __forceinline__ void window_words2(const ForestLaunch& L, int w, int64_t& g0, int64_t& g1) {
   const int64_t s = (int64_t)w * L.M, width = (w == L.W - 1) ? L.width_last : L.width;
   g0 = s >> 4;
   g1 = ((s + width - 1) >> 4) + 1;
 }
 
-template <int D>
+// RF = true: the random-forest base (RFBase, reference src/Base/models.py:54-66) on the same tile: every wave group walks ALL trees
+// of the window and adds, for ITS classes, the leaf's class-probability row (float64, global memory / L1) in estimator order —
+// the order of ForestClassifier.predict_proba's sums is a per-class matter, so the classes can be split between the groups without
+// changing a bit — the sums meet in LDS (float64 margins) and group 0 divides by the tree count.
+constexpr int CG2 = 8;  // classes a wave group may own (A <= 4 * CG2 = 32)
+template <int D, bool RF>
 // (HIP reads the second launch bound as waves per SIMD: two 8-wave blocks per CU = 4, i.e. at most 128 VGPRs)
 __global__ __launch_bounds__(NTHR2, WPS2) void k_base_forest2(ForestLaunch L, const uint32_t* __restrict__ nodes2) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -172,6 +199,42 @@ __global__ __launch_bounds__(NTHR2, WPS2) void k_base_forest2(ForestLaunch L, co
     const int n_groups = (A == 2) ? 1 : A;
     const int c_lo = (half * n_groups) / H2, c_hi = ((half + 1) * n_groups) / H2;
     const uint8_t* rec0 = L.packed + (size_t)t0 * tree_bytes;
+    if constexpr (RF) {
+      double* margd = reinterpret_cast<double*>(nlds + ((size_t)L.max_trees << D)) + hap;  // [A][T2] float64
+      const int r_lo = (half * A) / H2, r_hi = ((half + 1) * A) / H2;                      // this group's classes
+      double acc[CG2];
+#pragma unroll
+      for (int q = 0; q < CG2; ++q) acc[q] = 0.0;
+      constexpr int TPW = D <= 4 ? TPW2 : (D <= 6 ? TPW2 - 2 : TPW2 - 4);
+      const double* lv0 = L.rf_leafval + (size_t)t0 * ((size_t)A << D) + r_lo;
+      for (int t = 0; t < nt && !(L.flags & 1); t += TPW) {
+        uint32_t jj[TPW];
+        walk2_idx<D, TPW>(nlds, xcol, t, nt - 1, jj);
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+          if (t + k < nt) {
+            const double* v = lv0 + ((size_t)(t + k) * ((size_t)1 << D) + (jj[k] - (1u << D))) * A;
+#pragma unroll
+            for (int q = 0; q < CG2; ++q)
+              if (r_lo + q < r_hi) acc[q] += v[q];  // estimator order, class by class
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CG2; ++q)
+        if (r_lo + q < r_hi) margd[(r_lo + q) * T2] = acc[q];
+      __syncthreads();  // the sums of all classes are in LDS; every lane is done with window w's tile and nodes
+      if (half == 0 && n < L.N) {
+        const size_t o = ((size_t)n * L.W + w) * A;
+        const double cnt = (double)nt;
+        for (int a = 0; a < A; ++a) {
+          const double p = margd[a * T2] / cnt;
+          if (L.b64) L.b64[o + a] = p;
+          if (L.b32) L.b32[o + a] = (float)p;
+        }
+      }
+      continue;  // (the next iteration's first barrier comes after group 0 has read the sums: as for the margins below)
+    }
     for (int c = c_lo; c < c_hi && !(L.flags & 1); ++c) {
       const int a0 = (A == 2) ? 0 : cls0[c], a1 = (A == 2) ? nt : cls0[c + 1];
       constexpr int TPW = D <= 4 ? TPW2 : (D <= 6 ? TPW2 - 2 : TPW2 - 4);
@@ -239,9 +302,15 @@ __global__ __launch_bounds__(NTHR2, WPS2) void k_base_forest2(ForestLaunch L, co
 
 template <int D>
 hipError_t launch2_d(const ForestLaunch& L, const uint32_t* nodes2, size_t lds, hipStream_t s) {
-  GNX_LDS_OPTIN(lds, k_base_forest2<D>);
   const int n_runs = (L.n_windows + L.wrun - 1) / L.wrun;
-  hipLaunchKernelGGL((k_base_forest2<D>), dim3((unsigned)((L.N + T2 - 1) / T2), (unsigned)n_runs), dim3(NTHR2), lds, s, L, nodes2);
+  const dim3 grid((unsigned)((L.N + T2 - 1) / T2), (unsigned)n_runs);
+  if (L.rf_leafval) {
+    GNX_LDS_OPTIN(lds, k_base_forest2<D, true>);
+    hipLaunchKernelGGL((k_base_forest2<D, true>), grid, dim3(NTHR2), lds, s, L, nodes2);
+  } else {
+    GNX_LDS_OPTIN(lds, k_base_forest2<D, false>);
+    hipLaunchKernelGGL((k_base_forest2<D, false>), grid, dim3(NTHR2), lds, s, L, nodes2);
+  }
   return hipGetLastError();
 }
 
@@ -252,8 +321,8 @@ hipError_t launch_range2(ForestLaunch L, const uint32_t* nodes2, int w_first, in
   L.n_windows = n_windows;
   L.ring = gnx_forest_ring_words(width);
   L.flags = tune.forest_flags;
-  const size_t lds = gnx_forest2_lds_bytes(L.A, L.ring, L.max_trees, L.D);
-  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  const size_t lds = gnx_forest2_lds_bytes(L.A, L.ring, L.max_trees, L.D, L.rf_leafval != nullptr);
+  if (lds > (size_t)160 * 1024 || (L.rf_leafval && L.A > H2 * CG2)) return hipErrorInvalidValue;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(4 * WPS2) / NWV2));
   // windows per block: as k_base_forest — long runs re-use the shared half of every window (the first window of a run is staged
   // in full: about two window-steps), short runs fill the chip; blocks run in rounds of per_cu per CU
@@ -283,8 +352,8 @@ hipError_t launch_range2(ForestLaunch L, const uint32_t* nodes2, int w_first, in
 
 }  // namespace
 
-size_t gnx_forest2_lds_bytes(int A, int ring_words, int max_trees, int D) {
-  return (size_t)ring_words * T2 * 4 + (((size_t)max_trees << D) * 4 + 15 & ~(size_t)15) + (size_t)A * T2 * 4;
+size_t gnx_forest2_lds_bytes(int A, int ring_words, int max_trees, int D, bool rf) {  // rf: float64 class sums instead of float32 margins
+  return (size_t)ring_words * T2 * 4 + (((size_t)max_trees << D) * 4 + 15 & ~(size_t)15) + (size_t)A * T2 * (rf ? 8 : 4);
 }
 
 // node word of k_base_forest2 for a loader word (position << 4 | left-mask) of a window whose first word is g0, in a ring of
