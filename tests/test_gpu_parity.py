@@ -606,6 +606,15 @@ def _forest_oracle_trees(O, d):
                    default_left=d.fb_default_left)
 
 
+@pytest.fixture(params=["forest2", "forest1"])
+def forest_ctx(request, monkeypatch):
+    """both tree-base kernels on every geometry: k_base_forest2 (two blocks per CU: the default wherever its tile fits) and
+    k_base_forest (256-haplotype tile: the fallback, GNX_FOREST_IMPL=1).  The knob is read once per context."""
+    from gnomix_amd import _lib
+    monkeypatch.setenv("GNX_FOREST_IMPL", "1" if request.param == "forest1" else "0")
+    return _lib.Context(0)
+
+
 @pytest.mark.parametrize("C,M,A,ctx,N,rounds,depth", [
     (4037, 100, 7, 50, 70, 20, 4),     # the reference's XGBBase shape: 20 rounds, depth 4, A trees per round
     (4037, 100, 2, 50, 33, 20, 4),     # A == 2: binary:logistic, one tree per round
@@ -614,11 +623,11 @@ def _forest_oracle_trees(O, d):
     (937, 300, 12, 150, 1, 7, 1),      # stumps ("forest-of-stumps"), 3 windows, a single haplotype
     (1237, 48, 5, 24, 129, 4, 3),      # M multiple of 16: window starts on word boundaries
 ])
-def test_forest_base_vs_oracle(ga, oracle, C, M, A, ctx, N, rounds, depth):
+def test_forest_base_vs_oracle(ga, oracle, forest_ctx, C, M, A, ctx, N, rounds, depth):
     from gnomix_amd import synth
     d = synth.synthetic_forest_model(C, M, A, context=ctx, n_rounds=rounds, depth=depth, seed=C + A, p_early_leaf=0.2)
     X = synth.synthetic_X(N, C, seed=N + 1, miss=0.08)
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=forest_ctx)
     b32, b64 = dev.base_predict(X, want_f32=True, want_f64=True)
     ref = oracle.base_forest(_forest_oracle_trees(oracle, d), d.fb_win_tree0, X, M, ctx, A, missing=2)
     _close_f32(b32, ref)
@@ -626,7 +635,7 @@ def test_forest_base_vs_oracle(ga, oracle, C, M, A, ctx, N, rounds, depth):
     # the missing code matters: flipping every default direction must change some outputs
     d2 = synth.synthetic_forest_model(C, M, A, context=ctx, n_rounds=rounds, depth=depth, seed=C + A, p_early_leaf=0.2)
     d2.fb_default_left = 1 - d2.fb_default_left
-    b32b, _ = ga.DeviceModel(d2).base_predict(X, want_f32=True, want_f64=False)
+    b32b, _ = ga.DeviceModel(d2, ctx=forest_ctx).base_predict(X, want_f32=True, want_f64=False)
     ref2 = oracle.base_forest(_forest_oracle_trees(oracle, d2), d2.fb_win_tree0, X, M, ctx, A, missing=2)
     _close_f32(b32b, ref2)
     assert not np.array_equal(ref, ref2)
@@ -728,12 +737,12 @@ def _rf_dict(d):
     return {k[3:]: getattr(d, k) for k in ("rf_win_tree0", "rf_tree_off", "rf_left", "rf_right", "rf_feat", "rf_thr", "rf_value")}
 
 
-def test_rforest_base_golden_G9(ga, oracle):
+def test_rforest_base_golden_G9(ga, oracle, forest_ctx):
     """k_base_rforest against the REFERENCE's RFBase.predict_proba output (sklearn forests): bit-exact float64"""
     g = load_golden("G9_rf.npz")
     d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=int(g["A"]), S=5, context=int(g["ctx"]), base_kind="rforest",
                         **{k: g[k] for k in g.files if k.startswith("rf_")})
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=forest_ctx)
     b32, b64 = dev.base_predict(g["X"], want_f32=True, want_f64=True)
     assert np.array_equal(b64, g["B"])
     assert np.array_equal(b32, g["B"].astype(np.float32))
@@ -747,11 +756,11 @@ def test_rforest_base_golden_G9(ga, oracle):
     (937, 300, 20, 150, 1, 3, 1),       # stumps, A > 16, a single haplotype
     (1237, 48, 2, 24, 129, 9, 3),
 ])
-def test_rforest_base_vs_oracle(ga, oracle, C, M, A, ctx, N, trees, depth):
+def test_rforest_base_vs_oracle(ga, oracle, forest_ctx, C, M, A, ctx, N, trees, depth):
     from gnomix_amd import synth
     d = synth.synthetic_rforest_model(C, M, A, context=ctx, n_trees=trees, depth=depth, seed=C + A, p_early_leaf=0.2)
     X = synth.synthetic_X(N, C, seed=N + 2, miss=0.08)
-    b32, b64 = ga.DeviceModel(d).base_predict(X, want_f32=True, want_f64=True)
+    b32, b64 = ga.DeviceModel(d, ctx=forest_ctx).base_predict(X, want_f32=True, want_f64=True)
     ref = oracle.base_rforest(_rf_dict(d), X, M, ctx, A)
     assert np.array_equal(b64, ref)
     assert np.array_equal(b32, ref.astype(np.float32))
