@@ -169,6 +169,24 @@ __device__ __forceinline__ int put_f32(float v, char* o) {
   return (int)(o - o0);
 }
 
+// the length put_f32 would write, without writing (no per-thread character buffer: k_fb_len stays free of scratch)
+__device__ __forceinline__ int len_f32(float v) {
+  if (v != v) return 0;
+  uint32_t bits = __float_as_uint(v);
+  const int sign = (int)(bits >> 31);
+  bits &= 0x7fffffffu;
+  if (bits == 0x7f800000u || bits == 0) return sign + 3;
+  uint32_t f;
+  int e10;
+  f32_shortest(bits, f, e10);
+  const int k = f >= 100000000u ? 9 : f >= 10000000u ? 8 : f >= 1000000u ? 7 : f >= 100000u ? 6 : f >= 10000u ? 5 : f >= 1000u ? 4 : f >= 100u ? 3 : f >= 10u ? 2 : 1;
+  const int e = e10 + k - 1;
+  const double av = (double)__uint_as_float(bits);
+  if (av >= 1e-4 && av < 1e16) return sign + (e >= 0 ? (k <= e + 1 ? e + 3 : k + 1) : 1 - e + k);
+  const int ae = e < 0 ? -e : e;
+  return sign + k + (k > 1 ? 1 : 0) + 2 + (ae >= 100 ? 3 : 2);
+}
+
 // value (w, i = n * A + a) of proba (N, W, A)
 __device__ __forceinline__ float fb_value(const float* __restrict__ proba, int64_t W, int A, int64_t w, int64_t i) {
   const int64_t n = i / A;
@@ -183,8 +201,7 @@ __global__ __launch_bounds__(256) void k_fb_len(const float* __restrict__ proba,
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int l = 0;
   if (i < NA) {
-    char tmp[20];
-    l = 1 + put_f32(fb_value(proba, W, A, w, i), tmp);
+    l = 1 + len_f32(fb_value(proba, W, A, w, i));
     len[(size_t)w * NA + i] = (uint8_t)l;
   }
   __shared__ int red[256];
