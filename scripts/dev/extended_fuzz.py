@@ -49,5 +49,46 @@ for seed in range(lo, hi):
         bad += 1
         print("FAIL gbt", seed, dict(N=N, W=W, A=A, S=S), kw); traceback.print_exc(limit=2)
 print("gbt trainer vs oracle ok", ok)
-print("failures:", bad)
+
+# the CNN and CRF smoother trainers against the oracle's restatements on random small problems
+ok = 0
+for seed in range(lo, min(hi, lo + 120)):
+    r = np.random.RandomState(seed)
+    A, S, W, N = int(r.randint(2, 14)), int(2 * r.randint(0, 12) + 1), int(r.randint(1, 80)), int(r.randint(1, 90))
+    batch, ep = int(r.randint(1, N + 5)), int(r.randint(1, 5))
+    y = r.randint(A, size=(N, W)).astype(np.int32)
+    B = r.dirichlet(np.ones(A) * 0.5, size=(N, W)).astype(np.float32)
+    w0, b0 = train.cnn_init(A, S, seed=seed)
+    order = np.stack([r.permutation(N) for _ in range(ep)])
+    try:
+        w, b, loss = train.train_cnn_arrays(B, y, S, weight=w0, bias=b0, max_ep=ep, batch_size=batch, order=order)
+        wo, bo, lo_ = O.cnn_fit(B, y, w0, b0, ep, batch=batch, order=order)
+        assert np.abs(w - wo).max() < 1e-5 and np.abs(b - bo).max() < 1e-5 and np.allclose(loss, lo_, rtol=0, atol=1e-5)
+        ok += 1
+    except Exception:
+        bad += 1
+        print("FAIL cnn trainer", seed, (A, S, W, N, batch, ep)); traceback.print_exc(limit=3)
+print("cnn trainer vs oracle ok", ok)
+ok = 0
+for seed in range(lo, min(hi, lo + 60)):
+    r = np.random.RandomState(seed)
+    A, W, N = int(r.randint(2, 13)), int(r.randint(1, 60)), int(r.randint(1, 40))
+    y = r.randint(A, size=(N, W)).astype(np.int32)
+    B = r.dirichlet(np.ones(A) * 0.5, size=(N, W))
+    st0, tr0 = r.normal(0, 0.5, (A, A)), r.normal(0, 0.5, (A, A))
+    try:
+        _, _, info = train.train_crf_arrays(B, y, max_iterations=0, state0=st0, trans0=tr0)
+        f, gs, gt = O.crf_objective(B, y, st0, tr0)
+        gn = np.sqrt(np.sum(gs * gs) + np.sum(gt * gt))
+        assert abs(info["objective"] - f) <= 1e-10 * max(1.0, abs(f)) and abs(info["grad_norm"] - gn) <= 1e-9 * max(1.0, gn)
+        st, tr, info = train.train_crf_arrays(B, y)
+        _, gs, gt = O.crf_objective(B, y, st, tr)
+        assert info["converged"] and max(np.abs(gs).max(), np.abs(gt).max()) < 1e-6
+        ok += 1
+    except Exception:
+        bad += 1
+        print("FAIL crf trainer", seed, (A, W, N)); traceback.print_exc(limit=3)
+print("crf trainer vs oracle ok", ok)
+print("failures (all families):", bad)
+
 sys.exit(1 if bad else 0)
