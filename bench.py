@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline core-seconds budget scale (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="host-pointer (PCIe-inclusive) passes at N=1 (0 = skip)")
-    ap.add_argument("--vcf-reps", type=int, default=3, help="file-to-file passes (VCF text in, .msp/.fb out) at N=1 (0 = skip)")
+    ap.add_argument("--vcf-reps", type=int, default=5, help="file-to-file passes (VCF text in, .msp/.fb out) at N=1 (0 = skip)")
     ap.add_argument("--vcf-dir", default="", help="where the synthetic VCF and the outputs go (default: /dev/shm when it has room, else a temp dir)")
     ap.add_argument("--seed", type=int, default=94305)
     args = ap.parse_args()
