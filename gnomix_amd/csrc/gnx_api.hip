@@ -117,6 +117,8 @@ static void read_tune(gnx_tune& t) {
   if (const char* e = std::getenv("GNX_HOST_BATCH")) t.host_batch = std::atoll(e);
   t.h2d_overlap = geti("GNX_H2D_OVERLAP", 1);
   t.debug = std::getenv("GNX_DEBUG") ? atoi(std::getenv("GNX_DEBUG")) : 0;
+  if (const char* e = std::getenv("GNX_GNOFIX_IMPL")) t.gnofix_impl = std::string(e) == "f32" ? 1 : 0;
+  t.gnofix_threads = geti("GNX_GNOFIX_T", 0);
 }
 
 extern "C" {
@@ -461,9 +463,12 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
   ProfScope ps(ctx, GNX_K_BASE_LOGISTIC);
   if (m->lr_i8) {
     const bool dl = ctx->tune.lr_dl < 0 ? m->lr.NT >= 2 : ctx->tune.lr_dl != 0;
-    hipError_t e = ctx->tune.lr_ws ? gnx_launch_base_logistic_i8_ws(L, ctx->n_cu, ctx->tune, ctx->stream) : hipErrorNotSupported;
+    hipError_t e = hipErrorNotSupported;
+#ifdef GNX_EXPERIMENTS  // make EXPERIMENTS=1: the measured-slower structures of DESIGN.md 5.2 (scripts/dev/rejected/)
+    if (ctx->tune.lr_ws) e = gnx_launch_base_logistic_i8_ws(L, ctx->n_cu, ctx->tune, ctx->stream);
     if (e == hipErrorNotSupported && ctx->tune.lr_w512) e = gnx_launch_base_logistic_i8_w512(L, ctx->n_cu, ctx->tune, ctx->stream);
     if (e == hipErrorNotSupported && ctx->tune.lr_flat > 0 && m->lr.V8F) e = gnx_launch_base_logistic_i8_fl(L, ctx->n_cu, ctx->tune, ctx->stream);
+#endif
     if (e == hipErrorNotSupported && dl) e = gnx_launch_base_logistic_i8_dl(L, ctx->n_cu, ctx->tune, ctx->stream);
     if (e == hipErrorNotSupported) e = gnx_launch_base_logistic_i8(L, ctx->n_cu, ctx->tune, ctx->stream);  // > 2 column tiles
     HIPCHK(ctx, e);
@@ -513,18 +518,27 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     L.B = dB; L.b_is_f64 = b_is_f64; L.N = N;
     L.W = (int32_t)m->info.W; L.A = m->info.A; L.S = m->info.S;
     L.d = m->xgb; L.proba = d_p32; L.proba64 = d_p64; L.labels = d_lab;
+#ifdef GNX_EXPERIMENTS
     const bool h64 = m->xgb.rk_packed && m->xgb.impl == 2 && gnx_smooth_h64_waves(m->xgb, m->info.A, m->info.S) > 0;
     if (m->xgb.impl == 2 && !h64) return fail(ctx, GNX_EUNSUPPORTED, "GNX_SMOOTH_IMPL=h64: the model's strip does not fit the LDS");
+#else
+    [[maybe_unused]] constexpr bool h64 = false;
+#endif
     if (m->xgb.rk_packed) {
       const size_t n_pad = (size_t)((N + 63) / 64 * 64) * m->info.W * m->info.A;   // h64 parks whole 64-haplotype lines
       int rc = ws_reserve(ctx, ctx->ws_marg, n_pad * sizeof(float));
       if (rc != GNX_OK) return rc;
       L.marg = (float*)ctx->ws_marg.p;
+#ifdef GNX_EXPERIMENTS
       if (h64 && (rc = ws_reserve(ctx, ctx->ws_rank, gnx_smooth_h64_rank_bytes(N, L.W, L.A, L.S))) != GNX_OK) return rc;
+#endif
     }
     ProfScope ps(ctx, GNX_K_SMOOTH_XGB);
+#ifdef GNX_EXPERIMENTS
     if (h64) HIPCHK(ctx, gnx_launch_smooth_xgb_h64(L, (uint16_t*)ctx->ws_rank.p, ctx->tune, ctx->stream));
-    else if (m->xgb.rk_packed) HIPCHK(ctx, gnx_launch_smooth_xgb_rk(L, ctx->tune, ctx->stream));
+    else
+#endif
+    if (m->xgb.rk_packed) HIPCHK(ctx, gnx_launch_smooth_xgb_rk(L, ctx->tune, ctx->stream));
     else HIPCHK(ctx, gnx_launch_smooth_xgb(L, ctx->tune, ctx->stream));
     return GNX_OK;
   }
@@ -866,6 +880,16 @@ int gnx_calibrate_rows(gnx_model* m, const void* proba, int proba_is_f64, int64_
   return GNX_OK;
 }
 
+// which Gnofix kernel a model runs: the rank-strip kernel (k_gnofix.hip) wherever the smoother has a rank copy, else (or with
+// GNX_GNOFIX_IMPL=f32) the float32-strip kernel of rounds 1-3 (k_gnofix_f32.hip)
+static bool gnofix_use_rk(const gnx_model* m) {
+  return m->xgb.gf_packed && m->xgb.rk_thr && m->ctx->tune.gnofix_impl != 1 && m->info.C < ((int64_t)1 << 31);
+}
+static int gnofix_threads(const gnx_model* m) {
+  const int t = m->ctx->tune.gnofix_threads;
+  return (t == 256 || t == 512 || t == 1024) ? t : 512;
+}
+
 static int gnofix_check(gnx_model* m, int64_t ldx, int64_t n_ind, int32_t max_it, bool ptrs_ok, bool* in_lds) {
   gnx_ctx* ctx = m->ctx;
   // src/model.py:194: only a smoother with .gnofix == True (XGB_Smoother) supports re-phasing
@@ -875,24 +899,40 @@ static int gnofix_check(gnx_model* m, int64_t ldx, int64_t n_ind, int32_t max_it
   if (m->calibrate_on && m->calib_off)  // smoother.predict inside the loop would be calibrated (gnofix.py:80,190); the kernel's is not
     return fail(ctx, GNX_EUNSUPPORTED, "gnofix with calibrate=True is not built: switch calibration off for re-phasing");
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
-  *in_lds = gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, m->xgb.tree_bytes, true) <= 150 * 1024;
-  if (gnx_gnofix_lds_bytes(W, A, S, m->xgb.n_trees, m->xgb.tree_bytes, *in_lds) > 160 * 1024)
+  *in_lds = true;
+  if (gnofix_use_rk(m)) {
+    if (gnx_gnofix_lds_bytes(W, A, S, m->xgb.gf_pitch, gnx_gnofix_cap(m->xgb.gf_max_class, m->xgb.D, S, gnofix_threads(m)), m->xgb.D, gnofix_threads(m), m->xgb.n_trees) > (size_t)160 * 1024)
+      return fail(ctx, GNX_EUNSUPPORTED, "gnofix: W too large for the LDS working set (labels: 2 bytes per window)");
+    return GNX_OK;
+  }
+  *in_lds = gnx_gnofix_f32_lds_bytes(W, A, S, m->xgb.n_trees, m->xgb.tree_bytes, true) <= 150 * 1024;
+  if (gnx_gnofix_f32_lds_bytes(W, A, S, m->xgb.n_trees, m->xgb.tree_bytes, *in_lds) > 160 * 1024)
     return fail(ctx, GNX_EUNSUPPORTED, "gnofix: model too large for the LDS working set (n_trees * 16 B + S*A*8 B)");
   return GNX_OK;
 }
 
-// scratch of one device-resident batch of n individuals (grows only)
-static int gnofix_ws_reserve(gnx_model* m, int64_t n, int32_t max_it, bool in_lds, size_t* bp_off_out) {
+// scratch of one device-resident batch of n individuals (grows only).  ws_misc: [hist | par | dif | ranks] (rank kernel) or
+// [hist | float32 strips] (fallback, strips that do not fit the LDS)
+struct GnofixWs { size_t par = 0, dif = 0, rk = 0, pm = 0, bp = 0; };
+static int gnofix_ws_reserve(gnx_model* m, int64_t n, int32_t max_it, bool in_lds, GnofixWs* out) {
   gnx_ctx* ctx = m->ctx;
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S, pad = (S + 1) / 2;
   const size_t WA = (size_t)W * A, NWD = (size_t)(W + 31) / 32;
   int rc;
   if ((rc = ws_reserve(ctx, ctx->ws_p32, (size_t)2 * n * WA * 4)) != GNX_OK) return rc;
   if ((rc = ws_reserve(ctx, ctx->ws_y0, (size_t)2 * n * W * 4)) != GNX_OK) return rc;
-  size_t misc = (size_t)n * std::max(max_it, 1) * NWD * 4;
-  const size_t bp_off = (misc + 255) & ~(size_t)255;
-  if (!in_lds) misc = bp_off + (size_t)n * 2 * (W + 2 * pad) * A * 4;
-  if (bp_off_out) *bp_off_out = bp_off;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t misc = up((size_t)n * std::max(max_it, 1) * NWD * 4);
+  GnofixWs o;
+  if (gnofix_use_rk(m)) {
+    o.par = misc; misc += up((size_t)n * NWD * 4);
+    o.dif = misc; misc += up((size_t)n * NWD * 4);
+    o.rk = misc; misc += up((size_t)2 * n * WA * 2);
+    o.pm = misc; misc += up((size_t)2 * n * W * 4);
+  } else if (!in_lds) {
+    o.bp = misc; misc += (size_t)n * 2 * (W + 2 * pad) * A * 4;
+  }
+  if (out) *out = o;
   return ws_reserve(ctx, ctx->ws_misc, misc + 256);
 }
 
@@ -902,8 +942,8 @@ static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* d
   gnx_ctx* ctx = m->ctx;
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
   int rc;
-  size_t bp_off = 0;
-  if ((rc = gnofix_ws_reserve(m, n, max_it, in_lds, &bp_off)) != GNX_OK) return rc;
+  GnofixWs ws;
+  if ((rc = gnofix_ws_reserve(m, n, max_it, in_lds, &ws)) != GNX_OK) return rc;
   int32_t* dY0 = (int32_t*)ctx->ws_y0.p;
   // initial labels = smoother.predict(B) for every haplotype at once (gnofix.py:80)
   rc = gnx_smooth_predict_dev(m, dB, 1, 2 * n, (float*)ctx->ws_p32.p, nullptr, dY0);
@@ -911,11 +951,19 @@ static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* d
   GnofixLaunch L{};
   L.X = dX; L.ldx = ldx; L.C = m->info.C; L.B = dB; L.Y0 = dY0; L.Yout = dY; L.n_switches = dNs;
   L.W = W; L.A = A; L.S = S; L.max_it = max_it; L.d = m->xgb; L.class_tree0 = m->class_tree0;
-  L.bp_in_lds = in_lds ? 1 : 0;
   L.hist = (uint32_t*)ctx->ws_misc.p;
-  L.bp_scratch = in_lds ? nullptr : (float*)((char*)ctx->ws_misc.p + bp_off);
   ProfScope ps(ctx, GNX_K_GNOFIX);
-  HIPCHK(ctx, gnx_launch_gnofix(L, n, ctx->stream));
+  if (gnofix_use_rk(m)) {
+    char* base = (char*)ctx->ws_misc.p;
+    L.proba0 = (const float*)ctx->ws_p32.p; L.pmax0 = (const float*)(base + ws.pm);
+    L.par = (uint32_t*)(base + ws.par); L.dif = (const uint32_t*)(base + ws.dif); L.R = (const uint16_t*)(base + ws.rk);
+    L.gf = m->xgb.gf_packed; L.gf_pitch = m->xgb.gf_pitch; L.gf_cap = gnx_gnofix_cap(m->xgb.gf_max_class, m->xgb.D, S, gnofix_threads(m));
+    HIPCHK(ctx, gnx_launch_gnofix(L, n, gnofix_threads(m), ctx->stream));
+    return GNX_OK;
+  }
+  L.bp_in_lds = in_lds ? 1 : 0;
+  L.bp_scratch = in_lds ? nullptr : (float*)((char*)ctx->ws_misc.p + ws.bp);
+  HIPCHK(ctx, gnx_launch_gnofix_f32(L, n, ctx->stream));
   return GNX_OK;
 }
 

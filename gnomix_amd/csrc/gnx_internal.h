@@ -48,6 +48,8 @@ struct gnx_tune {
   int64_t host_batch = 0;               // GNX_HOST_BATCH: haplotypes per staging batch of the host-pointer entry points
   int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points
   int lr_lds_pad = 0, sm_lds_pad = 0;   // GNX_LDS_PAD="lr,sm": extra dynamic LDS bytes (occupancy experiments: scripts/dev/overlap_probe.py)
+  int gnofix_impl = 0;                  // GNX_GNOFIX_IMPL=f32: the float32-strip kernel (k_gnofix_f32) even where the rank kernel runs
+  int gnofix_threads = 0;               // GNX_GNOFIX_T: threads per individual of k_gnofix (192, 256, 384, 512)
   int debug = 0;                        // GNX_DEBUG
 };
 
@@ -165,7 +167,16 @@ struct SmoothXGBDev {
   const int32_t* rp_group_class = nullptr;
   int32_t rp_tree_bytes = 0, rp_n_groups = 0, rp_max_group = 0;
   int32_t impl = 0;                      // 1 rk, 2 h64, 3 rk with pointer nodes (GNX_SMOOTH_IMPL at model load)
+  // rank copy for k_gnofix: per tree 2^D node words (heap order; rank field << 16 | byte offset (a * gf_pitch + s) * 2 of feature
+  // s * A + a in the [class][gf_pitch] u16 tile) followed by 2^D float leaves; class-major tree order (class_tree0)
+  const uint32_t* gf_packed = nullptr;
+  int32_t gf_pitch = 0, gf_max_class = 0;
 };
+
+// 32-bit words per tree of SmoothXGBDev::gf_packed (2^D node words in heap order, slot 0 unused, then 2^D float leaves: the leaf of
+// heap index j is word j) and the zero trees that follow the last one (k_gnofix walks past a lane's range without clamping)
+__host__ __device__ inline int gnx_gf_tree_words(int D) { return 2 << D; }
+constexpr int GNX_GF_PAD_TREES = 24;
 
 constexpr int GNX_RK_RPL_MAX = 6;  // most 64-window segments per strip the rank kernel is instantiated for
 
@@ -289,8 +300,16 @@ struct GnofixLaunch {
   SmoothXGBDev d;
   const int32_t* class_tree0;  // [A+1] tree ranges per class in the packed (class-major) order
   int32_t bp_in_lds;
-  float* bp_scratch;       // [n_ind][2][W+2pad][A] when the strips do not fit LDS
+  float* bp_scratch;       // [n_ind][2][W+2pad][A] when the strips do not fit LDS (k_gnofix_f32 only)
   uint32_t* hist;          // [n_ind][max_it][ceil(W/32)] convergence signatures
+  // k_gnofix (rank strips): scratch of the pre- and post-passes and the tile's tree copy
+  const uint16_t* R;       // [2*n_ind][W][A] ranks of float32(B)
+  const uint32_t* dif;     // [n_ind][ceil(W/32)] "SNP block differs between the two haplotypes"
+  uint32_t* par;           // [n_ind][ceil(W/32)] final switch parity per window
+  const uint32_t* gf;      // SmoothXGBDev::gf_packed
+  const float* proba0;     // (2*n_ind, W, A) probabilities of the initial smoother pass (the labels Y0 come from)
+  const float* pmax0;      // [2*n_ind][W] scratch: their row maxima
+  int32_t gf_pitch, gf_cap;
 };
 
 // ---- calibrator (k_calibrate.hip) -----------------------------------------------------------------------
@@ -402,25 +421,30 @@ hipError_t gnx_launch_x_to_gt2(const int8_t* X, int64_t N, int64_t ldx, int64_t 
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+#ifdef GNX_EXPERIMENTS  // scripts/dev/rejected/ (make EXPERIMENTS=1)
 hipError_t gnx_launch_base_logistic_i8_w512(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_ws(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_fl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+hipError_t gnx_launch_smooth_xgb_h64(const SmoothXGBLaunch& L, uint16_t* Rk, const gnx_tune& tune, hipStream_t s);
+int gnx_smooth_h64_waves(const SmoothXGBDev& d, int A, int S);            // 0: the strip does not fit the LDS
+size_t gnx_smooth_h64_rank_bytes(int64_t N, int W, int A, int S);
+#endif
 hipError_t gnx_launch_fb_len(const float* d_proba, int64_t N, int64_t W, int A, uint8_t* d_len, unsigned long long* d_line_len, hipStream_t s);
 hipError_t gnx_launch_fb_emit(const float* d_proba, int64_t N, int64_t W, int A, const uint8_t* d_len, const char* d_pb, const int64_t* d_po,
                               const int64_t* d_line_off, char* d_body, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
-hipError_t gnx_launch_smooth_xgb_h64(const SmoothXGBLaunch& L, uint16_t* Rk, const gnx_tune& tune, hipStream_t s);
-int gnx_smooth_h64_waves(const SmoothXGBDev& d, int A, int S);            // 0: the strip does not fit the LDS
-size_t gnx_smooth_h64_rank_bytes(int64_t N, int W, int A, int S);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);
 hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwp,
                                 uint32_t* planes, hipStream_t s);
 hipError_t gnx_launch_covrsk(const CovRSKLaunch& L, hipStream_t s);
 size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width);
-hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
-size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, int tree_bytes, bool bp_in_lds);
+hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, int threads, hipStream_t s);
+size_t gnx_gnofix_lds_bytes(int W, int A, int S, int pitch, int cap, int D, int threads, int n_trees);
+int gnx_gnofix_cap(int max_class_trees, int D, int S, int threads);
+hipError_t gnx_launch_gnofix_f32(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
+size_t gnx_gnofix_f32_lds_bytes(int W, int A, int S, int n_trees, int tree_bytes, bool bp_in_lds);
 hipError_t gnx_launch_calibrate(const CalibLaunch& L, hipStream_t s);
 hipError_t gnx_train_lr_run(const int8_t* dX, int64_t N, int64_t ldx, const int32_t* dY, int64_t C, int64_t M, int64_t ctx, int A,
                             double Creg, double tol, int max_newton, int max_cg, double* h_coef, int64_t ldc, double* h_icpt,

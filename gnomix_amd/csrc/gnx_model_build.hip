@@ -159,6 +159,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
             }
           }
     if ((rc = gnx_dev_upload(m, V8, &m->lr.V8, 64)) != GNX_OK) return rc;
+#ifdef GNX_EXPERIMENTS
     // flat column tiles for k_base_logistic_i8_fl: column q = slot * 7 + limb, ceil(NC * 7 / 16) tiles instead of NT * 7
     // (A = 12 at the default context: 11 instead of 14); an experiment that measured slower (see the kernel's header): built only
     // when GNX_LR_FLAT=1 asks for it at model load
@@ -176,6 +177,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
       if ((rc = gnx_dev_upload(m, V8F, &m->lr.V8F, 64)) != GNX_OK) return rc;
       m->lr.NF = NF;
     }
+#endif
     if ((rc = gnx_dev_upload(m, wscale, &m->lr.wscale)) != GNX_OK) return rc;
   } else if ((rc = gnx_dev_upload(m, V, &m->lr.V)) != GNX_OK) return rc;
   if ((rc = gnx_dev_upload(m, icpt, &m->lr.icpt)) != GNX_OK) return rc;
@@ -353,7 +355,26 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
   // measured (chr22, 10 000 haplotypes, MI355X): rk 1.83 ms; h64 2.22 ms + 0.23 ms of rank pre-pass — conflict-free, and slower
   // (DESIGN.md 4.2b): the rank kernel stays the default, h64 is what GNX_SMOOTH_IMPL=h64 selects
   // (round 3, same inputs: rk 1.83 ms, pointer nodes 1.78 ms, bit-identical: default where the shape allows, "rk" = heap-index nodes)
+#ifdef GNX_EXPERIMENTS
   m->xgb.impl = (impl && std::string(impl) == "h64") ? 2 : (impl && std::string(impl) == "rk") ? 1 : 3;
+#else
+  m->xgb.impl = (impl && std::string(impl) == "rk") ? 1 : 3;
+#endif
+  // ---- the same trees for k_gnofix: heap-index nodes whose offsets address a [class][pitch] tile of 2S+2 window positions ----
+  if ((size_t)A * (2 * S + 2) * 2 <= 65535) {
+    const int pitch = 2 * S + 2;
+    const size_t tw = (size_t)gnx_gf_tree_words(D);
+    std::vector<uint32_t> gf((order.size() + GNX_GF_PAD_TREES) * tw, 0u);
+    for (size_t k = 0; k < order.size(); ++k) {
+      uint32_t* tb = gf.data() + k * tw;
+      tree_fill_rk(d, d->tree_off[order[k]], 0, 1, 0, D, U, pitch, tb, reinterpret_cast<float*>(tb + ((size_t)1 << D)));
+    }
+    if ((rc = gnx_dev_upload(m, gf, &m->xgb.gf_packed, 64)) != GNX_OK) return rc;
+    std::vector<int> cnt(A, 0);
+    int mc = 0;
+    for (size_t k = 0; k < order.size(); ++k) mc = std::max(mc, ++cnt[d->tree_class[order[k]]]);
+    m->xgb.gf_pitch = pitch; m->xgb.gf_max_class = mc;
+  }
   // ---- the same trees with pointer nodes (k_smooth_xgb_rk<.., PTR>): the walk keeps the ADDRESS of its node, no heap index ---
   if (D >= 2 && D <= 6) {
     const int tbp = 12 << D;
@@ -392,6 +413,7 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
     if ((rc = gnx_dev_upload(m, gp_class, &m->xgb.rp_group_class)) != GNX_OK) return rc;
     m->xgb.rp_tree_bytes = tbp; m->xgb.rp_n_groups = (int32_t)gp_class.size(); m->xgb.rp_max_group = Gp;
   }
+#ifdef GNX_EXPERIMENTS
   // ---- the same trees for k_smooth_xgb_h64 (lane = haplotype): pointer nodes whose w0 carries the feature's SLOT s * A + a --------
   if (D >= 2 && D <= 6 && (size_t)S * A < 65536) {
     const int tb8 = 12 << D;
@@ -448,6 +470,7 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
     if ((rc = gnx_dev_upload(m, g8_class, &m->xgb.h8_group_class)) != GNX_OK) return rc;
     m->xgb.h8_tree_bytes = tb8; m->xgb.h8_n_groups = (int32_t)g8_class.size(); m->xgb.h8_max_group = G8;
   }
+#endif
   return GNX_OK;
 }
 

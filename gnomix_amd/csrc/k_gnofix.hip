@@ -1,73 +1,50 @@
-// k_gnofix.hip — the Gnofix re-phasing loop on gfx950: one workgroup per individual.
+// k_gnofix.hip — the Gnofix re-phasing loop on gfx950 (round 4): rank strips, read-only; several individuals per CU.
 //
 // Replaces Gnomix.phase -> gnofix() with its default arguments (reference src/model.py:188-214,
-// src/Gnofix/gnofix.py:58-208: check_criterion="disc_smooth", max_center_offset=0, non_lin_s=0,
-// prob_comp="max", prior_switch_prob=0.5, padding=True, no naive switch) and track_switch /
-// correct_phase_error (src/Gnofix/phasing.py:182-198).
+// src/Gnofix/gnofix.py:58-208: check_criterion="disc_smooth", max_center_offset=0, non_lin_s=0, prob_comp="max",
+// prior_switch_prob=0.5, padding=True, no naive switch) and track_switch / correct_phase_error
+// (src/Gnofix/phasing.py:182-198).
 //
-// The loop is sequential per individual (every accepted switch changes B from window w to the end), so
-// parallelism is across individuals (grid) and inside one smoother evaluation (threads):
-//  * both haplotypes' float32 base probabilities live reflect-padded in LDS (global scratch when an
-//    individual does not fit), so the S*A features of any row are one contiguous slice;
-//  * a candidate switch = 4 rows x n_trees walks spread over the block (leaf values to LDS, then per
-//    (row, class) an IN-ORDER float32 sum — bit-identical to the sequential predictor), softmax, max;
-//  * an accepted switch swaps the two padded strips from w on, flips the per-window parity, swaps the labels of
-//    rows that only see windows >= w and re-evaluates the <= S+1 rows per haplotype whose sliding window
-//    straddles w (exactly what a full smoother.predict(B) would return, at ~1/5 of the work);
-//  * convergence (gnofix.py:108-113 compares whole X_m vectors) is tracked as a per-window signature
-//    parity & (block of SNPs differs between the two haplotypes), which is equal iff the X_m vectors are;
-//  * SNPs are swapped once at the end from the final parity (correct_phase_error applied cumulatively).
-// Round 2: nothing on the individual's critical path is left to one thread or to a window-by-window scan:
-//  * the next window whose labels change is found by ballot, THREADS windows at a time (the reference's `for w in range(1, W)`
-//    only ever acts on those);
-//  * a candidate's 4 x n_trees walks go NWALK_C per thread side by side (chains of dependent L2-latency loads: the 1200 trees,
-//    230 KB, stay in global memory), its softmax one (row, class) per lane;
-//  * after an accepted switch all threads classify the rows (swap / re-evaluate list by LDS atomic); the re-evaluation goes class
-//    by class with the class's trees staged in LDS, P lanes per row splitting them and handing the running float32 sum down the
-//    lanes in tree order (bit-identical to the sequential predictor);
-//  * the per-window "SNP blocks differ" flags stop at the first difference; the final SNP swap touches only windows of odd parity,
-//    one byte range per run of such windows, unaligned 16-byte pieces;
-//  * the convergence history is compared one past sweep per thread.
-// -DGNX_GNOFIX_CLOCKS turns n_switches into per-phase clock counts (scripts/dev/gnofix_phases.py).
+// The loop is sequential per individual (an accepted switch changes B from window w to the end), so the parallelism is across
+// individuals and inside one smoother evaluation.  Rounds 1-3 (k_gnofix_f32.hip, kept as the fallback) ran ONE 512-thread
+// workgroup per CU because the individual's two float32 strips filled the LDS (or lived in a global scratch that every accepted
+// switch rewrote): every pipe sat below 20 % while one block waited on its own dependent chains.  What changed:
+//  * The smoother only ever asks `p < threshold`, so the strips are 16-bit RANKS (gnx_rank.h; the same quantisation as
+//    k_smooth_xgb_rk): k_gnofix_ranks turns B into (2n, W, A) u16 once, fully parallel.
+//  * The strips are READ-ONLY.  A switch at w exchanges the two haplotypes from w on; instead of rewriting strips the kernel keeps
+//    the per-window switch PARITY it needs anyway (convergence test, final SNP swap): logical haplotype h at window u is physical
+//    haplotype h ^ parity(u).  An accepted switch is a flip of parity bits.  Nothing of size W*A lives in LDS or is ever written.
+//  * What a phase reads is local to w: a candidate reads S windows of both strips, the re-evaluation 2S+1.  That slice is gathered
+//    from L2 into a class-major [hap][class][GP] u16 tile (the tile k_smooth_xgb_rk walks), so a block needs ~25 KB of LDS and five
+//    to six 256-thread blocks share a CU: one block's L2 round trips and dependent walks hide behind the others'.
+//  * Candidate (4 rows x n_trees walks, trees in L2): the trees are dealt out over the block; a lane walks its few trees on all FOUR
+//    rows side by side (the tree's first 16 bytes — root and both children — are fetched once for the four rows; a depth-4 walk is 4
+//    dependent L2 round trips and a candidate is ONE batch of them) and parks the leaves in LDS; one lane per (row, class) then adds
+//    them in tree order — bit-identical to the sequential predictor.
+//  * Re-evaluation after an accepted switch (<= S+1 rows per haplotype): lane = row, consecutive windows in consecutive lanes
+//    (rank gathers of lanes on the same node are consecutive halfwords); the block holds THREADS / rows such row sets, each on a
+//    class of its own with that class's trees staged in LDS; a lane adds its leaves in tree order.
+//  * A candidate's two ORIGINAL rows are rows the smoother has already evaluated: the scope [center-37, center+37] is exactly what row
+//    center+1 of slide_window sees (no reflection: center is clipped to [37, W-38]), so their max-probabilities come from a
+//    per-row cache (k_gnofix_pmax from the initial smoother pass, kept current through swaps and re-evaluations) and only the two
+//    SWITCHED rows are walked: 7 instead of 13 cache-line requests per tree — the candidate phase is bound by the L1's line rate.
+//  * Work per individual varies by an order of magnitude (0 .. 13 accepted switches in config 5b) and a launch ends with its slowest
+//    individual: the block is 512 threads (two per CU), i.e. the critical path of ONE individual is what is kept short.
+//  * The three phases that touch X are kernels of their own, all of the chip on each: k_gnofix_dif ("does this window's SNP block
+//    differ between the two haplotypes", the convergence signature's other half) before, k_gnofix_swap (phasing.py:188-198 applied
+//    once from the final parity) after.  Inside the per-individual kernel they ran at one CU's 25 GB/s.
+//  * The next label change is a find-first-set over a bit mask kept beside the labels (no block barrier per search).
 #include "gnx_internal.h"
+#include "gnx_rank.h"
 
 namespace {
 
-constexpr int THREADS = 512;   // one workgroup per CU (the strips fill its LDS); 8 waves with up to 256 VGPRs each
-constexpr int NWAVES = THREADS / 64;
+#define GNX_NOUNROLL _Pragma("clang loop unroll(disable)")
+// a value the optimiser cannot see through: what is computed from it stays where it is written (per-thread index arithmetic of
+// every phase hoisted out of the sweep / candidate loops cost ~100 VGPRs held for the whole kernel)
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
-__device__ __forceinline__ int slide_src(int j, int W, int pad) {
-  if (j < pad) return pad - 1 - j;
-  if (j < pad + W) return j - pad;
-  return W - 1 - (j - pad - W);
-}
-
-// NW independent walks side by side (generic pointers: trees in global memory, rows in LDS or global); same arithmetic as gnx_walk
-template <int NW>
-__device__ __forceinline__ void walk_n(const uint8_t* const (&tb)[NW], const uint8_t* const (&row)[NW], int D, float (&out)[NW]) {
-  const uint32_t half = 1u << (D - 1);
-  uint32_t j[NW];
-#pragma unroll
-  for (int k = 0; k < NW; ++k) j[k] = 1;
-  for (int d = 0; d < D - 1; ++d) {
-    uint2 nd[NW];
-    float fv[NW];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) __builtin_memcpy(&nd[k], tb[k] + half * 16 + (j[k] - 1) * 8, 8);
-#pragma unroll
-    for (int k = 0; k < NW; ++k) __builtin_memcpy(&fv[k], row[k] + nd[k].x, 4);
-#pragma unroll
-    for (int k = 0; k < NW; ++k) j[k] = 2 * j[k] + ((fv[k] < __uint_as_float(nd[k].y)) ? 0u : 1u);
-  }
-  uint4 n4[NW];
-  float fv[NW];
-#pragma unroll
-  for (int k = 0; k < NW; ++k) __builtin_memcpy(&n4[k], tb[k] + (j[k] - half) * 16, 16);
-#pragma unroll
-  for (int k = 0; k < NW; ++k) __builtin_memcpy(&fv[k], row[k] + n4[k].x, 4);
-#pragma unroll
-  for (int k = 0; k < NW; ++k) out[k] = (fv[k] < __uint_as_float(n4[k].y)) ? __uint_as_float(n4[k].z) : __uint_as_float(n4[k].w);
-}
+constexpr int NWR = 8;       // re-evaluation: trees walked side by side per lane (chains of LDS reads)
 
 // ---- 16 SNPs of a haplotype row at any byte address (gfx950 global memory takes unaligned dwordx4; the rows of an individual are
 // ldx bytes apart with no alignment promise) ----
@@ -76,244 +53,536 @@ __device__ __forceinline__ snp16 ld16(const int8_t* p) { snp16 v; __builtin_memc
 __device__ __forceinline__ void st16(int8_t* p, const snp16& v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ bool neq(const snp16& a, const snp16& b) { return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) != 0; }
 
-__host__ __device__ inline size_t gnofix_swrows_bytes(int S, int A, bool strips_in_lds) {
-  const size_t a = (size_t)2 * (S + 2) * A * 4, b = (size_t)(strips_in_lds ? 2 : 4) * S * A * 4;
-  return a > b ? a : b;
+// ---- pre-pass 1: base probabilities -> ranks (float32 cast first: Smooth/utils.py:20) ----
+__global__ __launch_bounds__(256) void k_gnofix_ranks(const double* __restrict__ B, int64_t n, const float* __restrict__ U,
+                                                      const uint32_t* __restrict__ lut, int K, int steps, uint16_t* __restrict__ R) {
+  constexpr int NV = 4;
+  const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NV;
+  if (e0 >= n) return;
+  float p[NV];
+  uint32_t r[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) p[i] = (float)B[min(e0 + i, n - 1)];
+  ranks<NV>(U, lut, K, steps, p, r);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (e0 + i < n) R[e0 + i] = (uint16_t)r[i];
 }
-__host__ __device__ inline size_t gnofix_leafbuf_bytes(int n_trees, int tree_bytes) {
-  const size_t a = (size_t)4 * n_trees * 4, b = (size_t)8 * tree_bytes;  // at least 8 staged trees
-  return a > b ? a : b;
+
+// ---- pre-pass 1b: largest probability of every row of the initial smoother pass ----
+__global__ __launch_bounds__(256) void k_gnofix_pmax(const float* __restrict__ P, int64_t rows, int A, float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float* p = P + r * A;
+  float m = p[0];
+  for (int a = 1; a < A; ++a) m = fmaxf(m, p[a]);
+  out[r] = m;
 }
 
-constexpr int NWALK = 4;   // re-evaluation: trees of one (row, class) walked side by side
-constexpr int RE_PER = 40; // re-evaluation: most trees one lane walks per staged chunk (their leaves stay in registers)
-constexpr int NWALK_C = 10; // candidate: 4 rows x NT walks over the block (4 x 1200 = 4800 <= 10 x 512)
-
-template <bool SL>  // SL: the two padded strips live in LDS (else in global scratch: very long chromosomes)
-__global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int W = L.W, A = L.A, S = L.S, pad = (S + 1) / 2, half = (S - 1) / 2;
-  const int Wp = W + 2 * pad, F = S * A, D = L.d.D, NT = L.d.n_trees, NWD = (W + 31) / 32;
-  const int tid = threadIdx.x;
-  const int64_t ind = blockIdx.x;
-
-  // ---- carve LDS ----
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { uint8_t* p = lds + off; off += (bytes + 15) & ~(size_t)15; return p; };
-  float* bp;  // [2][Wp][A]
-  if constexpr (SL) bp = reinterpret_cast<float*>(carve((size_t)2 * Wp * A * 4));
-  else bp = L.bp_scratch + (size_t)ind * 2 * Wp * A;
-  // candidate rows [2][F] (SL: the switched pair; the original pair is read from the strips) or [4][F] (strips in global memory:
-  // original pair + switched pair); also the exp() of re-evaluated rows
-  float* swrows = reinterpret_cast<float*>(carve(gnofix_swrows_bytes(S, A, SL)));
-  // strips in global memory: the slice of both strips that a group of re-evaluated rows reads, [2][SEGW][A]
-  const int SEGW = 2 * S + 2;
-  float* seg = SL ? nullptr : reinterpret_cast<float*>(carve((size_t)2 * SEGW * A * 4));
-  float* leafbuf = reinterpret_cast<float*>(carve(gnofix_leafbuf_bytes(NT, L.d.tree_bytes)));  // [4][NT] leaves / staged trees
-  float* marg = reinterpret_cast<float*>(carve((size_t)2 * (S + 2) * A * 4));        // margins of re-evaluated rows
-  uint8_t* Y = carve((size_t)2 * W + 16);                                                 // labels [2][W]
-  uint32_t* par = reinterpret_cast<uint32_t*>(carve((size_t)NWD * 4));               // switch parity per window
-  uint32_t* dif = reinterpret_cast<uint32_t*>(carve((size_t)NWD * 4));               // SNP block differs m vs p
-  int* flags = reinterpret_cast<int*>(carve(128));                                   // [0]=accept [1]=converged [2],[3]=rows to re-evaluate [r0,r1) [4..4+NWAVES)=first change per wave
-  uint32_t* hist = L.hist + (size_t)ind * L.max_it * NWD;
-
-#ifdef GNX_GNOFIX_CLOCKS  // development aid: per-phase shader clocks, individual i reports phase (i & 7) in n_switches (units of 64 clocks)
-  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tprev = clock64();
-  const long long tstart = tprev;
-#define TICK(i) { __syncthreads(); const long long tn = clock64(); tacc[i] += tn - tprev; tprev = tn; }
-#else
-#define TICK(i)
-#endif
-  int8_t* Xm = L.X + (2 * ind) * L.ldx;
-  int8_t* Xp = Xm + L.ldx;
-  const int64_t C = L.C;
-  const int64_t ws = C / W;  // gnofix.py:74 window_size = len(M)//W
-
-  // ---- load: padded float32 strips, initial labels, per-window SNP difference ----
-  for (int e = tid; e < 2 * Wp * A; e += THREADS) {
-    const int h = e / (Wp * A), r = e - h * Wp * A;
-    const int j = r / A, a = r - j * A;
-    bp[e] = (float)L.B[(((size_t)(2 * ind + h)) * W + slide_src(j, W, pad)) * A + a];
-  }
-  for (int e = tid; e < 2 * W; e += THREADS) Y[e] = (uint8_t)L.Y0[(size_t)2 * ind * W + e];
-  for (int e = tid; e < NWD; e += THREADS) { par[e] = 0; dif[e] = 0; }
-  __syncthreads();
-  TICK(0)
-  const int wv = tid >> 6, ln = tid & 63;
-  // "does this window's SNP block differ between the two haplotypes": four lanes per window, 64 bytes per step, stopping at the first
-  // difference (heterozygous sites are dense, so a window is normally decided by its first step; identical blocks read it all)
-  for (int u0 = wv * 16; u0 < W; u0 += NWAVES * 16) {
-    const int u = u0 + (ln >> 2), q = ln & 3;
+// ---- pre-pass 2: per individual and window, "the SNP block differs between the two haplotypes" (gnofix.py:108-113 compares whole
+// X_m vectors; with the switch parity, X_m(a) == X_m(b) iff parity_a & dif == parity_b & dif).  Window u covers SNPs
+// [u*ws, (u+1)*ws), ws = C // W, the last one up to C (gnofix.py:74, phasing.py:192).  One wave = one 32-bit word of the mask: four
+// lanes per window, 64 bytes per step, stopping at the first difference. ----
+__global__ __launch_bounds__(256) void k_gnofix_dif(const int8_t* __restrict__ X, int64_t ldx, int64_t C, int W, uint32_t* __restrict__ dif) {
+  const int NWD = (W + 31) / 32;
+  const int ln = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= NWD) return;  // wave-uniform
+  const int64_t ind = blockIdx.y;
+  const int8_t* Xm = X + 2 * ind * ldx;
+  const int8_t* Xp = Xm + ldx;
+  const int64_t ws = C / W;
+  uint32_t word = 0;
+  for (int hf = 0; hf < 2; ++hf) {
+    const int u = q * 32 + hf * 16 + (ln >> 2), sub = ln & 3;
     const bool live = u < W;
     const int64_t j0 = live ? (int64_t)u * ws : 0, j1 = !live ? 0 : (u == W - 1) ? C : j0 + ws;
     bool d = false;
-    for (int64_t j = j0; ; j += 64) {
-      const int64_t a0 = j + q * 16, a1 = min(a0 + 16, j1);
+    for (int64_t j = j0;; j += 64) {
+      const int64_t a0 = j + sub * 16, a1 = min(a0 + 16, j1);
       if (!d && a0 < j1) {
-        if (a1 - a0 == 16) {
-          d = neq(ld16(Xm + a0), ld16(Xp + a0));
-        } else {
+        if (a1 - a0 == 16) d = neq(ld16(Xm + a0), ld16(Xp + a0));
+        else
           for (int64_t i = a0; i < a1; ++i) d |= Xm[i] != Xp[i];
-        }
       }
       const unsigned long long bal = __ballot(d);
       d = ((bal >> (ln & ~3)) & 0xfull) != 0;  // the window's four lanes agree
       if (__ballot(!d && j + 64 < j1) == 0) break;
     }
-    if (d && q == 0) atomicOr(&dif[u >> 5], 1u << (u & 31));
+    const unsigned long long bal = __ballot(d && sub == 0);  // window k of this half at bit 4k
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bits |= (uint32_t)((bal >> (4 * k)) & 1ull) << k;
+    word |= bits << (16 * hf);
   }
+  if (ln == 0) dif[(size_t)ind * NWD + q] = word;
+}
+
+// ---- post-pass: correct_phase_error applied once from the final parity (phasing.py:188-198): windows of odd parity exchange their
+// SNP blocks.  grid = (16 KB pieces of the chromosome, individuals); a block whose windows are all even leaves without a load. ----
+__global__ __launch_bounds__(256) void k_gnofix_swap(int8_t* __restrict__ X, int64_t ldx, int64_t C, int W, const uint32_t* __restrict__ par) {
+  constexpr int PER = 4;  // 16-byte pieces per thread
+  const int NWD = (W + 31) / 32;
+  const int64_t ind = blockIdx.y;
+  const uint32_t* P = par + (size_t)ind * NWD;
+  const uint32_t ws = (uint32_t)(C / W);
+  const int64_t b0 = (int64_t)blockIdx.x * (256 * PER * 16), b1 = min(b0 + 256 * PER * 16, C);
+  const int ua = (int)min((int64_t)W - 1, b0 / ws), ub = (int)min((int64_t)W - 1, (b1 - 1) / ws);
+  bool any = false;
+  for (int q = ua >> 5; q <= ub >> 5; ++q) {  // block-uniform
+    uint32_t m = P[q];
+    if (q == ua >> 5) m &= 0xffffffffu << (ua & 31);
+    if (q == ub >> 5) m &= 0xffffffffu >> (31 - (ub & 31));
+    any |= m != 0;
+  }
+  if (!any) return;
+  int8_t* Xm = X + 2 * ind * ldx;
+  int8_t* Xp = Xm + ldx;
+  auto odd = [&](int u) { return ((P[u >> 5] >> (u & 31)) & 1u) != 0; };
+  snp16 xa[PER], xb[PER];
+  int mode[PER];  // 0 nothing, 1 whole piece, 2 byte by byte (a window boundary or the chromosome's end inside the piece)
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t j = b0 + ((int64_t)k * 256 + threadIdx.x) * 16;
+    mode[k] = 0;
+    if (j >= C) continue;
+    const int u0 = (int)min((uint32_t)(W - 1), (uint32_t)j / ws), u1 = (int)min((uint32_t)(W - 1), (uint32_t)min(j + 15, C - 1) / ws);
+    if (j + 16 <= C && (u0 == u1 || (u1 == u0 + 1 && odd(u0) == odd(u1)))) mode[k] = odd(u0) ? 1 : 0;
+    else mode[k] = 2;
+    if (mode[k] == 1) { xa[k] = ld16(Xm + j); xb[k] = ld16(Xp + j); }
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t j = b0 + ((int64_t)k * 256 + threadIdx.x) * 16;
+    if (mode[k] == 1) { st16(Xm + j, xb[k]); st16(Xp + j, xa[k]); }
+    else if (mode[k] == 2) {
+      for (int64_t i = j; i < min(j + 16, C); ++i)
+        if (odd((int)min((uint32_t)(W - 1), (uint32_t)i / ws))) { const int8_t t = Xm[i]; Xm[i] = Xp[i]; Xp[i] = t; }
+    }
+  }
+}
+
+// Where a walk reads its trees from.  Global copy: buffer loads through a 128-bit descriptor held in SGPRs — a 32-bit word offset
+// per chain instead of a 64-bit address pair (flat loads made the candidate's 20 chains cost 235 VGPRs).  LDS stage: plain reads.
+struct TreesGlobal {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ uint32_t u32(uint32_t word) const { return __builtin_amdgcn_raw_buffer_load_b32(rs, word * 4u, 0, 0); }
+  __device__ __forceinline__ uint4 u128(uint32_t word) const {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, word * 4u, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  }
+};
+struct TreesLds {
+  const uint32_t* p;
+  __device__ __forceinline__ uint32_t u32(uint32_t word) const { return p[word]; }
+  __device__ __forceinline__ uint4 u128(uint32_t word) const { return *reinterpret_cast<const uint4*>(p + word); }
+};
+
+// Tree layout of k_gnofix (SmoothXGBDev::gf_packed): 2^D node words in heap order (slot 0 unused; rank field << 16 | byte offset of
+// the feature in the tile) followed by 2^D float leaves — the leaf of heap index j is word j.  Words 0..3 = {-, root, node 2, node 3}
+// arrive in ONE 16-byte read, so levels 0 and 1 cost one dependent round trip (D >= 2): a depth-4 walk is 4 of them.
+// NW trees t0, t0+1, .. side by side on ONE row (T = global memory or the LDS stage, row = LDS address of the row's tile origin).
+// With CLAMP the tree index stops at tmax (LDS stage); without, trees past the caller's range are walked and dropped by the caller
+// (the global copy is followed by GNX_GF_PAD_TREES zero trees), so every address is base + immediate.
+template <int NW, int DT, bool CLAMP, typename Trees>
+__device__ __forceinline__ void walk_seq(const Trees T, uint32_t t0, uint32_t tmax, const uint8_t* row, int Drt, float (&out)[NW]) {
+  const int D = DT ? DT : Drt;
+  const uint32_t TWc = 2u << D;
+  uint32_t j[NW];
+  uint32_t tb[NW];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) tb[k] = (CLAMP ? min(t0 + (uint32_t)k, tmax) : t0 + (uint32_t)k) * TWc;
+  auto level = [&]() {
+    uint32_t nd[NW], r[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) nd[k] = T.u32(tb[k] + j[k]);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) r[k] = *reinterpret_cast<const uint16_t*>(row + (nd[k] & 0xffffu));
+#pragma unroll
+    for (int k = 0; k < NW; ++k) j[k] = 2 * j[k] + ((r[k] < (nd[k] >> 16)) ? 0u : 1u);
+  };
+  if (D >= 2) {
+    uint4 top[NW];
+    uint32_t r[NW], n1[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) top[k] = T.u128(tb[k]);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) r[k] = *reinterpret_cast<const uint16_t*>(row + (top[k].y & 0xffffu));
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const bool right = !(r[k] < (top[k].y >> 16));
+      n1[k] = right ? top[k].w : top[k].z;
+      j[k] = right ? 3u : 2u;
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) r[k] = *reinterpret_cast<const uint16_t*>(row + (n1[k] & 0xffffu));
+#pragma unroll
+    for (int k = 0; k < NW; ++k) j[k] = 2 * j[k] + ((r[k] < (n1[k] >> 16)) ? 0u : 1u);
+    if constexpr (DT > 0) {
+#pragma unroll
+      for (int d = 2; d < DT; ++d) level();
+    } else {
+      for (int d = 2; d < D; ++d) level();
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) j[k] = 1;
+    for (int d = 0; d < D; ++d) level();
+  }
+#pragma unroll
+  for (int k = 0; k < NW; ++k) out[k] = __uint_as_float(T.u32(tb[k] + j[k]));
+}
+
+// Candidate: NT_ trees t0, t0 + STRIDE, .. of the global copy, each on the NR = 2 candidate rows (LDS addresses row + roff[r]); out[k*NR + r].
+template <int NT_, int STRIDE, int DT, typename Trees>
+__device__ __forceinline__ void walk4(const Trees T, uint32_t t0, const uint8_t* row, const uint32_t (&roff)[2], int Drt,
+                                      float* out) {
+  const int D = DT ? DT : Drt;
+  const uint32_t TWc = 2u << D;
+  uint32_t j[NT_ * 2];
+  uint32_t tw[NT_];
+#pragma unroll
+  for (int k = 0; k < NT_; ++k) tw[k] = (t0 + (uint32_t)(k * STRIDE)) * TWc;
+  auto level = [&]() {
+    uint32_t nd[NT_ * 2], r[NT_ * 2];
+#pragma unroll
+    for (int q = 0; q < NT_ * 2; ++q) nd[q] = T.u32(tw[q >> 1] + j[q]);
+#pragma unroll
+    for (int q = 0; q < NT_ * 2; ++q) r[q] = *reinterpret_cast<const uint16_t*>(row + roff[q & 1] + (nd[q] & 0xffffu));
+#pragma unroll
+    for (int q = 0; q < NT_ * 2; ++q) j[q] = 2 * j[q] + ((r[q] < (nd[q] >> 16)) ? 0u : 1u);
+  };
+  if (D >= 2) {
+    uint4 top[NT_];
+#pragma unroll
+    for (int k = 0; k < NT_; ++k) top[k] = T.u128(tw[k]);
+    uint32_t r[NT_ * 2], n1[NT_ * 2];
+#pragma unroll
+    for (int q = 0; q < NT_ * 2; ++q) r[q] = *reinterpret_cast<const uint16_t*>(row + roff[q & 1] + (top[q >> 1].y & 0xffffu));
+#pragma unroll
+    for (int q = 0; q < NT_ * 2; ++q) {
+      const bool right = !(r[q] < (top[q >> 1].y >> 16));
+      n1[q] = right ? top[q >> 1].w : top[q >> 1].z;
+      j[q] = right ? 3u : 2u;
+    }
+#pragma unroll
+    for (int q = 0; q < NT_ * 2; ++q) r[q] = *reinterpret_cast<const uint16_t*>(row + roff[q & 1] + (n1[q] & 0xffffu));
+#pragma unroll
+    for (int q = 0; q < NT_ * 2; ++q) j[q] = 2 * j[q] + ((r[q] < (n1[q] >> 16)) ? 0u : 1u);
+    if constexpr (DT > 0) {
+#pragma unroll
+      for (int d = 2; d < DT; ++d) level();
+    } else {
+      for (int d = 2; d < D; ++d) level();
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NT_ * 2; ++q) j[q] = 1;
+    for (int d = 0; d < D; ++d) level();
+  }
+#pragma unroll
+  for (int q = 0; q < NT_ * 2; ++q) out[q] = __uint_as_float(T.u32(tw[q >> 1] + j[q]));
+}
+
+__host__ __device__ inline int gnofix_rows_max(int S, int threads) { return 2 * min(S + 2, threads / 2); }
+
+struct GnofixLds {
+  size_t seg, Y, pmax, par, dif, chg, marg, ex, stage, flags, total;
+};
+__host__ __device__ inline GnofixLds gnofix_lds(int W, int A, int S, int GP, int cap, int D, int threads, int n_trees) {
+  auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const size_t NWD = (size_t)(W + 31) / 32, nrow = (size_t)gnofix_rows_max(S, threads);
+  GnofixLds o{};
+  size_t off = 0;
+  o.seg = off; off += r16((size_t)2 * A * GP * 2);
+  o.Y = off; off += r16((size_t)W * 2 + 16);
+  o.pmax = off; off += r16((size_t)2 * W * 4);
+  o.par = off; off += r16(NWD * 4);
+  o.dif = off; off += r16(NWD * 4);
+  o.chg = off; off += r16(NWD * 4 + 4);
+  o.marg = off; off += r16(nrow * A * 4);
+  o.ex = off; off += r16((size_t)(threads / 64) * 2 * A * 4);
+  {  // re-evaluation: `cap` staged trees for each of the block's row sets; candidate: the leaves [2][n_trees] (never both)
+    const size_t nset = (size_t)(threads / (int)nrow) > 0 ? (size_t)(threads / (int)nrow) : 1;
+    const size_t st = nset * cap * gnx_gf_tree_words(D) * 4, lb = (size_t)2 * n_trees * 4;
+    o.stage = off; off += r16(st > lb ? st : lb);
+  }
+  o.flags = off; off += 256;
+  o.total = off;
+  return o;
+}
+
+// what the per-individual kernel reads of a GnofixLaunch (a kernel argument block of 100 bytes instead of 400: fewer SGPRs held)
+struct GnofixK {
+  const uint16_t* R;
+  const uint32_t* dif;
+  uint32_t* par;
+  const uint32_t* gf;
+  const int32_t* class_tree0;
+  const int32_t* Y0;
+  const float* P0;   // (2n, W) largest probability per row of the initial smoother pass
+  int32_t* Yout;
+  int32_t* n_switches;
+  uint32_t* hist;
+  int32_t W, A, S, max_it, D, NT, GP, cap;
+  float base_score;
+};
+
+template <int THREADS, int DT>
+__global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(GnofixK L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int PER_T = THREADS >= 1024 ? 2 : THREADS >= 512 ? 3 : 5;  // candidate: most trees one lane walks (on the four rows side by side: chains of L2 loads) per round
+  constexpr int PF_MAX = THREADS >= 512 ? 4 : 8;                       // candidate: tile elements per thread that are fetched one candidate ahead
+  const int W = L.W, A = L.A, S = L.S, pad = (S + 1) / 2, half = (S - 1) / 2;
+  const int D = DT ? DT : L.D, NWD = (W + 31) / 32, GP = L.GP, TW = gnx_gf_tree_words(D), NT = L.NT;
+  const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+  const int64_t ind = blockIdx.x;
+  const GnofixLds o = gnofix_lds(W, A, S, GP, L.cap, D, THREADS, NT);
+  uint16_t* seg = reinterpret_cast<uint16_t*>(lds + o.seg);   // [2][A][GP] ranks: the tile every walk reads
+  uint16_t* Y = reinterpret_cast<uint16_t*>(lds + o.Y);       // labels: maternal | paternal << 8 per window
+  float* pmax = reinterpret_cast<float*>(lds + o.pmax);       // [W][2] largest smoother probability of (window, haplotype)'s row
+  uint32_t* par = reinterpret_cast<uint32_t*>(lds + o.par);   // switch parity per window
+  uint32_t* dif = reinterpret_cast<uint32_t*>(lds + o.dif);   // SNP block differs m vs p
+  uint8_t* chg = lds + o.chg;                                 // bit u: the labels of window u differ from window u-1's
+  float* marg = reinterpret_cast<float*>(lds + o.marg);       // candidate: [2][A]; re-evaluation: [A][NROW]
+  float* ex = reinterpret_cast<float*>(lds + o.ex);           // candidate: exp(margin - row max) [2][A], one copy per wave
+  uint32_t* stage = reinterpret_cast<uint32_t*>(lds + o.stage);  // re-evaluation: staged trees of one class
+  int* flags = reinterpret_cast<int*>(lds + o.flags);         // [0] accept, [2],[3] rows to re-evaluate [r0, r1), [8..40) past sweeps that differ
+  uint32_t* hist = L.hist + (size_t)ind * L.max_it * NWD;
+  const uint16_t* __restrict__ R0 = L.R + (size_t)2 * ind * W * A;  // physical haplotype h at + h*W*A
+  const size_t WA = (size_t)W * A;
+  const uint32_t invA = 0xFFFFFFFFu / (uint32_t)A + 1u;       // n / A = umulhi(n, invA) for n < 65536 (A <= 32)
+  const int NROW = gnofix_rows_max(S, THREADS), NSETMAX = max(1, THREADS / NROW);
+  int nmax = 0;  // most trees of one class
+  for (int c = 0; c < A; ++c) nmax = max(nmax, L.class_tree0[c + 1] - L.class_tree0[c]);
+#ifdef GNX_GNOFIX_CLOCKS  // development aid (scripts/dev/gnofix_phases.py): individual i reports phase (i & 7) in n_switches, units of 64 clocks
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+#define TICK(i) { const long long tn = clock64(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define TICK(i)
+#endif
+
+  // ---- load: labels, masks ----
+  for (int u = tid; u < W; u += THREADS) {
+    Y[u] = (uint16_t)(L.Y0[(size_t)2 * ind * W + u] | (L.Y0[(size_t)(2 * ind + 1) * W + u] << 8));
+    pmax[2 * u] = L.P0[(size_t)2 * ind * W + u];
+    pmax[2 * u + 1] = L.P0[(size_t)(2 * ind + 1) * W + u];
+  }
+  for (int q = tid; q < NWD; q += THREADS) { par[q] = 0; dif[q] = L.dif[(size_t)ind * NWD + q]; }
   __syncthreads();
-  TICK(1)
+  auto parbit = [&](int u) -> int { return (int)((par[u >> 5] >> (u & 31)) & 1u); };
+  auto mark_changes = [&](int t_) {  // one byte of the mask (8 windows) per thread
+    GNX_NOUNROLL for (int b = t_; b < NWD * 4; b += THREADS) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int u = b * 8 + k;
+        if (u >= 1 && u < W && Y[u] != Y[u - 1]) m |= 1u << k;
+      }
+      chg[b] = (uint8_t)m;
+    }
+  };
+  mark_changes(tid);
+  __syncthreads();
+  // check(): "disc_smooth" (gnofix.py:32): the reference walks w = 1 .. W-1 and acts only where a label changes; every wave finds
+  // the next such window for itself (same answer in every wave: no barrier)
+  auto next_change = [&](int from) -> int {
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(chg);
+    for (int q0 = from >> 5; q0 < NWD; q0 += 64) {
+      const int q = q0 + ln;
+      uint32_t m = q < NWD ? cw[q] : 0u;
+      if (q == from >> 5) m &= 0xffffffffu << (from & 31);
+      const unsigned long long bal = __ballot(m != 0);
+      if (bal) {
+        const int first = __builtin_ctzll(bal);
+        const uint32_t mw = (uint32_t)__shfl((int)m, first);
+        return (q0 + first) * 32 + __builtin_ctz(mw);
+      }
+    }
+    return W;
+  };
+
+  // the candidate's two rows = the switched pair, at tile positions 0..S-1 of the two halves
+  const uint32_t roff[2] = {0u, (uint32_t)(A * GP * 2)};
+  const uint8_t* crow = reinterpret_cast<const uint8_t*>(seg);
+  const uint32_t* __restrict__ GTp = L.gf;
+  const TreesGlobal GT{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(L.gf), 0, (uint32_t)((NT + GNX_GF_PAD_TREES) * TW * 4), 0x00020000)};  // (reads past the end return 0: the hardware's bounds check)
 
   int n_switch = 0;
+  TICK(0)
   for (int it = 0; it < L.max_it; ++it) {
+    const int ty = opaque(tid);
     // ---- convergence: has this X_m been seen at the start of an earlier sweep? (gnofix.py:108-113) ----
-    if (tid == 0) flags[1] = 0;
-    __syncthreads();
-    for (int k = tid; k < it; k += THREADS) {  // one past sweep per thread
-      bool same = true;
-      for (int q = 0; q < NWD && same; ++q) same = hist[(size_t)k * NWD + q] == (par[q] & dif[q]);
-      if (same) atomicOr(&flags[1], 1);
+    bool seen = false;
+    for (int k0 = 0; k0 < it; k0 += 1024) {  // 1024 past sweeps at a time: one "differs" bit each
+      const int nk = min(1024, it - k0);
+      if (ty < 32) flags[8 + ty] = 0;
+      __syncthreads();
+      GNX_NOUNROLL for (int e = ty; e < nk * NWD; e += THREADS) {
+        const int k = e / NWD, q = e - k * NWD;
+        if (hist[(size_t)(k0 + k) * NWD + q] != (par[q] & dif[q])) atomicOr(&flags[8 + (k >> 5)], 1 << (k & 31));
+      }
+      __syncthreads();
+      for (int k = 0; k < nk; k += 32) {
+        uint32_t m = ~(uint32_t)flags[8 + (k >> 5)];
+        if (nk - k < 32) m &= (1u << (nk - k)) - 1u;
+        seen |= m != 0;
+      }
+      __syncthreads();
     }
-    for (int q = tid; q < NWD; q += THREADS) hist[(size_t)it * NWD + q] = par[q] & dif[q];  // (harmless when converged: never read again)
-    __syncthreads();
-    if (flags[1]) break;
+    if (seen) break;
+    GNX_NOUNROLL for (int q = ty; q < NWD; q += THREADS) hist[(size_t)it * NWD + q] = par[q] & dif[q];
+    TICK(1)
 
-    // check(): "disc_smooth" (gnofix.py:32): the reference walks w = 1 .. W-1 and acts only where a label changes; the next such
-    // window at or after `from` is found THREADS windows at a time (labels of later windows may change while the sweep advances, so
-    // the search restarts after every candidate)
-    auto next_change = [&](int from) -> int {
-      for (int base = from; base < W; base += THREADS) {
-        const int wq = base + tid;
-        const bool hit = wq < W && (Y[wq] != Y[wq - 1] || Y[W + wq] != Y[W + wq - 1]);
-        const unsigned long long bal = __ballot(hit);
-        if ((tid & 63) == 0) flags[4 + (tid >> 6)] = bal ? base + (tid & ~63) + __builtin_ctzll(bal) : W;
-        __syncthreads();
-        int first = W;
+    // The tile elements of a candidate are per-thread values (e = tid + i * THREADS): when they fit PF_MAX registers, the NEXT
+    // candidate's are requested before this one's walks start (a rejected candidate — most are — changes neither the labels nor
+    // the parity, so the next change and its ranks are already known) and the L2 round trip hides behind the walks.
+    const bool pf_fits = 2 * S * A <= PF_MAX * THREADS;
+    uint16_t pfv[PF_MAX];
+    bool pf_valid = false;
+    auto cand_fetch = [&](int wq, int t_) {
+      const int cq = min(max(wq, half), W - 1 - half), loq = cq - half;
 #pragma unroll
-        for (int k = 0; k < NWAVES; ++k) first = min(first, flags[4 + k]);
-        __syncthreads();
-        if (first < W) return first;
+      for (int i = 0; i < PF_MAX; ++i) {
+        const int e = min(t_ + i * THREADS, 2 * S * A - 1);  // clamped: unconditional loads
+        const int h = e >= S * A ? 1 : 0, f = e - h * S * A;
+        const int sq = (int)__umulhi((uint32_t)f, invA), a = f - sq * A;
+        const int u = loq + sq;
+        pfv[i] = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
       }
-      return W;
     };
-    for (int w = next_change(1); w < W; w = next_change(w + 1)) {
+    int w = next_change(1);
+    while (w < W) {
       TICK(2)
+      const int tz = opaque(tid), lz = tz & 63;
       const int center = min(max(w, half), W - 1 - half);
-      const int lo = center - half;  // scope = windows [lo, lo+S)
-      // switched rows: m' = [B0[lo:w], B1[w:hi]], p' = [B1[lo:w], B0[w:hi]]   (gnofix.py:144-153)
-      constexpr int R0 = SL ? 2 : 0;  // first row kept in swrows
-      for (int e = tid; e < (4 - R0) * F; e += THREADS) {
-        const int r = R0 + e / F, f = e % F;
-        const int u = lo + f / A;
-        const int h = (r < 2) ? r : (u < w) ? (r - 2) : (3 - r);
-        swrows[e] = bp[((size_t)h * Wp + pad + u) * A + (f % A)];
-      }
-      __syncthreads();
-      // 4 rows x NT tree walks; rows 0,1 = original scope slices of the padded strips (unpadded window u
-      // sits at padded index u+pad; copied to LDS when the strips are in global memory), rows 2,3 = switched copies
-      for (int e0 = tid; e0 < 4 * NT; e0 += NWALK_C * THREADS) {
-        const uint8_t* tb[NWALK_C];
-        const uint8_t* rw[NWALK_C];
-        float lf[NWALK_C];
+      const int lo = center - half;  // scope = windows [lo, lo+S)   (gnofix.py:122-130)
+      // the switched pair m' = [B0[lo:w], B1[w:hi]], p' = [B1[lo:w], B0[w:hi]] (gnofix.py:144-153); the original pair's
+      // probabilities are those of the smoother's row center + 1 (pmax)
+      if (pf_fits) {
+        if (!pf_valid) cand_fetch(w, tz);
 #pragma unroll
-        for (int k = 0; k < NWALK_C; ++k) {
-          const int e = min(e0 + k * THREADS, 4 * NT - 1);  // clamped: the tail repeats the last walk and drops it
-          const int r = e & 3, t = e >> 2;
-          tb[k] = L.d.packed + (size_t)t * L.d.tree_bytes;
-          if constexpr (SL) rw[k] = reinterpret_cast<const uint8_t*>((r < 2) ? (bp + ((size_t)r * Wp + pad + lo) * A) : (swrows + (size_t)(r - 2) * F));
-          else rw[k] = reinterpret_cast<const uint8_t*>(swrows + (size_t)r * F);
+        for (int i = 0; i < PF_MAX; ++i) {
+          const int e = tz + i * THREADS;
+          if (e < 2 * S * A) {
+            const int h = e >= S * A ? 1 : 0, f = e - h * S * A;
+            const int s = (int)__umulhi((uint32_t)f, invA), a = f - s * A;
+            seg[(((lo + s < w) ? h : 1 - h) * A + a) * GP + s] = pfv[i];
+          }
         }
-        walk_n<NWALK_C>(tb, rw, D, lf);
-#pragma unroll
-        for (int k = 0; k < NWALK_C; ++k) {
-          const int e = e0 + k * THREADS;
-          if (e < 4 * NT) leafbuf[(size_t)(e & 3) * NT + (e >> 2)] = lf[k];
+      } else {
+        GNX_NOUNROLL for (int e = tz; e < 2 * S * A; e += THREADS) {
+          const int h = e >= S * A ? 1 : 0, f = e - h * S * A;
+          const int s = (int)__umulhi((uint32_t)f, invA), a = f - s * A;
+          const int u = lo + s;
+          const uint16_t v = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
+          seg[(((u < w) ? h : 1 - h) * A + a) * GP + s] = v;
         }
       }
-      __syncthreads();
-      if (tid < 4 * A) {  // per (row, class): in-order float32 sum of that class's trees (class-major packing)
-        const int r = tid / A, c = tid - r * A;
-        float ps = 0.f;
-        const int t1 = L.class_tree0[c + 1];
-        int t = L.class_tree0[c];
-        for (; t + 8 <= t1; t += 8) {  // loads first, then the adds in tree order
-          float v[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = leafbuf[(size_t)r * NT + t + k];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) ps += v[k];
-        }
-        for (; t < t1; ++t) ps += leafbuf[(size_t)r * NT + t];
-        marg[r * A + c] = L.d.base_score + ps;
-      }
-      __syncthreads();
-      // xgboost Softmax of the 4 rows, one (row, class) per lane: exp((double)(m - max)) -> float, in-order double sum, divide
-      float* ex = marg + 4 * A;
-      if (tid < 4 * A) {
-        const int r = tid / A;
-        float wmax = marg[r * A];
-        for (int a = 1; a < A; ++a) wmax = fmaxf(marg[r * A + a], wmax);
-        ex[tid] = (float)exp((double)(marg[tid] - wmax));
-      }
-      __syncthreads();
-      if (tid < 64) {  // lanes 0..3 = rows; the decision is taken by lane 0
-        float mx = 0.f;
-        if (tid < 4) {
-          double wsum = 0.0;
-          for (int a = 0; a < A; ++a) wsum += (double)ex[tid * A + a];
-          const float fs = (float)wsum;
-          mx = ex[tid * A] / fs;
-          for (int a = 1; a < A; ++a) mx = fmaxf(mx, ex[tid * A + a] / fs);
-        }
-        const float p_orig = fmaxf(__shfl(mx, 0), __shfl(mx, 1));   // prob_comp="max" over hap and ancestry
-        const float p_sw = fmaxf(__shfl(mx, 2), __shfl(mx, 3));
-        if (tid == 0) flags[0] = (p_sw * 0.5f > p_orig * 0.5f) ? 1 : 0;  // prior_switch_prob = 0.5 (gnofix.py:171)
-      }
+      const int w_next = next_change(w + 1);  // if this candidate is rejected
+      pf_valid = pf_fits && w_next < W;
+      if (pf_valid) cand_fetch(w_next, opaque(tid));
       __syncthreads();
       TICK(3)
-      if (!flags[0]) continue;
-
-      // ---- accept: swap the strips from window w on (incl. reflected pads), flip parity, relabel ----
-      ++n_switch;
-      for (int e = tid; e < Wp * A; e += THREADS) {
-        const int j = e / A;
-        if (slide_src(j, W, pad) >= w) {
-          const float t0 = bp[e], t1 = bp[(size_t)Wp * A + e];
-          bp[e] = t1;
-          bp[(size_t)Wp * A + e] = t0;
+      // 2 rows x n_trees walks: tree t = tz + k * THREADS on both rows side by side, leaves to LDS [row][tree]
+      {
+        float* leafbuf = reinterpret_cast<float*>(stage);
+        for (int tb = 0; tb < NT; tb += THREADS * PER_T) {
+          const int per_u = min(PER_T, (NT - tb + THREADS - 1) / THREADS);  // block-uniform
+          const uint32_t t0 = (uint32_t)min(tb + tz, NT - 1);              // (GNX_GF_PAD_TREES zero trees follow the last one)
+          float lf[PER_T * 2];
+          // ONE batch: the lane's per_u trees x 2 rows (D - 1 dependent L2 round trips + the leaves)
+          if (per_u <= 1) walk4<1, THREADS, DT>(GT, t0, crow, roff, D, lf);
+          else if (PER_T > 2 && per_u == 2) walk4<(PER_T > 2 ? 2 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
+          else if (PER_T > 3 && per_u == 3) walk4<(PER_T > 3 ? 3 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
+          else if (PER_T > 4 && per_u == 4) walk4<(PER_T > 4 ? 4 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
+          else walk4<PER_T, THREADS, DT>(GT, t0, crow, roff, D, lf);
+#pragma unroll
+          for (int k = 0; k < PER_T; ++k) {
+            const int t = tb + tz + k * THREADS;
+            if (k < per_u && t < NT) {
+#pragma unroll
+              for (int r = 0; r < 2; ++r) leafbuf[r * NT + t] = lf[k * 2 + r];
+            }
+          }
+        }
+        __syncthreads();
+        if (tz < 2 * A) {  // per (row, class): the float32 sum of the class's leaves in tree order (class-major packing)
+          const int r = (int)__umulhi((uint32_t)tz, invA), c = tz - r * A;
+          const float* lb = leafbuf + r * NT;
+          const int t1 = L.class_tree0[c + 1];
+          int t = L.class_tree0[c];
+          float ps = 0.f;
+          GNX_NOUNROLL for (; t + 8 <= t1; t += 8) {  // loads first, then the adds in tree order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = lb[t + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ps += v[k];
+          }
+          GNX_NOUNROLL for (; t < t1; ++t) ps += lb[t];
+          marg[tz] = L.base_score + ps;
         }
       }
-      for (int q = tid; q < NWD; q += THREADS) {
+      __syncthreads();
+      TICK(4)
+      // xgboost's Softmax of the 4 rows and the decision, by EVERY wave for itself (same answer, no second barrier; the LDS
+      // operations of one wave execute in order)
+      bool accept;
+      {
+        float* exw = ex + wv * 2 * A;
+        GNX_NOUNROLL for (int e = lz; e < 2 * A; e += 64) {
+          const int r = (int)__umulhi((uint32_t)e, invA);
+          float wmax = marg[r * A];
+          GNX_NOUNROLL for (int a = 1; a < A; ++a) wmax = fmaxf(marg[r * A + a], wmax);
+          exw[e] = (float)exp((double)(marg[e] - wmax));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float mx = 0.f;
+        if (lz < 2) {
+          double wsum = 0.0;
+          GNX_NOUNROLL for (int a = 0; a < A; ++a) wsum += (double)exw[lz * A + a];
+          const float fs = (float)wsum;
+          mx = exw[lz * A] / fs;
+          GNX_NOUNROLL for (int a = 1; a < A; ++a) mx = fmaxf(mx, exw[lz * A + a] / fs);
+        }
+        const float p_orig = fmaxf(pmax[2 * (center + 1)], pmax[2 * (center + 1) + 1]);  // prob_comp="max" over hap and ancestry
+        const float p_sw = fmaxf(__shfl(mx, 0), __shfl(mx, 1));
+        accept = p_sw * 0.5f > p_orig * 0.5f;                      // prior_switch_prob = 0.5 (gnofix.py:171)
+      }
+      TICK(5)
+      if (!accept) { w = w_next; continue; }
+      pf_valid = false;
+
+      // ---- accept: flip the parity from w on, relabel ----
+      ++n_switch;
+      GNX_NOUNROLL for (int q = tz; q < NWD; q += THREADS) {
         const int b0 = q * 32;
         uint32_t m = 0;
         if (w <= b0) m = 0xffffffffu;
         else if (w < b0 + 32) m = 0xffffffffu << (w - b0);
         par[q] ^= m;
       }
+      if (tz == 0) { flags[2] = W; flags[3] = 0; }
       __syncthreads();
-      // rows whose sliding window only sees windows >= w: the two haplotypes' rows are exchanged
-      // rows that see windows on both sides of w: re-evaluate.  Row w' sees unpadded windows
-      // {slide_src(w'+s)} = [max(0,w'-pad) .. min(W-1,w'+S-1-pad)] plus reflections that stay inside it
-      // except at the edges, where the reflected part can reach further: handled by the explicit min/max.
-      // (The rows to re-evaluate form one contiguous range [r0, r1): re-evaluating a row of that range that needed nothing, or one
-      // that was also swapped, just recomputes its label from the current strips.)
-      if (tid == 0) { flags[2] = W; flags[3] = 0; }
-      __syncthreads();
-      for (int wr = tid; wr < W; wr += THREADS) {  // every row classified by its own thread
+      // Row w' sees unpadded windows {slide_src(w'+s)}: rows that only see windows >= w exchange their two labels, rows that see
+      // both sides are re-evaluated.  (The rows to re-evaluate form one contiguous range [r0, r1): re-evaluating a row of that range
+      // that needed nothing, or one that was also swapped, just recomputes its label from the current strips.)
+      GNX_NOUNROLL for (int wr = tz; wr < W; wr += THREADS) {
         int mn = W, mx = -1;
-        // sources: j = wr .. wr+S-1
         const int j0 = wr, j1 = wr + S - 1;
-        // interior part
         const int a0 = max(j0, pad), a1 = min(j1, pad + W - 1);
         if (a0 <= a1) { mn = min(mn, a0 - pad); mx = max(mx, a1 - pad); }
         if (j0 < pad) { const int b1 = min(j1, pad - 1); mn = min(mn, pad - 1 - b1); mx = max(mx, pad - 1 - j0); }
         if (j1 >= pad + W) { const int b0 = max(j0, pad + W); mn = min(mn, W - 1 - (j1 - pad - W)); mx = max(mx, W - 1 - (b0 - pad - W)); }
-        if (mn >= w) {  // pure swap
-          const uint8_t t0 = Y[wr];
-          Y[wr] = Y[W + wr];
-          Y[W + wr] = t0;
+        if (mn >= w) {
+          const uint16_t y = Y[wr];
+          Y[wr] = (uint16_t)((y >> 8) | (y << 8));
+          const float p0 = pmax[2 * wr];
+          pmax[2 * wr] = pmax[2 * wr + 1];
+          pmax[2 * wr + 1] = p0;
         } else if (mx >= w) {
           atomicMin(&flags[2], wr);
           atomicMax(&flags[3], wr + 1);
@@ -321,167 +590,140 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
       }
       __syncthreads();
       const int r0 = flags[2], r1 = flags[3];
-      TICK(4)
-      // re-evaluate rows (h, r0..r1-1), S+2 windows at a time, class by class: the class's trees are staged in LDS (leafbuf is idle here), P lanes share a
-      // row and split the staged trees, and the row's sum is taken in tree order by handing the running sum down those lanes
-      const int tree_bytes = L.d.tree_bytes, cap = min((int)(gnofix_leafbuf_bytes(NT, tree_bytes) / tree_bytes), 64 * RE_PER);
-      uint8_t* stage_t = reinterpret_cast<uint8_t*>(leafbuf);
-      for (int gb = r0; gb < r1; gb += S + 2) {
-        const int nwin = min(S + 2, r1 - gb), nrow = 2 * nwin;  // row rr = (window gb + (rr >> 1), haplotype rr & 1)
-        if constexpr (!SL) {  // the rows read padded windows [gb, gb + nwin + S - 1) of both strips
-          const int nj = nwin + S - 1;
-          for (int e = tid; e < 2 * nj * A; e += THREADS) {
-            const int h = e / (nj * A), r = e - h * nj * A;
-            seg[(size_t)h * SEGW * A + r] = bp[((size_t)h * Wp + gb) * A + r];
-          }
+      TICK(6)
+      const int gstep = NROW / 2;
+      for (int gb = r0; gb < r1; gb += gstep) {
+        const int nwin = min(gstep, r1 - gb), nrow = 2 * nwin, nj = nwin + S - 1;  // rows read padded windows [gb, gb + nj)
+        GNX_NOUNROLL for (int e = tz; e < 2 * nj * A; e += THREADS) {
+          const int h = e >= nj * A ? 1 : 0, f = e - h * nj * A;
+          const int q = (int)__umulhi((uint32_t)f, invA), a = f - q * A;
+          const int u = slide_src(gb + q, W, pad);
+          seg[(h * A + a) * GP + q] = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
         }
-        for (int c = 0; c < A; ++c) {
-          const int t0 = L.class_tree0[c], t1 = L.class_tree0[c + 1];
-          for (int ts = t0; ts < t1; ts += cap) {
-            const int n_st = min(cap, t1 - ts);
-            __syncthreads();
-            {
-              const uint4* src = reinterpret_cast<const uint4*>(L.d.packed + (size_t)ts * tree_bytes);
-              uint4* dst = reinterpret_cast<uint4*>(stage_t);
-              for (int q = tid; q < n_st * (tree_bytes / 16); q += THREADS) dst[q] = src[q];
+        // lane = row (haplotype rh, window gb + rk) of row set `set`; set s walks class c0 + s
+        const int nset = min(NSETMAX, THREADS / nrow);
+        const int set = tz / nrow, rr = tz - set * nrow;
+        const bool rlive = set < nset;
+        const int rh = rr >= nwin ? 1 : 0, rk = rr - rh * nwin;
+        const uint8_t* rrow = reinterpret_cast<const uint8_t*>(seg) + ((size_t)rh * A * GP + rk) * 2;
+        const uint32_t* mystage = stage + (size_t)(rlive ? set : 0) * L.cap * TW;
+        GNX_NOUNROLL for (int c0 = 0; c0 < A; c0 += nset) {
+          const int c = c0 + set;
+          const bool clive = rlive && c < A;
+          const int t0 = clive ? L.class_tree0[c] : 0, cn = clive ? L.class_tree0[c + 1] - t0 : 0;
+          float ps = 0.f;
+          GNX_NOUNROLL for (int k0 = 0; k0 < nmax; k0 += L.cap) {
+            __syncthreads();  // the tile is complete / the previous chunk has been walked
+            GNX_NOUNROLL for (int sq = 0; sq < nset && c0 + sq < A; ++sq) {  // block-uniform
+              const int ts = L.class_tree0[c0 + sq] + k0, n_s = max(0, min(L.cap, L.class_tree0[c0 + sq + 1] - ts));
+              const uint4* src = reinterpret_cast<const uint4*>(GTp + (size_t)ts * TW);
+              uint4* dst = reinterpret_cast<uint4*>(stage + (size_t)sq * L.cap * TW);
+              GNX_NOUNROLL for (int q = tz; q < n_s * (TW / 4); q += THREADS) dst[q] = src[q];
             }
             __syncthreads();
-            // P lanes per row, rows never straddling a wave: the most lanes that still cover all rows in one pass of the block
-            // (at least enough for a lane's share of the staged trees to fit its registers)
-            int P = (n_st + RE_PER - 1) / RE_PER;
-            while (P < 64 && (P + 1) * 4 <= n_st && (nrow + 64 / (P + 1) - 1) / (64 / (P + 1)) <= NWAVES) ++P;
-            const int rpw = 64 / P;                      // rows per wave
-            const int per = (n_st + P - 1) / P;
-            const int n_pass = (nrow + rpw * NWAVES - 1) / (rpw * NWAVES);
-            for (int pass = 0; pass < n_pass; ++pass) {
-              const int p = ln % P, rr_ = (pass * NWAVES + wv) * rpw + ln / P;
-              const bool live = ln < rpw * P && rr_ < nrow;
-              const int rr = live ? rr_ : 0;
-              const int k = rr >> 1, h = rr & 1;
-              const uint8_t* row = reinterpret_cast<const uint8_t*>(SL ? bp + ((size_t)h * Wp + gb + k) * A : seg + ((size_t)h * SEGW + k) * A);
-              const int lo_t = min(p * per, n_st), cnt = live ? min(per, n_st - lo_t) : 0;
-              float lf[RE_PER];
+            const int n_st = max(0, min(L.cap, cn - k0));
+            GNX_NOUNROLL for (int t = 0; t < n_st; t += NWR) {
+              float ov[NWR];
+              walk_seq<NWR, DT, true>(TreesLds{mystage}, (uint32_t)t, (uint32_t)(n_st - 1), rrow, D, ov);
 #pragma unroll
-              for (int b = 0; b < RE_PER; b += NWALK) {
-                if (b < per && b < cnt) {
-                  const uint8_t* tb[NWALK];
-                  const uint8_t* rw[NWALK];
-                  float o[NWALK];
-#pragma unroll
-                  for (int i = 0; i < NWALK; ++i) { tb[i] = stage_t + (size_t)min(lo_t + b + i, n_st - 1) * tree_bytes; rw[i] = row; }
-                  walk_n<NWALK>(tb, rw, D, o);
-#pragma unroll
-                  for (int i = 0; i < NWALK; ++i) lf[b + i] = o[i];
-                }
-              }
-              float ps = (ts == t0) ? 0.f : marg[rr * A + c];  // (only lane p == 0 uses it)
-              for (int step = 0; step < P; ++step) {
-                const float up = __shfl_up(ps, 1);
-                if (p == step) {
-                  if (step > 0) ps = up;
-#pragma unroll
-                  for (int i = 0; i < RE_PER; ++i) if (i < per && i < cnt) ps += lf[i];  // tree order
-                }
-              }
-              if (live && p == P - 1) marg[rr * A + c] = ps;
+              for (int i = 0; i < NWR; ++i)
+                if (t + i < n_st) ps += ov[i];  // tree order
             }
           }
+          if (clive) marg[c * NROW + rr] = L.base_score + ps;
         }
         __syncthreads();
-        for (int e = tid; e < nrow * A; e += THREADS) {  // margin -> exp(margin - row max), one (row, class) per thread
-          const int rr = e / A;
-          float wmax = L.d.base_score + marg[rr * A];
-          for (int a = 1; a < A; ++a) wmax = fmaxf(L.d.base_score + marg[rr * A + a], wmax);
-          swrows[e] = (float)exp((double)((L.d.base_score + marg[e]) - wmax));  // (swrows is idle here)
+        // the rows' softmax: every set takes the exponentials of its classes (three short phases: row maximum, exp in place, sum + arg-max)
+        float wmax = 0.f;
+        if (rlive) {
+          wmax = marg[rr];
+          GNX_NOUNROLL for (int a = 1; a < A; ++a) wmax = fmaxf(marg[a * NROW + rr], wmax);
         }
         __syncthreads();
-        for (int rr = tid; rr < nrow; rr += THREADS) {
-          const float* m = swrows + rr * A;
+        if (rlive) {
+          GNX_NOUNROLL for (int a = set; a < A; a += nset) marg[a * NROW + rr] = (float)exp((double)(marg[a * NROW + rr] - wmax));
+        }
+        __syncthreads();
+        if (rlive && set == 0) {  // first maximum wins
           double wsum = 0.0;
-          for (int a = 0; a < A; ++a) wsum += (double)m[a];
+          GNX_NOUNROLL for (int a = 0; a < A; ++a) wsum += (double)marg[a * NROW + rr];
           const float fs = (float)wsum;
           int best = 0;
-          float bv = m[0] / fs;
-          for (int a = 1; a < A; ++a) { const float v = m[a] / fs; if (v > bv) { bv = v; best = a; } }
-          Y[(rr & 1) * W + gb + (rr >> 1)] = (uint8_t)best;
+          float bv = marg[rr] / fs;
+          GNX_NOUNROLL for (int a = 1; a < A; ++a) { const float v = marg[a * NROW + rr] / fs; if (v > bv) { bv = v; best = a; } }
+          reinterpret_cast<uint8_t*>(Y)[2 * (gb + rk) + rh] = (uint8_t)best;
+          pmax[2 * (gb + rk) + rh] = bv;
         }
         __syncthreads();
       }
-      TICK(5)
+      mark_changes(tz);
+      __syncthreads();
+      w = next_change(w + 1);
+      TICK(7)
     }
-    TICK(2)
+    __syncthreads();  // (the history row of this sweep is complete before the next convergence test reads it)
   }
 
-  // ---- outputs: labels, switch count, SNP swap from the final parity (phasing.py:188-198) ----
-  for (int e = tid; e < 2 * W; e += THREADS) L.Yout[(size_t)2 * ind * W + e] = Y[e];
-  TICK(2)
-  // Only windows of odd parity are touched; they come in a few long runs (every accepted switch flips "from w to the end"), so the
-  // block sweeps each run as one byte range, four 16-byte pieces per thread in flight for each row.
-  __syncthreads();                                  // Y is free from here: it takes the run starts
-  int* runs = reinterpret_cast<int*>(Y);            // <= W/2 starts, 2W bytes
-  if (tid == 0) flags[2] = 0;
+  // ---- outputs: labels, switch count, final parity (k_gnofix_swap applies it to the SNPs) ----
   __syncthreads();
-  auto flipped = [&](int u) { return ((par[u >> 5] >> (u & 31)) & 1u) != 0; };
-  for (int u = tid; u < W; u += THREADS)
-    if (flipped(u) && (u == 0 || !flipped(u - 1))) runs[atomicAdd(&flags[2], 1)] = u;
-  __syncthreads();
-  const int n_runs = flags[2];
-  for (int r = 0; r < n_runs; ++r) {
-    const int ua = runs[r];
-    int ub = ua + 1;
-    while (ub < W && flipped(ub)) ++ub;             // (block-uniform scan; runs are few)
-    const int64_t j0 = (int64_t)ua * ws, j1 = (ub == W) ? C : (int64_t)ub * ws;
-    const int64_t n16 = (j1 - j0) / 16;
-    for (int64_t k0 = 0; k0 < n16; k0 += 4 * THREADS) {
-      snp16 xa[4], xb[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t k = k0 + q * THREADS + tid;
-        if (k < n16) { xa[q] = ld16(Xm + j0 + k * 16); xb[q] = ld16(Xp + j0 + k * 16); }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t k = k0 + q * THREADS + tid;
-        if (k < n16) { st16(Xm + j0 + k * 16, xb[q]); st16(Xp + j0 + k * 16, xa[q]); }
-      }
-    }
-    for (int64_t j = j0 + n16 * 16 + tid; j < j1; j += THREADS) {
-      const int8_t t0 = Xm[j];
-      Xm[j] = Xp[j];
-      Xp[j] = t0;
-    }
+  for (int u = tid; u < W; u += THREADS) {
+    L.Yout[(size_t)2 * ind * W + u] = Y[u] & 0xff;
+    L.Yout[(size_t)(2 * ind + 1) * W + u] = Y[u] >> 8;
   }
-  TICK(6)
+  for (int q = tid; q < NWD; q += THREADS) L.par[(size_t)ind * NWD + q] = par[q];
 #ifdef GNX_GNOFIX_CLOCKS
-  tacc[7] = tprev - tstart;
   if (tid == 0 && L.n_switches) L.n_switches[ind] = (int)(tacc[ind & 7] >> 6);
 #else
   if (tid == 0 && L.n_switches) L.n_switches[ind] = n_switch;
 #endif
 }
 
-}  // namespace
-
-size_t gnx_gnofix_lds_bytes(int W, int A, int S, int n_trees, int tree_bytes, bool bp_in_lds) {
-  const int pad = (S + 1) / 2, Wp = W + 2 * pad, NWD = (W + 31) / 32;
-  auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  size_t t = 0;
-  if (bp_in_lds) t += r16((size_t)2 * Wp * A * 4);
-  t += r16(gnofix_swrows_bytes(S, A, bp_in_lds)) + (bp_in_lds ? 0 : r16((size_t)2 * (2 * S + 2) * A * 4)) +
-       r16(gnofix_leafbuf_bytes(n_trees, tree_bytes)) + r16((size_t)2 * (S + 2) * A * 4) + r16((size_t)2 * W + 16) +
-       2 * r16((size_t)NWD * 4) + 128;
-  return t;
+template <int THREADS>
+hipError_t launch_t(const GnofixLaunch& G, int64_t n_ind, hipStream_t s) {
+  const size_t lds = gnofix_lds(G.W, G.A, G.S, G.gf_pitch, G.gf_cap, G.d.D, THREADS, G.d.n_trees).total;
+  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  const GnofixK L{G.R, G.dif, G.par, G.gf, G.class_tree0, G.Y0, G.pmax0, G.Yout, G.n_switches, G.hist, G.W, G.A, G.S, G.max_it, G.d.D, G.d.n_trees,
+                  G.gf_pitch, G.gf_cap, G.d.base_score};
+  if (G.d.D == 4) {
+    GNX_LDS_OPTIN(lds, k_gnofix<THREADS, 4>);
+    hipLaunchKernelGGL((k_gnofix<THREADS, 4>), dim3((unsigned)n_ind), dim3(THREADS), lds, s, L);
+  } else {
+    GNX_LDS_OPTIN(lds, k_gnofix<THREADS, 0>);
+    hipLaunchKernelGGL((k_gnofix<THREADS, 0>), dim3((unsigned)n_ind), dim3(THREADS), lds, s, L);
+  }
+  return hipGetLastError();
 }
 
-hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, hipStream_t s) {
+}  // namespace
+
+// staged trees per row set and chunk of the re-evaluation: a whole class where ~40 KB hold one per row set, a multiple of NWR
+int gnx_gnofix_cap(int max_class_trees, int D, int S, int threads) {
+  const int tb = gnx_gf_tree_words(D) * 4, nset = std::max(1, threads / gnofix_rows_max(S, threads));
+  const int cap = std::max(NWR, (40960 / (tb * nset)) / NWR * NWR);
+  return std::min(cap, (max_class_trees + NWR - 1) / NWR * NWR);
+}
+
+size_t gnx_gnofix_lds_bytes(int W, int A, int S, int pitch, int cap, int D, int threads, int n_trees) {
+  return gnofix_lds(W, A, S, pitch, cap, D, threads, n_trees).total;
+}
+
+hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, int threads, hipStream_t s) {
   if (n_ind <= 0) return hipSuccess;
-  const size_t lds = gnx_gnofix_lds_bytes(L.W, L.A, L.S, L.d.n_trees, L.d.tree_bytes, L.bp_in_lds != 0);
-  if (L.bp_in_lds) {
-    GNX_LDS_OPTIN(lds, k_gnofix<true>);
-    hipLaunchKernelGGL(k_gnofix<true>, dim3((unsigned)n_ind), dim3(THREADS), lds, s, L);
-  } else {
-    GNX_LDS_OPTIN(lds, k_gnofix<false>);
-    hipLaunchKernelGGL(k_gnofix<false>, dim3((unsigned)n_ind), dim3(THREADS), lds, s, L);
+  const int NWD = (L.W + 31) / 32;
+  {  // ranks of the base probabilities, "SNP block differs" masks
+    const int64_t n = 2 * n_ind * (int64_t)L.W * L.A;
+    hipLaunchKernelGGL(k_gnofix_ranks, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, L.B, n, L.d.rk_thr, L.d.rk_lut, L.d.rk_K,
+                       L.d.rk_steps, const_cast<uint16_t*>(L.R));
+    hipLaunchKernelGGL(k_gnofix_pmax, dim3((unsigned)((2 * n_ind * L.W + 255) / 256)), dim3(256), 0, s, L.proba0, 2 * n_ind * (int64_t)L.W, L.A,
+                       const_cast<float*>(L.pmax0));
+    hipLaunchKernelGGL(k_gnofix_dif, dim3((unsigned)((NWD + 3) / 4), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W,
+                       const_cast<uint32_t*>(L.dif));
   }
+  hipError_t e;
+  if (threads == 256) e = launch_t<256>(L, n_ind, s);
+  else if (threads == 1024) e = launch_t<1024>(L, n_ind, s);
+  else e = launch_t<512>(L, n_ind, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_gnofix_swap, dim3((unsigned)((L.C + 16383) / 16384), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W, L.par);
   return hipGetLastError();
 }

@@ -40,18 +40,15 @@ def _lr_data(ga, C, M, A, ctx, seed):
 
 
 # ---------------------------------------------------------------- logistic base ------------------
-@pytest.fixture(params=["i8", "i8dl", "i8fl", "i8ws", "i8w512", "f64"])
+@pytest.fixture(params=["i8", "i8dl", "f64"])
 def lr_impl(request, monkeypatch):
-    """every variant of the logistic pass on every geometry: exact int8-limb fixed point with register-staged loads
-    (k_base_logistic_i8), the same arithmetic with LDS-direct loads (k_base_logistic_i8_dl), with LDS-direct loads issued by
-    dedicated producer waves (k_base_logistic_i8_ws), and f64 MFMA.  Launch knobs are read once per context, so each variant gets a
-    context of its own."""
+    """every shipped variant of the logistic pass on every geometry: exact int8-limb fixed point with register-staged loads
+    (k_base_logistic_i8), the same arithmetic with LDS-direct loads (k_base_logistic_i8_dl), and f64 MFMA.  Launch knobs are read
+    once per context, so each variant gets a context of its own.  (The measured-slower structures of DESIGN.md 5.2 live under
+    scripts/dev/rejected/ and are built by `make EXPERIMENTS=1` only.)"""
     from gnomix_amd import _lib
     monkeypatch.setenv("GNX_BASE_LR_IMPL", "f64" if request.param == "f64" else "i8")
     monkeypatch.setenv("GNX_LR_DL", "1" if request.param == "i8dl" else "0")
-    monkeypatch.setenv("GNX_LR_FLAT", "1" if request.param == "i8fl" else "0")      # flat column tiles where the model has them (8..13 tiles)
-    monkeypatch.setenv("GNX_LR_WS", "1" if request.param == "i8ws" else "0")
-    monkeypatch.setenv("GNX_LR_W512", "1" if request.param == "i8w512" else "0")   # 512 rows per block, 64-SNP steps
     return _lib.Context(0)
 
 
@@ -713,18 +710,7 @@ def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S
         pr, lr = ga.DeviceModel(d).smooth_predict(B)
         assert np.array_equal(pf, pr, equal_nan=True), rpl
         assert np.array_equal(lf, lr), rpl
-    # lane = haplotype kernel (k_smooth_ranks + k_smooth_xgb_h64): same ranks, same leaf order -> the same bits
-    monkeypatch.setenv("GNX_SMOOTH_IMPL", "h64")
     monkeypatch.delenv("GNX_RK_RPL")
-    for nw in ("16", "8", "4"):
-        monkeypatch.setenv("GNX_SM_NW", nw)
-        from gnomix_amd import _lib
-        ctx = _lib.Context(0)                                                 # GNX_SM_NW is read at gnx_init
-        ph, lh = ga.DeviceModel(d, ctx=ctx).smooth_predict(B)
-        assert np.array_equal(pf, ph, equal_nan=True), nw
-        assert np.array_equal(lf, lh), nw
-        ctx.close()
-    monkeypatch.delenv("GNX_SM_NW")
     finite = np.isfinite(B).all(axis=(1, 2))                                  # oracle as the third opinion
     T = _oracle_trees(oracle, d)
     p_ref, l_ref = oracle.smooth_xgb(T, B[finite], S)
