@@ -913,7 +913,7 @@ static int gnofix_check(gnx_model* m, int64_t ldx, int64_t n_ind, int32_t max_it
 
 // scratch of one device-resident batch of n individuals (grows only).  ws_misc: [hist | par | dif | ranks] (rank kernel) or
 // [hist | float32 strips] (fallback, strips that do not fit the LDS)
-struct GnofixWs { size_t par = 0, dif = 0, rk = 0, pm = 0, bp = 0; };
+struct GnofixWs { size_t par = 0, dif = 0, rk = 0, pm = 0, ord = 0, bp = 0; };
 static int gnofix_ws_reserve(gnx_model* m, int64_t n, int32_t max_it, bool in_lds, GnofixWs* out) {
   gnx_ctx* ctx = m->ctx;
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S, pad = (S + 1) / 2;
@@ -929,6 +929,7 @@ static int gnofix_ws_reserve(gnx_model* m, int64_t n, int32_t max_it, bool in_ld
     o.dif = misc; misc += up((size_t)n * NWD * 4);
     o.rk = misc; misc += up((size_t)2 * n * WA * 2);
     o.pm = misc; misc += up((size_t)2 * n * W * 4);
+    o.ord = misc; misc += up(((size_t)2 * n + 2 * ((size_t)W + 1)) * 4);
   } else if (!in_lds) {
     o.bp = misc; misc += (size_t)n * 2 * (W + 2 * pad) * A * 4;
   }
@@ -945,19 +946,33 @@ static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* d
   GnofixWs ws;
   if ((rc = gnofix_ws_reserve(m, n, max_it, in_lds, &ws)) != GNX_OK) return rc;
   int32_t* dY0 = (int32_t*)ctx->ws_y0.p;
-  // initial labels = smoother.predict(B) for every haplotype at once (gnofix.py:80)
-  rc = gnx_smooth_predict_dev(m, dB, 1, 2 * n, (float*)ctx->ws_p32.p, nullptr, dY0);
-  if (rc != GNX_OK) return rc;
   GnofixLaunch L{};
   L.X = dX; L.ldx = ldx; L.C = m->info.C; L.B = dB; L.Y0 = dY0; L.Yout = dY; L.n_switches = dNs;
   L.W = W; L.A = A; L.S = S; L.max_it = max_it; L.d = m->xgb; L.class_tree0 = m->class_tree0;
   L.hist = (uint32_t*)ctx->ws_misc.p;
-  ProfScope ps(ctx, GNX_K_GNOFIX);
-  if (gnofix_use_rk(m)) {
+  const bool rk = gnofix_use_rk(m);
+  if (rk) {
     char* base = (char*)ctx->ws_misc.p;
     L.proba0 = (const float*)ctx->ws_p32.p; L.pmax0 = (const float*)(base + ws.pm);
+    L.order = (const int32_t*)(base + ws.ord);
     L.par = (uint32_t*)(base + ws.par); L.dif = (const uint32_t*)(base + ws.dif); L.R = (const uint16_t*)(base + ws.rk);
     L.gf = m->xgb.gf_packed; L.gf_pitch = m->xgb.gf_pitch; L.gf_cap = gnx_gnofix_cap(m->xgb.gf_max_class, m->xgb.D, S, gnofix_threads(m));
+    // ranks of B and the SNP-difference masks of X need nothing of the smoother: they run beside it on the side stream
+    if (!ctx->s_aux) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+      for (int b = 0; b < 2; ++b) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_aux[b], hipEventDisableTiming));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_aux[0], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_aux[0], 0));
+    HIPCHK(ctx, gnx_launch_gnofix_prep(L, n, ctx->s_aux));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_aux[1], ctx->s_aux));
+  }
+  // initial labels = smoother.predict(B) for every haplotype at once (gnofix.py:80)
+  rc = gnx_smooth_predict_dev(m, dB, 1, 2 * n, (float*)ctx->ws_p32.p, nullptr, dY0);
+  if (rk) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[1], 0));  // (also on failure: the side stream is joined)
+  if (rc != GNX_OK) return rc;
+  ProfScope ps(ctx, GNX_K_GNOFIX);
+  if (rk) {
     HIPCHK(ctx, gnx_launch_gnofix(L, n, gnofix_threads(m), ctx->stream));
     return GNX_OK;
   }
@@ -988,9 +1003,10 @@ int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_
   const size_t WA = (size_t)W * m->info.A;
   // Batches of whole individuals alternate between the two halves of the staging workspaces: X and B of batch i+1 go up, and X / labels
   // of batch i-1 come back, while batch i is re-phased (three streams; page-locked host memory — gnx_host_alloc — makes the overlap
-  // real, pageable memory is still correct).  A batch is a multiple of the CU count (one workgroup per individual) near 1 GiB of X.
+  // real, pageable memory is still correct).  A batch is a multiple of the CU count near 2 GiB of X (the link, not the kernels, bounds this entry: small batches keep the pipeline's fill and drain short): the per-individual kernel keeps
+  // two workgroups per CU busy and ends with its slowest individual, so a batch should hold several individuals per CU.
   const int64_t cu = std::max(ctx->n_cu, 1);
-  int64_t nb = std::max<int64_t>(1, (((int64_t)1 << 30) / std::max<int64_t>(ldx, 1)) / 2);
+  int64_t nb = std::max<int64_t>(1, (((int64_t)2 << 30) / std::max<int64_t>(ldx, 1)) / 2);
   if (nb >= cu) nb -= nb % cu;
   if (ctx->tune.host_batch > 0) nb = std::max<int64_t>(1, ctx->tune.host_batch / 2);
   nb = std::min(nb, n_ind);

@@ -309,6 +309,7 @@ struct GnofixLaunch {
   const uint32_t* gf;      // SmoothXGBDev::gf_packed
   const float* proba0;     // (2*n_ind, W, A) probabilities of the initial smoother pass (the labels Y0 come from)
   const float* pmax0;      // [2*n_ind][W] scratch: their row maxima
+  const int32_t* order;    // scratch: [n_ind] dispatch order | [W+1] histogram | [n_ind] change counts | [W+1] bucket starts
   int32_t gf_pitch, gf_cap;
 };
 
@@ -440,6 +441,7 @@ hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t
                                 uint32_t* planes, hipStream_t s);
 hipError_t gnx_launch_covrsk(const CovRSKLaunch& L, hipStream_t s);
 size_t gnx_covrsk_lds_bytes(int A, int max_nw, int max_width);
+hipError_t gnx_launch_gnofix_prep(const GnofixLaunch& L, int64_t n_ind, hipStream_t s);
 hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, int threads, hipStream_t s);
 size_t gnx_gnofix_lds_bytes(int W, int A, int S, int pitch, int cap, int D, int threads, int n_trees);
 int gnx_gnofix_cap(int max_class_trees, int D, int S, int threads);

@@ -79,6 +79,45 @@ __global__ __launch_bounds__(256) void k_gnofix_pmax(const float* __restrict__ P
   out[r] = m;
 }
 
+// ---- pre-pass 1c: longest-first dispatch order.  An individual's work grows with its label changes (every sweep evaluates a
+// candidate at each) and a launch ends with its slowest block: individuals are handed to the per-individual kernel in descending
+// order of their initial change count (counting sort: histogram, descending prefix, scatter; ties in any order — every individual's
+// result is independent of the order). ----
+__global__ __launch_bounds__(256) void k_gnofix_count(const int32_t* __restrict__ Y0, int W, int32_t* __restrict__ cnt, int32_t* __restrict__ hist) {
+  const int64_t ind = blockIdx.x;
+  const int32_t* ym = Y0 + (size_t)2 * ind * W;
+  const int32_t* yp = ym + W;
+  int c = 0;
+  for (int u = 1 + threadIdx.x; u < W; u += 256) c += (ym[u] != ym[u - 1] || yp[u] != yp[u - 1]) ? 1 : 0;
+  __shared__ int tot;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  atomicAdd(&tot, c);
+  __syncthreads();
+  if (threadIdx.x == 0) { cnt[ind] = tot; atomicAdd(&hist[tot], 1); }
+}
+__global__ __launch_bounds__(256) void k_gnofix_scan(const int32_t* __restrict__ hist, int W, int32_t* __restrict__ start) {
+  // descending exclusive prefix over the W + 1 bins by one block: thread t owns a run of bins, the runs' totals are scanned by thread 0
+  __shared__ int part[256];
+  const int per = (W + 1 + 255) / 256, t = threadIdx.x;
+  const int hi = W - t * per, lo = max(hi - per + 1, 0);  // bins hi, hi-1, .. lo
+  int sum = 0;
+  for (int c = hi; c >= lo; --c) sum += hist[c];
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int k = 0; k < 256; ++k) { const int v = part[k]; part[k] = acc; acc += v; }
+  }
+  __syncthreads();
+  int acc = part[t];
+  for (int c = hi; c >= lo; --c) { start[c] = acc; acc += hist[c]; }
+}
+__global__ __launch_bounds__(256) void k_gnofix_scatter(const int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ start, int32_t* __restrict__ order) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) order[atomicAdd(&start[cnt[i]], 1)] = (int32_t)i;
+}
+
 // ---- pre-pass 2: per individual and window, "the SNP block differs between the two haplotypes" (gnofix.py:108-113 compares whole
 // X_m vectors; with the switch parity, X_m(a) == X_m(b) iff parity_a & dif == parity_b & dif).  Window u covers SNPs
 // [u*ws, (u+1)*ws), ws = C // W, the last one up to C (gnofix.py:74, phasing.py:192).  One wave = one 32-bit word of the mask: four
@@ -286,7 +325,7 @@ __device__ __forceinline__ void walk4(const Trees T, uint32_t t0, const uint8_t*
 __host__ __device__ inline int gnofix_rows_max(int S, int threads) { return 2 * min(S + 2, threads / 2); }
 
 struct GnofixLds {
-  size_t seg, Y, pmax, par, dif, chg, marg, ex, stage, flags, total;
+  size_t seg, Y, pmax, par, dif, chg, marg, ex, stage, flags, ct0, total;
 };
 __host__ __device__ inline GnofixLds gnofix_lds(int W, int A, int S, int GP, int cap, int D, int threads, int n_trees) {
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
@@ -307,6 +346,7 @@ __host__ __device__ inline GnofixLds gnofix_lds(int W, int A, int S, int GP, int
     o.stage = off; off += r16(st > lb ? st : lb);
   }
   o.flags = off; off += 256;
+  o.ct0 = off; off += r16((size_t)(A + 1) * 4);
   o.total = off;
   return o;
 }
@@ -320,6 +360,7 @@ struct GnofixK {
   const int32_t* class_tree0;
   const int32_t* Y0;
   const float* P0;   // (2n, W) largest probability per row of the initial smoother pass
+  const int32_t* order;  // [n] individual handled by block b
   int32_t* Yout;
   int32_t* n_switches;
   uint32_t* hist;
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   const int W = L.W, A = L.A, S = L.S, pad = (S + 1) / 2, half = (S - 1) / 2;
   const int D = DT ? DT : L.D, NWD = (W + 31) / 32, GP = L.GP, TW = gnx_gf_tree_words(D), NT = L.NT;
   const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
-  const int64_t ind = blockIdx.x;
+  const int64_t ind = L.order[blockIdx.x];
   const GnofixLds o = gnofix_lds(W, A, S, GP, L.cap, D, THREADS, NT);
   uint16_t* seg = reinterpret_cast<uint16_t*>(lds + o.seg);   // [2][A][GP] ranks: the tile every walk reads
   uint16_t* Y = reinterpret_cast<uint16_t*>(lds + o.Y);       // labels: maternal | paternal << 8 per window
@@ -346,6 +387,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   float* marg = reinterpret_cast<float*>(lds + o.marg);       // candidate: [2][A]; re-evaluation: [A][NROW]
   float* ex = reinterpret_cast<float*>(lds + o.ex);           // candidate: exp(margin - row max) [2][A], one copy per wave
   uint32_t* stage = reinterpret_cast<uint32_t*>(lds + o.stage);  // re-evaluation: staged trees of one class
+  int* ct0s = reinterpret_cast<int*>(lds + o.ct0);            // class_tree0 (A + 1 entries)
   int* flags = reinterpret_cast<int*>(lds + o.flags);         // [0] accept, [2],[3] rows to re-evaluate [r0, r1), [8..40) past sweeps that differ
   uint32_t* hist = L.hist + (size_t)ind * L.max_it * NWD;
   const uint16_t* __restrict__ R0 = L.R + (size_t)2 * ind * W * A;  // physical haplotype h at + h*W*A
@@ -354,6 +396,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   const int NROW = gnofix_rows_max(S, THREADS), NSETMAX = max(1, THREADS / NROW);
   int nmax = 0;  // most trees of one class
   for (int c = 0; c < A; ++c) nmax = max(nmax, L.class_tree0[c + 1] - L.class_tree0[c]);
+  if (threadIdx.x <= A) ct0s[threadIdx.x] = L.class_tree0[threadIdx.x];  // (published by the barrier of the load phase)
 #ifdef GNX_GNOFIX_CLOCKS  // development aid (scripts/dev/gnofix_phases.py): individual i reports phase (i & 7) in n_switches, units of 64 clocks
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
@@ -510,8 +553,8 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
         if (tz < 2 * A) {  // per (row, class): the float32 sum of the class's leaves in tree order (class-major packing)
           const int r = (int)__umulhi((uint32_t)tz, invA), c = tz - r * A;
           const float* lb = leafbuf + r * NT;
-          const int t1 = L.class_tree0[c + 1];
-          int t = L.class_tree0[c];
+          const int t1 = ct0s[c + 1];
+          int t = ct0s[c];
           float ps = 0.f;
           GNX_NOUNROLL for (; t + 8 <= t1; t += 8) {  // loads first, then the adds in tree order
             float v[8];
@@ -610,15 +653,33 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
         GNX_NOUNROLL for (int c0 = 0; c0 < A; c0 += nset) {
           const int c = c0 + set;
           const bool clive = rlive && c < A;
-          const int t0 = clive ? L.class_tree0[c] : 0, cn = clive ? L.class_tree0[c + 1] - t0 : 0;
+          const int t0 = clive ? ct0s[c] : 0, cn = clive ? ct0s[c + 1] - t0 : 0;
           float ps = 0.f;
           GNX_NOUNROLL for (int k0 = 0; k0 < nmax; k0 += L.cap) {
             __syncthreads();  // the tile is complete / the previous chunk has been walked
-            GNX_NOUNROLL for (int sq = 0; sq < nset && c0 + sq < A; ++sq) {  // block-uniform
-              const int ts = L.class_tree0[c0 + sq] + k0, n_s = max(0, min(L.cap, L.class_tree0[c0 + sq + 1] - ts));
-              const uint4* src = reinterpret_cast<const uint4*>(GTp + (size_t)ts * TW);
-              uint4* dst = reinterpret_cast<uint4*>(stage + (size_t)sq * L.cap * TW);
-              GNX_NOUNROLL for (int q = tz; q < n_s * (TW / 4); q += THREADS) dst[q] = src[q];
+            {  // the chunk [k0, k0 + cap) of the classes c0 .. c0 + nset - 1, one after the other in the stage: all of a thread's
+               // 16-byte pieces are requested before the first is stored (one L2 round trip per chunk, not one per piece)
+              constexpr int NST = 6;
+              const int per_set = L.cap * (TW / 4), total = nset * per_set;
+              const uint4* src = reinterpret_cast<const uint4*>(GTp);
+              uint4* dst = reinterpret_cast<uint4*>(stage);
+              GNX_NOUNROLL for (int g0 = 0; g0 < total; g0 += NST * THREADS) {
+                uint4 v[NST];
+                bool ok[NST];
+#pragma unroll
+                for (int k = 0; k < NST; ++k) {
+                  const int g = g0 + tz + k * THREADS;
+                  const int sq = g / per_set, wi = g - sq * per_set, cq = c0 + sq;
+                  ok[k] = g < total && cq < A;
+                  const int ts = ok[k] ? ct0s[cq] + k0 : 0;
+                  const int n_s = ok[k] ? max(0, min(L.cap, ct0s[cq + 1] - ts)) : 0;
+                  ok[k] = ok[k] && wi < n_s * (TW / 4);
+                  v[k] = src[ok[k] ? (size_t)ts * (TW / 4) + wi : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < NST; ++k)
+                  if (ok[k]) dst[g0 + tz + k * THREADS] = v[k];
+              }
             }
             __syncthreads();
             const int n_st = max(0, min(L.cap, cn - k0));
@@ -682,7 +743,7 @@ template <int THREADS>
 hipError_t launch_t(const GnofixLaunch& G, int64_t n_ind, hipStream_t s) {
   const size_t lds = gnofix_lds(G.W, G.A, G.S, G.gf_pitch, G.gf_cap, G.d.D, THREADS, G.d.n_trees).total;
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
-  const GnofixK L{G.R, G.dif, G.par, G.gf, G.class_tree0, G.Y0, G.pmax0, G.Yout, G.n_switches, G.hist, G.W, G.A, G.S, G.max_it, G.d.D, G.d.n_trees,
+  const GnofixK L{G.R, G.dif, G.par, G.gf, G.class_tree0, G.Y0, G.pmax0, G.order, G.Yout, G.n_switches, G.hist, G.W, G.A, G.S, G.max_it, G.d.D, G.d.n_trees,
                   G.gf_pitch, G.gf_cap, G.d.base_score};
   if (G.d.D == 4) {
     GNX_LDS_OPTIN(lds, k_gnofix<THREADS, 4>);
@@ -707,17 +768,33 @@ size_t gnx_gnofix_lds_bytes(int W, int A, int S, int pitch, int cap, int D, int 
   return gnofix_lds(W, A, S, pitch, cap, D, threads, n_trees).total;
 }
 
-hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, int threads, hipStream_t s) {
+// what depends on the inputs only (ranks of B, "SNP block differs" masks of X): the caller runs it on a side stream beside the
+// initial smoother pass (HBM-bound kernels next to an LDS-bound one)
+hipError_t gnx_launch_gnofix_prep(const GnofixLaunch& L, int64_t n_ind, hipStream_t s) {
   if (n_ind <= 0) return hipSuccess;
   const int NWD = (L.W + 31) / 32;
-  {  // ranks of the base probabilities, "SNP block differs" masks
-    const int64_t n = 2 * n_ind * (int64_t)L.W * L.A;
-    hipLaunchKernelGGL(k_gnofix_ranks, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, L.B, n, L.d.rk_thr, L.d.rk_lut, L.d.rk_K,
-                       L.d.rk_steps, const_cast<uint16_t*>(L.R));
+  const int64_t n = 2 * n_ind * (int64_t)L.W * L.A;
+  hipLaunchKernelGGL(k_gnofix_ranks, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, L.B, n, L.d.rk_thr, L.d.rk_lut, L.d.rk_K,
+                     L.d.rk_steps, const_cast<uint16_t*>(L.R));
+  hipLaunchKernelGGL(k_gnofix_dif, dim3((unsigned)((NWD + 3) / 4), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W,
+                     const_cast<uint32_t*>(L.dif));
+  return hipGetLastError();
+}
+
+// after the initial smoother pass (Y0, proba0) and gnx_launch_gnofix_prep
+hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, int threads, hipStream_t s) {
+  if (n_ind <= 0) return hipSuccess;
+  {
+    hipError_t e0 = hipMemsetAsync(const_cast<int32_t*>(L.order) + n_ind, 0, (size_t)(L.W + 1) * 4, s);  // scratch behind the order: hist[W+1] | cnt[n] | start[W+1]
+    if (e0 != hipSuccess) return e0;
+    int32_t* cnt = const_cast<int32_t*>(L.order) + n_ind + (L.W + 1);
+    int32_t* hist = const_cast<int32_t*>(L.order) + n_ind;
+    int32_t* start = cnt + n_ind;
+    hipLaunchKernelGGL(k_gnofix_count, dim3((unsigned)n_ind), dim3(256), 0, s, L.Y0, L.W, cnt, hist);
+    hipLaunchKernelGGL(k_gnofix_scan, dim3(1), dim3(256), 0, s, hist, L.W, start);
+    hipLaunchKernelGGL(k_gnofix_scatter, dim3((unsigned)((n_ind + 255) / 256)), dim3(256), 0, s, cnt, n_ind, start, const_cast<int32_t*>(L.order));
     hipLaunchKernelGGL(k_gnofix_pmax, dim3((unsigned)((2 * n_ind * L.W + 255) / 256)), dim3(256), 0, s, L.proba0, 2 * n_ind * (int64_t)L.W, L.A,
                        const_cast<float*>(L.pmax0));
-    hipLaunchKernelGGL(k_gnofix_dif, dim3((unsigned)((NWD + 3) / 4), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W,
-                       const_cast<uint32_t*>(L.dif));
   }
   hipError_t e;
   if (threads == 256) e = launch_t<256>(L, n_ind, s);
