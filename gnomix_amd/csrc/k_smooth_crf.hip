@@ -551,6 +551,166 @@ __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
   }
 }
 
+// ---- round 4: the same recurrence with CHECKPOINTED alphas (default) ---------------------------------------------------------------
+// k_smooth_crf_row16 is HBM-bound at chr1 / A = 12 (16.9 GB per launch: psi twice, every alpha and (c_t, 1/c_t) pair out and back,
+// marginals out).  Here the forward sweep parks alpha only at the end of every SEG-window segment; the backward sweep takes a segment's
+// psi (the registers of its prefetch stage), recomputes the segment's alphas and scales from the parked vector into wave-private LDS
+// (same instruction sequence: same bits) and runs beta through it.  Per launch: psi twice + marginals + 1/SEG of the alphas twice =
+// 11.2 GB instead of 16.9.  FWDPSI: the forward sweep computes psi from B itself (off the chain) and writes it for the backward
+// sweep — no k_crf_psi pass (B once + psi out instead of B once + psi out + psi in).
+template <int AT, bool FWDPSI>
+__global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
+  constexpr int SEG = 8;
+  __shared__ double la[4][SEG][64];      // [wave][step][lane] recomputed alpha_t(y)
+  __shared__ double2 lsc[4][SEG][4];     // [wave][step][row] (1/c_t, c_t)
+  const int A = L.A, W = L.W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y = lane & 15, row = lane >> 4;
+  const int64_t n = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 4 + row;
+  const bool label = y < A, active = label && n < L.N;
+  const int64_t nn = (n < L.N) ? n : 0;
+  const size_t row0 = (size_t)nn * W * A;
+  const int NSEG = (W + SEG - 1) / SEG;
+  double* ck = L.alpha + (size_t)nn * NSEG * A;  // [segment][label] alpha at the segment's last window
+
+  double Ef[AT], Eb[AT], Th[FWDPSI ? AT : 1];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+    const bool ok = label && i < A;
+    Ef[i] = ok ? L.etrans[i * A + y] : 0.0;
+    Eb[i] = ok ? L.etrans[y * A + i] : 0.0;
+    if constexpr (FWDPSI) Th[i] = ok ? L.state[i * A + y] : 0.0;
+  }
+  auto clampt = [&](int t) { return t < 0 ? 0 : (t > W - 1 ? W - 1 : t); };
+  const int yl = label ? y : 0;
+  auto loadB = [&](int t) -> double {
+    const size_t idx = row0 + (size_t)t * A + yl;
+    const double v = L.b_is_f64 ? reinterpret_cast<const double*>(L.B)[idx] : (double)reinterpret_cast<const float*>(L.B)[idx];
+    return label ? v : 0.0;
+  };
+  auto loadPsi = [&](int t) -> double { const double v = L.psi[row0 + (size_t)t * A + yl]; return label ? v : 0.0; };
+  // one step of the scaled forward recurrence: alpha_t = psi_t * (alpha_{t-1} . E) / c_t; returns alpha_t, sets (1/c_t, c_t)
+  auto fwd_step = [&](double a_prev, double psi, bool first, double& sc, double& sum) -> double {
+    double v = psi;
+    if (!first) {
+      double acc = 0.0;
+      row_dot<AT>(acc, dpp_ready(a_prev), Ef);
+      v = acc * psi;
+    }
+    sum = 0.0;
+    row_sum<AT>(sum, dpp_ready(v));
+    const bool nz = sum != 0.0;
+    sum = nz ? sum : 1.0;
+    sc = __builtin_amdgcn_rcp(sum);
+    sc = fma(fma(-sum, sc, 1.0), sc, sc);
+    sc = fma(fma(-sum, sc, 1.0), sc, sc);
+    sc = nz ? sc : 1.0;
+    return v * sc;
+  };
+
+  // ---- forward: alpha parked once per segment ----
+  double a_prev = 0.0;
+  double bn[SEG];
+#pragma unroll
+  for (int k = 0; k < SEG; ++k) bn[k] = FWDPSI ? loadB(clampt(k)) : loadPsi(clampt(k));
+  for (int sg = 0; sg < NSEG; ++sg) {
+    const int t0 = sg * SEG;
+    double bc[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) bc[k] = bn[k];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) bn[k] = FWDPSI ? loadB(clampt(t0 + SEG + k)) : loadPsi(clampt(t0 + SEG + k));
+    if constexpr (FWDPSI) {  // psi of the whole segment first: nothing of it is on the chain
+#pragma unroll
+      for (int k = 0; k < SEG; ++k) {
+        double sdot = 0.0;
+        row_dot<AT>(sdot, dpp_ready(bc[k]), Th);
+        bc[k] = label ? exp(sdot) : 0.0;
+        if (active && t0 + k < W) L.psi[row0 + (size_t)(t0 + k) * A + y] = bc[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) {
+      const int t = t0 + k;
+      if (t < W) {
+        double sc, sum;
+        a_prev = fwd_step(a_prev, bc[k], t == 0, sc, sum);
+      }
+    }
+    if (active) ck[(size_t)sg * A + y] = a_prev;
+  }
+  __threadfence_block();
+
+  // ---- backward: per segment recompute alpha into LDS, then beta and the marginals ----
+  double beta = 0.0, psi_next = 0.0;
+  double an = 0.0;
+  {
+    const int sg = NSEG - 1;
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) bn[k] = loadPsi(clampt(sg * SEG + k));
+    an = (active && sg > 0) ? ck[(size_t)(sg - 1) * A + y] : 0.0;
+  }
+  for (int sg = NSEG - 1; sg >= 0; --sg) {
+    const int t0 = sg * SEG;
+    double bc[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) bc[k] = bn[k];
+    double a_in = an;
+    {
+      const int sp = sg > 0 ? sg - 1 : 0;
+#pragma unroll
+      for (int k = 0; k < SEG; ++k) bn[k] = loadPsi(clampt(sp * SEG + k));
+      const double v = ck[(size_t)(sp > 0 ? sp - 1 : 0) * A + yl];  // unconditional; dropped for the first segment / padding lanes
+      an = (label && sp > 0) ? v : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) {
+      const int t = t0 + k;
+      if (t < W) {
+        double sc, sum;
+        a_in = fwd_step(a_in, bc[k], t == 0, sc, sum);
+        la[wave][k][lane] = a_in;
+        if (y == 0) lsc[wave][k][row] = make_double2(sc, sum);
+      }
+    }
+    // (wave-private LDS: a lane reads back its own alpha; the row's pair is written by its lane 0 — LDS operations of a wave run in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = SEG - 1; k >= 0; --k) {
+      const int t = t0 + k;
+      if (t < W) {
+        const double2 scur = lsc[wave][k][row];
+        const double sct = scur.x;
+        if (t < W - 1) {
+          double acc = 0.0;
+          row_dot<AT>(acc, dpp_ready(psi_next * beta), Eb);
+          beta = acc * sct;
+        } else {
+          beta = sct;
+        }
+        psi_next = bc[k];
+        const double m = la[wave][k][lane] * beta * scur.y;
+        double mx = label ? m : -1.0;
+        mx = fmax(mx, ror16<8>(mx));
+        mx = fmax(mx, ror16<4>(mx));
+        mx = fmax(mx, ror16<2>(mx));
+        mx = fmax(mx, ror16<1>(mx));
+        const unsigned long long hit = __ballot(label && m == mx);
+        const int best = __builtin_ctz((unsigned)(hit >> (lane & 48)) & 0xffffu);
+        if (active) {
+          const size_t o = row0 + (size_t)t * A + y;
+          if (L.proba64) L.proba64[o] = m;
+          if (L.proba32) L.proba32[o] = (float)m;
+          if (L.labels && y == 0) L.labels[(size_t)nn * W + t] = best;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 template <int AT>
@@ -590,12 +750,20 @@ hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune,
   if (L.A <= 16 && (impl == 0 || impl == 2 || (impl == 1 && L.A > 8))) {
     const int waves = 4;
     const dim3 grid((unsigned)((L.N + 4 * waves - 1) / (4 * waves)));
-    if (!(tune.crf_flags & 1)) {  // default: psi from the separate pass (GNX_CRF_FLAGS=1 fuses it: measured slower, see below)
+    if (!(tune.crf_flags & 3)) {  // default (round 4): checkpointed alphas; GNX_CRF_FLAGS=4 keeps k_crf_psi as a separate pass
+      const bool fwdpsi = !(tune.crf_flags & 4);
+      if (!fwdpsi) launch_psi(L, s);
+#define GNX_CK(AT_) \
+      if (fwdpsi) hipLaunchKernelGGL((k_smooth_crf_ck<AT_, true>), grid, dim3(64 * waves), 0, s, L); \
+      else hipLaunchKernelGGL((k_smooth_crf_ck<AT_, false>), grid, dim3(64 * waves), 0, s, L);
+      if (L.A <= 8) { GNX_CK(8) } else if (L.A <= 12) { GNX_CK(12) } else { GNX_CK(16) }
+#undef GNX_CK
+    } else if (tune.crf_flags & 2) {  // GNX_CRF_FLAGS=2: round 3's kernel (every alpha and scale pair parked), psi from the separate pass
       launch_psi(L, s);
       if (L.A <= 8) hipLaunchKernelGGL((k_smooth_crf_row16<8, false>), grid, dim3(64 * waves), 0, s, L);
       else if (L.A <= 12) hipLaunchKernelGGL((k_smooth_crf_row16<12, false>), grid, dim3(64 * waves), 0, s, L);
       else hipLaunchKernelGGL((k_smooth_crf_row16<16, false>), grid, dim3(64 * waves), 0, s, L);
-    } else {
+    } else {  // GNX_CRF_FLAGS=1: psi computed in both sweeps of round 3's kernel
       if (L.A <= 8) hipLaunchKernelGGL((k_smooth_crf_row16<8, true>), grid, dim3(64 * waves), 0, s, L);
       else if (L.A <= 12) hipLaunchKernelGGL((k_smooth_crf_row16<12, true>), grid, dim3(64 * waves), 0, s, L);
       else hipLaunchKernelGGL((k_smooth_crf_row16<16, true>), grid, dim3(64 * waves), 0, s, L);

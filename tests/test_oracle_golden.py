@@ -224,3 +224,61 @@ def test_cnn_smoother_golden_G11(oracle):
     assert proba.dtype == np.float32 and proba.shape == g["proba"].shape
     assert np.max(np.abs(proba - g["proba"])) < 1e-5      # the backend's tap order is not defined: a few float32 ulps
     assert np.array_equal(labels, g["labels"])
+
+
+# ---- CRF smoother (a7): an anchor that does not come from any forward-backward recursion ------------------------------------------
+def _crf_brute_force(B, state, trans):
+    """marginals and log Z of the linear chain score(y | x) = sum_t sum_a state[a][y_t] x[t][a] + sum_{t>=1} trans[y_{t-1}][y_t]
+    (src/Smooth/crf.py:9-15: all possible states and transitions) by ENUMERATING all A^W labelings"""
+    import itertools
+    W, A = B.shape
+    s = B @ state                                       # (W, A) state scores
+    scores, labelings = [], []
+    for y in itertools.product(range(A), repeat=W):
+        sc = sum(s[t, y[t]] for t in range(W)) + sum(trans[y[t - 1], y[t]] for t in range(1, W))
+        scores.append(sc)
+        labelings.append(y)
+    scores = np.array(scores)
+    mx = scores.max()
+    p = np.exp(scores - mx)
+    logz = mx + np.log(p.sum())
+    p /= p.sum()
+    marg = np.zeros((W, A))
+    for pr, y in zip(p, labelings):
+        for t in range(W):
+            marg[t, y[t]] += pr
+    return marg, logz, labelings, scores
+
+
+@pytest.mark.parametrize("A,W,seed", [(2, 1, 0), (2, 6, 1), (3, 2, 2), (3, 5, 3), (3, 6, 4)])
+def test_crf_restatement_vs_brute_force_enumeration(oracle, A, W, seed):
+    """smooth_crf's marginals / labels and crf_objective's value and gradient against the enumeration of all
+    A^W labelings — nothing of the oracle's (or the kernels') scaled forward-backward is shared with this check"""
+    rng = np.random.RandomState(seed)
+    B = rng.dirichlet(np.ones(A), size=(3, W))
+    state = rng.standard_normal((A, A)) * 1.5
+    trans = rng.standard_normal((A, A)) * 1.5
+    proba, labels = oracle.smooth_crf(B, state, trans)
+    logz = []
+    for n in range(B.shape[0]):
+        marg, lz, _, _ = _crf_brute_force(B[n], state, trans)
+        logz.append(lz)
+        assert np.max(np.abs(proba[n] - marg)) <= 1e-13
+        assert np.array_equal(labels[n], np.argmax(marg, axis=1)) or np.sort(marg, axis=1)[:, -1].min() - np.sort(marg, axis=1)[:, -2].max() < 1e-12
+    # the training objective: f = -sum_n log p(y_n | x_n) + c2 |w|^2 by enumeration, gradient by central differences of THAT
+    y = rng.randint(0, A, size=(B.shape[0], W))
+
+    def f_enum(st, tr):
+        f = 0.0
+        for n in range(B.shape[0]):
+            s = B[n] @ st
+            sc = sum(s[t, y[n, t]] for t in range(W)) + sum(tr[y[n, t - 1], y[n, t]] for t in range(1, W))
+            f -= sc - _crf_brute_force(B[n], st, tr)[1]
+        return f + 1.0 * (np.sum(st * st) + np.sum(tr * tr))
+    f, gs, gt = oracle.crf_objective(B, y, state, trans, c2=1.0)
+    assert abs(f - f_enum(state, trans)) <= 1e-11 * max(1.0, abs(f))
+    h = 1e-6
+    for (i, j) in [(0, 0), (A - 1, 0), (0, A - 1)]:
+        d = np.zeros((A, A)); d[i, j] = h
+        assert abs((f_enum(state + d, trans) - f_enum(state - d, trans)) / (2 * h) - gs[i, j]) <= 1e-6
+        assert abs((f_enum(state, trans + d) - f_enum(state, trans - d)) / (2 * h) - gt[i, j]) <= 1e-6
