@@ -14,7 +14,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 11
+GNX_ABI_VERSION = 12
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
@@ -104,6 +104,7 @@ class ModelInfo(C.Structure):
 _VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64
 SYMBOLS = {
     "gnx_abi_version": (C.c_int, []),
+    "gnx_device_count": (C.c_int, []),
     "gnx_host_alloc": (_I, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "gnx_host_free": (_I, [_VP, _VP]),
     "gnx_init": (C.c_int, [C.c_int, C.POINTER(_VP)]),
@@ -154,6 +155,8 @@ SYMBOLS = {
     "gnx_x_to_gt2_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),
     "gnx_infer_gt2": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _VP, _VP, _VP]),
     "gnx_phase_gt2": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, C.c_int32, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP]),
+    "gnx_infer_gt2_range": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _I64, _VP, _VP, _VP, _VP]),
+    "gnx_phase_gt2_range": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _I64, _VP, C.c_int32, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP]),
     "gnx_write_msp": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I64, _I64, _I64, _I]),
     "gnx_write_fb_dev": (C.c_int, [_VP, C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I64, _I64, _I64]),
     "gnx_write_fb": (C.c_int, [C.c_char_p, C.c_char_p, _I64, _VP, _VP, _VP, _I, _I64, _I64, _I64, _I]),

@@ -62,12 +62,14 @@ class _Prefetch:
         return self._out
 
 
-def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False, timings=None, query=None):
+def run_inference(base_args, model, snp_level=False, bed_file_output=False, verbose=False, timings=None, query=None, devices=None):
     """gnomix.py:37-100 with the HIP model behind the same steps.  The query never becomes an (N, C) host matrix: the library
     parses the text into 2-bit rows (gnx_vcf_read), `column_map` keeps vcf_to_npy's bookkeeping (SNP intersection, REF flips,
     absent SNPs) as one int32 per model SNP, the GPU builds X and runs base + smoother (or Gnofix) on it, and the library
     formats .msp / .fb / the phased VCF.  `timings` (a dict) receives the seconds of each stage; `query` = a _Prefetch of
-    vcfio.read_vcf started earlier (the command line parses the query while the GPU runtime starts and the model loads)."""
+    vcfio.read_vcf started earlier (the command line parses the query while the GPU runtime starts and the model loads).
+    `devices` = GPU ordinals (several: the individuals are cut over them, one context and one host thread each, the query parsed
+    once and the outputs written once: gnomix_amd/multi.py) or an existing multi.DeviceGroup; None = the model's own device."""
     from time import perf_counter as clock
     from . import postprocess as pp
     from . import vcfio
@@ -87,13 +89,21 @@ def run_inference(base_args, model, snp_level=False, bed_file_output=False, verb
         print("Inferring ancestry on query data...")
     t0 = clock()
     out = (model.dev.ctx.pinned_empty((N, model.W, model.A), model.dev.proba_dtype()), model.dev.ctx.pinned_empty((N, model.W), np.int32))
+    runner = model.dev
+    if devices is not None and not isinstance(devices, (list, tuple)):
+        runner = devices                                                   # a DeviceGroup the caller keeps
+    elif devices is not None and len(devices) > 1:
+        from .multi import DeviceGroup
+        runner = DeviceGroup(model.data, devices, first=model.dev)
+        T["replicate_model"] = clock() - t0
+        t0 = clock()
     if not base_args["phase"]:
-        proba, labels = model.dev.infer_gt2(vcf.gt2, N, src, out=out)
+        proba, labels = runner.infer_gt2(vcf.gt2, N, src, out=out)
         T["infer"] = clock() - t0
     else:
         assert model.smooth is not None, "Smoother is not trained, returning original haplotypes"
         assert model.smooth.gnofix, "Type of Smoother ({}) does not currently support re-phasing".format(model.smooth)
-        G_phased, proba, labels, _ = model.dev.phase_gt2(vcf.gt2, N, src, out_cols=fmt_idx, out=out)
+        G_phased, proba, labels, _ = runner.phase_gt2(vcf.gt2, N, src, out_cols=fmt_idx, out=out)
         T["phase"] = clock() - t0
         if verbose:
             print("Writing phased SNPs to disk...")
@@ -162,8 +172,10 @@ def main(argv=None):
         # thread starts the GPU runtime (~0.16 s), reads the model and builds its device tables (~0.15 s)
         from . import vcfio
         query = _Prefetch(lambda: vcfio.read_vcf(base_args["query_file"], chm=base_args["chm"], ctx=None))
+    from .multi import visible_devices
+    devices = visible_devices()        # every GPU of the node (GNX_DEVICES="0,1,.." narrows it): individuals are cut over them
     t_load = clock()
-    model = load_model(base_args["path_to_model"])
+    model = load_model(base_args["path_to_model"], device=devices[0])
     t_load = clock() - t_load
     model.n_cores = (config.get("model") or {}).get("n_cores")            # gnomix.py:365-367
     model.calibrate = (config.get("model") or {}).get("calibrate")
@@ -176,7 +188,7 @@ def main(argv=None):
         if t_startup is not None:
             T = {"interpreter_and_imports": t_startup, "load_model": t_load}
         run_inference(base_args, model, snp_level=bool(inf.get("snp_level_inference")),
-                      bed_file_output=bool(inf.get("bed_file_output")), verbose=True, timings=T, query=query)
+                      bed_file_output=bool(inf.get("bed_file_output")), verbose=True, timings=T, query=query, devices=devices)
         if os.environ.get("GNX_CLI_TIMING"):
             T["since_process_start"] = _since_process_start()
             sys.stderr.write("gnomix_amd timings (s): " + ", ".join("%s %.3f" % kv for kv in T.items()) + "\n")

@@ -125,6 +125,11 @@ extern "C" {
 
 int gnx_abi_version(void) { return GNX_ABI_VERSION; }
 
+int gnx_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int gnx_init(int device, gnx_ctx** out) {
   if (!out) return GNX_EINVAL;
   *out = nullptr;

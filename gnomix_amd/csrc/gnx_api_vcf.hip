@@ -56,6 +56,7 @@ int gnx_x_to_gt2_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ldx, int
 namespace {
 struct Gt2Job {
   int64_t C, ldx, nb;       // model SNPs, device row pitch of X, haplotypes per batch
+  int64_t ldg_d;            // row pitch of the device copy of G (only the bytes of this call's haplotype range)
   const uint8_t* dG;
   const int32_t* dsrc;
   int8_t* dX;
@@ -70,8 +71,9 @@ int check_src(gnx_ctx* ctx, const int32_t* src, int64_t C, int64_t V) {
   return GNX_OK;
 }
 
-// uploads G and the column map, sizes X for one batch; everything on the context stream
-int gt2_stage(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_t N, const int32_t* src, const int32_t* extra_cols,
+// uploads the haplotypes [h0, h0 + N) of G (h0 a multiple of 4: whole bytes of every variant row, one strided copy) and the column
+// map, sizes X for one batch; everything on the context stream
+int gt2_stage(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_t h0, int64_t N, const int32_t* src, const int32_t* extra_cols,
               int64_t n_extra, Gt2Job* J) {
   gnx_ctx* ctx = m->ctx;
   const int64_t C = m->info.C;
@@ -84,13 +86,18 @@ int gt2_stage(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_t N,
   if (ctx->tune.host_batch > 0) nb = (ctx->tune.host_batch + 3) / 4 * 4;  // tests: several batches on small inputs
   nb = std::max<int64_t>(4, nb);
   J->nb = std::min(nb, (N + 3) / 4 * 4);
-  if ((rc = gnx_ws_reserve(ctx, ctx->ws_gt2, (size_t)V * ldg + 64)) != GNX_OK) return rc;
+  const int64_t wbytes = (N + 3) / 4;
+  J->ldg_d = (h0 == 0 && wbytes == ldg) ? ldg : (wbytes + 63) / 64 * 64;
+  if ((rc = gnx_ws_reserve(ctx, ctx->ws_gt2, (size_t)V * J->ldg_d + 64)) != GNX_OK) return rc;
   if ((rc = gnx_ws_reserve(ctx, ctx->ws_src, (size_t)(C + n_extra) * 4 + 64)) != GNX_OK) return rc;
   if ((rc = gnx_ws_reserve(ctx, ctx->ws_xu, (size_t)J->nb * J->ldx + 256)) != GNX_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(ctx->ws_src.p, src, (size_t)C * 4, hipMemcpyHostToDevice, ctx->stream));
   if (n_extra > 0)
     HIPCHK(ctx, hipMemcpyAsync((int32_t*)ctx->ws_src.p + C, extra_cols, (size_t)n_extra * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (V > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->ws_gt2.p, G, (size_t)V * ldg, hipMemcpyHostToDevice, ctx->stream));
+  if (V > 0) {
+    if (J->ldg_d == ldg) HIPCHK(ctx, hipMemcpyAsync(ctx->ws_gt2.p, G, (size_t)V * ldg, hipMemcpyHostToDevice, ctx->stream));
+    else HIPCHK(ctx, hipMemcpy2DAsync(ctx->ws_gt2.p, (size_t)J->ldg_d, G + h0 / 4, (size_t)ldg, (size_t)wbytes, (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+  }
   J->dG = (const uint8_t*)ctx->ws_gt2.p;
   J->dsrc = (const int32_t*)ctx->ws_src.p;
   J->dX = (int8_t*)ctx->ws_xu.p;
@@ -100,13 +107,19 @@ int gt2_stage(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_t N,
 
 int gnx_infer_gt2(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_t N, const int32_t* src, float* p32, double* p64,
                   int32_t* lab) {
+  return gnx_infer_gt2_range(m, G, V, ldg, 0, N, src, p32, p64, lab);
+}
+
+int gnx_infer_gt2_range(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_t h0, int64_t N, const int32_t* src, float* p32,
+                        double* p64, int32_t* lab) {
   if (!m) return GNX_EINVAL;
   gnx_ctx* ctx = m->ctx;
-  if (N < 0 || V < 0 || ldg < (N + 3) / 4 || !src || (N > 0 && V > 0 && !G)) return gnx_fail(ctx, GNX_EINVAL, "infer_gt2: bad G / V / ldg / N / src");
+  if (N < 0 || V < 0 || h0 < 0 || (h0 & 3) || ldg < (h0 + N + 3) / 4 || !src || (N > 0 && V > 0 && !G))
+    return gnx_fail(ctx, GNX_EINVAL, "infer_gt2: bad G / V / ldg / first haplotype (a multiple of 4) / N / src");
   if (N == 0) return GNX_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Gt2Job J{};
-  int rc = gt2_stage(m, G, V, ldg, N, src, nullptr, 0, &J);
+  int rc = gt2_stage(m, G, V, ldg, h0, N, src, nullptr, 0, &J);
   if (rc != GNX_OK) return rc;
   const size_t WA = (size_t)m->info.W * m->info.A, Wn = (size_t)m->info.W;
   const int64_t nb = J.nb, n_batches = (N + nb - 1) / nb;
@@ -125,7 +138,7 @@ int gnx_infer_gt2(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_
     const int b = (int)(i % nbuf);
     const int64_t n0 = i * nb, n = std::min(nb, N - n0);
     if (nbuf == 2 && i >= 2) HIPCHK(ctx, hipStreamWaitEvent(sc, ctx->ev_out[b], 0));  // outputs of batch i-2 have left this half
-    HIPCHK(ctx, gnx_launch_gt2_to_x(J.dG, V, ldg, n0, n, J.dsrc, J.C, J.dX, J.ldx, sc));
+    HIPCHK(ctx, gnx_launch_gt2_to_x(J.dG, V, J.ldg_d, n0, n, J.dsrc, J.C, J.dX, J.ldx, sc));
     float* dp32 = (float*)((char*)ctx->ws_p32.p + (size_t)b * p32_b);
     double* dp64 = p64 ? (double*)((char*)ctx->ws_p64.p + (size_t)b * p64_b) : nullptr;
     int32_t* dlab = lab ? (int32_t*)((char*)ctx->ws_lab.p + (size_t)b * lab_b) : nullptr;
@@ -147,11 +160,17 @@ int gnx_infer_gt2(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_
 int gnx_phase_gt2(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_t N, const int32_t* src, int32_t max_it,
                   const int32_t* out_cols, int64_t n_out, uint8_t* G_out, int64_t ldg_out, float* p32, double* p64, int32_t* lab,
                   int32_t* n_switches) {
+  return gnx_phase_gt2_range(m, G, V, ldg, 0, N, src, max_it, out_cols, n_out, G_out, ldg_out, p32, p64, lab, n_switches);
+}
+
+int gnx_phase_gt2_range(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_t h0, int64_t N, const int32_t* src, int32_t max_it,
+                        const int32_t* out_cols, int64_t n_out, uint8_t* G_out, int64_t ldg_out, float* p32, double* p64, int32_t* lab,
+                        int32_t* n_switches) {
   if (!m) return GNX_EINVAL;
   gnx_ctx* ctx = m->ctx;
-  if (N < 0 || (N & 1) || V < 0 || ldg < (N + 3) / 4 || !src || (N > 0 && V > 0 && !G))
-    return gnx_fail(ctx, GNX_EINVAL, "phase_gt2: bad G / V / ldg / N / src (N = 2 * individuals)");
-  if (n_out < 0 || (G_out && (ldg_out < (N + 3) / 4 || (n_out > 0 && !out_cols)))) return gnx_fail(ctx, GNX_EINVAL, "phase_gt2: bad output rows");
+  if (N < 0 || (N & 1) || V < 0 || h0 < 0 || (h0 & 3) || ldg < (h0 + N + 3) / 4 || !src || (N > 0 && V > 0 && !G))
+    return gnx_fail(ctx, GNX_EINVAL, "phase_gt2: bad G / V / ldg / first haplotype (a multiple of 4) / N / src (N = 2 * individuals)");
+  if (n_out < 0 || (G_out && (ldg_out < (h0 + N + 3) / 4 || (n_out > 0 && !out_cols)))) return gnx_fail(ctx, GNX_EINVAL, "phase_gt2: bad output rows");
   if (m->info.smooth_kind != GNX_SMOOTH_XGB) return gnx_fail(ctx, GNX_ESTATE, "Type of Smoother does not currently support re-phasing");
   if (N == 0) return GNX_OK;
   if (!G_out) n_out = 0;
@@ -159,7 +178,7 @@ int gnx_phase_gt2(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_
     if (out_cols[r] < 0 || out_cols[r] >= m->info.C) return gnx_fail(ctx, GNX_EINVAL, "phase_gt2: output column outside the model's SNPs");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Gt2Job J{};
-  int rc = gt2_stage(m, G, V, ldg, N, src, out_cols, n_out, &J);
+  int rc = gt2_stage(m, G, V, ldg, h0, N, src, out_cols, n_out, &J);
   if (rc != GNX_OK) return rc;
   const size_t WA = (size_t)m->info.W * m->info.A, Wn = (size_t)m->info.W;
   // one workgroup per individual: batches of whole individuals; smaller than the inference batch (B is float64 here)
@@ -171,20 +190,23 @@ int gnx_phase_gt2(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_
   if (p64 && (rc = gnx_ws_reserve(ctx, ctx->ws_p64, nb * WA * 8)) != GNX_OK) return rc;
   if ((rc = gnx_ws_reserve(ctx, ctx->ws_lab, nb * Wn * 4 + (size_t)nb * 2 + 64)) != GNX_OK) return rc;
   if ((rc = gnx_ws_reserve(ctx, ctx->ws_b32, nb * WA * 4)) != GNX_OK) return rc;
+  // the phased rows of THIS range: a device matrix of its own pitch, copied into the caller's rows at byte h0 / 4 (the other bytes of
+  // G_out belong to other ranges — other contexts may be writing them — and are not touched)
+  const int64_t obytes = (N + 3) / 4, ldo_d = (obytes + 63) / 64 * 64;
   if (n_out > 0) {
-    if ((rc = gnx_ws_reserve(ctx, ctx->ws_gt2o, (size_t)n_out * ldg_out + 64)) != GNX_OK) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->ws_gt2o.p, 0, (size_t)n_out * ldg_out, ctx->stream));
+    if ((rc = gnx_ws_reserve(ctx, ctx->ws_gt2o, (size_t)n_out * ldo_d + 64)) != GNX_OK) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws_gt2o.p, 0, (size_t)n_out * ldo_d, ctx->stream));
   }
   hipStream_t sc = ctx->stream;
   for (int64_t i = 0; i < n_batches; ++i) {
     const int64_t n0 = i * nb, n = std::min(nb, N - n0);
-    HIPCHK(ctx, gnx_launch_gt2_to_x(J.dG, V, ldg, n0, n, J.dsrc, J.C, J.dX, J.ldx, sc));
+    HIPCHK(ctx, gnx_launch_gt2_to_x(J.dG, V, J.ldg_d, n0, n, J.dsrc, J.C, J.dX, J.ldx, sc));
     if ((rc = gnx_base_predict_dev(m, J.dX, n, J.ldx, nullptr, (double*)ctx->ws_b64.p)) != GNX_OK) return rc;
     int32_t* dY = (int32_t*)ctx->ws_lab.p;
     int32_t* dNs = dY + (size_t)nb * Wn;
     if ((rc = gnx_gnofix_dev(m, J.dX, J.ldx, (const double*)ctx->ws_b64.p, n / 2, max_it, dY, dNs)) != GNX_OK) return rc;
     if (n_out > 0)
-      HIPCHK(ctx, gnx_launch_x_to_gt2(J.dX, n, J.ldx, n0, J.dsrc + J.C, n_out, (uint8_t*)ctx->ws_gt2o.p, ldg_out, sc));
+      HIPCHK(ctx, gnx_launch_x_to_gt2(J.dX, n, J.ldx, n0, J.dsrc + J.C, n_out, (uint8_t*)ctx->ws_gt2o.p, ldo_d, sc));
     if (lab) HIPCHK(ctx, hipMemcpyAsync(lab + n0 * Wn, dY, n * Wn * 4, hipMemcpyDeviceToHost, sc));
     if (n_switches) HIPCHK(ctx, hipMemcpyAsync(n_switches + n0 / 2, dNs, (size_t)(n / 2) * 4, hipMemcpyDeviceToHost, sc));
     if (p32 || p64) {
@@ -194,7 +216,8 @@ int gnx_phase_gt2(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, int64_
       if (p64) HIPCHK(ctx, hipMemcpyAsync(p64 + n0 * WA, ctx->ws_p64.p, n * WA * 8, hipMemcpyDeviceToHost, sc));
     }
   }
-  if (n_out > 0) HIPCHK(ctx, hipMemcpyAsync(G_out, ctx->ws_gt2o.p, (size_t)n_out * ldg_out, hipMemcpyDeviceToHost, sc));
+  if (n_out > 0)
+    HIPCHK(ctx, hipMemcpy2DAsync(G_out + h0 / 4, (size_t)ldg_out, ctx->ws_gt2o.p, (size_t)ldo_d, (size_t)obytes, (size_t)n_out, hipMemcpyDeviceToHost, sc));
   HIPCHK(ctx, hipStreamSynchronize(sc));
   return GNX_OK;
 }

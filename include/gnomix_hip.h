@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 11
+#define GNX_ABI_VERSION 12
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -192,6 +192,8 @@ typedef struct gnx_model_info {
 } gnx_model_info;
 
 int gnx_abi_version(void);
+/* GPUs this process sees (HIP_VISIBLE_DEVICES applied); 0 without a usable runtime.  One gnx_ctx per device: gnx_init(d), 0 <= d < count. */
+int gnx_device_count(void);
 
 /* context */
 int gnx_init(int device, gnx_ctx** out);

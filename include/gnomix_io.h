@@ -91,12 +91,24 @@ int gnx_x_to_gt2_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ldx, int
  * G (V, ldg) gt2 with N = 2 * n_samples haplotypes (N even); outputs as gnx_infer: proba (N, W, A), labels (N, W). */
 int gnx_infer_gt2(gnx_model* model, const uint8_t* G, int64_t V, int64_t ldg, int64_t N, const int32_t* src,
                   float* proba_f32, double* proba_f64, int32_t* labels);
+/* The same for the haplotypes h0 .. h0 + N of G only (h0 a multiple of 4; whole samples: N even): what ONE device of a node does
+ * with its share of the query (individuals shard contiguously, the model is replicated, no collective).  One parsed
+ * query, one page-locked G; every device's context (its own host thread: a context is not thread-safe, different contexts are
+ * independent) uploads only its columns of the variant rows (one strided copy) and writes its own row block of the shared outputs:
+ * the output pointers address the rows of THIS range (row 0 = haplotype h0). */
+int gnx_infer_gt2_range(gnx_model* model, const uint8_t* G, int64_t V, int64_t ldg, int64_t h0, int64_t N, const int32_t* src,
+                        float* proba_f32, double* proba_f64, int32_t* labels);
 /* gnomix.py:60-72 with phase=True: B = base.predict_proba(X); X_phased, labels = model.phase(X, B);
  * proba = model.predict_proba(X_phased).  G_out (n_out, ldg_out) receives X_phased[:, out_cols[r]] as gt2 rows (may be
  * NULL); n_switches (N/2,) may be NULL. */
 int gnx_phase_gt2(gnx_model* model, const uint8_t* G, int64_t V, int64_t ldg, int64_t N, const int32_t* src, int32_t max_it,
                   const int32_t* out_cols, int64_t n_out, uint8_t* G_out, int64_t ldg_out, float* proba_f32,
                   double* proba_f64, int32_t* labels, int32_t* n_switches);
+/* ... for the haplotypes h0 .. h0 + N only (see gnx_infer_gt2_range; h0 a multiple of 4 = whole individuals).  Output pointers
+ * address the rows of this range; G_out is the WHOLE (n_out, ldg_out) matrix: the call writes bytes h0/4 .. of every row. */
+int gnx_phase_gt2_range(gnx_model* model, const uint8_t* G, int64_t V, int64_t ldg, int64_t h0, int64_t N, const int32_t* src,
+                        int32_t max_it, const int32_t* out_cols, int64_t n_out, uint8_t* G_out, int64_t ldg_out,
+                        float* proba_f32, double* proba_f64, int32_t* labels, int32_t* n_switches);
 
 /* ---- writers ----------------------------------------------------------------------------------------------------------
  * Every file = `head` (head_len bytes, written as is) + one text row per window / variant: the caller's row prefix

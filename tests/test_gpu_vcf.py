@@ -188,3 +188,47 @@ def test_write_fb_on_the_gpu_is_byte_identical_to_the_host_writer(tmp_path, N, W
     pp.write_fb(str(tmp_path / "dev"), meta, proba, pops, samples, ctx=ctx)
     a, b = open(str(tmp_path / "host.fb"), "rb").read(), open(str(tmp_path / "dev.fb"), "rb").read()
     assert len(a) == len(b) and a == b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("phase", [False, True])
+@pytest.mark.parametrize("n_ind,k", [(11, 3), (5, 2), (3, 3)])
+def test_one_process_several_contexts_writes_the_same_files(ga, tmp_path, phase, n_ind, k):
+    """SURVEY 8e on the file path (gnomix_amd/multi.py): the individuals of ONE parsed query cut over k contexts (here k contexts on
+    the one GPU of the box; a node gives each its own device), ragged blocks, every context uploading only its columns of the 2-bit
+    rows and writing its row block of the shared outputs — .msp / .fb (and the phased VCF) byte-identical to the one-context run"""
+    from gnomix_amd import synth, vcfio, cli, multi
+    rng = np.random.default_rng(100 * n_ind + k)
+    d = synth.synthetic_model(C=7037, M=100, A=5, S=21, n_rounds=5, seed=7)
+    q = _query(tmp_path, d, n_ind, rng)
+    d.gen_map_pos = np.array([1, int(d.snp_pos[len(d.snp_pos) // 3]), int(d.snp_pos[-1]) + 1000])
+    d.gen_map_cm = np.array([0.0, 1.5, 9.25])
+    d.population_order = np.array(["P%d" % a for a in range(d.A)])
+    blocks = multi.shard_individuals(n_ind, k)
+    assert sum(n for _, n in blocks) == n_ind and all(i0 % 2 == 0 for i0, _ in blocks) and all(n > 0 for _, n in blocks)
+    if n_ind >= 2 * k:
+        assert len(blocks) == k and len({n for _, n in blocks}) > 1 or n_ind % k == 0      # ragged
+    g = ga.HipGnomix(d, device=0)
+    outs = []
+    for name, devices in (("one", None), ("many", [0] * k)):
+        od = tmp_path / name
+        od.mkdir()
+        cli.run_inference({"query_file": q, "chm": "22", "output_basename": str(od), "phase": phase}, g, devices=devices)
+        outs.append(od)
+    files = ["query_results.msp", "query_results.fb"] + (["query_file_phased.vcf"] if phase else [])
+    for f in files:
+        a, b = (outs[0] / f).read_bytes(), (outs[1] / f).read_bytes()
+        assert len(a) > 100 and a == b, f
+    # the group API directly, labels only through float64 outputs as well
+    vcf = vcfio.read_vcf(q, chm="22", ctx=g.dev.ctx)
+    src, _, fi = vcfio.column_map(vcf, d.snp_pos, d.snp_ref, verbose=False)
+    grp = multi.DeviceGroup(d, [0] * k, first=g.dev)
+    p1, l1 = g.dev.infer_gt2(vcf.gt2, 2 * n_ind, src, proba_dtype=np.float64)
+    p2, l2 = grp.infer_gt2(vcf.gt2, 2 * n_ind, src, proba_dtype=np.float64)
+    assert np.array_equal(p1, p2) and np.array_equal(l1, l2)
+    if phase:
+        G1, q1, y1, s1 = g.dev.phase_gt2(vcf.gt2, 2 * n_ind, src, out_cols=fi)
+        G2, q2, y2, s2 = grp.phase_gt2(vcf.gt2, 2 * n_ind, src, out_cols=fi)
+        assert np.array_equal(G1, G2) and np.array_equal(q1, q2) and np.array_equal(y1, y2) and np.array_equal(s1, s2)
+    for m in grp.models[1:]:
+        m.close()
