@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="host-pointer (PCIe-inclusive) passes at N=1 (0 = skip)")
     ap.add_argument("--vcf-reps", type=int, default=5, help="file-to-file passes (VCF text in, .msp/.fb out) at N=1 (0 = skip)")
+    ap.add_argument("--phase-leg", type=int, default=1, help="file-to-file with phase=True on admixed individuals through a device-trained model (N=1; needs --vcf-reps > 0)")
     ap.add_argument("--vcf-dir", default="", help="where the synthetic VCF and the outputs go (default: /dev/shm when it has room, else a temp dir)")
     ap.add_argument("--seed", type=int, default=94305)
     args = ap.parse_args()
@@ -291,16 +292,32 @@ def main():
 
     if rank == 0 and world == 1 and args.trained:
         try:
-            res["trained_ensemble"] = _trained_ensemble(ctx, data, avg_sm * 1e3)
+            te = _trained_ensemble(ctx, data, avg_sm * 1e3)
+            res["trained_ensemble"] = te
+            # the same kernel on what it is for (a trained ensemble, ancestry tracts) next to the random-tree worst case of `value`
+            ms = te["trained_trees_tract_inputs_ms"]
+            ti = {"ms": ms, "frac": te["trained_node_steps"] * te["haplotypes"] / (ms * 1e-3) / LDS_PEAK_NODE_STEPS, "lds_conflict_frac": None}
+            try:
+                tc = json.load(open(os.path.join(ROOT, "profiles", "trained_inputs_latest.json")))
+                ti["lds_conflict_frac"] = tc.get("lds_conflict_frac_of_active")
+                ti["lds_conflict_source"] = tc.get("source")
+            except Exception:
+                pass
+            if dom == "k_smooth_xgb":
+                roofline["trained_inputs"] = ti
         except Exception as e:
             res["trained_ensemble"] = {"error": repr(e)}
 
     # ---- file to file: synthetic phased VCF -> .msp / .fb through the command line's own run_inference (never `value`) ----
-    if rank == 0 and world == 1 and args.vcf_reps > 0:
+    # at N > 1 it is ONE process (rank 0) driving all N devices (gnomix_amd/multi.py: one parse, one context and host thread per
+    # GPU, outputs written once) while the other ranks wait — the file path has no collective either
+    if rank == 0 and args.vcf_reps > 0:
         try:
-            res["e2e_vcf"] = _e2e_vcf(args, model, data, X, out)
+            res["e2e_vcf"] = _e2e_vcf(args, model, data, X, out, devices=list(range(world)) if world > 1 else None)
         except Exception as e:
             res["e2e_vcf"] = {"error": repr(e)}
+    if dist is not None:
+        dist.barrier()
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         res["cpu_baseline"] = _cpu_baseline(args, data, X, out)
@@ -389,6 +406,8 @@ def _trained_ensemble(ctx, data, bench_ms):
         out[name] = ms / max(n, 1)
         if d is not data:
             out["trained_nodes"] = int(len(d.left))
+            out["trained_node_steps"] = int(W * (len(d.tree_off) - 1) * 4)
+            out["haplotypes"] = N
             m.close()
     out["random_trees_bench_inputs_ms"] = bench_ms
     out["random_nodes"] = int(len(data.left))
@@ -396,11 +415,34 @@ def _trained_ensemble(ctx, data, bench_ms):
     return out
 
 
-def _e2e_vcf(args, model, data, X, out_dev):
+GENOME_SNPS = 17_738_000   # sum of C over the 22 chromosome models (chr22: 370 500)
+
+
+def _vcf_legs(run, reps):
+    """`reps` timed passes of run(T) (T receives the stage seconds) -> best / median of the WARM passes (the first creates page-locked
+    buffers and the worker pool: reported as first_pass_s), stages of the best one"""
+    rows = []
+    for _ in range(reps):
+        T = {}
+        t0 = time.perf_counter()
+        run(T)
+        T["total"] = time.perf_counter() - t0
+        rows.append(T)
+    warm = rows[1:] if len(rows) > 1 else rows
+    tot = sorted(t["total"] for t in warm)
+    best = min(warm, key=lambda t: t["total"])
+    return {"seconds": best["total"], "median_s": tot[len(tot) // 2], "first_pass_s": round(rows[0]["total"], 4), "passes": len(rows),
+            "stages_s": {k: round(v, 4) for k, v in best.items()}}
+
+
+def _e2e_vcf(args, model, data, X, out_dev, devices=None):
     """`north_star`: "throughput on synthetic phased VCFs".  The batch of the headline run is written as a phased VCF (GT-only
     records, '.' for missing calls; outside the timed region), then gnomix_amd.cli.run_inference — the command line's own
     function — takes it from TEXT to query_results.msp / .fb: native parse on every host core -> 2-bit rows over PCIe -> X built
-    in HBM -> base + smoother -> native formatting.  Also timed: the whole command line as a fresh process."""
+    in HBM -> base + smoother -> native formatting.  Legs: the plain text; the same file as BGZF (the reference's demo query is a
+    .vcf.gz: src/utils.py:64-66); phase=True on tract-structured admixed individuals with switch errors through a model TRAINED on
+    the device (gnx_train_logistic + gnx_train_gbt); the whole command line as a fresh process.  `devices`: GPU ordinals of a
+    one-process multi-GPU run (gnomix_amd/multi.py)."""
     import shutil
     import tempfile
     import numpy as np
@@ -417,47 +459,71 @@ def _e2e_vcf(args, model, data, X, out_dev):
     need = 4 * ns * C + (64 << 20) + N * model.W * model.A * 14
     root = args.vcf_dir
     if not root:
-        root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need else tempfile.gettempdir()
+        root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * need else tempfile.gettempdir()
     work = tempfile.mkdtemp(prefix="gnx_e2e_", dir=root)
+    cpus = usable_cpus()
+    io_threads = min(cpus[0], cpus[1] or cpus[0])
     try:
         ctx = model.ctx
-        # X (HBM) -> variant-major 2-bit rows -> text
-        ldg = (N + 15) // 16 * 4
-        cols = torch.arange(C, dtype=torch.int32, device=X.device)
-        Gd = torch.zeros((C, ldg), dtype=torch.uint8, device=X.device)
-        model._bind_torch_stream()
-        ctx.check(ctx.lib.gnx_x_to_gt2_dev(ctx.h, X.data_ptr(), N, X.stride(0), 0, cols.data_ptr(), C, Gd.data_ptr(), ldg))
-        torch.cuda.synchronize()
-        G = Gd.cpu().numpy()
-        del Gd
-        vcf_path = os.path.join(work, "query.vcf")
-        t0 = time.perf_counter()
-        synth.write_vcf_gt2(vcf_path, G, ns, data.snp_pos, data.snp_ref, data.snp_alt, chrom="22")
-        t_gen = time.perf_counter() - t0
-        vcf_bytes = os.path.getsize(vcf_path)
-        del G
-        gm = HipGnomix(data, ctx=ctx)
-        base_args = {"query_file": vcf_path, "chm": "22", "output_basename": work, "phase": False}
-        reps = []
-        for r in range(args.vcf_reps):
-            T = {}
+
+        def write_query(Xd, path):   # X (HBM) -> variant-major 2-bit rows -> text
+            n = Xd.shape[0]
+            ldg = (n + 15) // 16 * 4
+            cols = torch.arange(C, dtype=torch.int32, device=Xd.device)
+            Gd = torch.zeros((C, ldg), dtype=torch.uint8, device=Xd.device)
+            model._bind_torch_stream()
+            ctx.check(ctx.lib.gnx_x_to_gt2_dev(ctx.h, Xd.data_ptr(), n, Xd.stride(0), 0, cols.data_ptr(), C, Gd.data_ptr(), ldg))
+            torch.cuda.synchronize()
+            G = Gd.cpu().numpy()
+            del Gd
             t0 = time.perf_counter()
-            cli.run_inference(base_args, gm, verbose=False, timings=T)
-            T["total"] = time.perf_counter() - t0
-            reps.append(T)
-        best = min(reps, key=lambda t: t["total"])
+            synth.write_vcf_gt2(path, G, n // 2, data.snp_pos, data.snp_ref, data.snp_alt, chrom="22")
+            return time.perf_counter() - t0
+        vcf_path = os.path.join(work, "query.vcf")
+        t_gen = write_query(X, vcf_path)
+        vcf_bytes = os.path.getsize(vcf_path)
+        gm = HipGnomix(data, ctx=ctx)
+        group = None
+        if devices is not None and len(devices) > 1:
+            from gnomix_amd.multi import DeviceGroup
+            group = DeviceGroup(data, devices, first=gm.dev)
+        base_args = {"query_file": vcf_path, "chm": "22", "output_basename": work, "phase": False}
+        leg = _vcf_legs(lambda T: cli.run_inference(base_args, gm, verbose=False, timings=T, devices=group), args.vcf_reps)
+        best = leg["stages_s"]
         msp = open(os.path.join(work, "query_results.msp")).read().split("\n")[2:2 + model.W]
         lab_file = np.stack([np.array(ln.split("\t")[6:], dtype=np.int32) for ln in msp], axis=1)
         same = bool(np.array_equal(lab_file, out_dev[1].cpu().numpy()))
         fb_bytes = os.path.getsize(os.path.join(work, "query_results.fb"))
         msp_bytes = os.path.getsize(os.path.join(work, "query_results.msp"))
-        res = {"haplotypes_per_s": N / best["total"], "seconds": best["total"], "stages_s": {k: round(v, 4) for k, v in best.items()},
-               "first_pass_s": round(reps[0]["total"], 4), "vcf_GB": vcf_bytes / 1e9, "parse_GBps": vcf_bytes / best["read_vcf"] / 1e9,
-               "write_MBps": (fb_bytes + msp_bytes) / (best["write_fb"] + best["write_msp"]) / 1e6, "fb_MB": fb_bytes / 1e6,
-               "host_cpus_shown": usable_cpus()[0], "host_cpu_quota": usable_cpus()[1], "vcf_written_s": round(t_gen, 3), "dir": root,
-               "msp_labels_equal_device_path": same,
-               "note": "chr22 x %d samples as VCF TEXT in, query_results.msp + .fb out, through gnomix_amd.cli.run_inference; best of %d passes in "
-                       "this process (first_pass_s includes page-locked allocations and the worker pool's start); never `value`" % (ns, len(reps))}
+        msp_text = open(os.path.join(work, "query_results.msp")).read()
+        text_per_hap_genome = vcf_bytes / N * (GENOME_SNPS / C)
+        parse_rate = vcf_bytes / best["read_vcf"]
+        res = {"haplotypes_per_s": N / leg["seconds"], "haplotypes_per_s_median": N / leg["median_s"], "seconds": leg["seconds"],
+               "median_s": leg["median_s"], "stages_s": best, "first_pass_s": leg["first_pass_s"], "vcf_GB": vcf_bytes / 1e9,
+               "parse_GBps": parse_rate / 1e9, "write_MBps": (fb_bytes + msp_bytes) / (best["write_fb"] + best["write_msp"]) / 1e6,
+               "fb_MB": fb_bytes / 1e6, "host_cpus_shown": cpus[0], "host_cpu_quota": cpus[1], "vcf_written_s": round(t_gen, 3), "dir": root,
+               "devices": list(devices) if devices is not None else [ctx.device], "msp_labels_equal_device_path": same,
+               "whole_genome_from_text": {"text_MB_per_haplotype": text_per_hap_genome / 1e6,
+                                          "parse_bound_haplotypes_per_s": parse_rate / text_per_hap_genome,
+                                          "note": "22 chromosomes = %.1f x this file's SNPs: at the parse rate measured here ONE host reads whole-genome "
+                                                  "text for this many haplotypes per second whatever the number of GPUs — the north star's 50 k "
+                                                  "haplotypes/s is a device-resident / packed-input figure (DESIGN.md 5.1), not a from-text one" % (GENOME_SNPS / C)},
+               "note": "chr22 x %d samples as VCF TEXT in, query_results.msp + .fb out, through gnomix_amd.cli.run_inference; best and median of the "
+                       "%d warm passes in this process (first_pass_s includes page-locked allocations and the worker pool's start); never `value`"
+                       % (ns, max(args.vcf_reps - 1, 1))}
+        # ---- the same query as BGZF ----
+        try:
+            t0 = time.perf_counter()
+            gz_path = synth.bgzf_compress_file(vcf_path, os.path.join(work, "query.vcf.gz"), n_threads=io_threads)
+            t_gz = time.perf_counter() - t0
+            gz_args = dict(base_args, query_file=gz_path)
+            lg = _vcf_legs(lambda T: cli.run_inference(gz_args, gm, verbose=False, timings=T, devices=group), min(args.vcf_reps, 3))
+            res["bgzf"] = {"haplotypes_per_s": N / lg["seconds"], "haplotypes_per_s_median": N / lg["median_s"], "seconds": lg["seconds"],
+                           "stages_s": lg["stages_s"], "file_GB": os.path.getsize(gz_path) / 1e9, "text_GBps": vcf_bytes / lg["stages_s"]["read_vcf"] / 1e9,
+                           "compressed_in_s": round(t_gz, 2), "msp_identical": open(os.path.join(work, "query_results.msp")).read() == msp_text}
+            os.remove(gz_path)
+        except Exception as e:
+            res["bgzf"] = {"error": repr(e)}
         # the whole command line as a fresh process: interpreter + library + gnx_init + model load + the above
         try:
             mp = os.path.join(work, "model.gnx")
@@ -466,19 +532,90 @@ def _e2e_vcf(args, model, data, X, out_dev):
             t0 = time.perf_counter()
             env = dict(os.environ, GNX_CLI_TIMING="1")
             env.pop("GNX_NO_TORCH", None)
+            if devices is not None:
+                env["GNX_DEVICES"] = ",".join(str(d) for d in devices)
             pr = subprocess.run([sys.executable, os.path.join(ROOT, "gnomix.py"), vcf_path, outdir, "22", "False", mp],
                                 stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=work, env=env, text=True)
             rc = pr.returncode
             dt = time.perf_counter() - t0
             stages = [ln for ln in pr.stderr.splitlines() if ln.startswith("gnomix_amd timings")]
-            same_cli = rc == 0 and open(os.path.join(outdir, "query_results.msp")).read() == open(os.path.join(work, "query_results.msp")).read()
+            same_cli = rc == 0 and open(os.path.join(outdir, "query_results.msp")).read() == msp_text
             res["cli_process"] = {"wall_s": round(dt, 3), "haplotypes_per_s": N / dt, "rc": rc, "msp_identical": bool(same_cli),
                                   "stages": stages[-1] if stages else None}
+            shutil.rmtree(outdir, ignore_errors=True)
         except Exception as e:
             res["cli_process"] = {"error": repr(e)}
+        os.remove(vcf_path)
+        # ---- phase=True: a model trained on the device, admixed individuals with two switch errors each ----
+        if args.phase_leg:
+            try:
+                res["phase"] = _e2e_phase(args, ctx, data, work, write_query, devices)
+            except Exception as e:
+                res["phase"] = {"error": repr(e)}
+        if group is not None:
+            for m in group.models[1:]:
+                m.close()
         return res
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def _trained_model(ctx, data, dev, n1=2000, n2=600, seed=11):
+    """a chr22-shaped model TRAINED on the device from synthetic admixed haplotypes (Gnomix.train: logistic base on train1, tree
+    smoother on the base's probabilities of train2) -> (HipGnomix, allele frequencies, seconds)"""
+    import numpy as np
+    import gnomix_amd
+    from gnomix_amd import synth
+    d = synth.synthetic_model(C=data.C, M=data.M, A=data.A, S=data.S, n_rounds=1, seed=1)
+    for k in ("snp_pos", "snp_ref", "snp_alt", "gen_map_pos", "gen_map_cm", "population_order"):
+        setattr(d, k, getattr(data, k, None))
+    X1, y1, f = synth.synthetic_admixed_device(n1 // 2, data.C, data.M, data.A, dev, seed=seed)
+    X2, y2, _ = synth.synthetic_admixed_device(n2 // 2, data.C, data.M, data.A, dev, seed=seed + 1, freqs=f)
+    gm = gnomix_amd.HipGnomix(d, ctx=ctx)
+    t0 = time.perf_counter()
+    gm.train(((X1.cpu().numpy(), y1), (X2.cpu().numpy(), y2), (None, None)), retrain_base=False, evaluate=False)
+    return gm, f, time.perf_counter() - t0
+
+
+def _e2e_phase(args, ctx, data, work, write_query, devices):
+    import numpy as np
+    import torch
+    from gnomix_amd import cli, synth
+    dev = torch.device("cuda", ctx.device)
+    gm, f, t_train = _trained_model(ctx, data, dev)
+    n_ind = args.haps // 2
+    Xq, _, _ = synth.synthetic_admixed_device(n_ind, data.C, data.M, data.A, dev, seed=23, freqs=f, phase_errors=2)
+    path = os.path.join(work, "admixed.vcf")
+    write_query(Xq, path)
+    vb = os.path.getsize(path)
+    group = None
+    if devices is not None and len(devices) > 1:
+        from gnomix_amd.multi import DeviceGroup
+        group = DeviceGroup(gm.data, devices, first=gm.dev)
+    out = {}
+    for name, ph in (("phase_true", True), ("phase_false", False)):
+        a = {"query_file": path, "chm": "22", "output_basename": work, "phase": ph}
+        lg = _vcf_legs(lambda T: cli.run_inference(a, gm, verbose=False, timings=T, devices=group), 3 if ph else 2)
+        out[name] = {"haplotypes_per_s": 2 * n_ind / lg["seconds"], "seconds": lg["seconds"], "median_s": lg["median_s"], "stages_s": lg["stages_s"]}
+    _, _, _, nsw = (group or gm.dev).phase_gt2(*_gt2_of(path, gm, ctx))
+    out["mean_switches_per_individual"] = float(np.mean(nsw))
+    out["vcf_GB"] = vb / 1e9
+    out["model"] = "gnx_train_logistic (2000 admixed haplotypes) + gnx_train_gbt (600), %.1f s outside the timed region" % t_train
+    out["note"] = ("chr22 x %d admixed individuals (ancestry tracts, 2 switch errors each) as VCF text -> Gnofix -> query_results.msp / .fb + "
+                   "query_file_phased.vcf; the random-tree / unstructured-haplotype file of the other legs is the WORST case for Gnofix "
+                   "(a label change at almost every window: DESIGN.md 4.11) and is not what phase=True is for" % n_ind)
+    if group is not None:
+        for m in group.models[1:]:
+            m.close()
+    os.remove(path)
+    return out
+
+
+def _gt2_of(path, gm, ctx):
+    from gnomix_amd import vcfio
+    vcf = vcfio.read_vcf(path, chm="22", ctx=ctx)
+    src, _, _ = vcfio.column_map(vcf, gm.snp_pos, gm.snp_ref, verbose=False)
+    return vcf.gt2, 2 * vcf.n_samples, src
 
 
 def _cpu_baseline(args, data, X, out_dev):
@@ -519,17 +656,35 @@ def _cpu_baseline(args, data, X, out_dev):
     l_ref = np.concatenate([p[1] for p in parts])
     same = bool((out_dev[1][:n_s].cpu().numpy() == l_ref).all())
     t_base, t_sm = c1 - c0, c2 - c1
-    # the reference's arithmetic for the base leg: BLAS, window by window, on a sample sized for a few seconds
+    # the reference's arithmetic for the base leg: one BLAS product per window (what sklearn's predict_proba does), cut by windows
+    # over the same thread pool, every BLAS call single-threaded (numpy's pool would otherwise start one thread per CPU the host
+    # SHOWS — 256 on the GPU boxes — inside a 16-CPU quota: round 3 measured 173 haplotypes/s that way)
     n_b = int(min(n_s, 2000))
-    c0 = time.perf_counter()
-    Bb = O.base_lr_blas(Xs[:n_b], data.M, data.context, data.lr_coef, data.lr_intercept)
-    t_blas = time.perf_counter() - c0
+    blas_threads = None
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=1, user_api="blas")
+        blas_threads = 1
+    except Exception:
+        limit = None
+    Xb = Xs[:n_b]
+    Bb = np.empty((n_b, W, data.A), np.float64)
+    Xpad = O.base_lr_pad(Xb, data.context)
+    wr = [(w, min(W, w + max(1, W // (4 * cores)))) for w in range(0, W, max(1, W // (4 * cores)))]
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        c0 = time.perf_counter()
+        list(pool.map(lambda r: O.base_lr_blas(Xb, data.M, data.context, data.lr_coef, data.lr_intercept, r[0], r[1], Bb, Xpad), wr))
+        t_blas = time.perf_counter() - c0
+    if limit is not None:
+        limit.restore_original_limits() if hasattr(limit, "restore_original_limits") else limit.unregister()
     blas_err = float(np.abs(Bb - B[:n_b]).max())
     return {"value": n_s / (t_base + t_sm), "unit": "haplotypes/s", "cores": cores, "kind": "port",
             "base_lr_haplotypes_per_s": n_s / t_base, "smooth_xgb_haplotypes_per_s": n_s / t_sm,
             "one_core_haplotypes_per_s": 1.0 / per, "parallel_efficiency": (n_s / (t_base + t_sm)) / (cores / per),
             "base_lr_blas": {"haplotypes_per_s": n_b / t_blas, "sample": n_b, "max_abs_diff_vs_port": blas_err,
-                             "note": "numpy: Xw.astype(float64) @ coef.T per window (what sklearn's predict_proba does), BLAS threads as configured"},
+                             "threads": cores, "blas_threads_per_call": blas_threads,
+                             "note": "numpy: Xw.astype(float64) @ coef.T per window (what sklearn's predict_proba does), windows cut over the "
+                                     "same %d threads as the port, one BLAS thread per call (threadpoolctl)" % cores},
             "sample": "%d haplotypes of the same workload through oracle/gnx_oracle.c — the SCALAR C port of the reference's "
                       "algorithm, not the reference — on %d threads (host shows %d CPUs, %d schedulable, cgroup CPU quota %s): logistic base by windows "
                       "(370 tasks) %.2f s, tree smoother by haplotypes %.2f s wall; labels identical to the GPU's on the sample: %s.  "

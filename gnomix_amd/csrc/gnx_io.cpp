@@ -443,9 +443,12 @@ int write_blocks(const char* path, const char* head, int64_t head_len, int64_t n
         int spins = 0;
         while (filled[(size_t)(i % K)].load(std::memory_order_acquire) != i) pause(spins);
         const std::vector<char>& buf = ring[(size_t)(i % K)];
-        if (!failed.load(std::memory_order_relaxed) && !put(buf.data(), buf.size())) {
+        if (!put(buf.data(), buf.size())) {
+          // a failed write (disk full, file size limit) ends the job: the producers see `failed` and leave without filling the
+          // blocks they claimed, so waiting for those would never end (write_msp / write_fb hung on ENOSPC with > 1 thread)
           err_no = errno;
-          failed = 1;
+          failed.store(1, std::memory_order_release);
+          return;
         }
         written.store(i + 1, std::memory_order_release);
       }

@@ -25,7 +25,7 @@ def visible_devices():
     env = os.environ.get("GNX_DEVICES", "").strip()
     if env:
         return [int(t) for t in env.split(",") if t.strip() != ""]
-    n = _lib.load_library().gnx_device_count()
+    n = _lib.load().gnx_device_count()
     return list(range(max(n, 1)))
 
 

@@ -75,6 +75,10 @@ class HipSmoother:
         if self.dev.data.smooth_kind == "crf":   # CRF_Smoother: CRFsuite's objective, L-BFGS with device evaluations
             t = time()
             self.train_info = train_crf_smoother(self.dev.data, B, y.reshape(np.asarray(B).shape[0], -1), ctx=self.dev.ctx, **kw)
+            if not self.train_info.get("converged", True):   # as the logistic base does: a fit that stopped early must not pass silently
+                import warnings
+                warnings.warn("gnx_train_crf stopped after %s iterations without reaching its gradient tolerance: the CRF smoother is not "
+                              "converged" % self.train_info.get("iterations", "?"), RuntimeWarning, stacklevel=2)
             self.dev = DeviceModel(self.dev.data, ctx=self.dev.ctx)
             self.time["train"] = time() - t
             return self

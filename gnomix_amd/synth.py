@@ -299,3 +299,76 @@ def write_vcf_gt2(path, G, n_samples, pos, ref, alt, chrom="22", samples=None, m
     _lib.io_check(_lib.load().gnx_write_vcf_gt2(str(path).encode(), head, len(head), blob, off.ctypes.data, G.ctypes.data, V, G.shape[1],
                                                 int(n_samples), int(bool(missing_as_dot)), int(n_threads)))
     return str(path)
+
+
+def synthetic_admixed_device(n_ind, C, M, A, device, seed=0, mean_segments=3, phase_errors=0, miss=0.01, chunk=1024, freqs=None):
+    """Admixed individuals at SNP level, generated in HBM (torch): per-ancestry allele frequencies f[a, j] ~ U(0.05, 0.95), every
+    haplotype a mosaic of ancestry tracts (window granularity, `mean_segments` tracts on average), alleles ~ Bernoulli(f[tract
+    ancestry]), `miss` of the calls set to 2 (missing); `phase_errors` switch errors per individual exchange the two haplotypes
+    from a random SNP on (what Gnofix repairs).  -> X (2 * n_ind, C) int8 on `device`, y (2 * n_ind, W) int32 window labels of the
+    haplotypes BEFORE the switch errors (numpy), freqs (A, C) float32 on the device (pass it back in to draw more individuals of
+    the same populations)."""
+    import torch
+    W = C // M
+    n = 2 * n_ind
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    if freqs is None:
+        freqs = torch.rand((A, C), generator=g, device=device) * 0.9 + 0.05
+    rng = np.random.RandomState(seed)
+    y = np.empty((n, W), np.int32)
+    for h in range(n):
+        k = min(rng.poisson(max(mean_segments - 1, 0)), max(W - 1, 0))
+        cuts = np.sort(rng.choice(np.arange(1, W), size=k, replace=False)) if k else np.empty(0, int)
+        a = rng.randint(A)
+        prev = 0
+        for c in list(cuts) + [W]:
+            y[h, prev:c] = a
+            a = (a + 1 + rng.randint(max(A - 1, 1))) % A
+            prev = c
+    X = torch.empty((n, C), dtype=torch.int8, device=device)
+    win = torch.clamp(torch.arange(C, device=device) // M, max=W - 1)          # SNP -> window (the last window takes the remainder)
+    for i0 in range(0, n, chunk):
+        i1 = min(n, i0 + chunk)
+        yc = torch.as_tensor(y[i0:i1], device=device).long()[:, win]             # (chunk, C) ancestry of every SNP
+        u = torch.rand((i1 - i0, C), generator=g, device=device)
+        p = torch.zeros_like(u)
+        for a in range(A):
+            p = torch.where(yc == a, freqs[a].unsqueeze(0), p)
+        x = (u < p).to(torch.int8)
+        if miss > 0:
+            x = torch.where(torch.rand((i1 - i0, C), generator=g, device=device) < miss, torch.full_like(x, 2), x)
+        X[i0:i1] = x
+        del yc, u, p, x
+    for i in range(n_ind if phase_errors else 0):
+        for s in np.sort(rng.choice(np.arange(M, C - M), size=phase_errors, replace=False)):
+            t = X[2 * i, s:].clone()
+            X[2 * i, s:] = X[2 * i + 1, s:]
+            X[2 * i + 1, s:] = t
+    return X, y, freqs
+
+
+def bgzf_compress_file(src, dst, n_threads=8, level=1, piece=32 << 20):
+    """`src` -> `dst` in BGZF (bgzip's container: gzip members of <= 64 KB of text with a BC extra field, an empty member at the
+    end), the way the reference's demo query ships (.vcf.gz, src/utils.py:64-66); zlib on `n_threads` threads (it releases the GIL)."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def member(data):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = co.compress(data) + co.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw +
+                struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+    def work(buf):
+        return b"".join(member(buf[o:o + 65280]) for o in range(0, len(buf), 65280))
+    with open(src, "rb") as fi, open(dst, "wb") as fo, ThreadPoolExecutor(max_workers=max(1, n_threads)) as pool:
+        while True:
+            bufs = [b for b in (fi.read(piece) for _ in range(max(1, n_threads))) if b]
+            if not bufs:
+                break
+            for out in pool.map(work, bufs):
+                fo.write(out)
+        fo.write(member(b""))
+    return dst

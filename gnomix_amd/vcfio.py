@@ -65,9 +65,11 @@ class VcfData(Mapping):
         lib, h = self._hd.lib, self._hd.h
         n = int(self.info.n_variants) * int(self.info.ldg)
         buf = (C.c_uint8 * max(n, 1)).from_address(lib.gnx_vcf_gt2(h))
+        # the ctypes object is the base of the array and every view of it: hanging the handle on it keeps the library's matrix alive
+        # for as long as any such view exists, also after this VcfData is dropped (`g = read_vcf(p).gt2` dangled)
+        buf._gnx_handle = self._hd
         a = np.frombuffer(buf, dtype=np.uint8, count=n).reshape(int(self.info.n_variants), int(self.info.ldg))
         a.flags.writeable = False
-        self._keep = self._hd
         return a
 
     def _blob(self, field):
@@ -278,16 +280,20 @@ def update_vcf(vcf_data, mask=None, Updates=None):
 
 
 def read_headers(vcf_file):
-    """the '##' lines of a VCF (src/utils.py:232-245), through the library (plain, gzip or BGZF)"""
-    lib = _lib.load()
-    h = C.c_void_p()
-    rc = lib.gnx_vcf_read(None, str(vcf_file).encode(), None, 1, C.byref(h))
-    if rc != _lib.GNX_OK:
-        raise _lib.GnxError(rc, lib.gnx_io_last_error().decode(errors="replace"))
-    hd = _Handle(lib, h)
-    info = _lib.VcfInfo()
-    _lib.io_check(lib.gnx_vcf_get_info(h, C.byref(info)))
-    return VcfData(hd, info).meta_header
+    """the '##' lines of a VCF (src/utils.py:332-348), read without parsing a record: plain text directly, gzip / BGZF through
+    zlib's streaming reader, stopping at the first line that is not a meta line.  (The reference scans every line of the file; the
+    format puts all meta lines before #CHROM, so the result is the same for any VCF — and a multi-GB query is not read for it.)"""
+    import gzip
+    with open(vcf_file, "rb") as f:
+        magic = f.read(2)
+    opener = gzip.open if magic == b"\x1f\x8b" else open
+    out = []
+    with opener(vcf_file, "rb") as f:
+        for ln in f:
+            if not ln.startswith(b"##"):
+                break
+            out.append(ln.decode("utf-8", errors="replace").replace("\r\n", "\n"))
+    return "".join(out)
 
 
 # ---- phased VCF out ------------------------------------------------------------------------------------------------------------
@@ -311,7 +317,10 @@ def _names(data, n):
 def pack_gt2(npy):
     """(2n, V) haplotype-major integers -> (V, ldg) variant-major 2-bit rows (include/gnomix_io.h); host numpy, for callers
     that hold the matrix on the host (the file path gets these rows from the device: DeviceModel.phase_gt2)"""
-    a = (np.asarray(npy).T & 3).astype(np.uint8)   # (V, 2n)
+    npy = np.asarray(npy)
+    if npy.size and (npy.min() < 0 or npy.max() > 3):
+        raise ValueError("pack_gt2: entries must be 0 .. 3 (two bits per call); got values in [%s, %s]" % (npy.min(), npy.max()))
+    a = npy.T.astype(np.uint8)   # (V, 2n)
     V, N = a.shape
     ldg = (N + 15) // 16 * 4
     pad = np.zeros((V, ldg * 4), np.uint8)

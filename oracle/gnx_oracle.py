@@ -80,11 +80,18 @@ def base_lr_windows(X, M, ctx, coef, intercept, w0, w1, B):
     return B
 
 
-def base_lr_blas(X, M, ctx, coef, intercept, w0=0, w1=None, out=None):
+def base_lr_pad(X, ctx):
+    """Base.pad (src/Base/base.py:41-44): ctx reflected SNPs on both sides"""
+    X = np.asarray(X)
+    return np.concatenate([X[:, :ctx][:, ::-1], X, X[:, X.shape[1] - ctx:][:, ::-1]], axis=1) if ctx else X
+
+
+def base_lr_blas(X, M, ctx, coef, intercept, w0=0, w1=None, out=None, Xp=None):
     """The same step through the host's BLAS, window by window, the way the reference computes it: sklearn's
     LogisticRegression.predict_proba of an OvR model = expit(X_w.astype(float64) @ coef_.T + intercept_), normalised
     (src/Base/models.py:12-21 through src/Base/base.py:146-180; reflect padding of base.py:41-44).  Summation order is the
-    BLAS library's, so values differ from base_lr in the last bits (tests allow 1e-12)."""
+    BLAS library's, so values differ from base_lr in the last bits (tests allow 1e-12).  `Xp`: the reflect-padded matrix from an
+    earlier call (base_lr_pad), so that window ranges running on several threads share one copy."""
     X = np.asarray(X)
     N, Cn = X.shape
     W, A, ldc = coef.shape
@@ -92,7 +99,8 @@ def base_lr_blas(X, M, ctx, coef, intercept, w0=0, w1=None, out=None):
     M_ = M + 2 * ctx
     w1 = W if w1 is None else w1
     B = np.empty((N, W, A), np.float64) if out is None else out
-    Xp = np.concatenate([X[:, :ctx][:, ::-1], X, X[:, Cn - ctx:][:, ::-1]], axis=1) if ctx else X
+    if Xp is None:
+        Xp = base_lr_pad(X, ctx)
     for i in range(w0, w1):
         lo, n = (i * M, M_) if i < W - 1 else (Xp.shape[1] - (M_ + rem), M_ + rem)
         z = Xp[:, lo:lo + n].astype(np.float64) @ coef[i, :, :n].T + intercept[i]

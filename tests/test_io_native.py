@@ -382,3 +382,32 @@ def test_reader_survives_mutated_files(tmp_path):
         if m is not None and len(m["variants/POS"]) == a.n_variants:
             assert np.array_equal(a["calldata/GT"], m["calldata/GT"]) and np.array_equal(a["variants/POS"], m["variants/POS"])
     assert n_ok > 20 and n_err > 20
+
+
+@pytest.mark.parametrize("nt", [1, 4])
+def test_writers_report_a_failed_write_instead_of_hanging(tmp_path, nt):
+    """with more than one thread a failed write() (disk full, file size limit) left the writer waiting for blocks
+    nobody would fill.  A child process with RLIMIT_FSIZE = 100 KB (SIGXFSZ ignored, so write() fails with EFBIG) must get a
+    GnxError from write_msp within seconds."""
+    import subprocess
+    import sys
+    code = f"""
+import resource, signal, sys
+import numpy as np
+sys.path.insert(0, {ROOT!r})
+from gnomix_amd import postprocess as pp, _lib
+signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
+resource.setrlimit(resource.RLIMIT_FSIZE, (100 * 1024, 100 * 1024))
+N, W, A, M = 400, 300, 4, 10
+rng = np.random.default_rng(0)
+pos = np.sort(rng.choice(10 ** 6, W * M + 3, replace=False))
+meta = pp.get_meta_data("22", pos, pos[::2], W, M, np.array([0, 10 ** 6]), np.array([0.0, 3.3]))
+try:
+    pp.write_msp({str(tmp_path / 'big')!r}, meta, rng.integers(0, A, (N, W)), ["P%d" % a for a in range(A)], ["I%d" % i for i in range(N // 2)], n_threads={nt})
+except (_lib.GnxError, OSError) as e:
+    print("raised", type(e).__name__)
+    sys.exit(0)
+sys.exit(3)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "raised" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
