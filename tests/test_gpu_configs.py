@@ -148,3 +148,55 @@ def test_config4_multi_chromosome_models_in_one_context(ga, oracle):
     assert all(b > 0 for b in info)
     for m in models:
         m.close()
+
+
+def test_config4_whole_genome_22_models_resident_in_one_context(ga, oracle):
+    """BASELINE configs[3] at its real geometry on ONE GPU (W_k of synth.GENOME_W, C_k = 1000 W_k + 500, sum W =
+    17 727, A = 7, logistic base + xgb smoother): all 22 chromosome models resident in one context (what each of the 8 GPUs of the
+    config holds: the model is replicated, individuals are sharded), chromosome-major batches of the same 500 haplotypes.
+    Size-independent properties on every chromosome, the oracle on two haplotypes of the largest chromosome and of chr22, and the
+    HBM the models hold."""
+    import time
+    import torch
+    from gnomix_amd import synth, _lib
+    t_start = time.time()
+    A, S, N = 7, 75, 500
+    assert len(synth.GENOME_W) == 22 and sum(synth.GENOME_W) == 17_727
+    ctx = _lib.Context(0)
+    free0 = torch.cuda.mem_get_info()[0]
+    models, keep = [], {}
+    for k, Wk in enumerate(synth.GENOME_W):
+        d = synth.synthetic_model(C=1000 * Wk + 500, M=1000, A=A, S=S, n_rounds=100, seed=400 + k)
+        models.append(ga.DeviceModel(d, ctx=ctx))
+        if k in (0, 21):
+            keep[k] = d           # the oracle needs the host arrays of the two chromosomes it checks
+        del d
+    assert [m.W for m in models] == list(synth.GENOME_W)
+    held = sum(int(m.info.device_bytes) for m in models)
+    # ~112 bytes per (SNP, class pair) of int8 weight digits: 2.3 GB for the genome (DESIGN.md 2), and the device really holds it
+    assert 2.0e9 < held < 2.8e9, held
+    assert free0 - torch.cuda.mem_get_info()[0] >= 0.95 * held
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).cuda()
+    for k, m in enumerate(models):
+        X = synth.synthetic_X_device(N, m.C, "cuda:0", seed=900 + k)
+        p, lab = m.infer_device(X)
+        p2, lab2 = m.infer_device(X[perm].contiguous())                 # haplotypes are independent rows
+        torch.cuda.synchronize()
+        assert p.shape == (N, m.W, A) and lab.shape == (N, m.W)
+        assert torch.equal(p2, p[perm]) and torch.equal(lab2, lab[perm]), k
+        assert float((p.sum(-1) - 1).abs().max()) <= 1e-5 and bool(torch.isfinite(p).all())
+        assert torch.equal(lab.long(), p.argmax(-1)) or bool((p.gather(-1, lab.long().unsqueeze(-1)).squeeze(-1) == p.max(-1).values).all())
+        if k in keep:
+            d = keep[k]
+            idx = [0, N - 1]
+            Xh = X[idx].cpu().numpy()
+            Bo = oracle.base_lr(Xh, d.M, d.context, d.lr_coef, d.lr_intercept)
+            p_ref, l_ref = oracle.smooth_xgb(_trees(oracle, d), Bo, S)
+            assert np.array_equal(lab[idx].cpu().numpy(), l_ref) and np.max(np.abs(p[idx].cpu().numpy() - p_ref)) <= 1e-5, k
+            ph, lh = m.infer(X[:64].cpu().numpy())                      # the host-pointer route on the same rows
+            assert np.array_equal(ph, p[:64].cpu().numpy()) and np.array_equal(lh, lab[:64].cpu().numpy())
+        del X, p, lab, p2, lab2
+    for m in models:
+        m.close()
+    ctx.close()
+    assert time.time() - t_start < 120, "the whole-genome residency test is meant to stay near a minute"
