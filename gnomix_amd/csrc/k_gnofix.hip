@@ -216,6 +216,36 @@ struct TreesLds {
   __device__ __forceinline__ uint4 u128(uint32_t word) const { return *reinterpret_cast<const uint4*>(p + word); }
 };
 
+// One level of a rank walk in the instructions the hardware has for it (hipcc spends 6-7 VALU operations on the same C++: shift, mask,
+// compare, select, add): the rank's LDS address = row + low half of the node word (one SDWA add), the branch = "rank field <= rank"
+// straight from the node word's high half (SDWA compare into vcc), the heap index j = 2j + branch (add-with-carry from vcc).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t rank_addr(uint32_t nd, uint32_t row) {
+  uint32_t a;
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(a) : "v"(nd), "v"(row));
+  return a;
+}
+__device__ __forceinline__ uint32_t step_j(uint32_t j, uint32_t nd, uint32_t r) {
+  asm("v_cmp_le_u32_sdwa vcc, %1, %2 src0_sel:WORD_1 src1_sel:DWORD\n\t"
+      "v_addc_co_u32 %0, vcc, %0, %0, vcc"
+      : "+v"(j) : "v"(nd), "v"(r) : "vcc");
+  return j;
+}
+// levels 0 and 1 from the tree's first 16 bytes: j = 2 + branch, the level-1 node = branch ? right : left
+__device__ __forceinline__ void step_top(uint32_t root, uint32_t lo, uint32_t hi, uint32_t r, uint32_t& j, uint32_t& n1) {
+  asm("v_cmp_le_u32_sdwa vcc, %2, %3 src0_sel:WORD_1 src1_sel:DWORD\n\t"
+      "v_cndmask_b32 %1, %4, %5, vcc\n\t"
+      "v_addc_co_u32_e64 %0, vcc, 1, 1, vcc"
+      : "=&v"(j), "=&v"(n1) : "v"(root), "v"(r), "v"(lo), "v"(hi) : "vcc");
+}
+__device__ __forceinline__ uint32_t lds_rank(uint32_t addr) { return *(const __attribute__((address_space(3))) uint16_t*)(uintptr_t)addr; }
+#else   // host pass: never called
+__device__ inline uint32_t rank_addr(uint32_t, uint32_t) { return 0; }
+__device__ inline uint32_t step_j(uint32_t j, uint32_t, uint32_t) { return j; }
+__device__ inline void step_top(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t& j, uint32_t& n1) { j = n1 = 0; }
+__device__ inline uint32_t lds_rank(uint32_t) { return 0; }
+#endif
+
 // Tree layout of k_gnofix (SmoothXGBDev::gf_packed): 2^D node words in heap order (slot 0 unused; rank field << 16 | byte offset of
 // the feature in the tile) followed by 2^D float leaves — the leaf of heap index j is word j.  Words 0..3 = {-, root, node 2, node 3}
 // arrive in ONE 16-byte read, so levels 0 and 1 cost one dependent round trip (D >= 2): a depth-4 walk is 4 of them.
@@ -226,6 +256,7 @@ template <int NW, int DT, bool CLAMP, typename Trees>
 __device__ __forceinline__ void walk_seq(const Trees T, uint32_t t0, uint32_t tmax, const uint8_t* row, int Drt, float (&out)[NW]) {
   const int D = DT ? DT : Drt;
   const uint32_t TWc = 2u << D;
+  const uint32_t rowa = (uint32_t)(uintptr_t)row;  // (the low 32 bits of a generic pointer into the LDS are its LDS address)
   uint32_t j[NW];
   uint32_t tb[NW];
 #pragma unroll
@@ -235,9 +266,9 @@ __device__ __forceinline__ void walk_seq(const Trees T, uint32_t t0, uint32_t tm
 #pragma unroll
     for (int k = 0; k < NW; ++k) nd[k] = T.u32(tb[k] + j[k]);
 #pragma unroll
-    for (int k = 0; k < NW; ++k) r[k] = *reinterpret_cast<const uint16_t*>(row + (nd[k] & 0xffffu));
+    for (int k = 0; k < NW; ++k) r[k] = lds_rank(rank_addr(nd[k], rowa));
 #pragma unroll
-    for (int k = 0; k < NW; ++k) j[k] = 2 * j[k] + ((r[k] < (nd[k] >> 16)) ? 0u : 1u);
+    for (int k = 0; k < NW; ++k) j[k] = step_j(j[k], nd[k], r[k]);
   };
   if (D >= 2) {
     uint4 top[NW];
@@ -245,17 +276,13 @@ __device__ __forceinline__ void walk_seq(const Trees T, uint32_t t0, uint32_t tm
 #pragma unroll
     for (int k = 0; k < NW; ++k) top[k] = T.u128(tb[k]);
 #pragma unroll
-    for (int k = 0; k < NW; ++k) r[k] = *reinterpret_cast<const uint16_t*>(row + (top[k].y & 0xffffu));
+    for (int k = 0; k < NW; ++k) r[k] = lds_rank(rank_addr(top[k].y, rowa));
 #pragma unroll
-    for (int k = 0; k < NW; ++k) {
-      const bool right = !(r[k] < (top[k].y >> 16));
-      n1[k] = right ? top[k].w : top[k].z;
-      j[k] = right ? 3u : 2u;
-    }
+    for (int k = 0; k < NW; ++k) step_top(top[k].y, top[k].z, top[k].w, r[k], j[k], n1[k]);
 #pragma unroll
-    for (int k = 0; k < NW; ++k) r[k] = *reinterpret_cast<const uint16_t*>(row + (n1[k] & 0xffffu));
+    for (int k = 0; k < NW; ++k) r[k] = lds_rank(rank_addr(n1[k], rowa));
 #pragma unroll
-    for (int k = 0; k < NW; ++k) j[k] = 2 * j[k] + ((r[k] < (n1[k] >> 16)) ? 0u : 1u);
+    for (int k = 0; k < NW; ++k) j[k] = step_j(j[k], n1[k], r[k]);
     if constexpr (DT > 0) {
 #pragma unroll
       for (int d = 2; d < DT; ++d) level();
@@ -277,6 +304,7 @@ __device__ __forceinline__ void walk4(const Trees T, uint32_t t0, const uint8_t*
                                       float* out) {
   const int D = DT ? DT : Drt;
   const uint32_t TWc = 2u << D;
+  const uint32_t rowa[2] = {(uint32_t)(uintptr_t)row + roff[0], (uint32_t)(uintptr_t)row + roff[1]};
   uint32_t j[NT_ * 2];
   uint32_t tw[NT_];
 #pragma unroll
@@ -286,9 +314,9 @@ __device__ __forceinline__ void walk4(const Trees T, uint32_t t0, const uint8_t*
 #pragma unroll
     for (int q = 0; q < NT_ * 2; ++q) nd[q] = T.u32(tw[q >> 1] + j[q]);
 #pragma unroll
-    for (int q = 0; q < NT_ * 2; ++q) r[q] = *reinterpret_cast<const uint16_t*>(row + roff[q & 1] + (nd[q] & 0xffffu));
+    for (int q = 0; q < NT_ * 2; ++q) r[q] = lds_rank(rank_addr(nd[q], rowa[q & 1]));
 #pragma unroll
-    for (int q = 0; q < NT_ * 2; ++q) j[q] = 2 * j[q] + ((r[q] < (nd[q] >> 16)) ? 0u : 1u);
+    for (int q = 0; q < NT_ * 2; ++q) j[q] = step_j(j[q], nd[q], r[q]);
   };
   if (D >= 2) {
     uint4 top[NT_];
@@ -296,17 +324,13 @@ __device__ __forceinline__ void walk4(const Trees T, uint32_t t0, const uint8_t*
     for (int k = 0; k < NT_; ++k) top[k] = T.u128(tw[k]);
     uint32_t r[NT_ * 2], n1[NT_ * 2];
 #pragma unroll
-    for (int q = 0; q < NT_ * 2; ++q) r[q] = *reinterpret_cast<const uint16_t*>(row + roff[q & 1] + (top[q >> 1].y & 0xffffu));
+    for (int q = 0; q < NT_ * 2; ++q) r[q] = lds_rank(rank_addr(top[q >> 1].y, rowa[q & 1]));
 #pragma unroll
-    for (int q = 0; q < NT_ * 2; ++q) {
-      const bool right = !(r[q] < (top[q >> 1].y >> 16));
-      n1[q] = right ? top[q >> 1].w : top[q >> 1].z;
-      j[q] = right ? 3u : 2u;
-    }
+    for (int q = 0; q < NT_ * 2; ++q) step_top(top[q >> 1].y, top[q >> 1].z, top[q >> 1].w, r[q], j[q], n1[q]);
 #pragma unroll
-    for (int q = 0; q < NT_ * 2; ++q) r[q] = *reinterpret_cast<const uint16_t*>(row + roff[q & 1] + (n1[q] & 0xffffu));
+    for (int q = 0; q < NT_ * 2; ++q) r[q] = lds_rank(rank_addr(n1[q], rowa[q & 1]));
 #pragma unroll
-    for (int q = 0; q < NT_ * 2; ++q) j[q] = 2 * j[q] + ((r[q] < (n1[q] >> 16)) ? 0u : 1u);
+    for (int q = 0; q < NT_ * 2; ++q) j[q] = step_j(j[q], n1[q], r[q]);
     if constexpr (DT > 0) {
 #pragma unroll
       for (int d = 2; d < DT; ++d) level();

@@ -26,8 +26,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # an environment knob or an unusual model selects) are reported but do not fail the check.
 MUST_BE_CLEAN = [
     r"k_base_logistic_i8<2, 1, 8, 2>", r"k_base_logistic_i8_dl<1, 2, 16, 2>", r"k_base_logistic<",
-    r"k_smooth_xgb_rk<3, 8, 4, true, ", r"k_smooth_xgb_h64<", r"k_smooth_ranks", r"k_smooth_crf_row16<", r"k_crf_psi<", r"k_smooth_cnn<",
-    r"k_gnofix<", r"k_covrsk_dec_fast<\d+, 7>", r"k_covrsk_dec_fast<\d+, 0>", r"k_covrsk_dec<", r"k_svc_couple", r"k_calibrate",
+    r"k_smooth_xgb_rk<3, 8, 4, true, ", r"k_smooth_crf_ck<", r"k_smooth_crf_row16<", r"k_crf_psi<", r"k_smooth_cnn<",
+    r"k_gnofix<", r"k_gnofix_ranks", r"k_gnofix_dif", r"k_gnofix_swap", r"k_gnofix_pmax", r"k_gnofix_count", r"k_gnofix_scan", r"k_gnofix_scatter", r"k_covrsk_dec_fast<\d+, 7>", r"k_covrsk_dec_fast<\d+, 0>", r"k_covrsk_dec<", r"k_svc_couple", r"k_calibrate",
     r"k_base_forest2<", r"k_base_forest<1, true, 8, 1>", r"k_base_forest<1, true, 16, 1>",
     r"k_unpack2<", r"k_gt2_to_x<", r"k_x_to_gt2", r"k_tr_forward<", r"k_tr_backward<", r"k_gbt_",
 ]

@@ -314,6 +314,22 @@ def test_crf_end_to_end_and_no_phasing(ga, oracle):
 
 
 # ---------------------------------------------------------------- gnofix ----------------------------
+@pytest.fixture(params=["rk512", "rk256", "rk1024", "f32"])
+def gnofix_ctx(request, monkeypatch):
+    """every Gnofix kernel on every case: the rank-strip kernel (k_gnofix.hip) with 512 (default), 256 and 1024 threads per
+    individual, and the float32-strip kernel of rounds 1-3 (k_gnofix_f32.hip: the fallback for ensembles without a rank copy).
+    The knobs are read once per context."""
+    from gnomix_amd import _lib
+    if request.param == "f32":
+        monkeypatch.setenv("GNX_GNOFIX_IMPL", "f32")
+    else:
+        monkeypatch.setenv("GNX_GNOFIX_IMPL", "rk")
+        monkeypatch.setenv("GNX_GNOFIX_T", request.param[2:])
+    ctx = _lib.Context(0)
+    yield ctx
+    ctx.close()
+
+
 def _gnofix_model(ga, g, prefix):
     W, A, S, C = int(g["W"]), int(g["A"]), int(g["S"]), int(g["C"])
     return ga.GnxModelData(C=C, M=C // W, A=A, S=S, context=0, smooth_kind="xgb", tree_off=g[prefix + "tree_off"],
@@ -323,9 +339,9 @@ def _gnofix_model(ga, g, prefix):
 
 
 @pytest.mark.parametrize("name", ["none", "one", "two", "edges", "many", "rand"])
-def test_gnofix_golden_G5(ga, name):
+def test_gnofix_golden_G5(ga, name, gnofix_ctx):
     g = load_golden("G5_gnofix.npz")
-    dev = ga.DeviceModel(_gnofix_model(ga, g, "r_" if name == "rand" else "t_"))
+    dev = ga.DeviceModel(_gnofix_model(ga, g, "r_" if name == "rand" else "t_"), ctx=gnofix_ctx)
     X = np.stack([g[name + "_Xm"], g[name + "_Xp"]]).astype(np.int8)
     Xo, Y, nsw = dev.gnofix(X, g[name + "_B"], max_it=4 if name == "rand" else 50)
     assert np.array_equal(Xo[0], g[name + "_oXm"]) and np.array_equal(Xo[1], g[name + "_oXp"])   # vs the REFERENCE's gnofix()
@@ -340,7 +356,7 @@ def test_phase_wrapper_golden_G5(ga):
     assert np.array_equal(Xph, g["phase_oX"]) and np.array_equal(Yph, g["phase_oY"])  # vs reference Gnomix.phase()
 
 
-def test_gnofix_vs_oracle_random_individuals(ga, oracle):
+def test_gnofix_vs_oracle_random_individuals(ga, oracle, gnofix_ctx):
     """more individuals, chaotic smoother: many accepted switches, edge windows, max_it stops"""
     from gnomix_amd import synth
     W, A, S = 170, 5, 75
@@ -348,7 +364,7 @@ def test_gnofix_vs_oracle_random_individuals(ga, oracle):
     d = ga.GnxModelData(C=C, M=7, A=A, S=S, context=0, smooth_kind="xgb")
     for k, v in synth.synthetic_trees(6, A, S * A, seed=3, thr_lo=0.0, thr_hi=0.6, leaf_scale=1.0).items():
         setattr(d, k, v)
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=gnofix_ctx)
     T = _oracle_trees(oracle, d)
     rng = np.random.RandomState(0)
     n_ind = 12
@@ -483,7 +499,7 @@ def test_cli_end_to_end(ga, oracle, tmp_path, phase):
 
 
 @pytest.mark.parametrize("extra", [16, 4, 8, 13])  # row pitch: 16-, 4-, 8-byte and unaligned SNP granules
-def test_gnofix_wide_windows_and_equal_blocks(ga, oracle, extra):
+def test_gnofix_wide_windows_and_equal_blocks(ga, oracle, extra, gnofix_ctx):
     """windows of several hundred SNPs: blocks that are identical between the two haplotypes (no contribution to the
     convergence signature), blocks that differ only in their last SNP, and the vectorised SNP swap at every alignment"""
     from gnomix_amd import synth
@@ -492,7 +508,7 @@ def test_gnofix_wide_windows_and_equal_blocks(ga, oracle, extra):
     d = ga.GnxModelData(C=C, M=M, A=A, S=S, context=0, smooth_kind="xgb")
     for k, v in synth.synthetic_trees(3, A, S * A, seed=21, thr_lo=0.0, thr_hi=0.5, leaf_scale=1.0).items():
         setattr(d, k, v)
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=gnofix_ctx)
     T = _oracle_trees(oracle, d)
     rng = np.random.RandomState(40 + extra)
     n_ind = 3
@@ -517,15 +533,16 @@ def test_gnofix_wide_windows_and_equal_blocks(ga, oracle, extra):
     assert int(nsw.sum()) > 0
 
 
-def test_gnofix_strips_in_global_scratch(ga, oracle):
-    """an individual whose two padded strips exceed the LDS budget takes the global-scratch path"""
+def test_gnofix_strips_in_global_scratch(ga, oracle, gnofix_ctx):
+    """a long chromosome with many classes (W = 1500, A = 12): the float32 kernel's strips exceed the LDS and take its
+    global-scratch path; the rank kernel reads its tiles from the rank strips in HBM whatever W is"""
     from gnomix_amd import synth
     W, A, S = 1500, 12, 75
     C = W * 3 + 2
     d = ga.GnxModelData(C=C, M=3, A=A, S=S, context=0, smooth_kind="xgb")
     for k, v in synth.synthetic_trees(2, A, S * A, seed=8, thr_lo=0.0, thr_hi=0.4, leaf_scale=1.0).items():
         setattr(d, k, v)
-    dev = ga.DeviceModel(d)
+    dev = ga.DeviceModel(d, ctx=gnofix_ctx)
     T = _oracle_trees(oracle, d)
     rng = np.random.RandomState(2)
     X = rng.randint(0, 2, size=(4, C)).astype(np.int8)
