@@ -119,13 +119,20 @@ static void read_tune(gnx_tune& t) {
   t.debug = std::getenv("GNX_DEBUG") ? atoi(std::getenv("GNX_DEBUG")) : 0;
   if (const char* e = std::getenv("GNX_GNOFIX_IMPL")) t.gnofix_impl = std::string(e) == "f32" ? 1 : 0;
   t.gnofix_threads = geti("GNX_GNOFIX_T", 0);
+  t.gnofix_aux = geti("GNX_GNOFIX_AUX", 1);
 }
 
 extern "C" {
 
 int gnx_abi_version(void) { return GNX_ABI_VERSION; }
 
+// HIP maps streams onto 4 hardware queues by default and two streams on one queue serialise; a context uses up to five (see
+// gnomix_amd/_lib.py: load).  Effective when the runtime has not been initialised yet; an embedding application that has already
+// used HIP sets GPU_MAX_HW_QUEUES itself.
+static void want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 int gnx_device_count(void) {
+  want_hw_queues();
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
@@ -136,6 +143,7 @@ int gnx_init(int device, gnx_ctx** out) {
   gnx_ctx* ctx = new (std::nothrow) gnx_ctx();
   if (!ctx) return GNX_ENOMEM;
   ctx->device = device;
+  want_hw_queues();
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -943,8 +951,11 @@ static int gnofix_ws_reserve(gnx_model* m, int64_t n, int32_t max_it, bool in_ld
 }
 
 // device-resident batch: initial labels with the batched smoother kernel, then one workgroup per individual
+// side_stream: run the input-only pre-passes beside the smoother.  Not from the host-pointer pipeline: a fifth stream makes two of
+// them share a hardware queue (HIP maps streams onto 4 by default), and when those two are the copy-in and copy-out streams the
+// pipeline's H2D and D2H stop overlapping (measured: 13.3 k -> 9.2 k individuals/s through host pointers).
 static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int64_t n, int32_t max_it, int32_t* dY,
-                          int32_t* dNs, bool in_lds) {
+                          int32_t* dNs, bool in_lds, bool side_stream) {
   gnx_ctx* ctx = m->ctx;
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
   int rc;
@@ -963,18 +974,23 @@ static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* d
     L.par = (uint32_t*)(base + ws.par); L.dif = (const uint32_t*)(base + ws.dif); L.R = (const uint16_t*)(base + ws.rk);
     L.gf = m->xgb.gf_packed; L.gf_pitch = m->xgb.gf_pitch; L.gf_cap = gnx_gnofix_cap(m->xgb.gf_max_class, m->xgb.D, S, gnofix_threads(m));
     // ranks of B and the SNP-difference masks of X need nothing of the smoother: they run beside it on the side stream
-    if (!ctx->s_aux) {
+    side_stream = side_stream && ctx->tune.gnofix_aux;
+    if (side_stream && !ctx->s_aux) {
       HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
       for (int b = 0; b < 2; ++b) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_aux[b], hipEventDisableTiming));
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_aux[0], ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_aux[0], 0));
-    HIPCHK(ctx, gnx_launch_gnofix_prep(L, n, ctx->s_aux));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_aux[1], ctx->s_aux));
+    if (side_stream) {
+      HIPCHK(ctx, hipEventRecord(ctx->ev_aux[0], ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_aux[0], 0));
+      HIPCHK(ctx, gnx_launch_gnofix_prep(L, n, ctx->s_aux));
+      HIPCHK(ctx, hipEventRecord(ctx->ev_aux[1], ctx->s_aux));
+    } else {
+      HIPCHK(ctx, gnx_launch_gnofix_prep(L, n, ctx->stream));
+    }
   }
   // initial labels = smoother.predict(B) for every haplotype at once (gnofix.py:80)
   rc = gnx_smooth_predict_dev(m, dB, 1, 2 * n, (float*)ctx->ws_p32.p, nullptr, dY0);
-  if (rk) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[1], 0));  // (also on failure: the side stream is joined)
+  if (rk && side_stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[1], 0));  // (also on failure: the side stream is joined)
   if (rc != GNX_OK) return rc;
   ProfScope ps(ctx, GNX_K_GNOFIX);
   if (rk) {
@@ -993,7 +1009,7 @@ int gnx_gnofix_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int6
   bool in_lds = true;
   int rc = gnofix_check(m, ldx, n_ind, max_it, dX && dB && dY, &in_lds);
   if (rc != GNX_OK || n_ind == 0) return rc;
-  return gnofix_run_dev(m, dX, ldx, dB, n_ind, max_it, dY, d_n_switches, in_lds);
+  return gnofix_run_dev(m, dX, ldx, dB, n_ind, max_it, dY, d_n_switches, in_lds, true);
 }
 
 int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_ind, int32_t max_it, int32_t* Y,
@@ -1046,7 +1062,7 @@ int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_
     int32_t* dY = (int32_t*)((char*)ctx->ws_lab.p + (size_t)b * y_b);
     int32_t* dNs = dY + (size_t)2 * nb * W;
     if (nbuf == 2) HIPCHK(ctx, hipStreamWaitEvent(sc, ctx->ev_in[b], 0));
-    if ((rc = gnofix_run_dev(m, dX, ldx, dB, n, max_it, dY, dNs, in_lds)) != GNX_OK) return rc;
+    if ((rc = gnofix_run_dev(m, dX, ldx, dB, n, max_it, dY, dNs, in_lds, nbuf == 1)) != GNX_OK) return rc;
     if (nbuf == 2) HIPCHK(ctx, hipEventRecord(ctx->ev_done[b], sc));
     // (two halves: the next batch goes up before this one's results are awaited; one half: X is both input and output of it)
     if (nbuf == 2 && i + 1 < n_batches && (rc = issue_h2d(i + 1)) != GNX_OK) return rc;

@@ -49,6 +49,7 @@ struct gnx_tune {
   int h2d_overlap = 1;                  // GNX_H2D_OVERLAP=0: serial staging (one stream) in the host-pointer entry points
   int lr_lds_pad = 0, sm_lds_pad = 0;   // GNX_LDS_PAD="lr,sm": extra dynamic LDS bytes (occupancy experiments: scripts/dev/overlap_probe.py)
   int gnofix_impl = 0;                  // GNX_GNOFIX_IMPL=f32: the float32-strip kernel (k_gnofix_f32) even where the rank kernel runs
+  int gnofix_aux = 1;                   // GNX_GNOFIX_AUX=0: the input-only pre-passes of k_gnofix on the context stream instead of beside the smoother
   int gnofix_threads = 0;               // GNX_GNOFIX_T: threads per individual of k_gnofix (192, 256, 384, 512)
   int debug = 0;                        // GNX_DEBUG
 };
