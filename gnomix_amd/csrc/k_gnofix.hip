@@ -349,7 +349,7 @@ __device__ __forceinline__ void walk4(const Trees T, uint32_t t0, const uint8_t*
 __host__ __device__ inline int gnofix_rows_max(int S, int threads) { return 2 * min(S + 2, threads / 2); }
 
 struct GnofixLds {
-  size_t seg, Y, pmax, par, dif, chg, marg, ex, stage, flags, ct0, total;
+  size_t seg, Y, pmax, par, dif, chg, rej, marg, ex, stage, flags, ct0, total;
 };
 __host__ __device__ inline GnofixLds gnofix_lds(int W, int A, int S, int GP, int cap, int D, int threads, int n_trees) {
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
@@ -362,6 +362,7 @@ __host__ __device__ inline GnofixLds gnofix_lds(int W, int A, int S, int GP, int
   o.par = off; off += r16(NWD * 4);
   o.dif = off; off += r16(NWD * 4);
   o.chg = off; off += r16(NWD * 4 + 4);
+  o.rej = off; off += r16(NWD * 4 + 4);
   o.marg = off; off += r16(nrow * A * 4);
   o.ex = off; off += r16((size_t)(threads / 64) * 2 * A * 4);
   {  // re-evaluation: `cap` staged trees for each of the block's row sets; candidate: the leaves [2][n_trees] (never both)
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   uint32_t* par = reinterpret_cast<uint32_t*>(lds + o.par);   // switch parity per window
   uint32_t* dif = reinterpret_cast<uint32_t*>(lds + o.dif);   // SNP block differs m vs p
   uint8_t* chg = lds + o.chg;                                 // bit u: the labels of window u differ from window u-1's
+  uint32_t* rej = reinterpret_cast<uint32_t*>(lds + o.rej);   // bit u: the candidate at u was evaluated and rejected, and nothing it reads has changed since
   float* marg = reinterpret_cast<float*>(lds + o.marg);       // candidate: [2][A]; re-evaluation: [A][NROW]
   float* ex = reinterpret_cast<float*>(lds + o.ex);           // candidate: exp(margin - row max) [2][A], one copy per wave
   uint32_t* stage = reinterpret_cast<uint32_t*>(lds + o.stage);  // re-evaluation: staged trees of one class
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
     pmax[2 * u] = L.P0[(size_t)2 * ind * W + u];
     pmax[2 * u + 1] = L.P0[(size_t)(2 * ind + 1) * W + u];
   }
-  for (int q = tid; q < NWD; q += THREADS) { par[q] = 0; dif[q] = L.dif[(size_t)ind * NWD + q]; }
+  for (int q = tid; q < NWD; q += THREADS) { par[q] = 0; rej[q] = 0; dif[q] = L.dif[(size_t)ind * NWD + q]; }
   __syncthreads();
   auto parbit = [&](int u) -> int { return (int)((par[u >> 5] >> (u & 31)) & 1u); };
   auto mark_changes = [&](int t_) {  // one byte of the mask (8 windows) per thread
@@ -452,12 +454,18 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   mark_changes(tid);
   __syncthreads();
   // check(): "disc_smooth" (gnofix.py:32): the reference walks w = 1 .. W-1 and acts only where a label changes; every wave finds
-  // the next such window for itself (same answer in every wave: no barrier)
+  // the next such window for itself (same answer in every wave: no barrier).
+  // A candidate's decision is a function of the ranks of its scope [lo, lo + S) under the current parity, of the cached
+  // probabilities of row center + 1 and of w.  An accepted switch at w' changes none of them for a candidate whose scope lies
+  // entirely below w' (untouched) or entirely at / above w' (both strips and both cached rows exchange their roles: the switched
+  // pair is the same two rows in the other order, max over the pair unchanged).  So a candidate that was REJECTED stays rejected until a
+  // switch within S windows of it is accepted: `rej` remembers it and later sweeps (the reference re-evaluates every label change in
+  // every sweep, gnofix.py:93-116) skip the walk — the same decisions, a third to a half of the candidate evaluations.
   auto next_change = [&](int from) -> int {
     const uint32_t* cw = reinterpret_cast<const uint32_t*>(chg);
     for (int q0 = from >> 5; q0 < NWD; q0 += 64) {
       const int q = q0 + ln;
-      uint32_t m = q < NWD ? cw[q] : 0u;
+      uint32_t m = q < NWD ? (cw[q] & ~rej[q]) : 0u;
       if (q == from >> 5) m &= 0xffffffffu << (from & 31);
       const unsigned long long bal = __ballot(m != 0);
       if (bal) {
@@ -620,7 +628,11 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
         accept = p_sw * 0.5f > p_orig * 0.5f;                      // prior_switch_prob = 0.5 (gnofix.py:171)
       }
       TICK(5)
-      if (!accept) { w = w_next; continue; }
+      if (!accept) {
+        if (tz == 0) atomicOr(&rej[w >> 5], 1u << (w & 31));
+        w = w_next;
+        continue;
+      }
       pf_valid = false;
 
       // ---- accept: flip the parity from w on, relabel ----
@@ -631,6 +643,15 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
         if (w <= b0) m = 0xffffffffu;
         else if (w < b0 + 32) m = 0xffffffffu << (w - b0);
         par[q] ^= m;
+      }
+      GNX_NOUNROLL for (int q = tz; q < NWD; q += THREADS) {  // candidates within S windows of w are open again
+        const int lo_w = max(w - S, 0), hi_w = min(w + S, W - 1), b0 = q * 32;
+        if (b0 + 31 >= lo_w && b0 <= hi_w) {
+          uint32_t m = 0xffffffffu;
+          if (lo_w > b0) m &= 0xffffffffu << (lo_w - b0);
+          if (hi_w < b0 + 31) m &= 0xffffffffu >> (b0 + 31 - hi_w);
+          rej[q] &= ~m;
+        }
       }
       if (tz == 0) { flags[2] = W; flags[3] = 0; }
       __syncthreads();
