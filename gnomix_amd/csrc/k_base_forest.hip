@@ -31,6 +31,15 @@
 #include <cstdint>
 #include <cstdlib>
 
+#ifndef GNX_FOREST_PART
+#define GNX_FOREST_PART 0
+#endif
+// This file is compiled four times (Makefile: k_base_forest.o, k_base_forest_p1/p2/p3.o with -DGNX_FOREST_PART=1..3), each pass
+// instantiating two tree depths: one pass with all eight took 69 s, longer than the rest of the library together.
+hipError_t gnx_forest_v1_part1(const ForestLaunch& L, int haps, size_t lds, bool two, hipStream_t s);
+hipError_t gnx_forest_v1_part2(const ForestLaunch& L, int haps, size_t lds, bool two, hipStream_t s);
+hipError_t gnx_forest_v1_part3(const ForestLaunch& L, int haps, size_t lds, bool two, hipStream_t s);
+
 namespace {
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -420,6 +429,7 @@ hipError_t launch_xgb(const ForestLaunch& L, int haps, size_t lds, bool two, hip
   return two ? launch_k<D, false, 32, 2>(L, haps, lds, s) : launch_k<D, false, 32, 1>(L, haps, lds, s);
 }
 
+#if GNX_FOREST_PART == 0
 // windows [w_first, w_first + n_windows), all of padded width `width` (the last window of the chromosome goes alone)
 hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int64_t width, int n_cu, const gnx_tune& tune, hipStream_t s) {
   if (n_windows <= 0) return hipSuccess;
@@ -464,18 +474,29 @@ hipError_t launch_range(ForestLaunch L, int w_first, int n_windows, int64_t widt
   switch (L.D) {
     case 1: return launch_xgb<1>(L, threads, lds, two, s);
     case 2: return launch_xgb<2>(L, threads, lds, two, s);
-    case 3: return launch_xgb<3>(L, threads, lds, two, s);
-    case 4: return launch_xgb<4>(L, threads, lds, two, s);
-    case 5: return launch_xgb<5>(L, threads, lds, two, s);
-    case 6: return launch_xgb<6>(L, threads, lds, two, s);
-    case 7: return launch_xgb<7>(L, threads, lds, two, s);
-    case 8: return launch_xgb<8>(L, threads, lds, two, s);
+    case 3: case 4: return gnx_forest_v1_part1(L, threads, lds, two, s);
+    case 5: case 6: return gnx_forest_v1_part2(L, threads, lds, two, s);
+    case 7: case 8: return gnx_forest_v1_part3(L, threads, lds, two, s);
     default: return hipErrorInvalidValue;
   }
 }
 
+#endif
 }  // namespace
 
+#if GNX_FOREST_PART == 1
+hipError_t gnx_forest_v1_part1(const ForestLaunch& L, int haps, size_t lds, bool two, hipStream_t s) {
+  return L.D == 3 ? launch_xgb<3>(L, haps, lds, two, s) : launch_xgb<4>(L, haps, lds, two, s);
+}
+#elif GNX_FOREST_PART == 2
+hipError_t gnx_forest_v1_part2(const ForestLaunch& L, int haps, size_t lds, bool two, hipStream_t s) {
+  return L.D == 5 ? launch_xgb<5>(L, haps, lds, two, s) : launch_xgb<6>(L, haps, lds, two, s);
+}
+#elif GNX_FOREST_PART == 3
+hipError_t gnx_forest_v1_part3(const ForestLaunch& L, int haps, size_t lds, bool two, hipStream_t s) {
+  return L.D == 7 ? launch_xgb<7>(L, haps, lds, two, s) : launch_xgb<8>(L, haps, lds, two, s);
+}
+#else
 size_t gnx_forest_lds_bytes(int A, int ring_words, int max_trees, int tree_bytes, int threads) {
   return (size_t)ring_words * threads * 4 + (((size_t)max_trees * tree_bytes + 15) & ~(size_t)15) + (size_t)A * threads * 4;
 }
@@ -494,3 +515,4 @@ hipError_t gnx_launch_base_forest(const ForestLaunch& L, int n_cu, const gnx_tun
   if (e != hipSuccess) return e;
   return launch_range(L, L.W - 1, 1, L.width_last, n_cu, tune, s);
 }
+#endif
