@@ -301,6 +301,7 @@ def main():
                 tc = json.load(open(os.path.join(ROOT, "profiles", "trained_inputs_latest.json")))
                 ti["lds_conflict_frac"] = tc.get("lds_conflict_frac_of_active")
                 ti["lds_conflict_source"] = tc.get("source")
+                ti["lds_conflict_stale"] = tc.get("kernel_src_sha16") != kernel_src_sha16()   # (a committed counter, not a live one)
             except Exception:
                 pass
             if dom == "k_smooth_xgb":
