@@ -68,7 +68,7 @@ class TrainInfo(C.Structure):
 
 
 class GbtParams(C.Structure):
-    _fields_ = [("n_rounds", C.c_int32), ("max_depth", C.c_int32), ("max_bin", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("n_rounds", C.c_int32), ("max_depth", C.c_int32), ("max_bin", C.c_int32), ("tree_method", C.c_int32),
                 ("eta", C.c_double), ("lam", C.c_double), ("gamma", C.c_double), ("min_child_weight", C.c_double),
                 ("base_score", C.c_double)]
 

@@ -1130,6 +1130,7 @@ static int gbt_check(gnx_ctx* ctx, const void* B, const int32_t* y, int64_t N, i
   if (W < 2 * S) return fail(ctx, GNX_EINVAL, "Smoother size to large for given window size. ");  // src/Smooth/models.py:13
   if (P->n_rounds < 1 || P->n_rounds > 100000 || P->max_depth < 1 || P->max_depth > 5 || P->max_bin < 2 || P->max_bin > 256)
     return fail(ctx, GNX_EINVAL, "train_gbt: n_rounds >= 1, 1 <= max_depth <= 5, 2 <= max_bin <= 256");
+  if (P->tree_method != 0 && P->tree_method != 1) return fail(ctx, GNX_EINVAL, "train_gbt: tree_method is 0 (histogram) or 1 (exact greedy)");
   if (!(P->eta > 0.0) || !(P->lambda >= 0.0) || !(P->gamma >= 0.0) || !(P->min_child_weight >= 0.0))
     return fail(ctx, GNX_EINVAL, "train_gbt: eta > 0, lambda / gamma / min_child_weight >= 0");
   if ((int64_t)N * W >= ((int64_t)1 << 31)) return fail(ctx, GNX_EINVAL, "train_gbt: N * W must stay below 2^31 rows");

@@ -17,6 +17,10 @@
 //   * the softmax goes through det_exp (plain IEEE operations in a fixed order) because the oracle must reproduce p exactly.
 // The trees come back in the layout gnx_model_desc takes (tree_off / left / right / feat / cond / tree_class), thresholds on
 // the 1/65536 grid, so the trained smoother runs on k_smooth_xgb_rk like any other.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <thread>
 #include <vector>
 
 #include "gnx_internal.h"
@@ -358,6 +362,156 @@ __global__ __launch_bounds__(256) void k_gbt_margin(float* Fm, const uint8_t* po
   Fm[e] += nV[c * MAXN + pos[(size_t)c * G.R + i]];
 }
 
+// ---- exact greedy (gnx_gbt_params::tree_method = 1) ------------------------------------------------------------------------------
+// xgboost's tree_method="exact" (what XGBClassifier(...) of src/Smooth/models.py:14-20 uses for data of this size; ColMaker's column
+// scan restated, NOT pinned to xgboost: absent from the image): per node and feature the node's rows in ascending feature value,
+// a candidate between every two consecutive DISTINCT values v0 < v1: rows up to v0 left, threshold (v0 + v1) * 0.5f (v1 when that
+// rounds down to v0).  All features s*A + a of one class column a read the same values — the haplotypes' padded strips of that column —
+// so ONE sorted list of strip positions per column (sorted on the host once per training) serves its S features: feature s sees
+// position (n, j) as row (n, j - s).  k_gbt_exact_scan: one wave per (feature, class tree), 64 sorted positions per step; for every
+// node present in the step a masked wave scan gives each of its rows the node's sums before it and the previous value of the node
+// (the last row of an earlier step is carried in LDS); gains in float64 from exact int64 sums, first-best-wins in scan order — the
+// CPU oracle (gnxo_train_gbt, tree_method 1: a qsort per node and feature) grows IDENTICAL trees (tests/test_train_gbt.py).
+struct ExBest {
+  double gain;   // < 0: no admissible split of this node on this feature
+  float thr;
+  int32_t pad_;
+  long long GL, HL;
+};
+
+__device__ __forceinline__ float gbt_mid(float v0, float v1) {
+  const float m = (v0 + v1) * 0.5f;
+  return m > v0 ? m : v1;
+}
+
+__global__ __launch_bounds__(64) void k_gbt_exact_scan(const int32_t* __restrict__ ordn, const int32_t* __restrict__ ordj, const float* __restrict__ val,
+                                                      const long long* __restrict__ gq, const long long* __restrict__ hq, const uint8_t* __restrict__ pos,
+                                                      const int32_t* __restrict__ st, const long long* __restrict__ nG, const long long* __restrict__ nH,
+                                                      ExBest* __restrict__ cand, int d, double lambda, double gamma, double mcw, Geom G) {
+  __shared__ long long accG[32], accH[32], bGL[32], bHL[32], nodeG[32], nodeH[32];
+  __shared__ double bgain[32];
+  __shared__ float lastv[32], bthr[32];
+  __shared__ int seen[32], open_[32], found[32];
+  const int nl = 1 << d, base = nl - 1, lane = threadIdx.x;
+  const int f = blockIdx.x, c = blockIdx.y, sft = f / G.A, a = f - sft * G.A;
+  if (lane < nl) {
+    const int node = base + lane;
+    accG[lane] = 0; accH[lane] = 0; seen[lane] = 0; found[lane] = 0;
+    open_[lane] = st[c * MAXN + node] == 1;
+    nodeG[lane] = nG[c * MAXN + node]; nodeH[lane] = nH[c * MAXN + node];
+    bgain[lane] = gamma > 1e-6 ? gamma : 1e-6;
+  }
+  __syncthreads();
+  const int64_t NP = G.N * G.Wp, col = (int64_t)a * NP;
+  const long long* gc = gq + (size_t)c * G.R;
+  const long long* hc = hq + (size_t)c * G.R;
+  const uint8_t* pc = pos + (size_t)c * G.R;
+  for (int64_t p0 = 0; p0 < NP; p0 += 64) {
+    const int64_t p = p0 + lane;
+    const bool in = p < NP;
+    const int n = in ? ordn[col + p] : 0, j = in ? ordj[col + p] : 0;
+    const float v = in ? val[col + p] : 0.f;
+    const int w = j - sft;
+    const bool valid = in && w >= 0 && w < G.W;
+    const int64_t row = valid ? (int64_t)n * G.W + w : 0;
+    const int k = valid ? (int)pc[row] - base : -1;
+    const bool live = valid && k >= 0 && k < nl && open_[k];
+    const long long g = live ? gc[row] : 0, h = live ? hc[row] : 0;
+    unsigned long long rem = __ballot(live);
+    while (rem) {
+      const int kcur = __shfl(k, __builtin_ctzll(rem));
+      const bool mask = live && k == kcur;
+      const unsigned long long bal = __ballot(mask);
+      rem &= ~bal;
+      long long sg = mask ? g : 0, sh = mask ? h : 0;
+      const long long ig = sg, ih = sh;
+      for (int o = 1; o < 64; o <<= 1) {
+        const long long tg = __shfl_up(sg, o), th = __shfl_up(sh, o);
+        if (lane >= o) { sg += tg; sh += th; }
+      }
+      const unsigned long long below = bal & ((1ull << lane) - 1ull);
+      bool hasp = below != 0;
+      float vp = __shfl(v, hasp ? 63 - __builtin_clzll(below) : 0);
+      if (!hasp) { vp = lastv[kcur]; hasp = seen[kcur] != 0; }
+      bool ok = false;
+      double gain = 0.0;
+      long long GL = 0, HL = 0;
+      if (mask && hasp && vp < v) {
+        GL = accG[kcur] + (sg - ig);
+        HL = accH[kcur] + (sh - ih);
+        const double gl = (double)GL / FIX, hl = (double)HL / FIX;
+        const double gr = (double)(nodeG[kcur] - GL) / FIX, hr = (double)(nodeH[kcur] - HL) / FIX;
+        if (!(hl < mcw || hr < mcw)) {
+          const double Gd = (double)nodeG[kcur] / FIX, Hd = (double)nodeH[kcur] / FIX;
+          gain = (gl * gl / (hl + lambda) + gr * gr / (hr + lambda)) - Gd * Gd / (Hd + lambda);
+          ok = gain > bgain[kcur];   // strictly better than every earlier candidate of this node on this feature
+        }
+      }
+      const unsigned long long cb = __ballot(ok);
+      if (cb) {  // the largest gain of the step, the earliest lane among equals
+        double mx = ok ? gain : -1.0;
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        const int win = __builtin_ctzll(__ballot(ok && gain == mx));
+        if (lane == win) { bgain[kcur] = gain; bthr[kcur] = gbt_mid(vp, v); bGL[kcur] = GL; bHL[kcur] = HL; found[kcur] = 1; }
+      }
+      if (lane == 63 - __builtin_clzll(bal)) { accG[kcur] += sg; accH[kcur] += sh; lastv[kcur] = v; seen[kcur] = 1; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  __syncthreads();
+  if (lane < nl) {
+    ExBest* dst = cand + ((size_t)c * nl + lane) * G.F + f;
+    dst->gain = found[lane] ? bgain[lane] : -1.0;
+    dst->thr = bthr[lane];
+    dst->pad_ = 0;
+    dst->GL = bGL[lane];
+    dst->HL = bHL[lane];
+  }
+}
+
+// best feature of every open node: features in ascending order, strictly larger gain replaces (first best wins)
+__global__ void k_gbt_exact_pick(const ExBest* cand, long long* nG, long long* nH, int32_t* nF, int32_t* nB, int32_t* st, int d, int A, int F) {
+  const int nl = 1 << d, base = nl - 1;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= A * nl) return;
+  const int c = e / nl, k = e - c * nl, node = base + k, o = c * MAXN;
+  if (st[o + node] != 1) return;
+  const ExBest* cq = cand + (size_t)e * F;
+  int bf = -1;
+  double bg = 0.0;
+  for (int f = 0; f < F; ++f) {
+    const double tg = cq[f].gain;
+    if (tg < 0.0) continue;
+    if (bf < 0 || tg > bg) { bf = f; bg = tg; }
+  }
+  if (bf >= 0) {
+    const long long GL = cq[bf].GL, HL = cq[bf].HL;
+    const long long Gn = nG[o + node], Hn = nH[o + node];
+    st[o + node] = 2; nF[o + node] = bf; nB[o + node] = __float_as_int(cq[bf].thr);
+    const int l = 2 * node + 1, r = 2 * node + 2;
+    st[o + l] = 1; st[o + r] = 1;
+    nG[o + l] = GL; nH[o + l] = HL; nG[o + r] = Gn - GL; nH[o + r] = Hn - HL;
+  } else {
+    st[o + node] = 3;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gbt_exact_partition(const float* Bf, uint8_t* pos, const int32_t* st, const int32_t* nF, const int32_t* nB, int d, Geom G) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (i >= G.R) return;
+  const int node = pos[(size_t)c * G.R + i];
+  if (node >= (1 << d) - 1 && st[c * MAXN + node] == 2) {
+    const int64_t n = i / G.W;
+    const int w = (int)(i - n * G.W);
+    const int f = nF[c * MAXN + node], sft = f / G.A, a = f - sft * G.A;
+    const float v = Bf[(n * G.W + slide_src(w + sft, G.W, G.pad)) * G.A + a];
+    pos[(size_t)c * G.R + i] = (uint8_t)(v < __int_as_float(nB[c * MAXN + node]) ? 2 * node + 1 : 2 * node + 2);
+  }
+}
+
 struct DevBuf {
   void* p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
@@ -440,6 +594,50 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
   hipLaunchKernelGGL(k_gbt_fill, dim3(gRA), dim3(256), 0, s, bFm.as<float>(), (float)P.base_score, RA);
   GBT_HIP(hipGetLastError());
 
+  // ---- exact greedy: one sorted list of padded strip positions per class column (host sort, once per training) ----
+  const bool exact = P.tree_method == 1;
+  DevBuf bOrdN, bOrdJ, bVal, bEx;
+  if (exact) {
+    const int64_t NP = N * G.Wp;
+    std::vector<float> hB((size_t)RA);
+    GBT_HIP(hipMemcpyAsync(hB.data(), bBf.p, (size_t)RA * 4, hipMemcpyDeviceToHost, s));
+    GBT_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> on((size_t)A * NP), oj((size_t)A * NP);
+    std::vector<float> ov((size_t)A * NP);
+    auto sort_col = [&](int a) {
+      std::vector<float> v((size_t)NP);
+      for (int64_t n = 0; n < N; ++n)
+        for (int64_t j = 0; j < G.Wp; ++j) {
+          const int64_t src = j < G.pad ? G.pad - 1 - j : (j < G.pad + W ? j - G.pad : W - 1 - (j - G.pad - W));
+          v[(size_t)(n * G.Wp + j)] = hB[(size_t)((n * W + src) * A + a)];
+        }
+      std::vector<int32_t> idx((size_t)NP);
+      std::iota(idx.begin(), idx.end(), 0);
+      std::sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return v[(size_t)x] < v[(size_t)y] || (v[(size_t)x] == v[(size_t)y] && x < y); });
+      for (int64_t p = 0; p < NP; ++p) {
+        const int32_t q = idx[(size_t)p];
+        on[(size_t)a * NP + p] = (int32_t)(q / G.Wp);
+        oj[(size_t)a * NP + p] = (int32_t)(q % G.Wp);
+        ov[(size_t)a * NP + p] = v[(size_t)q];
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      for (int a = 0; a < A; ++a) {
+        try { th.emplace_back(sort_col, a); } catch (...) { sort_col(a); }
+      }
+      for (auto& t : th) t.join();
+    }
+    GBT_HIP(bOrdN.alloc((size_t)A * NP * 4));
+    GBT_HIP(bOrdJ.alloc((size_t)A * NP * 4));
+    GBT_HIP(bVal.alloc((size_t)A * NP * 4));
+    GBT_HIP(bEx.alloc((size_t)A * 16 * G.F * sizeof(ExBest)));
+    GBT_HIP(hipMemcpyAsync(bOrdN.p, on.data(), (size_t)A * NP * 4, hipMemcpyHostToDevice, s));
+    GBT_HIP(hipMemcpyAsync(bOrdJ.p, oj.data(), (size_t)A * NP * 4, hipMemcpyHostToDevice, s));
+    GBT_HIP(hipMemcpyAsync(bVal.p, ov.data(), (size_t)A * NP * 4, hipMemcpyHostToDevice, s));
+    GBT_HIP(hipStreamSynchronize(s));   // (the host vectors leave scope)
+  }
+
   // ---- histogram geometry per level: features per block from the LDS budget, row slices to fill the chip ----
   int fpb[8], nsl[8];
   size_t part_entries = 0;
@@ -489,7 +687,14 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
     else hipLaunchKernelGGL(k_gbt_grad<32>, dim3(gR), dim3(256), 0, s, bFm.as<float>(), dy, bG.as<long long>(), bH.as<long long>(), rG, rH, bLoss.as<long long>() + r, bPos.as<uint8_t>(), rS, G);
     GBT_HIP(hipMemsetAsync(dCnt, 0, (size_t)A * MAXN * 4, s));
     GBT_HIP(hipMemsetAsync(dBuild, 0xff, (size_t)A * MAXN * 4, s));  // (the roots are built; children are decided by k_gbt_choose)
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; exact && d < D; ++d) {
+      const int nl = 1 << d;
+      hipLaunchKernelGGL(k_gbt_exact_scan, dim3((unsigned)G.F, (unsigned)A), dim3(64), 0, s, bOrdN.as<int32_t>(), bOrdJ.as<int32_t>(), bVal.as<float>(),
+                         bG.as<long long>(), bH.as<long long>(), bPos.as<uint8_t>(), rS, rG, rH, bEx.as<ExBest>(), d, P.lambda, P.gamma, P.min_child_weight, G);
+      hipLaunchKernelGGL(k_gbt_exact_pick, dim3((unsigned)((A * nl + 63) / 64)), dim3(64), 0, s, bEx.as<ExBest>(), rG, rH, rF, rB, rS, d, A, (int)G.F);
+      hipLaunchKernelGGL(k_gbt_exact_partition, dim3(gR, (unsigned)A), dim3(256), 0, s, bBf.as<float>(), bPos.as<uint8_t>(), rS, rF, rB, d, G);
+    }
+    for (int d = 0; !exact && d < D; ++d) {
       const int nl = 1 << d, fg = (G.F + fpb[d] - 1) / fpb[d];
       long long* Hcur = bLev.as<long long>() + (size_t)(d & 1) * lev_entries;
       const long long* Hprev = bLev.as<long long>() + (size_t)((d & 1) ^ 1) * lev_entries;
@@ -528,7 +733,8 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
       const int64_t q = nn + idx[node];
       if (hS[o + node] == 2) {
         left[q] = idx[2 * node + 1]; right[q] = idx[2 * node + 2]; feat[q] = hF[o + node];
-        cond[q] = cuts[(size_t)(hF[o + node] % A) * 256 + hB[o + node]];
+        if (exact) std::memcpy(&cond[q], &hB[o + node], 4);   // the threshold's float32 bits
+        else cond[q] = cuts[(size_t)(hF[o + node] % A) * 256 + hB[o + node]];
       } else {
         left[q] = -1; right[q] = -1; feat[q] = 0; cond[q] = hV[o + node];
       }

@@ -64,10 +64,14 @@ def lr_objective(coef_row, intercept, Xw, ypm, C_reg=3.0):
 
 
 def train_gbt_arrays(B, y, S, n_rounds=100, max_depth=4, learning_rate=0.1, reg_lambda=1.0, gamma=0.0, min_child_weight=1.0,
-                     max_bin=256, base_score=0.5, ctx=None, device=0):
+                     max_bin=256, base_score=0.5, tree_method="hist", ctx=None, device=0):
     """B (N, W, A) base probabilities of the smoother's training haplotypes (float32 / float64; a CUDA tensor stays on the
     device), y (N, W) labels -> (dict of tree arrays as GnxModelData takes them, losses (n_rounds + 1,)).  Defaults are the
-    reference's XGBClassifier arguments (src/Smooth/models.py:14-20)."""
+    reference's XGBClassifier arguments (src/Smooth/models.py:14-20).  tree_method: "hist" (max_bin quantile bins per class column) or
+    "exact" (xgboost's exact greedy enumeration: a candidate between every two distinct values of a node's rows; slower, and like the
+    histogram form not pinned to xgboost's own floating-point trajectory)."""
+    if tree_method not in ("hist", "exact"):
+        raise ValueError("tree_method is 'hist' or 'exact'")
     ctx = ctx or _lib.default_context(device)
     on_dev = hasattr(B, "is_cuda") and B.is_cuda
     if on_dev:
@@ -96,7 +100,7 @@ def train_gbt_arrays(B, y, S, n_rounds=100, max_depth=4, learning_rate=0.1, reg_
     left = np.zeros(T * per_tree, np.int32); right = np.zeros(T * per_tree, np.int32); feat = np.zeros(T * per_tree, np.int32)
     cond = np.zeros(T * per_tree, np.float32); loss = np.zeros(int(n_rounds) + 1, np.float64)
     nn = C.c_int64(0)
-    P = _lib.GbtParams(int(n_rounds), int(max_depth), int(max_bin), 0, float(learning_rate), float(reg_lambda), float(gamma),
+    P = _lib.GbtParams(int(n_rounds), int(max_depth), int(max_bin), 1 if tree_method == "exact" else 0, float(learning_rate), float(reg_lambda), float(gamma),
                        float(min_child_weight), float(base_score))
     ctx.check(fn(ctx.h, b_ptr, int(is64), y_ptr, int(N), int(W), int(A), int(S), C.byref(P), tree_off.ctypes.data, tree_class.ctypes.data,
                  left.ctypes.data, right.ctypes.data, feat.ctypes.data, cond.ctypes.data, C.addressof(nn), loss.ctypes.data))

@@ -664,9 +664,25 @@ static double gnx_det_exp(double x) { /* x <= 0 */
 #define GBT_MAXNODES 63      /* heap positions of a tree of depth <= 5 */
 
 typedef struct {
-  int32_t n_rounds, max_depth, max_bin, reserved;
+  int32_t n_rounds, max_depth, max_bin, tree_method; /* tree_method: 0 = histogram (max_bin quantile bins), 1 = exact greedy */
   double eta, lambda, gamma, min_child_weight, base_score;
 } gnxo_gbt_params;
+
+/* exact greedy (xgboost's tree_method="exact", the default XGBClassifier(...) of src/Smooth/models.py:14-20 gets for data of this
+ * size; ColMaker::EnumerateSplit restated from its documentation, NOT pinned to xgboost — absent from this image): per node and
+ * feature the node's rows in ascending feature value; between two consecutive DISTINCT values v0 < v1 the split "x < thr" with
+ * thr = (v0 + v1) * 0.5f in float32 (v1 itself when that rounds down to v0, so that v0 < thr <= v1 always holds) sends the rows up
+ * to v0 left.  Same gain, constraints, fixed-point sums and first-best-wins order (features ascending, then values ascending) as the
+ * histogram form. */
+typedef struct { float v; int64_t g, h; } gbt_vgh;
+static int gbt_vgh_cmp(const void* a, const void* b) {
+  const float x = ((const gbt_vgh*)a)->v, y = ((const gbt_vgh*)b)->v;
+  return (x > y) - (x < y);
+}
+static float gbt_mid(float v0, float v1) {
+  const float m = (v0 + v1) * 0.5f;
+  return m > v0 ? m : v1;
+}
 
 /* Outputs (caller-allocated): tree_off[T+1], tree_class[T], and node arrays of capacity T*63: left, right, feat (int32),
  * cond (float32: threshold of an internal node, value of a leaf).  T = n_rounds*A.  Returns the number of nodes or < 0.
@@ -749,7 +765,7 @@ int64_t gnxo_train_gbt(const void* B, int is_f64, const int32_t* y, int64_t N, i
     for (int64_t c = 0; c < A; ++c, ++t) {
       int64_t nG[GBT_MAXNODES], nH[GBT_MAXNODES];
       int32_t nF[GBT_MAXNODES], nB[GBT_MAXNODES], st[GBT_MAXNODES]; /* st: 0 unused, 1 open, 2 internal, 3 leaf */
-      float nV[GBT_MAXNODES];
+      float nV[GBT_MAXNODES], nT[GBT_MAXNODES]; /* nT: exact mode's thresholds */
       memset(st, 0, sizeof(st));
       const int64_t* g = gq + c * R;
       const int64_t* h = hq + c * R;
@@ -761,6 +777,63 @@ int64_t gnxo_train_gbt(const void* B, int is_f64, const int32_t* y, int64_t N, i
         int any = 0;
         for (int k = 0; k < nl; ++k) any |= st[base + k] == 1;
         if (!any) break;
+        if (P->tree_method == 1) { /* ---- exact greedy ---- */
+          gbt_vgh* buf = (gbt_vgh*)malloc((size_t)R * sizeof(gbt_vgh));
+          if (!buf) return GNXO_ENOMEM;
+          for (int k = 0; k < nl; ++k) {
+            const int node = base + k;
+            if (st[node] != 1) continue;
+            const double Gd = (double)nG[node] / GBT_FIX, Hd = (double)nH[node] / GBT_FIX;
+            const double root_term = Gd * Gd / (Hd + P->lambda);
+            double best = P->gamma > 1e-6 ? P->gamma : 1e-6;
+            int bf = -1;
+            float bthr = 0.f;
+            int64_t bGL = 0, bHL = 0;
+            for (int64_t f = 0; f < F; ++f) {
+              const int64_t sft = f / A, a = f % A;
+              int64_t m = 0;
+              for (int64_t n = 0; n < N; ++n)
+                for (int64_t w = 0; w < W; ++w) {
+                  const int64_t i = n * W + w;
+                  if (pos[i] != node) continue;
+                  buf[m].v = Bf[(n * W + slide_src(w + sft, W, pad)) * A + a];
+                  buf[m].g = g[i];
+                  buf[m].h = h[i];
+                  ++m;
+                }
+              qsort(buf, (size_t)m, sizeof(gbt_vgh), gbt_vgh_cmp);
+              int64_t GL = 0, HL = 0;
+              for (int64_t q = 0; q + 1 < m; ++q) {
+                GL += buf[q].g;
+                HL += buf[q].h;
+                if (!(buf[q].v < buf[q + 1].v)) continue;
+                const double gl = (double)GL / GBT_FIX, hl = (double)HL / GBT_FIX;
+                const double gr = (double)(nG[node] - GL) / GBT_FIX, hr = (double)(nH[node] - HL) / GBT_FIX;
+                if (hl < P->min_child_weight || hr < P->min_child_weight) continue;
+                const double gain = (gl * gl / (hl + P->lambda) + gr * gr / (hr + P->lambda)) - root_term;
+                if (gain > best) { best = gain; bf = (int)f; bthr = gbt_mid(buf[q].v, buf[q + 1].v); bGL = GL; bHL = HL; }
+              }
+            }
+            if (bf >= 0) {
+              st[node] = 2; nF[node] = bf; nT[node] = bthr; nB[node] = 0;
+              const int l = 2 * node + 1, rr = 2 * node + 2;
+              st[l] = 1; st[rr] = 1;
+              nG[l] = bGL; nH[l] = bHL; nG[rr] = nG[node] - bGL; nH[rr] = nH[node] - bHL;
+            } else {
+              st[node] = 3;
+            }
+          }
+          free(buf);
+          for (int64_t n = 0; n < N; ++n)
+            for (int64_t w = 0; w < W; ++w) {
+              const int64_t i = n * W + w;
+              const int node = pos[i];
+              if (node < base || st[node] != 2) continue;
+              const float v = Bf[(n * W + slide_src(w + nF[node] / A, W, pad)) * A + nF[node] % A];
+              pos[i] = (uint8_t)(v < nT[node] ? 2 * node + 1 : 2 * node + 2);
+            }
+          continue;
+        }
         memset(hist, 0, (size_t)nl * F * 256 * 2 * sizeof(int64_t));
         for (int64_t n = 0; n < N; ++n)
           for (int64_t w = 0; w < W; ++w) {
@@ -827,7 +900,7 @@ int64_t gnxo_train_gbt(const void* B, int is_f64, const int32_t* y, int64_t N, i
         const int64_t o = nn + idx[node];
         if (st[node] == 2) {
           left[o] = idx[2 * node + 1]; right[o] = idx[2 * node + 2]; feat[o] = nF[node];
-          cond[o] = cuts[(nF[node] % A) * 256 + nB[node]];
+          cond[o] = P->tree_method == 1 ? nT[node] : cuts[(nF[node] % A) * 256 + nB[node]];
         } else {
           left[o] = -1; right[o] = -1; feat[o] = 0; cond[o] = nV[node];
         }

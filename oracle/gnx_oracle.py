@@ -610,8 +610,9 @@ class _CGbtParams(C.Structure):
 
 
 def train_gbt(B, y, S, n_rounds=100, max_depth=4, eta=0.1, lam=1.0, gamma=0.0, min_child_weight=1.0, max_bin=256,
-              base_score=0.5):
-    """Smoother.train of XGB_Smoother (src/Smooth/smooth.py:28-38, src/Smooth/models.py:14-20) in the histogram form.
+              base_score=0.5, exact=False):
+    """Smoother.train of XGB_Smoother (src/Smooth/smooth.py:28-38, src/Smooth/models.py:14-20) in the histogram form, or with
+    exact=True as exact greedy split enumeration (every boundary between two distinct feature values of a node's rows).
     B (N, W, A) base probabilities, y (N, W) labels.  Returns (Trees, losses (n_rounds+1,))."""
     B = np.ascontiguousarray(B)
     is64 = B.dtype == np.float64
@@ -623,7 +624,7 @@ def train_gbt(B, y, S, n_rounds=100, max_depth=4, eta=0.1, lam=1.0, gamma=0.0, m
     tree_off = np.zeros(T + 1, np.int32); tree_class = np.zeros(T, np.int32)
     left = np.zeros(T * 63, np.int32); right = np.zeros(T * 63, np.int32); feat = np.zeros(T * 63, np.int32)
     cond = np.zeros(T * 63, np.float32); loss = np.zeros(n_rounds + 1, np.float64)
-    P = _CGbtParams(n_rounds, max_depth, max_bin, 0, eta, lam, gamma, min_child_weight, base_score)
+    P = _CGbtParams(n_rounds, max_depth, max_bin, 1 if exact else 0, eta, lam, gamma, min_child_weight, base_score)
     fn = lib().gnxo_train_gbt
     fn.restype = C.c_int64
     fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(_CGbtParams)] + [C.c_void_p] * 7

@@ -34,6 +34,15 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 trees_d, loss_d = train.train_gbt_arrays(Bd, yd, S)
 res["gpu_device_tensors"] = {"seconds": time.perf_counter() - t0, "identical_to_host_run": bool(all(np.array_equal(trees[k], trees_d[k]) for k in trees))}
+# exact greedy (tree_method="exact"): a few rounds timed, scaled to 100 (a round costs the same whatever its number)
+ex_rounds = int(os.environ.get("EXACT_ROUNDS", "5"))
+if ex_rounds > 0:
+    t0 = time.perf_counter()
+    trees_e, loss_e = train.train_gbt_arrays(B, y, S, n_rounds=ex_rounds, tree_method="exact")
+    dt = time.perf_counter() - t0
+    _, loss_h = train.train_gbt_arrays(B, y, S, n_rounds=ex_rounds)
+    res["gpu_exact_greedy"] = {"rounds_timed": ex_rounds, "seconds": dt, "seconds_scaled_to_100_rounds": dt * 100 / ex_rounds,
+                               "loss_after": float(loss_e[-1]), "histogram_loss_after_same_rounds": float(loss_h[-1])}
 try:
     if cpu_rounds <= 0:
         raise ImportError

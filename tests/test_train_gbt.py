@@ -52,6 +52,43 @@ def test_oracle_gbt_tracks_sklearn_histogram_boosting(oracle):
     assert 0.6 * sk_loss < loss[-1] < 1.6 * sk_loss
 
 
+def test_oracle_exact_greedy_root_split_vs_numpy_enumeration(oracle):
+    """tree_method = exact: the first tree's root split against a numpy enumeration that shares nothing with the C code — every
+    feature, every boundary between two distinct values, float64 sums of the first round's gradients (all classes at p = 1/A)"""
+    B, y = _problem(14, 30, 3, seed=3)
+    B = B.astype(np.float32)
+    S, A, lam = 7, 3, 1.0
+    T, loss = oracle.train_gbt(B, y, S, n_rounds=2, max_depth=3, exact=True)
+    assert np.all(np.diff(loss) < 0)
+    rows = oracle.slide_window(B, S).reshape(-1, S * A)                   # (N*W, S*A) float32, the matrix xgboost would see
+    yy = y.reshape(-1)
+    p0 = 1.0 / A                                                           # margins start equal
+    g = p0 - (yy == 0)                                                     # tree 0 = class 0
+    h = np.full(len(yy), 2 * p0 * (1 - p0))
+    G, H = g.sum(), h.sum()
+    best = (1e-6, -1, None)
+    for f in range(S * A):
+        o = np.argsort(rows[:, f], kind="stable")
+        v, gl, hl = rows[o, f], np.cumsum(g[o]), np.cumsum(h[o])
+        cut = np.nonzero(v[:-1] < v[1:])[0]
+        for q in cut:
+            if hl[q] < 1.0 or H - hl[q] < 1.0:
+                continue
+            gain = gl[q] ** 2 / (hl[q] + lam) + (G - gl[q]) ** 2 / (H - hl[q] + lam) - G * G / (H + lam)
+            if gain > best[0] + 1e-9:                                      # first best wins (1e-9: float64 vs fixed-point sums)
+                thr = np.float32((v[q] + v[q + 1]) * np.float32(0.5))
+                best = (gain, f, thr if thr > v[q] else v[q + 1])
+    assert T.left[0] >= 0 and T.feat[0] == best[1] and T.cond[0] == best[2], (T.feat[0], T.cond[0], best)
+    # the split really separates the root's rows as the sums said: left rows are exactly those with value < threshold
+    left_rows = rows[:, best[1]] < T.cond[0]
+    assert 0 < left_rows.sum() < len(yy)
+    # exact thresholds are midpoints of data values, not grid points; the histogram form's are grid points
+    Th, _ = oracle.train_gbt(B, y, S, n_rounds=2, max_depth=3)
+    internal = T.left >= 0
+    assert not np.all(T.cond[internal] * 65536 == np.round(T.cond[internal] * 65536))
+    assert np.all(Th.cond[Th.left >= 0] * 65536 == np.round(Th.cond[Th.left >= 0] * 65536))
+
+
 def test_oracle_gbt_rejects_bad_geometry(oracle):
     B, y = _problem(4, 20, 3, seed=2)
     with pytest.raises(ValueError):
@@ -96,6 +133,47 @@ def test_gbt_trees_identical_to_oracle(ga, oracle, case, dtype):
     assert np.array_equal(trees["cond"].view(np.uint32), T.cond.view(np.uint32))          # thresholds AND leaf values, bit for bit
     assert np.array_equal(trees["tree_class"], T.tree_class)
     assert np.allclose(loss, loss_ref, rtol=0, atol=1e-6)
+
+
+EXACT_CASES = [
+    dict(N=14, W=40, A=3, S=11, kw=dict(n_rounds=6)),
+    dict(N=10, W=64, A=7, S=15, kw=dict(n_rounds=3)),
+    dict(N=12, W=30, A=2, S=5, kw=dict(n_rounds=8, max_depth=3)),
+    dict(N=8, W=60, A=4, S=21, kw=dict(n_rounds=2, max_depth=5)),
+    dict(N=12, W=36, A=3, S=9, kw=dict(n_rounds=5, gamma=0.5, min_child_weight=3.0, reg_lambda=0.0, learning_rate=0.3)),
+    dict(N=3, W=170, A=12, S=75, kw=dict(n_rounds=1)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EXACT_CASES, ids=lambda c: "N%dW%dA%dS%d" % (c["N"], c["W"], c["A"], c["S"]))
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gbt_exact_greedy_trees_identical_to_oracle(ga, oracle, case, dtype):
+    """tree_method="exact" (k_gbt_exact_scan: sorted strip positions per class column, masked wave scans per node) against the
+    oracle's qsort-per-node-and-feature restatement: identical trees, thresholds and leaf values bit for bit.  Inputs with repeated
+    values (rounded probabilities) exercise the distinct-value rule."""
+    from gnomix_amd import train
+    B, y = _problem(case["N"], case["W"], case["A"], seed=case["N"] + case["S"])
+    if case["S"] == 9:
+        B = np.round(B, 2) + 1e-3                                            # many ties
+        B /= B.sum(-1, keepdims=True)
+    B = B.astype(dtype)
+    kw = dict(case["kw"])
+    okw = dict(kw)
+    if "reg_lambda" in okw: okw["lam"] = okw.pop("reg_lambda")
+    if "learning_rate" in okw: okw["eta"] = okw.pop("learning_rate")
+    T, loss_ref = oracle.train_gbt(B, y, case["S"], exact=True, **okw)
+    trees, loss = train.train_gbt_arrays(B, y, case["S"], tree_method="exact", **kw)
+    assert np.array_equal(trees["tree_off"], T.tree_off)
+    assert np.array_equal(trees["left"], T.left) and np.array_equal(trees["right"], T.right)
+    assert np.array_equal(trees["feat"], T.feat)
+    assert np.array_equal(trees["cond"].view(np.uint32), T.cond.view(np.uint32))
+    assert np.allclose(loss, loss_ref, rtol=0, atol=1e-6)
+    # the trained ensemble is an ordinary smoother model: labels on the training rows through the HIP smoother
+    d = ga.GnxModelData(C=case["W"] * 10 + 3, M=10, A=case["A"], S=case["S"], context=0, smooth_kind="xgb", **trees)
+    _, lab = ga.DeviceModel(d).smooth_predict(B.astype(np.float32))
+    _, l_ref = oracle.smooth_xgb(T, B.astype(np.float32), case["S"])
+    assert np.array_equal(lab, l_ref)
 
 
 @pytest.mark.gpu
