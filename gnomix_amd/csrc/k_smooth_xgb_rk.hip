@@ -561,7 +561,7 @@ hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tu
     // as many waves per CU as the LDS allows: 8-wave blocks unless 4-wave blocks pack the 160 KB better
     const size_t l8 = lds_bytes<8>(L.d, L.A), l4 = lds_bytes<4>(L.d, L.A);
     const size_t w8 = l8 <= (size_t)160 * 1024 ? ((size_t)160 * 1024 / l8) * 8 : 0, w4 = l4 <= (size_t)160 * 1024 ? ((size_t)160 * 1024 / l4) * 4 : 0;
-    nw = (w8 >= w4 && w8 > 0) ? 8 : (w4 > 0 ? 4 : 2);
+    nw = (w8 > w4) ? 8 : (w4 > 0 ? 4 : 2);  // equal wave counts: the smaller block (A = 12 at chr1: 16 waves per CU either way, 4-wave blocks 3 % faster)
     if (L.N < 8) nw = L.N < 3 ? 2 : 4;
   }
 #define GNX_SM_CASE(R_) \
