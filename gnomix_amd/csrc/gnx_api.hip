@@ -566,7 +566,7 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
     SmoothCRFLaunch L{};
     L.psi = (double*)ctx->ws_psi.p;
     L.B = dB; L.b_is_f64 = b_is_f64; L.N = N; L.W = (int32_t)m->info.W; L.A = m->info.A;
-    L.state = m->crf_state; L.etrans = m->crf_etrans;
+    L.state = m->crf_state; L.etrans = m->crf_etrans; L.norm_mask = m->crf_norm_mask;
     L.alpha = alpha; L.scale = (double*)ctx->ws_scale.p;
     L.proba64 = d_p64; L.proba32 = d_p32; L.labels = d_lab;
     ProfScope ps(ctx, GNX_K_SMOOTH_CRF);

@@ -232,6 +232,7 @@ struct SmoothCRFLaunch {
   double* proba64;        // optional
   float* proba32;         // optional
   int32_t* labels;        // optional
+  int32_t norm_mask;      // k_smooth_crf_ck takes the forward scale at windows t with (t & norm_mask) == norm_mask (0, 1 or 3: gnx_build_crf)
 };
 
 // ---- cnn smoother (k_smooth_cnn.hip) -----------------------------------------------------------------
@@ -373,6 +374,7 @@ struct gnx_model {
   // CRF
   const double* crf_state = nullptr;  // device (A,A)
   const double* crf_etrans = nullptr; // device (A,A) exp(trans)
+  int32_t crf_norm_mask = 0;          // windows between two forward scales - 1, from the weights' range (gnx_build_crf)
   const float* cnn_weight = nullptr;  // device [A_in][S][AP] (transposed from torch's (out, in, k) at load), AP = gnx_cnn_ap(A)
   const float* cnn_bias = nullptr;    // device (AP,)
   // calibrator

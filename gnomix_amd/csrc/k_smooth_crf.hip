@@ -589,13 +589,24 @@ __global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
     return label ? v : 0.0;
   };
   auto loadPsi = [&](int t) -> double { const double v = L.psi[row0 + (size_t)t * A + yl]; return label ? v : 0.0; };
-  // one step of the scaled forward recurrence: alpha_t = psi_t * (alpha_{t-1} . E) / c_t; returns alpha_t, sets (1/c_t, c_t)
-  auto fwd_step = [&](double a_prev, double psi, bool first, double& sc, double& sum) -> double {
+  // one step of the scaled forward recurrence: alpha_t = psi_t * (alpha_{t-1} . E) / c_t; returns alpha_t, sets (1/c_t, c_t).
+  // The scales only keep the numbers in range: ANY positive c_t give the same marginals as long as both sweeps use the same ones and
+  // the last window's is the true row sum (then prod c_t = Z).  The kernel is bound by its float64 DPP multiply-adds (8 cycles each:
+  // a 3 072-wave round takes 1431 windows x 3 waves x ~1 180 cycles), and a row sum is 12 of the ~84 per window: the sum and its
+  // reciprocal are taken every (norm_mask + 1)-th window only (and at the last one), c_t = 1 in between.  gnx_build_crf picks
+  // 4, 2 or 1 windows from the weights' range so that the unscaled stretch stays inside float64 (4 for any trained model).
+  const int norm_mask = L.norm_mask;
+  auto fwd_step = [&](double a_prev, double psi, int t, double& sc, double& sum) -> double {
     double v = psi;
-    if (!first) {
+    if (t != 0) {
       double acc = 0.0;
       row_dot<AT>(acc, dpp_ready(a_prev), Ef);
       v = acc * psi;
+    }
+    if ((t & norm_mask) != norm_mask && t != W - 1) {   // wave-uniform
+      sc = 1.0;
+      sum = 1.0;
+      return v;
     }
     sum = 0.0;
     row_sum<AT>(sum, dpp_ready(v));
@@ -634,7 +645,7 @@ __global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
       const int t = t0 + k;
       if (t < W) {
         double sc, sum;
-        a_prev = fwd_step(a_prev, bc[k], t == 0, sc, sum);
+        a_prev = fwd_step(a_prev, bc[k], t, sc, sum);
       }
     }
     if (active) ck[(size_t)sg * A + y] = a_prev;
@@ -668,7 +679,7 @@ __global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
       const int t = t0 + k;
       if (t < W) {
         double sc, sum;
-        a_in = fwd_step(a_in, bc[k], t == 0, sc, sum);
+        a_in = fwd_step(a_in, bc[k], t, sc, sum);
         la[wave][k][lane] = a_in;
         if (y == 0) lsc[wave][k][row] = make_double2(sc, sum);
       }

@@ -299,6 +299,26 @@ def test_crf_vs_oracle(ga, oracle, monkeypatch, N, W, A, impl):
     assert sm.gnofix is False and np.array_equal(sm.predict(B), l_ref)
 
 
+@pytest.mark.parametrize("scale", [5.0, 10.0, 20.0, 40.0])   # forward scale every 4th, 4th or 2nd, 2nd, every window
+@pytest.mark.parametrize("W,A", [(133, 12), (61, 5)])
+def test_crf_weights_far_beyond_a_trained_model(ga, oracle, scale, W, A):
+    """the default kernel takes the forward scale every fourth window only (k_smooth_crf_ck, NORM): weights 10x and 40x a trained
+    model's (per-window factors down to e^-160) must still give the oracle's marginals — the oracle rescales at every window."""
+    rng = np.random.RandomState(int(scale) + W)
+    N = 37
+    B = rng.dirichlet(np.ones(A) * 0.3, size=(N, W))
+    state = rng.standard_normal((A, A)) * scale
+    trans = rng.standard_normal((A, A)) * scale
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=75, context=5, smooth_kind="crf", crf_state=state, crf_trans=trans)
+    dev = ga.DeviceModel(d)
+    p_ref, l_ref = oracle.smooth_crf(B, state, trans)
+    assert np.isfinite(p_ref).all()
+    p, lab = dev.smooth_predict(B)
+    assert np.isfinite(p).all() and np.max(np.abs(p - p_ref)) < 1e-9
+    clear = np.sort(p_ref, -1)[..., -1] - np.sort(p_ref, -1)[..., -2] > 1e-9
+    assert np.array_equal(lab[clear], l_ref[clear])
+
+
 def test_crf_end_to_end_and_no_phasing(ga, oracle):
     from gnomix_amd import synth
     d = synth.synthetic_model(C=12037, M=100, A=12, S=75, seed=4, smooth="crf")
