@@ -37,7 +37,7 @@ struct gnx_tune {
   int sm_nw = 0;                        // GNX_SM_NW: waves per block of the rank smoother
   int sm_pair = 1;                      // GNX_SM_PAIR=0: one tree at a time per lane in the rank smoother (default: two)
   int smf_rpl = 0, smf_nw = 0;          // GNX_SM_TUNE="rpl,nw": float smoother
-  int crf_impl = 0;                     // GNX_CRF_IMPL=scan|row|lanes (default: row for up to 16 labels, lanes above)
+  int crf_impl = 0;                     // GNX_CRF_IMPL=scan|row|lanes (default: row for up to 16 labels, lanes above); quad in the EXPERIMENTS build
   int crf_flags = 0;                    // GNX_CRF_FLAGS bit 0: row kernel computes psi itself instead of reading the pre-pass's (slower)
   int forest_threads = 0;               // GNX_FOREST_T
   int forest_wrun = 0;                  // GNX_FOREST_WRUN: windows per block of the forest bases
@@ -234,6 +234,10 @@ struct SmoothCRFLaunch {
   int32_t* labels;        // optional
   int32_t norm_mask;      // k_smooth_crf_ck takes the forward scale at windows t with (t & norm_mask) == norm_mask (0, 1 or 3: gnx_build_crf)
 };
+
+#ifdef GNX_EXPERIMENTS
+hipError_t gnx_launch_smooth_crf_quad(const SmoothCRFLaunch& L, hipStream_t s);  // scripts/dev/rejected/k_smooth_crf_quad.hip: four lanes per haplotype, A <= 12
+#endif
 
 // ---- cnn smoother (k_smooth_cnn.hip) -----------------------------------------------------------------
 struct SmoothCNNLaunch {

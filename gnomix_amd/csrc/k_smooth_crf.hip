@@ -757,7 +757,11 @@ hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune,
   if (!L.psi) return hipErrorInvalidValue;
   // Up to 16 labels: one haplotype per 16-lane DPP row (k_smooth_crf_row16).  GNX_CRF_IMPL=scan keeps the round-2a kernel for up to 8
   // labels (one lane per haplotype, LDS ring), =lanes the shuffle kernel (A lanes per haplotype), which also serves 17..32 labels.
-  const int impl = tune.crf_impl;  // 0 auto, 1 scan, 2 row, 3 lanes
+  const int impl = tune.crf_impl;  // 0 auto, 1 scan, 2 row, 3 lanes, 4 quad
+#ifdef GNX_EXPERIMENTS
+  // four lanes per haplotype (scripts/dev/rejected/k_smooth_crf_quad.hip): correct, 5 % slower than the row kernel at chr1 / A = 12
+  if (L.A <= 12 && impl == 4) return gnx_launch_smooth_crf_quad(L, s);
+#endif
   if (L.A <= 16 && (impl == 0 || impl == 2 || (impl == 1 && L.A > 8))) {
     const int waves = 4;
     const dim3 grid((unsigned)((L.N + 4 * waves - 1) / (4 * waves)));
