@@ -246,6 +246,43 @@ __device__ inline void step_top(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t
 __device__ inline uint32_t lds_rank(uint32_t) { return 0; }
 #endif
 
+// exp() for the softmax exponentials (float32 results of a float64 evaluation: the oracle does the same to stand in for glibc's
+// correctly rounded expf, xgboost's Softmax of a float margin).  The device library's exp keeps its 18 polynomial / reduction constants
+// in VECTOR registers for the whole kernel once the scalar file is full — 18 of this kernel's 128.  Here every constant is moved into
+// a scalar pair by a volatile asm right where it is used, so nothing can be hoisted: Cody-Waite reduction (n = rint(x / ln 2),
+// r = x - n ln 2 in two parts), degree-13 Taylor polynomial of e^r (|r| <= 0.347: truncation 1.3e-17 relative), v_ldexp_f64 (overflow
+// -> inf, underflow -> 0 like exp).  Within 1 ulp of libm (checked on the host against 2e7 arguments); arguments here are <= 0.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <uint32_t LO, uint32_t HI>
+__device__ __forceinline__ double sconst() {  // a float64 constant in a scalar pair the optimiser cannot see through (nor hoist)
+  uint32_t lo, hi;
+  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"(LO), "n"(HI));
+  return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ double exp_sc(double x) {
+  const double n = rint(x * sconst<0x652b82feu, 0x3ff71547u>());            // 1 / ln 2
+  double r = fma(n, sconst<0xfee00000u, 0xbfe62e42u>(), x);                 // -ln 2, high part (fdlibm's split: n ln2_hi is exact)
+  r = fma(n, sconst<0x35793c76u, 0xbdea39efu>(), r);                        // -ln 2, low part
+  double p = sconst<0x13a86d09u, 0x3de61246u>();                            // 1/13!
+  p = fma(p, r, sconst<0xeff8d898u, 0x3e21eed8u>());                        // 1/12!
+  p = fma(p, r, sconst<0x67f544e4u, 0x3e5ae645u>());                        // 1/11!
+  p = fma(p, r, sconst<0xb7789f5cu, 0x3e927e4fu>());                        // 1/10!
+  p = fma(p, r, sconst<0xa556c734u, 0x3ec71de3u>());                        // 1/9!
+  p = fma(p, r, sconst<0x1a01a01au, 0x3efa01a0u>());                        // 1/8!
+  p = fma(p, r, sconst<0x1a01a01au, 0x3f2a01a0u>());                        // 1/7!
+  p = fma(p, r, sconst<0x16c16c17u, 0x3f56c16cu>());                        // 1/6!
+  p = fma(p, r, sconst<0x11111111u, 0x3f811111u>());                        // 1/5!
+  p = fma(p, r, sconst<0x55555555u, 0x3fa55555u>());                        // 1/4!
+  p = fma(p, r, sconst<0x55555555u, 0x3fc55555u>());                        // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)n);
+}
+#else
+__device__ inline double exp_sc(double x) { return x; }
+#endif
+
 // Tree layout of k_gnofix (SmoothXGBDev::gf_packed): 2^D node words in heap order (slot 0 unused; rank field << 16 | byte offset of
 // the feature in the tile) followed by 2^D float leaves — the leaf of heap index j is word j.  Words 0..3 = {-, root, node 2, node 3}
 // arrive in ONE 16-byte read, so levels 0 and 1 cost one dependent round trip (D >= 2): a depth-4 walk is 4 of them.
@@ -349,7 +386,7 @@ __device__ __forceinline__ void walk4(const Trees T, uint32_t t0, const uint8_t*
 __host__ __device__ inline int gnofix_rows_max(int S, int threads) { return 2 * min(S + 2, threads / 2); }
 
 struct GnofixLds {
-  size_t seg, Y, pmax, par, dif, chg, rej, marg, ex, stage, flags, ct0, total;
+  size_t seg, Y, pmax, par, dif, chg, rej, dirty, marg, ex, stage, flags, ct0, total;
 };
 __host__ __device__ inline GnofixLds gnofix_lds(int W, int A, int S, int GP, int cap, int D, int threads, int n_trees) {
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
@@ -363,6 +400,7 @@ __host__ __device__ inline GnofixLds gnofix_lds(int W, int A, int S, int GP, int
   o.dif = off; off += r16(NWD * 4);
   o.chg = off; off += r16(NWD * 4 + 4);
   o.rej = off; off += r16(NWD * 4 + 4);
+  o.dirty = off; off += r16(NWD * 4 + 4);
   o.marg = off; off += r16(nrow * A * 4);
   o.ex = off; off += r16((size_t)(threads / 64) * 2 * A * 4);
   {  // re-evaluation: `cap` staged trees for each of the block's row sets; candidate: the leaves [2][n_trees] (never both)
@@ -401,7 +439,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   const int W = L.W, A = L.A, S = L.S, pad = (S + 1) / 2, half = (S - 1) / 2;
   const int D = DT ? DT : L.D, NWD = (W + 31) / 32, GP = L.GP, TW = gnx_gf_tree_words(D), NT = L.NT;
   const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
-  const int64_t ind = L.order[blockIdx.x];
+  const int64_t ind = __builtin_amdgcn_readfirstlane(L.order[blockIdx.x]);   // (scalar: what is derived from it stays out of the vector registers)
   const GnofixLds o = gnofix_lds(W, A, S, GP, L.cap, D, THREADS, NT);
   uint16_t* seg = reinterpret_cast<uint16_t*>(lds + o.seg);   // [2][A][GP] ranks: the tile every walk reads
   uint16_t* Y = reinterpret_cast<uint16_t*>(lds + o.Y);       // labels: maternal | paternal << 8 per window
@@ -463,8 +501,9 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   // every sweep, gnofix.py:93-116) skip the walk — the same decisions, a third to a half of the candidate evaluations.
   auto next_change = [&](int from) -> int {
     const uint32_t* cw = reinterpret_cast<const uint32_t*>(chg);
+    const int lq = opaque(ln);  // (keeps the three per-lane mask addresses out of the registers held for the whole kernel)
     for (int q0 = from >> 5; q0 < NWD; q0 += 64) {
-      const int q = q0 + ln;
+      const int q = q0 + lq;
       uint32_t m = q < NWD ? (cw[q] & ~rej[q]) : 0u;
       if (q == from >> 5) m &= 0xffffffffu << (from & 31);
       const unsigned long long bal = __ballot(m != 0);
@@ -484,29 +523,75 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   const TreesGlobal GT{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(L.gf), 0, (uint32_t)((NT + GNX_GF_PAD_TREES) * TW * 4), 0x00020000)};  // (reads past the end return 0: the hardware's bounds check)
 
   int n_switch = 0;
-  TICK(0)
-  for (int it = 0; it < L.max_it; ++it) {
-    const int ty = opaque(tid);
-    // ---- convergence: has this X_m been seen at the start of an earlier sweep? (gnofix.py:108-113) ----
-    bool seen = false;
-    for (int k0 = 0; k0 < it; k0 += 1024) {  // 1024 past sweeps at a time: one "differs" bit each
-      const int nk = min(1024, it - k0);
-      if (ty < 32) flags[8 + ty] = 0;
-      __syncthreads();
-      GNX_NOUNROLL for (int e = ty; e < nk * NWD; e += THREADS) {
-        const int k = e / NWD, q = e - k * NWD;
-        if (hist[(size_t)(k0 + k) * NWD + q] != (par[q] & dif[q])) atomicOr(&flags[8 + (k >> 5)], 1 << (k & 31));
+  // Re-evaluation is LAZY where switches come thick (round 4).  The reference calls smoother.predict(B) after every accepted switch
+  // (gnofix.py:157-176); what the loop reads of that result before the next accepted switch is only (a) the labels up to the next label
+  // change and (b) the cached probabilities of row center + 1 of the next candidate.  A switch within DENSE_GAP windows of the
+  // previous one of the same sweep therefore only MARKS its rows [r0, r1) dirty; the scan cleans rows as it needs them, KS windows at
+  // a time (the candidate's machinery: every tree from L2 on the chunk's row pairs, leaves to LDS, in-order sums), and whatever is
+  // still dirty is evaluated in big batches at the start of the next sweep / before the outputs.  A row's values depend on the strips
+  // and the parity only, so WHEN it is evaluated changes nothing it evaluates to: same decisions, same labels (tests: G5, fuzz).
+  // With a label change at nearly every window (random trees on unstructured haplotypes) a switch costs one or two small chunks
+  // instead of 2 (S - 1) rows x n_trees walks.  Isolated switches keep the immediate big batch.
+  constexpr int DENSE_GAP = 12, CHUNKS_PER_SWITCH = 2;
+  const int gstep = NROW / 2;
+  const int KS = max(1, min(8, (int)((o.flags - o.stage) / ((size_t)8 * NT))));   // windows per small chunk: leaves [2 KS][NT] in the stage
+  uint32_t* dirty = reinterpret_cast<uint32_t*>(lds + o.dirty);
+  for (int q = tid; q < NWD; q += THREADS) dirty[q] = 0;
+  __syncthreads();
+  auto first_dirty = [&](int from) -> int {  // first dirty window >= from (every wave for itself)
+    const int lq = opaque(ln);
+    for (int q0 = from >> 5; q0 < NWD; q0 += 64) {
+      const int q = q0 + lq;
+      uint32_t m = q < NWD ? dirty[q] : 0u;
+      if (q == from >> 5) m &= 0xffffffffu << (from & 31);
+      const unsigned long long bal = __ballot(m != 0);
+      if (bal) {
+        const int first = __builtin_ctzll(bal);
+        const uint32_t mw = (uint32_t)__shfl((int)m, first);
+        return min(W, (q0 + first) * 32 + __builtin_ctz(mw));
       }
-      __syncthreads();
-      for (int k = 0; k < nk; k += 32) {
-        uint32_t m = ~(uint32_t)flags[8 + (k >> 5)];
-        if (nk - k < 32) m &= (1u << (nk - k)) - 1u;
-        seen |= m != 0;
-      }
-      __syncthreads();
     }
-    if (seen) break;
-    GNX_NOUNROLL for (int q = ty; q < NWD; q += THREADS) hist[(size_t)it * NWD + q] = par[q] & dif[q];
+    return W;
+  };
+  auto set_dirty = [&](int lo_, int hi_, bool on, int t_) {  // windows [lo_, hi_)
+    GNX_NOUNROLL for (int q = t_; q < NWD; q += THREADS) {
+      const int b0 = q * 32;
+      if (b0 + 32 > lo_ && b0 < hi_) {
+        uint32_t m = 0xffffffffu;
+        if (lo_ > b0) m &= 0xffffffffu << (lo_ - b0);
+        if (hi_ < b0 + 32) m &= 0xffffffffu >> (b0 + 32 - hi_);
+        if (on) dirty[q] |= m; else dirty[q] &= ~m;
+      }
+    }
+  };
+  bool any_dirty = false;
+  TICK(0)
+  for (int it = 0;; ++it) {
+    const int ty = opaque(tid);
+    bool finishing = it >= L.max_it;
+    if (!finishing) {
+      // ---- convergence: has this X_m been seen at the start of an earlier sweep? (gnofix.py:108-113) ----
+      bool seen = false;
+      for (int k0 = 0; k0 < it; k0 += 1024) {  // 1024 past sweeps at a time: one "differs" bit each
+        const int nk = min(1024, it - k0);
+        if (ty < 32) flags[8 + ty] = 0;
+        __syncthreads();
+        GNX_NOUNROLL for (int e = ty; e < nk * NWD; e += THREADS) {
+          const int k = e / NWD, q = e - k * NWD;
+          if (hist[(size_t)(k0 + k) * NWD + q] != (par[q] & dif[q])) atomicOr(&flags[8 + (k >> 5)], 1 << (k & 31));
+        }
+        __syncthreads();
+        for (int k = 0; k < nk; k += 32) {
+          uint32_t m = ~(uint32_t)flags[8 + (k >> 5)];
+          if (nk - k < 32) m &= (1u << (nk - k)) - 1u;
+          seen |= m != 0;
+        }
+        __syncthreads();
+      }
+      if (seen) finishing = true;
+      else { GNX_NOUNROLL for (int q = ty; q < NWD; q += THREADS) hist[(size_t)it * NWD + q] = par[q] & dif[q]; }
+    }
+    if (finishing && !any_dirty) break;
     TICK(1)
 
     // The tile elements of a candidate are per-thread values (e = tid + i * THREADS): when they fit PF_MAX registers, the NEXT
@@ -526,162 +611,17 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
         pfv[i] = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
       }
     };
-    int w = next_change(1);
-    while (w < W) {
-      TICK(2)
-      const int tz = opaque(tid), lz = tz & 63;
-      const int center = min(max(w, half), W - 1 - half);
-      const int lo = center - half;  // scope = windows [lo, lo+S)   (gnofix.py:122-130)
-      // the switched pair m' = [B0[lo:w], B1[w:hi]], p' = [B1[lo:w], B0[w:hi]] (gnofix.py:144-153); the original pair's
-      // probabilities are those of the smoother's row center + 1 (pmax)
-      if (pf_fits) {
-        if (!pf_valid) cand_fetch(w, tz);
-#pragma unroll
-        for (int i = 0; i < PF_MAX; ++i) {
-          const int e = tz + i * THREADS;
-          if (e < 2 * S * A) {
-            const int h = e >= S * A ? 1 : 0, f = e - h * S * A;
-            const int s = (int)__umulhi((uint32_t)f, invA), a = f - s * A;
-            seg[(((lo + s < w) ? h : 1 - h) * A + a) * GP + s] = pfv[i];
-          }
-        }
-      } else {
-        GNX_NOUNROLL for (int e = tz; e < 2 * S * A; e += THREADS) {
-          const int h = e >= S * A ? 1 : 0, f = e - h * S * A;
-          const int s = (int)__umulhi((uint32_t)f, invA), a = f - s * A;
-          const int u = lo + s;
-          const uint16_t v = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
-          seg[(((u < w) ? h : 1 - h) * A + a) * GP + s] = v;
-        }
-      }
-      const int w_next = next_change(w + 1);  // if this candidate is rejected
-      pf_valid = pf_fits && w_next < W;
-      if (pf_valid) cand_fetch(w_next, opaque(tid));
-      __syncthreads();
-      TICK(3)
-      // 2 rows x n_trees walks: tree t = tz + k * THREADS on both rows side by side, leaves to LDS [row][tree]
-      {
-        float* leafbuf = reinterpret_cast<float*>(stage);
-        for (int tb = 0; tb < NT; tb += THREADS * PER_T) {
-          const int per_u = min(PER_T, (NT - tb + THREADS - 1) / THREADS);  // block-uniform
-          const uint32_t t0 = (uint32_t)min(tb + tz, NT - 1);              // (GNX_GF_PAD_TREES zero trees follow the last one)
-          float lf[PER_T * 2];
-          // ONE batch: the lane's per_u trees x 2 rows (D - 1 dependent L2 round trips + the leaves)
-          if (per_u <= 1) walk4<1, THREADS, DT>(GT, t0, crow, roff, D, lf);
-          else if (PER_T > 2 && per_u == 2) walk4<(PER_T > 2 ? 2 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
-          else if (PER_T > 3 && per_u == 3) walk4<(PER_T > 3 ? 3 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
-          else if (PER_T > 4 && per_u == 4) walk4<(PER_T > 4 ? 4 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
-          else walk4<PER_T, THREADS, DT>(GT, t0, crow, roff, D, lf);
-#pragma unroll
-          for (int k = 0; k < PER_T; ++k) {
-            const int t = tb + tz + k * THREADS;
-            if (k < per_u && t < NT) {
-#pragma unroll
-              for (int r = 0; r < 2; ++r) leafbuf[r * NT + t] = lf[k * 2 + r];
-            }
-          }
-        }
+    int pf_w = -1;
+    int scan_from = 1, last_acc = -(1 << 20), chunks_left = 0;
+    bool big_pending = false, flushing = any_dirty;
+    int bp_lo = 0, bp_hi = 0;
+    if (flushing) { bp_lo = __builtin_amdgcn_readfirstlane(first_dirty(0)); bp_hi = min(W, bp_lo + gstep); big_pending = bp_lo < W; flushing = big_pending; any_dirty = big_pending; }
+    while (true) {
+      if (big_pending) {  // ---- rows [bp_lo, bp_hi) in batches of up to gstep windows x 2 haplotypes, class by class from staged trees ----
+        const int tz = opaque(tid);
         __syncthreads();
-        if (tz < 2 * A) {  // per (row, class): the float32 sum of the class's leaves in tree order (class-major packing)
-          const int r = (int)__umulhi((uint32_t)tz, invA), c = tz - r * A;
-          const float* lb = leafbuf + r * NT;
-          const int t1 = ct0s[c + 1];
-          int t = ct0s[c];
-          float ps = 0.f;
-          GNX_NOUNROLL for (; t + 8 <= t1; t += 8) {  // loads first, then the adds in tree order
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = lb[t + k];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) ps += v[k];
-          }
-          GNX_NOUNROLL for (; t < t1; ++t) ps += lb[t];
-          marg[tz] = L.base_score + ps;
-        }
-      }
-      __syncthreads();
-      TICK(4)
-      // xgboost's Softmax of the 4 rows and the decision, by EVERY wave for itself (same answer, no second barrier; the LDS
-      // operations of one wave execute in order)
-      bool accept;
-      {
-        float* exw = ex + wv * 2 * A;
-        GNX_NOUNROLL for (int e = lz; e < 2 * A; e += 64) {
-          const int r = (int)__umulhi((uint32_t)e, invA);
-          float wmax = marg[r * A];
-          GNX_NOUNROLL for (int a = 1; a < A; ++a) wmax = fmaxf(marg[r * A + a], wmax);
-          exw[e] = (float)exp((double)(marg[e] - wmax));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float mx = 0.f;
-        if (lz < 2) {
-          double wsum = 0.0;
-          GNX_NOUNROLL for (int a = 0; a < A; ++a) wsum += (double)exw[lz * A + a];
-          const float fs = (float)wsum;
-          mx = exw[lz * A] / fs;
-          GNX_NOUNROLL for (int a = 1; a < A; ++a) mx = fmaxf(mx, exw[lz * A + a] / fs);
-        }
-        const float p_orig = fmaxf(pmax[2 * (center + 1)], pmax[2 * (center + 1) + 1]);  // prob_comp="max" over hap and ancestry
-        const float p_sw = fmaxf(__shfl(mx, 0), __shfl(mx, 1));
-        accept = p_sw * 0.5f > p_orig * 0.5f;                      // prior_switch_prob = 0.5 (gnofix.py:171)
-      }
-      TICK(5)
-      if (!accept) {
-        if (tz == 0) atomicOr(&rej[w >> 5], 1u << (w & 31));
-        w = w_next;
-        continue;
-      }
-      pf_valid = false;
-
-      // ---- accept: flip the parity from w on, relabel ----
-      ++n_switch;
-      GNX_NOUNROLL for (int q = tz; q < NWD; q += THREADS) {
-        const int b0 = q * 32;
-        uint32_t m = 0;
-        if (w <= b0) m = 0xffffffffu;
-        else if (w < b0 + 32) m = 0xffffffffu << (w - b0);
-        par[q] ^= m;
-      }
-      GNX_NOUNROLL for (int q = tz; q < NWD; q += THREADS) {  // candidates within S windows of w are open again
-        const int lo_w = max(w - S, 0), hi_w = min(w + S, W - 1), b0 = q * 32;
-        if (b0 + 31 >= lo_w && b0 <= hi_w) {
-          uint32_t m = 0xffffffffu;
-          if (lo_w > b0) m &= 0xffffffffu << (lo_w - b0);
-          if (hi_w < b0 + 31) m &= 0xffffffffu >> (b0 + 31 - hi_w);
-          rej[q] &= ~m;
-        }
-      }
-      if (tz == 0) { flags[2] = W; flags[3] = 0; }
-      __syncthreads();
-      // Row w' sees unpadded windows {slide_src(w'+s)}: rows that only see windows >= w exchange their two labels, rows that see
-      // both sides are re-evaluated.  (The rows to re-evaluate form one contiguous range [r0, r1): re-evaluating a row of that range
-      // that needed nothing, or one that was also swapped, just recomputes its label from the current strips.)
-      GNX_NOUNROLL for (int wr = tz; wr < W; wr += THREADS) {
-        int mn = W, mx = -1;
-        const int j0 = wr, j1 = wr + S - 1;
-        const int a0 = max(j0, pad), a1 = min(j1, pad + W - 1);
-        if (a0 <= a1) { mn = min(mn, a0 - pad); mx = max(mx, a1 - pad); }
-        if (j0 < pad) { const int b1 = min(j1, pad - 1); mn = min(mn, pad - 1 - b1); mx = max(mx, pad - 1 - j0); }
-        if (j1 >= pad + W) { const int b0 = max(j0, pad + W); mn = min(mn, W - 1 - (j1 - pad - W)); mx = max(mx, W - 1 - (b0 - pad - W)); }
-        if (mn >= w) {
-          const uint16_t y = Y[wr];
-          Y[wr] = (uint16_t)((y >> 8) | (y << 8));
-          const float p0 = pmax[2 * wr];
-          pmax[2 * wr] = pmax[2 * wr + 1];
-          pmax[2 * wr + 1] = p0;
-        } else if (mx >= w) {
-          atomicMin(&flags[2], wr);
-          atomicMax(&flags[3], wr + 1);
-        }
-      }
-      __syncthreads();
-      const int r0 = flags[2], r1 = flags[3];
-      TICK(6)
-      const int gstep = NROW / 2;
-      for (int gb = r0; gb < r1; gb += gstep) {
-        const int nwin = min(gstep, r1 - gb), nrow = 2 * nwin, nj = nwin + S - 1;  // rows read padded windows [gb, gb + nj)
+      for (int gb = bp_lo; gb < bp_hi; gb += gstep) {
+        const int nwin = min(gstep, bp_hi - gb), nrow = 2 * nwin, nj = nwin + S - 1;  // rows read padded windows [gb, gb + nj)
         GNX_NOUNROLL for (int e = tz; e < 2 * nj * A; e += THREADS) {
           const int h = e >= nj * A ? 1 : 0, f = e - h * nj * A;
           const int q = (int)__umulhi((uint32_t)f, invA), a = f - q * A;
@@ -747,7 +687,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
         }
         __syncthreads();
         if (rlive) {
-          GNX_NOUNROLL for (int a = set; a < A; a += nset) marg[a * NROW + rr] = (float)exp((double)(marg[a * NROW + rr] - wmax));
+          GNX_NOUNROLL for (int a = set; a < A; a += nset) marg[a * NROW + rr] = (float)exp_sc((double)(marg[a * NROW + rr] - wmax));
         }
         __syncthreads();
         if (rlive && set == 0) {  // first maximum wins
@@ -762,25 +702,270 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
         }
         __syncthreads();
       }
-      mark_changes(tz);
+        set_dirty(bp_lo, bp_hi, false, tz);
+        mark_changes(tz);
+        __syncthreads();
+        big_pending = false;
+        pf_valid = false;  // (nothing prefetched survives a big batch: its registers are free in there)
+#pragma unroll
+        for (int i = 0; i < PF_MAX; ++i) pfv[i] = 0;
+        if (flushing) {
+          bp_lo = __builtin_amdgcn_readfirstlane(first_dirty(0));
+          bp_hi = min(W, bp_lo + gstep);
+          big_pending = bp_lo < W;
+          flushing = big_pending;
+          any_dirty = big_pending;
+        }
+        TICK(7)
+        continue;
+      }
+      if (finishing) break;
+      int w = __builtin_amdgcn_readfirstlane(next_change(scan_from));   // (block-uniform values: scalar registers)
+      int d = -1;  // >= 0: rows have to be cleaned before the candidate at w can be looked at
+      if (any_dirty) {
+        // rows that have to be current first: [scan_from - 1, w] (the labels that make w the next change) and row center + 1 (its
+        // cached probabilities)
+        d = __builtin_amdgcn_readfirstlane(first_dirty(max(scan_from - 1, 0)));
+        if (d > min(w, W - 1)) {
+          d = -1;
+          if (w < W) {
+            const int rc = min(max(w, half), W - 1 - half) + 1;
+            if (__builtin_amdgcn_readfirstlane((int)((dirty[rc >> 5] >> (rc & 31)) & 1u))) d = rc;
+          }
+        }
+        // a big batch instead of a small chunk when no change is ahead by the stale labels, or when the switches have stopped coming
+        // (the chunks since the last accepted switch have used up their allowance: the rest of the dirty rows ahead at the big
+        // batch's cost per row)
+        if (d >= 0 && (w >= W || chunks_left == 0)) {
+          bp_lo = d; bp_hi = min(W, d + gstep); big_pending = true;
+          continue;
+        }
+        if (d >= 0) --chunks_left;
+      }
+      if (d < 0 && w >= W) break;
+      TICK(2)
+      // ONE walk site for both: a candidate = the switched pair at w (one row pair), a small chunk = windows [d, d + npair) of the
+      // current strips (npair row pairs); every tree from L2 on each pair, leaves to LDS, per (row, class) the in-order sum.
+      const bool chunk = d >= 0;
+      const int tz = opaque(tid), lz = tz & 63;
+      const int center = min(max(w, half), W - 1 - half);
+      const int lo = center - half;  // scope = windows [lo, lo+S)   (gnofix.py:122-130)
+      const int npair = chunk ? min(min(min(KS, THREADS / 64), S + 2), W - d) : 1;   // (chunk: npair + S - 1 <= 2 S + 1 tile positions, the pitch, as in the big batch)
+      if (chunk) {
+        const int nj = npair + S - 1;
+        __syncthreads();
+        GNX_NOUNROLL for (int e = tz; e < 2 * nj * A; e += THREADS) {
+          const int h = e >= nj * A ? 1 : 0, f = e - h * nj * A;
+          const int q = (int)__umulhi((uint32_t)f, invA), a = f - q * A;
+          const int u = slide_src(d + q, W, pad);
+          seg[(h * A + a) * GP + q] = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
+        }
+      } else {
+        // the switched pair m' = [B0[lo:w], B1[w:hi]], p' = [B1[lo:w], B0[w:hi]] (gnofix.py:144-153); the original pair's
+        // probabilities are those of the smoother's row center + 1 (pmax)
+        if (pf_fits) {
+          if (!(pf_valid && pf_w == w)) cand_fetch(w, tz);
+#pragma unroll
+          for (int i = 0; i < PF_MAX; ++i) {
+            const int e = tz + i * THREADS;
+            if (e < 2 * S * A) {
+              const int h = e >= S * A ? 1 : 0, f = e - h * S * A;
+              const int s = (int)__umulhi((uint32_t)f, invA), a = f - s * A;
+              seg[(((lo + s < w) ? h : 1 - h) * A + a) * GP + s] = pfv[i];
+            }
+          }
+        } else {
+          GNX_NOUNROLL for (int e = tz; e < 2 * S * A; e += THREADS) {
+            const int h = e >= S * A ? 1 : 0, f = e - h * S * A;
+            const int s = (int)__umulhi((uint32_t)f, invA), a = f - s * A;
+            const int u = lo + s;
+            const uint16_t v = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
+            seg[(((u < w) ? h : 1 - h) * A + a) * GP + s] = v;
+          }
+        }
+        const int w_next = __builtin_amdgcn_readfirstlane(next_change(w + 1));  // if this candidate is rejected
+        pf_valid = pf_fits && w_next < W;
+        pf_w = w_next;
+        if (pf_valid) cand_fetch(w_next, opaque(tid));
+      }
       __syncthreads();
-      w = next_change(w + 1);
-      TICK(7)
+      TICK(3)
+      // 2 rows x n_trees walks per pair: tree t = tz + k * THREADS on both rows side by side, leaves to LDS [pair][row][tree]
+      {
+        float* leafbuf = reinterpret_cast<float*>(stage);
+        GNX_NOUNROLL for (int kp = 0; kp < npair; ++kp) {
+          const uint8_t* krow = crow + 2 * kp;
+          const int lb0 = 2 * kp * NT;
+          for (int tb = 0; tb < NT; tb += THREADS * PER_T) {
+            const int per_u = min(PER_T, (NT - tb + THREADS - 1) / THREADS);  // block-uniform
+            const uint32_t t0 = (uint32_t)min(tb + tz, NT - 1);              // (GNX_GF_PAD_TREES zero trees follow the last one)
+            float lf[PER_T * 2];
+            // ONE batch: the lane's per_u trees x 2 rows (D - 1 dependent L2 round trips + the leaves)
+            if (per_u <= 1) walk4<1, THREADS, DT>(GT, t0, krow, roff, D, lf);
+            else if (PER_T > 2 && per_u == 2) walk4<(PER_T > 2 ? 2 : 1), THREADS, DT>(GT, t0, krow, roff, D, lf);
+            else if (PER_T > 3 && per_u == 3) walk4<(PER_T > 3 ? 3 : 1), THREADS, DT>(GT, t0, krow, roff, D, lf);
+            else if (PER_T > 4 && per_u == 4) walk4<(PER_T > 4 ? 4 : 1), THREADS, DT>(GT, t0, krow, roff, D, lf);
+            else walk4<PER_T, THREADS, DT>(GT, t0, krow, roff, D, lf);
+#pragma unroll
+            for (int k = 0; k < PER_T; ++k) {
+              const int t = tb + tz + k * THREADS;
+              if (k < per_u && t < NT) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) leafbuf[lb0 + r * NT + t] = lf[k * 2 + r];
+              }
+            }
+          }
+        }
+        __syncthreads();
+        if (tz < 2 * npair * A) {  // per (row, class): the float32 sum of the class's leaves in tree order; row rr = 2 pair + haplotype
+          const int rr = (int)__umulhi((uint32_t)tz, invA), c = tz - rr * A;
+          const float* lb = leafbuf + (size_t)rr * NT;
+          const int t1 = ct0s[c + 1];
+          int t = ct0s[c];
+          float ps = 0.f;
+          GNX_NOUNROLL for (; t + 8 <= t1; t += 8) {  // loads first, then the adds in tree order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = lb[t + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ps += v[k];
+          }
+          GNX_NOUNROLL for (; t < t1; ++t) ps += lb[t];
+          marg[c * NROW + rr] = L.base_score + ps;
+        }
+      }
+      __syncthreads();
+      TICK(4)
+      // xgboost's Softmax.  The exponentials of all (row, class) pairs first — ONE site for the candidate's two rows (by every wave
+      // for itself: same answer, no second barrier; the LDS operations of one wave execute in order) and the chunk's 2 npair rows
+      // (spread over the block) — then per row the sum, the probabilities and their maximum.
+      float* exw = chunk ? ex : ex + wv * 2 * A;
+      {
+        const int nr = 2 * npair, e0 = chunk ? tz : lz, estep = chunk ? THREADS : 64;
+        GNX_NOUNROLL for (int e = e0; e < nr * A; e += estep) {
+          const int r = (int)__umulhi((uint32_t)e, invA), ce = e - r * A;
+          float wmax = marg[r];
+          GNX_NOUNROLL for (int a = 1; a < A; ++a) wmax = fmaxf(marg[a * NROW + r], wmax);
+          exw[e] = (float)exp_sc((double)(marg[ce * NROW + r] - wmax));
+        }
+      }
+      if (chunk) {
+        __syncthreads();
+        if (tz < 2 * npair) {  // first maximum wins (as in the big batch)
+          const int rr = tz;
+          double wsum = 0.0;
+          GNX_NOUNROLL for (int a = 0; a < A; ++a) wsum += (double)exw[rr * A + a];
+          const float fs = (float)wsum;
+          int best = 0;
+          float bv = exw[rr * A] / fs;
+          GNX_NOUNROLL for (int a = 1; a < A; ++a) { const float v = exw[rr * A + a] / fs; if (v > bv) { bv = v; best = a; } }
+          reinterpret_cast<uint8_t*>(Y)[2 * (d + (rr >> 1)) + (rr & 1)] = (uint8_t)best;
+          pmax[2 * (d + (rr >> 1)) + (rr & 1)] = bv;
+        }
+        set_dirty(d, d + npair, false, tz);
+        __syncthreads();
+        mark_changes(tz);
+        __syncthreads();
+        TICK(7)
+        continue;
+      }
+      bool accept;
+      {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float mx = 0.f;
+        if (lz < 2) {
+          double wsum = 0.0;
+          GNX_NOUNROLL for (int a = 0; a < A; ++a) wsum += (double)exw[lz * A + a];
+          const float fs = (float)wsum;
+          mx = exw[lz * A] / fs;
+          GNX_NOUNROLL for (int a = 1; a < A; ++a) mx = fmaxf(mx, exw[lz * A + a] / fs);
+        }
+        const float p_orig = fmaxf(pmax[2 * (center + 1)], pmax[2 * (center + 1) + 1]);  // prob_comp="max" over hap and ancestry
+        const float p_sw = fmaxf(__shfl(mx, 0), __shfl(mx, 1));
+        accept = p_sw * 0.5f > p_orig * 0.5f;                      // prior_switch_prob = 0.5 (gnofix.py:171)
+      }
+      TICK(5)
+      scan_from = w + 1;
+      if (!accept) {
+        if (tz == 0) atomicOr(&rej[w >> 5], 1u << (w & 31));
+        continue;
+      }
+      pf_valid = false;
+
+      // ---- accept: flip the parity from w on, relabel ----
+      ++n_switch;
+      GNX_NOUNROLL for (int q = tz; q < NWD; q += THREADS) {
+        const int b0 = q * 32;
+        uint32_t m = 0;
+        if (w <= b0) m = 0xffffffffu;
+        else if (w < b0 + 32) m = 0xffffffffu << (w - b0);
+        par[q] ^= m;
+      }
+      GNX_NOUNROLL for (int q = tz; q < NWD; q += THREADS) {  // candidates within S windows of w are open again
+        const int lo_w = max(w - S, 0), hi_w = min(w + S, W - 1), b0 = q * 32;
+        if (b0 + 31 >= lo_w && b0 <= hi_w) {
+          uint32_t m = 0xffffffffu;
+          if (lo_w > b0) m &= 0xffffffffu << (lo_w - b0);
+          if (hi_w < b0 + 31) m &= 0xffffffffu >> (b0 + 31 - hi_w);
+          rej[q] &= ~m;
+        }
+      }
+      if (tz == 0) { flags[2] = W; flags[3] = 0; }
+      __syncthreads();
+      // Row w' sees unpadded windows {slide_src(w'+s)}: rows that only see windows >= w exchange their two labels, rows that see
+      // both sides are re-evaluated.  (The rows to re-evaluate form one contiguous range [r0, r1): re-evaluating a row of that range
+      // that needed nothing, or one that was also swapped, just recomputes its label from the current strips.)
+      GNX_NOUNROLL for (int wr = tz; wr < W; wr += THREADS) {
+        int mn = W, mx = -1;
+        const int j0 = wr, j1 = wr + S - 1;
+        const int a0 = max(j0, pad), a1 = min(j1, pad + W - 1);
+        if (a0 <= a1) { mn = min(mn, a0 - pad); mx = max(mx, a1 - pad); }
+        if (j0 < pad) { const int b1 = min(j1, pad - 1); mn = min(mn, pad - 1 - b1); mx = max(mx, pad - 1 - j0); }
+        if (j1 >= pad + W) { const int b0 = max(j0, pad + W); mn = min(mn, W - 1 - (j1 - pad - W)); mx = max(mx, W - 1 - (b0 - pad - W)); }
+        if (mn >= w) {
+          const uint16_t y = Y[wr];
+          Y[wr] = (uint16_t)((y >> 8) | (y << 8));
+          const float p0 = pmax[2 * wr];
+          pmax[2 * wr] = pmax[2 * wr + 1];
+          pmax[2 * wr + 1] = p0;
+        } else if (mx >= w) {
+          atomicMin(&flags[2], wr);
+          atomicMax(&flags[3], wr + 1);
+        }
+      }
+      __syncthreads();
+      const int r0 = flags[2], r1 = flags[3];
+      TICK(6)
+      if (w - last_acc < DENSE_GAP) {  // thick: mark, clean on demand
+        set_dirty(r0, r1, true, tz);
+        any_dirty = true;
+        chunks_left = CHUNKS_PER_SWITCH;
+        mark_changes(tz);
+        __syncthreads();
+      } else {
+        bp_lo = r0; bp_hi = r1; big_pending = r0 < r1;
+        if (!big_pending) { mark_changes(tz); __syncthreads(); }
+      }
+      last_acc = w;
     }
+    if (finishing) break;
     __syncthreads();  // (the history row of this sweep is complete before the next convergence test reads it)
   }
 
   // ---- outputs: labels, switch count, final parity (k_gnofix_swap applies it to the SNPs) ----
   __syncthreads();
-  for (int u = tid; u < W; u += THREADS) {
+  const int te = opaque(tid);  // (else the load phase's per-thread addresses stay in registers until here)
+  for (int u = te; u < W; u += THREADS) {
     L.Yout[(size_t)2 * ind * W + u] = Y[u] & 0xff;
     L.Yout[(size_t)(2 * ind + 1) * W + u] = Y[u] >> 8;
   }
-  for (int q = tid; q < NWD; q += THREADS) L.par[(size_t)ind * NWD + q] = par[q];
+  for (int q = te; q < NWD; q += THREADS) L.par[(size_t)ind * NWD + q] = par[q];
 #ifdef GNX_GNOFIX_CLOCKS
-  if (tid == 0 && L.n_switches) L.n_switches[ind] = (int)(tacc[ind & 7] >> 6);
+  if (te == 0 && L.n_switches) L.n_switches[ind] = (int)(tacc[ind & 7] >> 6);
 #else
-  if (tid == 0 && L.n_switches) L.n_switches[ind] = n_switch;
+  if (te == 0 && L.n_switches) L.n_switches[ind] = n_switch;
 #endif
 }
 
