@@ -526,15 +526,17 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
   // Re-evaluation is LAZY where switches come thick (round 4).  The reference calls smoother.predict(B) after every accepted switch
   // (gnofix.py:157-176); what the loop reads of that result before the next accepted switch is only (a) the labels up to the next label
   // change and (b) the cached probabilities of row center + 1 of the next candidate.  A switch within DENSE_GAP windows of the
-  // previous one of the same sweep therefore only MARKS its rows [r0, r1) dirty; the scan cleans rows as it needs them, KS windows at
-  // a time (the candidate's machinery: every tree from L2 on the chunk's row pairs, leaves to LDS, in-order sums), and whatever is
-  // still dirty is evaluated in big batches at the start of the next sweep / before the outputs.  A row's values depend on the strips
-  // and the parity only, so WHEN it is evaluated changes nothing it evaluates to: same decisions, same labels (tests: G5, fuzz).
-  // With a label change at nearly every window (random trees on unstructured haplotypes) a switch costs one or two small chunks
-  // instead of 2 (S - 1) rows x n_trees walks.  Isolated switches keep the immediate big batch.
-  constexpr int DENSE_GAP = 12, CHUNKS_PER_SWITCH = 2;
+  // previous one of the same sweep therefore only MARKS its rows [r0, r1) dirty; the scan cleans rows as it needs them, CLEAN_WIN
+  // windows at a time — a SHORT batch of the same re-evaluation code: with few rows every class gets a row set of its own (the stage
+  // is cut into A slices of cap' trees), so it costs one class's walks instead of A / 3 classes' — and whatever is still dirty is
+  // evaluated in full batches at the start of the next sweep / before the outputs.  A row's values depend on the strips and the
+  // parity only, so WHEN it is evaluated changes nothing it evaluates to: same decisions, same labels (tests: G5, fuzz, phase_gt2).
+  // With a label change at nearly every window (random trees on unstructured haplotypes) a switch costs one short batch instead of
+  // 2 (S - 1) rows x n_trees walks.  Isolated switches keep the immediate full batch.
+  // (measured on MI355X, worst case / config 5b: 8 / 8 / 3 -> 405 ms / 6.46 ms; 12 / 12 / 2 -> 401 / 6.66; 12 / 24 / 2 -> 452 / 6.69;
+  //  36 / 36 / 1 -> 469 / 6.75; 8 / 4 / 4 -> 452 / 6.63; never lazy (round 4's first version) -> 619 / 6.51)
+  constexpr int DENSE_GAP = 8, CLEAN_WIN = 8, CLEANS_PER_SWITCH = 3;
   const int gstep = NROW / 2;
-  const int KS = max(1, min(8, (int)((o.flags - o.stage) / ((size_t)8 * NT))));   // windows per small chunk: leaves [2 KS][NT] in the stage
   uint32_t* dirty = reinterpret_cast<uint32_t*>(lds + o.dirty);
   for (int q = tid; q < NWD; q += THREADS) dirty[q] = 0;
   __syncthreads();
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
       }
     };
     int pf_w = -1;
-    int scan_from = 1, last_acc = -(1 << 20), chunks_left = 0;
+    int scan_from = 1, last_acc = -(1 << 20), cleans_left = 0;
     bool big_pending = false, flushing = any_dirty;
     int bp_lo = 0, bp_hi = 0;
     if (flushing) { bp_lo = __builtin_amdgcn_readfirstlane(first_dirty(0)); bp_hi = min(W, bp_lo + gstep); big_pending = bp_lo < W; flushing = big_pending; any_dirty = big_pending; }
@@ -620,32 +622,36 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
       if (big_pending) {  // ---- rows [bp_lo, bp_hi) in batches of up to gstep windows x 2 haplotypes, class by class from staged trees ----
         const int tz = opaque(tid);
         __syncthreads();
-      for (int gb = bp_lo; gb < bp_hi; gb += gstep) {
-        const int nwin = min(gstep, bp_hi - gb), nrow = 2 * nwin, nj = nwin + S - 1;  // rows read padded windows [gb, gb + nj)
+      const int blo = __builtin_amdgcn_readfirstlane(bp_lo), bhi = __builtin_amdgcn_readfirstlane(bp_hi);  // (block-uniform: scalar registers for what derives from them)
+      for (int gb = blo; gb < bhi; gb += gstep) {
+        const int nwin = min(gstep, bhi - gb), nrow = 2 * nwin, nj = nwin + S - 1;  // rows read padded windows [gb, gb + nj)
         GNX_NOUNROLL for (int e = tz; e < 2 * nj * A; e += THREADS) {
           const int h = e >= nj * A ? 1 : 0, f = e - h * nj * A;
           const int q = (int)__umulhi((uint32_t)f, invA), a = f - q * A;
           const int u = slide_src(gb + q, W, pad);
           seg[(h * A + a) * GP + q] = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
         }
-        // lane = row (haplotype rh, window gb + rk) of row set `set`; set s walks class c0 + s
-        const int nset = min(NSETMAX, THREADS / nrow);
+        // lane = row (haplotype rh, window gb + rk) of row set `set`; set s walks class c0 + s.  The stage holds NSETMAX * cap trees:
+        // a full batch has NSETMAX sets of `cap` trees, a short one up to A sets of capE (a multiple of NWR) — more classes side by
+        // side, more staging rounds per class.
+        const int nset = min(min(A, THREADS / nrow), max(NSETMAX, NSETMAX * L.cap / NWR));
+        const int capE = nset <= NSETMAX ? L.cap : max(NWR, (NSETMAX * L.cap / nset) / NWR * NWR);
         const int set = tz / nrow, rr = tz - set * nrow;
         const bool rlive = set < nset;
         const int rh = rr >= nwin ? 1 : 0, rk = rr - rh * nwin;
         const uint8_t* rrow = reinterpret_cast<const uint8_t*>(seg) + ((size_t)rh * A * GP + rk) * 2;
-        const uint32_t* mystage = stage + (size_t)(rlive ? set : 0) * L.cap * TW;
+        const uint32_t* mystage = stage + (size_t)(rlive ? set : 0) * capE * TW;
         GNX_NOUNROLL for (int c0 = 0; c0 < A; c0 += nset) {
           const int c = c0 + set;
           const bool clive = rlive && c < A;
           const int t0 = clive ? ct0s[c] : 0, cn = clive ? ct0s[c + 1] - t0 : 0;
           float ps = 0.f;
-          GNX_NOUNROLL for (int k0 = 0; k0 < nmax; k0 += L.cap) {
+          GNX_NOUNROLL for (int k0 = 0; k0 < nmax; k0 += capE) {
             __syncthreads();  // the tile is complete / the previous chunk has been walked
             {  // the chunk [k0, k0 + cap) of the classes c0 .. c0 + nset - 1, one after the other in the stage: all of a thread's
                // 16-byte pieces are requested before the first is stored (one L2 round trip per chunk, not one per piece)
               constexpr int NST = 6;
-              const int per_set = L.cap * (TW / 4), total = nset * per_set;
+              const int per_set = capE * (TW / 4), total = nset * per_set;
               const uint4* src = reinterpret_cast<const uint4*>(GTp);
               uint4* dst = reinterpret_cast<uint4*>(stage);
               GNX_NOUNROLL for (int g0 = 0; g0 < total; g0 += NST * THREADS) {
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
                   const int sq = g / per_set, wi = g - sq * per_set, cq = c0 + sq;
                   ok[k] = g < total && cq < A;
                   const int ts = ok[k] ? ct0s[cq] + k0 : 0;
-                  const int n_s = ok[k] ? max(0, min(L.cap, ct0s[cq + 1] - ts)) : 0;
+                  const int n_s = ok[k] ? max(0, min(capE, ct0s[cq + 1] - ts)) : 0;
                   ok[k] = ok[k] && wi < n_s * (TW / 4);
                   v[k] = src[ok[k] ? (size_t)ts * (TW / 4) + wi : 0];
                 }
@@ -667,7 +673,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
               }
             }
             __syncthreads();
-            const int n_st = max(0, min(L.cap, cn - k0));
+            const int n_st = max(0, min(capE, cn - k0));
             GNX_NOUNROLL for (int t = 0; t < n_st; t += NWR) {
               float ov[NWR];
               walk_seq<NWR, DT, true>(TreesLds{mystage}, (uint32_t)t, (uint32_t)(n_st - 1), rrow, D, ov);
@@ -733,34 +739,22 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
             if (__builtin_amdgcn_readfirstlane((int)((dirty[rc >> 5] >> (rc & 31)) & 1u))) d = rc;
           }
         }
-        // a big batch instead of a small chunk when no change is ahead by the stale labels, or when the switches have stopped coming
-        // (the chunks since the last accepted switch have used up their allowance: the rest of the dirty rows ahead at the big
-        // batch's cost per row)
-        if (d >= 0 && (w >= W || chunks_left == 0)) {
-          bp_lo = d; bp_hi = min(W, d + gstep); big_pending = true;
+        // clean [d, d + CLEAN_WIN) — a short batch: few rows, so every class gets a row set of its own and the batch costs one class's
+        // walks — or a full batch when no change is ahead by the stale labels / the switches have stopped coming (the short batches
+        // since the last accepted switch have used up their allowance)
+        if (d >= 0) {
+          const bool full = w >= W || cleans_left == 0;
+          if (!full) --cleans_left;
+          bp_lo = d; bp_hi = min(W, d + (full ? gstep : CLEAN_WIN)); big_pending = true;
           continue;
         }
-        if (d >= 0) --chunks_left;
       }
       if (d < 0 && w >= W) break;
       TICK(2)
-      // ONE walk site for both: a candidate = the switched pair at w (one row pair), a small chunk = windows [d, d + npair) of the
-      // current strips (npair row pairs); every tree from L2 on each pair, leaves to LDS, per (row, class) the in-order sum.
-      const bool chunk = d >= 0;
       const int tz = opaque(tid), lz = tz & 63;
       const int center = min(max(w, half), W - 1 - half);
       const int lo = center - half;  // scope = windows [lo, lo+S)   (gnofix.py:122-130)
-      const int npair = chunk ? min(min(min(KS, THREADS / 64), S + 2), W - d) : 1;   // (chunk: npair + S - 1 <= 2 S + 1 tile positions, the pitch, as in the big batch)
-      if (chunk) {
-        const int nj = npair + S - 1;
-        __syncthreads();
-        GNX_NOUNROLL for (int e = tz; e < 2 * nj * A; e += THREADS) {
-          const int h = e >= nj * A ? 1 : 0, f = e - h * nj * A;
-          const int q = (int)__umulhi((uint32_t)f, invA), a = f - q * A;
-          const int u = slide_src(d + q, W, pad);
-          seg[(h * A + a) * GP + q] = R0[(size_t)(h ^ parbit(u)) * WA + (size_t)u * A + a];
-        }
-      } else {
+      {
         // the switched pair m' = [B0[lo:w], B1[w:hi]], p' = [B1[lo:w], B0[w:hi]] (gnofix.py:144-153); the original pair's
         // probabilities are those of the smoother's row center + 1 (pmax)
         if (pf_fits) {
@@ -790,36 +784,32 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
       }
       __syncthreads();
       TICK(3)
-      // 2 rows x n_trees walks per pair: tree t = tz + k * THREADS on both rows side by side, leaves to LDS [pair][row][tree]
+      // 2 rows x n_trees walks: tree t = tz + k * THREADS on both rows side by side, leaves to LDS [row][tree]
       {
         float* leafbuf = reinterpret_cast<float*>(stage);
-        GNX_NOUNROLL for (int kp = 0; kp < npair; ++kp) {
-          const uint8_t* krow = crow + 2 * kp;
-          const int lb0 = 2 * kp * NT;
-          for (int tb = 0; tb < NT; tb += THREADS * PER_T) {
-            const int per_u = min(PER_T, (NT - tb + THREADS - 1) / THREADS);  // block-uniform
-            const uint32_t t0 = (uint32_t)min(tb + tz, NT - 1);              // (GNX_GF_PAD_TREES zero trees follow the last one)
-            float lf[PER_T * 2];
-            // ONE batch: the lane's per_u trees x 2 rows (D - 1 dependent L2 round trips + the leaves)
-            if (per_u <= 1) walk4<1, THREADS, DT>(GT, t0, krow, roff, D, lf);
-            else if (PER_T > 2 && per_u == 2) walk4<(PER_T > 2 ? 2 : 1), THREADS, DT>(GT, t0, krow, roff, D, lf);
-            else if (PER_T > 3 && per_u == 3) walk4<(PER_T > 3 ? 3 : 1), THREADS, DT>(GT, t0, krow, roff, D, lf);
-            else if (PER_T > 4 && per_u == 4) walk4<(PER_T > 4 ? 4 : 1), THREADS, DT>(GT, t0, krow, roff, D, lf);
-            else walk4<PER_T, THREADS, DT>(GT, t0, krow, roff, D, lf);
+        for (int tb = 0; tb < NT; tb += THREADS * PER_T) {
+          const int per_u = min(PER_T, (NT - tb + THREADS - 1) / THREADS);  // block-uniform
+          const uint32_t t0 = (uint32_t)min(tb + tz, NT - 1);              // (GNX_GF_PAD_TREES zero trees follow the last one)
+          float lf[PER_T * 2];
+          // ONE batch: the lane's per_u trees x 2 rows (D - 1 dependent L2 round trips + the leaves)
+          if (per_u <= 1) walk4<1, THREADS, DT>(GT, t0, crow, roff, D, lf);
+          else if (PER_T > 2 && per_u == 2) walk4<(PER_T > 2 ? 2 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
+          else if (PER_T > 3 && per_u == 3) walk4<(PER_T > 3 ? 3 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
+          else if (PER_T > 4 && per_u == 4) walk4<(PER_T > 4 ? 4 : 1), THREADS, DT>(GT, t0, crow, roff, D, lf);
+          else walk4<PER_T, THREADS, DT>(GT, t0, crow, roff, D, lf);
 #pragma unroll
-            for (int k = 0; k < PER_T; ++k) {
-              const int t = tb + tz + k * THREADS;
-              if (k < per_u && t < NT) {
+          for (int k = 0; k < PER_T; ++k) {
+            const int t = tb + tz + k * THREADS;
+            if (k < per_u && t < NT) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r) leafbuf[lb0 + r * NT + t] = lf[k * 2 + r];
-              }
+              for (int r = 0; r < 2; ++r) leafbuf[r * NT + t] = lf[k * 2 + r];
             }
           }
         }
         __syncthreads();
-        if (tz < 2 * npair * A) {  // per (row, class): the float32 sum of the class's leaves in tree order; row rr = 2 pair + haplotype
-          const int rr = (int)__umulhi((uint32_t)tz, invA), c = tz - rr * A;
-          const float* lb = leafbuf + (size_t)rr * NT;
+        if (tz < 2 * A) {  // per (row, class): the float32 sum of the class's leaves in tree order (class-major packing)
+          const int r = (int)__umulhi((uint32_t)tz, invA), c = tz - r * A;
+          const float* lb = leafbuf + r * NT;
           const int t1 = ct0s[c + 1];
           int t = ct0s[c];
           float ps = 0.f;
@@ -831,46 +821,22 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
             for (int k = 0; k < 8; ++k) ps += v[k];
           }
           GNX_NOUNROLL for (; t < t1; ++t) ps += lb[t];
-          marg[c * NROW + rr] = L.base_score + ps;
+          marg[tz] = L.base_score + ps;
         }
       }
       __syncthreads();
       TICK(4)
-      // xgboost's Softmax.  The exponentials of all (row, class) pairs first — ONE site for the candidate's two rows (by every wave
-      // for itself: same answer, no second barrier; the LDS operations of one wave execute in order) and the chunk's 2 npair rows
-      // (spread over the block) — then per row the sum, the probabilities and their maximum.
-      float* exw = chunk ? ex : ex + wv * 2 * A;
-      {
-        const int nr = 2 * npair, e0 = chunk ? tz : lz, estep = chunk ? THREADS : 64;
-        GNX_NOUNROLL for (int e = e0; e < nr * A; e += estep) {
-          const int r = (int)__umulhi((uint32_t)e, invA), ce = e - r * A;
-          float wmax = marg[r];
-          GNX_NOUNROLL for (int a = 1; a < A; ++a) wmax = fmaxf(marg[a * NROW + r], wmax);
-          exw[e] = (float)exp_sc((double)(marg[ce * NROW + r] - wmax));
-        }
-      }
-      if (chunk) {
-        __syncthreads();
-        if (tz < 2 * npair) {  // first maximum wins (as in the big batch)
-          const int rr = tz;
-          double wsum = 0.0;
-          GNX_NOUNROLL for (int a = 0; a < A; ++a) wsum += (double)exw[rr * A + a];
-          const float fs = (float)wsum;
-          int best = 0;
-          float bv = exw[rr * A] / fs;
-          GNX_NOUNROLL for (int a = 1; a < A; ++a) { const float v = exw[rr * A + a] / fs; if (v > bv) { bv = v; best = a; } }
-          reinterpret_cast<uint8_t*>(Y)[2 * (d + (rr >> 1)) + (rr & 1)] = (uint8_t)best;
-          pmax[2 * (d + (rr >> 1)) + (rr & 1)] = bv;
-        }
-        set_dirty(d, d + npair, false, tz);
-        __syncthreads();
-        mark_changes(tz);
-        __syncthreads();
-        TICK(7)
-        continue;
-      }
+      // xgboost's Softmax of the 4 rows and the decision, by EVERY wave for itself (same answer, no second barrier; the LDS
+      // operations of one wave execute in order)
       bool accept;
       {
+        float* exw = ex + wv * 2 * A;
+        GNX_NOUNROLL for (int e = lz; e < 2 * A; e += 64) {
+          const int r = (int)__umulhi((uint32_t)e, invA);
+          float wmax = marg[r * A];
+          GNX_NOUNROLL for (int a = 1; a < A; ++a) wmax = fmaxf(marg[r * A + a], wmax);
+          exw[e] = (float)exp_sc((double)(marg[e] - wmax));
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -941,7 +907,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
       if (w - last_acc < DENSE_GAP) {  // thick: mark, clean on demand
         set_dirty(r0, r1, true, tz);
         any_dirty = true;
-        chunks_left = CHUNKS_PER_SWITCH;
+        cleans_left = CLEANS_PER_SWITCH;
         mark_changes(tz);
         __syncthreads();
       } else {
