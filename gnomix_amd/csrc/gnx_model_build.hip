@@ -829,14 +829,14 @@ int gnx_build_crf(gnx_model* m, const gnx_model_desc* d) {
   for (int i = 0; i < A * A; ++i) et[(size_t)i] = std::exp(d->crf_trans[i]);
   // How many windows the forward recurrence may run between two rescalings (k_smooth_crf_ck): with B on the simplex one window
   // multiplies a normalised alpha by a factor within e^(+-r), r = max|theta| + max|tau|; float64 holds e^(+-708).  r is doubled
-  // for slack (B rows that sum to more than 1), so four windows need r <= 75, two r <= 150 — a trained model's r is ~10.
+  // for slack (B rows that sum to more than 1), so eight windows need r <= 37.5, four r <= 75, two r <= 150 — a trained model's r is ~10.
   double smax = 0.0, tmax = 0.0;
   for (int i = 0; i < A * A; ++i) {
     smax = std::max(smax, std::fabs(d->crf_state[i]));
     tmax = std::max(tmax, std::fabs(d->crf_trans[i]));
   }
   const double r = smax + tmax;
-  m->crf_norm_mask = !(r <= 150.0) ? 0 : (r <= 75.0 ? 3 : 1);
+  m->crf_norm_mask = !(r <= 150.0) ? 0 : (r <= 37.5 ? 7 : (r <= 75.0 ? 3 : 1));
   int rc;
   if ((rc = gnx_dev_upload(m, st, &m->crf_state)) != GNX_OK) return rc;
   if ((rc = gnx_dev_upload(m, et, &m->crf_etrans)) != GNX_OK) return rc;

@@ -36,6 +36,7 @@
 //  * The next label change is a find-first-set over a bit mask kept beside the labels (no block barrier per search).
 #include "gnx_internal.h"
 #include "gnx_rank.h"
+#include "gnx_exp.h"
 
 namespace {
 
@@ -246,42 +247,9 @@ __device__ inline void step_top(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t
 __device__ inline uint32_t lds_rank(uint32_t) { return 0; }
 #endif
 
-// exp() for the softmax exponentials (float32 results of a float64 evaluation: the oracle does the same to stand in for glibc's
-// correctly rounded expf, xgboost's Softmax of a float margin).  The device library's exp keeps its 18 polynomial / reduction constants
-// in VECTOR registers for the whole kernel once the scalar file is full — 18 of this kernel's 128.  Here every constant is moved into
-// a scalar pair by a volatile asm right where it is used, so nothing can be hoisted: Cody-Waite reduction (n = rint(x / ln 2),
-// r = x - n ln 2 in two parts), degree-13 Taylor polynomial of e^r (|r| <= 0.347: truncation 1.3e-17 relative), v_ldexp_f64 (overflow
-// -> inf, underflow -> 0 like exp).  Within 1 ulp of libm (checked on the host against 2e7 arguments); arguments here are <= 0.
-#if defined(__HIP_DEVICE_COMPILE__)
-template <uint32_t LO, uint32_t HI>
-__device__ __forceinline__ double sconst() {  // a float64 constant in a scalar pair the optimiser cannot see through (nor hoist)
-  uint32_t lo, hi;
-  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"(LO), "n"(HI));
-  return __hiloint2double((int)hi, (int)lo);
-}
-__device__ __forceinline__ double exp_sc(double x) {
-  const double n = rint(x * sconst<0x652b82feu, 0x3ff71547u>());            // 1 / ln 2
-  double r = fma(n, sconst<0xfee00000u, 0xbfe62e42u>(), x);                 // -ln 2, high part (fdlibm's split: n ln2_hi is exact)
-  r = fma(n, sconst<0x35793c76u, 0xbdea39efu>(), r);                        // -ln 2, low part
-  double p = sconst<0x13a86d09u, 0x3de61246u>();                            // 1/13!
-  p = fma(p, r, sconst<0xeff8d898u, 0x3e21eed8u>());                        // 1/12!
-  p = fma(p, r, sconst<0x67f544e4u, 0x3e5ae645u>());                        // 1/11!
-  p = fma(p, r, sconst<0xb7789f5cu, 0x3e927e4fu>());                        // 1/10!
-  p = fma(p, r, sconst<0xa556c734u, 0x3ec71de3u>());                        // 1/9!
-  p = fma(p, r, sconst<0x1a01a01au, 0x3efa01a0u>());                        // 1/8!
-  p = fma(p, r, sconst<0x1a01a01au, 0x3f2a01a0u>());                        // 1/7!
-  p = fma(p, r, sconst<0x16c16c17u, 0x3f56c16cu>());                        // 1/6!
-  p = fma(p, r, sconst<0x11111111u, 0x3f811111u>());                        // 1/5!
-  p = fma(p, r, sconst<0x55555555u, 0x3fa55555u>());                        // 1/4!
-  p = fma(p, r, sconst<0x55555555u, 0x3fc55555u>());                        // 1/3!
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)n);
-}
-#else
-__device__ inline double exp_sc(double x) { return x; }
-#endif
+// exp() for the softmax exponentials: float32 results of a float64 evaluation (the oracle does the same to stand in for glibc's
+// correctly rounded expf, xgboost's Softmax of a float margin); constants from scalar pairs, gnx_exp.h
+__device__ __forceinline__ double exp_sc(double x) { return gnx_exp_sc(x); }
 
 // Tree layout of k_gnofix (SmoothXGBDev::gf_packed): 2^D node words in heap order (slot 0 unused; rank field << 16 | byte offset of
 // the feature in the tile) followed by 2^D float leaves — the leaf of heap index j is word j.  Words 0..3 = {-, root, node 2, node 3}

@@ -19,6 +19,7 @@
 // k_crf_scan / k_smooth_crf_lanes keep the oracle's left-to-right association (float64, no FMA contraction); the row kernel fuses
 // its multiply-adds (marginals within 1e-11 of the oracle's, labels identical).
 #include "gnx_internal.h"
+#include "gnx_exp.h"
 
 namespace {
 
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   constexpr int SEG = 8;
   __shared__ double la[4][SEG][64];      // [wave][step][lane] recomputed alpha_t(y)
   __shared__ double2 lsc[4][SEG][4];     // [wave][step][row] (1/c_t, c_t)
+  __shared__ double lth[FWDPSI ? AT : 1][16];  // theta[i][y]: read per segment in the psi phase only (24 registers less held through the chain)
   const int A = L.A, W = L.W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int y = lane & 15, row = lane >> 4;
@@ -573,13 +575,15 @@ __global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   const int NSEG = (W + SEG - 1) / SEG;
   double* ck = L.alpha + (size_t)nn * NSEG * A;  // [segment][label] alpha at the segment's last window
 
-  double Ef[AT], Eb[AT], Th[FWDPSI ? AT : 1];
+  double Ef[AT];  // (Eb, the transposed coefficients of the backward product, are loaded after the forward sweep: 24 registers less in it)
 #pragma unroll
-  for (int i = 0; i < AT; ++i) {
-    const bool ok = label && i < A;
-    Ef[i] = ok ? L.etrans[i * A + y] : 0.0;
-    Eb[i] = ok ? L.etrans[y * A + i] : 0.0;
-    if constexpr (FWDPSI) Th[i] = ok ? L.state[i * A + y] : 0.0;
+  for (int i = 0; i < AT; ++i) Ef[i] = (label && i < A) ? L.etrans[i * A + y] : 0.0;
+  if constexpr (FWDPSI) {
+    for (int e = threadIdx.x; e < AT * 16; e += blockDim.x) {
+      const int i = e >> 4, yy = e & 15;
+      lth[i][yy] = (i < A && yy < A) ? L.state[i * A + yy] : 0.0;
+    }
+    __syncthreads();
   }
   auto clampt = [&](int t) { return t < 0 ? 0 : (t > W - 1 ? W - 1 : t); };
   const int yl = label ? y : 0;
@@ -632,11 +636,18 @@ __global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
 #pragma unroll
     for (int k = 0; k < SEG; ++k) bn[k] = FWDPSI ? loadB(clampt(t0 + SEG + k)) : loadPsi(clampt(t0 + SEG + k));
     if constexpr (FWDPSI) {  // psi of the whole segment first: nothing of it is on the chain
+      double Th[AT];
+      {
+        int yo = y;
+        asm volatile("" : "+v"(yo));  // (an address the optimiser cannot prove loop-invariant: the reads stay inside the segment)
+#pragma unroll
+        for (int i = 0; i < AT; ++i) Th[i] = lth[i][yo];
+      }
 #pragma unroll
       for (int k = 0; k < SEG; ++k) {
         double sdot = 0.0;
         row_dot<AT>(sdot, dpp_ready(bc[k]), Th);
-        bc[k] = label ? exp(sdot) : 0.0;
+        bc[k] = label ? gnx_exp_sc(sdot) : 0.0;
         if (active && t0 + k < W) L.psi[row0 + (size_t)(t0 + k) * A + y] = bc[k];
       }
     }
@@ -653,6 +664,13 @@ __global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   __threadfence_block();
 
   // ---- backward: per segment recompute alpha into LDS, then beta and the marginals ----
+  double Eb[AT];
+  {
+    int yo = y;
+    asm volatile("" : "+v"(yo));  // (keeps these loads below the forward sweep)
+#pragma unroll
+    for (int i = 0; i < AT; ++i) Eb[i] = (label && i < A) ? L.etrans[yo * A + i] : 0.0;
+  }
   double beta = 0.0, psi_next = 0.0;
   double an = 0.0;
   {
