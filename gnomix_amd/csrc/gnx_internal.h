@@ -232,7 +232,7 @@ struct SmoothCRFLaunch {
   double* proba64;        // optional
   float* proba32;         // optional
   int32_t* labels;        // optional
-  int32_t norm_mask;      // k_smooth_crf_ck takes the forward scale at windows t with (t & norm_mask) == norm_mask (0, 1 or 3: gnx_build_crf)
+  int32_t norm_mask;      // k_smooth_crf_ck takes the forward scale at windows t with (t & norm_mask) == norm_mask (0, 1, 3 or 7: gnx_build_crf)
 };
 
 #ifdef GNX_EXPERIMENTS

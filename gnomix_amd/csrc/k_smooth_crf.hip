@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   // the last window's is the true row sum (then prod c_t = Z).  The kernel is bound by its float64 DPP multiply-adds (8 cycles each:
   // a 3 072-wave round takes 1431 windows x 3 waves x ~1 180 cycles), and a row sum is 12 of the ~84 per window: the sum and its
   // reciprocal are taken every (norm_mask + 1)-th window only (and at the last one), c_t = 1 in between.  gnx_build_crf picks
-  // 4, 2 or 1 windows from the weights' range so that the unscaled stretch stays inside float64 (4 for any trained model).
+  // 8, 4, 2 or 1 windows from the weights' range so that the unscaled stretch stays inside float64 (8 for any trained model).
   const int norm_mask = L.norm_mask;
   auto fwd_step = [&](double a_prev, double psi, int t, double& sc, double& sum) -> double {
     double v = psi;

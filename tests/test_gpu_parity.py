@@ -299,10 +299,10 @@ def test_crf_vs_oracle(ga, oracle, monkeypatch, N, W, A, impl):
     assert sm.gnofix is False and np.array_equal(sm.predict(B), l_ref)
 
 
-@pytest.mark.parametrize("scale", [5.0, 10.0, 20.0, 40.0])   # forward scale every 4th, 4th or 2nd, 2nd, every window
+@pytest.mark.parametrize("scale", [2.0, 5.0, 10.0, 20.0, 40.0])   # forward scale every 8th, 8th or 4th, 4th or 2nd, 2nd, every window
 @pytest.mark.parametrize("W,A", [(133, 12), (61, 5)])
 def test_crf_weights_far_beyond_a_trained_model(ga, oracle, scale, W, A):
-    """the default kernel takes the forward scale every fourth window only (k_smooth_crf_ck, NORM): weights 10x and 40x a trained
+    """the default kernel takes the forward scale every eighth window only (k_smooth_crf_ck, norm_mask): weights 10x and 40x a trained
     model's (per-window factors down to e^-160) must still give the oracle's marginals — the oracle rescales at every window."""
     rng = np.random.RandomState(int(scale) + W)
     N = 37
