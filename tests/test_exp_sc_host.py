@@ -1,0 +1,65 @@
+"""gnx_exp.h's exp (the CRF potentials, Gnofix's softmax exponentials) restated on the host with THE HEADER'S OWN constants.
+
+The device function is a fixed sequence of IEEE operations (v_mul_f64, v_rndne_f64, v_fma_f64, v_cvt_i32_f64, v_ldexp_f64), so the
+same sequence in C with fma() / rint() / ldexp() yields the same bits for every argument; what can go wrong is a constant.  The
+constants are parsed out of gnomix_amd/csrc/gnx_exp.h (in the order the function uses them), compiled into a small C program and
+compared with glibc's exp over 3e6 arguments in [-745, 709]: within 2 units of the last place, exact behaviour at the ends.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+C_SRC = r"""
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+static double K(uint32_t lo, uint32_t hi) { uint64_t b = ((uint64_t)hi << 32) | lo; double d; memcpy(&d, &b, 8); return d; }
+static const uint32_t C[][2] = { %s };
+static double exp_sc(double x) {
+  double n = rint(x * K(C[0][0], C[0][1]));
+  double r = fma(n, K(C[1][0], C[1][1]), x);
+  r = fma(n, K(C[2][0], C[2][1]), r);
+  double p = K(C[3][0], C[3][1]);
+  for (int i = 4; i < %d; ++i) p = fma(p, r, K(C[i][0], C[i][1]));
+  p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+int main(void) {
+  double worst = 0.0; uint64_t s = 88172645463325252ULL; long bad = 0;
+  for (long i = 0; i < 3000000; ++i) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    const double u = (double)(s >> 11) / 9007199254740992.0;
+    const double x = (i %% 3 == 0) ? -745.0 + u * 1454.0 : (i %% 3 == 1 ? -40.0 + u * 80.0 : -1.0 + u * 2.0);
+    const double a = exp_sc(x), b = exp(x);
+    if (b > 1e-300 && b < 1e300) { const double e = fabs(a - b) / b; if (e > worst) worst = e; if (e > 4.5e-16) ++bad; }
+  }
+  printf("%%.3e %%ld %%g %%g %%g %%.17g\n", worst, bad, exp_sc(0.0), exp_sc(710.0), exp_sc(-800.0), exp_sc(1.0));
+  return 0;
+}
+"""
+
+
+def test_exp_sc_constants_and_accuracy(tmp_path):
+    hdr = open(os.path.join(ROOT, "gnomix_amd", "csrc", "gnx_exp.h")).read()
+    body = hdr[hdr.index("double gnx_exp_sc(double x)"):hdr.index("#else")]
+    consts = re.findall(r"<0x([0-9a-fA-F]{8})u, 0x([0-9a-fA-F]{8})u>", body)
+    # use order in the function: 1/ln2, -ln2_hi, -ln2_lo, then (1/12! is the addend of the first polynomial step, 1/13! its multiplicand)
+    assert len(consts) == 14
+    order = [consts[0], consts[1], consts[2], consts[4], consts[3]] + consts[5:]
+    table = ", ".join("{0x%su, 0x%su}" % c for c in order)
+    src = tmp_path / "exp_sc.c"
+    src.write_text(C_SRC % (table, len(order)))
+    exe = tmp_path / "exp_sc"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    worst, bad = float(out[0]), int(out[1])
+    assert worst < 4.5e-16 and bad == 0, out          # 2 units of the last place of the value
+    assert float(out[2]) == 1.0 and out[3] == "inf" and float(out[4]) == 0.0
+    import math
+    assert abs(float(out[5]) - math.e) < 1e-15
