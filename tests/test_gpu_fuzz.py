@@ -123,6 +123,37 @@ def test_random_gnofix_vs_oracle(oracle, seed):
         assert int(nsw[i]) == ns, (seed, i)
 
 
+@pytest.mark.parametrize("A,S,W", [(7, 75, 310), (5, 31, 260), (12, 75, 230)])
+def test_gnofix_where_switches_come_thick(oracle, A, S, W):
+    """a chaotic smoother on unstructured haplotypes: a label change at nearly every window and dozens of accepted switches per sweep,
+    i.e. the regime in which k_gnofix only marks the rows of a switch and brings them up to date when the scan reads them (short
+    cleaning batches, full batches at the start of a sweep).  Labels, phased SNPs and switch counts must be the reference loop's."""
+    import gnomix_amd
+    from gnomix_amd import synth
+    rng = np.random.RandomState(A * 1000 + W)
+    M = 5
+    C = W * M + 3
+    d = gnomix_amd.GnxModelData(C=C, M=M, A=A, S=S, context=0, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(4, A, S * A, seed=A + S, thr_lo=0.0, thr_hi=0.6, leaf_scale=1.0).items():
+        setattr(d, k, v)
+    dev = gnomix_amd.DeviceModel(d)
+    T = oracle.Trees(d.tree_off, d.left, d.right, d.feat, d.cond, d.tree_class, d.A, d.base_score)
+    n_ind = 3
+    X = rng.randint(0, 2, size=(2 * n_ind, C)).astype(np.int8)
+    B = rng.dirichlet(np.ones(A), size=(2 * n_ind, W))
+    Xo, Y, nsw = dev.gnofix(X, B, max_it=8)
+    rows = lambda r: oracle.xgb_predict_proba(T, r)
+    labs = lambda b: oracle.smooth_xgb(T, b, S)[1]
+    total = 0
+    for i in range(n_ind):
+        Xm, Xp, Ym, Yp, _, ns = oracle.gnofix(X[2 * i], X[2 * i + 1], B[2 * i:2 * i + 2], S, rows, labs, max_it=8)
+        assert np.array_equal(Xo[2 * i], Xm) and np.array_equal(Xo[2 * i + 1], Xp), i
+        assert np.array_equal(Y[2 * i], Ym) and np.array_equal(Y[2 * i + 1], Yp), i
+        assert int(nsw[i]) == ns, i
+        total += ns
+    assert total >= 20 * n_ind, total   # (else the inputs no longer exercise the thick regime)
+
+
 @pytest.mark.parametrize("seed", range(20))
 def test_random_covrsk_vs_oracle(oracle, seed):
     """random window widths (canonical-length fast path and generic path), class counts and support-vector sets"""
