@@ -57,3 +57,9 @@ __device__ __forceinline__ double gnx_exp_sc(double x) {
 #else   // host pass: never called
 __device__ inline double gnx_exp_sc(double x) { return x; }
 #endif
+
+// xgboost's Softmax exponentiates a float32 margin difference with expf; glibc's expf is correctly rounded in all but a vanishing
+// share of cases, which a float64 evaluation rounded to float32 reproduces (the oracle does the same).  ONE function for every softmax
+// of the tree smoother on the device — the initial smoother pass, Gnofix's candidates and its re-evaluation — so that equal margins
+// give equal probabilities whichever kernel evaluates them.
+__device__ __forceinline__ float gnx_softmax_exp(float d) { return (float)gnx_exp_sc((double)d); }

@@ -247,10 +247,6 @@ __device__ inline void step_top(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t
 __device__ inline uint32_t lds_rank(uint32_t) { return 0; }
 #endif
 
-// exp() for the softmax exponentials: float32 results of a float64 evaluation (the oracle does the same to stand in for glibc's
-// correctly rounded expf, xgboost's Softmax of a float margin); constants from scalar pairs, gnx_exp.h
-__device__ __forceinline__ double exp_sc(double x) { return gnx_exp_sc(x); }
-
 // Tree layout of k_gnofix (SmoothXGBDev::gf_packed): 2^D node words in heap order (slot 0 unused; rank field << 16 | byte offset of
 // the feature in the tile) followed by 2^D float leaves — the leaf of heap index j is word j.  Words 0..3 = {-, root, node 2, node 3}
 // arrive in ONE 16-byte read, so levels 0 and 1 cost one dependent round trip (D >= 2): a depth-4 walk is 4 of them.
@@ -661,7 +657,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
         }
         __syncthreads();
         if (rlive) {
-          GNX_NOUNROLL for (int a = set; a < A; a += nset) marg[a * NROW + rr] = (float)exp_sc((double)(marg[a * NROW + rr] - wmax));
+          GNX_NOUNROLL for (int a = set; a < A; a += nset) marg[a * NROW + rr] = gnx_softmax_exp(marg[a * NROW + rr] - wmax);
         }
         __syncthreads();
         if (rlive && set == 0) {  // first maximum wins
@@ -803,7 +799,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
           const int r = (int)__umulhi((uint32_t)e, invA);
           float wmax = marg[r * A];
           GNX_NOUNROLL for (int a = 1; a < A; ++a) wmax = fmaxf(marg[r * A + a], wmax);
-          exw[e] = (float)exp_sc((double)(marg[e] - wmax));
+          exw[e] = gnx_softmax_exp(marg[e] - wmax);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

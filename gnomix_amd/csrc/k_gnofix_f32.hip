@@ -32,6 +32,7 @@
 //  * the convergence history is compared one past sweep per thread.
 // -DGNX_GNOFIX_CLOCKS turns n_switches into per-phase clock counts (scripts/dev/gnofix_phases.py).
 #include "gnx_internal.h"
+#include "gnx_exp.h"
 
 namespace {
 
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
         const int r = tid / A;
         float wmax = marg[r * A];
         for (int a = 1; a < A; ++a) wmax = fmaxf(marg[r * A + a], wmax);
-        ex[tid] = (float)exp((double)(marg[tid] - wmax));
+        ex[tid] = gnx_softmax_exp(marg[tid] - wmax);
       }
       __syncthreads();
       if (tid < 64) {  // lanes 0..3 = rows; the decision is taken by lane 0
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(THREADS) void k_gnofix(GnofixLaunch L) {
           const int rr = e / A;
           float wmax = L.d.base_score + marg[rr * A];
           for (int a = 1; a < A; ++a) wmax = fmaxf(L.d.base_score + marg[rr * A + a], wmax);
-          swrows[e] = (float)exp((double)((L.d.base_score + marg[e]) - wmax));  // (swrows is idle here)
+          swrows[e] = gnx_softmax_exp((L.d.base_score + marg[e]) - wmax);  // (swrows is idle here)
         }
         __syncthreads();
         for (int rr = tid; rr < nrow; rr += THREADS) {

@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "gnx_internal.h"
+#include "gnx_exp.h"
 
 namespace {
 
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb(SmoothXGBLaunch L) {
     for (int a = 1; a < A; ++a) wmax = fmaxf(o[a], wmax);
     double wsum = 0.0;
     for (int a = 0; a < A; ++a) {
-      const float e = (float)exp((double)(o[a] - wmax));
+      const float e = gnx_softmax_exp(o[a] - wmax);
       o[a] = e;
       wsum += (double)e;
     }
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void k_smooth_rows(SmoothXGBDev d, const float
     float wmax = m[0];
     for (int a = 1; a < A; ++a) wmax = fmaxf(m[a], wmax);
     double wsum = 0.0;
-    for (int a = 0; a < A; ++a) { m[a] = (float)exp((double)(m[a] - wmax)); wsum += (double)m[a]; }
+    for (int a = 0; a < A; ++a) { m[a] = gnx_softmax_exp(m[a] - wmax); wsum += (double)m[a]; }
     const float fs = (float)wsum;
     for (int a = 0; a < A; ++a) proba[(r0 + threadIdx.x) * A + a] = m[a] / fs;
   }

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "gnx_internal.h"
+#include "gnx_exp.h"
 #include "gnx_rank.h"
 
 namespace {
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_smooth_xgb_rk(SmoothXGBLaunch L)
     for (int a = 1; a < A; ++a) wmax = fmaxf(mg[(size_t)a * NW], wmax);
     double wsum = 0.0;
     for (int a = 0; a < A; ++a) {
-      const float e = (float)exp((double)(mg[(size_t)a * NW] - wmax));
+      const float e = gnx_softmax_exp(mg[(size_t)a * NW] - wmax);
       o[a] = e;
       wsum += (double)e;
     }
