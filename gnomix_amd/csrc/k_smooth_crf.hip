@@ -18,6 +18,7 @@
 //     k_smooth_crf_lanes (any label count; the only kernel for 17..32) stay selectable with GNX_CRF_IMPL and serve as cross-checks.
 // k_crf_scan / k_smooth_crf_lanes keep the oracle's left-to-right association (float64, no FMA contraction); the row kernel fuses
 // its multiply-adds (marginals within 1e-11 of the oracle's, labels identical).
+#include <cstdlib>
 #include "gnx_internal.h"
 #include "gnx_exp.h"
 
@@ -559,11 +560,11 @@ __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
 // (same instruction sequence: same bits) and runs beta through it.  Per launch: psi twice + marginals + 1/SEG of the alphas twice =
 // 11.2 GB instead of 16.9.  FWDPSI: the forward sweep computes psi from B itself (off the chain) and writes it for the backward
 // sweep — no k_crf_psi pass (B once + psi out instead of B once + psi out + psi in).
-template <int AT, bool FWDPSI>
-__global__ __launch_bounds__(256) void k_smooth_crf_ck(SmoothCRFLaunch L) {
+template <int AT, bool FWDPSI, int NWB>   // NWB waves per workgroup
+__global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   constexpr int SEG = 8;
-  __shared__ double la[4][SEG][64];      // [wave][step][lane] recomputed alpha_t(y)
-  __shared__ double2 lsc[4][SEG][4];     // [wave][step][row] (1/c_t, c_t)
+  __shared__ double la[NWB][SEG][64];    // [wave][step][lane] recomputed alpha_t(y)
+  __shared__ double2 lsc[NWB][SEG][4];   // [wave][step][row] (1/c_t, c_t)
   __shared__ double lth[FWDPSI ? AT : 1][16];  // theta[i][y]: read per segment in the psi phase only (24 registers less held through the chain)
   const int A = L.A, W = L.W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -786,11 +787,20 @@ hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune,
     if (!(tune.crf_flags & 3)) {  // default (round 4): checkpointed alphas; GNX_CRF_FLAGS=4 keeps k_crf_psi as a separate pass
       const bool fwdpsi = !(tune.crf_flags & 4);
       if (!fwdpsi) launch_psi(L, s);
+      // ONE wave per workgroup: the waves of the last, partly filled round spread over the SIMDs one by one instead of four by four
+      // (measured: 1-2 % at 25 000 chr1 haplotypes = 6 250 waves on 4 096 slots, nothing at chr22; scripts/dev/crf_nsweep.py shows the
+      // rounds: 4 096 waves 2.42 ms, 6 144 3.63 ms, 6 250 4.05 ms, 8 192 4.76 ms — a SIMD with three waves in the second round is the
+      // critical path of the launch)
+      static const int nwb_env = [] { const char* e = std::getenv("GNX_CRF_NWB"); return e ? atoi(e) : 1; }();
+      const int nwb = nwb_env == 4 ? 4 : 1;   // (GNX_CRF_NWB=4: the four-wave workgroups of the first version, kept for comparison)
+      const dim3 gridw((unsigned)((L.N + 4 * nwb - 1) / (4 * nwb)));
+#define GNX_CK1(AT_, F_, W_) hipLaunchKernelGGL((k_smooth_crf_ck<AT_, F_, W_>), gridw, dim3(64 * W_), 0, s, L)
 #define GNX_CK(AT_) \
-      if (fwdpsi) hipLaunchKernelGGL((k_smooth_crf_ck<AT_, true>), grid, dim3(64 * waves), 0, s, L); \
-      else hipLaunchKernelGGL((k_smooth_crf_ck<AT_, false>), grid, dim3(64 * waves), 0, s, L);
+      if (fwdpsi) { if (nwb == 1) GNX_CK1(AT_, true, 1); else GNX_CK1(AT_, true, 4); } \
+      else { if (nwb == 1) GNX_CK1(AT_, false, 1); else GNX_CK1(AT_, false, 4); }
       if (L.A <= 8) { GNX_CK(8) } else if (L.A <= 12) { GNX_CK(12) } else { GNX_CK(16) }
 #undef GNX_CK
+#undef GNX_CK1
     } else if (tune.crf_flags & 2) {  // GNX_CRF_FLAGS=2: round 3's kernel (every alpha and scale pair parked), psi from the separate pass
       launch_psi(L, s);
       if (L.A <= 8) hipLaunchKernelGGL((k_smooth_crf_row16<8, false>), grid, dim3(64 * waves), 0, s, L);
