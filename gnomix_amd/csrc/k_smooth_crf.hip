@@ -403,6 +403,20 @@ __device__ __forceinline__ double dpp_ready(double v) {
   asm volatile("s_nop 1" : "+v"(v));
   return v;
 }
+// maximum of a 32-bit value over the 16 lanes of a DPP row (every lane gets it): v_max_u32 with the rotated value as its DPP operand
+__device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
+  uint32_t r;
+  asm("s_nop 1\n\t"
+      "v_max_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+      : "=&v"(r) : "v"(v));
+  return r;
+}
 template <int K>
 __device__ __forceinline__ double ror16(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -672,6 +686,8 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
 #pragma unroll
     for (int i = 0; i < AT; ++i) Eb[i] = (label && i < A) ? L.etrans[yo * A + i] : 0.0;
   }
+  size_t oy = row0 + (size_t)y;
+  asm volatile("" : "+v"(oy));
   double beta = 0.0, psi_next = 0.0;
   double an = 0.0;
   {
@@ -722,15 +738,17 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
         }
         psi_next = bc[k];
         const double m = la[wave][k][lane] * beta * scur.y;
-        double mx = label ? m : -1.0;
-        mx = fmax(mx, ror16<8>(mx));
-        mx = fmax(mx, ror16<4>(mx));
-        mx = fmax(mx, ror16<2>(mx));
-        mx = fmax(mx, ror16<1>(mx));
-        const unsigned long long hit = __ballot(label && m == mx);
+        // arg-max over the row, first maximum wins.  Marginals are >= 0, so float64 order is the order of the bit patterns: the row
+        // maximum of the HIGH words by four 32-bit DPP rotations (v_max_u32 with a row_ror operand: 4 instructions instead of the
+        // 8 moves + 8 v_max_f64 of a float64 butterfly), then the maximum of the LOW words among the lanes that hold it.
+        const uint32_t mh = label ? (uint32_t)__double2hiint(m) : 0u, ml = (uint32_t)__double2loint(m);
+        const uint32_t hmax = row_max_u32(mh);
+        const bool top = label && mh == hmax;
+        const uint32_t lmax = row_max_u32(top ? ml : 0u);
+        const unsigned long long hit = __ballot(top && ml == lmax);
         const int best = __builtin_ctz((unsigned)(hit >> (lane & 48)) & 0xffffu);
         if (active) {
-          const size_t o = row0 + (size_t)t * A + y;
+          const size_t o = oy + (size_t)(t * A);   // (t * A: one scalar multiply; oy = row0 + y is opaque to the optimiser, which otherwise rebuilds ((n W + t) A + y) in 64-bit vector arithmetic every window)
           if (L.proba64) L.proba64[o] = m;
           if (L.proba32) L.proba32[o] = (float)m;
           if (L.labels && y == 0) L.labels[(size_t)nn * W + t] = best;
