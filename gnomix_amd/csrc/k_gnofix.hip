@@ -34,6 +34,9 @@
 //    differ between the two haplotypes", the convergence signature's other half) before, k_gnofix_swap (phasing.py:188-198 applied
 //    once from the final parity) after.  Inside the per-individual kernel they ran at one CU's 25 GB/s.
 //  * The next label change is a find-first-set over a bit mask kept beside the labels (no block barrier per search).
+//  * Where accepted switches come thick (a label change at nearly every window: a chaotic smoother on unstructured haplotypes) the
+//    re-evaluation is LAZY: a switch marks its rows dirty, the scan brings rows up to date only when it reads them (short batches:
+//    one row set per class), the rest at the start of the next sweep.  Same decisions in the same order; see the sweep loop.
 #include "gnx_internal.h"
 #include "gnx_rank.h"
 #include "gnx_exp.h"
