@@ -108,7 +108,7 @@ static void read_tune(gnx_tune& t) {
   if (const char* e = std::getenv("GNX_SM_TUNE")) std::sscanf(e, "%d,%d", &t.smf_rpl, &t.smf_nw);
   if (const char* e = std::getenv("GNX_CRF_FLAGS")) t.crf_flags = atoi(e);
   if (const char* e = std::getenv("GNX_LDS_PAD")) std::sscanf(e, "%d,%d", &t.lr_lds_pad, &t.sm_lds_pad);
-  if (const char* e = std::getenv("GNX_CRF_IMPL")) t.crf_impl = !std::strcmp(e, "scan") ? 1 : !std::strcmp(e, "row") ? 2 : !std::strcmp(e, "lanes") ? 3 : !std::strcmp(e, "quad") ? 4 : 0;
+  if (const char* e = std::getenv("GNX_CRF_IMPL")) t.crf_impl = !std::strcmp(e, "scan") ? 1 : !std::strcmp(e, "row") ? 2 : !std::strcmp(e, "lanes") ? 3 : !std::strcmp(e, "quad") ? 4 : !std::strcmp(e, "mm") ? 5 : 0;
   t.forest_threads = geti("GNX_FOREST_T", 0);
   t.forest_wrun = geti("GNX_FOREST_WRUN", 0);
   t.forest_halves = geti("GNX_FOREST_H", 0);

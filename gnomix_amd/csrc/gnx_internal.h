@@ -236,6 +236,7 @@ struct SmoothCRFLaunch {
 };
 
 #ifdef GNX_EXPERIMENTS
+hipError_t gnx_launch_smooth_crf_mm(const SmoothCRFLaunch& L, hipStream_t s);   // scripts/dev/rejected/k_smooth_crf_mm.hip: products on the float64 MFMA, 16 haplotypes per wave, A <= 16
 hipError_t gnx_launch_smooth_crf_quad(const SmoothCRFLaunch& L, hipStream_t s);  // scripts/dev/rejected/k_smooth_crf_quad.hip: four lanes per haplotype, A <= 12
 #endif
 

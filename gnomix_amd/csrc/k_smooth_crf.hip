@@ -388,15 +388,111 @@ template <int I>
 __device__ __forceinline__ void fmac_bcast(double& acc, double v, double c) {  // acc += (lane I of this row's v) * c
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(c), "n"(I));
 }
-template <int AT, int I = 0>
-__device__ __forceinline__ void row_dot(double& acc, double v, const double (&coef)[AT]) {
-  fmac_bcast<I>(acc, v, coef[I]);
-  if constexpr (I + 1 < AT) row_dot<AT, I + 1>(acc, v, coef);
+// The AT multiply-adds of a row product as ONE asm statement: between separate statements the compiler (which cannot see into
+// them) puts a wait state after every float64 DPP operation — ~100 s_nop per window, each an issue slot of the wave's in-order
+// stream.  The chain needs none: the accumulator is not the DPP source, and plain VALU read-after-write is interlocked in hardware.
+// (scripts/dev/f64_rate_probe.hip: v_fmac_f64_dpp issues at the full float64 rate, 4 cycles, 12 cycles dependent — like v_fma_f64.)
+template <int AT>
+__device__ __forceinline__ void row_dot(double& acc, double v, const double (&c)[AT]) {
+  static_assert(AT == 8 || AT == 12 || AT == 16, "row widths the launchers use");
+  if constexpr (AT == 8) {
+    asm(
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+  } else if constexpr (AT == 12) {
+    asm(
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]), "v"(c[11]));
+  } else {
+    asm(
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]), "v"(c[11]),
+                    "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+  }
 }
-template <int AT, int I = 0>
+template <int AT>
 __device__ __forceinline__ void row_sum(double& acc, double v) {
-  fmac_bcast<I>(acc, v, 1.0);
-  if constexpr (I + 1 < AT) row_sum<AT, I + 1>(acc, v);
+  static_assert(AT == 8 || AT == 12 || AT == 16, "row widths the launchers use");
+  const double one = 1.0;   // (the DPP encoding takes registers only)
+  if constexpr (AT == 8) {
+    asm(
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(v), "v"(one));
+  } else if constexpr (AT == 12) {
+    asm(
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(v), "v"(one));
+  } else {
+    asm(
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(v), "v"(one));
+  }
 }
 // gfx9 wants two wait states between the VALU write of a VGPR and a DPP read of it; inline asm is opaque to the hazard recogniser
 __device__ __forceinline__ double dpp_ready(double v) {
@@ -610,9 +706,9 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   auto loadPsi = [&](int t) -> double { const double v = L.psi[row0 + (size_t)t * A + yl]; return label ? v : 0.0; };
   // one step of the scaled forward recurrence: alpha_t = psi_t * (alpha_{t-1} . E) / c_t; returns alpha_t, sets (1/c_t, c_t).
   // The scales only keep the numbers in range: ANY positive c_t give the same marginals as long as both sweeps use the same ones and
-  // the last window's is the true row sum (then prod c_t = Z).  The kernel is bound by its float64 DPP multiply-adds (8 cycles each:
-  // a 3 072-wave round takes 1431 windows x 3 waves x ~1 180 cycles), and a row sum is 12 of the ~84 per window: the sum and its
-  // reciprocal are taken every (norm_mask + 1)-th window only (and at the last one), c_t = 1 in between.  gnx_build_crf picks
+  // the last window's is the true row sum (then prod c_t = Z).  A row sum is 12 dependent DPP multiply-adds, a reciprocal with two
+  // refinement steps and a multiply on the critical path of two of the three sweeps: the sum and its reciprocal are taken every
+  // (norm_mask + 1)-th window only (and at the last one), c_t = 1 in between (config 5a: 5.19 -> 4.42 ms at every 4th).  gnx_build_crf picks
   // 8, 4, 2 or 1 windows from the weights' range so that the unscaled stretch stays inside float64 (8 for any trained model).
   const int norm_mask = L.norm_mask;
   auto fwd_step = [&](double a_prev, double psi, int t, double& sc, double& sum) -> double {
@@ -796,6 +892,8 @@ hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune,
   // labels (one lane per haplotype, LDS ring), =lanes the shuffle kernel (A lanes per haplotype), which also serves 17..32 labels.
   const int impl = tune.crf_impl;  // 0 auto, 1 scan, 2 row, 3 lanes, 4 quad
 #ifdef GNX_EXPERIMENTS
+  // the row products on the float64 matrix cores (scripts/dev/rejected/k_smooth_crf_mm.hip): no faster, see its header
+  if (L.A <= 16 && impl == 5) return gnx_launch_smooth_crf_mm(L, s);
   // four lanes per haplotype (scripts/dev/rejected/k_smooth_crf_quad.hip): correct, 5 % slower than the row kernel at chr1 / A = 12
   if (L.A <= 12 && impl == 4) return gnx_launch_smooth_crf_quad(L, s);
 #endif

@@ -4,7 +4,7 @@
 // sklearn_crfsuite.CRF.predict_marginals), same arithmetic as k_smooth_crf.hip (scaled forward-backward, marginals alpha beta c).
 //
 // Why another layout.  k_smooth_crf_ck puts one haplotype on a 16-lane DPP row, one label per lane: every cross-label sum is a chain
-// of v_fmac_f64_dpp row_newbcast — the only DPP form float64 has — which issue at HALF the float64 rate (8 cycles), on rows that are
+// of v_fmac_f64_dpp row_newbcast — the only DPP form float64 has — which were thought to issue at HALF the float64 rate (scripts/dev/f64_rate_probe.hip later measured the full rate), on rows that are
 // a quarter padding at 12 labels.  The counters say the kernel is bound by exactly those instructions (VALU-busy, HBM at 3 TB/s),
 // ~250 VALU cycles per haplotype and window.  Here a haplotype is a QUAD of lanes and a lane owns LPL = ceil(A/4) consecutive labels:
 //   * a cross-label product is LPL x 4 LPL plain v_fma_f64 per lane (full rate, no padding lanes) against coefficients in registers,
