@@ -16,46 +16,64 @@ __device__ __forceinline__ double gnx_sconst() {  // a float64 constant in a sca
   asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"(LO), "n"(HI));
   return __hiloint2double((int)hi, (int)lo);
 }
-template <uint32_t LO, uint32_t HI>
-__device__ __forceinline__ double gnx_fma_sc(double a, double b) {  // a * b + constant, the constant as the instruction's scalar operand
+// N arguments at once: every constant is moved into its scalar pair ONCE for all of them (1 / N of the scalar instructions per
+// result — they are issue slots of the wave's in-order stream like any other) and the N dependent chains interleave.
+template <uint32_t LO, uint32_t HI, int N>
+__device__ __forceinline__ void gnx_fma_sc(double (&a)[N], const double (&b)[N]) {  // a = a * b + constant (the instruction's scalar operand)
   const double c = gnx_sconst<LO, HI>();
-  double d;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
-  return d;
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "s"(c));
 }
-template <uint32_t LO, uint32_t HI>
-__device__ __forceinline__ double gnx_fma_cs(double a, double b) {  // a * constant + b
+template <uint32_t LO, uint32_t HI, int N>
+__device__ __forceinline__ void gnx_fma_cs(double (&r)[N], const double (&n)[N]) {  // r = n * constant + r
   const double c = gnx_sconst<LO, HI>();
-  double d;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(c), "v"(b));
-  return d;
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %0" : "+v"(r[i]) : "v"(n[i]), "s"(c));
 }
-__device__ __forceinline__ double gnx_exp_sc(double x) {
-  double n;
+template <int N>
+__device__ __forceinline__ void gnx_exp_scN(double (&x)[N]) {  // x[i] = exp(x[i])
+  double n[N], p[N];
   {
     const double c = gnx_sconst<0x652b82feu, 0x3ff71547u>();  // 1 / ln 2
-    asm("v_mul_f64 %0, %1, %2" : "=v"(n) : "v"(x), "s"(c));
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm("v_mul_f64 %0, %1, %2" : "=v"(n[i]) : "v"(x[i]), "s"(c));
   }
-  n = rint(n);
-  double r = gnx_fma_cs<0xfee00000u, 0xbfe62e42u>(n, x);   // -ln 2, high part
-  r = gnx_fma_cs<0x35793c76u, 0xbdea39efu>(n, r);          // -ln 2, low part
-  double p = gnx_fma_sc<0xeff8d898u, 0x3e21eed8u>(gnx_sconst<0x13a86d09u, 0x3de61246u>(), r);  // 1/13! r + 1/12!
-  p = gnx_fma_sc<0x67f544e4u, 0x3e5ae645u>(p, r);          // 1/11!
-  p = gnx_fma_sc<0xb7789f5cu, 0x3e927e4fu>(p, r);          // 1/10!
-  p = gnx_fma_sc<0xa556c734u, 0x3ec71de3u>(p, r);          // 1/9!
-  p = gnx_fma_sc<0x1a01a01au, 0x3efa01a0u>(p, r);          // 1/8!
-  p = gnx_fma_sc<0x1a01a01au, 0x3f2a01a0u>(p, r);          // 1/7!
-  p = gnx_fma_sc<0x16c16c17u, 0x3f56c16cu>(p, r);          // 1/6!
-  p = gnx_fma_sc<0x11111111u, 0x3f811111u>(p, r);          // 1/5!
-  p = gnx_fma_sc<0x55555555u, 0x3fa55555u>(p, r);          // 1/4!
-  p = gnx_fma_sc<0x55555555u, 0x3fc55555u>(p, r);          // 1/3!
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)n);
+#pragma unroll
+  for (int i = 0; i < N; ++i) n[i] = rint(n[i]);
+  gnx_fma_cs<0xfee00000u, 0xbfe62e42u, N>(x, n);   // r = x - n ln 2: high part (fdlibm's split: n ln2_hi is exact)
+  gnx_fma_cs<0x35793c76u, 0xbdea39efu, N>(x, n);   // low part
+  {
+    const double c = gnx_sconst<0x13a86d09u, 0x3de61246u>();  // 1/13!
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = c;
+  }
+  gnx_fma_sc<0xeff8d898u, 0x3e21eed8u, N>(p, x);   // 1/12!
+  gnx_fma_sc<0x67f544e4u, 0x3e5ae645u, N>(p, x);   // 1/11!
+  gnx_fma_sc<0xb7789f5cu, 0x3e927e4fu, N>(p, x);   // 1/10!
+  gnx_fma_sc<0xa556c734u, 0x3ec71de3u, N>(p, x);   // 1/9!
+  gnx_fma_sc<0x1a01a01au, 0x3efa01a0u, N>(p, x);   // 1/8!
+  gnx_fma_sc<0x1a01a01au, 0x3f2a01a0u, N>(p, x);   // 1/7!
+  gnx_fma_sc<0x16c16c17u, 0x3f56c16cu, N>(p, x);   // 1/6!
+  gnx_fma_sc<0x11111111u, 0x3f811111u, N>(p, x);   // 1/5!
+  gnx_fma_sc<0x55555555u, 0x3fa55555u, N>(p, x);   // 1/4!
+  gnx_fma_sc<0x55555555u, 0x3fc55555u, N>(p, x);   // 1/3!
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    p[i] = fma(p[i], x[i], 0.5);
+    p[i] = fma(p[i], x[i], 1.0);
+    p[i] = fma(p[i], x[i], 1.0);
+    x[i] = __builtin_ldexp(p[i], (int)n[i]);
+  }
+}
+__device__ __forceinline__ double gnx_exp_sc(double x) {
+  double v[1] = {x};
+  gnx_exp_scN<1>(v);
+  return v[0];
 }
 #else   // host pass: never called
 __device__ inline double gnx_exp_sc(double x) { return x; }
+template <int N>
+__device__ inline void gnx_exp_scN(double (&)[N]) {}
 #endif
 
 // xgboost's Softmax exponentiates a float32 margin difference with expf; glibc's expf is correctly rounded in all but a vanishing

@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
 // sweep — no k_crf_psi pass (B once + psi out instead of B once + psi out + psi in).
 template <int AT, bool FWDPSI, int NWB>   // NWB waves per workgroup
 __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
-  constexpr int SEG = 8;
+  constexpr int SEG = 8, EXPW = 4;
   __shared__ double la[NWB][SEG][64];    // [wave][step][lane] recomputed alpha_t(y)
   __shared__ double2 lsc[NWB][SEG][4];   // [wave][step][row] (1/c_t, c_t)
   __shared__ double lth[FWDPSI ? AT : 1][16];  // theta[i][y]: read per segment in the psi phase only (24 registers less held through the chain)
@@ -744,8 +744,10 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
     double bc[SEG];
 #pragma unroll
     for (int k = 0; k < SEG; ++k) bc[k] = bn[k];
+    if constexpr (!FWDPSI) {
 #pragma unroll
-    for (int k = 0; k < SEG; ++k) bn[k] = FWDPSI ? loadB(clampt(t0 + SEG + k)) : loadPsi(clampt(t0 + SEG + k));
+      for (int k = 0; k < SEG; ++k) bn[k] = loadPsi(clampt(t0 + SEG + k));
+    }
     if constexpr (FWDPSI) {  // psi of the whole segment first: nothing of it is on the chain
       double Th[AT];
       {
@@ -755,12 +757,24 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
         for (int i = 0; i < AT; ++i) Th[i] = lth[i][yo];
       }
 #pragma unroll
-      for (int k = 0; k < SEG; ++k) {
-        double sdot = 0.0;
-        row_dot<AT>(sdot, dpp_ready(bc[k]), Th);
-        bc[k] = label ? gnx_exp_sc(sdot) : 0.0;
-        if (active && t0 + k < W) L.psi[row0 + (size_t)(t0 + k) * A + y] = bc[k];
+      for (int k0 = 0; k0 < SEG; k0 += EXPW) {   // EXPW windows at a time: the exponential's constants are moved into scalar pairs once for all of them
+        double sd[EXPW];
+#pragma unroll
+        for (int i = 0; i < EXPW; ++i) {
+          sd[i] = 0.0;
+          row_dot<AT>(sd[i], dpp_ready(bc[k0 + i]), Th);
+        }
+        gnx_exp_scN<EXPW>(sd);
+#pragma unroll
+        for (int i = 0; i < EXPW; ++i) {
+          bc[k0 + i] = label ? sd[i] : 0.0;
+          if (active && t0 + k0 + i < W) L.psi[row0 + (size_t)(t0 + k0 + i) * A + y] = bc[k0 + i];
+        }
       }
+    }
+    if constexpr (FWDPSI) {  // the next segment's B: requested AFTER the psi phase (its registers are free in there) — the 8 chain steps
+#pragma unroll                // that follow are several microseconds, more than the loads need
+      for (int k = 0; k < SEG; ++k) bn[k] = loadB(clampt(t0 + SEG + k));
     }
 #pragma unroll
     for (int k = 0; k < SEG; ++k) {

@@ -47,11 +47,11 @@ int main(void) {
 
 def test_exp_sc_constants_and_accuracy(tmp_path):
     hdr = open(os.path.join(ROOT, "gnomix_amd", "csrc", "gnx_exp.h")).read()
-    body = hdr[hdr.index("double gnx_exp_sc(double x)"):hdr.index("#else")]
-    consts = re.findall(r"<0x([0-9a-fA-F]{8})u, 0x([0-9a-fA-F]{8})u>", body)
-    # use order in the function: 1/ln2, -ln2_hi, -ln2_lo, then (1/12! is the addend of the first polynomial step, 1/13! its multiplicand)
+    body = hdr[hdr.index("void gnx_exp_scN(double (&x)[N])"):hdr.index("__device__ __forceinline__ double gnx_exp_sc(double x)")]
+    consts = re.findall(r"<0x([0-9a-fA-F]{8})u, 0x([0-9a-fA-F]{8})u", body)
+    # in the order the function uses them: 1/ln2, -ln2_hi, -ln2_lo, 1/13!, 1/12!, .., 1/3!
     assert len(consts) == 14
-    order = [consts[0], consts[1], consts[2], consts[4], consts[3]] + consts[5:]
+    order = consts
     table = ", ".join("{0x%su, 0x%su}" % c for c in order)
     src = tmp_path / "exp_sc.c"
     src.write_text(C_SRC % (table, len(order)))
