@@ -711,14 +711,19 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   // (norm_mask + 1)-th window only (and at the last one), c_t = 1 in between (config 5a: 5.19 -> 4.42 ms at every 4th).  gnx_build_crf picks
   // 8, 4, 2 or 1 windows from the weights' range so that the unscaled stretch stays inside float64 (8 for any trained model).
   const int norm_mask = L.norm_mask;
-  auto fwd_step = [&](double a_prev, double psi, int t, double& sc, double& sum) -> double {
+  auto norm_at = [&](int t) { return (t & norm_mask) == norm_mask || t == W - 1; };
+  // a segment whose windows need no checks: all inside the chain, not the first, the scale exactly at its last window (interval 8 = SEG)
+  auto plain_seg = [&](int t0) { return norm_mask == SEG - 1 && t0 > 0 && t0 + SEG < W; };
+  // (first / norm are wave-uniform; the interior segments pass compile-time constants: the window's checks cost issue slots like
+  //  everything else — scripts/dev/f64_rate_probe.hip, DESIGN.md 4.3: the kernel is bound by the length of its instruction stream)
+  auto fwd_step = [&](double a_prev, double psi, bool first, bool norm, double& sc, double& sum) -> double {
     double v = psi;
-    if (t != 0) {
+    if (!first) {
       double acc = 0.0;
       row_dot<AT>(acc, dpp_ready(a_prev), Ef);
       v = acc * psi;
     }
-    if ((t & norm_mask) != norm_mask && t != W - 1) {   // wave-uniform
+    if (!norm) {
       sc = 1.0;
       sum = 1.0;
       return v;
@@ -741,6 +746,7 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   for (int k = 0; k < SEG; ++k) bn[k] = FWDPSI ? loadB(clampt(k)) : loadPsi(clampt(k));
   for (int sg = 0; sg < NSEG; ++sg) {
     const int t0 = sg * SEG;
+    const bool plain = plain_seg(t0);
     double bc[SEG];
 #pragma unroll
     for (int k = 0; k < SEG; ++k) bc[k] = bn[k];
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
 #pragma unroll
         for (int i = 0; i < EXPW; ++i) {
           bc[k0 + i] = label ? sd[i] : 0.0;
-          if (active && t0 + k0 + i < W) L.psi[row0 + (size_t)(t0 + k0 + i) * A + y] = bc[k0 + i];
+          if (active && (plain || t0 + k0 + i < W)) L.psi[row0 + (size_t)(t0 + k0 + i) * A + y] = bc[k0 + i];
         }
       }
     }
@@ -776,12 +782,20 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
 #pragma unroll                // that follow are several microseconds, more than the loads need
       for (int k = 0; k < SEG; ++k) bn[k] = loadB(clampt(t0 + SEG + k));
     }
+    if (plain) {
 #pragma unroll
-    for (int k = 0; k < SEG; ++k) {
-      const int t = t0 + k;
-      if (t < W) {
+      for (int k = 0; k < SEG; ++k) {
         double sc, sum;
-        a_prev = fwd_step(a_prev, bc[k], t, sc, sum);
+        a_prev = fwd_step(a_prev, bc[k], false, k == SEG - 1, sc, sum);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SEG; ++k) {
+        const int t = t0 + k;
+        if (t < W) {
+          double sc, sum;
+          a_prev = fwd_step(a_prev, bc[k], t == 0, norm_at(t), sc, sum);
+        }
       }
     }
     if (active) ck[(size_t)sg * A + y] = a_prev;
@@ -819,50 +833,69 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
       const double v = ck[(size_t)(sp > 0 ? sp - 1 : 0) * A + yl];  // unconditional; dropped for the first segment / padding lanes
       an = (label && sp > 0) ? v : 0.0;
     }
+    const bool plain = plain_seg(t0);
+    if (plain) {
 #pragma unroll
-    for (int k = 0; k < SEG; ++k) {
-      const int t = t0 + k;
-      if (t < W) {
+      for (int k = 0; k < SEG; ++k) {
         double sc, sum;
-        a_in = fwd_step(a_in, bc[k], t, sc, sum);
+        a_in = fwd_step(a_in, bc[k], false, k == SEG - 1, sc, sum);
         la[wave][k][lane] = a_in;
-        if (y == 0) lsc[wave][k][row] = make_double2(sc, sum);
+        if (k == SEG - 1 && y == 0) lsc[wave][0][row] = make_double2(sc, sum);   // (the segment's one scale pair; the others are (1, 1))
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SEG; ++k) {
+        const int t = t0 + k;
+        if (t < W) {
+          double sc, sum;
+          a_in = fwd_step(a_in, bc[k], t == 0, norm_at(t), sc, sum);
+          la[wave][k][lane] = a_in;
+          if (y == 0) lsc[wave][k][row] = make_double2(sc, sum);
+        }
       }
     }
     // (wave-private LDS: a lane reads back its own alpha; the row's pair is written by its lane 0 — LDS operations of a wave run in order)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int k = SEG - 1; k >= 0; --k) {
+    // one window of the backward sweep; `chk`: the window may lie beyond W - 1 or be W - 1 itself; (sx, sy) = its (1/c_t, c_t)
+    auto beta_step = [&](int k, bool chk, double sx, double sy) {
       const int t = t0 + k;
-      if (t < W) {
+      if (chk && !(t < W)) return;
+      if (!chk || t < W - 1) {
+        double acc = 0.0;
+        row_dot<AT>(acc, dpp_ready(psi_next * beta), Eb);
+        beta = acc * sx;
+      } else {
+        beta = sx;
+      }
+      psi_next = bc[k];
+      const double m = la[wave][k][lane] * beta * sy;
+      // arg-max over the row, first maximum wins.  Marginals are >= 0, so float64 order is the order of the bit patterns: the row
+      // maximum of the HIGH words by four 32-bit DPP rotations (v_max_u32 with a row_ror operand: 4 instructions instead of the
+      // 8 moves + 8 v_max_f64 of a float64 butterfly), then the maximum of the LOW words among the lanes that hold it.
+      const uint32_t mh = label ? (uint32_t)__double2hiint(m) : 0u, ml = (uint32_t)__double2loint(m);
+      const uint32_t hmax = row_max_u32(mh);
+      const bool top = label && mh == hmax;
+      const uint32_t lmax = row_max_u32(top ? ml : 0u);
+      const unsigned long long hit = __ballot(top && ml == lmax);
+      const int best = __builtin_ctz((unsigned)(hit >> (lane & 48)) & 0xffffu);
+      if (active) {
+        const size_t o = oy + (size_t)(t * A);   // (t * A: one scalar multiply; oy = row0 + y is opaque to the optimiser, which otherwise rebuilds ((n W + t) A + y) in 64-bit vector arithmetic every window)
+        if (L.proba64) L.proba64[o] = m;
+        if (L.proba32) L.proba32[o] = (float)m;
+        if (L.labels && y == 0) L.labels[(size_t)nn * W + t] = best;
+      }
+    };
+    if (plain) {
+      const double2 s7 = lsc[wave][0][row];
+#pragma unroll
+      for (int k = SEG - 1; k >= 0; --k) beta_step(k, false, k == SEG - 1 ? s7.x : 1.0, k == SEG - 1 ? s7.y : 1.0);
+    } else {
+#pragma unroll
+      for (int k = SEG - 1; k >= 0; --k) {
         const double2 scur = lsc[wave][k][row];
-        const double sct = scur.x;
-        if (t < W - 1) {
-          double acc = 0.0;
-          row_dot<AT>(acc, dpp_ready(psi_next * beta), Eb);
-          beta = acc * sct;
-        } else {
-          beta = sct;
-        }
-        psi_next = bc[k];
-        const double m = la[wave][k][lane] * beta * scur.y;
-        // arg-max over the row, first maximum wins.  Marginals are >= 0, so float64 order is the order of the bit patterns: the row
-        // maximum of the HIGH words by four 32-bit DPP rotations (v_max_u32 with a row_ror operand: 4 instructions instead of the
-        // 8 moves + 8 v_max_f64 of a float64 butterfly), then the maximum of the LOW words among the lanes that hold it.
-        const uint32_t mh = label ? (uint32_t)__double2hiint(m) : 0u, ml = (uint32_t)__double2loint(m);
-        const uint32_t hmax = row_max_u32(mh);
-        const bool top = label && mh == hmax;
-        const uint32_t lmax = row_max_u32(top ? ml : 0u);
-        const unsigned long long hit = __ballot(top && ml == lmax);
-        const int best = __builtin_ctz((unsigned)(hit >> (lane & 48)) & 0xffffu);
-        if (active) {
-          const size_t o = oy + (size_t)(t * A);   // (t * A: one scalar multiply; oy = row0 + y is opaque to the optimiser, which otherwise rebuilds ((n W + t) A + y) in 64-bit vector arithmetic every window)
-          if (L.proba64) L.proba64[o] = m;
-          if (L.proba32) L.proba32[o] = (float)m;
-          if (L.labels && y == 0) L.labels[(size_t)nn * W + t] = best;
-        }
+        beta_step(k, true, scur.x, scur.y);
       }
     }
     __builtin_amdgcn_wave_barrier();
