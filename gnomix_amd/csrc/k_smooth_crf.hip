@@ -812,6 +812,8 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   }
   size_t oy = row0 + (size_t)y;
   asm volatile("" : "+v"(oy));
+  size_t rowy = row0 + (size_t)yl;
+  asm volatile("" : "+v"(rowy));
   double beta = 0.0, psi_next = 0.0;
   double an = 0.0;
   {
@@ -828,8 +830,11 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
     double a_in = an;
     {
       const int sp = sg > 0 ? sg - 1 : 0;
+      {  // segment sp always lies inside the chain: one per-lane address and scalar offsets k * A — no clamp, no 64-bit multiply per window
+        const double* pp = L.psi + (rowy + (size_t)(sp * SEG * A));
 #pragma unroll
-      for (int k = 0; k < SEG; ++k) bn[k] = loadPsi(clampt(sp * SEG + k));
+        for (int k = 0; k < SEG; ++k) { const double v = pp[k * A]; bn[k] = label ? v : 0.0; }
+      }
       const double v = ck[(size_t)(sp > 0 ? sp - 1 : 0) * A + yl];  // unconditional; dropped for the first segment / padding lanes
       an = (label && sp > 0) ? v : 0.0;
     }
