@@ -123,6 +123,32 @@ def test_random_gnofix_vs_oracle(oracle, seed):
         assert int(nsw[i]) == ns, (seed, i)
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_crf_vs_oracle(oracle, seed):
+    """random CRF-smoother geometries: label counts on both sides of the kernels' row widths (8 / 12 / 16, the 17+ kernel), chain lengths
+    around the segment length (8) and its multiples, weight ranges that select every forward-scale interval (8, 4, 2, 1 windows),
+    float32 and float64 base probabilities"""
+    import gnomix_amd
+    rng = np.random.RandomState(9000 + seed)
+    A = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 20]))
+    W = int(rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 31, 64, 65, 100, 257, 1000]))
+    N = int(rng.choice([1, 3, 4, 5, 17, 64, 130]))
+    scale = float(rng.choice([0.3, 1.0, 3.0, 9.0, 25.0]))
+    state = rng.standard_normal((A, A)) * scale
+    trans = rng.standard_normal((A, A)) * scale * float(rng.choice([0.2, 1.0]))
+    B = rng.dirichlet(np.ones(A) * float(rng.choice([0.2, 1.0, 5.0])), size=(N, W))
+    if rng.randint(2):
+        B = B.astype(np.float32)
+    d = gnomix_amd.GnxModelData(C=W * 10 + 3, M=10, A=A, S=75, context=5, smooth_kind="crf", crf_state=state, crf_trans=trans)
+    dev = gnomix_amd.DeviceModel(d)
+    p_ref, l_ref = oracle.smooth_crf(B.astype(np.float64), state, trans)
+    p, lab = dev.smooth_predict(B)
+    assert np.isfinite(p).all() and np.max(np.abs(p - p_ref)) < 1e-10, seed
+    top = np.sort(p_ref, -1)
+    clear = top[..., -1] - top[..., -2] > 1e-9
+    assert np.array_equal(lab[clear], l_ref[clear]), seed
+
+
 @pytest.mark.parametrize("A,S,W", [(7, 75, 310), (5, 31, 260), (12, 75, 230)])
 def test_gnofix_where_switches_come_thick(oracle, A, S, W):
     """a chaotic smoother on unstructured haplotypes: a label change at nearly every window and dozens of accepted switches per sweep,
