@@ -740,6 +740,8 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   };
 
   // ---- forward: alpha parked once per segment ----
+  size_t rowyf = row0 + (size_t)yl;
+  asm volatile("" : "+v"(rowyf));
   double a_prev = 0.0;
   double bn[SEG];
 #pragma unroll
@@ -779,8 +781,21 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
       }
     }
     if constexpr (FWDPSI) {  // the next segment's B: requested AFTER the psi phase (its registers are free in there) — the 8 chain steps
-#pragma unroll                // that follow are several microseconds, more than the loads need
-      for (int k = 0; k < SEG; ++k) bn[k] = loadB(clampt(t0 + SEG + k));
+      if (t0 + 2 * SEG <= W) {  // that follow are several microseconds, more than the loads need.  Inside the chain: no clamps
+        const size_t e0 = rowyf + (size_t)((t0 + SEG) * A);
+        if (L.b_is_f64) {
+          const double* pp = reinterpret_cast<const double*>(L.B) + e0;
+#pragma unroll
+          for (int k = 0; k < SEG; ++k) { const double v = pp[k * A]; bn[k] = label ? v : 0.0; }
+        } else {
+          const float* pp = reinterpret_cast<const float*>(L.B) + e0;
+#pragma unroll
+          for (int k = 0; k < SEG; ++k) { const double v = (double)pp[k * A]; bn[k] = label ? v : 0.0; }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < SEG; ++k) bn[k] = loadB(clampt(t0 + SEG + k));
+      }
     }
     if (plain) {
 #pragma unroll
