@@ -879,6 +879,7 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // one window of the backward sweep; `chk`: the window may lie beyond W - 1 or be W - 1 itself; (sx, sy) = its (1/c_t, c_t)
+    unsigned long long hits[SEG];   // plain segments: the windows' arg-max ballots, turned into labels and stored once per segment
     auto beta_step = [&](int k, bool chk, double sx, double sy) {
       const int t = t0 + k;
       if (chk && !(t < W)) return;
@@ -899,18 +900,26 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
       const bool top = label && mh == hmax;
       const uint32_t lmax = row_max_u32(top ? ml : 0u);
       const unsigned long long hit = __ballot(top && ml == lmax);
-      const int best = __builtin_ctz((unsigned)(hit >> (lane & 48)) & 0xffffu);
+      if (!chk) hits[k] = hit;
       if (active) {
         const size_t o = oy + (size_t)(t * A);   // (t * A: one scalar multiply; oy = row0 + y is opaque to the optimiser, which otherwise rebuilds ((n W + t) A + y) in 64-bit vector arithmetic every window)
         if (L.proba64) L.proba64[o] = m;
         if (L.proba32) L.proba32[o] = (float)m;
-        if (L.labels && y == 0) L.labels[(size_t)nn * W + t] = best;
+        if (chk && L.labels && y == 0) L.labels[(size_t)nn * W + t] = __builtin_ctz((unsigned)(hit >> (lane & 48)) & 0xffffu);
       }
     };
     if (plain) {
       const double2 s7 = lsc[wave][0][row];
 #pragma unroll
       for (int k = SEG - 1; k >= 0; --k) beta_step(k, false, k == SEG - 1 ? s7.x : 1.0, k == SEG - 1 ? s7.y : 1.0);
+      if (L.labels && active && y == 0) {   // the segment's 8 labels of this row: two 16-byte stores instead of eight masked 4-byte ones
+        int lb[SEG];
+#pragma unroll
+        for (int k = 0; k < SEG; ++k) lb[k] = __builtin_ctz((unsigned)(hits[k] >> (lane & 48)) & 0xffffu);
+        int* lp = L.labels + ((size_t)nn * W + t0);
+#pragma unroll
+        for (int k = 0; k < SEG; ++k) lp[k] = lb[k];
+      }
     } else {
 #pragma unroll
       for (int k = SEG - 1; k >= 0; --k) {
