@@ -14,7 +14,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 12
+GNX_ABI_VERSION = 13
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
@@ -128,6 +128,7 @@ SYMBOLS = {
     "gnx_unpack_x_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _I64]),
     "gnx_infer_packed": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP, _VP]),
     "gnx_infer_packed_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP, _VP]),
+    "gnx_base_predict_packed_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP]),
     "gnx_smooth_rows": (C.c_int, [_VP, _VP, _I64, _VP]),
     "gnx_calibrate_rows": (C.c_int, [_VP, _VP, _I, _I64, _VP]),
     "gnx_gnofix": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),

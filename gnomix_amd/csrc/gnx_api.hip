@@ -103,6 +103,7 @@ static void read_tune(gnx_tune& t) {
   t.lr_w512 = geti("GNX_LR_W512", 0);
   t.lr_ws_pw = geti("GNX_LR_WS_PW", 2);
   t.lr_nbuf = geti("GNX_LR_NBUF", 0);
+  t.lr_p2 = geti("GNX_LR_P2", 1);
   t.sm_nw = geti("GNX_SM_NW", 0);
   t.sm_pair = geti("GNX_SM_PAIR", 1);
   if (const char* e = std::getenv("GNX_SM_TUNE")) std::sscanf(e, "%d,%d", &t.smf_rpl, &t.smf_nw);
@@ -585,17 +586,66 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
   return fail(ctx, GNX_ESTATE, "model has no smoother");
 }
 
-int gnx_infer_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx, float* d_p32, double* d_p64, int32_t* d_lab) {
+// ---- packed (2-bit) input: the 2-bit-native logistic pass where the model has its planes, otherwise widen + the int8 kernels ----
+static bool lr_p2_usable(const gnx_model* m) {
+  return m->info.base_kind == GNX_BASE_LOGISTIC && m->lr_i8 && m->lr.V2 && m->ctx->tune.lr_p2 != 0;
+}
+
+int gnx_base_predict_packed_dev(gnx_model* m, const uint8_t* dP, int64_t N, int64_t ldp, float* d_b32, double* d_b64) {
   if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  const int64_t C = m->info.C, rowb = (C + 3) / 4;
+  if (N < 0 || ldp < rowb || (N > 0 && !dP)) return fail(ctx, GNX_EINVAL, "base_predict_packed: bad P / N / ldp");
+  if (N == 0 || (!d_b32 && !d_b64)) return GNX_OK;
+  if (lr_p2_usable(m)) {
+    // the kernel fetches 64-byte runs unconditionally: only the last row could read past the matrix
+    const size_t need = (size_t)C + 128;
+    if (ctx->ws_lastrow.cap < need) {
+      int rc = ws_reserve(ctx, ctx->ws_lastrow, need);
+      if (rc != GNX_OK) return rc;
+      HIPCHK(ctx, hipMemsetAsync(ctx->ws_lastrow.p, 0, ctx->ws_lastrow.cap, ctx->stream));  // the int8 pass counts on a zero tail
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws_lastrow.p, 0, (size_t)rowb + 128, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lastrow.p, dP + (N - 1) * ldp, (size_t)rowb, hipMemcpyDeviceToDevice, ctx->stream));
+    BaseLRLaunch L{};
+    L.X = reinterpret_cast<const int8_t*>(dP);
+    L.last_row = (const int8_t*)ctx->ws_lastrow.p;
+    L.N = N; L.ldx = ldp; L.d = m->lr;
+    L.h_win_chunk0 = m->lr_h_win_run0.data(); L.h_win_chunk1 = m->lr_h_win_run1.data();
+    L.W = (int32_t)m->info.W; L.A = m->info.A;
+    L.b32 = d_b32; L.b64 = d_b64;
+    ProfScope ps(ctx, GNX_K_BASE_LOGISTIC);
+    const hipError_t e = gnx_launch_base_logistic_p2(L, ctx->n_cu, ctx->tune, ctx->stream);
+    if (e != hipErrorNotSupported) {
+      HIPCHK(ctx, e);
+      return GNX_OK;
+    }
+  }
+  const int64_t ldx = ((C + 15) / 16) * 16;
+  int rc = ws_reserve(ctx, ctx->ws_xu, (size_t)N * ldx + 256);
+  if (rc != GNX_OK) return rc;
+  HIPCHK(ctx, gnx_launch_unpack2(dP, N, ldp, C, (int8_t*)ctx->ws_xu.p, ldx, ctx->stream));
+  return gnx_base_predict_dev(m, (const int8_t*)ctx->ws_xu.p, N, ldx, d_b32, d_b64);
+}
+
+// base + smoother with B kept in context scratch; X int8 (packed == false) or 2-bit rows
+static int infer_any_dev(gnx_model* m, const void* dIn, bool packed, int64_t N, int64_t ld, float* d_p32, double* d_p64, int32_t* d_lab) {
   gnx_ctx* ctx = m->ctx;
   if (N <= 0) return N == 0 ? GNX_OK : fail(ctx, GNX_EINVAL, "infer: N < 0");
   const size_t n = (size_t)N * m->info.W * m->info.A;
   const bool f64 = (m->info.smooth_kind == GNX_SMOOTH_CRF);  // CRF consumes float64 base probabilities
   int rc = ws_reserve(ctx, f64 ? ctx->ws_b64 : ctx->ws_b32, n * (f64 ? 8 : 4));
   if (rc != GNX_OK) return rc;
-  rc = gnx_base_predict_dev(m, dX, N, ldx, f64 ? nullptr : (float*)ctx->ws_b32.p, f64 ? (double*)ctx->ws_b64.p : nullptr);
+  float* b32 = f64 ? nullptr : (float*)ctx->ws_b32.p;
+  double* b64 = f64 ? (double*)ctx->ws_b64.p : nullptr;
+  rc = packed ? gnx_base_predict_packed_dev(m, (const uint8_t*)dIn, N, ld, b32, b64) : gnx_base_predict_dev(m, (const int8_t*)dIn, N, ld, b32, b64);
   if (rc != GNX_OK) return rc;
   return gnx_smooth_predict_dev(m, f64 ? ctx->ws_b64.p : ctx->ws_b32.p, f64, N, d_p32, d_p64, d_lab);
+}
+
+int gnx_infer_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx, float* d_p32, double* d_p64, int32_t* d_lab) {
+  if (!m) return GNX_EINVAL;
+  return infer_any_dev(m, dX, false, N, ldx, d_p32, d_p64, d_lab);
 }
 
 // ---- host-pointer entry points: stage, run, copy back, synchronise -------------------------------------
@@ -695,7 +745,8 @@ static int infer_host(gnx_model* m, const void* src, bool packed, int64_t N, int
   const size_t in_bytes = (((size_t)nb * ld + 64) + 255) & ~(size_t)255;
   gnx_devbuf& wsin = packed ? ctx->ws_pk : ctx->ws_x;
   if ((rc = ws_reserve(ctx, wsin, in_bytes * nbuf)) != GNX_OK) return rc;
-  if (packed && (rc = ws_reserve(ctx, ctx->ws_xu, (size_t)nb * ldx_dev + 256)) != GNX_OK) return rc;
+  const bool p2 = packed && lr_p2_usable(m);  // 2-bit rows go straight into the logistic pass
+  if (packed && !p2 && (rc = ws_reserve(ctx, ctx->ws_xu, (size_t)nb * ldx_dev + 256)) != GNX_OK) return rc;
   const size_t p32_b = (nb * WA * 4 + 255) & ~(size_t)255, p64_b = (nb * WA * 8 + 255) & ~(size_t)255, lab_b = (nb * Wn * 4 + 255) & ~(size_t)255;
   if ((rc = ws_reserve(ctx, ctx->ws_p32, p32_b * nbuf)) != GNX_OK) return rc;
   if (p64 && (rc = ws_reserve(ctx, ctx->ws_p64, p64_b * nbuf)) != GNX_OK) return rc;
@@ -727,7 +778,7 @@ static int infer_host(gnx_model* m, const void* src, bool packed, int64_t N, int
     }
     const int8_t* dX = (const int8_t*)((char*)wsin.p + (size_t)b * in_bytes);
     int64_t ldx = ld;
-    if (packed) {
+    if (packed && !p2) {
       HIPCHK(ctx, gnx_launch_unpack2((const uint8_t*)dX, n, ld, C, (int8_t*)ctx->ws_xu.p, ldx_dev, sc));
       dX = (const int8_t*)ctx->ws_xu.p;
       ldx = ldx_dev;
@@ -735,7 +786,7 @@ static int infer_host(gnx_model* m, const void* src, bool packed, int64_t N, int
     float* dp32 = (float*)((char*)ctx->ws_p32.p + (size_t)b * p32_b);
     double* dp64 = p64 ? (double*)((char*)ctx->ws_p64.p + (size_t)b * p64_b) : nullptr;
     int32_t* dlab = lab ? (int32_t*)((char*)ctx->ws_lab.p + (size_t)b * lab_b) : nullptr;
-    if ((rc = gnx_infer_dev(m, dX, n, ldx, dp32, dp64, dlab)) != GNX_OK) return rc;
+    if ((rc = infer_any_dev(m, dX, p2, n, ldx, dp32, dp64, dlab)) != GNX_OK) return rc;
     if (nbuf == 2) HIPCHK(ctx, hipEventRecord(ctx->ev_done[b], sc));
     // the next batch's input goes out BEFORE this batch's outputs are awaited (pageable D2H blocks the host thread)
     if (i + 1 < n_batches && (rc = issue_h2d(i + 1)) != GNX_OK) return rc;
@@ -840,11 +891,7 @@ int gnx_infer_packed_dev(gnx_model* m, const uint8_t* dP, int64_t N, int64_t ldp
   gnx_ctx* ctx = m->ctx;
   if (N < 0 || ldp < (m->info.C + 3) / 4 || (N > 0 && !dP)) return fail(ctx, GNX_EINVAL, "infer_packed: bad P / N / ldp");
   if (N == 0) return GNX_OK;
-  const int64_t ldx = ((m->info.C + 15) / 16) * 16;
-  int rc = ws_reserve(ctx, ctx->ws_xu, (size_t)N * ldx + 256);
-  if (rc != GNX_OK) return rc;
-  HIPCHK(ctx, gnx_launch_unpack2(dP, N, ldp, m->info.C, (int8_t*)ctx->ws_xu.p, ldx, ctx->stream));
-  return gnx_infer_dev(m, (const int8_t*)ctx->ws_xu.p, N, ldx, d_p32, d_p64, d_lab);
+  return infer_any_dev(m, dP, true, N, ldp, d_p32, d_p64, d_lab);
 }
 
 int gnx_smooth_rows(gnx_model* m, const float* rows, int64_t R, float* proba) {

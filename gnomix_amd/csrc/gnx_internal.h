@@ -31,6 +31,8 @@ struct gnx_tune {
                                         // column tiles (A > 8 at the default context), where it measured 2.5 vs 3.1 ms (A = 12,
                                         // chr22); with one column tile both kernels run at the same 1.14-1.16 ms
   int lr_nbuf = 0;                      // GNX_LR_NBUF: ring slots of the LDS-direct kernel
+  int lr_p2 = 1;                        // GNX_LR_P2=0: packed (2-bit) input is widened to int8 in HBM and run through the int8 kernels
+                                        // instead of k_base_logistic_p2 (A/B runs; the outputs are bit-identical)
   int lr_flat = -1;                     // GNX_LR_FLAT: 1 = flat column tiles (k_base_logistic_i8_fl) wherever built, 0 = never
   int lr_w512 = 0;                      // GNX_LR_W512=1: 512 rows per block, 64-SNP steps (k_base_logistic_i8_w512)
   int lr_ws = 0, lr_ws_pw = 2;          // GNX_LR_WS=1: wave-specialised kernel (k_base_logistic_i8_ws); GNX_LR_WS_PW: producer waves (2, 4)
@@ -111,6 +113,15 @@ struct BaseLRDev {
   int32_t NT = 0;  // 16-column tiles
   int32_t NF = 0;  // flat column tiles of V8F (0: not built)
   int32_t max_piece_chunks = 0;  // longest piece, in chunks
+  // 2-bit-native pass (k_base_logistic_p2.hip): the same pieces walked in RUNS of 256 SNPs (64 packed bytes per haplotype row,
+  // byte-aligned: a piece starts at SNP b0 & ~3, the up to three SNPs before b0 meet zero weights); one run = 4 MFMA entries
+  const int8_t* V2 = nullptr;            // [n_runs][4 entries][NT][7 limbs][64 lanes][16 bytes], k order of the in-register unpack
+  const int32_t* run_byte = nullptr;     // [n_runs] byte offset of the run within a packed row
+  const int32_t* run_flush0 = nullptr;   // [n_runs] first window flushed after this run (-1 none)
+  const int32_t* run_nflush = nullptr;   // [n_runs] number of windows flushed after this run
+  const int32_t* win_run0 = nullptr;     // [W] first run a block must start from to compute window w
+  const int32_t* win_run1 = nullptr;     // [W] one past the run after which window w is flushed
+  int32_t n_runs = 0;
 };
 
 struct BaseLRLaunch {
@@ -370,6 +381,7 @@ struct gnx_model {
   std::vector<void*> dev_allocs;
   BaseLRDev lr;
   std::vector<int32_t> lr_h_win_chunk0, lr_h_win_chunk1;
+  std::vector<int32_t> lr_h_win_run0, lr_h_win_run1;   // host copies of lr.win_run0/1 (launcher of the 2-bit pass)
   bool lr_i8 = true;
   SmoothXGBDev xgb;
   CovRSKDev svc;
@@ -430,6 +442,9 @@ hipError_t gnx_launch_x_to_gt2(const int8_t* X, int64_t N, int64_t ldx, int64_t 
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_dl(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
+// 2-bit rows: L.X = packed matrix (gnx_pack_x layout), L.ldx = its row stride in bytes, L.last_row = zero-padded copy of packed row
+// N-1, L.h_win_chunk0/1 = HOST copies of d.win_run0/1; hipErrorNotSupported when no instantiation fits
+hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 #ifdef GNX_EXPERIMENTS  // scripts/dev/rejected/ (make EXPERIMENTS=1)
 hipError_t gnx_launch_base_logistic_i8_w512(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_base_logistic_i8_ws(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s);

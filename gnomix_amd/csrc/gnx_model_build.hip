@@ -179,6 +179,112 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
     }
 #endif
     if ((rc = gnx_dev_upload(m, wscale, &m->lr.wscale)) != GNX_OK) return rc;
+    // ---- the same weights for the 2-bit-native pass (k_base_logistic_p2.hip): the pieces walked in byte-aligned runs of 256 SNPs.
+    // Lane kq of a row's four lanes holds SNPs [64 kq, 64 kq + 64) of the run as four 32-bit words; entry k multiplies word k of every
+    // lane, whose in-register unpack puts SNP field f = 4 (t & 3) + (t >> 2) at k position t: k position (kq, t) of entry k of a run
+    // starting at SNP s is SNP  s + 64 kq + 16 k + 4 (t & 3) + (t >> 2).  Same folded weights, same f_w, same digits as V8.
+    {
+      const char* p2env = std::getenv("GNX_LR_P2");
+      const bool want_p2 = NT <= 2 && !(p2env && std::atoi(p2env) == 0);
+      if (want_p2) {
+        std::vector<int32_t> run_byte, run_flush0, run_nflush, piece_run0(n_pieces + 1);
+        std::vector<int64_t> run_s, run_b0, run_b1;
+        {
+          int64_t wi = 0;
+          for (size_t k = 0; k < n_pieces; ++k) {
+            piece_run0[k] = (int32_t)run_byte.size();
+            const int64_t b0 = bounds[k], b1 = bounds[k + 1];
+            const int64_t s0 = b0 & ~(int64_t)3;
+            const int64_t nr = (b1 - s0 + 255) / 256;
+            int64_t f0 = wi, nf = 0;
+            while (wi < W && fpos[(size_t)wi] == b1) { ++wi; ++nf; }
+            for (int64_t r = 0; r < nr; ++r) {
+              run_byte.push_back((int32_t)((s0 + 256 * r) / 4));
+              run_s.push_back(s0 + 256 * r); run_b0.push_back(b0); run_b1.push_back(b1);
+              const bool last = (r == nr - 1);
+              run_flush0.push_back(last && nf ? (int32_t)f0 : -1);
+              run_nflush.push_back(last ? (int32_t)nf : 0);
+            }
+          }
+          piece_run0[n_pieces] = (int32_t)run_byte.size();
+        }
+        const size_t n_runs = run_byte.size();
+        std::vector<int32_t> win_run0((size_t)W), win_run1((size_t)W);
+        for (int64_t i = 0; i < W; ++i) {
+          const int64_t s = std::max<int64_t>(wstart(i) - cx, 0);
+          size_t k = (size_t)(std::upper_bound(bounds.begin(), bounds.end(), s) - bounds.begin()) - 1;
+          if (k >= n_pieces) k = n_pieces - 1;
+          win_run0[(size_t)i] = piece_run0[k];
+          const size_t kf = (size_t)(std::lower_bound(bounds.begin(), bounds.end(), fpos[(size_t)i]) - bounds.begin());
+          win_run1[(size_t)i] = piece_run0[kf];
+        }
+        const size_t entry_bytes = (size_t)NT * 7 * 64 * 16;
+        std::vector<int8_t> V2(n_runs * 4 * entry_bytes, 0);
+        auto fill_runs = [&](size_t r_lo, size_t r_hi) {
+          std::vector<double> wsum((size_t)A);
+          std::vector<uint8_t> any((size_t)A);
+          for (size_t r = r_lo; r < r_hi; ++r)
+            for (int k = 0; k < 4; ++k)
+              for (int kq = 0; kq < 4; ++kq)
+                for (int t = 0; t < 16; ++t) {
+                  const int64_t j = run_s[r] + 64 * kq + 16 * k + 4 * (t & 3) + (t >> 2);
+                  if (j < run_b0[r] || j >= run_b1[r]) continue;
+                  const int64_t p = j + cx;
+                  const int64_t i0 = std::min<int64_t>(p / M, W - 1);
+                  for (int64_t slot = 0; slot < R; ++slot) {
+                    const int64_t i = i0 - (((i0 - slot) % R + R) % R);
+                    if (i < 0 || p >= wend(i)) continue;
+                    const int64_t ws_ = wstart(i), we_ = wend(i);
+                    int64_t pp[3];
+                    int np = 0;
+                    if (j < cx) pp[np++] = cx - 1 - j;
+                    pp[np++] = p;
+                    if (j >= C - cx) pp[np++] = 2 * C + cx - 1 - j;
+                    for (int a = 0; a < A; ++a) {
+                      double acc = 0.0;
+                      bool got = false;
+                      for (int q = 0; q < np; ++q)
+                        if (pp[q] >= ws_ && pp[q] < we_) {
+                          acc += coef[((size_t)i * A + a) * (size_t)ldc + (size_t)(pp[q] - ws_)];
+                          got = true;
+                        }
+                      if (!got || acc == 0.0) continue;
+                      const int64_t col = slot * A + a;
+                      const int nt = (int)(col / 16), c16 = (int)(col % 16);
+                      long long q = std::llrint(std::ldexp(acc, fexp[(size_t)i]));
+                      for (int l = 0; l < 7; ++l) {
+                        const long long dg = (l < 6) ? ((((q + 128) % 256) + 256) % 256) - 128 : q;
+                        V2[((((r * 4 + (size_t)k) * NT + (size_t)nt) * 7 + (size_t)l) * 64 + (size_t)(kq * 16 + c16)) * 16 + (size_t)t] = (int8_t)dg;
+                        q = (q - dg) / 256;
+                      }
+                    }
+                  }
+                }
+        };
+        {
+          unsigned nth = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+          nth = (unsigned)std::min<size_t>(nth, std::max<size_t>(1, n_runs / 64));
+          if (nth <= 1) fill_runs(0, n_runs);
+          else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nth; ++t) {
+              const size_t lo = n_runs * t / nth, hi = n_runs * (t + 1) / nth;
+              try { th.emplace_back(fill_runs, lo, hi); } catch (...) { fill_runs(lo, hi); }
+            }
+            for (auto& t : th) t.join();
+          }
+        }
+        if ((rc = gnx_dev_upload(m, V2, &m->lr.V2, 64)) != GNX_OK) return rc;
+        if ((rc = gnx_dev_upload(m, run_byte, &m->lr.run_byte)) != GNX_OK) return rc;
+        if ((rc = gnx_dev_upload(m, run_flush0, &m->lr.run_flush0)) != GNX_OK) return rc;
+        if ((rc = gnx_dev_upload(m, run_nflush, &m->lr.run_nflush)) != GNX_OK) return rc;
+        if ((rc = gnx_dev_upload(m, win_run0, &m->lr.win_run0)) != GNX_OK) return rc;
+        if ((rc = gnx_dev_upload(m, win_run1, &m->lr.win_run1)) != GNX_OK) return rc;
+        m->lr_h_win_run0 = win_run0;
+        m->lr_h_win_run1 = win_run1;
+        m->lr.n_runs = (int32_t)n_runs;
+      }
+    }
   } else if ((rc = gnx_dev_upload(m, V, &m->lr.V)) != GNX_OK) return rc;
   if ((rc = gnx_dev_upload(m, icpt, &m->lr.icpt)) != GNX_OK) return rc;
   if ((rc = gnx_dev_upload(m, chunk_j0, &m->lr.chunk_j0)) != GNX_OK) return rc;

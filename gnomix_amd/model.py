@@ -521,6 +521,47 @@ class DeviceModel:
                                                      None if f64 else B.data_ptr(), B.data_ptr() if f64 else None))
         return B
 
+    def pack_device(self, X_t):
+        """int8 (N, C) CUDA tensor -> the gnx_pack_x layout as a uint8 CUDA tensor (N, gnx_packed_row_bytes(C)): SNP j of a row =
+        bits 2 (j % 4).. of byte j // 4 (torch ops; a test / bench utility, the product packs on the host or in k_gt2)"""
+        import torch
+        assert X_t.is_cuda and X_t.dtype == torch.int8 and X_t.dim() == 2
+        N, C = X_t.shape
+        ldp = int(self.lib.gnx_packed_row_bytes(self.C))
+        P = torch.zeros((N, ldp), dtype=torch.uint8, device=X_t.device)
+        step = max(1, (1 << 28) // max(C, 1))
+        for n0 in range(0, N, step):
+            x = X_t[n0:n0 + step].to(torch.uint8) & 3
+            pad = (-C) % 4
+            if pad:
+                x = torch.nn.functional.pad(x, (0, pad))
+            x = x.view(x.shape[0], -1, 4)
+            P[n0:n0 + step, :x.shape[1]] = x[:, :, 0] | (x[:, :, 1] << 2) | (x[:, :, 2] << 4) | (x[:, :, 3] << 6)
+        return P
+
+    def base_predict_packed_device(self, P_t, f64=False):
+        """Base.predict_proba on device-resident 2-bit rows (gnx_base_predict_packed_dev)"""
+        import torch
+        assert P_t.is_cuda and P_t.dtype == torch.uint8 and P_t.dim() == 2 and P_t.stride(1) == 1
+        self._bind_torch_stream()
+        N = P_t.shape[0]
+        B = torch.empty((N, self.W, self.A), dtype=torch.float64 if f64 else torch.float32, device=P_t.device)
+        self.ctx.check(self.lib.gnx_base_predict_packed_dev(self.h, P_t.data_ptr(), N, P_t.stride(0),
+                                                            None if f64 else B.data_ptr(), B.data_ptr() if f64 else None))
+        return B
+
+    def infer_packed_device(self, P_t, want_proba=True, want_labels=True):
+        """P_t: torch uint8 CUDA tensor (N, >= ceil(C/4)) of 2-bit rows resident in HBM -> (proba f32 tensor, labels i32 tensor)."""
+        import torch
+        assert P_t.is_cuda and P_t.dtype == torch.uint8 and P_t.dim() == 2 and P_t.stride(1) == 1
+        self._bind_torch_stream()
+        N = P_t.shape[0]
+        p = torch.empty((N, self.W, self.A), dtype=torch.float32, device=P_t.device) if want_proba else None
+        lab = torch.empty((N, self.W), dtype=torch.int32, device=P_t.device) if want_labels else None
+        self.ctx.check(self.lib.gnx_infer_packed_dev(self.h, P_t.data_ptr(), N, P_t.stride(0), p.data_ptr() if want_proba else None,
+                                                     None, lab.data_ptr() if want_labels else None))
+        return p, lab
+
     def gnofix_device(self, X_t, B_t, max_it=50):
         """X_t (2n, C) int8 CUDA tensor re-phased IN PLACE, B_t (2n, W, A) float64 -> (labels i32 (2n, W), n_switches i32 (n,))"""
         import torch

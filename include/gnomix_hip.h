@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 12
+#define GNX_ABI_VERSION 13
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -246,12 +246,18 @@ int gnx_infer_dev(gnx_model* model, const int8_t* dX, int64_t N, int64_t ldx, fl
  *   gnx_infer_packed    gnx_infer on packed host input: batches are copied, widened on the device and run through the same
  *                       kernels, H2D / kernels / D2H overlapped on three streams; results are bit-identical to gnx_infer's.
  *   gnx_unpack_x_dev    the widening pass alone, on the context stream (device pointers).
- *   gnx_infer_packed_dev  device-resident packed input. */
+ *   gnx_infer_packed_dev  device-resident packed input.
+ *   gnx_base_predict_packed_dev  Base.predict_proba (src/Base/base.py:146-180) on device-resident packed input.
+ * With the logistic base (up to 32 class columns per SNP, i.e. A <= 16 at the default context) packed rows are NOT widened:
+ * k_base_logistic_p2 reads the 2-bit rows and expands them to the int8 MFMA operand in registers — a quarter of the X bytes
+ * through HBM and the L1s; B is bit-identical to the int8 entry points'.  Other bases widen to int8 in device scratch first. */
 int64_t gnx_packed_row_bytes(int64_t C);
 int gnx_pack_x(const int8_t* X, int64_t N, int64_t ldx, int64_t C, uint8_t* packed, int64_t ldp, int n_threads);
 int gnx_unpack_x_dev(gnx_ctx* ctx, const uint8_t* d_packed, int64_t N, int64_t ldp, int64_t C, int8_t* dX, int64_t ldx);
 int gnx_infer_packed(gnx_model* model, const uint8_t* packed, int64_t N, int64_t ldp, float* proba_f32, double* proba_f64,
                      int32_t* labels);
+int gnx_base_predict_packed_dev(gnx_model* model, const uint8_t* d_packed, int64_t N, int64_t ldp, float* d_b_f32,
+                                double* d_b_f64);
 int gnx_infer_packed_dev(gnx_model* model, const uint8_t* d_packed, int64_t N, int64_t ldp, float* d_proba_f32,
                          double* d_proba_f64, int32_t* d_labels);
 
