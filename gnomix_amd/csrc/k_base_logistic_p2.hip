@@ -27,15 +27,8 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-struct __attribute__((packed, aligned(1))) xbytes16 { v4i v; };
 
 constexpr int LIMBS = 7;
-
-__device__ __forceinline__ v4i load_x16(const uint8_t* p) {  // unaligned, unconditional global_load_dwordx4
-  xbytes16 r;
-  __builtin_memcpy(&r, p, 16);
-  return r.v;
-}
 
 __device__ __forceinline__ v4i unpack16(int w) {  // 16 two-bit fields -> 16 int8 bytes, field 4b + d at byte b of reg d
   const unsigned u = (unsigned)w;
@@ -47,11 +40,15 @@ __device__ __forceinline__ v4i unpack16(int w) {  // 16 two-bit fields -> 16 int
   return r;
 }
 
+// Z = (hi 2^24 + lo) 2^-f_w with hi = sum_{l>=3} acc_l 2^{8(l-3)}, lo = sum_{l<3} acc_l 2^{8l}: the same exact integers
+// k_base_logistic_i8's combine() forms in int64 (|acc_l| < 2^20 for K <= 2500 SNPs, so |lo| < 2^37, |hi| < 2^45: every fma below is
+// exact), here on the float64 pipe: 7 conversions + 5 fmas instead of ~60 instructions of 64-bit integer arithmetic and two
+// int64 -> double conversions per accumulator register.  One rounding (the last addition), as there: bit-identical Z.
 __device__ __forceinline__ double combine(const v4i (&acc)[LIMBS], int reg, double scale) {
-  long long lo = (long long)acc[0][reg] + ((long long)acc[1][reg] << 8) + ((long long)acc[2][reg] << 16);
-  long long hi = (long long)acc[3][reg] + ((long long)acc[4][reg] << 8) + ((long long)acc[5][reg] << 16) +
-                 ((long long)acc[6][reg] << 24);
-  return ((double)hi * 16777216.0 + (double)lo) * scale;
+  const double lo = __builtin_fma(__builtin_fma((double)acc[2][reg], 256.0, (double)acc[1][reg]), 256.0, (double)acc[0][reg]);
+  const double hi = __builtin_fma(__builtin_fma(__builtin_fma((double)acc[6][reg], 256.0, (double)acc[5][reg]), 256.0, (double)acc[4][reg]),
+                                  256.0, (double)acc[3][reg]);
+  return (hi * 16777216.0 + lo) * scale;
 }
 
 template <int N>
@@ -60,29 +57,35 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// MT 16-row tiles per wave, NT column tiles, WAVES waves per block, NBUF = 3 ring slots of one half-run (2 entries) each.
-template <int MT, int NT, int WAVES, int NBUF>
+// MT 16-row tiles per wave, NT column tiles, WAVES waves per block, XSN LDS stages of X runs in flight, ZT = 1: the flush goes
+// through a 16-row scratch one tile at a time (a quarter of the epilogue rows in LDS), 0: all MT tiles at once.
+// Plane ring: 3 slots of one half-run (2 entries) each.
+template <int MT, int NT, int WAVES, int XSN, int ZT>
 __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int NBUF = 3;
   constexpr int EPS = 2;                          // MFMA entries per plane step (half a run)
   constexpr int ENTRY_BYTES = NT * LIMBS * 1024;  // digit planes of one entry (64 k positions)
   constexpr int STEP_BYTES = EPS * ENTRY_BYTES;
   constexpr int THREADS = WAVES * 64;
-  constexpr int ROWS = WAVES * MT * 16;           // haplotypes per block
   constexpr int NKB = STEP_BYTES / 1024;          // 1 KB plane blocks per step
   constexpr int PLD = (NKB + WAVES - 1) / WAVES;  // plane loads per wave per step
   constexpr int D = NBUF - 1;                     // plane steps in flight beyond the one being multiplied
-  static_assert(D == 2, "the vmcnt arithmetic below assumes two plane steps (one run) in flight");
-  // vector-memory instructions younger than the planes of step s when a wave waits for them: the planes of step s+1 and the X loads
-  // of one run (see the issue order in GNX_P2_RUN)
-  constexpr int WAITN = PLD + MT;
+  constexpr int ZROWS = ZT ? 16 : MT * 16;        // rows of the wave's epilogue scratch
+  // Issue order per run r (every wave, unconditional, clamped):  X(r+XSN) | planes(2r+2) | planes(2r+3).  When a wave waits for the
+  // planes of the even step 2r, the only younger vector-memory instructions are the planes of 2r+1; for the odd step 2r+1 they are
+  // X(r+XSN) and the planes of 2r+2.  X(r) is older than the planes of step 2r (XSN >= 1), so the even wait covers it too.
+  constexpr int WAIT_EVEN = PLD, WAIT_ODD = PLD + MT;
+  static_assert(XSN >= 1 && WAIT_ODD < 64, "vmcnt is a 6-bit counter");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   const int A = L.A, W = L.W, R = L.d.R;
-  uint8_t* vbuf = lds;                             // [NBUF][STEP_BYTES]
-  double* zb = reinterpret_cast<double*>(vbuf + (size_t)NBUF * STEP_BYTES) + (size_t)wave * (MT * 16) * A;
-  double* tab_ic = reinterpret_cast<double*>(vbuf + (size_t)NBUF * STEP_BYTES) + (size_t)ROWS * A;  // [max_wins][A] intercepts
-  double* tab_sc = tab_ic + (size_t)L.max_wins * A;                                                  // [max_wins] 2^-f_w
+  uint8_t* vbuf = lds;                                                           // [NBUF][STEP_BYTES]
+  uint8_t* xl = vbuf + (size_t)NBUF * STEP_BYTES + (size_t)wave * (XSN * MT * 1024);  // [WAVES][XSN][MT][64 lanes][16 B], wave-private
+  double* zb0 = reinterpret_cast<double*>(vbuf + (size_t)NBUF * STEP_BYTES + (size_t)WAVES * XSN * MT * 1024);
+  double* zb = zb0 + (size_t)wave * ZROWS * A;
+  double* tab_ic = zb0 + (size_t)WAVES * ZROWS * A;  // [max_wins][A] intercepts
+  double* tab_sc = tab_ic + (size_t)L.max_wins * A;   // [max_wins] 2^-f_w
   int* tab_rb = reinterpret_cast<int*>(tab_sc + L.max_wins);
   int* tab_nfl = tab_rb + L.max_chunks;
   int* tab_fl0 = tab_nfl + L.max_chunks;
@@ -102,8 +105,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
   const int r_end = L.d.win_run1[wb - 1];
   const int n_runs = r_end - r_begin;
   const int n_steps = 2 * n_runs;
-  const int64_t n0b = (int64_t)htile * ROWS;       // first haplotype of the block
-  const int64_t n0 = n0b + (int64_t)wave * (MT * 16);
+  const int64_t n0 = (int64_t)htile * (WAVES * MT * 16) + (int64_t)wave * (MT * 16);  // first haplotype of the wave
 
   for (int e = tid; e < n_runs; e += THREADS) {
     tab_rb[e] = L.d.run_byte[r_begin + e];
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
   }
   __syncthreads();
 
-  // the lane's rows: tile mt, row i16; its 16 bytes of a run = packed bytes [16 kq, 16 kq + 16)
+  // the lane's rows: tile mt, row i16; its 16 bytes of a run = packed bytes [16 kq, 16 kq + 16) of the run
   const uint8_t* xrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -128,7 +130,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
   const int8_t* vsrc = L.d.V2 + (size_t)r_begin * (2 * STEP_BYTES) + (size_t)lane * 16;
 
   // every load is unconditional and clamped (tail steps re-fetch the last one into a slot nobody reads): the number of
-  // vector-memory instructions per step is the constant the vmcnt arithmetic relies on
+  // vector-memory instructions per step is the constant the vmcnt arithmetic relies on.  X goes HBM -> LDS directly too
+  // (lane-linear: the lane reads back exactly the 16 bytes it fetched), so that no register waits on a load the compiler tracks:
+  // hipcc's waitcnt insertion gives up on VGPR loads in flight across the flush's loops and stores (s_waitcnt vmcnt(0) at first use)
+  auto issue_x = [&](int run) {
+    const int rb = tab_rb[min(run, n_runs - 1)];
+    uint8_t* dst = xl + (size_t)(run % XSN) * (MT * 1024);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[mt] + rb), (lptr_t)(dst + mt * 1024), 16, 0, 0);
+  };
   auto issue_planes = [&](int step) {
     const int st = min(step, n_steps - 1);
     const int8_t* src = vsrc + (size_t)st * STEP_BYTES;
@@ -148,7 +158,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) acc[mt][nt][l] = v4i{0, 0, 0, 0};
 
-  auto mfma_entry = [&](const uint8_t* pb, const v4i (&xa)[MT]) {
+  const int abl = L.flags;  // development ablations (GNX_LR_FLAGS, timing only): 1 raw logits, 2 no MFMA, 4 no flush
+  auto mfma_entry = [&](const uint8_t* pb, const v4i (&xc)[MT], int k) {
+    if (abl & 2) return;
+    v4i xa[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xc[mt][k]);
     const v4i* vb = reinterpret_cast<const v4i*>(pb) + lane;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -160,16 +175,53 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
       }
   };
 
+  // sigmoid, normaliser and division for the ZROWS rows x A classes parked in zb.  Per element the arithmetic and the class order
+  // of the row sum are those of k_base_logistic_i8 (bit-identical B); what differs is who does what:
+  //   phase 1  LPR = 64 / ZROWS lanes per row: lane (row, sub) turns classes sub, sub + LPR, .. into p = 1 / (1 + exp(-(z + icpt)))
+  //   phase 2  every lane sums its row's A values in class order (LPR times redundantly: A additions against A/LPR exps), then
+  //            divides its own classes
+  //   phase 3  the wave walks the ZROWS x A block linearly, 64 consecutive elements per store (a row's A values are contiguous in
+  //            B): (row, class) of element lane + 64 it advance by (64 / A, 64 % A) — no integer division in the loop
+  constexpr int LPR = 64 / ZROWS;
+  const int frow = lane % ZROWS, fsub = lane / ZROWS;
+  const int e_r0 = lane / A, e_a0 = lane - e_r0 * A, e_dr = 64 / A, e_da = 64 - e_dr * A;
+  auto emit = [&](int w, int64_t nrow0) {
+    double* zr = zb + frow * A;
+    if (!(abl & 1)) {
+      const double* ic = tab_ic + (w - wt0) * A;
+      for (int a = fsub; a < A; a += LPR) zr[a] = 1.0 / (1.0 + exp(-(zr[a] + ic[a])));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double sum = 0.0;
+      for (int c = 0; c < A; ++c) sum += zr[c];
+      for (int a = fsub; a < A; a += LPR) zr[a] = zr[a] / sum;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    int rl = e_r0, a = e_a0;
+    const size_t ow = (size_t)w * A;
+    for (int e = lane; e < ZROWS * A; e += 64) {
+      const int64_t n = nrow0 + rl;
+      if (n < L.N) {
+        const size_t o = (size_t)n * W * A + ow + a;
+        const double v = zb[e];
+        if (L.b64) L.b64[o] = v;
+        if (L.b32) L.b32[o] = (float)v;
+      }
+      a += e_da; rl += e_dr;
+      if (a >= A) { a -= A; ++rl; }
+    }
+  };
+
   // ---- piece end: the windows that finished with run rl (block-uniform) ----
   auto flush = [&](int rl) {
     const int nfl = tab_nfl[rl];
-    if (nfl <= 0) return;
+    if (nfl <= 0 || (abl & 4)) return;
     const int w0 = tab_fl0[rl];
     for (int w = w0; w < w0 + nfl; ++w) {
       const int cbase = (w % R) * A;
       const double scale = tab_sc[w - wt0];
+      const bool out = w >= wa && w < wb;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int col = nt * 16 + i16 - cbase;
@@ -177,112 +229,79 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
           if (mine) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)  // int32 16x16 C/D layout: column = lane&15, row = 4*(lane>>4) + reg
-              zb[(mt * 16 + 4 * kq + r) * A + col] = combine(acc[mt][nt], r, scale);
+              zb[((ZT ? 0 : mt * 16) + 4 * kq + r) * A + col] = combine(acc[mt][nt], r, scale);
           }
 #pragma unroll
           for (int l = 0; l < LIMBS; ++l)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mt][nt][l][r] = mine ? 0 : acc[mt][nt][l][r];
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zb is wave-private: LDS ops of one wave complete in order
-      if (w >= wa && w < wb) {
-        // sigmoid, normaliser and division for the wave's MT*16 rows x A classes, spread over all 64 lanes; per element the
-        // arithmetic and the class order of the row sum are those of k_base_logistic_i8 (bit-identical B)
-        const int ne = MT * 16 * A;
-        const double* ic = tab_ic + (w - wt0) * A;
-        for (int e = lane; e < ne; e += 64) {
-          const int a = e % A;
-          zb[e] = 1.0 / (1.0 + exp(-(zb[e] + ic[a])));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int e = lane; e < ne; e += 64) {
-          const int rl_ = e / A, a = e - rl_ * A;
-          const double* z = zb + rl_ * A;
-          double sum = 0.0;
-          for (int c = 0; c < A; ++c) sum += z[c];
-          const double v = z[a] / sum;
-          const int64_t n = n0 + rl_;
-          if (n < L.N) {
-            const size_t o = ((size_t)n * W + w) * A + a;
-            if (L.b64) L.b64[o] = v;
-            if (L.b32) L.b32[o] = (float)v;
-          }
+        if (ZT) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zb is wave-private: LDS ops of one wave complete in order
+          if (out) emit(w, n0 + mt * 16);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!ZT) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (out) emit(w, n0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
   };
 
-  v4i xsA[MT], xsB[MT];  // two register stages of X: even runs in A, odd runs in B
-
-#define GNX_P2_XLOAD(XS, RUN)                                                          \
-  {                                                                                    \
-    const int rb_ = tab_rb[min((RUN), n_runs - 1)];                                    \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) XS[mt] = load_x16(xrow[mt] + rb_); \
-  }
-
-#define GNX_P2_STEP_SYNC(STEP)                                                                                                  \
-  {                                                                                                                             \
-    wait_vm<WAITN>(); /* the wave's own plane loads of this step (and everything older: its X run) have landed */               \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                          \
-    __builtin_amdgcn_s_barrier(); /* all shares of the step are in LDS; every wave is done with the step before it */           \
-    asm volatile("" ::: "memory");                                                                                              \
-    issue_planes((STEP) + D);     /* into the slot the previous step just left */                                               \
-  }
-
-// one run = two plane steps; issue order per run: planes(2r+2) | planes(2r+3) | X(r+2)
-#define GNX_P2_RUN(XS, RUN)                                                                      \
-  {                                                                                              \
-    const int r_ = (RUN);                                                                        \
-    const bool live_ = r_ < n_runs;                                                              \
-    v4i xa_[MT];                                                                                 \
-    GNX_P2_STEP_SYNC(2 * r_);                                                                    \
-    if (live_) {                                                                                 \
-      const uint8_t* sb_ = vbuf + (size_t)((2 * r_) % NBUF) * STEP_BYTES;                        \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xa_[mt] = unpack16(XS[mt][0]);           \
-      mfma_entry(sb_, xa_);                                                                      \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xa_[mt] = unpack16(XS[mt][1]);           \
-      mfma_entry(sb_ + ENTRY_BYTES, xa_);                                                        \
-    }                                                                                            \
-    GNX_P2_STEP_SYNC(2 * r_ + 1);                                                                \
-    const uint8_t* sc_ = vbuf + (size_t)((2 * r_ + 1) % NBUF) * STEP_BYTES;                      \
-    if (live_) {                                                                                 \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xa_[mt] = unpack16(XS[mt][2]);           \
-      mfma_entry(sc_, xa_);                                                                      \
-    }                                                                                            \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xa_[mt] = unpack16(XS[mt][3]);             \
-    GNX_P2_XLOAD(XS, r_ + 2); /* the stage is free: every word of run r has been unpacked */     \
-    if (live_) {                                                                                 \
-      mfma_entry(sc_ + ENTRY_BYTES, xa_);                                                        \
-      flush(r_);                                                                                 \
-    }                                                                                            \
-  }
-
-  // ---- prologue, in the steady state's issue order (the vmcnt arithmetic counts on it): X(0) | planes(0) | planes(1) | X(1) ----
-  GNX_P2_XLOAD(xsA, 0);
+  // ---- prologue, in the steady state's issue order: X(0) .. X(XSN-1) | planes(0) | planes(1) ----
+#pragma unroll
+  for (int p = 0; p < XSN; ++p) issue_x(p);
   issue_planes(0);
   issue_planes(1);
-  GNX_P2_XLOAD(xsB, 1);
 
-  for (int r = 0; r < n_runs; r += 2) {
-    GNX_P2_RUN(xsA, r);
-    GNX_P2_RUN(xsB, r + 1);
+  for (int r = 0; r < n_runs; ++r) {
+    // ---- even step 2r: the planes of the step and X(r) have landed; every wave is done with step 2r-1 ----
+    wait_vm<WAIT_EVEN>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    v4i xc[MT];
+    {
+      const uint8_t* xs = xl + (size_t)(r % XSN) * (MT * 1024) + lane * 16;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xc[mt] = *reinterpret_cast<const v4i*>(xs + mt * 1024);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the run sits in registers: its stage is free
+    issue_x(r + XSN);
+    issue_planes(2 * r + D);
+    {
+      const uint8_t* sb = vbuf + (size_t)((2 * r) % NBUF) * STEP_BYTES;
+      mfma_entry(sb, xc, 0);
+      mfma_entry(sb + ENTRY_BYTES, xc, 1);
+    }
+    // ---- odd step 2r+1 ----
+    wait_vm<WAIT_ODD>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_planes(2 * r + 1 + D);
+    {
+      const uint8_t* sb = vbuf + (size_t)((2 * r + 1) % NBUF) * STEP_BYTES;
+      mfma_entry(sb, xc, 2);
+      mfma_entry(sb + ENTRY_BYTES, xc, 3);
+    }
+    flush(r);
   }
   wait_vm<0>();  // nothing of this block may still be writing LDS when it retires
-#undef GNX_P2_RUN
-#undef GNX_P2_STEP_SYNC
-#undef GNX_P2_XLOAD
 }
 
-template <int MT, int NT, int WAVES, int NBUF>
+template <int MT, int NT, int WAVES, int XSN, int ZT>
 size_t lds_need(int A, int max_runs, int max_wins) {
-  return (size_t)NBUF * (2 * NT * LIMBS * 1024) + (size_t)WAVES * MT * 16 * A * sizeof(double) + (size_t)3 * max_runs * sizeof(int) +
-         (size_t)max_wins * (A + 1) * sizeof(double);
+  return (size_t)3 * (2 * NT * LIMBS * 1024) + (size_t)WAVES * XSN * MT * 1024 + (size_t)WAVES * (ZT ? 16 : MT * 16) * A * sizeof(double) +
+         (size_t)3 * max_runs * sizeof(int) + (size_t)max_wins * (A + 1) * sizeof(double);
 }
 
-template <int MT, int NT, int WAVES, int NBUF>
+template <int MT, int NT, int WAVES, int XSN, int ZT>
 hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   BaseLRLaunch P = L;
+  P.flags = tune.lr_flags;
   const int haps_per_block = WAVES * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
   // window ranges: a multiple of 8 (one XCD each); every range re-walks the runs of its first windows' lead-in, so fewer, longer
@@ -304,7 +323,7 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
     }
     P.max_chunks = max_runs + 8;
     P.max_wins = wch + 2 * L.d.R + 4;
-    lds = lds_need<MT, NT, WAVES, NBUF>(L.A, P.max_chunks, P.max_wins);
+    lds = lds_need<MT, NT, WAVES, XSN, ZT>(L.A, P.max_chunks, P.max_wins);
     if (lds <= (size_t)160 * 1024 || wch == 4) break;
   }
   if (lds > (size_t)160 * 1024) return hipErrorNotSupported;
@@ -312,8 +331,9 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
   const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
   P.wch = wch;
   P.n_htiles = (int)gx;
-  GNX_LDS_OPTIN(lds, k_base_logistic_p2<MT, NT, WAVES, NBUF>);
-  hipLaunchKernelGGL((k_base_logistic_p2<MT, NT, WAVES, NBUF>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
+  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2<%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d\n", MT, NT, WAVES, XSN, ZT, lds, (long long)(gx * n_ranges8), wch);
+  GNX_LDS_OPTIN(lds, k_base_logistic_p2<MT, NT, WAVES, XSN, ZT>);
+  hipLaunchKernelGGL((k_base_logistic_p2<MT, NT, WAVES, XSN, ZT>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
   return hipGetLastError();
 }
 
@@ -324,22 +344,29 @@ hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gn
   if (L.N <= 0) return hipSuccess;
   if (!L.d.V2 || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
   const bool small = L.N <= 64 * 8;
-  const int tm = tune.lr_mt, tw = tune.lr_waves;
+  const int tm = tune.lr_mt, tw = tune.lr_waves, tx = tune.lr_nbuf;  // GNX_LR_TUNE="mt,waves", GNX_LR_NBUF = X stages (development)
   switch (L.d.NT) {
     case 1:
-      if (tm == 1 && tw == 4) return launch<1, 1, 4, 3>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8) return launch<2, 1, 8, 3>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 16) return launch<2, 1, 16, 3>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 4) return launch<4, 1, 4, 3>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8) return launch<4, 1, 8, 3>(L, n_cu, tune, s);
-      if (small) return launch<1, 1, 4, 3>(L, n_cu, tune, s);
-      return launch<4, 1, 8, 3>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 1) return launch<2, 1, 8, 1, 1>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 2) return launch<2, 1, 8, 2, 1>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 3) return launch<2, 1, 8, 3, 1>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 16 && tx == 1) return launch<2, 1, 16, 1, 1>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 16 && tx == 2) return launch<2, 1, 16, 2, 1>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 4 && tx == 1) return launch<4, 1, 4, 1, 1>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 4 && tx == 2) return launch<4, 1, 4, 2, 1>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 1) return launch<4, 1, 8, 1, 1>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 2) return launch<4, 1, 8, 2, 1>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 12) return launch<4, 1, 8, 2, 0>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 11) return launch<4, 1, 8, 1, 0>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 12) return launch<2, 1, 8, 2, 0>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 3) return launch<4, 1, 8, 3, 1>(L, n_cu, tune, s);
+      if (small) return launch<1, 1, 4, 2, 0>(L, n_cu, tune, s);
+      return launch<4, 1, 8, 2, 1>(L, n_cu, tune, s);
     case 2:
-      if (tm == 1 && tw == 4) return launch<1, 2, 4, 3>(L, n_cu, tune, s);
-      if (tm == 1 && tw == 16) return launch<1, 2, 16, 3>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8) return launch<2, 2, 8, 3>(L, n_cu, tune, s);
-      if (small) return launch<1, 2, 4, 3>(L, n_cu, tune, s);
-      return launch<2, 2, 8, 3>(L, n_cu, tune, s);
+      if (tm == 1 && tw == 16 && tx == 2) return launch<1, 2, 16, 2, 0>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 1) return launch<2, 2, 8, 1, 1>(L, n_cu, tune, s);
+      if (small) return launch<1, 2, 4, 2, 0>(L, n_cu, tune, s);
+      return launch<2, 2, 8, 2, 1>(L, n_cu, tune, s);
     default: return hipErrorNotSupported;
   }
 }

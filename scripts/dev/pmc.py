@@ -41,13 +41,13 @@ def main():
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 if pat.search(r["Kernel_Name"]):
-                    k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void (anonymous namespace)::", "")
+                    k = re.sub(r"\(Base.*|\(Smooth.*|\(Gnofix.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", ""))
                     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         shutil.rmtree(d, ignore_errors=True)
     for k, v in agg.items():
         a = {c: sum(x) / len(x) for c, x in v.items()}
         n = max(len(x) for x in v.values())
-        print("%s  (%d launches)" % (k[:70], n))
+        print("%s  (%d launches)" % (k[:100], n))
         print("   " + "  ".join("%s=%.4g" % (c, a[c]) for c in sorted(a)))
         der = {}
         if "SQ_BUSY_CYCLES" in a and a["SQ_BUSY_CYCLES"]:
