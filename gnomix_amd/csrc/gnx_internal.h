@@ -114,7 +114,7 @@ struct BaseLRDev {
   int32_t NF = 0;  // flat column tiles of V8F (0: not built)
   int32_t max_piece_chunks = 0;  // longest piece, in chunks
   // 2-bit-native pass (k_base_logistic_p2.hip): the same pieces walked in RUNS of 256 SNPs (64 packed bytes per haplotype row,
-  // byte-aligned: a piece starts at SNP b0 & ~3, the up to three SNPs before b0 meet zero weights); one run = 4 MFMA entries
+  // dword-aligned: a piece starts at SNP b0 & ~15, the up to 15 SNPs before b0 meet zero weights); one run = 4 MFMA entries
   const int8_t* V2 = nullptr;            // [n_runs][4 entries][NT][7 limbs][64 lanes][16 bytes], k order of the in-register unpack
   const int32_t* run_byte = nullptr;     // [n_runs] byte offset of the run within a packed row
   const int32_t* run_flush0 = nullptr;   // [n_runs] first window flushed after this run (-1 none)

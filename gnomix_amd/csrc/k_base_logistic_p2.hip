@@ -11,8 +11,10 @@
 //   * a 32-bit word (16 SNPs) becomes the 16 int8 bytes of the MFMA A operand in 7 VALU operations:
 //         reg d = (word >> 2d) & 0x03030303        (d = 0..3; byte b of reg d = field 4b + d)
 //     — the VALU was 22 % busy, the matrix pipe 15 %;
-//   * pieces start on a byte boundary: a piece [b0, b1) is walked from SNP b0 & ~3 in runs of 256 SNPs (4 MFMA entries), the up to
-//     three SNPs before b0 and everything from b1 on meet zero weights; windows are flushed after the last run of their piece;
+//   * pieces start on a 32-bit boundary of the packed row: a piece [b0, b1) is walked from SNP b0 & ~15 in runs of 256 SNPs (4 MFMA
+//     entries), the up to 15 SNPs before b0 and everything from b1 on meet zero weights (M = 1000, context 500: 500 + 12 SNPs = exactly
+//     two runs); windows are flushed after the last run of their piece.  Loads that are not dword-aligned are split by the texture
+//     addresser (~4.5 L1 tag accesses per lane instead of ~0.5: the first version, byte-aligned, ran at the L1's tag rate);
 //   * the digit planes go L2 -> LDS directly (global_load_lds_dwordx4) through an NBUF-deep ring of half-runs (2 entries), ONE block
 //     barrier per half-run, exactly as in k_base_logistic_i8_dl.hip; X is two register stages (run r in use, run r+1 in flight; the
 //     loads of run r+2 are issued the moment the last word of run r has been unpacked).
@@ -60,7 +62,7 @@ __device__ __forceinline__ void wait_vm() {
 // MT 16-row tiles per wave, NT column tiles, WAVES waves per block, XSN LDS stages of X runs in flight, ZT = 1: the flush goes
 // through a 16-row scratch one tile at a time (a quarter of the epilogue rows in LDS), 0: all MT tiles at once.
 // Plane ring: 3 slots of one half-run (2 entries) each.
-template <int MT, int NT, int WAVES, int XSN, int ZT>
+template <int MT, int NT, int WAVES, int XSN, int ZT, int SPLIT>
 __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int NBUF = 3;
@@ -77,7 +79,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
   // X(r+XSN) and the planes of 2r+2.  X(r) is older than the planes of step 2r (XSN >= 1), so the even wait covers it too.
   constexpr int WAIT_EVEN = PLD, WAIT_ODD = PLD + MT;
   static_assert(XSN >= 1 && WAIT_ODD < 64, "vmcnt is a 6-bit counter");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // SPLIT = 1: the two streams are issued by DIFFERENT waves, because vmcnt retires in order: a wave that waits for its planes of
+  // step s also waits for every X load it issued before them, so with both streams in one wave X never gets more than ~one run of
+  // lead however many stages it has (measured: 1, 2 and 3 stages run the same 0.53 ms skeleton).  Even waves issue all plane loads,
+  // odd waves issue the X runs of themselves and of their even neighbour; the block barrier of every step publishes both.
+  //   even wave, any step s:   planes(s) were issued two steps ago, only the planes of s+1 are younger     -> vmcnt(PLDS)
+  //   odd wave, even step 2r:  X(r+XSN) is issued at step 2r+1, so X(r+1) .. X(r+XSN-1) are younger than X(r) -> vmcnt((XSN-1) 2 MT)
+  // X(r+XSN) goes into the stage of X(r) one barrier after every wave has read it: 2 XSN - 1 steps of lead.
+  constexpr int PLDS = (NKB + WAVES / 2 - 1) / (WAVES / 2);
+  constexpr int WAIT_XS = (XSN - 1) * 2 * MT;
+  static_assert(!SPLIT || (WAIT_XS < 64 && WAVES % 2 == 0), "vmcnt is a 6-bit counter");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool xwave = SPLIT && (wave & 1);
   const int i16 = lane & 15, kq = lane >> 4;
   const int A = L.A, W = L.W, R = L.d.R;
   uint8_t* vbuf = lds;                                                           // [NBUF][STEP_BYTES]
@@ -121,10 +134,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
   __syncthreads();
 
   // the lane's rows: tile mt, row i16; its 16 bytes of a run = packed bytes [16 kq, 16 kq + 16) of the run
-  const uint8_t* xrow[MT];
+  constexpr int XT = SPLIT ? 2 * MT : MT;  // tiles a loading wave fetches: SPLIT: those of waves wave-1 and wave
+  const uint8_t* xrow[XT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int64_t n = n0 + mt * 16 + i16;  // rows >= N-1 read the zero-padded copy of the last row (rows past N are never written)
+  for (int mt = 0; mt < XT; ++mt) {
+    const int64_t n = n0 + (SPLIT ? mt - MT : mt) * 16 + i16;  // rows >= N-1 read the zero-padded copy of the last row (rows past N are never written)
     xrow[mt] = (n >= L.N - 1 ? reinterpret_cast<const uint8_t*>(L.last_row) : reinterpret_cast<const uint8_t*>(L.X) + n * L.ldx) + 16 * kq;
   }
   const int8_t* vsrc = L.d.V2 + (size_t)r_begin * (2 * STEP_BYTES) + (size_t)lane * 16;
@@ -135,17 +149,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
   // hipcc's waitcnt insertion gives up on VGPR loads in flight across the flush's loops and stores (s_waitcnt vmcnt(0) at first use)
   auto issue_x = [&](int run) {
     const int rb = tab_rb[min(run, n_runs - 1)];
-    uint8_t* dst = xl + (size_t)(run % XSN) * (MT * 1024);
+    if (SPLIT) {  // tiles 0..MT-1 belong to wave - 1, whose stages precede this wave's
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[mt] + rb), (lptr_t)(dst + mt * 1024), 16, 0, 0);
+      for (int mt = 0; mt < XT; ++mt) {
+        uint8_t* dst = xl + (mt < MT ? -(XSN * MT * 1024) : 0) + (size_t)(run % XSN) * (MT * 1024) + (mt % MT) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(xrow[mt] + rb), (lptr_t)dst, 16, 0, 0);
+      }
+    } else {
+      uint8_t* dst = xl + (size_t)(run % XSN) * (MT * 1024);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[mt] + rb), (lptr_t)(dst + mt * 1024), 16, 0, 0);
+    }
   };
   auto issue_planes = [&](int step) {
     const int st = min(step, n_steps - 1);
     const int8_t* src = vsrc + (size_t)st * STEP_BYTES;
     uint8_t* vdst = vbuf + (size_t)(step % NBUF) * STEP_BYTES;
 #pragma unroll
-    for (int it = 0; it < PLD; ++it) {
-      const int kb = min(wave + it * WAVES, NKB - 1);
+    for (int it = 0; it < (SPLIT ? PLDS : PLD); ++it) {
+      const int kb = SPLIT ? min((wave >> 1) + it * (WAVES / 2), NKB - 1) : min(wave + it * WAVES, NKB - 1);
       __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kb * 1024), (lptr_t)(vdst + (size_t)kb * 1024), 16, 0, 0);
     }
   };
@@ -251,14 +273,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
   };
 
   // ---- prologue, in the steady state's issue order: X(0) .. X(XSN-1) | planes(0) | planes(1) ----
+  if (!SPLIT || xwave) {
 #pragma unroll
-  for (int p = 0; p < XSN; ++p) issue_x(p);
-  issue_planes(0);
-  issue_planes(1);
+    for (int p = 0; p < XSN; ++p) issue_x(p);
+  }
+  if (!SPLIT || !xwave) {
+    issue_planes(0);
+    issue_planes(1);
+  }
 
   for (int r = 0; r < n_runs; ++r) {
     // ---- even step 2r: the planes of the step and X(r) have landed; every wave is done with step 2r-1 ----
-    wait_vm<WAIT_EVEN>();
+    if (SPLIT) {
+      if (xwave) wait_vm<WAIT_XS>();
+      else wait_vm<PLDS>();
+    } else wait_vm<WAIT_EVEN>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -268,20 +297,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) xc[mt] = *reinterpret_cast<const v4i*>(xs + mt * 1024);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the run sits in registers: its stage is free
-    issue_x(r + XSN);
-    issue_planes(2 * r + D);
+    if (SPLIT) {
+      if (!xwave) issue_planes(2 * r + D);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the run sits in registers: its stage is free
+      issue_x(r + XSN);
+      issue_planes(2 * r + D);
+    }
     {
       const uint8_t* sb = vbuf + (size_t)((2 * r) % NBUF) * STEP_BYTES;
       mfma_entry(sb, xc, 0);
       mfma_entry(sb + ENTRY_BYTES, xc, 1);
     }
     // ---- odd step 2r+1 ----
-    wait_vm<WAIT_ODD>();
+    if (SPLIT) {
+      if (!xwave) wait_vm<PLDS>();
+    } else wait_vm<WAIT_ODD>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue_planes(2 * r + 1 + D);
+    if (SPLIT) {
+      if (xwave) issue_x(r + XSN);  // every wave has read X(r) out of this stage (before the barrier above)
+      else issue_planes(2 * r + 1 + D);
+    } else issue_planes(2 * r + 1 + D);
     {
       const uint8_t* sb = vbuf + (size_t)((2 * r + 1) % NBUF) * STEP_BYTES;
       mfma_entry(sb, xc, 2);
@@ -298,7 +336,7 @@ size_t lds_need(int A, int max_runs, int max_wins) {
          (size_t)3 * max_runs * sizeof(int) + (size_t)max_wins * (A + 1) * sizeof(double);
 }
 
-template <int MT, int NT, int WAVES, int XSN, int ZT>
+template <int MT, int NT, int WAVES, int XSN, int ZT, int SPLIT = 1>
 hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   BaseLRLaunch P = L;
   P.flags = tune.lr_flags;
@@ -331,9 +369,9 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
   const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
   P.wch = wch;
   P.n_htiles = (int)gx;
-  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2<%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d\n", MT, NT, WAVES, XSN, ZT, lds, (long long)(gx * n_ranges8), wch);
-  GNX_LDS_OPTIN(lds, k_base_logistic_p2<MT, NT, WAVES, XSN, ZT>);
-  hipLaunchKernelGGL((k_base_logistic_p2<MT, NT, WAVES, XSN, ZT>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
+  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2<%d,%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d\n", MT, NT, WAVES, XSN, ZT, SPLIT, lds, (long long)(gx * n_ranges8), wch);
+  GNX_LDS_OPTIN(lds, k_base_logistic_p2<MT, NT, WAVES, XSN, ZT, SPLIT>);
+  hipLaunchKernelGGL((k_base_logistic_p2<MT, NT, WAVES, XSN, ZT, SPLIT>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
   return hipGetLastError();
 }
 
@@ -344,29 +382,29 @@ hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gn
   if (L.N <= 0) return hipSuccess;
   if (!L.d.V2 || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
   const bool small = L.N <= 64 * 8;
-  const int tm = tune.lr_mt, tw = tune.lr_waves, tx = tune.lr_nbuf;  // GNX_LR_TUNE="mt,waves", GNX_LR_NBUF = X stages (development)
+  const int tm = tune.lr_mt, tw = tune.lr_waves, tx = tune.lr_nbuf;  // GNX_LR_TUNE="mt,waves", GNX_LR_NBUF = X stages + 10 * ZT + 100 * unsplit (development)
   switch (L.d.NT) {
     case 1:
-      if (tm == 2 && tw == 8 && tx == 1) return launch<2, 1, 8, 1, 1>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 2) return launch<2, 1, 8, 2, 1>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 3) return launch<2, 1, 8, 3, 1>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 16 && tx == 1) return launch<2, 1, 16, 1, 1>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 16 && tx == 2) return launch<2, 1, 16, 2, 1>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 4 && tx == 1) return launch<4, 1, 4, 1, 1>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 1) return launch<4, 1, 8, 1, 0>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 2) return launch<4, 1, 8, 2, 0>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 12) return launch<4, 1, 8, 2, 1>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 13) return launch<4, 1, 8, 3, 1>(L, n_cu, tune, s);
+      if (tm == 4 && tw == 8 && tx == 102) return launch<4, 1, 8, 2, 0, 0>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 1) return launch<2, 1, 8, 1, 0>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 2) return launch<2, 1, 8, 2, 0>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 3) return launch<2, 1, 8, 3, 0>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 12) return launch<2, 1, 8, 2, 1>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 102) return launch<2, 1, 8, 2, 0, 0>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 16 && tx == 2) return launch<2, 1, 16, 2, 0>(L, n_cu, tune, s);
       if (tm == 4 && tw == 4 && tx == 2) return launch<4, 1, 4, 2, 1>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 1) return launch<4, 1, 8, 1, 1>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 2) return launch<4, 1, 8, 2, 1>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 12) return launch<4, 1, 8, 2, 0>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 11) return launch<4, 1, 8, 1, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 12) return launch<2, 1, 8, 2, 0>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 3) return launch<4, 1, 8, 3, 1>(L, n_cu, tune, s);
       if (small) return launch<1, 1, 4, 2, 0>(L, n_cu, tune, s);
-      return launch<4, 1, 8, 2, 1>(L, n_cu, tune, s);
+      return launch<4, 1, 8, 2, 0>(L, n_cu, tune, s);
     case 2:
       if (tm == 1 && tw == 16 && tx == 2) return launch<1, 2, 16, 2, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 1) return launch<2, 2, 8, 1, 1>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 1) return launch<2, 2, 8, 1, 0>(L, n_cu, tune, s);
+      if (tm == 2 && tw == 8 && tx == 102) return launch<2, 2, 8, 2, 0, 0>(L, n_cu, tune, s);
       if (small) return launch<1, 2, 4, 2, 0>(L, n_cu, tune, s);
-      return launch<2, 2, 8, 2, 1>(L, n_cu, tune, s);
+      return launch<2, 2, 8, 2, 0>(L, n_cu, tune, s);
     default: return hipErrorNotSupported;
   }
 }
