@@ -31,6 +31,8 @@ struct gnx_tune {
                                         // column tiles (A > 8 at the default context), where it measured 2.5 vs 3.1 ms (A = 12,
                                         // chr22); with one column tile both kernels run at the same 1.14-1.16 ms
   int lr_nbuf = 0;                      // GNX_LR_NBUF: ring slots of the LDS-direct kernel
+  int p2_mt = 0, p2_cw = 0, p2_xsn = 0, p2_nbuf = 0, p2_old = 0;  // GNX_P2_TUNE="mt,compute waves,X stages,plane slots[,1 = k_base_logistic_p2]":
+                                        // shape of the 2-bit-native logistic pass (development)
   int lr_p2 = 1;                        // GNX_LR_P2=0: packed (2-bit) input is widened to int8 in HBM and run through the int8 kernels
                                         // instead of k_base_logistic_p2 (A/B runs; the outputs are bit-identical)
   int lr_flat = -1;                     // GNX_LR_FLAT: 1 = flat column tiles (k_base_logistic_i8_fl) wherever built, 0 = never

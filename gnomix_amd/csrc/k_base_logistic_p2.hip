@@ -148,6 +148,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
   // (lane-linear: the lane reads back exactly the 16 bytes it fetched), so that no register waits on a load the compiler tracks:
   // hipcc's waitcnt insertion gives up on VGPR loads in flight across the flush's loops and stores (s_waitcnt vmcnt(0) at first use)
   auto issue_x = [&](int run) {
+    if (L.flags & 8) return;
     const int rb = tab_rb[min(run, n_runs - 1)];
     if (SPLIT) {  // tiles 0..MT-1 belong to wave - 1, whose stages precede this wave's
 #pragma unroll
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
     }
   };
   auto issue_planes = [&](int step) {
+    if (L.flags & 16) return;
     const int st = min(step, n_steps - 1);
     const int8_t* src = vsrc + (size_t)st * STEP_BYTES;
     uint8_t* vdst = vbuf + (size_t)(step % NBUF) * STEP_BYTES;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
       else wait_vm<PLDS>();
     } else wait_vm<WAIT_EVEN>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(L.flags & 32)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     v4i xc[MT];
     {
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
       if (!xwave) wait_vm<PLDS>();
     } else wait_vm<WAIT_ODD>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(L.flags & 32)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (SPLIT) {
       if (xwave) issue_x(r + XSN);  // every wave has read X(r) out of this stage (before the barrier above)
@@ -328,6 +330,267 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L)
     flush(r);
   }
   wait_vm<0>();  // nothing of this block may still be writing LDS when it retires
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_base_logistic_p2w: the same pass with DEDICATED loader waves.  A wave that issues vector-memory instructions stalls at the issue
+// while the L1's miss queue is full, so in the kernel above the time the memory system needs for X (HBM-bound: ~0.3 ms of the 0.75
+// at config 2) was added to the issuing waves' MFMA and flush time instead of hiding behind it (ablations: loads only 0.38 ms, + MFMA
+// 0.15, + flush 0.2 = the full kernel).  Here CW compute waves never touch global memory except for the flush's stores; wave CW
+// issues every plane load, wave CW + 1 every X load (the rows of all compute waves), and the block barrier of each step publishes
+// what has landed:
+//   plane loader, step s:   vmcnt((D - 1) NKB), barrier, planes(s + D) into the slot step s - 1 left
+//   X loader, run r:        vmcnt((XSN - 1) CW MT), barrier(2r), barrier(2r + 1), X(r + XSN) into the stage every wave read at step 2r
+//   compute wave, run r:    barrier(2r), X(r) LDS -> registers, entries 0, 1, barrier(2r + 1), entries 2, 3, flush
+template <int MT, int NT, int CW, int XSN, int NBUF>
+__global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int EPS = 2;
+  constexpr int ENTRY_BYTES = NT * LIMBS * 1024;
+  constexpr int STEP_BYTES = EPS * ENTRY_BYTES;
+  constexpr int THREADS = (CW + 2) * 64;
+  constexpr int NKB = STEP_BYTES / 1024;
+  constexpr int D = NBUF - 1;
+  constexpr int ZROWS = MT * 16;
+  constexpr int XTILES = CW * MT;
+  static_assert((D - 1) * NKB < 64 && (XSN - 1) * XTILES < 64 && XSN >= 1 && D >= 1, "vmcnt is a 6-bit counter");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int A = L.A, W = L.W, R = L.d.R;
+  uint8_t* vbuf = lds;                                               // [NBUF][STEP_BYTES]
+  uint8_t* xl0 = vbuf + (size_t)NBUF * STEP_BYTES;                   // [XSN][CW][MT][64 lanes][16 B]
+  double* zb0 = reinterpret_cast<double*>(xl0 + (size_t)XSN * XTILES * 1024);
+  double* tab_ic = zb0 + (size_t)CW * ZROWS * A;   // [max_wins][A] intercepts
+  double* tab_sc = tab_ic + (size_t)L.max_wins * A;  // [max_wins] 2^-f_w
+  int* tab_rb = reinterpret_cast<int*>(tab_sc + L.max_wins);
+  int* tab_nfl = tab_rb + L.max_chunks;
+  int* tab_fl0 = tab_nfl + L.max_chunks;
+
+  int wrange, htile;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    wrange = xcd + 8 * (j / L.n_htiles);
+    htile = j % L.n_htiles;
+  }
+  const int wa = wrange * L.wch;
+  if (wa >= W) return;  // whole block exits before any barrier
+  const int wb = min(W, wa + L.wch);
+  const int r_begin = L.d.win_run0[wa];
+  const int r_end = L.d.win_run1[wb - 1];
+  const int n_runs = r_end - r_begin;
+  const int n_steps = 2 * n_runs;
+  const int64_t n0b = (int64_t)htile * (CW * MT * 16);  // first haplotype of the block
+
+  for (int e = tid; e < n_runs; e += THREADS) {
+    tab_rb[e] = L.d.run_byte[r_begin + e];
+    tab_nfl[e] = L.d.run_nflush[r_begin + e];
+    tab_fl0[e] = L.d.run_flush0[r_begin + e];
+  }
+  const int wt0 = max(0, wa - R - 1);
+  for (int e = tid; e < L.max_wins * A; e += THREADS) {
+    const int ew = e / A, a = e - ew * A;
+    tab_ic[e] = L.d.icpt[min(wt0 + ew, W - 1) * A + a];
+  }
+  for (int e = tid; e < L.max_wins; e += THREADS) tab_sc[e] = L.d.wscale[min(wt0 + e, W - 1)];
+  __syncthreads();
+  const int abl = L.flags;  // development ablations (GNX_LR_FLAGS, timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes
+
+  if (wave == CW) {
+    // ---- plane loader ----
+    const int8_t* vsrc = L.d.V2 + (size_t)r_begin * (2 * STEP_BYTES) + (size_t)lane * 16;
+    auto issue_planes = [&](int step) {
+      if (abl & 16) return;
+      const int8_t* src = vsrc + (size_t)min(step, n_steps - 1) * STEP_BYTES;
+      uint8_t* vdst = vbuf + (size_t)(step % NBUF) * STEP_BYTES;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kb * 1024), (lptr_t)(vdst + (size_t)kb * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < D; ++p) issue_planes(p);
+    for (int s = 0; s < n_steps; ++s) {
+      wait_vm<(D - 1) * NKB>();  // the planes of step s have landed (only those of s+1 .. s+D-1 are younger)
+      __builtin_amdgcn_s_barrier();
+      issue_planes(s + D);        // every compute wave is done with step s-1, whose slot this is
+    }
+    wait_vm<0>();
+    return;
+  }
+  if (wave == CW + 1) {
+    // ---- X loader: tile t = (compute wave t / MT, its tile t % MT); lane (row i16, 16 packed bytes kq) as in the compute waves ----
+    const uint8_t* xrow[XTILES];
+#pragma unroll
+    for (int t = 0; t < XTILES; ++t) {
+      const int64_t n = n0b + t * 16 + i16;  // rows >= N-1 read the zero-padded copy of the last row (rows past N are never written)
+      xrow[t] = (n >= L.N - 1 ? reinterpret_cast<const uint8_t*>(L.last_row) : reinterpret_cast<const uint8_t*>(L.X) + n * L.ldx) + 16 * kq;
+    }
+    auto issue_x = [&](int run) {
+      if (abl & 8) return;
+      const int rb = tab_rb[min(run, n_runs - 1)];
+      uint8_t* dst = xl0 + (size_t)(run % XSN) * (XTILES * 1024);
+#pragma unroll
+      for (int t = 0; t < XTILES; ++t) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[t] + rb), (lptr_t)(dst + t * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < XSN; ++p) issue_x(p);
+    for (int r = 0; r < n_runs; ++r) {
+      wait_vm<(XSN - 1) * XTILES>();  // X(r) has landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // step 2r
+      __builtin_amdgcn_s_barrier();   // step 2r+1: every compute wave has X(r) in registers
+      issue_x(r + XSN);
+    }
+    wait_vm<0>();
+    return;
+  }
+
+  // ---- compute waves ----
+  const int64_t n0 = n0b + (int64_t)wave * (MT * 16);
+  double* zb = zb0 + (size_t)wave * ZROWS * A;
+  v4i acc[MT][NT][LIMBS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int l = 0; l < LIMBS; ++l) acc[mt][nt][l] = v4i{0, 0, 0, 0};
+
+  auto mfma_entry = [&](const uint8_t* pb, const v4i (&xc)[MT], int k) {
+    if (abl & 2) return;
+    v4i xa[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xc[mt][k]);
+    const v4i* vb = reinterpret_cast<const v4i*>(pb) + lane;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int l = 0; l < LIMBS; ++l) {
+        const v4i b = vb[(nt * LIMBS + l) * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][nt][l], 0, 0, 0);
+      }
+  };
+
+  // the epilogue of k_base_logistic_p2 (same three phases, same arithmetic: bit-identical B)
+  constexpr int LPR = 64 / ZROWS;
+  const int frow = lane % ZROWS, fsub = lane / ZROWS;
+  const int e_r0 = lane / A, e_a0 = lane - e_r0 * A, e_dr = 64 / A, e_da = 64 - e_dr * A;
+  auto emit = [&](int w) {
+    double* zr = zb + frow * A;
+    if (!(abl & 1)) {
+      const double* ic = tab_ic + (w - wt0) * A;
+      for (int a = fsub; a < A; a += LPR) zr[a] = 1.0 / (1.0 + exp(-(zr[a] + ic[a])));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double sum = 0.0;
+      for (int c = 0; c < A; ++c) sum += zr[c];
+      for (int a = fsub; a < A; a += LPR) zr[a] = zr[a] / sum;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    int rl = e_r0, a = e_a0;
+    const size_t ow = (size_t)w * A;
+    for (int e = lane; e < ZROWS * A; e += 64) {
+      const int64_t n = n0 + rl;
+      if (n < L.N) {
+        const size_t o = (size_t)n * W * A + ow + a;
+        const double v = zb[e];
+        if (L.b64) L.b64[o] = v;
+        if (L.b32) L.b32[o] = (float)v;
+      }
+      a += e_da; rl += e_dr;
+      if (a >= A) { a -= A; ++rl; }
+    }
+  };
+  auto flush = [&](int rl) {
+    const int nfl = tab_nfl[rl];
+    if (nfl <= 0 || (abl & 4)) return;
+    const int w0 = tab_fl0[rl];
+    for (int w = w0; w < w0 + nfl; ++w) {
+      const int cbase = (w % R) * A;
+      const double scale = tab_sc[w - wt0];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = nt * 16 + i16 - cbase;
+          const bool mine = (col >= 0) && (col < A);
+          if (mine) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)  // int32 16x16 C/D layout: column = lane&15, row = 4*(lane>>4) + reg
+              zb[(mt * 16 + 4 * kq + r) * A + col] = combine(acc[mt][nt], r, scale);
+          }
+#pragma unroll
+          for (int l = 0; l < LIMBS; ++l)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][nt][l][r] = mine ? 0 : acc[mt][nt][l][r];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zb is wave-private: LDS ops of one wave complete in order
+      if (w >= wa && w < wb) emit(w);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+
+  for (int r = 0; r < n_runs; ++r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // step 2r: its planes and X(r) are in LDS
+    asm volatile("" ::: "memory");
+    v4i xc[MT];
+    {
+      const uint8_t* xs = xl0 + (size_t)(r % XSN) * (XTILES * 1024) + (size_t)wave * (MT * 1024) + lane * 16;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xc[mt] = *reinterpret_cast<const v4i*>(xs + mt * 1024);
+    }
+    {
+      const uint8_t* sb = vbuf + (size_t)((2 * r) % NBUF) * STEP_BYTES;
+      mfma_entry(sb, xc, 0);
+      mfma_entry(sb + ENTRY_BYTES, xc, 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // step 2r+1
+    asm volatile("" ::: "memory");
+    {
+      const uint8_t* sb = vbuf + (size_t)((2 * r + 1) % NBUF) * STEP_BYTES;
+      mfma_entry(sb, xc, 2);
+      mfma_entry(sb + ENTRY_BYTES, xc, 3);
+    }
+    flush(r);
+  }
+}
+
+template <int MT, int NT, int CW, int XSN, int NBUF>
+hipError_t launch_w(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
+  BaseLRLaunch P = L;
+  P.flags = tune.lr_flags;
+  const int haps_per_block = CW * MT * 16;
+  const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
+  const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : 4;
+  int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
+  want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
+  if (tune.lr_want > 0) want = tune.lr_want;
+  int wch = 0, n_ranges = 0;
+  size_t lds = 0;
+  for (;; want += 8) {
+    wch = (int)((L.W + want - 1) / want);
+    if (wch < 4) wch = 4;
+    n_ranges = (L.W + wch - 1) / wch;
+    int max_runs = 0;
+    for (int r = 0; r < n_ranges; ++r) {
+      const int wa = r * wch, wb = std::min(L.W, wa + wch);
+      max_runs = std::max(max_runs, L.h_win_chunk1[(size_t)wb - 1] - L.h_win_chunk0[(size_t)wa]);
+    }
+    P.max_chunks = max_runs + 8;
+    P.max_wins = wch + 2 * L.d.R + 4;
+    lds = (size_t)NBUF * (2 * NT * LIMBS * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)CW * MT * 16 * L.A * sizeof(double) +
+          (size_t)3 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
+    if (lds <= (size_t)160 * 1024 || wch == 4) break;
+  }
+  if (lds > (size_t)160 * 1024) return hipErrorNotSupported;
+  const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
+  P.wch = wch;
+  P.n_htiles = (int)gx;
+  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2w<%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d\n", MT, NT, CW, XSN, NBUF, lds, (long long)(gx * n_ranges8), wch);
+  GNX_LDS_OPTIN(lds, k_base_logistic_p2w<MT, NT, CW, XSN, NBUF>);
+  hipLaunchKernelGGL((k_base_logistic_p2w<MT, NT, CW, XSN, NBUF>), dim3((unsigned)(gx * n_ranges8)), dim3((CW + 2) * 64), lds, s, P);
+  return hipGetLastError();
 }
 
 template <int MT, int NT, int WAVES, int XSN, int ZT>
@@ -382,29 +645,38 @@ hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gn
   if (L.N <= 0) return hipSuccess;
   if (!L.d.V2 || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
   const bool small = L.N <= 64 * 8;
-  const int tm = tune.lr_mt, tw = tune.lr_waves, tx = tune.lr_nbuf;  // GNX_LR_TUNE="mt,waves", GNX_LR_NBUF = X stages + 10 * ZT + 100 * unsplit (development)
+  const int tm = tune.p2_mt, tw = tune.p2_cw, tx = tune.p2_xsn, tb = tune.p2_nbuf ? tune.p2_nbuf : 3;
+#define GNX_P2W(MT_, NT_, CW_, XS_, NB_) \
+  if (tm == MT_ && tw == CW_ && tx == XS_ && tb == NB_) return launch_w<MT_, NT_, CW_, XS_, NB_>(L, n_cu, tune, s);
+#define GNX_P2O(MT_, NT_, WV_, XS_, ZT_, SP_) \
+  if (tm == MT_ && tw == WV_ && tx == XS_ && tb == 10 * ZT_ + SP_) return launch<MT_, NT_, WV_, XS_, ZT_, SP_>(L, n_cu, tune, s);
   switch (L.d.NT) {
     case 1:
-      if (tm == 4 && tw == 8 && tx == 1) return launch<4, 1, 8, 1, 0>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 2) return launch<4, 1, 8, 2, 0>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 12) return launch<4, 1, 8, 2, 1>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 13) return launch<4, 1, 8, 3, 1>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 8 && tx == 102) return launch<4, 1, 8, 2, 0, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 1) return launch<2, 1, 8, 1, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 2) return launch<2, 1, 8, 2, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 3) return launch<2, 1, 8, 3, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 12) return launch<2, 1, 8, 2, 1>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 102) return launch<2, 1, 8, 2, 0, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 16 && tx == 2) return launch<2, 1, 16, 2, 0>(L, n_cu, tune, s);
-      if (tm == 4 && tw == 4 && tx == 2) return launch<4, 1, 4, 2, 1>(L, n_cu, tune, s);
-      if (small) return launch<1, 1, 4, 2, 0>(L, n_cu, tune, s);
-      return launch<4, 1, 8, 2, 0>(L, n_cu, tune, s);
+      if (tune.p2_old) {  // k_base_logistic_p2: every wave loads and multiplies (nbuf field = 10 * ZT + SPLIT)
+        GNX_P2O(4, 1, 8, 2, 0, 1) GNX_P2O(4, 1, 8, 2, 0, 0) GNX_P2O(2, 1, 8, 3, 0, 1) GNX_P2O(2, 1, 8, 2, 0, 0)
+        return hipErrorInvalidValue;
+      }
+      if (tm) {
+        GNX_P2W(2, 1, 8, 2, 3) GNX_P2W(2, 1, 8, 3, 3) GNX_P2W(2, 1, 8, 4, 3) GNX_P2W(2, 1, 8, 4, 4) GNX_P2W(2, 1, 8, 3, 4)
+        GNX_P2W(2, 1, 10, 3, 3) GNX_P2W(2, 1, 12, 3, 3) GNX_P2W(2, 1, 14, 3, 3) GNX_P2W(2, 1, 14, 2, 3) GNX_P2W(2, 1, 12, 2, 4)
+        GNX_P2W(4, 1, 6, 2, 3) GNX_P2W(4, 1, 6, 3, 3) GNX_P2W(1, 1, 14, 4, 3)
+        return hipErrorInvalidValue;
+      }
+      if (small) return launch_w<1, 1, 4, 2, 3>(L, n_cu, tune, s);
+      return launch_w<2, 1, 8, 4, 4>(L, n_cu, tune, s);
     case 2:
-      if (tm == 1 && tw == 16 && tx == 2) return launch<1, 2, 16, 2, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 1) return launch<2, 2, 8, 1, 0>(L, n_cu, tune, s);
-      if (tm == 2 && tw == 8 && tx == 102) return launch<2, 2, 8, 2, 0, 0>(L, n_cu, tune, s);
-      if (small) return launch<1, 2, 4, 2, 0>(L, n_cu, tune, s);
-      return launch<2, 2, 8, 2, 0>(L, n_cu, tune, s);
+      if (tune.p2_old) {
+        GNX_P2O(2, 2, 8, 2, 0, 1) GNX_P2O(2, 2, 8, 2, 0, 0) GNX_P2O(1, 2, 16, 2, 0, 1)
+        return hipErrorInvalidValue;
+      }
+      if (tm) {
+        GNX_P2W(2, 2, 6, 2, 3) GNX_P2W(2, 2, 6, 3, 3) GNX_P2W(1, 2, 8, 4, 3) GNX_P2W(1, 2, 14, 4, 3) GNX_P2W(1, 2, 14, 3, 3) GNX_P2W(1, 2, 12, 4, 3)
+        return hipErrorInvalidValue;
+      }
+      if (small) return launch_w<1, 2, 4, 2, 3>(L, n_cu, tune, s);
+      return launch_w<2, 2, 6, 3, 3>(L, n_cu, tune, s);
     default: return hipErrorNotSupported;
   }
+#undef GNX_P2W
+#undef GNX_P2O
 }

@@ -66,7 +66,7 @@ def bench(C, M, A, N, label):
     t_p2 = timeit(lambda: dev.base_predict_packed_device(Pt))
     same = torch.equal(dev.base_predict_device(Xt), dev.base_predict_packed_device(Pt))
     print(f"{label}: load {t_load:.2f} s  int8 {t_i8:.3f} ms  p2 {t_p2:.3f} ms  ({N * C / 4 / t_p2 / 1e6:.1f} GB/s of 2-bit X, {N * C / t_i8 / 1e6:.1f} GB/s of int8 X)  identical={same}  "
-          f"tune={os.environ.get('GNX_LR_TUNE', '-')} bpc={os.environ.get('GNX_LR_BPC', '-')}", flush=True)
+          f"tune={os.environ.get('GNX_P2_TUNE', '-')} bpc={os.environ.get('GNX_LR_BPC', '-')}", flush=True)
 
 
 if __name__ == "__main__":
@@ -76,6 +76,8 @@ if __name__ == "__main__":
         print("CHECK", "FAILED" if bad else "PASSED")
     if mode in ("all", "bench"):
         bench(370500, 1000, 7, 10000, "config2 chr22 A=7")
+    if mode in ("aligned",):
+        bench(379392, 1024, 7, 10000, "aligned M=1024 C=379392")
     if mode in ("bench12",):
         bench(370500, 1000, 12, 16384, "chr22 A=12")
     if mode in ("c5",):

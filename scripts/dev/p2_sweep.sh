@@ -1,3 +1,3 @@
 python scripts/dev/p2_check.py check 2>&1 | tail -1
-for c in "4,8,1" "4,8,2" "4,8,13" "4,8,102" "2,8,2" "2,8,3" "2,8,102"; do IFS=, read m w x <<< "$c"; for f in 0 6; do GNX_LR_NBUF=$x GNX_LR_FLAGS=$f GNX_LR_TUNE=$m,$w GNX_LR_BPC=4 python scripts/dev/p2_check.py bench 2>&1 | grep config2 | sed "s/^/xsn=$x flags=$f /" | cut -c1-150; done; done
-GNX_PMC_SETS=tcp python scripts/dev/pmc.py 'k_base_logistic_p2' -- python scripts/dev/p2_check.py bench 2>&1 | grep -v "^   derived" | cut -c1-400
+for c in "2,8,4,4" "2,8,3,4" "2,10,3,3" "2,12,3,3" "2,14,3,3" "2,14,2,3" "2,12,2,4" "4,6,2,3" "4,6,3,3" "1,14,4,3"; do for b in 2 4; do GNX_P2_TUNE=$c GNX_LR_BPC=$b python scripts/dev/p2_check.py bench 2>&1 | grep -E "config2|rror" | cut -c1-175; done; done
+for c in "2,6,2,3" "2,6,3,3" "1,8,4,3" "1,14,4,3" "1,14,3,3" "1,12,4,3"; do GNX_P2_TUNE=$c python scripts/dev/p2_check.py bench12 2>&1 | grep -E "chr22|rror" | cut -c1-175; done
