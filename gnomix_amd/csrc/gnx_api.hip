@@ -104,7 +104,7 @@ static void read_tune(gnx_tune& t) {
   t.lr_ws_pw = geti("GNX_LR_WS_PW", 2);
   t.lr_nbuf = geti("GNX_LR_NBUF", 0);
   t.lr_p2 = geti("GNX_LR_P2", 1);
-  if (const char* e = std::getenv("GNX_P2_TUNE")) std::sscanf(e, "%d,%d,%d,%d,%d", &t.p2_mt, &t.p2_cw, &t.p2_xsn, &t.p2_nbuf, &t.p2_old);
+  if (const char* e = std::getenv("GNX_P2_TUNE")) std::sscanf(e, "%d,%d,%d,%d,%d", &t.p2_mt, &t.p2_cw, &t.p2_ew, &t.p2_xsn, &t.p2_nbuf);
   t.sm_nw = geti("GNX_SM_NW", 0);
   t.sm_pair = geti("GNX_SM_PAIR", 1);
   if (const char* e = std::getenv("GNX_SM_TUNE")) std::sscanf(e, "%d,%d", &t.smf_rpl, &t.smf_nw);

@@ -31,7 +31,7 @@ struct gnx_tune {
                                         // column tiles (A > 8 at the default context), where it measured 2.5 vs 3.1 ms (A = 12,
                                         // chr22); with one column tile both kernels run at the same 1.14-1.16 ms
   int lr_nbuf = 0;                      // GNX_LR_NBUF: ring slots of the LDS-direct kernel
-  int p2_mt = 0, p2_cw = 0, p2_xsn = 0, p2_nbuf = 0, p2_old = 0;  // GNX_P2_TUNE="mt,compute waves,X stages,plane slots[,1 = k_base_logistic_p2]":
+  int p2_mt = 0, p2_cw = 0, p2_ew = 0, p2_xsn = 0, p2_nbuf = 0;  // GNX_P2_TUNE="mt,compute waves,epilogue waves,X stages,plane slots":
                                         // shape of the 2-bit-native logistic pass (development)
   int lr_p2 = 1;                        // GNX_LR_P2=0: packed (2-bit) input is widened to int8 in HBM and run through the int8 kernels
                                         // instead of k_base_logistic_p2 (A/B runs; the outputs are bit-identical)
@@ -124,6 +124,7 @@ struct BaseLRDev {
   const int32_t* win_run0 = nullptr;     // [W] first run a block must start from to compute window w
   const int32_t* win_run1 = nullptr;     // [W] one past the run after which window w is flushed
   int32_t n_runs = 0;
+  int32_t NT2 = 0;   // column tiles of V2: 1 (column = slot * A + class, R * A <= 16) or R (one tile per slot, column = class; A <= 16)
 };
 
 struct BaseLRLaunch {
@@ -135,6 +136,7 @@ struct BaseLRLaunch {
   const int32_t* h_win_chunk1;
   int32_t W, A, wch;    // wch = windows per block
   int32_t n_htiles;     // i8 path: haplotype tiles (1-D XCD-aware grid)
+  int32_t n_rg8;        // 2-bit pass: groups of 8 window ranges (the grid holds NT2 passes of n_rg8 * 8 ranges x n_htiles tiles)
   int32_t flags;        // development ablation switches (0 in production)
   int32_t max_chunks;   // i8 path: upper bound of chunks one block walks (sizes its LDS tables)
   int32_t max_wins;     // i8 path: upper bound of windows one block may flush

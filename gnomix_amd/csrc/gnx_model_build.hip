@@ -185,8 +185,16 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
     // lane, whose in-register unpack puts SNP field f = 4 (t & 3) + (t >> 2) at k position t: k position (kq, t) of entry k of a run
     // starting at SNP s is SNP  s + 64 kq + 16 k + 4 (t & 3) + (t >> 2).  Same folded weights, same f_w, same digits as V8.
     {
-      const char* p2env = std::getenv("GNX_LR_P2");
-      const bool want_p2 = NT <= 2 && !(p2env && std::atoi(p2env) == 0);
+      // column tiles of the 2-bit pass: one tile (column = slot * A + class, as in V8) when the R * A class columns of a SNP fit 16;
+      // otherwise one tile PER SLOT (column = class) and one pass per tile (k_base_logistic_p2.hip)
+      const int NT2 = NC <= 16 ? 1 : (A <= 16 ? (int)R : 0);
+      const int64_t cs2 = NT2 == 1 ? A : 16;
+      const char* p2env = std::getenv("GNX_LR_P2");  // 0: never build the planes; 2: build them whatever the padding costs (tests)
+      const int p2mode = p2env ? std::atoi(p2env) : 1;
+      // runs are 256 SNPs: short pieces (small windows) would multiply mostly padding — such models keep the int8 kernels
+      int64_t padded = 0;
+      for (size_t k = 0; k < n_pieces; ++k) padded += ((bounds[k + 1] - (bounds[k] & ~(int64_t)15) + 255) / 256) * 256;
+      const bool want_p2 = NT2 > 0 && p2mode != 0 && (p2mode == 2 || padded * 4 <= C * 5);
       if (want_p2) {
         std::vector<int32_t> run_byte, run_flush0, run_nflush, piece_run0(n_pieces + 1);
         std::vector<int64_t> run_s, run_b0, run_b1;
@@ -220,7 +228,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
           const size_t kf = (size_t)(std::lower_bound(bounds.begin(), bounds.end(), fpos[(size_t)i]) - bounds.begin());
           win_run1[(size_t)i] = piece_run0[kf];
         }
-        const size_t entry_bytes = (size_t)NT * 7 * 64 * 16;
+        const size_t entry_bytes = (size_t)NT2 * 7 * 64 * 16;
         std::vector<int8_t> V2(n_runs * 4 * entry_bytes, 0);
         auto fill_runs = [&](size_t r_lo, size_t r_hi) {
           std::vector<double> wsum((size_t)A);
@@ -251,12 +259,12 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
                           got = true;
                         }
                       if (!got || acc == 0.0) continue;
-                      const int64_t col = slot * A + a;
+                      const int64_t col = slot * cs2 + a;
                       const int nt = (int)(col / 16), c16 = (int)(col % 16);
                       long long q = std::llrint(std::ldexp(acc, fexp[(size_t)i]));
                       for (int l = 0; l < 7; ++l) {
                         const long long dg = (l < 6) ? ((((q + 128) % 256) + 256) % 256) - 128 : q;
-                        V2[((((r * 4 + (size_t)k) * NT + (size_t)nt) * 7 + (size_t)l) * 64 + (size_t)(kq * 16 + c16)) * 16 + (size_t)t] = (int8_t)dg;
+                        V2[((((r * 4 + (size_t)k) * NT2 + (size_t)nt) * 7 + (size_t)l) * 64 + (size_t)(kq * 16 + c16)) * 16 + (size_t)t] = (int8_t)dg;
                         q = (q - dg) / 256;
                       }
                     }
@@ -285,6 +293,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
         m->lr_h_win_run0 = win_run0;
         m->lr_h_win_run1 = win_run1;
         m->lr.n_runs = (int32_t)n_runs;
+        m->lr.NT2 = NT2;
       }
     }
   } else if ((rc = gnx_dev_upload(m, V, &m->lr.V)) != GNX_OK) return rc;

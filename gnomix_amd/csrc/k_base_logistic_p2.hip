@@ -1,23 +1,38 @@
-// k_base_logistic_p2.hip — the exact int8 logistic pass on 2-BIT haplotype rows (gfx950).
+// k_base_logistic_p2.hip — the exact int8 logistic pass on 2-BIT haplotype rows, wave-specialised (gfx950).
 //
-// Same contract, arithmetic (7 balanced base-256 limbs on v_mfma_i32_16x16x64_i8, one float64 rounding), column slots, pieces,
-// flush epilogue and XCD-aware grid as k_base_logistic_i8.hip / k_base_logistic_i8_dl.hip (reference src/Base/base.py:146-180,
-// src/Base/models.py:12-21; X values per src/utils.py:153) — B is BIT-IDENTICAL to theirs.  What differs is where X lives:
-// the int8 kernels are bound by the L1's miss queue (5.05 GB of L1 fill per launch, 3.45 GB of it X); here
-//   * X stays packed in HBM, four SNPs per byte (the gnx_pack_x layout: SNP j = bits 2(j%4).. of byte j/4): a quarter of the fill;
-//   * a lane fetches 16 packed bytes = 64 SNPs of ONE haplotype row per load, the four lanes of a row (lane>>4 = 0..3) cover 64
-//     contiguous bytes = one RUN of 256 SNPs, 16 rows per wave instruction — no X tile in LDS at all: a wave owns its rows, and
-//     which SNP sits at which k position of the MFMA is the weight planes' business (they are laid out to match at model load);
-//   * a 32-bit word (16 SNPs) becomes the 16 int8 bytes of the MFMA A operand in 7 VALU operations:
-//         reg d = (word >> 2d) & 0x03030303        (d = 0..3; byte b of reg d = field 4b + d)
-//     — the VALU was 22 % busy, the matrix pipe 15 %;
-//   * pieces start on a 32-bit boundary of the packed row: a piece [b0, b1) is walked from SNP b0 & ~15 in runs of 256 SNPs (4 MFMA
-//     entries), the up to 15 SNPs before b0 and everything from b1 on meet zero weights (M = 1000, context 500: 500 + 12 SNPs = exactly
-//     two runs); windows are flushed after the last run of their piece.  Loads that are not dword-aligned are split by the texture
-//     addresser (~4.5 L1 tag accesses per lane instead of ~0.5: the first version, byte-aligned, ran at the L1's tag rate);
-//   * the digit planes go L2 -> LDS directly (global_load_lds_dwordx4) through an NBUF-deep ring of half-runs (2 entries), ONE block
-//     barrier per half-run, exactly as in k_base_logistic_i8_dl.hip; X is two register stages (run r in use, run r+1 in flight; the
-//     loads of run r+2 are issued the moment the last word of run r has been unpacked).
+// Same contract, arithmetic (7 balanced base-256 limbs on v_mfma_i32_16x16x64_i8, one float64 rounding), pieces, window flush and
+// XCD-aware grid as k_base_logistic_i8.hip / k_base_logistic_i8_dl.hip (reference src/Base/base.py:146-180,
+// src/Base/models.py:12-21; X values per src/utils.py:153) — B is BIT-IDENTICAL to theirs.  What differs:
+//
+//  * X stays packed in HBM, four SNPs per byte (the gnx_pack_x layout: SNP j = bits 2(j%4).. of byte j/4).  The int8 kernels are
+//    bound by the L1's miss queue (5.05 GB of L1 fill per launch at config 2, 3.45 GB of it X); this is a quarter of the X bytes.
+//  * A lane fetches 16 packed bytes = 64 SNPs of ONE haplotype row, the four lanes of a row (lane>>4) cover 64 contiguous bytes = one
+//    RUN of 256 SNPs, 16 rows per wave instruction, HBM -> LDS directly (global_load_lds_dwordx4, lane-linear: a compute lane reads
+//    back the 16 bytes "its" loader lane fetched).  A 32-bit word (16 SNPs) becomes the 16 int8 bytes of the MFMA A operand in 7 VALU
+//    operations:  reg d = (word >> 2d) & 0x03030303  (byte b of reg d = field 4b + d) — which SNP sits at which k position of the
+//    MFMA is the weight planes' business: they are laid out to match at model load (gnx_build_lr, V2).
+//  * Pieces start on a 32-bit boundary of the packed row: a piece [b0, b1) is walked from SNP b0 & ~15 in runs of 256 SNPs (4 MFMA
+//    entries = 2 plane steps); the up to 15 SNPs before b0 and everything from b1 on meet zero weights (M = 1000, context 500:
+//    500 + 12 SNPs = exactly two runs).  Loads that are not dword-aligned are split by the texture addresser (~4.5 L1 tag accesses
+//    per lane instead of ~0.5: the first, byte-aligned version ran at the L1's tag rate).
+//  * ROLES.  A wave that issues vector-memory instructions stalls at the issue while the L1's miss queue is full, and vmcnt retires
+//    in order; with every wave loading and multiplying, the memory time (~0.38 ms of loads at config 2), the MFMA time (0.15) and the
+//    epilogue's float64 VALU time (0.2) simply added up (0.75 ms; ablations in DESIGN.md).  Here a block is
+//        CW compute waves     LDS -> registers, unpack, MFMA; at a window's end: accumulators -> exact logits z in LDS, nothing else
+//        EW epilogue waves    z -> sigmoid, row normaliser, division, coalesced stores to B — float64 VALU work that now runs on the
+//                             SIMD's vector pipe WHILE the compute waves keep the matrix pipe busy, spread over the steps until the
+//                             next window ends (two z buffers)
+//        1 plane loader       the digit planes of step s+D, L2 -> LDS ring of NBUF half-runs
+//        1 X loader           the runs of ALL compute waves' rows, XSN stages ahead
+//    and ONE block barrier per step publishes whatever has landed / been parked:
+//        plane loader, step s:  vmcnt((D-1) NKB), barrier, planes(s+D) into the slot step s-1 left
+//        X loader, run r:       vmcnt((XSN-1) CW MT), barrier(2r), barrier(2r+1), X(r+XSN) into the stage every wave read at step 2r
+//        compute wave, run r:   barrier(2r), X(r) LDS -> registers, entries 0, 1, barrier(2r+1), entries 2, 3, park finished windows
+//        epilogue wave:         barrier, its share of the parked window, barrier, ...
+//  * COLUMN TILES.  Up to 16 class columns per SNP (R A <= 16, e.g. A = 7 at the default context): one tile, column = slot A + class,
+//    as in the int8 kernels.  More (A = 12: 24 columns): one tile PER SLOT (column = class) and one PASS per tile — blocks of pass t
+//    multiply only tile t and finish only the windows w with w % R == t, so every pass is the one-tile kernel (256 rows per block, 119
+//    VGPRs) and X is read R times, at a quarter byte per SNP (the two-tile int8 kernels need 112 accumulator registers per 32 rows).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -59,319 +74,51 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// MT 16-row tiles per wave, NT column tiles, WAVES waves per block, XSN LDS stages of X runs in flight, ZT = 1: the flush goes
-// through a 16-row scratch one tile at a time (a quarter of the epilogue rows in LDS), 0: all MT tiles at once.
-// Plane ring: 3 slots of one half-run (2 entries) each.
-template <int MT, int NT, int WAVES, int XSN, int ZT, int SPLIT>
-__global__ __launch_bounds__(WAVES * 64) void k_base_logistic_p2(BaseLRLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  constexpr int NBUF = 3;
-  constexpr int EPS = 2;                          // MFMA entries per plane step (half a run)
-  constexpr int ENTRY_BYTES = NT * LIMBS * 1024;  // digit planes of one entry (64 k positions)
-  constexpr int STEP_BYTES = EPS * ENTRY_BYTES;
-  constexpr int THREADS = WAVES * 64;
-  constexpr int NKB = STEP_BYTES / 1024;          // 1 KB plane blocks per step
-  constexpr int PLD = (NKB + WAVES - 1) / WAVES;  // plane loads per wave per step
-  constexpr int D = NBUF - 1;                     // plane steps in flight beyond the one being multiplied
-  constexpr int ZROWS = ZT ? 16 : MT * 16;        // rows of the wave's epilogue scratch
-  // Issue order per run r (every wave, unconditional, clamped):  X(r+XSN) | planes(2r+2) | planes(2r+3).  When a wave waits for the
-  // planes of the even step 2r, the only younger vector-memory instructions are the planes of 2r+1; for the odd step 2r+1 they are
-  // X(r+XSN) and the planes of 2r+2.  X(r) is older than the planes of step 2r (XSN >= 1), so the even wait covers it too.
-  constexpr int WAIT_EVEN = PLD, WAIT_ODD = PLD + MT;
-  static_assert(XSN >= 1 && WAIT_ODD < 64, "vmcnt is a 6-bit counter");
-  // SPLIT = 1: the two streams are issued by DIFFERENT waves, because vmcnt retires in order: a wave that waits for its planes of
-  // step s also waits for every X load it issued before them, so with both streams in one wave X never gets more than ~one run of
-  // lead however many stages it has (measured: 1, 2 and 3 stages run the same 0.53 ms skeleton).  Even waves issue all plane loads,
-  // odd waves issue the X runs of themselves and of their even neighbour; the block barrier of every step publishes both.
-  //   even wave, any step s:   planes(s) were issued two steps ago, only the planes of s+1 are younger     -> vmcnt(PLDS)
-  //   odd wave, even step 2r:  X(r+XSN) is issued at step 2r+1, so X(r+1) .. X(r+XSN-1) are younger than X(r) -> vmcnt((XSN-1) 2 MT)
-  // X(r+XSN) goes into the stage of X(r) one barrier after every wave has read it: 2 XSN - 1 steps of lead.
-  constexpr int PLDS = (NKB + WAVES / 2 - 1) / (WAVES / 2);
-  constexpr int WAIT_XS = (XSN - 1) * 2 * MT;
-  static_assert(!SPLIT || (WAIT_XS < 64 && WAVES % 2 == 0), "vmcnt is a 6-bit counter");
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool xwave = SPLIT && (wave & 1);
-  const int i16 = lane & 15, kq = lane >> 4;
-  const int A = L.A, W = L.W, R = L.d.R;
-  uint8_t* vbuf = lds;                                                           // [NBUF][STEP_BYTES]
-  uint8_t* xl = vbuf + (size_t)NBUF * STEP_BYTES + (size_t)wave * (XSN * MT * 1024);  // [WAVES][XSN][MT][64 lanes][16 B], wave-private
-  double* zb0 = reinterpret_cast<double*>(vbuf + (size_t)NBUF * STEP_BYTES + (size_t)WAVES * XSN * MT * 1024);
-  double* zb = zb0 + (size_t)wave * ZROWS * A;
-  double* tab_ic = zb0 + (size_t)WAVES * ZROWS * A;  // [max_wins][A] intercepts
-  double* tab_sc = tab_ic + (size_t)L.max_wins * A;   // [max_wins] 2^-f_w
-  int* tab_rb = reinterpret_cast<int*>(tab_sc + L.max_wins);
-  int* tab_nfl = tab_rb + L.max_chunks;
-  int* tab_fl0 = tab_nfl + L.max_chunks;
-
-  // XCD-aware decomposition: all blocks of one window range on ONE XCD (its L2 serves the range's digit planes)
-  int wrange, htile;
-  {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, j = b >> 3;
-    wrange = xcd + 8 * (j / L.n_htiles);
-    htile = j % L.n_htiles;
-  }
-  const int wa = wrange * L.wch;
-  if (wa >= W) return;  // whole block exits before any barrier
-  const int wb = min(W, wa + L.wch);
-  const int r_begin = L.d.win_run0[wa];
-  const int r_end = L.d.win_run1[wb - 1];
-  const int n_runs = r_end - r_begin;
-  const int n_steps = 2 * n_runs;
-  const int64_t n0 = (int64_t)htile * (WAVES * MT * 16) + (int64_t)wave * (MT * 16);  // first haplotype of the wave
-
-  for (int e = tid; e < n_runs; e += THREADS) {
-    tab_rb[e] = L.d.run_byte[r_begin + e];
-    tab_nfl[e] = L.d.run_nflush[r_begin + e];
-    tab_fl0[e] = L.d.run_flush0[r_begin + e];
-  }
-  const int wt0 = max(0, wa - R - 1);
-  for (int e = tid; e < L.max_wins; e += THREADS) {
-    const int w = min(wt0 + e, W - 1);
-    tab_sc[e] = L.d.wscale[w];
-    for (int a = 0; a < A; ++a) tab_ic[e * A + a] = L.d.icpt[w * A + a];
-  }
-  __syncthreads();
-
-  // the lane's rows: tile mt, row i16; its 16 bytes of a run = packed bytes [16 kq, 16 kq + 16) of the run
-  constexpr int XT = SPLIT ? 2 * MT : MT;  // tiles a loading wave fetches: SPLIT: those of waves wave-1 and wave
-  const uint8_t* xrow[XT];
-#pragma unroll
-  for (int mt = 0; mt < XT; ++mt) {
-    const int64_t n = n0 + (SPLIT ? mt - MT : mt) * 16 + i16;  // rows >= N-1 read the zero-padded copy of the last row (rows past N are never written)
-    xrow[mt] = (n >= L.N - 1 ? reinterpret_cast<const uint8_t*>(L.last_row) : reinterpret_cast<const uint8_t*>(L.X) + n * L.ldx) + 16 * kq;
-  }
-  const int8_t* vsrc = L.d.V2 + (size_t)r_begin * (2 * STEP_BYTES) + (size_t)lane * 16;
-
-  // every load is unconditional and clamped (tail steps re-fetch the last one into a slot nobody reads): the number of
-  // vector-memory instructions per step is the constant the vmcnt arithmetic relies on.  X goes HBM -> LDS directly too
-  // (lane-linear: the lane reads back exactly the 16 bytes it fetched), so that no register waits on a load the compiler tracks:
-  // hipcc's waitcnt insertion gives up on VGPR loads in flight across the flush's loops and stores (s_waitcnt vmcnt(0) at first use)
-  auto issue_x = [&](int run) {
-    if (L.flags & 8) return;
-    const int rb = tab_rb[min(run, n_runs - 1)];
-    if (SPLIT) {  // tiles 0..MT-1 belong to wave - 1, whose stages precede this wave's
-#pragma unroll
-      for (int mt = 0; mt < XT; ++mt) {
-        uint8_t* dst = xl + (mt < MT ? -(XSN * MT * 1024) : 0) + (size_t)(run % XSN) * (MT * 1024) + (mt % MT) * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)(xrow[mt] + rb), (lptr_t)dst, 16, 0, 0);
-      }
-    } else {
-      uint8_t* dst = xl + (size_t)(run % XSN) * (MT * 1024);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[mt] + rb), (lptr_t)(dst + mt * 1024), 16, 0, 0);
-    }
-  };
-  auto issue_planes = [&](int step) {
-    if (L.flags & 16) return;
-    const int st = min(step, n_steps - 1);
-    const int8_t* src = vsrc + (size_t)st * STEP_BYTES;
-    uint8_t* vdst = vbuf + (size_t)(step % NBUF) * STEP_BYTES;
-#pragma unroll
-    for (int it = 0; it < (SPLIT ? PLDS : PLD); ++it) {
-      const int kb = SPLIT ? min((wave >> 1) + it * (WAVES / 2), NKB - 1) : min(wave + it * WAVES, NKB - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kb * 1024), (lptr_t)(vdst + (size_t)kb * 1024), 16, 0, 0);
-    }
-  };
-
-  v4i acc[MT][NT][LIMBS];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int l = 0; l < LIMBS; ++l) acc[mt][nt][l] = v4i{0, 0, 0, 0};
-
-  const int abl = L.flags;  // development ablations (GNX_LR_FLAGS, timing only): 1 raw logits, 2 no MFMA, 4 no flush
-  auto mfma_entry = [&](const uint8_t* pb, const v4i (&xc)[MT], int k) {
-    if (abl & 2) return;
-    v4i xa[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xc[mt][k]);
-    const v4i* vb = reinterpret_cast<const v4i*>(pb) + lane;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int l = 0; l < LIMBS; ++l) {
-        const v4i b = vb[(nt * LIMBS + l) * 64];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][nt][l], 0, 0, 0);
-      }
-  };
-
-  // sigmoid, normaliser and division for the ZROWS rows x A classes parked in zb.  Per element the arithmetic and the class order
-  // of the row sum are those of k_base_logistic_i8 (bit-identical B); what differs is who does what:
-  //   phase 1  LPR = 64 / ZROWS lanes per row: lane (row, sub) turns classes sub, sub + LPR, .. into p = 1 / (1 + exp(-(z + icpt)))
-  //   phase 2  every lane sums its row's A values in class order (LPR times redundantly: A additions against A/LPR exps), then
-  //            divides its own classes
-  //   phase 3  the wave walks the ZROWS x A block linearly, 64 consecutive elements per store (a row's A values are contiguous in
-  //            B): (row, class) of element lane + 64 it advance by (64 / A, 64 % A) — no integer division in the loop
-  constexpr int LPR = 64 / ZROWS;
-  const int frow = lane % ZROWS, fsub = lane / ZROWS;
-  const int e_r0 = lane / A, e_a0 = lane - e_r0 * A, e_dr = 64 / A, e_da = 64 - e_dr * A;
-  auto emit = [&](int w, int64_t nrow0) {
-    double* zr = zb + frow * A;
-    if (!(abl & 1)) {
-      const double* ic = tab_ic + (w - wt0) * A;
-      for (int a = fsub; a < A; a += LPR) zr[a] = 1.0 / (1.0 + exp(-(zr[a] + ic[a])));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      double sum = 0.0;
-      for (int c = 0; c < A; ++c) sum += zr[c];
-      for (int a = fsub; a < A; a += LPR) zr[a] = zr[a] / sum;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    int rl = e_r0, a = e_a0;
-    const size_t ow = (size_t)w * A;
-    for (int e = lane; e < ZROWS * A; e += 64) {
-      const int64_t n = nrow0 + rl;
-      if (n < L.N) {
-        const size_t o = (size_t)n * W * A + ow + a;
-        const double v = zb[e];
-        if (L.b64) L.b64[o] = v;
-        if (L.b32) L.b32[o] = (float)v;
-      }
-      a += e_da; rl += e_dr;
-      if (a >= A) { a -= A; ++rl; }
-    }
-  };
-
-  // ---- piece end: the windows that finished with run rl (block-uniform) ----
-  auto flush = [&](int rl) {
-    const int nfl = tab_nfl[rl];
-    if (nfl <= 0 || (abl & 4)) return;
-    const int w0 = tab_fl0[rl];
-    for (int w = w0; w < w0 + nfl; ++w) {
-      const int cbase = (w % R) * A;
-      const double scale = tab_sc[w - wt0];
-      const bool out = w >= wa && w < wb;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int col = nt * 16 + i16 - cbase;
-          const bool mine = (col >= 0) && (col < A);
-          if (mine) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)  // int32 16x16 C/D layout: column = lane&15, row = 4*(lane>>4) + reg
-              zb[((ZT ? 0 : mt * 16) + 4 * kq + r) * A + col] = combine(acc[mt][nt], r, scale);
-          }
-#pragma unroll
-          for (int l = 0; l < LIMBS; ++l)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][nt][l][r] = mine ? 0 : acc[mt][nt][l][r];
-        }
-        if (ZT) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zb is wave-private: LDS ops of one wave complete in order
-          if (out) emit(w, n0 + mt * 16);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-      }
-      if (!ZT) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (out) emit(w, n0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    }
-  };
-
-  // ---- prologue, in the steady state's issue order: X(0) .. X(XSN-1) | planes(0) | planes(1) ----
-  if (!SPLIT || xwave) {
-#pragma unroll
-    for (int p = 0; p < XSN; ++p) issue_x(p);
-  }
-  if (!SPLIT || !xwave) {
-    issue_planes(0);
-    issue_planes(1);
-  }
-
-  for (int r = 0; r < n_runs; ++r) {
-    // ---- even step 2r: the planes of the step and X(r) have landed; every wave is done with step 2r-1 ----
-    if (SPLIT) {
-      if (xwave) wait_vm<WAIT_XS>();
-      else wait_vm<PLDS>();
-    } else wait_vm<WAIT_EVEN>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!(L.flags & 32)) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    v4i xc[MT];
-    {
-      const uint8_t* xs = xl + (size_t)(r % XSN) * (MT * 1024) + lane * 16;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xc[mt] = *reinterpret_cast<const v4i*>(xs + mt * 1024);
-    }
-    if (SPLIT) {
-      if (!xwave) issue_planes(2 * r + D);
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the run sits in registers: its stage is free
-      issue_x(r + XSN);
-      issue_planes(2 * r + D);
-    }
-    {
-      const uint8_t* sb = vbuf + (size_t)((2 * r) % NBUF) * STEP_BYTES;
-      mfma_entry(sb, xc, 0);
-      mfma_entry(sb + ENTRY_BYTES, xc, 1);
-    }
-    // ---- odd step 2r+1 ----
-    if (SPLIT) {
-      if (!xwave) wait_vm<PLDS>();
-    } else wait_vm<WAIT_ODD>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!(L.flags & 32)) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (SPLIT) {
-      if (xwave) issue_x(r + XSN);  // every wave has read X(r) out of this stage (before the barrier above)
-      else issue_planes(2 * r + 1 + D);
-    } else issue_planes(2 * r + 1 + D);
-    {
-      const uint8_t* sb = vbuf + (size_t)((2 * r + 1) % NBUF) * STEP_BYTES;
-      mfma_entry(sb, xc, 2);
-      mfma_entry(sb + ENTRY_BYTES, xc, 3);
-    }
-    flush(r);
-  }
-  wait_vm<0>();  // nothing of this block may still be writing LDS when it retires
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// k_base_logistic_p2w: the same pass with DEDICATED loader waves.  A wave that issues vector-memory instructions stalls at the issue
-// while the L1's miss queue is full, so in the kernel above the time the memory system needs for X (HBM-bound: ~0.3 ms of the 0.75
-// at config 2) was added to the issuing waves' MFMA and flush time instead of hiding behind it (ablations: loads only 0.38 ms, + MFMA
-// 0.15, + flush 0.2 = the full kernel).  Here CW compute waves never touch global memory except for the flush's stores; wave CW
-// issues every plane load, wave CW + 1 every X load (the rows of all compute waves), and the block barrier of each step publishes
-// what has landed:
-//   plane loader, step s:   vmcnt((D - 1) NKB), barrier, planes(s + D) into the slot step s - 1 left
-//   X loader, run r:        vmcnt((XSN - 1) CW MT), barrier(2r), barrier(2r + 1), X(r + XSN) into the stage every wave read at step 2r
-//   compute wave, run r:    barrier(2r), X(r) LDS -> registers, entries 0, 1, barrier(2r + 1), entries 2, 3, flush
-template <int MT, int NT, int CW, int XSN, int NBUF>
-__global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunch L) {
+// MT 16-row tiles per compute wave, CW compute waves, EW epilogue waves (0: the compute waves finish their windows themselves),
+// XSN stages of X runs, NBUF plane slots of one half-run (2 entries, 14 KB) each.
+template <int MT, int CW, int EW, int XSN, int NBUF>
+__global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  constexpr int EPS = 2;
-  constexpr int ENTRY_BYTES = NT * LIMBS * 1024;
-  constexpr int STEP_BYTES = EPS * ENTRY_BYTES;
-  constexpr int THREADS = (CW + 2) * 64;
+  constexpr int ENTRY_BYTES = LIMBS * 1024;       // digit planes of one entry (64 k positions) of ONE column tile
+  constexpr int STEP_BYTES = 2 * ENTRY_BYTES;
+  constexpr int THREADS = (CW + EW + 2) * 64;
   constexpr int NKB = STEP_BYTES / 1024;
   constexpr int D = NBUF - 1;
-  constexpr int ZROWS = MT * 16;
+  constexpr int ZROWS = MT * 16;                  // rows a compute wave parks per window
   constexpr int XTILES = CW * MT;
+  constexpr int RWS = EW ? CW * ZROWS / EW : ZROWS;  // rows one finishing wave handles per window
+  constexpr int LPR = 64 / RWS;                      // lanes per row in the sigmoid phase
   static_assert((D - 1) * NKB < 64 && (XSN - 1) * XTILES < 64 && XSN >= 1 && D >= 1, "vmcnt is a 6-bit counter");
+  static_assert(RWS <= 64 && 64 % RWS == 0 && (!EW || CW % EW == 0), "an epilogue wave takes whole compute waves, at most 64 rows");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, kq = lane >> 4;
-  const int A = L.A, W = L.W, R = L.d.R;
+  const int A = L.A, W = L.W, R = L.d.R, NT2 = L.d.NT2;
+  const bool slot_tiles = NT2 > 1;                 // one column tile per slot, one pass per tile
   uint8_t* vbuf = lds;                                               // [NBUF][STEP_BYTES]
   uint8_t* xl0 = vbuf + (size_t)NBUF * STEP_BYTES;                   // [XSN][CW][MT][64 lanes][16 B]
-  double* zb0 = reinterpret_cast<double*>(xl0 + (size_t)XSN * XTILES * 1024);
-  double* tab_ic = zb0 + (size_t)CW * ZROWS * A;   // [max_wins][A] intercepts
-  double* tab_sc = tab_ic + (size_t)L.max_wins * A;  // [max_wins] 2^-f_w
+  double* zq = reinterpret_cast<double*>(xl0 + (size_t)XSN * XTILES * 1024);  // [2][CW][ZROWS][A] parked logits
+  double* tab_ic = zq + (size_t)2 * CW * ZROWS * A;  // [max_wins][A] intercepts
+  double* tab_sc = tab_ic + (size_t)L.max_wins * A;   // [max_wins] 2^-f_w
   int* tab_rb = reinterpret_cast<int*>(tab_sc + L.max_wins);
-  int* tab_nfl = tab_rb + L.max_chunks;
-  int* tab_fl0 = tab_nfl + L.max_chunks;
+  int* tab_nfl = tab_rb + L.max_chunks;   // windows of THIS pass that end with the run
+  int* tab_fl0 = tab_nfl + L.max_chunks;  // the first of them
+  int* tab_gap = tab_fl0 + L.max_chunks;  // runs until the next run that ends a window of this pass (0: none follows)
 
-  int wrange, htile;
+  // XCD-aware decomposition: all blocks of one window range (and pass) on ONE XCD (its L2 serves the range's digit planes)
+  int wrange, htile, pass;
   {
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
-    wrange = xcd + 8 * (j / L.n_htiles);
-    htile = j % L.n_htiles;
+    const int g = j / L.n_htiles;
+    htile = j - g * L.n_htiles;
+    pass = g / L.n_rg8;
+    wrange = xcd + 8 * (g - pass * L.n_rg8);
   }
   const int wa = wrange * L.wch;
   if (wa >= W) return;  // whole block exits before any barrier
@@ -384,8 +131,14 @@ __global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunc
 
   for (int e = tid; e < n_runs; e += THREADS) {
     tab_rb[e] = L.d.run_byte[r_begin + e];
-    tab_nfl[e] = L.d.run_nflush[r_begin + e];
-    tab_fl0[e] = L.d.run_flush0[r_begin + e];
+    int nf = L.d.run_nflush[r_begin + e], f0 = L.d.run_flush0[r_begin + e];
+    if (slot_tiles && nf > 0) {  // windows f0 .. f0+nf-1 end here; this pass owns those with w % R == pass (at most one: nf <= R)
+      const int w = f0 + ((pass - f0) % R + R) % R;
+      nf = w < f0 + nf ? 1 : 0;
+      f0 = w;
+    }
+    tab_nfl[e] = nf;
+    tab_fl0[e] = f0;
   }
   const int wt0 = max(0, wa - R - 1);
   for (int e = tid; e < L.max_wins * A; e += THREADS) {
@@ -394,17 +147,29 @@ __global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunc
   }
   for (int e = tid; e < L.max_wins; e += THREADS) tab_sc[e] = L.d.wscale[min(wt0 + e, W - 1)];
   __syncthreads();
+  if (tid == 0) {
+    int next = -1;
+    for (int r = n_runs - 1; r >= 0; --r) {
+      tab_gap[r] = next < 0 ? 0 : next - r;
+      if (tab_nfl[r] > 0) next = r;
+    }
+  }
+  __syncthreads();
   const int abl = L.flags;  // development ablations (GNX_LR_FLAGS, timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes
 
-  if (wave == CW) {
-    // ---- plane loader ----
-    const int8_t* vsrc = L.d.V2 + (size_t)r_begin * (2 * STEP_BYTES) + (size_t)lane * 16;
+  if (wave == CW + EW) {
+    // ================================================== plane loader ==================================================
+    // entry e of the block's run r_begin + e / 4: tile `pass` of [run][4 entries][NT2 tiles][7 limbs][64 lanes][16 B]
+    const int8_t* vsrc = L.d.V2 + ((size_t)r_begin * 4 * NT2 + pass) * ENTRY_BYTES + (size_t)lane * 16;
     auto issue_planes = [&](int step) {
       if (abl & 16) return;
-      const int8_t* src = vsrc + (size_t)min(step, n_steps - 1) * STEP_BYTES;
+      const int8_t* src = vsrc + (size_t)min(step, n_steps - 1) * 2 * NT2 * ENTRY_BYTES;
       uint8_t* vdst = vbuf + (size_t)(step % NBUF) * STEP_BYTES;
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kb * 1024), (lptr_t)(vdst + (size_t)kb * 1024), 16, 0, 0);
+      for (int kb = 0; kb < NKB; ++kb) {
+        const size_t so = (size_t)(kb / LIMBS) * NT2 * ENTRY_BYTES + (size_t)(kb % LIMBS) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(vdst + (size_t)kb * 1024), 16, 0, 0);
+      }
     };
 #pragma unroll
     for (int p = 0; p < D; ++p) issue_planes(p);
@@ -413,11 +178,13 @@ __global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunc
       __builtin_amdgcn_s_barrier();
       issue_planes(s + D);        // every compute wave is done with step s-1, whose slot this is
     }
-    wait_vm<0>();
+    wait_vm<0>();                 // nothing of this wave may still be writing LDS when the block retires
+    if (EW) __builtin_amdgcn_s_barrier();  // the trailing barrier of the compute / epilogue waves
     return;
   }
-  if (wave == CW + 1) {
-    // ---- X loader: tile t = (compute wave t / MT, its tile t % MT); lane (row i16, 16 packed bytes kq) as in the compute waves ----
+  if (wave == CW + EW + 1) {
+    // ================================================== X loader ==================================================
+    // tile t = (compute wave t / MT, its tile t % MT); lane (row i16, 16 packed bytes kq) as in the compute waves
     const uint8_t* xrow[XTILES];
 #pragma unroll
     for (int t = 0; t < XTILES; ++t) {
@@ -441,19 +208,109 @@ __global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunc
       issue_x(r + XSN);
     }
     wait_vm<0>();
+    if (EW) __builtin_amdgcn_s_barrier();
     return;
   }
 
-  // ---- compute waves ----
+  // ---- what the compute waves and the epilogue waves share: finishing RWS rows x A classes parked at zr0 ----
+  // Per element the arithmetic and the class order of the row sum are those of k_base_logistic_i8 (bit-identical B):
+  //   phase 1  LPR = 64 / RWS lanes per row: lane (row, sub) turns classes sub, sub + LPR, .. into p = 1 / (1 + exp(-(z + icpt)))
+  //   phase 2  every lane sums its row's A values in class order (LPR times redundantly), then divides its own classes
+  //   phase 3  the wave walks the RWS x A block linearly, 64 consecutive elements per store (a row's A values are contiguous in
+  //            B): (row, class) of element lane + 64 it advance by (64 / A, 64 % A) — no integer division in the loop
+  // (`rows` is a compile-time constant at both call sites: RWS in the epilogue waves, ZROWS where a compute wave finishes its own)
+  const int e_r0 = lane / A, e_a0 = lane - e_r0 * A, e_dr = 64 / A, e_da = 64 - e_dr * A;
+  auto phase1 = [&](double* zr0, int w, int it0, int it1, int rows) {
+    if (abl & 1) return;
+    const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
+    double* zr = zr0 + frow * A;
+    const double* ic = tab_ic + (w - wt0) * A;
+    for (int it = it0; it < it1; ++it) {
+      const int a = fsub + it * lpr;
+      if (a < A) zr[a] = 1.0 / (1.0 + exp(-(zr[a] + ic[a])));
+    }
+  };
+  auto finish = [&](double* zr0, int w, int64_t nrow0, int rows) {
+    if (!(abl & 1)) {
+      const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
+      double* zr = zr0 + frow * A;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own phase-1 writes (LDS ops of one wave complete in order)
+      double sum = 0.0;
+      for (int c = 0; c < A; ++c) sum += zr[c];
+      for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] / sum;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    int rl = e_r0, a = e_a0;
+    const size_t ow = (size_t)w * A;
+    for (int e = lane; e < rows * A; e += 64) {
+      const int64_t n = nrow0 + rl;
+      if (n < L.N && !(abl & 32)) {
+        const size_t o = (size_t)n * W * A + ow + a;
+        const double v = zr0[e];
+        if (L.b64) L.b64[o] = v;
+        if (L.b32) L.b32[o] = (float)v;
+      }
+      a += e_da; rl += e_dr;
+      if (a >= A) { a -= A; ++rl; }
+    }
+  };
+
+  if (EW && wave >= CW) {
+    // ================================================== epilogue waves ==================================================
+    // Replays the block-uniform window schedule of the compute waves: a run that ends exactly one window of this pass inside
+    // [wa, wb) parks it in buffer (parked count & 1); the job then has 2 * gap steps — until the next window of this pass ends —
+    // to get through phase 1 (spread evenly over all steps but the last) and the finish (last step).
+    const int ew = wave - CW;
+    const int64_t nrow0 = n0b + (int64_t)ew * RWS;
+    const int n_it = (A + LPR - 1) / LPR;  // phase-1 iterations of a lane
+    int parked = 0;
+    bool job = false;
+    int job_w = 0, job_step = 0, job_nst = 0;
+    double* job_z = nullptr;
+    auto job_work = [&]() {
+      if (!job) return;
+      if (job_step < job_nst - 1) {
+        phase1(job_z, job_w, n_it * job_step / (job_nst - 1), n_it * (job_step + 1) / (job_nst - 1), RWS);
+      } else {
+        finish(job_z, job_w, nrow0, RWS);
+        job = false;
+      }
+      ++job_step;
+    };
+    for (int r = 0; r < n_runs; ++r) {
+      lds_barrier();  // step 2r
+      job_work();
+      lds_barrier();  // step 2r+1
+      job_work();
+      // what the compute waves park at the end of this run (visible after the next barrier)
+      const int nfl = (abl & 4) ? 0 : tab_nfl[r];
+      if (nfl == 1) {
+        const int w = tab_fl0[r];
+        if (w >= wa && w < wb) {
+          job = true;
+          job_w = w;
+          job_step = 0;
+          job_nst = 2 * (tab_gap[r] > 0 ? tab_gap[r] : n_runs - 1 - r);  // 0 (last run): after the trailing barrier
+          job_z = zq + (size_t)(parked & 1) * (CW * ZROWS * A) + (size_t)ew * RWS * A;
+          ++parked;
+        }
+      }
+    }
+    lds_barrier();  // trailing barrier: the last run's windows are parked
+    if (job) {      // nothing follows: all of it at once
+      phase1(job_z, job_w, 0, n_it, RWS);
+      finish(job_z, job_w, nrow0, RWS);
+    }
+    return;
+  }
+
+  // ================================================== compute waves ==================================================
   const int64_t n0 = n0b + (int64_t)wave * (MT * 16);
-  double* zb = zb0 + (size_t)wave * ZROWS * A;
-  v4i acc[MT][NT][LIMBS];
+  v4i acc[MT][LIMBS];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int l = 0; l < LIMBS; ++l) acc[mt][nt][l] = v4i{0, 0, 0, 0};
+    for (int l = 0; l < LIMBS; ++l) acc[mt][l] = v4i{0, 0, 0, 0};
 
   auto mfma_entry = [&](const uint8_t* pb, const v4i (&xc)[MT], int k) {
     if (abl & 2) return;
@@ -462,77 +319,51 @@ __global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunc
     for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xc[mt][k]);
     const v4i* vb = reinterpret_cast<const v4i*>(pb) + lane;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int l = 0; l < LIMBS; ++l) {
+      const v4i b = vb[l * 64];
 #pragma unroll
-      for (int l = 0; l < LIMBS; ++l) {
-        const v4i b = vb[(nt * LIMBS + l) * 64];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][nt][l], 0, 0, 0);
-      }
+      for (int mt = 0; mt < MT; ++mt) acc[mt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][l], 0, 0, 0);
+    }
   };
 
-  // the epilogue of k_base_logistic_p2 (same three phases, same arithmetic: bit-identical B)
-  constexpr int LPR = 64 / ZROWS;
-  const int frow = lane % ZROWS, fsub = lane / ZROWS;
-  const int e_r0 = lane / A, e_a0 = lane - e_r0 * A, e_dr = 64 / A, e_da = 64 - e_dr * A;
-  auto emit = [&](int w) {
-    double* zr = zb + frow * A;
-    if (!(abl & 1)) {
-      const double* ic = tab_ic + (w - wt0) * A;
-      for (int a = fsub; a < A; a += LPR) zr[a] = 1.0 / (1.0 + exp(-(zr[a] + ic[a])));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      double sum = 0.0;
-      for (int c = 0; c < A; ++c) sum += zr[c];
-      for (int a = fsub; a < A; a += LPR) zr[a] = zr[a] / sum;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    int rl = e_r0, a = e_a0;
-    const size_t ow = (size_t)w * A;
-    for (int e = lane; e < ZROWS * A; e += 64) {
-      const int64_t n = n0 + rl;
-      if (n < L.N) {
-        const size_t o = (size_t)n * W * A + ow + a;
-        const double v = zb[e];
-        if (L.b64) L.b64[o] = v;
-        if (L.b32) L.b32[o] = (float)v;
-      }
-      a += e_da; rl += e_dr;
-      if (a >= A) { a -= A; ++rl; }
-    }
-  };
+  // ---- piece end: the windows of this pass that finished with run rl (block-uniform) ----
+  int parked = 0;
   auto flush = [&](int rl) {
     const int nfl = tab_nfl[rl];
     if (nfl <= 0 || (abl & 4)) return;
     const int w0 = tab_fl0[rl];
     for (int w = w0; w < w0 + nfl; ++w) {
-      const int cbase = (w % R) * A;
+      const int cbase = slot_tiles ? 0 : (w % R) * A;
       const double scale = tab_sc[w - wt0];
+      const bool out = w >= wa && w < wb;
+      double* zw = zq + (size_t)(parked & 1) * (CW * ZROWS * A) + (size_t)wave * ZROWS * A;
+      const int col = i16 - cbase;
+      const bool mine = (col >= 0) && (col < A);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mine && out && !(abl & 64)) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int col = nt * 16 + i16 - cbase;
-          const bool mine = (col >= 0) && (col < A);
-          if (mine) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)  // int32 16x16 C/D layout: column = lane&15, row = 4*(lane>>4) + reg
-              zb[(mt * 16 + 4 * kq + r) * A + col] = combine(acc[mt][nt], r, scale);
-          }
-#pragma unroll
-          for (int l = 0; l < LIMBS; ++l)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][nt][l][r] = mine ? 0 : acc[mt][nt][l][r];
+          for (int r = 0; r < 4; ++r)  // int32 16x16 C/D layout: column = lane&15, row = 4*(lane>>4) + reg
+            zw[(mt * 16 + 4 * kq + r) * A + col] = combine(acc[mt], r, scale);
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zb is wave-private: LDS ops of one wave complete in order
-      if (w >= wa && w < wb) emit(w);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][l][r] = mine ? 0 : acc[mt][l][r];
+      }
+      if (!out) continue;
+      if (EW && nfl == 1) {
+        ++parked;  // an epilogue wave takes it from here (after the next barrier)
+      } else {     // several windows end at once (chromosome ends, wide contexts), or no epilogue waves: finish it here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        phase1(zw, w, 0, (A + 64 / ZROWS - 1) / (64 / ZROWS), ZROWS);
+        finish(zw, w, n0, ZROWS);
+      }
     }
   };
 
   for (int r = 0; r < n_runs; ++r) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // step 2r: its planes and X(r) are in LDS
-    asm volatile("" ::: "memory");
+    lds_barrier();  // step 2r: its planes and X(r) are in LDS
     v4i xc[MT];
     {
       const uint8_t* xs = xl0 + (size_t)(r % XSN) * (XTILES * 1024) + (size_t)wave * (MT * 1024) + lane * 16;
@@ -544,9 +375,7 @@ __global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunc
       mfma_entry(sb, xc, 0);
       mfma_entry(sb + ENTRY_BYTES, xc, 1);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // step 2r+1
-    asm volatile("" ::: "memory");
+    lds_barrier();  // step 2r+1
     {
       const uint8_t* sb = vbuf + (size_t)((2 * r + 1) % NBUF) * STEP_BYTES;
       mfma_entry(sb, xc, 2);
@@ -554,61 +383,19 @@ __global__ __launch_bounds__((CW + 2) * 64) void k_base_logistic_p2w(BaseLRLaunc
     }
     flush(r);
   }
+  if (EW) lds_barrier();  // trailing barrier: the last run's parked windows become visible to the epilogue waves
 }
 
-template <int MT, int NT, int CW, int XSN, int NBUF>
-hipError_t launch_w(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
+template <int MT, int CW, int EW, int XSN, int NBUF>
+hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   BaseLRLaunch P = L;
   P.flags = tune.lr_flags;
   const int haps_per_block = CW * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
-  const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : 4;
-  int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
-  want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
-  if (tune.lr_want > 0) want = tune.lr_want;
-  int wch = 0, n_ranges = 0;
-  size_t lds = 0;
-  for (;; want += 8) {
-    wch = (int)((L.W + want - 1) / want);
-    if (wch < 4) wch = 4;
-    n_ranges = (L.W + wch - 1) / wch;
-    int max_runs = 0;
-    for (int r = 0; r < n_ranges; ++r) {
-      const int wa = r * wch, wb = std::min(L.W, wa + wch);
-      max_runs = std::max(max_runs, L.h_win_chunk1[(size_t)wb - 1] - L.h_win_chunk0[(size_t)wa]);
-    }
-    P.max_chunks = max_runs + 8;
-    P.max_wins = wch + 2 * L.d.R + 4;
-    lds = (size_t)NBUF * (2 * NT * LIMBS * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)CW * MT * 16 * L.A * sizeof(double) +
-          (size_t)3 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
-    if (lds <= (size_t)160 * 1024 || wch == 4) break;
-  }
-  if (lds > (size_t)160 * 1024) return hipErrorNotSupported;
-  const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
-  P.wch = wch;
-  P.n_htiles = (int)gx;
-  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2w<%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d\n", MT, NT, CW, XSN, NBUF, lds, (long long)(gx * n_ranges8), wch);
-  GNX_LDS_OPTIN(lds, k_base_logistic_p2w<MT, NT, CW, XSN, NBUF>);
-  hipLaunchKernelGGL((k_base_logistic_p2w<MT, NT, CW, XSN, NBUF>), dim3((unsigned)(gx * n_ranges8)), dim3((CW + 2) * 64), lds, s, P);
-  return hipGetLastError();
-}
-
-template <int MT, int NT, int WAVES, int XSN, int ZT>
-size_t lds_need(int A, int max_runs, int max_wins) {
-  return (size_t)3 * (2 * NT * LIMBS * 1024) + (size_t)WAVES * XSN * MT * 1024 + (size_t)WAVES * (ZT ? 16 : MT * 16) * A * sizeof(double) +
-         (size_t)3 * max_runs * sizeof(int) + (size_t)max_wins * (A + 1) * sizeof(double);
-}
-
-template <int MT, int NT, int WAVES, int XSN, int ZT, int SPLIT = 1>
-hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
-  BaseLRLaunch P = L;
-  P.flags = tune.lr_flags;
-  const int haps_per_block = WAVES * MT * 16;
-  const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
   // window ranges: a multiple of 8 (one XCD each); every range re-walks the runs of its first windows' lead-in, so fewer, longer
   // ranges move fewer bytes and more, shorter ones balance the tail
   const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : 4;
-  int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
+  int64_t want = ((int64_t)bpc * n_cu + gx * L.d.NT2 - 1) / (gx * L.d.NT2);
   want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
   if (tune.lr_want > 0) want = tune.lr_want;
   int wch = 0, n_ranges = 0;
@@ -624,59 +411,45 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
     }
     P.max_chunks = max_runs + 8;
     P.max_wins = wch + 2 * L.d.R + 4;
-    lds = lds_need<MT, NT, WAVES, XSN, ZT>(L.A, P.max_chunks, P.max_wins);
+    lds = (size_t)NBUF * (2 * LIMBS * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)2 * CW * MT * 16 * L.A * sizeof(double) +
+          (size_t)4 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
     if (lds <= (size_t)160 * 1024 || wch == 4) break;
   }
   if (lds > (size_t)160 * 1024) return hipErrorNotSupported;
-  lds = std::min(lds + (size_t)std::max(tune.lr_lds_pad, 0), (size_t)160 * 1024);
   const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
   P.wch = wch;
   P.n_htiles = (int)gx;
-  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2<%d,%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d\n", MT, NT, WAVES, XSN, ZT, SPLIT, lds, (long long)(gx * n_ranges8), wch);
-  GNX_LDS_OPTIN(lds, k_base_logistic_p2<MT, NT, WAVES, XSN, ZT, SPLIT>);
-  hipLaunchKernelGGL((k_base_logistic_p2<MT, NT, WAVES, XSN, ZT, SPLIT>), dim3((unsigned)(gx * n_ranges8)), dim3(WAVES * 64), lds, s, P);
+  P.n_rg8 = n_ranges8 / 8;
+  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2<%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d passes=%d\n", MT, CW, EW, XSN, NBUF, lds, (long long)(gx * n_ranges8 * L.d.NT2), wch, L.d.NT2);
+  GNX_LDS_OPTIN(lds, k_base_logistic_p2<MT, CW, EW, XSN, NBUF>);
+  hipLaunchKernelGGL((k_base_logistic_p2<MT, CW, EW, XSN, NBUF>), dim3((unsigned)(gx * n_ranges8 * L.d.NT2)), dim3((CW + EW + 2) * 64), lds, s, P);
   return hipGetLastError();
 }
 
 }  // namespace
 
-// returns hipErrorNotSupported when no instantiation fits (the caller widens X to int8 and runs the int8 kernels)
+// L.X = packed matrix (gnx_pack_x layout), L.ldx = its row stride in bytes, L.last_row = zero-padded copy of packed row N-1,
+// L.h_win_chunk0/1 = HOST copies of d.win_run0/1.  Returns hipErrorNotSupported when the model has no 2-bit planes or no
+// instantiation fits (the caller widens X to int8 and runs the int8 kernels).
 hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
-  if (!L.d.V2 || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
-  const bool small = L.N <= 64 * 8;
-  const int tm = tune.p2_mt, tw = tune.p2_cw, tx = tune.p2_xsn, tb = tune.p2_nbuf ? tune.p2_nbuf : 3;
-#define GNX_P2W(MT_, NT_, CW_, XS_, NB_) \
-  if (tm == MT_ && tw == CW_ && tx == XS_ && tb == NB_) return launch_w<MT_, NT_, CW_, XS_, NB_>(L, n_cu, tune, s);
-#define GNX_P2O(MT_, NT_, WV_, XS_, ZT_, SP_) \
-  if (tm == MT_ && tw == WV_ && tx == XS_ && tb == 10 * ZT_ + SP_) return launch<MT_, NT_, WV_, XS_, ZT_, SP_>(L, n_cu, tune, s);
-  switch (L.d.NT) {
-    case 1:
-      if (tune.p2_old) {  // k_base_logistic_p2: every wave loads and multiplies (nbuf field = 10 * ZT + SPLIT)
-        GNX_P2O(4, 1, 8, 2, 0, 1) GNX_P2O(4, 1, 8, 2, 0, 0) GNX_P2O(2, 1, 8, 3, 0, 1) GNX_P2O(2, 1, 8, 2, 0, 0)
-        return hipErrorInvalidValue;
-      }
-      if (tm) {
-        GNX_P2W(2, 1, 8, 2, 3) GNX_P2W(2, 1, 8, 3, 3) GNX_P2W(2, 1, 8, 4, 3) GNX_P2W(2, 1, 8, 4, 4) GNX_P2W(2, 1, 8, 3, 4)
-        GNX_P2W(2, 1, 10, 3, 3) GNX_P2W(2, 1, 12, 3, 3) GNX_P2W(2, 1, 14, 3, 3) GNX_P2W(2, 1, 14, 2, 3) GNX_P2W(2, 1, 12, 2, 4)
-        GNX_P2W(4, 1, 6, 2, 3) GNX_P2W(4, 1, 6, 3, 3) GNX_P2W(1, 1, 14, 4, 3)
-        return hipErrorInvalidValue;
-      }
-      if (small) return launch_w<1, 1, 4, 2, 3>(L, n_cu, tune, s);
-      return launch_w<2, 1, 8, 4, 4>(L, n_cu, tune, s);
-    case 2:
-      if (tune.p2_old) {
-        GNX_P2O(2, 2, 8, 2, 0, 1) GNX_P2O(2, 2, 8, 2, 0, 0) GNX_P2O(1, 2, 16, 2, 0, 1)
-        return hipErrorInvalidValue;
-      }
-      if (tm) {
-        GNX_P2W(2, 2, 6, 2, 3) GNX_P2W(2, 2, 6, 3, 3) GNX_P2W(1, 2, 8, 4, 3) GNX_P2W(1, 2, 14, 4, 3) GNX_P2W(1, 2, 14, 3, 3) GNX_P2W(1, 2, 12, 4, 3)
-        return hipErrorInvalidValue;
-      }
-      if (small) return launch_w<1, 2, 4, 2, 3>(L, n_cu, tune, s);
-      return launch_w<2, 2, 6, 3, 3>(L, n_cu, tune, s);
-    default: return hipErrorNotSupported;
+  if (!L.d.V2 || L.d.NT2 < 1 || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
+  const bool small = L.N <= 64 * 4;
+  const int tm = tune.p2_mt, tw = tune.p2_cw, te = tune.p2_ew, tx = tune.p2_xsn, tb = tune.p2_nbuf ? tune.p2_nbuf : 3;
+#define GNX_P2(MT_, CW_, EW_, XS_, NB_) \
+  if (tm == MT_ && tw == CW_ && te == EW_ && tx == XS_ && tb == NB_) return launch<MT_, CW_, EW_, XS_, NB_>(L, n_cu, tune, s);
+  if (tm) {  // GNX_P2_TUNE="mt,cw,ew,xsn,nbuf" (development)
+    GNX_P2(2, 8, 4, 3, 3) GNX_P2(2, 8, 4, 4, 3) GNX_P2(2, 8, 4, 3, 4) GNX_P2(2, 8, 4, 2, 3)
+    GNX_P2(2, 8, 0, 3, 4) GNX_P2(2, 8, 0, 4, 4) GNX_P2(1, 4, 0, 2, 3) GNX_P2(1, 8, 2, 4, 3) GNX_P2(1, 8, 4, 4, 3)
+    return hipErrorInvalidValue;
   }
-#undef GNX_P2W
-#undef GNX_P2O
+#undef GNX_P2
+  if (small) return launch<1, 4, 0, 2, 3>(L, n_cu, tune, s);
+  // 256 rows per block, 4 epilogue waves; the parked logits (2 x 256 rows x A doubles) share the LDS with the plane ring and the X
+  // stages: the deepest configuration that fits (A <= 12: 4 plane slots + 3 X stages; more classes: shallower)
+  hipError_t e = launch<2, 8, 4, 3, 4>(L, n_cu, tune, s);
+  if (e == hipErrorNotSupported) e = launch<2, 8, 4, 3, 3>(L, n_cu, tune, s);
+  if (e == hipErrorNotSupported) e = launch<2, 8, 4, 2, 3>(L, n_cu, tune, s);
+  if (e == hipErrorNotSupported) e = launch<1, 8, 4, 4, 3>(L, n_cu, tune, s);
+  return e;
 }
