@@ -1,0 +1,168 @@
+"""-m gpu: k_base_logistic_p2, the logistic base pass that reads 2-bit rows (gnx_base_predict_packed_dev / gnx_infer_packed*).
+
+Bar: B BIT-identical to the int8 kernels' (both compute the logits exactly in integers; the epilogue's float64 arithmetic is the
+same expression per element), hence also <= 1e-12 from the reference's own output (G1, G15) and the oracle.
+Reference contract: src/Base/base.py:146-180, src/Base/models.py:12-21; X values src/utils.py:153."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import gnomix_amd
+    gnomix_amd.load_library()
+    return gnomix_amd
+
+
+@pytest.fixture
+def p2ctx(monkeypatch):
+    """GNX_LR_P2=2: build the 2-bit planes whatever the run padding costs (the small windows of the test geometries would otherwise
+    keep the int8 kernels); the variable is read at model load and at context creation"""
+    from gnomix_amd import _lib
+    monkeypatch.setenv("GNX_LR_P2", "2")
+    return _lib.Context(0)
+
+
+def _both(dev, X, f64=True):
+    import torch
+    Xt = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+    P = torch.from_numpy(np.asarray(dev.pack_x(X))).cuda()
+    b_i8 = dev.base_predict_device(Xt, f64=f64)
+    b_p2 = dev.base_predict_packed_device(P, f64=f64)
+    torch.cuda.synchronize()
+    return b_i8.cpu().numpy(), b_p2.cpu().numpy()
+
+
+GEOMS = [
+    (4037, 100, 7, 50, 24),      # default context ratio 0.5
+    (4037, 100, 7, 0, 5),        # no context
+    (2531, 100, 3, 30, 70),      # ratio 0.3: windows end mid-piece
+    (1999, 64, 2, 32, 130),      # M multiple of 64
+    (3001, 100, 12, 50, 33),     # A = 12: 24 class columns -> one tile per slot, two passes
+    (2201, 100, 9, 50, 600),     # A = 9, more rows than one block
+    (1801, 60, 7, 45, 50),       # ratio 0.75: R = 3 slots, 21 columns -> three passes
+    (1503, 100, 16, 50, 9),      # A = 16: a full tile per slot
+    (2777, 100, 5, 120, 40),     # ratio 1.2: 4 slots, reflections reach window 1
+    (1237, 50, 7, 25, 600),      # many rows, short runs
+    (1237, 50, 7, 25, 1),        # a single haplotype
+    (937, 300, 4, 150, 66),      # W = 3 windows only
+    (20500, 1000, 7, 500, 700),  # the chr22 window shape (two 256-SNP runs per piece), three row tiles, epilogue waves
+    (30500, 1000, 12, 500, 1100),  # the same with two passes
+]
+
+
+@pytest.mark.parametrize("C,M,A,ctx,N", GEOMS)
+def test_p2_is_bit_identical_to_int8(ga, oracle, p2ctx, C, M, A, ctx, N):
+    from gnomix_amd import synth
+    d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=ctx, seed=C + A, smooth=None)
+    X = synth.synthetic_X(N, C, seed=N, miss=0.03)
+    dev = ga.DeviceModel(d, ctx=p2ctx)
+    for f64 in (True, False):
+        b_i8, b_p2 = _both(dev, X, f64)
+        assert np.array_equal(b_i8, b_p2), ("f64" if f64 else "f32")
+    ref = oracle.base_lr(X[: min(N, 64)], M, ctx, d.lr_coef, d.lr_intercept)
+    assert np.max(np.abs(_both(dev, X[: min(N, 64)])[1] - ref)) < 1e-12
+
+
+@pytest.mark.parametrize("tune", ["2,8,0,3,4", "2,8,4,2,3", "1,8,4,4,3", "1,8,2,4,3", "1,4,0,2,3"])
+def test_p2_every_shape(ga, monkeypatch, tune):
+    """the instantiations the dispatcher can fall back to (no epilogue waves, shallower rings, 16-row tiles), forced"""
+    from gnomix_amd import synth, _lib
+    monkeypatch.setenv("GNX_LR_P2", "2")
+    monkeypatch.setenv("GNX_P2_TUNE", tune)
+    ctx = _lib.Context(0)
+    for (C, M, A, cx, N) in ((20500, 1000, 7, 500, 700), (6100, 200, 12, 100, 300), (1801, 60, 7, 45, 50)):
+        d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=cx, seed=C, smooth=None)
+        X = synth.synthetic_X(N, C, seed=N, miss=0.03)
+        b_i8, b_p2 = _both(ga.DeviceModel(d, ctx=ctx), X)
+        assert np.array_equal(b_i8, b_p2), (tune, C, A)
+
+
+def test_p2_goldens_of_the_reference(ga, p2ctx):
+    """G1 / G15: the REFERENCE's own Base.predict_proba output, through the 2-bit pass"""
+    import torch
+    from conftest import load_golden
+    for name, A in (("G1_lr.npz", None), ("G15_lr_binary.npz", 2)):
+        g = load_golden(name)
+        d = ga.GnxModelData(C=int(g["C"]), M=int(g["M"]), A=int(g["A"]) if A is None else A, S=5, context=int(g["ctx"]),
+                            base_kind="logistic", lr_coef=g["coef"], lr_intercept=g["intercept"])
+        dev = ga.DeviceModel(d, ctx=p2ctx)
+        b_i8, b_p2 = _both(dev, g["X"])
+        assert np.array_equal(b_i8, b_p2)
+        assert np.max(np.abs(b_p2 - g["B"])) < 1e-12
+        assert np.array_equal(np.argmax(b_p2, -1), np.argmax(g["B"], -1))
+
+
+def test_p2_row_strides_offsets_and_the_value_3(ga, p2ctx):
+    """packed rows at an odd stride from an odd base address (loads split by the addresser: slower, same bytes), and fields that hold
+    3 (not an int8 code the reference produces, but representable): same numbers as widening to int8 first"""
+    import torch
+    from gnomix_amd import synth
+    C, M, A, cx, N = 5037, 100, 7, 50, 77
+    d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=cx, seed=3, smooth=None)
+    dev = ga.DeviceModel(d, ctx=p2ctx)
+    X = synth.synthetic_X(N, C, seed=9, miss=0.05)
+    X[::3, ::7] = 3
+    P = np.asarray(dev.pack_x(X))
+    ref = dev.base_predict_device(torch.from_numpy(X).cuda(), f64=True).cpu().numpy()
+    for stride_extra, off in ((0, 0), (3, 1), (61, 2), (128, 0)):
+        ldp = P.shape[1] + stride_extra
+        buf = torch.full((N * ldp + 64,), 0xFF, dtype=torch.uint8, device="cuda")
+        view = buf[off:off + N * ldp].view(N, ldp)
+        view[:, :P.shape[1]] = torch.from_numpy(P).cuda()
+        got = dev.base_predict_packed_device(view, f64=True).cpu().numpy()
+        assert np.array_equal(got, ref), (stride_extra, off)
+
+
+@pytest.mark.parametrize("smooth,A", [("xgb", 7), ("crf", 12), ("cnn", 3)])
+def test_infer_packed_through_p2(ga, monkeypatch, smooth, A):
+    """gnx_infer_packed (host batches on three streams, several batches forced) and gnx_infer_packed_dev with the 2-bit pass ==
+    gnx_infer on int8"""
+    import torch
+    from gnomix_amd import synth, _lib
+    monkeypatch.setenv("GNX_LR_P2", "2")
+    monkeypatch.setenv("GNX_HOST_BATCH", "64")
+    C, M, S, N = 6037, 100, 21, 333
+    d = synth.synthetic_model(C=C, M=M, A=A, S=S, n_rounds=6, seed=C, smooth=smooth)
+    X = synth.synthetic_X(N, C, seed=N, miss=0.05)
+    dev = ga.DeviceModel(d, ctx=_lib.Context(0))
+    p_ref, l_ref = dev.infer(X)
+    P = dev.pack_x(X)
+    p, l = dev.infer_packed(P)
+    assert p.dtype == p_ref.dtype and np.array_equal(p, p_ref) and np.array_equal(l, l_ref)
+    if smooth == "xgb":
+        pt, lt = dev.infer_packed_device(torch.from_numpy(np.asarray(P)).cuda())
+        assert np.array_equal(pt.cpu().numpy(), p_ref) and np.array_equal(lt.cpu().numpy(), l_ref)
+
+
+def test_small_windows_keep_the_int8_kernels(ga):
+    """without GNX_LR_P2=2 a model whose pieces would be mostly run padding gets no 2-bit planes: packed input is widened on the
+    device and runs through the int8 kernels, bit-identical as before"""
+    from gnomix_amd import synth, _lib
+    d = synth.synthetic_model(C=6037, M=100, A=7, S=21, n_rounds=6, seed=1)
+    X = synth.synthetic_X(70, d.C, seed=2)
+    dev = ga.DeviceModel(d, ctx=_lib.Context(0))
+    p_ref, l_ref = dev.infer(X)
+    p, l = dev.infer_packed(dev.pack_x(X))
+    assert np.array_equal(p, p_ref) and np.array_equal(l, l_ref)
+
+
+@pytest.mark.parametrize("A,N", [(7, 10000), (12, 4096)])
+def test_p2_full_size_chr22(ga, A, N):
+    """BASELINE configs[1] geometry (C = 370 500, W = 370), X generated in HBM: the 2-bit pass == the int8 pass on every one of
+    the N x 370 x A probabilities, default dispatch (no environment knobs)"""
+    import torch
+    from gnomix_amd import synth, _lib
+    d = synth.synthetic_model(C=370500, M=1000, A=A, S=75, context=500, seed=0, smooth=None)
+    dev = ga.DeviceModel(d, ctx=_lib.Context(0))
+    g = torch.Generator(device="cuda").manual_seed(A)
+    Xt = (torch.rand((N, d.C), device="cuda", generator=g) < 0.4).to(torch.int8)
+    Xt[torch.rand((N, d.C), device="cuda", generator=g) < 0.01] = 2
+    Pt = dev.pack_device(Xt)
+    assert torch.equal(dev.base_predict_device(Xt), dev.base_predict_packed_device(Pt))
+    assert torch.equal(dev.base_predict_device(Xt[:777], f64=True), dev.base_predict_packed_device(Pt[:777], f64=True))
+    # permutation of the rows permutes the outputs (row tiles, loader lanes and epilogue waves see different rows)
+    perm = torch.randperm(N, device="cuda", generator=g)
+    assert torch.equal(dev.base_predict_packed_device(Pt[perm].contiguous()), dev.base_predict_packed_device(Pt)[perm])
