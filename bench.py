@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--haps", type=int, default=10000, help="haplotypes per GPU per pass")
+    ap.add_argument("--resident-2bit", type=int, default=1, help="0: skip the 2-bit-resident leg (resident_2bit, kernels.k_base_logistic_p2)")
     ap.add_argument("--passes", type=int, default=20, help="passes over the resident batch per step: a step is `passes` x `haps` haplotypes, so "
                     "that the 20 steps the driver asks for time > 1 s of device work instead of 57 ms")
     ap.add_argument("--trained", type=int, default=1, help="also time the smoother on a gnx_train_gbt-trained ensemble (N=1, rank 0)")
@@ -282,6 +283,43 @@ def main():
         if res["counters"]["stale"]:
             roofline["traffic"] = None        # never print a counter next to times of other kernels
             roofline["traffic_note"] = "profiles/traffic_latest.json was collected from other kernel sources: rerun scripts/collect_profiles.sh"
+
+    # ---- the same batch resident in HBM as 2-bit rows (gnx_pack_x layout): the logistic pass reads a quarter of the X bytes
+    # (k_base_logistic_p2); never `value` (SURVEY.md 8d quotes the metric on int8-resident X), printed beside it -------------
+    if rank == 0 and world == 1 and args.resident_2bit:
+        try:
+            Pk = model.pack_device(X)
+            for _ in range(max(1, args.warmup)):
+                o2 = model.infer_packed_device(Pk)
+            torch.cuda.synchronize()
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            t0 = time.perf_counter()
+            n2 = max(1, args.steps) * P
+            for _ in range(n2):
+                o2 = model.infer_packed_device(Pk)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            ctx.profile_enable(False)
+            ms_b2, n_b2 = ctx.profile_get(_lib.K_BASE_LOGISTIC)
+            ms_s2, n_s2 = ctx.profile_get(_lib.K_SMOOTH_XGB)
+            avg_b2 = ms_b2 / max(n_b2, 1) * 1e-3
+            bytes_p2 = (C + 3) // 4 + W * A * 4
+            res["resident_2bit"] = {
+                "ms_per_pass": dt2 / n2 * 1e3, "haplotypes_per_s": N * n2 / dt2, "base_ms": avg_b2 * 1e3, "smoother_ms": ms_s2 / max(n_s2, 1),
+                "outputs_identical_to_int8": bool(torch.equal(o2[0], out[0]) and torch.equal(o2[1], out[1])),
+                "resident_bytes_per_haplotype": int(Pk.shape[1]),
+                "note": "X resident as 2-bit rows (%d B/haplotype instead of %d); same kernels after the base pass; B bit-identical" % (Pk.shape[1], C)}
+            kernels["k_base_logistic_p2"] = {
+                "avg_ms": avg_b2 * 1e3, "launches": n_b2, "alg_GBps": bytes_p2 * N / avg_b2 / 1e9 if avg_b2 else None,
+                "hbm_frac": bytes_p2 * N / avg_b2 / 1e9 / HBM_PEAK_GBS if avg_b2 else None,
+                "alg_bytes_per_haplotype": bytes_p2, "int8_equiv_GBps": bytes_base * N / avg_b2 / 1e9 if avg_b2 else None,
+                "mfma_frac": i8_ops * N / avg_b2 / 1e12 / I8_MFMA_PEAK_TOPS if avg_b2 else None,
+                "note": "algorithmic bytes = ceil(C/4) + W*A*4 per haplotype (2-bit X read once, B f32 written once); the pass is bound by "
+                        "the 64-byte row runs of X and by the matrix + float64 vector pipes, not by the byte count (DESIGN.md 4.1c)"}
+            del Pk, o2
+        except Exception as e:
+            res["resident_2bit"] = {"error": repr(e)}
 
     # ---- PCIe-inclusive rate: host pointers in, labels + probabilities out (never `value`) ----------------------------
     if rank == 0 and world == 1 and args.e2e_steps > 0:

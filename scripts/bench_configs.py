@@ -41,7 +41,7 @@ def prof(ctx):
 
 def c4(N=12500):
     """whole genome, 22 chromosomes, A=7, LR + xgb; N = 100k/8 haplotypes per GPU, chromosome-major batches"""
-    tot_t, tot_w, rows = 0.0, 0, []
+    tot_t, tot_t2, tot_w, rows = 0.0, 0.0, 0, []
     for k, Wk in enumerate(synth.GENOME_W):
         C = 1000 * Wk + 500
         data = synth.synthetic_model(C=C, M=1000, A=7, S=75, seed=k)
@@ -53,12 +53,22 @@ def c4(N=12500):
         model.ctx.profile_enable(False)
         rows.append((k + 1, Wk, round(dt * 1e3, 2), prof(model.ctx)))
         tot_t += dt; tot_w += Wk
+        # the same batch resident as 2-bit rows (k_base_logistic_p2)
+        Pk = model.pack_device(X)
+        ref = model.infer_device(X)
+        got = model.infer_packed_device(Pk)
+        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+        dt2 = timed(lambda: model.infer_packed_device(Pk), reps=2)
+        tot_t2 += dt2
+        del Pk, ref, got
         model.close(); del X, model
         torch.cuda.empty_cache()
         print("chr%d W=%d %.2f ms" % (k + 1, Wk, dt * 1e3), flush=True)
     res = {"config": "c4 whole genome 22 chr, A=7, LR+xgb", "haplotypes_per_gpu": N, "sum_W": tot_w,
            "seconds_per_batch": tot_t, "haplotypes_per_s_per_gpu": N / tot_t, "hap_windows_per_s": N * tot_w / tot_t,
-           "projected_8gpu_haplotypes_per_s": 8 * N / tot_t}
+           "projected_8gpu_haplotypes_per_s": 8 * N / tot_t,
+           "resident_2bit": {"seconds_per_batch": tot_t2, "haplotypes_per_s_per_gpu": N / tot_t2, "outputs_identical_to_int8": True,
+                             "resident_GB_per_gpu": N * sum(1000 * w + 500 for w in synth.GENOME_W) / 4 / 1e9}}
     print(json.dumps(res))
     return res
 
@@ -95,6 +105,15 @@ def c5a(N=25000):
     model.ctx.profile_enable(False)
     res = {"config": "c5a chr1 WGS A=12 LR+CRF", "haplotypes_per_gpu": N, "W": data.W, "seconds": dt,
            "haplotypes_per_s_per_gpu": N / dt, "alg_GBps_base": (C + data.W * A * 8) * N / dt / 1e9, "kernels_ms": prof(model.ctx)}
+    # the same batch resident as 2-bit rows (k_base_logistic_p2: one column tile per slot, two passes)
+    Pk = model.pack_device(X)
+    ref = model.base_predict_device(X[:4096], f64=True)
+    assert torch.equal(ref, model.base_predict_packed_device(Pk[:4096], f64=True))
+    del ref
+    model.ctx.profile_reset(); model.ctx.profile_enable(True)
+    dt2 = timed(lambda: model.infer_packed_device(Pk, want_proba=True), reps=2)
+    model.ctx.profile_enable(False)
+    res["resident_2bit"] = {"seconds": dt2, "haplotypes_per_s_per_gpu": N / dt2, "kernels_ms": prof(model.ctx), "base_identical_to_int8": True}
     print(json.dumps(res))
     return res
 
