@@ -153,6 +153,7 @@ SYMBOLS = {
     "gnx_vcf_strings": (C.c_int, [_VP, _I, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_I64)]),
     "gnx_vcf_gt_int8": (C.c_int, [_VP, _VP, _I]),
     "gnx_gt2_to_x_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),
+    "gnx_gt2_to_p2_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),
     "gnx_x_to_gt2_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),
     "gnx_infer_gt2": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _VP, _VP, _VP]),
     "gnx_phase_gt2": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, C.c_int32, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP]),

@@ -1298,3 +1298,6 @@ int gnx_profile_get(gnx_ctx* ctx, int kid, double* total_ms, int64_t* launches) 
 }  // extern "C"
 
 int gnx_pipe_init(gnx_ctx* ctx) { return pipe_init(ctx); }
+bool gnx_lr_p2_usable(const gnx_model* m) {
+  return m->info.base_kind == GNX_BASE_LOGISTIC && m->lr_i8 && m->lr.V2 && m->ctx->tune.lr_p2 != 0;
+}

@@ -43,6 +43,15 @@ int gnx_gt2_to_x_dev(gnx_ctx* ctx, const uint8_t* dG, int64_t V, int64_t ldg, in
   return GNX_OK;
 }
 
+int gnx_gt2_to_p2_dev(gnx_ctx* ctx, const uint8_t* dG, int64_t V, int64_t ldg, int64_t n0, int64_t N, const int32_t* d_src, int64_t C,
+                      uint8_t* dP, int64_t ldp) {
+  if (!ctx) return GNX_EINVAL;
+  if (N < 0 || C < 0 || V < 0 || n0 < 0 || (n0 & 3) || ldp < (C + 3) / 4 || ldg < (n0 + N + 3) / 4 || (N > 0 && C > 0 && (!dG || !d_src || !dP)))
+    return gnx_fail(ctx, GNX_EINVAL, "gt2_to_p2: bad arguments (n0 must be a multiple of 4, ldg >= ceil((n0 + N) / 4), ldp >= ceil(C / 4))");
+  HIPCHK(ctx, gnx_launch_gt2_to_p2(dG, V, ldg, n0, N, d_src, C, dP, ldp, ctx->stream));
+  return GNX_OK;
+}
+
 int gnx_x_to_gt2_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ldx, int64_t n0, const int32_t* d_cols, int64_t V, uint8_t* dG,
                      int64_t ldg) {
   if (!ctx) return GNX_EINVAL;
@@ -134,15 +143,22 @@ int gnx_infer_gt2_range(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, 
     if ((rc = gnx_ws_reserve(ctx, f64 ? ctx->ws_b64 : ctx->ws_b32, nb * WA * (f64 ? 8 : 4))) != GNX_OK) return rc;
   }
   hipStream_t sc = ctx->stream, so = nbuf == 2 ? ctx->s_out : ctx->stream;
+  const bool p2 = gnx_lr_p2_usable(m);
+  const int64_t ldp2 = (J.C + 255) / 256 * 64;  // 64-byte aligned packed rows (<= J.ldx / 4: the batch fits the int8 workspace)
   for (int64_t i = 0; i < n_batches; ++i) {
     const int b = (int)(i % nbuf);
     const int64_t n0 = i * nb, n = std::min(nb, N - n0);
     if (nbuf == 2 && i >= 2) HIPCHK(ctx, hipStreamWaitEvent(sc, ctx->ev_out[b], 0));  // outputs of batch i-2 have left this half
-    HIPCHK(ctx, gnx_launch_gt2_to_x(J.dG, V, J.ldg_d, n0, n, J.dsrc, J.C, J.dX, J.ldx, sc));
     float* dp32 = (float*)((char*)ctx->ws_p32.p + (size_t)b * p32_b);
     double* dp64 = p64 ? (double*)((char*)ctx->ws_p64.p + (size_t)b * p64_b) : nullptr;
     int32_t* dlab = lab ? (int32_t*)((char*)ctx->ws_lab.p + (size_t)b * lab_b) : nullptr;
-    if ((rc = gnx_infer_dev(m, J.dX, n, J.ldx, dp32, dp64, dlab)) != GNX_OK) return rc;
+    if (p2) {  // the haplotype rows stay 2-bit: transposed as they are, read packed by the logistic pass
+      HIPCHK(ctx, gnx_launch_gt2_to_p2(J.dG, V, J.ldg_d, n0, n, J.dsrc, J.C, (uint8_t*)J.dX, ldp2, sc));
+      if ((rc = gnx_infer_packed_dev(m, (const uint8_t*)J.dX, n, ldp2, dp32, dp64, dlab)) != GNX_OK) return rc;
+    } else {
+      HIPCHK(ctx, gnx_launch_gt2_to_x(J.dG, V, J.ldg_d, n0, n, J.dsrc, J.C, J.dX, J.ldx, sc));
+      if ((rc = gnx_infer_dev(m, J.dX, n, J.ldx, dp32, dp64, dlab)) != GNX_OK) return rc;
+    }
     if (nbuf == 2) {
       HIPCHK(ctx, hipEventRecord(ctx->ev_done[b], sc));
       HIPCHK(ctx, hipStreamWaitEvent(so, ctx->ev_done[b], 0));

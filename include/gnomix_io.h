@@ -9,6 +9,7 @@
  *   gnx_infer_gt2           <- vcf_to_npy + Base.predict_proba + Smoother.predict_proba src/utils.py:104-159, gnomix.py:49-58
  *   gnx_phase_gt2           <- vcf_to_npy + Gnomix.phase + Gnomix.predict_proba         gnomix.py:49-72, src/model.py:188-214
  *   gnx_gt2_to_x_dev        <- the matrix vcf_to_npy returns, built in HBM              src/utils.py:118-153
+ *   gnx_gt2_to_p2_dev       <- the same matrix, four SNPs per byte (k_base_logistic_p2 reads it)   src/utils.py:118-153
  *   gnx_x_to_gt2_dev        <- X_query_phased[:, fmt_idx] per variant                   gnomix.py:69, src/utils.py:299-308
  *   gnx_write_msp           <- write_msp                                                src/postprocess.py:84-98
  *   gnx_write_fb            <- write_fb (pandas to_csv of float columns)                src/postprocess.py:100-126
@@ -82,6 +83,11 @@ int gnx_vcf_gt_int8(const gnx_vcf* vcf, int8_t* out, int n_threads);
  * (filled with the missing code 2, utils.py:131).  X[n, c] for haplotypes n0 <= n < n0 + N, rows ldx bytes apart. */
 int gnx_gt2_to_x_dev(gnx_ctx* ctx, const uint8_t* dG, int64_t V, int64_t ldg, int64_t n0, int64_t N, const int32_t* d_src,
                      int64_t C, int8_t* dX, int64_t ldx);
+/* the same matrix as 2-bit rows (the gnx_pack_x layout of gnomix_hip.h: SNP c of haplotype n = bits 2 (c % 4).. of byte c / 4 of
+ * row n, rows ldp >= ceil(C / 4) bytes apart): what gnx_infer_gt2* hands to the 2-bit-native logistic pass — the haplotype-major
+ * matrix never exists as int8 on that route */
+int gnx_gt2_to_p2_dev(gnx_ctx* ctx, const uint8_t* dG, int64_t V, int64_t ldg, int64_t n0, int64_t N, const int32_t* d_src,
+                      int64_t C, uint8_t* dP, int64_t ldp);
 /* the way back for the phased VCF: row r of G_out = column cols[r] of X (values & 3), haplotypes n0 .. n0 + N written
  * into their fields (whole bytes: n0 and N multiples of 4 unless the range ends the row; other bytes untouched) */
 int gnx_x_to_gt2_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ldx, int64_t n0, const int32_t* d_cols, int64_t V,

@@ -76,6 +76,43 @@ def test_gt2_to_x_and_back(ga, V, N, C, ldx_extra, n0):
     ctx.reset_stream()
 
 
+@pytest.mark.parametrize("V,N,C,ldp_extra,n0", [(300, 70, 257, 0, 0), (64, 1030, 64, 0, 0), (500, 2100, 1037, 27, 0), (200, 48, 130, 62, 16),
+                                                (200, 52, 131, 5, 4), (90, 6, 1, 0, 0), (1500, 4096 + 20, 300, 212, 1024)])
+def test_gt2_to_p2(ga, V, N, C, ldp_extra, n0):
+    """k_gt2_to_p2: the haplotype-major matrix as 2-bit rows == gnx_pack_x of the int8 matrix k_gt2_to_x builds (numpy statement)"""
+    import torch
+    from gnomix_amd import _lib
+    rng = np.random.default_rng(V * N + C + 1)
+    G, code = _rows(rng, V, N)
+    src = rng.integers(0, V, C).astype(np.int32)
+    src |= (rng.random(C) < 0.2).astype(np.int32) << 30
+    src[rng.random(C) < 0.15] = -1
+    ctx = _lib.default_context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ldg = G.shape[1]
+    n = N - n0
+    canon = (C + 15) // 16 * 4
+    ldp = canon + ldp_extra
+    Gd = torch.from_numpy(G).cuda()
+    sd = torch.from_numpy(src).cuda()
+    Pd = torch.full((n * ldp + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    base = Pd.data_ptr() + (0 if ldp % 4 == 0 else 1)        # a misaligned buffer takes the byte-store variant
+    ctx.check(ctx.lib.gnx_gt2_to_p2_dev(ctx.h, Gd.data_ptr(), V, ldg, n0, n, sd.data_ptr(), C, base, ldp))
+    torch.cuda.synchronize()
+    off = base - Pd.data_ptr()
+    got = Pd[off:off + n * ldp].cpu().numpy().reshape(n, ldp)
+    want = _x_from(code, src)[n0:]
+    fields = np.stack([(got[:, c // 4] >> (2 * (c % 4))) & 3 for c in range(C)], axis=1).astype(np.int8)
+    assert np.array_equal(fields, want)
+    nb = (C + 3) // 4
+    if C % 4:
+        assert not (got[:, nb - 1] >> (2 * (C % 4))).any()              # the fields past C of the last byte are zero
+    assert (got[:, canon:] == 0xEE).all() and (Pd[off + n * ldp:].cpu().numpy() == 0xEE).all()   # nothing outside the canonical row
+    assert ctx.lib.gnx_gt2_to_p2_dev(ctx.h, Gd.data_ptr(), V, ldg, 2, n, sd.data_ptr(), C, base, ldp) == _lib.GNX_EINVAL
+    assert ctx.lib.gnx_gt2_to_p2_dev(ctx.h, Gd.data_ptr(), V, ldg, 0, n, sd.data_ptr(), C, base, (C + 3) // 4 - 1) == _lib.GNX_EINVAL
+    ctx.reset_stream()
+
+
 def _query(tmp_path, d, n_ind, rng, drop=200, flip_frac=0.05, miss=0.02):
     """a model with SNP metadata + a query VCF that lacks `drop` model SNPs, has extra SNPs of its own, REF mismatches and
     missing calls; returns (vcf path, the matrix the reference's vcf_to_npy builds from it)"""
@@ -95,10 +132,12 @@ def _query(tmp_path, d, n_ind, rng, drop=200, flip_frac=0.05, miss=0.02):
     return p
 
 
+@pytest.mark.parametrize("p2", ["1", "2"])   # "2": the logistic pass reads the 2-bit rows k_gt2_to_p2 builds (GNX_LR_P2, forced for small windows)
 @pytest.mark.parametrize("C,M,A,S,n_ind,smooth", [(6037, 100, 7, 21, 35, "xgb"), (4112, 100, 4, 11, 17, "xgb"), (3001, 50, 12, 75, 4, "crf"),
                                                   (2049, 64, 3, 9, 64, "cnn")])
-def test_infer_gt2_equals_vcf_to_npy_then_infer(ga, tmp_path, monkeypatch, C, M, A, S, n_ind, smooth):
+def test_infer_gt2_equals_vcf_to_npy_then_infer(ga, tmp_path, monkeypatch, C, M, A, S, n_ind, smooth, p2):
     from gnomix_amd import synth, vcfio, _lib
+    monkeypatch.setenv("GNX_LR_P2", p2)
     rng = np.random.default_rng(C)
     d = synth.synthetic_model(C=C, M=M, A=A, S=S, n_rounds=6, seed=C, smooth=smooth)
     p = _query(tmp_path, d, n_ind, rng)
