@@ -133,6 +133,7 @@ SYMBOLS = {
     "gnx_calibrate_rows": (C.c_int, [_VP, _VP, _I, _I64, _VP]),
     "gnx_gnofix": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
     "gnx_gnofix_dev": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
+    "gnx_gnofix_packed_dev": (C.c_int, [_VP, _VP, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
     "gnx_train_logistic": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _I64, _I64, _I64, C.c_int32, C.c_double, C.c_double, C.c_int32, _VP, _I64, _VP,
                                      C.POINTER(TrainInfo)]),
     "gnx_train_logistic_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _I64, _I64, _I64, C.c_int32, C.c_double, C.c_double, C.c_int32, _VP, _I64,

@@ -1003,7 +1003,7 @@ static int gnofix_ws_reserve(gnx_model* m, int64_t n, int32_t max_it, bool in_ld
 // them share a hardware queue (HIP maps streams onto 4 by default), and when those two are the copy-in and copy-out streams the
 // pipeline's H2D and D2H stop overlapping (measured: 13.3 k -> 9.2 k individuals/s through host pointers).
 static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int64_t n, int32_t max_it, int32_t* dY,
-                          int32_t* dNs, bool in_lds, bool side_stream) {
+                          int32_t* dNs, bool in_lds, bool side_stream, bool packed = false) {
   gnx_ctx* ctx = m->ctx;
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
   int rc;
@@ -1012,6 +1012,7 @@ static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* d
   int32_t* dY0 = (int32_t*)ctx->ws_y0.p;
   GnofixLaunch L{};
   L.X = dX; L.ldx = ldx; L.C = m->info.C; L.B = dB; L.Y0 = dY0; L.Yout = dY; L.n_switches = dNs;
+  L.x_packed = packed ? 1 : 0;
   L.W = W; L.A = A; L.S = S; L.max_it = max_it; L.d = m->xgb; L.class_tree0 = m->class_tree0;
   L.hist = (uint32_t*)ctx->ws_misc.p;
   const bool rk = gnofix_use_rk(m);
@@ -1049,6 +1050,19 @@ static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* d
   L.bp_scratch = in_lds ? nullptr : (float*)((char*)ctx->ws_misc.p + ws.bp);
   HIPCHK(ctx, gnx_launch_gnofix_f32(L, n, ctx->stream));
   return GNX_OK;
+}
+
+int gnx_gnofix_packed_dev(gnx_model* m, uint8_t* dP, int64_t ldp, const double* dB, int64_t n_ind, int32_t max_it, int32_t* dY,
+                          int32_t* d_n_switches) {
+  if (!m) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  if (ldp < (m->info.C + 3) / 4 || (ldp & 3) || ((uintptr_t)dP & 3))
+    return fail(ctx, GNX_EINVAL, "gnofix_packed: rows must be 4-byte aligned, ldp a multiple of 4 and >= ceil(C / 4)");
+  bool in_lds = true;
+  int rc = gnofix_check(m, m->info.C, n_ind, max_it, dP && dB && dY, &in_lds);
+  if (rc != GNX_OK || n_ind == 0) return rc;
+  if (!gnofix_use_rk(m)) return fail(ctx, GNX_EUNSUPPORTED, "gnofix_packed: the model's smoother has no rank-quantised copy (k_gnofix); use gnx_gnofix_dev");
+  return gnofix_run_dev(m, reinterpret_cast<int8_t*>(dP), ldp, dB, n_ind, max_it, dY, d_n_switches, in_lds, true, true);
 }
 
 int gnx_gnofix_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int64_t n_ind, int32_t max_it, int32_t* dY,
@@ -1298,6 +1312,7 @@ int gnx_profile_get(gnx_ctx* ctx, int kid, double* total_ms, int64_t* launches) 
 }  // extern "C"
 
 int gnx_pipe_init(gnx_ctx* ctx) { return pipe_init(ctx); }
+bool gnx_gnofix_packed_ok(const gnx_model* m) { return m->info.smooth_kind == GNX_SMOOTH_XGB && gnofix_use_rk(m); }
 bool gnx_lr_p2_usable(const gnx_model* m) {
   return m->info.base_kind == GNX_BASE_LOGISTIC && m->lr_i8 && m->lr.V2 && m->ctx->tune.lr_p2 != 0;
 }

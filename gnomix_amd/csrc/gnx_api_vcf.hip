@@ -214,20 +214,36 @@ int gnx_phase_gt2_range(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, 
     HIPCHK(ctx, hipMemsetAsync(ctx->ws_gt2o.p, 0, (size_t)n_out * ldo_d, ctx->stream));
   }
   hipStream_t sc = ctx->stream;
+  // the haplotype rows stay 2-bit end to end where the model has the 2-bit logistic pass and the rank-strip Gnofix kernel:
+  // gt2 -> packed rows -> base -> Gnofix (swaps 2-bit SNP blocks) -> gt2 rows of the phased VCF, and the final predict_proba
+  const bool p2 = gnx_lr_p2_usable(m) && gnx_gnofix_packed_ok(m);
+  const int64_t ldp2 = (J.C + 255) / 256 * 64;
   for (int64_t i = 0; i < n_batches; ++i) {
     const int64_t n0 = i * nb, n = std::min(nb, N - n0);
-    HIPCHK(ctx, gnx_launch_gt2_to_x(J.dG, V, J.ldg_d, n0, n, J.dsrc, J.C, J.dX, J.ldx, sc));
-    if ((rc = gnx_base_predict_dev(m, J.dX, n, J.ldx, nullptr, (double*)ctx->ws_b64.p)) != GNX_OK) return rc;
     int32_t* dY = (int32_t*)ctx->ws_lab.p;
     int32_t* dNs = dY + (size_t)nb * Wn;
-    if ((rc = gnx_gnofix_dev(m, J.dX, J.ldx, (const double*)ctx->ws_b64.p, n / 2, max_it, dY, dNs)) != GNX_OK) return rc;
-    if (n_out > 0)
-      HIPCHK(ctx, gnx_launch_x_to_gt2(J.dX, n, J.ldx, n0, J.dsrc + J.C, n_out, (uint8_t*)ctx->ws_gt2o.p, ldo_d, sc));
+    if (p2) {
+      uint8_t* dP = (uint8_t*)J.dX;
+      HIPCHK(ctx, gnx_launch_gt2_to_p2(J.dG, V, J.ldg_d, n0, n, J.dsrc, J.C, dP, ldp2, sc));
+      if ((rc = gnx_base_predict_packed_dev(m, dP, n, ldp2, nullptr, (double*)ctx->ws_b64.p)) != GNX_OK) return rc;
+      if ((rc = gnx_gnofix_packed_dev(m, dP, ldp2, (const double*)ctx->ws_b64.p, n / 2, max_it, dY, dNs)) != GNX_OK) return rc;
+      if (n_out > 0)
+        HIPCHK(ctx, gnx_launch_p2_to_gt2(dP, n, ldp2, n0, J.dsrc + J.C, n_out, (uint8_t*)ctx->ws_gt2o.p, ldo_d, sc));
+    } else {
+      HIPCHK(ctx, gnx_launch_gt2_to_x(J.dG, V, J.ldg_d, n0, n, J.dsrc, J.C, J.dX, J.ldx, sc));
+      if ((rc = gnx_base_predict_dev(m, J.dX, n, J.ldx, nullptr, (double*)ctx->ws_b64.p)) != GNX_OK) return rc;
+      if ((rc = gnx_gnofix_dev(m, J.dX, J.ldx, (const double*)ctx->ws_b64.p, n / 2, max_it, dY, dNs)) != GNX_OK) return rc;
+      if (n_out > 0)
+        HIPCHK(ctx, gnx_launch_x_to_gt2(J.dX, n, J.ldx, n0, J.dsrc + J.C, n_out, (uint8_t*)ctx->ws_gt2o.p, ldo_d, sc));
+    }
     if (lab) HIPCHK(ctx, hipMemcpyAsync(lab + n0 * Wn, dY, n * Wn * 4, hipMemcpyDeviceToHost, sc));
     if (n_switches) HIPCHK(ctx, hipMemcpyAsync(n_switches + n0 / 2, dNs, (size_t)(n / 2) * 4, hipMemcpyDeviceToHost, sc));
     if (p32 || p64) {
       // model.predict_proba(X_phased) (gnomix.py:72): base + smoother again on the re-phased haplotypes
-      if ((rc = gnx_infer_dev(m, J.dX, n, J.ldx, (float*)ctx->ws_p32.p, p64 ? (double*)ctx->ws_p64.p : nullptr, nullptr)) != GNX_OK) return rc;
+      float* q32 = (float*)ctx->ws_p32.p;
+      double* q64 = p64 ? (double*)ctx->ws_p64.p : nullptr;
+      rc = p2 ? gnx_infer_packed_dev(m, (const uint8_t*)J.dX, n, ldp2, q32, q64, nullptr) : gnx_infer_dev(m, J.dX, n, J.ldx, q32, q64, nullptr);
+      if (rc != GNX_OK) return rc;
       if (p32) HIPCHK(ctx, hipMemcpyAsync(p32 + n0 * WA, ctx->ws_p32.p, n * WA * 4, hipMemcpyDeviceToHost, sc));
       if (p64) HIPCHK(ctx, hipMemcpyAsync(p64 + n0 * WA, ctx->ws_p64.p, n * WA * 8, hipMemcpyDeviceToHost, sc));
     }

@@ -312,8 +312,9 @@ struct CovRSKLaunch {
 
 // ---- gnofix (k_gnofix.hip) ----------------------------------------------------------------------------
 struct GnofixLaunch {
-  int8_t* X;               // (2*n_ind, ldx) re-phased in place
+  int8_t* X;               // (2*n_ind, ldx) re-phased in place; x_packed: 2-bit rows (gnx_pack_x layout, 4-byte aligned), ldx bytes apart
   int64_t ldx, C;
+  int32_t x_packed;
   const double* B;         // (2*n_ind, W, A) base probabilities
   const int32_t* Y0;       // (2*n_ind, W) initial smoother labels
   int32_t* Yout;           // (2*n_ind, W)
@@ -410,6 +411,7 @@ struct gnx_model {
 int gnx_fail(gnx_ctx* ctx, int code, const std::string& msg);
 int gnx_ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes);
 int gnx_pipe_init(gnx_ctx* ctx);
+bool gnx_gnofix_packed_ok(const gnx_model* m);  // gnx_gnofix_packed_dev can run (rank-strip Gnofix kernel)
 bool gnx_lr_p2_usable(const gnx_model* m);  // packed (2-bit) rows go straight into the logistic pass (k_base_logistic_p2)
 void* gnx_pin_alloc(size_t bytes);  // page-locked host memory through the process-wide reuse list (gnx_api.hip); NULL on failure
 void gnx_pin_free(void* p);
@@ -444,6 +446,8 @@ hipError_t gnx_launch_gt2_to_x(const uint8_t* G, int64_t V, int64_t ldg, int64_t
                                int8_t* X, int64_t ldx, hipStream_t s);
 hipError_t gnx_launch_gt2_to_p2(const uint8_t* G, int64_t V, int64_t ldg, int64_t n0, int64_t N, const int32_t* src, int64_t C,
                                 uint8_t* P, int64_t ldp, hipStream_t s);
+hipError_t gnx_launch_p2_to_gt2(const uint8_t* P, int64_t N, int64_t ldp, int64_t n0, const int32_t* cols, int64_t V, uint8_t* G,
+                                int64_t ldg, hipStream_t s);
 hipError_t gnx_launch_x_to_gt2(const int8_t* X, int64_t N, int64_t ldx, int64_t n0, const int32_t* cols, int64_t V, uint8_t* G,
                                int64_t ldg, hipStream_t s);
 hipError_t gnx_launch_base_logistic(const BaseLRLaunch& L, int n_cu, hipStream_t s);

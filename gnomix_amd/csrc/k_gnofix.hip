@@ -902,6 +902,82 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : 3)) void k_gnofix(Gn
 #endif
 }
 
+// ---- the same two passes on 2-BIT rows (the gnx_pack_x layout: SNP j = bits 2 (j % 4).. of byte j / 4; rows 4-byte aligned): a
+// 32-bit word = 16 SNPs, a quarter of the bytes of the int8 matrix through HBM ----
+__global__ __launch_bounds__(256) void k_gnofix_dif_p2(const uint8_t* __restrict__ P, int64_t ldp, int64_t C, int W, uint32_t* __restrict__ dif) {
+  const int NWD = (W + 31) / 32;
+  const int ln = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= NWD) return;  // wave-uniform
+  const int64_t ind = blockIdx.y;
+  const uint32_t* Pm = reinterpret_cast<const uint32_t*>(P + 2 * ind * ldp);
+  const uint32_t* Pp = reinterpret_cast<const uint32_t*>(P + (2 * ind + 1) * ldp);
+  const int64_t ws = C / W;
+  uint32_t word = 0;
+  for (int hf = 0; hf < 2; ++hf) {
+    const int u = q * 32 + hf * 16 + (ln >> 2), sub = ln & 3;
+    const bool live = u < W;
+    const int64_t j0 = live ? (int64_t)u * ws : 0, j1 = !live ? 0 : (u == W - 1) ? C : j0 + ws;  // SNPs [j0, j1)
+    const int64_t d0 = j0 >> 4, d1 = live ? (j1 - 1) >> 4 : -1;                                  // 32-bit words [d0, d1]
+    bool d = false;
+    for (int64_t w0 = d0;; w0 += 4) {
+      const int64_t wi = w0 + sub;
+      if (!d && wi <= d1) {
+        uint32_t mask = 0xffffffffu;
+        if (wi == d0) mask &= 0xffffffffu << (2 * (int)(j0 & 15));
+        if (wi == d1) mask &= 0xffffffffu >> (30 - 2 * (int)((j1 - 1) & 15));
+        d = ((Pm[wi] ^ Pp[wi]) & mask) != 0;
+      }
+      const unsigned long long bal = __ballot(d);
+      d = ((bal >> (ln & ~3)) & 0xfull) != 0;  // the window's four lanes agree
+      if (__ballot(!d && w0 + 4 <= d1) == 0) break;
+    }
+    const unsigned long long bal = __ballot(d && sub == 0);  // window k of this half at bit 4k
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bits |= (uint32_t)((bal >> (4 * k)) & 1ull) << k;
+    word |= bits << (16 * hf);
+  }
+  if (ln == 0) dif[(size_t)ind * NWD + q] = word;
+}
+
+__global__ __launch_bounds__(256) void k_gnofix_swap_p2(uint8_t* __restrict__ P, int64_t ldp, int64_t C, int W, const uint32_t* __restrict__ par) {
+  constexpr int PER = 4;  // 32-bit words (16 SNPs) per thread
+  const int NWD = (W + 31) / 32;
+  const int64_t ind = blockIdx.y;
+  const uint32_t* Q = par + (size_t)ind * NWD;
+  const uint32_t ws = (uint32_t)(C / W);
+  const int64_t b0 = (int64_t)blockIdx.x * (256 * PER * 16), b1 = min(b0 + 256 * PER * 16, C);  // SNP range of the block
+  if (b0 >= C) return;
+  const int ua = (int)min((int64_t)W - 1, b0 / ws), ub = (int)min((int64_t)W - 1, (b1 - 1) / ws);
+  bool any = false;
+  for (int q = ua >> 5; q <= ub >> 5; ++q) {  // block-uniform
+    uint32_t m = Q[q];
+    if (q == ua >> 5) m &= 0xffffffffu << (ua & 31);
+    if (q == ub >> 5) m &= 0xffffffffu >> (31 - (ub & 31));
+    any |= m != 0;
+  }
+  if (!any) return;
+  uint32_t* Pm = reinterpret_cast<uint32_t*>(P + 2 * ind * ldp);
+  uint32_t* Pp = reinterpret_cast<uint32_t*>(P + (2 * ind + 1) * ldp);
+  auto odd = [&](int u) { return ((Q[u >> 5] >> (u & 31)) & 1u) != 0; };
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t j = b0 + ((int64_t)k * 256 + threadIdx.x) * 16;
+    if (j >= C) continue;
+    const int nf = (int)min((int64_t)16, C - j);
+    const int u0 = (int)min((uint32_t)(W - 1), (uint32_t)j / ws), u1 = (int)min((uint32_t)(W - 1), (uint32_t)(j + nf - 1) / ws);
+    uint32_t mask = 0;
+    if (u0 == u1) mask = odd(u0) ? (nf == 16 ? 0xffffffffu : (1u << (2 * nf)) - 1u) : 0u;
+    else
+      for (int f = 0; f < nf; ++f)
+        if (odd((int)min((uint32_t)(W - 1), (uint32_t)(j + f) / ws))) mask |= 3u << (2 * f);
+    if (!mask) continue;
+    const uint32_t a = Pm[j >> 4], b = Pp[j >> 4];
+    Pm[j >> 4] = (a & ~mask) | (b & mask);
+    Pp[j >> 4] = (b & ~mask) | (a & mask);
+  }
+}
+
 template <int THREADS>
 hipError_t launch_t(const GnofixLaunch& G, int64_t n_ind, hipStream_t s) {
   const size_t lds = gnofix_lds(G.W, G.A, G.S, G.gf_pitch, G.gf_cap, G.d.D, THREADS, G.d.n_trees).total;
@@ -939,8 +1015,12 @@ hipError_t gnx_launch_gnofix_prep(const GnofixLaunch& L, int64_t n_ind, hipStrea
   const int64_t n = 2 * n_ind * (int64_t)L.W * L.A;
   hipLaunchKernelGGL(k_gnofix_ranks, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, L.B, n, L.d.rk_thr, L.d.rk_lut, L.d.rk_K,
                      L.d.rk_steps, const_cast<uint16_t*>(L.R));
-  hipLaunchKernelGGL(k_gnofix_dif, dim3((unsigned)((NWD + 3) / 4), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W,
-                     const_cast<uint32_t*>(L.dif));
+  if (L.x_packed)
+    hipLaunchKernelGGL(k_gnofix_dif_p2, dim3((unsigned)((NWD + 3) / 4), (unsigned)n_ind), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(L.X),
+                       L.ldx, L.C, L.W, const_cast<uint32_t*>(L.dif));
+  else
+    hipLaunchKernelGGL(k_gnofix_dif, dim3((unsigned)((NWD + 3) / 4), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W,
+                       const_cast<uint32_t*>(L.dif));
   return hipGetLastError();
 }
 
@@ -964,6 +1044,10 @@ hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, int threads, 
   else if (threads == 1024) e = launch_t<1024>(L, n_ind, s);
   else e = launch_t<512>(L, n_ind, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_gnofix_swap, dim3((unsigned)((L.C + 16383) / 16384), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W, L.par);
+  if (L.x_packed)
+    hipLaunchKernelGGL(k_gnofix_swap_p2, dim3((unsigned)((L.C + 16383) / 16384), (unsigned)n_ind), dim3(256), 0, s, reinterpret_cast<uint8_t*>(L.X),
+                       L.ldx, L.C, L.W, L.par);
+  else
+    hipLaunchKernelGGL(k_gnofix_swap, dim3((unsigned)((L.C + 16383) / 16384), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W, L.par);
   return hipGetLastError();
 }

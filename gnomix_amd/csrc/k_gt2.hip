@@ -183,7 +183,37 @@ __global__ __launch_bounds__(256) void k_x_to_gt2(const int8_t* __restrict__ X, 
   }
 }
 
+// the same from 2-bit haplotype rows (gnx_pack_x layout)
+__global__ __launch_bounds__(256) void k_p2_to_gt2(const uint8_t* __restrict__ P, int64_t N, int64_t ldp, int64_t n0,
+                                                   const int32_t* __restrict__ cols, int64_t V, uint8_t* __restrict__ G, int64_t ldg,
+                                                   int64_t words) {
+  const int64_t total = V * words;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / words, d = e - r * words;
+    const int64_t c = cols[r];
+    const int64_t cb = c >> 2;
+    const int sh = 2 * (int)(c & 3);
+    uint32_t w = 0;
+    const int64_t hb = 16 * d;
+    const int nh = (int)((N - hb < 16) ? N - hb : 16);
+    for (int j = 0; j < nh; ++j) w |= (((uint32_t)P[(hb + j) * ldp + cb] >> sh) & 3u) << (2 * j);
+    uint8_t* dst = G + r * ldg + ((n0 + hb) >> 2);
+    const int nb = (nh + 3) >> 2;
+    for (int b = 0; b < nb; ++b) dst[b] = (uint8_t)(w >> (8 * b));
+  }
+}
+
 }  // namespace
+
+hipError_t gnx_launch_p2_to_gt2(const uint8_t* P, int64_t N, int64_t ldp, int64_t n0, const int32_t* cols, int64_t V, uint8_t* G,
+                                int64_t ldg, hipStream_t s) {
+  if (N <= 0 || V <= 0) return hipSuccess;
+  const int64_t words = (N + 15) / 16;
+  const int64_t total = V * words;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)256 * 64);
+  hipLaunchKernelGGL(k_p2_to_gt2, dim3(blocks), dim3(256), 0, s, P, N, ldp, n0, cols, V, G, ldg, words);
+  return hipGetLastError();
+}
 
 hipError_t gnx_launch_gt2_to_x(const uint8_t* G, int64_t V, int64_t ldg, int64_t n0, int64_t N, const int32_t* src, int64_t C,
                                int8_t* X, int64_t ldx, hipStream_t s) {

@@ -575,6 +575,20 @@ class DeviceModel:
                                                Y.data_ptr(), ns.data_ptr()))
         return Y, ns
 
+    def gnofix_packed_device(self, P_t, B_t, max_it=50):
+        """P_t (2n, ldp) uint8 CUDA tensor of 2-bit rows (gnx_pack_x layout) re-phased IN PLACE, B_t (2n, W, A) float64 ->
+        (labels i32 (2n, W), n_switches i32 (n,))  (gnx_gnofix_packed_dev)"""
+        import torch
+        assert P_t.is_cuda and P_t.dtype == torch.uint8 and P_t.stride(1) == 1
+        assert B_t.is_cuda and B_t.dtype == torch.float64 and B_t.is_contiguous()
+        self._bind_torch_stream()
+        n_ind = P_t.shape[0] // 2
+        Y = torch.empty((2 * n_ind, self.W), dtype=torch.int32, device=P_t.device)
+        ns = torch.empty((n_ind,), dtype=torch.int32, device=P_t.device)
+        self.ctx.check(self.lib.gnx_gnofix_packed_dev(self.h, P_t.data_ptr(), P_t.stride(0), B_t.data_ptr(), n_ind, int(max_it),
+                                                      Y.data_ptr(), ns.data_ptr()))
+        return Y, ns
+
     def smooth_predict_device(self, B_t):
         import torch
         assert B_t.is_cuda and B_t.is_contiguous() and B_t.dtype in (torch.float32, torch.float64)

@@ -276,6 +276,10 @@ int gnx_gnofix(gnx_model* model, int8_t* X, int64_t ldx, const double* B, int64_
                int32_t* Y, int32_t* n_switches);
 int gnx_gnofix_dev(gnx_model* model, int8_t* dX, int64_t ldx, const double* dB, int64_t n_ind, int32_t max_it,
                    int32_t* dY, int32_t* d_n_switches);
+/* the same on device-resident 2-bit rows (gnx_pack_x layout; dP 4-byte aligned, ldp a multiple of 4): the SNP blocks of the
+ * windows with odd final switch parity are exchanged in the packed rows (a quarter of the bytes of the int8 matrix) */
+int gnx_gnofix_packed_dev(gnx_model* model, uint8_t* d_packed, int64_t ldp, const double* dB, int64_t n_ind, int32_t max_it,
+                          int32_t* dY, int32_t* d_n_switches);
 
 /* Base.train for the logistic base (src/Base/base.py:104-127 -> per window
  * LogisticRegression(penalty="l2", C=3., solver="liblinear", max_iter=1000).fit(X_w, y_w), src/Base/models.py:12-21; called

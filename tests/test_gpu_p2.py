@@ -166,3 +166,72 @@ def test_p2_full_size_chr22(ga, A, N):
     # permutation of the rows permutes the outputs (row tiles, loader lanes and epilogue waves see different rows)
     perm = torch.randperm(N, device="cuda", generator=g)
     assert torch.equal(dev.base_predict_packed_device(Pt[perm].contiguous()), dev.base_predict_packed_device(Pt)[perm])
+
+
+# ---------------------------------------------------------------- Gnofix on 2-bit rows ------------------
+def _unpack(P, C):
+    P = np.asarray(P)
+    return np.stack([(P[:, c // 4] >> (2 * (c % 4))) & 3 for c in range(C)], axis=1).astype(np.int8)
+
+
+def _gnofix_both(dev, X, B, max_it):
+    """(X', Y, n_switches) of the int8 host entry point and of gnx_gnofix_packed_dev on the packed copy of the same rows"""
+    import torch
+    Xo, Y, nsw = dev.gnofix(X.copy(), B, max_it=max_it)
+    Pt = torch.from_numpy(np.asarray(dev.pack_x(X))).cuda()
+    Yt, nt = dev.gnofix_packed_device(Pt, torch.from_numpy(np.ascontiguousarray(B, dtype=np.float64)).cuda(), max_it=max_it)
+    torch.cuda.synchronize()
+    return (Xo, Y, nsw), (_unpack(Pt.cpu().numpy(), X.shape[1]), Yt.cpu().numpy(), nt.cpu().numpy())
+
+
+@pytest.mark.parametrize("W,A,S,M,extra,n_ind,seed", [
+    (170, 5, 75, 7, 5, 12, 0),       # windows of 7 SNPs: several windows inside one 32-bit word of the packed row
+    (96, 5, 11, 208, 16, 3, 56),     # wide windows, blocks equal between the haplotypes or differing in their last SNP only
+    (96, 5, 11, 208, 13, 3, 53),     # ... C not a multiple of 4: the last byte of a row is partial
+    (40, 3, 9, 1000, 500, 5, 7),     # the chr22 window shape
+])
+def test_gnofix_packed_equals_int8(ga, W, A, S, M, extra, n_ind, seed):
+    """Gnomix.phase's loop (src/model.py:188-214, src/Gnofix/gnofix.py:58-208) with X as 2-bit rows: the same labels, switch counts
+    and re-phased SNPs as the int8 route (itself pinned to the reference's gnofix() by G5 and to the oracle)"""
+    from gnomix_amd import synth, _lib
+    C = W * M + extra
+    d = ga.GnxModelData(C=C, M=M, A=A, S=S, context=0, smooth_kind="xgb")
+    for k, v in synth.synthetic_trees(4, A, S * A, seed=3 + seed, thr_lo=0.0, thr_hi=0.6, leaf_scale=1.0).items():
+        setattr(d, k, v)
+    dev = ga.DeviceModel(d, ctx=_lib.Context(0))
+    rng = np.random.RandomState(seed)
+    X = rng.randint(0, 3, size=(2 * n_ind, C)).astype(np.int8)
+    for i in range(n_ind):
+        for u in range(W):
+            kind = rng.randint(4)
+            lo, hi = u * M, (u + 1) * M if u < W - 1 else C
+            if kind == 0:
+                X[2 * i + 1, lo:hi] = X[2 * i, lo:hi]
+            elif kind == 1:
+                X[2 * i + 1, lo:hi] = X[2 * i, lo:hi]
+                X[2 * i + 1, hi - 1] ^= 1
+    B = rng.dirichlet(np.ones(A) * 0.3, size=(2 * n_ind, W))
+    (Xo, Y, nsw), (Xq, Yq, nq) = _gnofix_both(dev, X, B, 6)
+    assert np.array_equal(Yq, Y) and np.array_equal(nq, nsw)
+    assert np.array_equal(Xq, Xo)
+    assert int(nsw.sum()) > 0
+
+
+def test_gnofix_packed_goldens_G5(ga):
+    """the REFERENCE's gnofix() outputs (G5) through the 2-bit route"""
+    from conftest import load_golden
+    from gnomix_amd import _lib
+    g = load_golden("G5_gnofix.npz")
+    ctx = _lib.Context(0)
+    for name in ("none", "one", "two", "edges", "many", "rand"):
+        prefix = "r_" if name == "rand" else "t_"
+        W, A, S, C = int(g["W"]), int(g["A"]), int(g["S"]), int(g["C"])
+        d = ga.GnxModelData(C=C, M=C // W, A=A, S=S, context=0, smooth_kind="xgb", tree_off=g[prefix + "tree_off"], left=g[prefix + "left"],
+                            right=g[prefix + "right"], feat=g[prefix + "feat"], cond=g[prefix + "cond"], tree_class=g[prefix + "tree_class"],
+                            base_score=float(g[prefix + "base_score"]))
+        dev = ga.DeviceModel(d, ctx=ctx)
+        X = np.stack([g[name + "_Xm"], g[name + "_Xp"]]).astype(np.int8)
+        _, (Xq, Yq, nq) = _gnofix_both(dev, X, g[name + "_B"], 4 if name == "rand" else 50)
+        assert np.array_equal(Xq[0], g[name + "_oXm"]) and np.array_equal(Xq[1], g[name + "_oXp"]), name
+        assert np.array_equal(Yq[0], g[name + "_oYm"]) and np.array_equal(Yq[1], g[name + "_oYp"]), name
+        assert int(nq[0]) == int(g[name + "_nhist"]) - 2

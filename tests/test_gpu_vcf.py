@@ -166,10 +166,12 @@ def test_infer_gt2_equals_vcf_to_npy_then_infer(ga, tmp_path, monkeypatch, C, M,
     ctx.close()
 
 
+@pytest.mark.parametrize("p2", ["1", "2"])   # "2": the rows stay 2-bit through base, Gnofix and the way back (GNX_LR_P2)
 @pytest.mark.parametrize("C,M,A,n_ind,batch", [(16037, 100, 4, 9, 0), (9037, 60, 5, 14, 8)])
-def test_phase_gt2_equals_the_int8_route(ga, tmp_path, monkeypatch, C, M, A, n_ind, batch):
+def test_phase_gt2_equals_the_int8_route(ga, tmp_path, monkeypatch, C, M, A, n_ind, batch, p2):
     """gnomix.py:60-72: B = base.predict_proba(X); X_phased, labels = model.phase(X, B); proba = model.predict_proba(X_phased)"""
     from gnomix_amd import synth, vcfio, _lib
+    monkeypatch.setenv("GNX_LR_P2", p2)
     rng = np.random.default_rng(C)
     d = synth.synthetic_model(C=C, M=M, A=A, S=75, n_rounds=8, seed=11)
     p = _query(tmp_path, d, n_ind, rng)
