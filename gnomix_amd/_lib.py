@@ -107,6 +107,7 @@ SYMBOLS = {
     "gnx_device_count": (C.c_int, []),
     "gnx_host_alloc": (_I, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "gnx_host_free": (_I, [_VP, _VP]),
+    "gnx_host_flags": (_I, [_VP, C.POINTER(C.c_uint)]),
     "gnx_init": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "gnx_ctx_free": (None, [_VP]),
     "gnx_last_error": (C.c_char_p, [_VP]),

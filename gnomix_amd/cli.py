@@ -90,13 +90,29 @@ def run_inference(base_args, model, snp_level=False, bed_file_output=False, verb
     t0 = clock()
     out = (model.dev.ctx.pinned_empty((N, model.W, model.A), model.dev.proba_dtype()), model.dev.ctx.pinned_empty((N, model.W), np.int32))
     runner = model.dev
+    own_group = None
     if devices is not None and not isinstance(devices, (list, tuple)):
         runner = devices                                                   # a DeviceGroup the caller keeps
-    elif devices is not None and len(devices) > 1:
+    elif devices is not None and len(devices) > 1 and vcf.n_samples > 1:
         from .multi import DeviceGroup
-        runner = DeviceGroup(model.data, devices, first=model.dev)
+        # no more replicas than shards of whole individuals; made on one thread per device; released below whatever happens
+        own_group = DeviceGroup(model.data, devices, first=model.dev, n_ind=vcf.n_samples)
+        if len(own_group.models) > 1:
+            runner = own_group
         T["replicate_model"] = clock() - t0
         t0 = clock()
+    try:
+        return _run_and_write(model, base_args, runner, vcf, src, vcf_idx, fmt_idx, N, out, T, t0, snp_level, bed_file_output, verbose)
+    finally:
+        if own_group is not None:
+            own_group.close()
+
+
+def _run_and_write(model, base_args, runner, vcf, src, vcf_idx, fmt_idx, N, out, T, t0, snp_level, bed_file_output, verbose):
+    from time import perf_counter as clock
+    from . import postprocess as pp
+    from . import vcfio
+    chm, output_path = base_args["chm"], base_args["output_basename"]
     if not base_args["phase"]:
         proba, labels = runner.infer_gt2(vcf.gt2, N, src, out=out)
         T["infer"] = clock() - t0

@@ -249,7 +249,7 @@ void* gnx_pin_alloc(size_t bytes) {
     }
   }
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
     // the idle list may be what exhausts the pinnable memory: release it and try once more
     std::vector<std::pair<void*, size_t>> drop;
     {
@@ -259,7 +259,7 @@ void* gnx_pin_alloc(size_t bytes) {
       for (auto& d : drop) c.live.erase(d.first);
     }
     for (auto& d : drop) (void)hipHostFree(d.first);
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
   }
   std::lock_guard<std::mutex> g(c.mu);
   c.live[p] = bytes;
@@ -291,6 +291,11 @@ int gnx_host_alloc(gnx_ctx* ctx, size_t bytes, void** out) {
   *out = gnx_pin_alloc(bytes);
   if (!*out) return fail(ctx, GNX_ENOMEM, "hipHostMalloc(" + std::to_string(bytes) + ") failed");
   return GNX_OK;
+}
+
+int gnx_host_flags(const void* p, unsigned* flags) {
+  if (!p || !flags) return GNX_EINVAL;
+  return hipHostGetFlags(flags, const_cast<void*>(p)) == hipSuccess ? GNX_OK : GNX_EHIP;
 }
 
 int gnx_host_free(gnx_ctx* ctx, void* p) {

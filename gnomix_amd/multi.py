@@ -21,12 +21,22 @@ from .model import DeviceModel
 
 
 def visible_devices():
-    """device ordinals to use: GNX_DEVICES="0,2,3" or every GPU the process sees"""
+    """device ordinals to use: GNX_DEVICES="0,2,3" or every GPU the process sees.  Every ordinal is checked against
+    gnx_device_count(): a wrong list fails here, with a message, instead of inside gnx_init on a worker thread."""
+    n = max(int(_lib.load().gnx_device_count()), 0)
     env = os.environ.get("GNX_DEVICES", "").strip()
-    if env:
-        return [int(t) for t in env.split(",") if t.strip() != ""]
-    n = _lib.load().gnx_device_count()
-    return list(range(max(n, 1)))
+    if not env:
+        return list(range(max(n, 1)))
+    try:
+        devs = [int(t) for t in env.split(",") if t.strip() != ""]
+    except ValueError:
+        raise _lib.GnxError(_lib.GNX_EINVAL, "GNX_DEVICES=%r: a comma-separated list of device ordinals is expected" % env) from None
+    if not devs:
+        raise _lib.GnxError(_lib.GNX_EINVAL, "GNX_DEVICES=%r names no device" % env)
+    bad = [d for d in devs if d < 0 or d >= n]
+    if bad:
+        raise _lib.GnxError(_lib.GNX_EINVAL, "GNX_DEVICES=%r: ordinals %s are outside the %d visible device(s)" % (env, bad, n))
+    return devs
 
 
 def shard_individuals(n_ind, k, weights=None):
@@ -46,29 +56,94 @@ def shard_individuals(n_ind, k, weights=None):
     return out
 
 
+class DeviceGroupError(_lib.GnxError):
+    """one or more devices of a DeviceGroup failed: .failures = [(position in the group, device ordinal, exception), ...]"""
+
+    def __init__(self, failures):
+        self.failures = failures
+        code = next((e.code for _, _, e in failures if isinstance(e, _lib.GnxError)), _lib.GNX_EHIP)
+        super().__init__(code, "; ".join("device %d (context %d of the group): %s" % (d, i, e) for i, d, e in failures))
+
+
 class DeviceGroup:
     """replicas of one model, one per entry of `devices` (the same ordinal may appear several times: several contexts on one
-    GPU — how the tests exercise the sharded path on a single-GPU box)"""
+    GPU — how the tests exercise the sharded path on a single-GPU box).
 
-    def __init__(self, data, devices=None, first=None):
+    `n_ind`: the number of individuals the group will be asked to shard, when known: no more replicas are made than there are
+    shards (a one-sample query on an 8-GPU node makes none).  Replicas are loaded on one thread per device (a model upload is a
+    host-side re-layout plus one copy: the devices do not wait for each other).  The group owns the contexts it made — close()
+    (or a failed job) releases them — never the caller's `first`."""
+
+    def __init__(self, data, devices=None, first=None, n_ind=None):
         devices = list(devices) if devices is not None else visible_devices()
+        if not devices:
+            raise _lib.GnxError(_lib.GNX_EINVAL, "DeviceGroup: no device")
+        n_dev = max(int(_lib.load().gnx_device_count()), 0)
+        bad = [d for d in devices if not isinstance(d, (int, np.integer)) or d < 0 or d >= max(n_dev, 1)]
+        if bad:
+            raise _lib.GnxError(_lib.GNX_EINVAL, "DeviceGroup: ordinals %s are outside the %d visible device(s)" % (bad, n_dev))
+        if n_ind is not None:
+            devices = devices[:max(1, len(shard_individuals(int(n_ind), len(devices))))]
         self.devices = devices
-        self.models = []
+        self.data = data
+        self._own = []
+        models = [None] * len(devices)
+        errs = []
+
+        def load(i, d):
+            try:
+                models[i] = DeviceModel(data, ctx=_lib.Context(int(d)))
+            except BaseException as e:   # noqa: BLE001 - reported below
+                errs.append((i, int(d), e))
+        ts = []
         for i, d in enumerate(devices):
             if i == 0 and first is not None:
-                self.models.append(first)            # a DeviceModel the caller already loaded (its context is kept)
+                models[0] = first                       # a DeviceModel the caller already loaded (its context is kept)
             else:
-                self.models.append(DeviceModel(data, ctx=_lib.Context(d)))
+                ts.append(threading.Thread(target=load, args=(i, d), daemon=True))
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        self.models = models
+        self._own = [m for i, m in enumerate(models) if m is not None and not (i == 0 and first is not None)]
+        if errs:
+            self.close()
+            raise DeviceGroupError(sorted(errs, key=lambda f: f[0]))
         m0 = self.models[0]
         self.W, self.A, self.C = m0.W, m0.A, m0.C
-        self.data = data
+        self._sync_state()
+
+    def _sync_state(self):
+        """what gnomix.py pokes into the loaded model after the fact (gnomix.py:365-370: model.calibrate, model.smooth.calibrate)
+        lives in the FIRST model: every replica follows it before each run, or the shards of one output would differ"""
+        m0 = self.models[0]
+        want = bool(getattr(m0, "calibrated", False))
+        for m in self.models[1:]:
+            if bool(getattr(m, "calibrated", False)) != want:
+                m.set_calibrate(want)
 
     def close(self):
-        for m in self.models:
-            m.close()
+        """releases the replicas (and their contexts) this group made; the caller's `first` stays open"""
+        for m in self._own:
+            try:
+                ctx = m.ctx
+                m.close()
+                ctx.close()
+            except Exception:   # noqa: BLE001 - closing is best effort
+                pass
+        self._own = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _run(self, jobs):
-        """jobs: [(model, callable)] -> each on its own thread (ctypes releases the GIL for the duration of a library call)"""
+        """jobs: [(model, callable)] -> each on its own thread (ctypes releases the GIL for the duration of a library call).  Every
+        job runs to its end (a library call cannot be cancelled); if any failed the group closes its contexts and ONE error names
+        every failed device."""
         errs = [None] * len(jobs)
 
         def work(i, fn):
@@ -81,9 +156,13 @@ class DeviceGroup:
             t.start()
         for t in ts:
             t.join()
-        for e in errs:
-            if e is not None:
-                raise e
+        failures = [(i, int(self.devices[self.models.index(m)]) if m in self.models else -1, e) for i, ((m, _), e) in enumerate(zip(jobs, errs)) if e is not None]
+        if failures:
+            self.close()
+            for _, _, e in failures:
+                if isinstance(e, (KeyboardInterrupt, SystemExit)):
+                    raise e
+            raise DeviceGroupError(failures)
 
     def _outputs(self, N, proba_dtype, out):
         m0 = self.models[0]
@@ -100,6 +179,7 @@ class DeviceGroup:
     def infer_gt2(self, G, N, src, proba_dtype=None, out=None):
         """DeviceModel.infer_gt2 with the individuals cut over the group's devices -> (proba, labels)"""
         m0 = self.models[0]
+        self._sync_state()
         G, N, src = m0._gt2_args(G, N, src)
         if N % 2:
             raise ValueError("N = 2 * samples")
@@ -121,6 +201,7 @@ class DeviceGroup:
     def phase_gt2(self, G, N, src, out_cols=None, max_it=50, proba_dtype=None, out=None):
         """DeviceModel.phase_gt2 cut the same way -> (G_phased or None, proba, labels, n_switches)"""
         m0 = self.models[0]
+        self._sync_state()
         G, N, src = m0._gt2_args(G, N, src)
         if N % 2:
             raise ValueError("phase_gt2: N = 2 * individuals")

@@ -207,6 +207,11 @@ int gnx_synchronize(gnx_ctx* ctx);
  * a caller that lets its VCF reader fill a buffer from gnx_host_alloc avoids that extra pass. */
 int gnx_host_alloc(gnx_ctx* ctx, size_t bytes, void** out);
 int gnx_host_free(gnx_ctx* ctx, void* p);
+/* allocation flags of a gnx_host_alloc buffer (hipHostGetFlags).  Every buffer is hipHostMallocPortable (bit 0): page-locked for
+ * EVERY device of the process, because the one-process multi-GPU file path (gnomix_amd/multi.py) hands the same parsed genotype
+ * rows and output arrays to contexts on different devices. */
+#define GNX_HOST_PORTABLE 0x1u
+int gnx_host_flags(const void* p, unsigned* flags);
 
 /* model */
 int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* desc, gnx_model** out);

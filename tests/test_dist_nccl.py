@@ -76,6 +76,23 @@ def test_bench_force_dist_runs_the_rccl_path_on_one_gpu():
     assert isinstance(line["label_checksum"], int)
 
 
+def test_bench_force_dist_with_the_file_leg_on_two_contexts():
+    """first contact of the two multi-GPU paths on a 1-GPU box: the timed loop through torch.distributed / RCCL (world 1) AND the
+    e2e_vcf leg through multi.DeviceGroup([0, 0]) (two contexts, two host threads, shared page-locked rows and outputs)"""
+    e = _env()
+    e["GNX_BENCH_FORCE_DIST"] = "1"
+    e["GNX_BENCH_VCF_DEVICES"] = "0,0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--haps", "512",
+                        "--cpu-seconds", "0", "--e2e-steps", "0", "--vcf-reps", "1", "--trained", "0"], capture_output=True, text=True,
+                       timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["dist_backend"] == "nccl" and line["value"] > 0
+    v = line["e2e_vcf"]
+    assert "error" not in v, v
+    assert v["devices"] == [0, 0] and v["msp_labels_equal_device_path"] is True and v["haplotypes_per_s"] > 0
+
+
 def test_bench_refuses_more_gpus_than_the_box_has():
     import torch
     have = torch.cuda.device_count()

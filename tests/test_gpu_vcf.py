@@ -273,3 +273,93 @@ def test_one_process_several_contexts_writes_the_same_files(ga, tmp_path, phase,
         assert np.array_equal(G1, G2) and np.array_equal(q1, q2) and np.array_equal(y1, y2) and np.array_equal(s1, s2)
     for m in grp.models[1:]:
         m.close()
+
+
+# ---------------------------------------------------------------- multi-GPU first-contact hardening ------------------
+def test_page_locked_buffers_are_portable(ga):
+    """every buffer multi.py shares between contexts (the parsed gt2 rows, the outputs) comes from gnx_host_alloc: page-locked for
+    EVERY device of the process (hipHostMallocPortable), not only for the device that was current when it was made"""
+    import ctypes
+    from gnomix_amd import _lib
+    ctx = _lib.default_context(0)
+    arr = ctx.pinned_empty((1 << 20,), np.uint8)
+    fl = ctypes.c_uint(0)
+    assert ctx.lib.gnx_host_flags(arr.ctypes.data, ctypes.byref(fl)) == _lib.GNX_OK
+    assert fl.value & 1, hex(fl.value)      # GNX_HOST_PORTABLE
+    assert ctx.lib.gnx_host_flags(None, ctypes.byref(fl)) == _lib.GNX_EINVAL
+
+
+def test_gnx_devices_is_validated(ga, monkeypatch):
+    from gnomix_amd import multi, _lib
+    n = _lib.load().gnx_device_count()
+    monkeypatch.setenv("GNX_DEVICES", "0,%d" % n)
+    with pytest.raises(_lib.GnxError, match="outside"):
+        multi.visible_devices()
+    monkeypatch.setenv("GNX_DEVICES", ",")
+    with pytest.raises(_lib.GnxError, match="names no device"):
+        multi.visible_devices()
+    monkeypatch.setenv("GNX_DEVICES", "zero")
+    with pytest.raises(_lib.GnxError):
+        multi.visible_devices()
+    monkeypatch.setenv("GNX_DEVICES", "0, 0")
+    assert multi.visible_devices() == [0, 0]
+    monkeypatch.delenv("GNX_DEVICES")
+    assert multi.visible_devices() == list(range(n))
+    from gnomix_amd import synth
+    d = synth.synthetic_model(C=1037, M=100, A=3, S=5, n_rounds=2, seed=1)
+    with pytest.raises(_lib.GnxError, match="outside"):
+        multi.DeviceGroup(d, [0, n + 3])
+
+
+def test_device_group_reports_every_failed_device_and_closes(ga, tmp_path):
+    """k = 3 contexts, two of them broken (their model handles closed under the group): ONE error names both, the group's own
+    contexts are released, the caller's first model keeps working"""
+    from gnomix_amd import synth, vcfio, multi, _lib
+    rng = np.random.default_rng(5)
+    d = synth.synthetic_model(C=4037, M=100, A=4, S=11, n_rounds=4, seed=2)
+    n_ind = 12
+    q = _query(tmp_path, d, n_ind, rng)
+    first = ga.DeviceModel(d, ctx=_lib.Context(0))
+    vcf = vcfio.read_vcf(q, chm="22", ctx=first.ctx)
+    src, _, _ = vcfio.column_map(vcf, d.snp_pos, d.snp_ref, verbose=False)
+    grp = multi.DeviceGroup(d, [0, 0, 0], first=first)
+    assert len(grp.models) == 3 and len(grp._own) == 2
+    p_ok, l_ok = grp.infer_gt2(vcf.gt2, 2 * n_ind, src)
+    grp.models[1].close()
+    grp.models[2].close()
+    with pytest.raises(multi.DeviceGroupError) as ei:
+        grp.infer_gt2(vcf.gt2, 2 * n_ind, src)
+    assert [f[0] for f in ei.value.failures] == [1, 2] and "context 1" in str(ei.value) and "context 2" in str(ei.value)
+    assert grp._own == []
+    p1, l1 = first.infer_gt2(vcf.gt2, 2 * n_ind, src)       # the caller's model and context are untouched
+    assert np.array_equal(l1, l_ok) and np.array_equal(p1, p_ok)
+    # a group never makes more replicas than there are shards of whole individuals
+    g2 = multi.DeviceGroup(d, [0] * 8, first=first, n_ind=3)
+    assert len(g2.models) <= 3
+    g2.close()
+
+
+def test_device_group_follows_the_first_models_calibrate_switch(ga, tmp_path):
+    """gnomix.py:365-370 pokes model.calibrate after loading; the replicas must calibrate (or not) like the first model, or the
+    shards of one output array would differ"""
+    from gnomix_amd import synth, vcfio, multi, _lib
+    rng = np.random.default_rng(6)
+    d = synth.synthetic_model(C=4037, M=100, A=4, S=11, n_rounds=4, seed=3)
+    xs = [np.sort(rng.random(9)) for _ in range(d.A)]
+    d.calib_off = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int32)
+    d.calib_x = np.concatenate(xs)
+    d.calib_y = np.concatenate([np.sort(rng.random(len(x))) for x in xs])
+    n_ind = 10
+    q = _query(tmp_path, d, n_ind, rng)
+    first = ga.DeviceModel(d, ctx=_lib.Context(0))
+    vcf = vcfio.read_vcf(q, chm="22", ctx=first.ctx)
+    src, _, _ = vcfio.column_map(vcf, d.snp_pos, d.snp_ref, verbose=False)
+    with multi.DeviceGroup(d, [0, 0, 0], first=first) as grp:
+        for on in (True, False, True):
+            first.set_calibrate(on)
+            p1, l1 = first.infer_gt2(vcf.gt2, 2 * n_ind, src)
+            p2, l2 = grp.infer_gt2(vcf.gt2, 2 * n_ind, src)
+            assert p1.dtype == p2.dtype and np.array_equal(p1, p2) and np.array_equal(l1, l2), on
+        raw = first.infer_gt2(vcf.gt2, 2 * n_ind, src)[0]
+        first.set_calibrate(False)
+        assert not np.array_equal(raw.astype(np.float64), first.infer_gt2(vcf.gt2, 2 * n_ind, src)[0].astype(np.float64))
