@@ -948,12 +948,16 @@ int gnx_calibrate_rows(gnx_model* m, const void* proba, int proba_is_f64, int64_
 
 // which Gnofix kernel a model runs: the rank-strip kernel (k_gnofix.hip) wherever the smoother has a rank copy, else (or with
 // GNX_GNOFIX_IMPL=f32) the float32-strip kernel of rounds 1-3 (k_gnofix_f32.hip)
-static bool gnofix_use_rk(const gnx_model* m) {
-  return m->xgb.gf_packed && m->xgb.rk_thr && m->ctx->tune.gnofix_impl != 1 && m->info.C < ((int64_t)1 << 31);
-}
 static int gnofix_threads(const gnx_model* m) {
   const int t = m->ctx->tune.gnofix_threads;
   return (t == 256 || t == 512 || t == 1024) ? t : 512;
+}
+static bool gnofix_use_rk(const gnx_model* m) {
+  if (!(m->xgb.gf_packed && m->xgb.rk_thr && m->ctx->tune.gnofix_impl != 1 && m->info.C < ((int64_t)1 << 31))) return false;
+  // the rank kernel keeps ~10 bytes per window next to the staged trees: where that does not fit the 160 KB (W beyond ~10 k, very
+  // fine windows) the float32-strip kernel with its global-scratch strips still runs (it did before the rank kernel existed)
+  const int W = (int)m->info.W, A = m->info.A, S = m->info.S, T = gnofix_threads(m);
+  return gnx_gnofix_lds_bytes(W, A, S, m->xgb.gf_pitch, gnx_gnofix_cap(m->xgb.gf_max_class, m->xgb.D, S, T), m->xgb.D, T, m->xgb.n_trees) <= (size_t)160 * 1024;
 }
 
 static int gnofix_check(gnx_model* m, int64_t ldx, int64_t n_ind, int32_t max_it, bool ptrs_ok, bool* in_lds) {
@@ -1200,7 +1204,8 @@ static int gbt_check(gnx_ctx* ctx, const void* B, const int32_t* y, int64_t N, i
   if (P->tree_method != 0 && P->tree_method != 1) return fail(ctx, GNX_EINVAL, "train_gbt: tree_method is 0 (histogram) or 1 (exact greedy)");
   if (!(P->eta > 0.0) || !(P->lambda >= 0.0) || !(P->gamma >= 0.0) || !(P->min_child_weight >= 0.0))
     return fail(ctx, GNX_EINVAL, "train_gbt: eta > 0, lambda / gamma / min_child_weight >= 0");
-  if ((int64_t)N * W >= ((int64_t)1 << 31)) return fail(ctx, GNX_EINVAL, "train_gbt: N * W must stay below 2^31 rows");
+  // rows are indexed in int32, the exact-greedy sort over the PADDED windows of a haplotype (W + 2 * ((S + 1) / 2)) as well
+  if ((int64_t)N * ((int64_t)W + 2 * ((S + 1) / 2)) >= ((int64_t)1 << 31)) return fail(ctx, GNX_EINVAL, "train_gbt: N * (W + S + 1) must stay below 2^31 rows");
   return GNX_OK;
 }
 

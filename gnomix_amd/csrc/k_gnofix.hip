@@ -1015,12 +1015,15 @@ hipError_t gnx_launch_gnofix_prep(const GnofixLaunch& L, int64_t n_ind, hipStrea
   const int64_t n = 2 * n_ind * (int64_t)L.W * L.A;
   hipLaunchKernelGGL(k_gnofix_ranks, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, L.B, n, L.d.rk_thr, L.d.rk_lut, L.d.rk_K,
                      L.d.rk_steps, const_cast<uint16_t*>(L.R));
-  if (L.x_packed)
-    hipLaunchKernelGGL(k_gnofix_dif_p2, dim3((unsigned)((NWD + 3) / 4), (unsigned)n_ind), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(L.X),
-                       L.ldx, L.C, L.W, const_cast<uint32_t*>(L.dif));
-  else
-    hipLaunchKernelGGL(k_gnofix_dif, dim3((unsigned)((NWD + 3) / 4), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W,
-                       const_cast<uint32_t*>(L.dif));
+  for (int64_t i0 = 0; i0 < n_ind; i0 += 65535) {  // the individual is grid.y: at most 65535 per launch
+    const unsigned ny = (unsigned)std::min<int64_t>(65535, n_ind - i0);
+    uint32_t* dif = const_cast<uint32_t*>(L.dif) + (size_t)i0 * NWD;
+    if (L.x_packed)
+      hipLaunchKernelGGL(k_gnofix_dif_p2, dim3((unsigned)((NWD + 3) / 4), ny), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(L.X) + 2 * i0 * L.ldx,
+                         L.ldx, L.C, L.W, dif);
+    else
+      hipLaunchKernelGGL(k_gnofix_dif, dim3((unsigned)((NWD + 3) / 4), ny), dim3(256), 0, s, L.X + 2 * i0 * L.ldx, L.ldx, L.C, L.W, dif);
+  }
   return hipGetLastError();
 }
 
@@ -1044,10 +1047,15 @@ hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, int threads, 
   else if (threads == 1024) e = launch_t<1024>(L, n_ind, s);
   else e = launch_t<512>(L, n_ind, s);
   if (e != hipSuccess) return e;
-  if (L.x_packed)
-    hipLaunchKernelGGL(k_gnofix_swap_p2, dim3((unsigned)((L.C + 16383) / 16384), (unsigned)n_ind), dim3(256), 0, s, reinterpret_cast<uint8_t*>(L.X),
-                       L.ldx, L.C, L.W, L.par);
-  else
-    hipLaunchKernelGGL(k_gnofix_swap, dim3((unsigned)((L.C + 16383) / 16384), (unsigned)n_ind), dim3(256), 0, s, L.X, L.ldx, L.C, L.W, L.par);
+  const int NWD = (L.W + 31) / 32;
+  for (int64_t i0 = 0; i0 < n_ind; i0 += 65535) {  // the individual is grid.y: at most 65535 per launch
+    const unsigned ny = (unsigned)std::min<int64_t>(65535, n_ind - i0);
+    const uint32_t* par = L.par + (size_t)i0 * NWD;
+    if (L.x_packed)
+      hipLaunchKernelGGL(k_gnofix_swap_p2, dim3((unsigned)((L.C + 16383) / 16384), ny), dim3(256), 0, s, reinterpret_cast<uint8_t*>(L.X) + 2 * i0 * L.ldx,
+                         L.ldx, L.C, L.W, par);
+    else
+      hipLaunchKernelGGL(k_gnofix_swap, dim3((unsigned)((L.C + 16383) / 16384), ny), dim3(256), 0, s, L.X + 2 * i0 * L.ldx, L.ldx, L.C, L.W, par);
+  }
   return hipGetLastError();
 }

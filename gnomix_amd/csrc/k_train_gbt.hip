@@ -18,6 +18,7 @@
 // The trees come back in the layout gnx_model_desc takes (tree_off / left / right / feat / cond / tree_class), thresholds on
 // the 1/65536 grid, so the trained smoother runs on k_smooth_xgb_rk like any other.
 #include <algorithm>
+#include <limits>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -609,7 +610,8 @@ hipError_t gnx_train_gbt_run(const void* dB, int b_is_f64, const int32_t* dy, in
       for (int64_t n = 0; n < N; ++n)
         for (int64_t j = 0; j < G.Wp; ++j) {
           const int64_t src = j < G.pad ? G.pad - 1 - j : (j < G.pad + W ? j - G.pad : W - 1 - (j - G.pad - W));
-          v[(size_t)(n * G.Wp + j)] = hB[(size_t)((n * W + src) * A + a)];
+          const float f = hB[(size_t)((n * W + src) * A + a)];
+          v[(size_t)(n * G.Wp + j)] = f == f ? f : std::numeric_limits<float>::infinity();  // a NaN would break the comparator's strict weak order
         }
       std::vector<int32_t> idx((size_t)NP);
       std::iota(idx.begin(), idx.end(), 0);

@@ -329,7 +329,7 @@ typedef struct gnx_gbt_params {
   int32_t max_depth;         /* 4, at most 5 */
   int32_t max_bin;           /* 256, at most 256 */
   int32_t tree_method;       /* 0 = histogram (max_bin quantile bins per class column, xgboost's "hist"); 1 = exact greedy: a candidate
-                                between every two distinct feature values of a node's rows (xgboost's "exact"; max_depth <= 4) */
+                                between every two distinct feature values of a node's rows (xgboost's "exact"); NaN probabilities sort as +inf */
   double eta;                /* 0.1  (learning_rate) */
   double lambda;             /* 1.0  (reg_lambda) */
   double gamma;              /* 0.0  (min_split_loss) */

@@ -200,3 +200,77 @@ def test_config4_whole_genome_22_models_resident_in_one_context(ga, oracle):
         m.close()
     ctx.close()
     assert time.time() - t_start < 120, "the whole-genome residency test is meant to stay near a minute"
+
+
+@pytest.mark.timeout(600)
+def test_config5_full_size_properties(ga, oracle):
+    """BASELINE configs[4] at its real SNP geometry on one GPU's share of the work: chr1 WGS density C = 1 431 500, M = 1000
+    (2 000-SNP windows, W = 1431), A = 12, N = 256 haplotypes.
+      (5a) logistic base -> CRF smoother (src/Smooth/crf.py:17-67; the reference rejects CRF + Gnofix, src/model.py:194)
+      (5b) logistic base -> xgb smoother -> Gnofix (src/model.py:188-214) on tract-structured individuals with switch errors
+    Size-independent properties (row permutation and batch splits are invisible bit for bit, probabilities sum to 1, labels are the
+    argmax, the 2-bit route equals the int8 route) plus the oracle on two haplotypes / one individual."""
+    import torch
+    from gnomix_amd import synth, _lib
+    C, M, A, S, N = 1_431_500, 1000, 12, 75, 256
+    ctx = _lib.Context(0)
+    rng = np.random.RandomState(5)
+    # ---------------- (5a) ----------------
+    d = synth.synthetic_model(C=C, M=M, A=A, S=S, seed=5, smooth="crf")
+    assert d.W == 1431 and d.lr_coef.shape == (1431, 12, 2500)
+    dev = ga.DeviceModel(d, ctx=ctx)
+    X = synth.synthetic_X(N, C, seed=17, miss=0.01)
+    p, lab = dev.infer(X)                                  # float64 (CRF computes in float64)
+    assert p.dtype == np.float64 and p.shape == (N, 1431, A)
+    assert np.allclose(p.sum(-1), 1.0, atol=1e-9) and np.array_equal(lab, np.argmax(p, -1)) and np.isfinite(p).all()
+    perm = rng.permutation(N)
+    p2, l2 = dev.infer(X[perm])
+    assert np.array_equal(p2, p[perm]) and np.array_equal(l2, lab[perm])
+    p3, l3 = dev.infer(X[:101])                            # another row tiling, a ragged batch
+    assert np.array_equal(p3, p[:101]) and np.array_equal(l3, lab[:101])
+    pk, lk = dev.infer_packed(dev.pack_x(X))               # 2-bit rows: one column tile per slot, two passes
+    assert np.array_equal(pk, p) and np.array_equal(lk, lab)
+    idx = [3, N - 1]
+    Bo = oracle.base_lr(X[idx], M, d.context, d.lr_coef, d.lr_intercept)
+    _, Bh = dev.base_predict(X[idx])
+    assert np.max(np.abs(Bh - Bo)) < 1e-12
+    po, lo = oracle.smooth_crf(Bo, d.crf_state, d.crf_trans)
+    assert np.max(np.abs(p[idx] - po)) < 1e-9 and np.array_equal(lab[idx], lo)
+    dev.close()
+    del d, dev, p, p2, p3, pk
+    # ---------------- (5b) ----------------
+    n_ind = N // 2
+    d = synth.synthetic_model(C=C, M=M, A=A, S=S, seed=6, smooth=None)
+    d.smooth_kind = "xgb"
+    for k, v in synth.synthetic_smoothing_trees(100, A, S, seed=6).items():
+        setattr(d, k, v)
+    dev = ga.DeviceModel(d, ctx=ctx)
+    B = synth.synthetic_phased_individuals(n_ind, d.W, A, seed=3)      # admixed individuals, two switch errors per haplotype pair
+    Xq = rng.randint(0, 2, size=(N, C)).astype(np.int8)
+    Xo, Y, nsw = dev.gnofix(Xq, B)
+    assert int(nsw.sum()) > n_ind // 2 and int(nsw.max()) >= 2          # the loop really re-phases
+    T = oracle.Trees(d.tree_off, d.left, d.right, d.feat, d.cond, d.tree_class, d.A, d.base_score)
+    rows = lambda r: oracle.xgb_predict_proba(T, r)
+    labs = lambda b: oracle.smooth_xgb(T, b, S)[1]
+    i = int(np.argmax(nsw))                                            # the individual with the most accepted switches
+    Xm, Xp, Ym, Yp, _, ns = oracle.gnofix(Xq[2 * i], Xq[2 * i + 1], B[2 * i:2 * i + 2], S, rows, labs)
+    assert np.array_equal(Xo[2 * i], Xm) and np.array_equal(Xo[2 * i + 1], Xp)
+    assert np.array_equal(Y[2 * i], Ym) and np.array_equal(Y[2 * i + 1], Yp) and int(nsw[i]) == ns
+    permi = rng.permutation(n_ind)
+    rowsp = np.stack([2 * permi, 2 * permi + 1], 1).reshape(-1)
+    Xo2, Y2, nsw2 = dev.gnofix(Xq[rowsp], B[rowsp])
+    assert np.array_equal(Xo2, Xo[rowsp]) and np.array_equal(Y2, Y[rowsp]) and np.array_equal(nsw2, nsw[permi])
+    # the same individuals as 2-bit rows resident in HBM: identical labels, switch counts and re-phased SNPs
+    Pt = torch.from_numpy(np.asarray(dev.pack_x(Xq))).cuda()
+    Yt, nt = dev.gnofix_packed_device(Pt, torch.from_numpy(B).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(Yt.cpu().numpy(), Y) and np.array_equal(nt.cpu().numpy(), nsw)
+    assert torch.equal(Pt.cpu(), torch.from_numpy(np.asarray(dev.pack_x(Xo))))
+    # the whole phase pipeline of the command line on a few individuals: base (logistic) -> smoother -> Gnofix -> predict_proba
+    _, Bb = dev.base_predict(Xq[:8])
+    Xp8, Y8, n8 = dev.gnofix(Xq[:8], Bb, max_it=3)
+    Xp8b, Y8b, n8b = dev.gnofix(Xq[:8][[2, 3, 0, 1, 6, 7, 4, 5]], Bb[[2, 3, 0, 1, 6, 7, 4, 5]], max_it=3)
+    assert np.array_equal(Y8b, Y8[[2, 3, 0, 1, 6, 7, 4, 5]]) and np.array_equal(Xp8b, Xp8[[2, 3, 0, 1, 6, 7, 4, 5]])
+    pf, lf = dev.infer(Xp8)
+    assert np.allclose(pf.sum(-1), 1.0, atol=1e-5) and np.array_equal(lf, np.argmax(pf, -1))
+    ctx.close()
