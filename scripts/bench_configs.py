@@ -165,6 +165,41 @@ def c5b(n_ind=4096):
     return res
 
 
+def c5br(n_ind=2048):
+    """config 5b with everything resident in HBM (no staging): chr1 WGS (W = 1431), A = 12, xgb smoother + Gnofix on individuals
+    with two switch errors per haplotype pair — the workload README / DESIGN quote for the Gnofix kernel's counters
+    (profiles/r05_c5br_*), once on int8 rows and once on 2-bit rows (gnx_gnofix_packed_dev)"""
+    W, A, S = 1431, 12, 75
+    C = 1000 * W + 500
+    data = gnomix_amd.GnxModelData(C=C, M=1000, A=A, S=S, context=500, smooth_kind="xgb")
+    for k, v in synth.synthetic_smoothing_trees(100, A, S, seed=6).items():
+        setattr(data, k, v)
+    model = gnomix_amd.DeviceModel(data)
+    B = synth.synthetic_phased_individuals(n_ind, W, A, seed=3)
+    Xd = torch.randint(0, 2, (2 * n_ind, C), dtype=torch.int8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    Bd = torch.from_numpy(B).cuda()
+    Pd = model.pack_device(Xd)
+    Y0, n0 = model.gnofix_device(Xd.clone(), Bd)          # sizes the workspaces
+    out = {}
+    for name, src, fn in (("int8", Xd, model.gnofix_device), ("packed", Pd, model.gnofix_packed_device)):
+        best = 1e9
+        for _ in range(3):
+            w = src.clone()
+            torch.cuda.synchronize()
+            model.ctx.profile_reset(); model.ctx.profile_enable(True)
+            t0 = time.perf_counter()
+            Y, ns = fn(w, Bd)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+            model.ctx.profile_enable(False)
+        assert torch.equal(Y, Y0) and torch.equal(ns, n0)
+        out[name] = {"seconds": best, "individuals_per_s": n_ind / best, "kernels_ms": prof(model.ctx)}
+    res = {"config": "c5br chr1 WGS A=12 xgb smoother + Gnofix, device-resident", "individuals": n_ind, "mean_switches": float(n0.float().mean()),
+           "int8_rows": out["int8"], "packed_rows": out["packed"]}
+    print(json.dumps(res))
+    return res
+
+
 def cf(N=10000):
     """chr22 (config 2 geometry) with the tree-ensemble base: XGBBase shape, 20 rounds x 7 classes, depth 4, per window"""
     C, M, A = 370_500, 1000, 7

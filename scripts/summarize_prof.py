@@ -100,7 +100,7 @@ def main(src, dst, tag):
             for k, v in pmc.items():
                 b = v.get("derived", {}).get("hbm_bytes_per_launch")
                 if b is not None:
-                    name = "k_base_logistic" if "k_base_logistic" in k else "k_smooth_xgb" if "k_smooth_xgb" in k else k
+                    name = "k_base_logistic_p2" if "k_base_logistic_p2" in k else "k_base_logistic" if "k_base_logistic" in k else "k_smooth_xgb" if "k_smooth_xgb" in k else k
                     traffic[name] = b
             # stamp: the kernel sources these counters were collected from (bench.py prints counters.stale when its own differ)
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
