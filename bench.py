@@ -719,7 +719,18 @@ def _cpu_baseline(args, data, X, out_dev):
     if limit is not None:
         limit.restore_original_limits() if hasattr(limit, "restore_original_limits") else limit.unregister()
     blas_err = float(np.abs(Bb - B[:n_b]).max())
-    return {"value": n_s / (t_base + t_sm), "unit": "haplotypes/s", "cores": cores, "kind": "port",
+    # the stated baseline: the FASTER CPU arithmetic of each leg — the reference's own base arithmetic (one BLAS product per window,
+    # float64) and the port's tree smoother (xgboost itself is absent from the image) — each scaled to one haplotype and added
+    t_base_port = t_base / n_s
+    t_base_blas = t_blas / n_b
+    t_base_best = min(t_base_port, t_base_blas)
+    composite = 1.0 / (t_base_best + t_sm / n_s)
+    return {"value": composite, "unit": "haplotypes/s", "cores": cores, "kind": "blas+port",
+            "components": {"base": "base_lr_blas (numpy / BLAS, the reference's arithmetic)" if t_base_blas <= t_base_port else "oracle port (scalar C)",
+                           "base_haplotypes_per_s": 1.0 / t_base_best, "base_threads": cores, "blas_threads_per_call": blas_threads,
+                           "smoother": "oracle port (scalar C walker, float32 sums in tree order)", "smoother_haplotypes_per_s": n_s / t_sm,
+                           "smoother_threads": cores},
+            "port_only_haplotypes_per_s": n_s / (t_base + t_sm),
             "base_lr_haplotypes_per_s": n_s / t_base, "smooth_xgb_haplotypes_per_s": n_s / t_sm,
             "one_core_haplotypes_per_s": 1.0 / per, "parallel_efficiency": (n_s / (t_base + t_sm)) / (cores / per),
             "base_lr_blas": {"haplotypes_per_s": n_b / t_blas, "sample": n_b, "max_abs_diff_vs_port": blas_err,

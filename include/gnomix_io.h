@@ -77,6 +77,11 @@ int gnx_vcf_strings(const gnx_vcf* vcf, int field, const char** blob, const int6
 /* calldata/GT exactly as scikit-allel returns it: (n_variants, n_samples, 2) int8, -1 = missing */
 int gnx_vcf_gt_int8(const gnx_vcf* vcf, int8_t* out, int n_threads);
 
+/* raw DEFLATE (RFC 1951) -> exactly out_n bytes at `out` (the payload of one BGZF block and its ISIZE): the word-at-a-time
+ * decoder gnx_vcf_read inflates .vcf.gz queries with (csrc/gnx_inflate.cpp; zlib remains the fallback for a block it rejects).
+ * 0: ok; -1: corrupt or truncated input, or a size other than out_n.  No context, no GPU. */
+int gnx_io_inflate_raw(const uint8_t* in, size_t in_n, uint8_t* out, size_t out_n);
+
 /* ---- gt2 <-> the int8 matrix of the models, on the device (context stream; device pointers) --------------------------
  * src (C,) int32 describes vcf_to_npy's column map: src[c] = v | (flip << 30) — model SNP c is variant row v of G, with
  * 0 <-> 1 exchanged when the query's REF differs from the model's (utils.py:136-147) — or -1: absent from the query
