@@ -194,31 +194,37 @@ struct Bits {
 // one compressed block's symbols.  FAST: no bounds checks — the caller guarantees >= 8 input bytes and >= 274 output bytes of slack
 // at the top of every trip.  Returns 0 at end of block, 1 when the slack ran out (continue in the other mode), -1 on corrupt data.
 template <bool FAST>
-int run_block(Bits& b, const Tables& T, uint8_t* out_begin, uint8_t*& outp, uint8_t* out_end) {
+__attribute__((always_inline)) inline int run_block(Bits& bits, const Tables& T, uint8_t* out_begin, uint8_t*& outp, uint8_t* out_end) {
+  // the bit reader lives in locals for the whole block: `out` is a byte pointer, which may alias anything — through the Bits
+  // reference every stored byte would force the buffer, the count and the input pointer back to memory and in again
+  Bits b = bits;
   uint8_t* out = outp;
+  const uint32_t* const ll = T.ll;
+  const uint32_t* const dt = T.d;
+  int rc;
   for (;;) {
     if (FAST) {
-      if (b.in_end - b.in < 8 || out_end - out < 274) { outp = out; return 1; }
+      if (b.in_end - b.in < 8 || out_end - out < 274) { rc = 1; break; }
       b.refill_fast();
     } else {
       b.refill_safe();
-      if (b.over > 8) { outp = out; return -1; }
+      if (b.over > 8) { rc = -1; break; }
     }
-    uint32_t e = T.ll[b.peek(LL_BITS)];
+    uint32_t e = ll[b.peek(LL_BITS)];
     if (e & F_SUB) {
       b.drop((int)(e & 31));
-      e = T.ll[(e >> 16) + b.peek((int)((e >> 8) & 31))];
+      e = ll[(e >> 16) + b.peek((int)((e >> 8) & 31))];
     }
     b.drop((int)(e & 31));
     if (e & F_LIT) {
-      if (!FAST && out >= out_end) { outp = out; return -1; }
+      if (!FAST && out >= out_end) { rc = -1; break; }
       *out++ = (uint8_t)(e >> 16);
       if (FAST) {  // up to two more literals from the bits already in the buffer (>= 56 - 15 bits are left)
-        e = T.ll[b.peek(LL_BITS)];
+        e = ll[b.peek(LL_BITS)];
         if ((e & (F_LIT | F_SUB)) == F_LIT) {
           b.drop((int)(e & 31));
           *out++ = (uint8_t)(e >> 16);
-          e = T.ll[b.peek(LL_BITS)];
+          e = ll[b.peek(LL_BITS)];
           if ((e & (F_LIT | F_SUB)) == F_LIT) {
             b.drop((int)(e & 31));
             *out++ = (uint8_t)(e >> 16);
@@ -228,54 +234,76 @@ int run_block(Bits& b, const Tables& T, uint8_t* out_begin, uint8_t*& outp, uint
       continue;
     }
     if (e & (F_EOB | F_BAD)) {
-      outp = out;
-      return (e & F_EOB) ? 0 : -1;
+      rc = (e & F_EOB) ? 0 : -1;
+      break;
     }
     const int xl = (int)((e >> 8) & 31);
-    uint32_t length = (e >> 16) + b.peek(xl);
+    const uint32_t length = (e >> 16) + b.peek(xl);
     b.drop(xl);
     if (!FAST) b.refill_safe();
-    uint32_t f = T.d[b.peek(D_BITS)];
+    uint32_t f = dt[b.peek(D_BITS)];
     if (f & F_SUB) {
       b.drop((int)(f & 31));
-      f = T.d[(f >> 16) + b.peek((int)((f >> 8) & 31))];
+      f = dt[(f >> 16) + b.peek((int)((f >> 8) & 31))];
     }
-    if (f & F_BAD) { outp = out; return -1; }
+    if (f & F_BAD) { rc = -1; break; }
     b.drop((int)(f & 31));
     const int xd = (int)((f >> 8) & 31);
     if (FAST && b.n < xd) b.refill_fast();  // (15 + 5 + 15 bits are gone at worst: 21 are left, 13 may be needed — never taken)
     const uint32_t dist = (f >> 16) + b.peek(xd);
     b.drop(xd);
-    if (dist > (size_t)(out - out_begin)) { outp = out; return -1; }
+    if (dist > (size_t)(out - out_begin)) { rc = -1; break; }
     const uint8_t* src = out - dist;
     if (FAST) {
       uint8_t* const end = out + length;
       if (dist >= 8) {
-        do {
+        uint64_t w;
+        memcpy(&w, src, 8);  // most matches of genotype text are a field or two long: one word, no loop
+        memcpy(out, &w, 8);
+        if (length > 8) {
+          src += 8;
+          out += 8;
+          do {
+            memcpy(&w, src, 8);
+            memcpy(out, &w, 8);
+            src += 8;
+            out += 8;
+          } while (out < end);
+        }
+      } else if (dist == 1) {
+        memset(out, *src, length);
+      } else {
+        // a short period ("0|0\t" repeats at distance 4): the first 8 bytes one by one — each may read what the one before wrote —
+        // then the copy continues in words from the multiple of the period that is >= 8 (its bytes exist by now)
+        for (int i = 0; i < 8; ++i) out[i] = src[i];
+        static const uint8_t kWide[8] = {0, 8, 8, 9, 8, 10, 12, 14};
+        out += 8;
+        src = out - kWide[dist];
+        while (out < end) {
           uint64_t w;
           memcpy(&w, src, 8);
           memcpy(out, &w, 8);
           src += 8;
           out += 8;
-        } while (out < end);
-      } else if (dist == 1) {
-        memset(out, *src, length);
-      } else {
-        do { *out++ = *src++; } while (out < end);
+        }
       }
       out = end;
     } else {
-      if ((size_t)(out_end - out) < length) { outp = out; return -1; }
+      if ((size_t)(out_end - out) < length) { rc = -1; break; }
       for (uint32_t i = 0; i < length; ++i) out[i] = src[i];
       out += length;
     }
   }
+  bits = b;
+  outp = out;
+  return rc;
 }
 
 }  // namespace
 
 // raw DEFLATE stream `in` -> exactly out_n bytes at `out`.  0: ok; -1: corrupt, truncated, or a size other than out_n.
-extern "C" int gnx_io_inflate_raw(const uint8_t* in, size_t in_n, uint8_t* out, size_t out_n) {
+// (two clones, chosen once by the loader: with BMI2 the variable shifts of the bit reader are shrx / bzhi, without a detour through cl)
+extern "C" __attribute__((target_clones("default", "bmi2"))) int gnx_io_inflate_raw(const uint8_t* in, size_t in_n, uint8_t* out, size_t out_n) {
   if ((!in && in_n) || (!out && out_n)) return -1;
   Bits b;
   b.in = in;
