@@ -117,13 +117,14 @@ struct BaseLRDev {
   int32_t max_piece_chunks = 0;  // longest piece, in chunks
   // 2-bit-native pass (k_base_logistic_p2.hip): the same pieces walked in RUNS of 256 SNPs (64 packed bytes per haplotype row,
   // dword-aligned: a piece starts at SNP b0 & ~15, the up to 15 SNPs before b0 meet zero weights); one run = 4 MFMA entries
-  const int8_t* V2 = nullptr;            // [n_runs][4 entries][NT][7 limbs][64 lanes][16 bytes], k order of the in-register unpack
+  const int8_t* V2 = nullptr;            // [n_runs][EPR entries][NT2][7 limbs][64 lanes][16 bytes], k order of the in-register unpack
   const int32_t* run_byte = nullptr;     // [n_runs] byte offset of the run within a packed row
   const int32_t* run_flush0 = nullptr;   // [n_runs] first window flushed after this run (-1 none)
   const int32_t* run_nflush = nullptr;   // [n_runs] number of windows flushed after this run
   const int32_t* win_run0 = nullptr;     // [W] first run a block must start from to compute window w
   const int32_t* win_run1 = nullptr;     // [W] one past the run after which window w is flushed
   int32_t n_runs = 0;
+  int32_t EPR = 0;   // MFMA entries per run of V2: 4 (runs of 256 SNPs, 64 packed bytes per row) or 8 (512 SNPs, 128 bytes)
   int32_t NT2 = 0;   // column tiles of V2: 1 (column = slot * A + class, R * A <= 16) or R (one tile per slot, column = class; A <= 16)
 };
 

@@ -183,7 +183,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
     // (a piece [b0, b1) starts at SNP b0 & ~15: the up to 15 SNPs before b0 and everything from b1 on meet zero weights).
     // Lane kq of a row's four lanes holds SNPs [64 kq, 64 kq + 64) of the run as four 32-bit words; entry k multiplies word k of every
     // lane, whose in-register unpack puts SNP field f = 4 (t & 3) + (t >> 2) at k position t: k position (kq, t) of entry k of a run
-    // starting at SNP s is SNP  s + 64 kq + 16 k + 4 (t & 3) + (t >> 2).  Same folded weights, same f_w, same digits as V8.
+    // starting at SNP s is SNP  s + 16 EPR kq + 16 k + 4 (t & 3) + (t >> 2)  (EPR = entries per run, 4 or 8).  Same folded weights, same f_w, same digits as V8.
     {
       // column tiles of the 2-bit pass: one tile (column = slot * A + class, as in V8) when the R * A class columns of a SNP fit 16;
       // otherwise one tile PER SLOT (column = class) and one pass per tile (k_base_logistic_p2.hip)
@@ -191,10 +191,18 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
       const int64_t cs2 = NT2 == 1 ? A : 16;
       const char* p2env = std::getenv("GNX_LR_P2");  // 0: never build the planes; 2: build them whatever the padding costs (tests)
       const int p2mode = p2env ? std::atoi(p2env) : 1;
-      // runs are 256 SNPs: short pieces (small windows) would multiply mostly padding — such models keep the int8 kernels
-      int64_t padded = 0;
-      for (size_t k = 0; k < n_pieces; ++k) padded += ((bounds[k + 1] - (bounds[k] & ~(int64_t)15) + 255) / 256) * 256;
-      const bool want_p2 = NT2 > 0 && p2mode != 0 && (p2mode == 2 || padded * 4 <= C * 5);
+      // a run is RS = 512 SNPs (128 packed bytes per row visit: whole cache lines, 8 MFMA entries) where the pieces are long enough for
+      // that, else 256 (64 bytes, 4 entries); short pieces (small windows) would multiply mostly padding — such models keep the int8
+      // kernels.  GNX_LR_P2_RUN=256|512 forces a run length (tests, A/B runs).
+      auto padded_with = [&](int64_t rs) {
+        int64_t p = 0;
+        for (size_t k = 0; k < n_pieces; ++k) p += ((bounds[k + 1] - (bounds[k] & ~(int64_t)15) + rs - 1) / rs) * rs;
+        return p;
+      };
+      int64_t RS = padded_with(512) * 4 <= C * 5 ? 512 : 256;
+      if (const char* e = std::getenv("GNX_LR_P2_RUN")) { const int v = std::atoi(e); if (v == 256 || v == 512) RS = v; }
+      const int EPR = (int)(RS / 64);
+      const bool want_p2 = NT2 > 0 && p2mode != 0 && (p2mode == 2 || padded_with(RS) * 4 <= C * 5);
       if (want_p2) {
         std::vector<int32_t> run_byte, run_flush0, run_nflush, piece_run0(n_pieces + 1);
         std::vector<int64_t> run_s, run_b0, run_b1;
@@ -205,12 +213,12 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
             const int64_t b0 = bounds[k], b1 = bounds[k + 1];
             const int64_t s0 = b0 & ~(int64_t)15;  // 32-bit aligned in the packed row: a load that is not dword-aligned is split by the
                                                     // texture addresser (measured: ~4.5 L1 tag accesses per lane instead of ~0.5)
-            const int64_t nr = (b1 - s0 + 255) / 256;
+            const int64_t nr = (b1 - s0 + RS - 1) / RS;
             int64_t f0 = wi, nf = 0;
             while (wi < W && fpos[(size_t)wi] == b1) { ++wi; ++nf; }
             for (int64_t r = 0; r < nr; ++r) {
-              run_byte.push_back((int32_t)((s0 + 256 * r) / 4));
-              run_s.push_back(s0 + 256 * r); run_b0.push_back(b0); run_b1.push_back(b1);
+              run_byte.push_back((int32_t)((s0 + RS * r) / 4));
+              run_s.push_back(s0 + RS * r); run_b0.push_back(b0); run_b1.push_back(b1);
               const bool last = (r == nr - 1);
               run_flush0.push_back(last && nf ? (int32_t)f0 : -1);
               run_nflush.push_back(last ? (int32_t)nf : 0);
@@ -229,15 +237,15 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
           win_run1[(size_t)i] = piece_run0[kf];
         }
         const size_t entry_bytes = (size_t)NT2 * 7 * 64 * 16;
-        std::vector<int8_t> V2(n_runs * 4 * entry_bytes, 0);
+        std::vector<int8_t> V2(n_runs * (size_t)EPR * entry_bytes, 0);
         auto fill_runs = [&](size_t r_lo, size_t r_hi) {
           std::vector<double> wsum((size_t)A);
           std::vector<uint8_t> any((size_t)A);
           for (size_t r = r_lo; r < r_hi; ++r)
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < EPR; ++k)
               for (int kq = 0; kq < 4; ++kq)
                 for (int t = 0; t < 16; ++t) {
-                  const int64_t j = run_s[r] + 64 * kq + 16 * k + 4 * (t & 3) + (t >> 2);
+                  const int64_t j = run_s[r] + 16 * EPR * kq + 16 * k + 4 * (t & 3) + (t >> 2);  // lane kq holds 16 EPR SNPs of the run, word k of them
                   if (j < run_b0[r] || j >= run_b1[r]) continue;
                   const int64_t p = j + cx;
                   const int64_t i0 = std::min<int64_t>(p / M, W - 1);
@@ -264,7 +272,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
                       long long q = std::llrint(std::ldexp(acc, fexp[(size_t)i]));
                       for (int l = 0; l < 7; ++l) {
                         const long long dg = (l < 6) ? ((((q + 128) % 256) + 256) % 256) - 128 : q;
-                        V2[((((r * 4 + (size_t)k) * NT2 + (size_t)nt) * 7 + (size_t)l) * 64 + (size_t)(kq * 16 + c16)) * 16 + (size_t)t] = (int8_t)dg;
+                        V2[((((r * (size_t)EPR + (size_t)k) * NT2 + (size_t)nt) * 7 + (size_t)l) * 64 + (size_t)(kq * 16 + c16)) * 16 + (size_t)t] = (int8_t)dg;
                         q = (q - dg) / 256;
                       }
                     }
@@ -294,6 +302,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
         m->lr_h_win_run1 = win_run1;
         m->lr.n_runs = (int32_t)n_runs;
         m->lr.NT2 = NT2;
+        m->lr.EPR = EPR;
       }
     }
   } else if ((rc = gnx_dev_upload(m, V, &m->lr.V)) != GNX_OK) return rc;

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "gnx_internal.h"
+#include "gnx_exp.h"
 
 namespace {
 
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8(BaseLRLaunch L)
             double* z = zb + lane * A;
             double sum = 0.0;
             for (int a = 0; a < A; ++a) {
-              const double p = 1.0 / (1.0 + exp(-(z[a] + tab_ic[(w - wt0) * A + a])));
+              const double p = 1.0 / (1.0 + gnx_exp_sc(-(z[a] + tab_ic[(w - wt0) * A + a])));
               z[a] = p;
               sum += p;
             }

@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "gnx_internal.h"
+#include "gnx_exp.h"
 
 namespace {
 
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8_dl(BaseLRLaunch
             const double* ic = tab_ic + (w - wt0) * A;
             for (int e = lane; e < ne; e += 64) {
               const int a = e % A;
-              zb[e] = 1.0 / (1.0 + exp(-(zb[e] + ic[a])));
+              zb[e] = 1.0 / (1.0 + gnx_exp_sc(-(zb[e] + ic[a])));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (int e = lane; e < ne; e += 64) {

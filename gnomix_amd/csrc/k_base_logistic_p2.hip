@@ -38,6 +38,7 @@
 #include <cstdlib>
 
 #include "gnx_internal.h"
+#include "gnx_exp.h"
 
 namespace {
 
@@ -74,15 +75,16 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ void lds_barrier() {
+__device__ __forceinline__ void lds_barrier(bool skip = false) {  // skip: development ablation (GNX_LR_FLAGS & 32, timing only)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (!skip) __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
 
 // MT 16-row tiles per compute wave, CW compute waves, EW epilogue waves (0: the compute waves finish their windows themselves),
-// XSN stages of X runs, NBUF plane slots of one half-run (2 entries, 14 KB) each.
-template <int MT, int CW, int EW, int XSN, int NBUF>
+// XSN stages of X runs, NBUF plane slots of one step (2 entries, 14 KB) each, EPR entries per run: 4 (256 SNPs = 64 packed bytes per
+// row visit, four lanes per row) or 8 (512 SNPs = 128 bytes = whole cache lines per row visit, eight lanes per row).
+template <int MT, int CW, int EW, int XSN, int NBUF, int EPR>
 __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int ENTRY_BYTES = LIMBS * 1024;       // digit planes of one entry (64 k positions) of ONE column tile
@@ -92,17 +94,20 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
   constexpr int D = NBUF - 1;
   constexpr int ZROWS = MT * 16;                  // rows a compute wave parks per window
   constexpr int XTILES = CW * MT;
+  constexpr int SPR = EPR / 2;                    // plane steps (block barriers) per run
+  constexpr int XLD = EPR / 4;                    // X loads (1 KB each) per 16-row tile and run
+  static_assert(EPR == 4 || EPR == 8, "entries per run");
   constexpr int RWS = EW ? CW * ZROWS / EW : ZROWS;  // rows one finishing wave handles per window
   constexpr int LPR = 64 / RWS;                      // lanes per row in the sigmoid phase
-  static_assert((D - 1) * NKB < 64 && (XSN - 1) * XTILES < 64 && XSN >= 1 && D >= 1, "vmcnt is a 6-bit counter");
+  static_assert((D - 1) * NKB < 64 && (XSN - 1) * XTILES * XLD < 64 && XSN >= 1 && D >= 1, "vmcnt is a 6-bit counter");
   static_assert(RWS <= 64 && 64 % RWS == 0 && (!EW || CW % EW == 0), "an epilogue wave takes whole compute waves, at most 64 rows");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, kq = lane >> 4;
   const int A = L.A, W = L.W, R = L.d.R, NT2 = L.d.NT2;
   const bool slot_tiles = NT2 > 1;                 // one column tile per slot, one pass per tile
   uint8_t* vbuf = lds;                                               // [NBUF][STEP_BYTES]
-  uint8_t* xl0 = vbuf + (size_t)NBUF * STEP_BYTES;                   // [XSN][CW][MT][64 lanes][16 B]
-  double* zq = reinterpret_cast<double*>(xl0 + (size_t)XSN * XTILES * 1024);  // [2][CW][ZROWS][A] parked logits
+  uint8_t* xl0 = vbuf + (size_t)NBUF * STEP_BYTES;                   // [XSN][CW][MT][XLD][64 lanes][16 B]
+  double* zq = reinterpret_cast<double*>(xl0 + (size_t)XSN * XTILES * XLD * 1024);  // [2][CW][ZROWS][A] parked logits
   double* tab_ic = zq + (size_t)2 * CW * ZROWS * A;  // [max_wins][A] intercepts
   double* tab_sc = tab_ic + (size_t)L.max_wins * A;   // [max_wins] 2^-f_w
   int* tab_rb = reinterpret_cast<int*>(tab_sc + L.max_wins);
@@ -126,7 +131,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
   const int r_begin = L.d.win_run0[wa];
   const int r_end = L.d.win_run1[wb - 1];
   const int n_runs = r_end - r_begin;
-  const int n_steps = 2 * n_runs;
+  const int n_steps = SPR * n_runs;
   const int64_t n0b = (int64_t)htile * (CW * MT * 16);  // first haplotype of the block
 
   for (int e = tid; e < n_runs; e += THREADS) {
@@ -155,12 +160,13 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
     }
   }
   __syncthreads();
-  const int abl = L.flags;  // development ablations (GNX_LR_FLAGS, timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes
+  const int abl = L.flags;  // development ablations (GNX_LR_FLAGS, timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes, 32 no barriers, 64 no combine
+  const bool nobar = (abl & 32) != 0;
 
   if (wave == CW + EW) {
     // ================================================== plane loader ==================================================
     // entry e of the block's run r_begin + e / 4: tile `pass` of [run][4 entries][NT2 tiles][7 limbs][64 lanes][16 B]
-    const int8_t* vsrc = L.d.V2 + ((size_t)r_begin * 4 * NT2 + pass) * ENTRY_BYTES + (size_t)lane * 16;
+    const int8_t* vsrc = L.d.V2 + ((size_t)r_begin * EPR * NT2 + pass) * ENTRY_BYTES + (size_t)lane * 16;
     auto issue_planes = [&](int step) {
       if (abl & 16) return;
       const int8_t* src = vsrc + (size_t)min(step, n_steps - 1) * 2 * NT2 * ENTRY_BYTES;
@@ -175,40 +181,50 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
     for (int p = 0; p < D; ++p) issue_planes(p);
     for (int s = 0; s < n_steps; ++s) {
       wait_vm<(D - 1) * NKB>();  // the planes of step s have landed (only those of s+1 .. s+D-1 are younger)
-      __builtin_amdgcn_s_barrier();
+      if (!nobar) __builtin_amdgcn_s_barrier();
       issue_planes(s + D);        // every compute wave is done with step s-1, whose slot this is
     }
     wait_vm<0>();                 // nothing of this wave may still be writing LDS when the block retires
-    if (EW) __builtin_amdgcn_s_barrier();  // the trailing barrier of the compute / epilogue waves
+    if (EW && !nobar) __builtin_amdgcn_s_barrier();  // the trailing barrier of the compute / epilogue waves
     return;
   }
   if (wave == CW + EW + 1) {
     // ================================================== X loader ==================================================
-    // tile t = (compute wave t / MT, its tile t % MT); lane (row i16, 16 packed bytes kq) as in the compute waves
-    const uint8_t* xrow[XTILES];
+    // tile t = (compute wave t / MT, its tile t % MT).  EPR = 4: load 0 of a tile = 16 rows x 64 bytes, lane (row i16, 16 packed bytes
+    // kq) exactly as the compute lane that reads them back.  EPR = 8: load q of a tile = rows 8q .. 8q+7 x 128 bytes — eight lanes
+    // cover one row's whole run — lane i fetching row 8q + (i >> 3), logical 16-byte piece (i & 7) ^ (i >> 3) (source-side swizzle:
+    // LDS-direct loads land lane-linear, and the compute lanes' ds_read_b128 of piece p of 16 rows at a 128-byte pitch would
+    // otherwise hit one bank group 8 ways)
+    const uint8_t* xrow[XTILES * XLD];
 #pragma unroll
-    for (int t = 0; t < XTILES; ++t) {
-      const int64_t n = n0b + t * 16 + i16;  // rows >= N-1 read the zero-padded copy of the last row (rows past N are never written)
-      xrow[t] = (n >= L.N - 1 ? reinterpret_cast<const uint8_t*>(L.last_row) : reinterpret_cast<const uint8_t*>(L.X) + n * L.ldx) + 16 * kq;
+    for (int t = 0; t < XTILES * XLD; ++t) {
+      const int tile = t / XLD, q = t % XLD;
+      const int row = EPR == 8 ? 8 * q + (lane >> 3) : i16;
+      const int piece = EPR == 8 ? ((lane & 7) ^ (lane >> 3)) : kq;
+      const int64_t n = n0b + tile * 16 + row;  // rows >= N-1 read the zero-padded copy of the last row (rows past N are never written)
+      xrow[t] = (n >= L.N - 1 ? reinterpret_cast<const uint8_t*>(L.last_row) : reinterpret_cast<const uint8_t*>(L.X) + n * L.ldx) + 16 * piece;
     }
     auto issue_x = [&](int run) {
       if (abl & 8) return;
       const int rb = tab_rb[min(run, n_runs - 1)];
-      uint8_t* dst = xl0 + (size_t)(run % XSN) * (XTILES * 1024);
+      uint8_t* dst = xl0 + (size_t)(run % XSN) * (XTILES * XLD * 1024);
 #pragma unroll
-      for (int t = 0; t < XTILES; ++t) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[t] + rb), (lptr_t)(dst + t * 1024), 16, 0, 0);
+      for (int t = 0; t < XTILES * XLD; ++t) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[t] + rb), (lptr_t)(dst + t * 1024), 16, 0, 0);
     };
 #pragma unroll
     for (int p = 0; p < XSN; ++p) issue_x(p);
     for (int r = 0; r < n_runs; ++r) {
-      wait_vm<(XSN - 1) * XTILES>();  // X(r) has landed
+      wait_vm<(XSN - 1) * XTILES * XLD>();  // X(r) has landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // step 2r
-      __builtin_amdgcn_s_barrier();   // step 2r+1: every compute wave has X(r) in registers
+      if (!nobar) __builtin_amdgcn_s_barrier();   // first step of the run
+      if (!nobar) __builtin_amdgcn_s_barrier();   // second step: every compute wave has X(r) in registers
       issue_x(r + XSN);
+#pragma unroll
+      for (int h = 2; h < SPR; ++h)
+        if (!nobar) __builtin_amdgcn_s_barrier();
     }
     wait_vm<0>();
-    if (EW) __builtin_amdgcn_s_barrier();
+    if (EW && !nobar) __builtin_amdgcn_s_barrier();
     return;
   }
 
@@ -227,7 +243,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
     const double* ic = tab_ic + (w - wt0) * A;
     for (int it = it0; it < it1; ++it) {
       const int a = fsub + it * lpr;
-      if (a < A) zr[a] = 1.0 / (1.0 + exp(-(zr[a] + ic[a])));
+      if (a < A) zr[a] = 1.0 / (1.0 + gnx_exp_sc(-(zr[a] + ic[a])));
     }
   };
   auto finish = [&](double* zr0, int w, int64_t nrow0, int rows) {
@@ -278,10 +294,11 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
       ++job_step;
     };
     for (int r = 0; r < n_runs; ++r) {
-      lds_barrier();  // step 2r
-      job_work();
-      lds_barrier();  // step 2r+1
-      job_work();
+#pragma unroll
+      for (int h = 0; h < SPR; ++h) {
+        lds_barrier(nobar);  // step SPR r + h
+        job_work();
+      }
       // what the compute waves park at the end of this run (visible after the next barrier)
       const int nfl = (abl & 4) ? 0 : tab_nfl[r];
       if (nfl == 1) {
@@ -290,13 +307,13 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
           job = true;
           job_w = w;
           job_step = 0;
-          job_nst = 2 * (tab_gap[r] > 0 ? tab_gap[r] : n_runs - 1 - r);  // 0 (last run): after the trailing barrier
+          job_nst = SPR * (tab_gap[r] > 0 ? tab_gap[r] : n_runs - 1 - r);  // 0 (last run): after the trailing barrier
           job_z = zq + (size_t)(parked & 1) * (CW * ZROWS * A) + (size_t)ew * RWS * A;
           ++parked;
         }
       }
     }
-    lds_barrier();  // trailing barrier: the last run's windows are parked
+    lds_barrier(nobar);  // trailing barrier: the last run's windows are parked
     if (job) {      // nothing follows: all of it at once
       phase1(job_z, job_w, 0, n_it, RWS);
       finish(job_z, job_w, nrow0, RWS);
@@ -312,11 +329,11 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) acc[mt][l] = v4i{0, 0, 0, 0};
 
-  auto mfma_entry = [&](const uint8_t* pb, const v4i (&xc)[MT], int k) {
+  auto mfma_entry = [&](const uint8_t* pb, const v4i (&xc)[MT][XLD], int k) {  // k: compile-time after unrolling
     if (abl & 2) return;
     v4i xa[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xc[mt][k]);
+    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xc[mt][k >> 2][k & 3]);
     const v4i* vb = reinterpret_cast<const v4i*>(pb) + lane;
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
@@ -363,30 +380,34 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
   };
 
   for (int r = 0; r < n_runs; ++r) {
-    lds_barrier();  // step 2r: its planes and X(r) are in LDS
-    v4i xc[MT];
-    {
-      const uint8_t* xs = xl0 + (size_t)(r % XSN) * (XTILES * 1024) + (size_t)wave * (MT * 1024) + lane * 16;
+    v4i xc[MT][XLD];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xc[mt] = *reinterpret_cast<const v4i*>(xs + mt * 1024);
-    }
-    {
-      const uint8_t* sb = vbuf + (size_t)((2 * r) % NBUF) * STEP_BYTES;
-      mfma_entry(sb, xc, 0);
-      mfma_entry(sb + ENTRY_BYTES, xc, 1);
-    }
-    lds_barrier();  // step 2r+1
-    {
-      const uint8_t* sb = vbuf + (size_t)((2 * r + 1) % NBUF) * STEP_BYTES;
-      mfma_entry(sb, xc, 2);
-      mfma_entry(sb + ENTRY_BYTES, xc, 3);
+    for (int h = 0; h < SPR; ++h) {
+      lds_barrier(nobar);  // step SPR r + h: its planes (and, at h = 0, X(r)) are in LDS
+      if (h == 0) {
+        const uint8_t* xs = xl0 + (size_t)(r % XSN) * (XTILES * XLD * 1024) + (size_t)wave * (MT * XLD * 1024);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (EPR == 8) {  // row i16 of the tile sits in load i16 >> 3 at row slot i16 & 7; pieces 2 kq, 2 kq + 1, un-swizzled
+            const int rr = i16 & 7;
+            const uint8_t* rowp = xs + mt * 2048 + (i16 >> 3) * 1024 + rr * 128;
+            xc[mt][0] = *reinterpret_cast<const v4i*>(rowp + (((2 * kq) ^ rr) << 4));
+            xc[mt][XLD - 1] = *reinterpret_cast<const v4i*>(rowp + (((2 * kq + 1) ^ rr) << 4));
+          } else {
+            xc[mt][0] = *reinterpret_cast<const v4i*>(xs + mt * 1024 + lane * 16);
+          }
+        }
+      }
+      const uint8_t* sb = vbuf + (size_t)((SPR * r + h) % NBUF) * STEP_BYTES;
+      mfma_entry(sb, xc, 2 * h);
+      mfma_entry(sb + ENTRY_BYTES, xc, 2 * h + 1);
     }
     flush(r);
   }
-  if (EW) lds_barrier();  // trailing barrier: the last run's parked windows become visible to the epilogue waves
+  if (EW) lds_barrier(nobar);  // trailing barrier: the last run's parked windows become visible to the epilogue waves
 }
 
-template <int MT, int CW, int EW, int XSN, int NBUF>
+template <int MT, int CW, int EW, int XSN, int NBUF, int EPR>
 hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   BaseLRLaunch P = L;
   P.flags = tune.lr_flags;
@@ -411,7 +432,7 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
     }
     P.max_chunks = max_runs + 8;
     P.max_wins = wch + 2 * L.d.R + 4;
-    lds = (size_t)NBUF * (2 * LIMBS * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)2 * CW * MT * 16 * L.A * sizeof(double) +
+    lds = (size_t)NBUF * (2 * LIMBS * 1024) + (size_t)XSN * CW * MT * (EPR / 4) * 1024 + (size_t)2 * CW * MT * 16 * L.A * sizeof(double) +
           (size_t)4 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
     if (lds <= (size_t)160 * 1024 || wch == 4) break;
   }
@@ -420,9 +441,9 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
   P.wch = wch;
   P.n_htiles = (int)gx;
   P.n_rg8 = n_ranges8 / 8;
-  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2<%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d passes=%d\n", MT, CW, EW, XSN, NBUF, lds, (long long)(gx * n_ranges8 * L.d.NT2), wch, L.d.NT2);
-  GNX_LDS_OPTIN(lds, k_base_logistic_p2<MT, CW, EW, XSN, NBUF>);
-  hipLaunchKernelGGL((k_base_logistic_p2<MT, CW, EW, XSN, NBUF>), dim3((unsigned)(gx * n_ranges8 * L.d.NT2)), dim3((CW + EW + 2) * 64), lds, s, P);
+  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2<%d,%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d passes=%d\n", MT, CW, EW, XSN, NBUF, EPR, lds, (long long)(gx * n_ranges8 * L.d.NT2), wch, L.d.NT2);
+  GNX_LDS_OPTIN(lds, k_base_logistic_p2<MT, CW, EW, XSN, NBUF, EPR>);
+  hipLaunchKernelGGL((k_base_logistic_p2<MT, CW, EW, XSN, NBUF, EPR>), dim3((unsigned)(gx * n_ranges8 * L.d.NT2)), dim3((CW + EW + 2) * 64), lds, s, P);
   return hipGetLastError();
 }
 
@@ -433,23 +454,33 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
 // instantiation fits (the caller widens X to int8 and runs the int8 kernels).
 hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
-  if (!L.d.V2 || L.d.NT2 < 1 || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
+  if (!L.d.V2 || L.d.NT2 < 1 || (L.d.EPR != 4 && L.d.EPR != 8) || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
   const bool small = L.N <= 64 * 4;
   const int tm = tune.p2_mt, tw = tune.p2_cw, te = tune.p2_ew, tx = tune.p2_xsn, tb = tune.p2_nbuf ? tune.p2_nbuf : 3;
-#define GNX_P2(MT_, CW_, EW_, XS_, NB_) \
-  if (tm == MT_ && tw == CW_ && te == EW_ && tx == XS_ && tb == NB_) return launch<MT_, CW_, EW_, XS_, NB_>(L, n_cu, tune, s);
-  if (tm) {  // GNX_P2_TUNE="mt,cw,ew,xsn,nbuf" (development)
-    GNX_P2(2, 8, 4, 3, 3) GNX_P2(2, 8, 4, 4, 3) GNX_P2(2, 8, 4, 3, 4) GNX_P2(2, 8, 4, 2, 3)
-    GNX_P2(2, 8, 0, 3, 4) GNX_P2(2, 8, 0, 4, 4) GNX_P2(1, 4, 0, 2, 3) GNX_P2(1, 8, 2, 4, 3) GNX_P2(1, 8, 4, 4, 3)
+#define GNX_P2(MT_, CW_, EW_, XS_, NB_)                                                                                          \
+  if (tm == MT_ && tw == CW_ && te == EW_ && tx == XS_ && tb == NB_)                                                             \
+    return L.d.EPR == 8 ? launch<MT_, CW_, EW_, (XS_ > 2 ? 2 : XS_), NB_, 8>(L, n_cu, tune, s) : launch<MT_, CW_, EW_, XS_, NB_, 4>(L, n_cu, tune, s);
+  if (tm) {  // GNX_P2_TUNE="mt,cw,ew,xsn,nbuf" (development; with 512-SNP runs at most two X stages: vmcnt is a 6-bit counter)
+    GNX_P2(2, 8, 4, 3, 3) GNX_P2(2, 8, 4, 3, 4) GNX_P2(2, 8, 4, 2, 3) GNX_P2(2, 8, 4, 2, 4) GNX_P2(2, 8, 4, 1, 4)
+    GNX_P2(2, 8, 0, 3, 4) GNX_P2(1, 4, 0, 2, 3) GNX_P2(1, 8, 2, 4, 3) GNX_P2(1, 8, 4, 4, 3)
+    GNX_P2(2, 4, 2, 2, 3) GNX_P2(2, 4, 2, 1, 3) GNX_P2(2, 4, 2, 1, 4) GNX_P2(4, 4, 4, 1, 3)
     return hipErrorInvalidValue;
   }
 #undef GNX_P2
-  if (small) return launch<1, 4, 0, 2, 3>(L, n_cu, tune, s);
+  if (L.d.EPR == 8) {  // runs of 512 SNPs: 128 packed bytes per row visit
+    if (small) return launch<1, 4, 0, 2, 3, 8>(L, n_cu, tune, s);
+    hipError_t e = launch<2, 8, 4, 2, 4, 8>(L, n_cu, tune, s);
+    if (e == hipErrorNotSupported) e = launch<2, 8, 4, 2, 3, 8>(L, n_cu, tune, s);
+    if (e == hipErrorNotSupported) e = launch<2, 8, 4, 1, 3, 8>(L, n_cu, tune, s);
+    if (e == hipErrorNotSupported) e = launch<1, 8, 4, 2, 3, 8>(L, n_cu, tune, s);
+    return e;
+  }
+  if (small) return launch<1, 4, 0, 2, 3, 4>(L, n_cu, tune, s);
   // 256 rows per block, 4 epilogue waves; the parked logits (2 x 256 rows x A doubles) share the LDS with the plane ring and the X
   // stages: the deepest configuration that fits (A <= 12: 4 plane slots + 3 X stages; more classes: shallower)
-  hipError_t e = launch<2, 8, 4, 3, 4>(L, n_cu, tune, s);
-  if (e == hipErrorNotSupported) e = launch<2, 8, 4, 3, 3>(L, n_cu, tune, s);
-  if (e == hipErrorNotSupported) e = launch<2, 8, 4, 2, 3>(L, n_cu, tune, s);
-  if (e == hipErrorNotSupported) e = launch<1, 8, 4, 4, 3>(L, n_cu, tune, s);
+  hipError_t e = launch<2, 8, 4, 3, 4, 4>(L, n_cu, tune, s);
+  if (e == hipErrorNotSupported) e = launch<2, 8, 4, 3, 3, 4>(L, n_cu, tune, s);
+  if (e == hipErrorNotSupported) e = launch<2, 8, 4, 2, 3, 4>(L, n_cu, tune, s);
+  if (e == hipErrorNotSupported) e = launch<1, 8, 4, 4, 3, 4>(L, n_cu, tune, s);
   return e;
 }

@@ -53,9 +53,11 @@ GEOMS = [
 ]
 
 
+@pytest.mark.parametrize("run", ["256", "512"])   # run length of the packed rows' walk: 64 or 128 bytes per row visit (GNX_LR_P2_RUN forces)
 @pytest.mark.parametrize("C,M,A,ctx,N", GEOMS)
-def test_p2_is_bit_identical_to_int8(ga, oracle, p2ctx, C, M, A, ctx, N):
+def test_p2_is_bit_identical_to_int8(ga, oracle, p2ctx, monkeypatch, C, M, A, ctx, N, run):
     from gnomix_amd import synth
+    monkeypatch.setenv("GNX_LR_P2_RUN", run)
     d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=ctx, seed=C + A, smooth=None)
     X = synth.synthetic_X(N, C, seed=N, miss=0.03)
     dev = ga.DeviceModel(d, ctx=p2ctx)
@@ -66,18 +68,20 @@ def test_p2_is_bit_identical_to_int8(ga, oracle, p2ctx, C, M, A, ctx, N):
     assert np.max(np.abs(_both(dev, X[: min(N, 64)])[1] - ref)) < 1e-12
 
 
-@pytest.mark.parametrize("tune", ["2,8,0,3,4", "2,8,4,2,3", "1,8,4,4,3", "1,8,2,4,3", "1,4,0,2,3"])
+@pytest.mark.parametrize("tune", ["2,8,0,3,4", "2,8,4,2,3", "2,8,4,1,4", "1,8,4,4,3", "1,8,2,4,3", "1,4,0,2,3", "2,4,2,2,3"])
 def test_p2_every_shape(ga, monkeypatch, tune):
     """the instantiations the dispatcher can fall back to (no epilogue waves, shallower rings, 16-row tiles), forced"""
     from gnomix_amd import synth, _lib
     monkeypatch.setenv("GNX_LR_P2", "2")
     monkeypatch.setenv("GNX_P2_TUNE", tune)
     ctx = _lib.Context(0)
-    for (C, M, A, cx, N) in ((20500, 1000, 7, 500, 700), (6100, 200, 12, 100, 300), (1801, 60, 7, 45, 50)):
-        d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=cx, seed=C, smooth=None)
-        X = synth.synthetic_X(N, C, seed=N, miss=0.03)
-        b_i8, b_p2 = _both(ga.DeviceModel(d, ctx=ctx), X)
-        assert np.array_equal(b_i8, b_p2), (tune, C, A)
+    for run in ("256", "512"):
+        monkeypatch.setenv("GNX_LR_P2_RUN", run)
+        for (C, M, A, cx, N) in ((20500, 1000, 7, 500, 700), (6100, 200, 12, 100, 300), (1801, 60, 7, 45, 50)):
+            d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=cx, seed=C, smooth=None)
+            X = synth.synthetic_X(N, C, seed=N, miss=0.03)
+            b_i8, b_p2 = _both(ga.DeviceModel(d, ctx=ctx), X)
+            assert np.array_equal(b_i8, b_p2), (tune, run, C, A)
 
 
 def test_p2_goldens_of_the_reference(ga, p2ctx):
