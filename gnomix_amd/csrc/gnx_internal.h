@@ -188,7 +188,31 @@ struct SmoothXGBDev {
   // s * A + a in the [class][gf_pitch] u16 tile) followed by 2^D float leaves; class-major tree order (class_tree0)
   const uint32_t* gf_packed = nullptr;
   int32_t gf_pitch = 0, gf_max_class = 0;
+  // bit-sliced copy for k_smooth_xgb_bs (ensembles of depth <= 4; NULL otherwise), trees in the same class-major order, every tree
+  // a complete depth-4 heap.  The kernel never walks: per chunk of bs_wc windows it sorts each class's base probabilities once
+  // (per-class ranks -> counting sort), keeps for every prefix length n of that order the bitmap "window is NOT among the n
+  // smallest" (rows of the table G), and a node (class a, threshold k, window offset s) is the row n = #{p < threshold} shifted by
+  // s: 32 windows per 32-bit operation.  Node j (heap 1..15) of a tree = words 2j, 2j+1 of its 32-word block:
+  //   w0 = (s & 31) | ((a * Wp) & 255) << 8 | (LDS byte address of the node's counter) << 16
+  //   w1 = LDS byte address of word s >> 5 of class a's row 0 (rows are GnxBsLayout::rb bytes apart)
+  const uint32_t* bs_nodes = nullptr;    // [n_trees][32]
+  const float* bs_leaves = nullptr;      // [n_trees][16]
+  const float* bs_thr = nullptr;         // per-class sorted distinct finite thresholds: class c = [bs_uoff[c], bs_uoff[c+1])
+  const uint32_t* bs_lut = nullptr;      // [A][1024] first | (last << 16) candidate per 1/1024-wide bucket, relative to the class
+  const int32_t* bs_uoff = nullptr;      // [A+1]
+  const int32_t* bs_binoff = nullptr;    // [A+1] first counter of class c (ranks 0..K_c, then the NaN / outside-the-chromosome bin)
+  const int32_t* bs_class_tree0 = nullptr;  // [A+1]
+  int32_t bs_steps = 0, bs_nbins = 0, bs_wc = 0, bs_nthr = 0;
 };
+
+// LDS map of k_smooth_xgb_bs (bytes from the block's first LDS byte, which the kernel checks to be address 0: the node words carry
+// absolute addresses).  wp = padded windows per chunk (<= 255: counters are bytes), nr = wp + 1 rows per class, rw words per row
+// (one beyond the last real one: a shifted read takes two), nseg segments of sl prefix lengths the rows are built in.
+struct GnxBsLayout {
+  int32_t wp, nr, rw, rb, nbins, hist_bytes, off_cnt, off_hist, off_P, off_bin, off_pi, off_seg, off_wtot, nseg, sl, total;
+  uint32_t inv_sl;  // ceil(2^32 / sl): n / sl = umulhi(n, inv_sl) for n < 256
+};
+GnxBsLayout gnx_bs_layout(int A, int S, int wc, int nbins);  // k_smooth_xgb_bs.hip
 
 // 32-bit words per tree of SmoothXGBDev::gf_packed (2^D node words in heap order, slot 0 unused, then 2^D float leaves: the leaf of
 // heap index j is word j) and the zero trees that follow the last one (k_gnofix walks past a lane's range without clamping)
@@ -233,6 +257,7 @@ struct SmoothXGBLaunch {
   double* proba64;   // optional widened copy
   int32_t* labels;   // optional
 };
+
 
 // ---- crf smoother (k_smooth_crf.hip) ------------------------------------------------------------------
 struct SmoothCRFLaunch {
@@ -470,6 +495,10 @@ hipError_t gnx_launch_fb_emit(const float* d_proba, int64_t N, int64_t W, int A,
                               const int64_t* d_line_off, char* d_body, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
+// bit-sliced tree smoother (k_smooth_xgb_bs.hip); bins = gnx_smooth_bs_scratch_bytes() of device scratch (the rank pre-pass's output)
+hipError_t gnx_launch_smooth_xgb_bs(const SmoothXGBLaunch& L, uint16_t* bins, int n_cu, const gnx_tune& tune, hipStream_t s);
+size_t gnx_smooth_bs_scratch_bytes(int64_t N, int W, int A);
+bool gnx_smooth_bs_fits(const SmoothXGBDev& d, int A, int S);
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);
 hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwp,

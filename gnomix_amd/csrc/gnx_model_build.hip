@@ -600,6 +600,94 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
   return GNX_OK;
 }
 
+// bit-sliced trees (layout in gnx_internal.h: SmoothXGBDev::bs_nodes); Uc = per-class sorted thresholds, Y = the kernel's LDS map
+static void tree_fill_bs(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, const std::vector<std::vector<float>>& Uc,
+                         const std::vector<int32_t>& binoff, const GnxBsLayout& Y, uint32_t* words, float* leaves) {
+  const bool leaf = d->left[o + nid] == -1;
+  if (depth == 4) {
+    leaves[j - 16u] = d->cond[o + nid];
+    return;
+  }
+  // early leaf: both subtrees replicate the leaf, any node will do (class 0, rank field 0: row 0 = "every window goes right")
+  uint32_t a = 0, kf = 0, sw = 0;
+  if (!leaf) {
+    const float thr = d->cond[o + nid];
+    const int f = d->feat[o + nid], A = d->A;
+    a = (uint32_t)(f % A);
+    sw = (uint32_t)(f / A);
+    const std::vector<float>& U = Uc[a];
+    if (thr != thr || thr == -std::numeric_limits<float>::infinity()) kf = 0;                       // p < thr never holds
+    else if (thr == std::numeric_limits<float>::infinity()) kf = (uint32_t)U.size() + 1u;          // holds unless p is NaN
+    else kf = (uint32_t)(std::lower_bound(U.begin(), U.end(), thr) - U.begin()) + 1u;              // p < U[k] <=> rank(p) < k+1
+  }
+  const uint32_t cnt_addr = (uint32_t)Y.off_cnt + (uint32_t)binoff[a] + kf;
+  words[2 * j] = (sw & 31u) | (((a * (uint32_t)Y.wp) & 255u) << 8) | (cnt_addr << 16);
+  words[2 * j + 1] = (uint32_t)Y.off_P + a * (uint32_t)(Y.nr * Y.rb) + (sw >> 5) * 4u;
+  tree_fill_bs(d, o, leaf ? nid : d->left[o + nid], 2 * j, depth + 1, Uc, binoff, Y, words, leaves);
+  tree_fill_bs(d, o, leaf ? nid : d->right[o + nid], 2 * j + 1, depth + 1, Uc, binoff, Y, words, leaves);
+}
+
+// k_smooth_xgb_bs: ensembles of depth <= 4 whose padded chunk fits byte counters and whose tables fit the LDS
+static int build_xgb_bs(gnx_model* m, const gnx_model_desc* d, const std::vector<int32_t>& order, int D) {
+  const char* impl = std::getenv("GNX_SMOOTH_IMPL");
+  if (impl && std::string(impl) == "f32") return GNX_OK;
+  const int A = d->A, S = d->S;
+  if (D > 4 || A > 16) return GNX_OK;
+  std::vector<std::vector<float>> Uc((size_t)A);
+  for (int t = 0; t < d->n_trees; ++t)
+    for (int32_t k = d->tree_off[t]; k < d->tree_off[t + 1]; ++k)
+      if (d->left[k] != -1 && std::isfinite(d->cond[k])) Uc[(size_t)(d->feat[k] % A)].push_back(d->cond[k]);
+  std::vector<int32_t> uoff((size_t)A + 1, 0), binoff((size_t)A + 1, 0);
+  std::vector<float> U;
+  for (int c = 0; c < A; ++c) {
+    std::vector<float>& u = Uc[(size_t)c];
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    if (u.empty()) u.push_back(0.5f);
+    if (u.size() > 60000) return GNX_OK;
+    U.insert(U.end(), u.begin(), u.end());
+    uoff[(size_t)c + 1] = (int32_t)U.size();
+    binoff[(size_t)c + 1] = binoff[(size_t)c] + (int32_t)u.size() + 2;  // ranks 0..K_c and the NaN bin
+  }
+  const int nbins = binoff[(size_t)A];
+  if (nbins > 65000) return GNX_OK;
+  int wc = 128;  // windows per chunk; counters are bytes: the padded chunk must stay below 256 windows
+  if (wc + S - 1 > 255 || gnx_bs_layout(A, S, wc, nbins).total > 160 * 1024) return GNX_OK;
+  const GnxBsLayout Y = gnx_bs_layout(A, S, wc, nbins);
+  std::vector<uint32_t> lut((size_t)A * 1024);
+  int steps = 0;
+  for (int c = 0; c < A; ++c) {
+    const std::vector<float>& u = Uc[(size_t)c];
+    const int K = (int)u.size();
+    for (int b = 0; b < 1024; ++b) {
+      const int lo = b == 0 ? 0 : (int)(std::lower_bound(u.begin(), u.end(), (float)b / 1024.0f) - u.begin());
+      const int hi = b == 1023 ? K : (int)(std::lower_bound(u.begin(), u.end(), (float)(b + 1) / 1024.0f) - u.begin());
+      lut[(size_t)c * 1024 + (size_t)b] = (uint32_t)lo | ((uint32_t)hi << 16);
+      int st = 0;
+      while ((1 << st) < hi - lo + 1) ++st;
+      steps = std::max(steps, st);
+    }
+  }
+  std::vector<uint32_t> nodes(order.size() * 32, 0u);
+  std::vector<float> leaves(order.size() * 16, 0.f);
+  for (size_t k = 0; k < order.size(); ++k)
+    tree_fill_bs(d, d->tree_off[order[k]], 0, 1, 0, Uc, binoff, Y, nodes.data() + k * 32, leaves.data() + k * 16);
+  std::vector<int32_t> ct0((size_t)A + 1, 0);
+  for (int t = 0; t < d->n_trees; ++t) ct0[(size_t)d->tree_class[t] + 1] += 1;
+  for (int c = 0; c < A; ++c) ct0[(size_t)c + 1] += ct0[(size_t)c];
+  int rc;
+  if ((rc = gnx_dev_upload(m, nodes, &m->xgb.bs_nodes, 128)) != GNX_OK) return rc;
+  if ((rc = gnx_dev_upload(m, leaves, &m->xgb.bs_leaves, 64)) != GNX_OK) return rc;
+  if ((rc = gnx_dev_upload(m, U, &m->xgb.bs_thr, 64)) != GNX_OK) return rc;
+  if ((rc = gnx_dev_upload(m, lut, &m->xgb.bs_lut)) != GNX_OK) return rc;
+  if ((rc = gnx_dev_upload(m, uoff, &m->xgb.bs_uoff)) != GNX_OK) return rc;
+  if ((rc = gnx_dev_upload(m, binoff, &m->xgb.bs_binoff)) != GNX_OK) return rc;
+  if ((rc = gnx_dev_upload(m, ct0, &m->xgb.bs_class_tree0)) != GNX_OK) return rc;
+  m->xgb.bs_steps = steps; m->xgb.bs_nbins = nbins; m->xgb.bs_wc = wc; m->xgb.bs_nthr = (int32_t)U.size();
+  if (impl && std::string(impl) == "bs") m->xgb.impl = 4;
+  return GNX_OK;
+}
+
 int gnx_build_xgb(gnx_model* m, const gnx_model_desc* d) {
   gnx_ctx* ctx = m->ctx;
   const int A = d->A, S = d->S, F = S * A;
@@ -658,7 +746,8 @@ int gnx_build_xgb(gnx_model* m, const gnx_model_desc* d) {
   m->xgb.base_score = d->base_score;
   m->info.n_trees = d->n_trees;
   m->info.tree_depth = D;
-  return build_xgb_rk(m, d, order, D);
+  if ((rc = build_xgb_rk(m, d, order, D)) != GNX_OK) return rc;
+  return build_xgb_bs(m, d, order, D);
 }
 
 // ------------------------------------------------------------------------------------------------

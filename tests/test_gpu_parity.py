@@ -748,11 +748,61 @@ def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S
         assert np.array_equal(pf, pr, equal_nan=True), rpl
         assert np.array_equal(lf, lr), rpl
     monkeypatch.delenv("GNX_RK_RPL")
+    # the bit-sliced kernel (k_smooth_xgb_bs: no walks; depth <= 4, other ensembles keep the rank kernel)
+    monkeypatch.setenv("GNX_SMOOTH_IMPL", "bs")
+    pr, lr = ga.DeviceModel(d).smooth_predict(B)
+    assert np.array_equal(pf, pr, equal_nan=True)
+    assert np.array_equal(lf, lr)
     finite = np.isfinite(B).all(axis=(1, 2))                                  # oracle as the third opinion
     T = _oracle_trees(oracle, d)
     p_ref, l_ref = oracle.smooth_xgb(T, B[finite], S)
     assert np.array_equal(lf[finite], l_ref)
     _close_f32(pf[finite], p_ref)
+
+
+@pytest.mark.parametrize("W,A,S,rounds,depth,drop", [
+    (370, 7, 75, 37, 4, 0),      # chr22 shape: three chunks of 128 windows, the last one ragged; an odd tree-group tail
+    (127, 7, 31, 9, 4, 5),       # one chunk, shorter than 128 windows; classes with different numbers of trees
+    (129, 2, 5, 40, 3, 1),       # two classes, a second chunk of one window, shallow trees padded to depth 4
+    (1431, 12, 75, 3, 4, 7),     # chr1 / 12 ancestries: the 16-wave block
+    (300, 16, 129, 2, 2, 0),     # the widest smoother a 128-window chunk takes (padded chunk = 256 windows -> falls back), 16 classes
+    (260, 8, 127, 5, 4, 0),      # padded chunk = 254 windows: the widest smoother the byte counters take
+    (200, 16, 31, 2, 4, 3),      # 16 classes
+])
+def test_smooth_bitsliced_kernel_equals_rank_kernel(ga, monkeypatch, W, A, S, rounds, depth, drop):
+    """k_smooth_xgb_bs (sorted prefixes + bit-sliced node evaluation, gnomix_amd/csrc/k_smooth_xgb_bs.hip) never walks a tree; its
+    float32 margins are the same sums in the same order, so probabilities and labels must be BIT-identical to the rank kernel's,
+    whatever the chunking, the number of classes and trees per class, on thresholds hit exactly, NaN and infinities."""
+    from gnomix_amd import synth
+    rng = np.random.RandomState(W * 3 + A)
+    d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=S, context=5, smooth_kind="xgb")
+    T = synth.synthetic_trees(rounds, A, S * A, depth=depth, seed=W + 1, thr_lo=0.0, thr_hi=1.0, p_early_leaf=0.15)
+    if drop:                                                                  # the last classes get one tree less
+        n = len(T["tree_class"]) - drop
+        nn = int(T["tree_off"][n])
+        T = dict(tree_off=T["tree_off"][:n + 1], tree_class=T["tree_class"][:n],
+                 **{k: T[k][:nn] for k in ("left", "right", "feat", "cond")})
+    for k, v in T.items():
+        setattr(d, k, v)
+    N = 13
+    B = rng.dirichlet(np.ones(A) * 0.4, size=(N, W)).astype(np.float32)
+    thr = d.cond[d.left != -1]
+    pick = rng.choice(thr, size=B.shape)
+    m = rng.random_sample(B.shape)
+    B = np.where(m < 0.3, pick, B)
+    B = np.where((m >= 0.3) & (m < 0.4), np.nextafter(pick, np.float32(-1)), B)
+    special = np.array([0.0, 1.0, -0.25, 1.75, np.inf, -np.inf, np.nan, -0.0], np.float32)
+    B = np.where(m > 0.97, rng.choice(special, size=B.shape), B).astype(np.float32)
+    B[:, : W // 3] = B[:, :1]                                                 # a tract: every window of it ties with every other
+    monkeypatch.setenv("GNX_SMOOTH_IMPL", "rk")
+    pr, lr = ga.DeviceModel(d).smooth_predict(B)
+    monkeypatch.setenv("GNX_SMOOTH_IMPL", "bs")
+    dev = ga.DeviceModel(d)
+    pb, lb = dev.smooth_predict(B)
+    assert np.array_equal(pr, pb, equal_nan=True)
+    assert np.array_equal(lr, lb)
+    p64 = dev.smooth_predict(B.astype(np.float64))[0]                         # float64 B is narrowed exactly as the rank kernel does
+    assert np.array_equal(pr, p64, equal_nan=True)
 
 
 # ---------------------------------------------------------------- random-forest base (RFBase) -----
