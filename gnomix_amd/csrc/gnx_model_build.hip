@@ -191,15 +191,16 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
       const int64_t cs2 = NT2 == 1 ? A : 16;
       const char* p2env = std::getenv("GNX_LR_P2");  // 0: never build the planes; 2: build them whatever the padding costs (tests)
       const int p2mode = p2env ? std::atoi(p2env) : 1;
-      // a run is RS = 512 SNPs (128 packed bytes per row visit: whole cache lines, 8 MFMA entries) where the pieces are long enough for
-      // that, else 256 (64 bytes, 4 entries); short pieces (small windows) would multiply mostly padding — such models keep the int8
-      // kernels.  GNX_LR_P2_RUN=256|512 forces a run length (tests, A/B runs).
+      // a run is RS = 256 SNPs (64 packed bytes per row visit, 4 MFMA entries).  Runs of 512 (128 bytes = whole cache lines per row
+      // visit, 8 entries; GNX_LR_P2_RUN=512) were built as the "next lever" and measured the same: 0.595 / 0.608 ms at config 2,
+      // 9.52 / 9.59 ms at config 5a (scripts/dev/p2_runlen.sh) — the pass is bound on the matrix / epilogue side by then, and the
+      // longer run costs 16 KB more LDS.  Short pieces (small windows) would multiply mostly padding: such models keep the int8 kernels.
       auto padded_with = [&](int64_t rs) {
         int64_t p = 0;
         for (size_t k = 0; k < n_pieces; ++k) p += ((bounds[k + 1] - (bounds[k] & ~(int64_t)15) + rs - 1) / rs) * rs;
         return p;
       };
-      int64_t RS = padded_with(512) * 4 <= C * 5 ? 512 : 256;
+      int64_t RS = 256;
       if (const char* e = std::getenv("GNX_LR_P2_RUN")) { const int v = std::atoi(e); if (v == 256 || v == 512) RS = v; }
       const int EPR = (int)(RS / 64);
       const bool want_p2 = NT2 > 0 && p2mode != 0 && (p2mode == 2 || padded_with(RS) * 4 <= C * 5);

@@ -17,9 +17,9 @@
 //      rows:     G[a][n] = bitmap of the windows that are NOT among the first n of pi_a, for n = 0..Wp (Wp + 1 rows of Wp bits: a
 //                prefix OR, built in segments).  Node (a, k, s) is row cnt[a][k] shifted by s: "goes right" for 32 windows per word.
 //   then every wave on its own, no block barrier: wave = one class, groups of 16 of its trees:
-//   B  planes:   lane = (tree, block of 32 windows): 15 x (counter byte, two row words, v_alignbit) and 11 v_bfi select, level by
-//                level, the bit of the node each window actually visits: four words = the four bits of 32 leaf indices, which a
-//                256-entry LDS table (byte -> its bits spread to every fourth position) interleaves into eight 4-bit indices per word.
+//   B  planes:   lane = (tree, 64 windows): 15 x (counter byte, three row words, two v_alignbit) and 11 v_bfi select, level by
+//                level, the bit of the node each window actually visits: four words = the four bits of 32 leaf indices, interleaved
+//                into eight 4-bit indices per word in registers (v_perm_b32 as a four-entry table: spread8).
 //   C  leaves:   lane = window (and window + 64): one word of eight leaf indices per tree (shared by eight lanes), v_bfe, one LDS
 //                gather of the leaf, summed in tree order.
 // (First version: planes as wave masks in SGPRs — v_cndmask + 3 v_addc_co per leaf index — through a per-block scratch line in L2
@@ -57,26 +57,21 @@ __device__ __forceinline__ uint32_t sub_b1(uint32_t raw, uint32_t w) {
   asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(raw), "v"(w));
   return d;
 }
-// byte K of g, times 4: the spread table sits at LDS address 0, so this IS the address of its entry
+// byte K of g with its eight bits spread to every fourth position, in registers: the byte's four 2-bit fields become the four
+// selector bytes of a v_perm_b32 over the pool {0x00, 0x01, 0x10, 0x11} (field f -> byte with bit 0 of f at bit 0, bit 1 at bit 4).
+// 5 VALU and no LDS gather (a 256-entry table in the LDS costs ~7 cycles of the LDS pipe per look-up: random bytes, 32 banks, and
+// the LDS pipe is what bounds phase B).
 template <int K>
-__device__ __forceinline__ uint32_t byte4(uint32_t g, uint32_t two) {
-  uint32_t d;
-  if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(two), "v"(g));
-  if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(two), "v"(g));
-  if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(two), "v"(g));
-  if constexpr (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(two), "v"(g));
-  return d;
-}
-__device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t b) {  // (a << sh) | b
-  uint32_t d;
-  asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"((uint32_t)sh), "v"(b));
-  return d;
+__device__ __forceinline__ uint32_t spread8(uint32_t g) {
+  const uint32_t b = (g >> (8 * K)) & 255u;            // v_bfe_u32
+  uint32_t t = (b << 6) | b;                            // v_lshl_or_b32
+  t = (t << 12) | t;                                    // v_lshl_or_b32: b | b << 6 | b << 12 | b << 18
+  return __builtin_amdgcn_perm(0u, 0x11100100u, t & 0x03030303u);  // selector bytes 0..3 pick bytes of the second operand
 }
 // byte K of the four go-right planes -> eight 4-bit leaf indices (plane 0 = most significant bit)
 template <int K>
-__device__ __forceinline__ uint32_t nib8(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3, uint32_t two) {
-  const uint32_t t0 = *lds_at<uint32_t>(byte4<K>(g0, two)), t1 = *lds_at<uint32_t>(byte4<K>(g1, two));
-  const uint32_t t2 = *lds_at<uint32_t>(byte4<K>(g2, two)), t3 = *lds_at<uint32_t>(byte4<K>(g3, two));
+__device__ __forceinline__ uint32_t nib8(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3) {
+  const uint32_t t0 = spread8<K>(g0), t1 = spread8<K>(g1), t2 = spread8<K>(g2), t3 = spread8<K>(g3);
   return (((t0 << 1 | t1) << 1 | t2) << 1) | t3;
 }
 // 15 go-right words of one block of 32 windows -> the four planes of the leaf index
@@ -194,7 +189,7 @@ struct BsArgs {
 template <int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_smooth_xgb_bs(BsArgs Q) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  constexpr int WC = 128, NH = 2, NWAVE = NT / 64, TG = 32;
+  constexpr int WC = 128, NH = 2, TG = 32;
   const GnxBsLayout Y = Q.Y;
   const int A = Q.A, W = Q.W, S = Q.S, pad = (S + 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,11 +202,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   uint16_t* const bin16 = reinterpret_cast<uint16_t*>(lds + Y.off_bin);
   uint8_t* const pi8 = lds + Y.off_pi;
   uint32_t* const wtot = reinterpret_cast<uint32_t*>(lds + Y.off_wtot);
-  // where the sort's tie counters were: the row build's segment totals, then per wave {leaf indices, leaves} + the spread table, then margins
+  // where the sort's tie counters were: the row build's segment totals, then per wave {leaf indices, leaves}, then margins
   uint32_t* const seg32 = reinterpret_cast<uint32_t*>(lds + Y.off_seg);
   uint32_t* const nibw = hist32 + wave * (WAVE_AREA / 4);          // [TG][4 blocks][4] words: eight 4-bit leaf indices each
   float* const lvw = reinterpret_cast<float*>(nibw + TG * 16);     // [16][16]: the leaves of half a group
-  uint32_t* const spread = reinterpret_cast<uint32_t*>(lds);       // [256] at LDS address 0: bit m of the byte at bit 4m
   float* const mg = reinterpret_cast<float*>(hist32);              // [WC][A]
   float* const ev_tmp = mg + WC * A;                               // [WC][A]
   const int flags = Q.flags;
@@ -220,13 +214,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const int per = A * Y.wp;
   const size_t NWA = (size_t)W * A;
 
-  if (tid < 256) {
-    uint32_t v = (uint32_t)tid;
-    v = (v | (v << 12)) & 0x000F000Fu;
-    v = (v | (v << 6)) & 0x03030303u;
-    v = (v | (v << 3)) & 0x11111111u;
-    spread[tid] = v;
-  }
   for (int64_t item = blockIdx.x; item < Q.items; item += gridDim.x) {
     const int64_t n = item / Q.nch;
     const int ch = (int)(item - n * Q.nch);
@@ -344,7 +331,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const uint32_t hf8 = (uint32_t)(lane & 1) * 8u;
       const uint32_t sh = (uint32_t)(lane & 7) * 4u;  // C: lane = window (and window + 64)
       const uint32_t* nb = nibw + (lane >> 3);        // + tree * 16 (+ 8 for window + 64)
-      const uint32_t rb = (uint32_t)Y.rb, two = 2u;
+      const uint32_t rb = (uint32_t)Y.rb;
       const uint32_t nib_addr = (uint32_t)(uintptr_t)nibw + (uint32_t)lane * 32u, lv_addr = (uint32_t)(uintptr_t)lvw + (uint32_t)lane * 16u;
 
       uint4 cur[8];
@@ -384,9 +371,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           }
           uint32_t g0, g1, g2, g3;
           mux15(Ga, g0, g1, g2, g3);
-          *lds_at<uint4>(nib_addr) = make_uint4(nib8<0>(g0, g1, g2, g3, two), nib8<1>(g0, g1, g2, g3, two), nib8<2>(g0, g1, g2, g3, two), nib8<3>(g0, g1, g2, g3, two));
+          *lds_at<uint4>(nib_addr) = make_uint4(nib8<0>(g0, g1, g2, g3), nib8<1>(g0, g1, g2, g3), nib8<2>(g0, g1, g2, g3), nib8<3>(g0, g1, g2, g3));
           mux15(Gb, g0, g1, g2, g3);
-          *lds_at<uint4>(nib_addr + 16u) = make_uint4(nib8<0>(g0, g1, g2, g3, two), nib8<1>(g0, g1, g2, g3, two), nib8<2>(g0, g1, g2, g3, two), nib8<3>(g0, g1, g2, g3, two));
+          *lds_at<uint4>(nib_addr + 16u) = make_uint4(nib8<0>(g0, g1, g2, g3), nib8<1>(g0, g1, g2, g3), nib8<2>(g0, g1, g2, g3), nib8<3>(g0, g1, g2, g3));
         }
         *lds_at<uint4>(lv_addr) = lcur[0];  // leaves of the group's first 16 trees
         const uint4 lsecond = lcur[1];
@@ -498,7 +485,7 @@ GnxBsLayout gnx_bs_layout(int A, int S, int wc, int nbins) {
   shared = std::max(shared, nwave * WAVE_AREA);
   shared = std::max(shared, 2 * wc * A * 4);
   y.hist_bytes = (shared + 15) & ~15;
-  y.off_cnt = 1024;                     // the spread table owns LDS addresses 0..1023
+  y.off_cnt = 0;
   y.off_hist = y.off_cnt + y.nbins;
   y.off_bin = y.off_hist + y.nbins;     // counter indices and order sit behind the tie counters; the segment totals go behind those
   y.off_pi = y.off_bin + bin_bytes;

@@ -66,6 +66,25 @@ class HipGnomix:
         from .metrics import confusion
         return confusion(y, y_pred)
 
+    def _score_splits(self, splits):
+        """The bookkeeping half of Gnomix.train (src/model.py:127-151), one split at a time.  The reference scores the base on a
+        split's own haplotypes and the smoother on labels predicted from base probabilities: for "train" those are two different
+        sets (base: train1; smoother: train2, whose probabilities `train` already holds), for "val" one.  Keys as the reference
+        stores them: <base|smooth>_<split>_acc[_bal] in `accuracies`, the split's name in `Confusion_Matrices`."""
+        acc, cms = {}, {}
+        for name, parts in splits.items():
+            if parts is None:
+                continue
+            (X, y), smoother_part = parts
+            B = self.base.predict_proba(X)
+            labels = self.smooth.predict(B)
+            B_s, y_s = smoother_part if smoother_part is not None else (B, y)
+            labels_s = labels if smoother_part is None else self.smooth.predict(B_s)
+            acc["base_%s_acc" % name], acc["base_%s_acc_bal" % name] = self.base.evaluate(X=None, y=y, B=B)
+            acc["smooth_%s_acc" % name], acc["smooth_%s_acc_bal" % name] = self.smooth.evaluate(B=None, y=y_s, y_pred=labels_s)
+            cms[name] = self.conf_matrix(y=y, y_pred=labels)
+        return acc, cms
+
     def train(self, data, retrain_base=True, evaluate=True, verbose=False, **smoother_kw):
         """Gnomix.train (src/model.py:104-167) on the device: base on train1, smoother on the base's probabilities of train2,
         the reference's accuracies / confusion matrices, base again on all the data.
@@ -80,21 +99,9 @@ class HipGnomix:
             self.smooth.train_calibrator(self.base.predict_proba(X_t1), y_t1)
             self.dev = self.smooth.dev
             self.base.dev = self.dev
-        if evaluate:   # src/model.py:127-151
-            Acc, CM = {}, {}
-            B_t1 = self.base.predict_proba(X_t1)
-            y_t1_pred = self.smooth.predict(B_t1)
-            y_t2_pred = self.smooth.predict(B_t2)
-            Acc["base_train_acc"], Acc["base_train_acc_bal"] = self.base.evaluate(X=None, y=y_t1, B=B_t1)
-            Acc["smooth_train_acc"], Acc["smooth_train_acc_bal"] = self.smooth.evaluate(B=None, y=y_t2, y_pred=y_t2_pred)
-            CM["train"] = self.conf_matrix(y=y_t1, y_pred=y_t1_pred)
-            if X_v is not None:
-                B_v = self.base.predict_proba(X_v)
-                y_v_pred = self.smooth.predict(B_v)
-                Acc["base_val_acc"], Acc["base_val_acc_bal"] = self.base.evaluate(X=None, y=y_v, B=B_v)
-                Acc["smooth_val_acc"], Acc["smooth_val_acc_bal"] = self.smooth.evaluate(B=None, y=y_v, y_pred=y_v_pred)
-                CM["val"] = self.conf_matrix(y=y_v, y_pred=y_v_pred)
-            self.accuracies, self.Confusion_Matrices = Acc, CM
+        if evaluate:
+            self.accuracies, self.Confusion_Matrices = self._score_splits(
+                {"train": ((X_t1, y_t1), (B_t2, y_t2)), "val": None if X_v is None else ((X_v, y_v), None)})
         if retrain_base:
             parts = [(X_t1, y_t1), (X_t2, y_t2)] + ([(X_v, y_v)] if X_v is not None else [])
             self.train_base(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
