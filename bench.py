@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--haps", type=int, default=10000, help="haplotypes per GPU per pass")
+    ap.add_argument("--smoother-bs", type=int, default=1, help="0: skip the k_smooth_xgb_bs leg (kernels.k_smooth_xgb_bs)")
     ap.add_argument("--resident-2bit", type=int, default=1, help="0: skip the 2-bit-resident leg (resident_2bit, kernels.k_base_logistic_p2)")
     ap.add_argument("--passes", type=int, default=20, help="passes over the resident batch per step: a step is `passes` x `haps` haplotypes, so "
                     "that the 20 steps the driver asks for time > 1 s of device work instead of 57 ms")
@@ -320,6 +321,40 @@ def main():
             del Pk, o2
         except Exception as e:
             res["resident_2bit"] = {"error": repr(e)}
+
+    # ---- the parked alternative of the dominant kernel on the same base probabilities: k_smooth_xgb_bs (no tree walks:
+    # gnomix_amd/csrc/k_smooth_xgb_bs.hip; GNX_SMOOTH_IMPL=bs), timed alone and compared bit for bit; never `value` ------------------
+    if rank == 0 and world == 1 and args.smoother_bs:
+        try:
+            Bd = model.base_predict_device(X, f64=False)
+            p_ref, l_ref = model.smooth_predict_device(Bd)
+            prev = os.environ.get("GNX_SMOOTH_IMPL")
+            os.environ["GNX_SMOOTH_IMPL"] = "bs"
+            try:
+                m_bs = gnomix_amd.DeviceModel(data, ctx=ctx)
+            finally:
+                if prev is None:
+                    os.environ.pop("GNX_SMOOTH_IMPL")
+                else:
+                    os.environ["GNX_SMOOTH_IMPL"] = prev
+            p_bs, l_bs = m_bs.smooth_predict_device(Bd)
+            torch.cuda.synchronize()
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            for _ in range(10):
+                m_bs.smooth_predict_device(Bd)
+            torch.cuda.synchronize()
+            ctx.profile_enable(False)
+            ms_bs, n_bs = ctx.profile_get(_lib.K_SMOOTH_XGB)
+            kernels["k_smooth_xgb_bs"] = {
+                "avg_ms": ms_bs / max(n_bs, 1), "launches": n_bs, "node_steps_per_s_equiv": node_steps * N / (ms_bs / max(n_bs, 1) * 1e-3),
+                "outputs_identical_to_k_smooth_xgb_rk": bool(torch.equal(p_bs, p_ref) and torch.equal(l_bs, l_ref)),
+                "note": "parked (slower than the rank walk, DESIGN.md 4.2b): per chunk of 128 windows a counting sort of every class's base "
+                        "probabilities, prefix bitmaps, 15 shifted row reads + 11 v_bfi per tree and 32 windows, ordered leaf sums; "
+                        "avg_ms includes its rank pre-pass (k_bs_ranks)"}
+            del m_bs, Bd, p_bs, l_bs, p_ref, l_ref
+        except Exception as e:
+            kernels["k_smooth_xgb_bs"] = {"error": repr(e)}
 
     # ---- PCIe-inclusive rate: host pointers in, labels + probabilities out (never `value`) ----------------------------
     if rank == 0 and world == 1 and args.e2e_steps > 0:

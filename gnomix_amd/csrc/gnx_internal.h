@@ -193,7 +193,7 @@ struct SmoothXGBDev {
   // (per-class ranks -> counting sort), keeps for every prefix length n of that order the bitmap "window is NOT among the n
   // smallest" (rows of the table G), and a node (class a, threshold k, window offset s) is the row n = #{p < threshold} shifted by
   // s: 32 windows per 32-bit operation.  Node j (heap 1..15) of a tree = words 2j, 2j+1 of its 32-word block:
-  //   w0 = (s & 31) | ((a * Wp) & 255) << 8 | (LDS byte address of the node's counter) << 16
+  //   w0 = (s & 31) | (LDS byte address of the node's counter) << 16   (byte 1: zero)
   //   w1 = LDS byte address of word s >> 5 of class a's row 0 (rows are GnxBsLayout::rb bytes apart)
   const uint32_t* bs_nodes = nullptr;    // [n_trees][32]
   const float* bs_leaves = nullptr;      // [n_trees][16]
@@ -202,7 +202,7 @@ struct SmoothXGBDev {
   const int32_t* bs_uoff = nullptr;      // [A+1]
   const int32_t* bs_binoff = nullptr;    // [A+1] first counter of class c (ranks 0..K_c, then the NaN / outside-the-chromosome bin)
   const int32_t* bs_class_tree0 = nullptr;  // [A+1]
-  int32_t bs_steps = 0, bs_nbins = 0, bs_wc = 0, bs_nthr = 0;
+  int32_t bs_steps = 0, bs_nbins = 0, bs_wc = 0, bs_nthr = 0, bs_maxbins = 0;
 };
 
 // LDS map of k_smooth_xgb_bs (bytes from the block's first LDS byte, which the kernel checks to be address 0: the node words carry

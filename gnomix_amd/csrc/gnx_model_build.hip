@@ -622,7 +622,7 @@ static void tree_fill_bs(const gnx_model_desc* d, int32_t o, int32_t nid, uint32
     else kf = (uint32_t)(std::lower_bound(U.begin(), U.end(), thr) - U.begin()) + 1u;              // p < U[k] <=> rank(p) < k+1
   }
   const uint32_t cnt_addr = (uint32_t)Y.off_cnt + (uint32_t)binoff[a] + kf;
-  words[2 * j] = (sw & 31u) | (((a * (uint32_t)Y.wp) & 255u) << 8) | (cnt_addr << 16);
+  words[2 * j] = (sw & 31u) | (cnt_addr << 16);
   words[2 * j + 1] = (uint32_t)Y.off_P + a * (uint32_t)(Y.nr * Y.rb) + (sw >> 5) * 4u;
   tree_fill_bs(d, o, leaf ? nid : d->left[o + nid], 2 * j, depth + 1, Uc, binoff, Y, words, leaves);
   tree_fill_bs(d, o, leaf ? nid : d->right[o + nid], 2 * j + 1, depth + 1, Uc, binoff, Y, words, leaves);
@@ -648,7 +648,8 @@ static int build_xgb_bs(gnx_model* m, const gnx_model_desc* d, const std::vector
     if (u.size() > 60000) return GNX_OK;
     U.insert(U.end(), u.begin(), u.end());
     uoff[(size_t)c + 1] = (int32_t)U.size();
-    binoff[(size_t)c + 1] = binoff[(size_t)c] + (int32_t)u.size() + 2;  // ranks 0..K_c and the NaN bin
+    // ranks 0..K_c and the NaN bin (the class's LAST counter), padded to 16 bytes: a wave scans its class's counters as words
+    binoff[(size_t)c + 1] = binoff[(size_t)c] + (((int32_t)u.size() + 2 + 15) & ~15);
   }
   const int nbins = binoff[(size_t)A];
   if (nbins > 65000) return GNX_OK;
@@ -685,6 +686,7 @@ static int build_xgb_bs(gnx_model* m, const gnx_model_desc* d, const std::vector
   if ((rc = gnx_dev_upload(m, binoff, &m->xgb.bs_binoff)) != GNX_OK) return rc;
   if ((rc = gnx_dev_upload(m, ct0, &m->xgb.bs_class_tree0)) != GNX_OK) return rc;
   m->xgb.bs_steps = steps; m->xgb.bs_nbins = nbins; m->xgb.bs_wc = wc; m->xgb.bs_nthr = (int32_t)U.size();
+  for (int c = 0; c < A; ++c) m->xgb.bs_maxbins = std::max(m->xgb.bs_maxbins, binoff[(size_t)c + 1] - binoff[(size_t)c]);
   if (impl && std::string(impl) == "bs") m->xgb.impl = 4;
   return GNX_OK;
 }

@@ -12,11 +12,12 @@
 //                #{thresholds of class a <= p} (the rank kernel's quantisation with per-class threshold lists; NaN -> the class's
 //                last counter), 16 bits, parked in HBM: the dependent table look-ups run at full occupancy instead of inside a block.
 //   k_smooth_xgb_bs, per chunk of WC = 128 windows of one haplotype (Wp = WC + S - 1 padded windows):
-//   A  sort:     byte histogram of the chunk's counter indices; an exclusive scan turns it into cnt[a][k] = #{w' : rank < k}, i.e.
+//   A  sort:     byte histogram of the class's counter indices; an exclusive scan turns it into cnt[a][k] = #{w' : rank < k}, i.e.
 //                for every node the number n of padded windows that go LEFT at it; a counting sort gives each class's order pi_a.
 //      rows:     G[a][n] = bitmap of the windows that are NOT among the first n of pi_a, for n = 0..Wp (Wp + 1 rows of Wp bits: a
 //                prefix OR, built in segments).  Node (a, k, s) is row cnt[a][k] shifted by s: "goes right" for 32 windows per word.
-//   then every wave on its own, no block barrier: wave = one class, groups of 16 of its trees:
+//                (all of A per class by ONE wave, no block barrier: a class's counters, order and rows are its own)
+//   then, after the one barrier that publishes every class's rows, every wave on its own again: wave = one class, groups of 32 of its trees:
 //   B  planes:   lane = (tree, 64 windows): 15 x (counter byte, three row words, two v_alignbit) and 11 v_bfi select, level by
 //                level, the bit of the node each window actually visits: four words = the four bits of 32 leaf indices, interleaved
 //                into eight 4-bit indices per word in registers (v_perm_b32 as a four-entry table: spread8).
@@ -46,15 +47,16 @@ template <typename T>
 __device__ T* lds_at(uint32_t) { return nullptr; }  // host pass: never called
 #endif
 
+// LDS traffic between the lanes of ONE wave: the wave's LDS operations complete in order, the compiler must not move them across
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint32_t bfi(uint32_t sel, uint32_t a, uint32_t b) {  // sel ? a : b, one instruction (hipcc splits the C form)
   uint32_t d;
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(sel), "v"(a), "v"(b));
-  return d;
-}
-// (raw - byte 1 of w) mod 256, zero-extended: the node's count of windows going left
-__device__ __forceinline__ uint32_t sub_b1(uint32_t raw, uint32_t w) {
-  uint32_t d;
-  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(raw), "v"(w));
   return d;
 }
 // byte K of g with its eight bits spread to every fourth position, in registers: the byte's four 2-bit fields become the four
@@ -201,7 +203,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   uint32_t* const P32 = reinterpret_cast<uint32_t*>(lds + Y.off_P);
   uint16_t* const bin16 = reinterpret_cast<uint16_t*>(lds + Y.off_bin);
   uint8_t* const pi8 = lds + Y.off_pi;
-  uint32_t* const wtot = reinterpret_cast<uint32_t*>(lds + Y.off_wtot);
   // where the sort's tie counters were: the row build's segment totals, then per wave {leaf indices, leaves}, then margins
   uint32_t* const seg32 = reinterpret_cast<uint32_t*>(lds + Y.off_seg);
   uint32_t* const nibw = hist32 + wave * (WAVE_AREA / 4);          // [TG][4 blocks][4] words: eight 4-bit leaf indices each
@@ -210,8 +211,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   float* const ev_tmp = mg + WC * A;                               // [WC][A]
   const int flags = Q.flags;
 
-  const int nwords = Y.nbins / 4;
-  const int per = A * Y.wp;
   const size_t NWA = (size_t)W * A;
 
   for (int64_t item = blockIdx.x; item < Q.items; item += gridDim.x) {
@@ -219,90 +218,83 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int ch = (int)(item - n * Q.nch);
     const int w0 = ch * WC;
 
-    // ---- A0: clear the histogram ----
-    for (int i = tid; i < nwords; i += NT) hist32[i] = 0u;
-    for (int i = tid; i < A * Y.rw * Y.nseg; i += NT) seg32[i] = 0u;
-    __syncthreads();
-
-    // ---- A1: counter indices of the chunk's padded windows (reflected at the chromosome's ends), byte histogram ----
-    for (int e = tid; e < ((flags & 4) ? 0 : per); e += NT) {
-      const int wq = (int)__umulhi((uint32_t)e, Q.invA), c = e - wq * A;
-      const int j = w0 + wq;
-      int bin;
-      if (j <= W + S - 2) bin = Q.bins[(size_t)n * NWA + (size_t)slide_src(j, W, pad) * A + c];
-      else bin = Q.binoff[c + 1] - 1;  // beyond the last padded window any real window reads: never less than a threshold
-      bin16[c * Y.wp + wq] = (uint16_t)bin;
-      atomicAdd(&hist32[bin >> 2], 1u << ((bin & 3) * 8));
-    }
-    __syncthreads();
-
-    // ---- A2: exclusive scan of the byte histogram (mod 256: a node subtracts its class's base) -> cnt; clear hist for A3 ----
-    {
-      const int q = (nwords + NT - 1) / NT;  // <= QMAX (launcher)
-      uint32_t x[QMAX];
-      uint32_t sum = 0;
-      const int wi0 = tid * q;
-#pragma unroll
-      for (int i = 0; i < QMAX; ++i) {
-        x[i] = 0u;
-        if (i < q) {
-          x[i] = (wi0 + i < nwords) ? hist32[wi0 + i] : 0u;
-          sum = __builtin_amdgcn_sad_u8(x[i], 0u, sum);
-        }
+    // ---- A: sort and rows, wave = class, no block barrier: everything below touches only class c's counters, order and rows ----
+    if (wave < A && !(flags & 4)) {
+      const int c = wave;
+      const int b0 = Q.binoff[c], b1 = Q.binoff[c + 1];          // multiples of 16
+      const int cw0 = b0 >> 2, cwn = (b1 - b0) >> 2;               // the class's counter words
+      uint32_t* const segc = seg32 + c * Y.rw * Y.nseg;
+      uint16_t* const binc = bin16 + c * Y.wp;
+      uint8_t* const pic = pi8 + c * 256;
+      // A0: clear the class's histogram and segment totals
+      for (int i = lane; i < cwn; i += 64) hist32[cw0 + i] = 0u;
+      for (int i = lane; i < Y.rw * Y.nseg; i += 64) segc[i] = 0u;
+      wave_sync();
+      // A1: counter indices of the chunk's padded windows (reflected at the chromosome's ends), byte histogram
+      for (int wq = lane; wq < Y.wp; wq += 64) {
+        const int j = w0 + wq;
+        int bin;
+        if (j <= W + S - 2) bin = Q.bins[(size_t)n * NWA + (size_t)slide_src(j, W, pad) * A + c];
+        else bin = b1 - 1;  // beyond the last padded window any real window reads: never less than a threshold
+        binc[wq] = (uint16_t)bin;
+        atomicAdd(&hist32[bin >> 2], 1u << ((bin & 3) * 8));
       }
-      uint32_t inc = sum;
+      wave_sync();
+      // A2: exclusive scan of the class's byte histogram -> cnt[k] = #{windows of rank < k}; clear hist for A3
+      {
+        const int q = (cwn + 63) >> 6;  // <= QMAX (launcher)
+        uint32_t x[QMAX];
+        uint32_t sum = 0;
+        const int wi0 = lane * q;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d);
-        if (lane >= d) inc += t;
-      }
-      if (lane == 63) wtot[wave] = inc;
-      __syncthreads();
-      uint32_t run = inc - sum;
-      for (int w = 0; w < wave; ++w) run += wtot[w];
-#pragma unroll
-      for (int i = 0; i < QMAX; ++i) {
-        if (i < q && wi0 + i < nwords) {
-          uint32_t out = (run & 255u) * 0x01010101u;
-          if (x[i]) {
-            const uint32_t b0 = x[i] & 255u, b1 = (x[i] >> 8) & 255u, b2 = (x[i] >> 16) & 255u, b3 = x[i] >> 24;
-            const uint32_t p1 = run + b0, p2 = p1 + b1, p3 = p2 + b2;
-            out = (run & 255u) | ((p1 & 255u) << 8) | ((p2 & 255u) << 16) | (p3 << 24);
-            run = p3 + b3;
-            hist32[wi0 + i] = 0u;
+        for (int i = 0; i < QMAX; ++i) {
+          x[i] = 0u;
+          if (i < q) {
+            x[i] = (wi0 + i < cwn) ? hist32[cw0 + wi0 + i] : 0u;
+            sum = __builtin_amdgcn_sad_u8(x[i], 0u, sum);
           }
-          cnt32[wi0 + i] = out;
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t t = __shfl_up(inc, d);
+          if (lane >= d) inc += t;
+        }
+        uint32_t run = inc - sum;
+#pragma unroll
+        for (int i = 0; i < QMAX; ++i) {
+          if (i < q && wi0 + i < cwn) {
+            uint32_t out = (run & 255u) * 0x01010101u;
+            if (x[i]) {
+              const uint32_t y0 = x[i] & 255u, y1 = (x[i] >> 8) & 255u, y2 = (x[i] >> 16) & 255u, y3 = x[i] >> 24;
+              const uint32_t p1 = run + y0, p2 = p1 + y1, p3 = p2 + y2;
+              out = (run & 255u) | ((p1 & 255u) << 8) | ((p2 & 255u) << 16) | (p3 << 24);
+              run = p3 + y3;
+              hist32[cw0 + wi0 + i] = 0u;
+            }
+            cnt32[cw0 + wi0 + i] = out;
+          }
         }
       }
-    }
-    __syncthreads();
-
-    // ---- A3: counting sort: position of every padded window in its class's order (ties in arrival order: only the prefix lengths
-    //          cnt[k] are ever used as row numbers, and those fall between tie groups) ----
-    for (int e = tid; e < ((flags & 4) ? 0 : per); e += NT) {
-      const int wq = (int)__umulhi((uint32_t)e, Q.invA), c = e - wq * A;
-      const int bin = bin16[c * Y.wp + wq];
-      const uint32_t old = atomicAdd(&hist32[bin >> 2], 1u << ((bin & 3) * 8));
-      const uint32_t tie = (old >> ((bin & 3) * 8)) & 255u;
-      const uint32_t pos = ((uint32_t)cnt8[bin] + tie - (uint32_t)(c * Y.wp)) & 255u;
-      pi8[c * 256 + pos] = (uint8_t)wq;
-      // the row build's segment totals: windows of word wq >> 5 that enter the order within segment pos / sl
-      atomicOr(&seg32[(c * Y.rw + (wq >> 5)) * Y.nseg + (int)__umulhi(pos, Y.inv_sl)], 1u << (wq & 31));
-    }
-    __syncthreads();
-
-    // ---- A4: rows G[c][n] = ~(windows among the first n of pi_c), column (c, word) x segment of n per lane ----
-    {
-      const int ncol = A * Y.rw;
-      const int sl = Y.sl;  // multiple of 4
-      const bool on = tid < ncol * Y.nseg && !(flags & 8);
-      const int sg = tid / ncol, col = tid - sg * ncol;
-      const int c = col / Y.rw, jw = col - c * Y.rw;
-      const int n0 = sg * sl, n1 = min(n0 + sl, Y.wp);
-      const uint32_t* pw = reinterpret_cast<const uint32_t*>(pi8 + c * 256);
-      if (on) {
+      wave_sync();
+      // A3: counting sort: position of every padded window in the class's order (ties in arrival order: only the prefix lengths
+      //     cnt[k] are ever used as row numbers, and those fall between tie groups); the row build's segment totals on the way
+      for (int wq = lane; wq < Y.wp; wq += 64) {
+        const int bin = binc[wq];
+        const uint32_t old = atomicAdd(&hist32[bin >> 2], 1u << ((bin & 3) * 8));
+        const uint32_t pos = (uint32_t)cnt8[bin] + ((old >> ((bin & 3) * 8)) & 255u);
+        pic[pos] = (uint8_t)wq;
+        atomicOr(&segc[(wq >> 5) * Y.nseg + (int)__umulhi(pos, Y.inv_sl)], 1u << (wq & 31));
+      }
+      wave_sync();
+      // A4: rows G[c][n] = ~(windows among the first n of the order), lane = (word jw of the row, segment sg of n)
+      if (lane < Y.rw * Y.nseg && !(flags & 8)) {
+        const int sl = Y.sl;  // multiple of 4
+        const int sg = lane / Y.rw, jw = lane - sg * Y.rw;
+        const int n0 = sg * sl, n1 = min(n0 + sl, Y.wp);
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(pic);
         uint32_t cur = 0;
-        for (int s2 = 0; s2 < sg; ++s2) cur |= seg32[col * Y.nseg + s2];
+        for (int s2 = 0; s2 < sg; ++s2) cur |= segc[jw * Y.nseg + s2];
         uint32_t* row = P32 + (size_t)c * Y.nr * Y.rw + jw;
         for (int nn = n0; nn < n1; nn += 4) {
           const uint32_t w4 = pw[nn >> 2];
@@ -318,7 +310,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (n1 == Y.wp && n0 < n1) row[(size_t)Y.wp * Y.rw] = ~cur;
       }
     }
-    __syncthreads();
+    __syncthreads();  // every class's counters and rows are in place
 
     // ---- trees: every wave on its own (wave = class), groups of TG trees: B (planes -> leaf indices) then C (leaves) ----
     float acc[NH];
@@ -356,7 +348,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           for (int j = 1; j < 16; ++j) raw[j] = *lds_at<uint8_t>(nw[2 * j] >> 16);
           __builtin_amdgcn_sched_barrier(0);  // all fifteen counter reads in flight before the first is used (hipcc sinks each to its use)
 #pragma unroll
-          for (int j = 1; j < 16; ++j) row[j] = __umul24(sub_b1(raw[j], nw[2 * j]), rb) + (nw[2 * j + 1] + hf8);
+          for (int j = 1; j < 16; ++j) row[j] = __umul24(raw[j], rb) + (nw[2 * j + 1] + hf8);
           uint32_t Ga[16], Gb[16];
           {
             uint32_t x0[16], x1[16], x2[16];
@@ -474,7 +466,7 @@ GnxBsLayout gnx_bs_layout(int A, int S, int wc, int nbins) {
   y.rw = wc / 32 + ((S - 1) >> 5) + 1;  // last word a shifted read of the last block touches, + 1 (covers every padded window)
   y.rb = y.rw * 4;
   y.nbins = (nbins + 15) & ~15;
-  y.nseg = std::max(1, std::min(16, threads / (A * y.rw)));
+  y.nseg = std::max(1, std::min(16, 64 / y.rw));  // a wave builds its class's rows: (word, segment) per lane
   y.sl = (((y.wp + y.nseg - 1) / y.nseg) + 3) & ~3;
   y.inv_sl = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)y.sl - 1) / (uint64_t)y.sl);
   // the sort's scratch (tie counters, counter indices, order: dead once the rows are built) shares its bytes with the row build's
@@ -500,7 +492,7 @@ bool gnx_smooth_bs_fits(const SmoothXGBDev& d, int A, int S) {
   if (!d.bs_nodes || d.bs_wc != 128) return false;
   const GnxBsLayout Y = gnx_bs_layout(A, S, d.bs_wc, d.bs_nbins);
   const int nt = bs_threads(A);
-  return Y.total <= 160 * 1024 && Y.wp <= 255 && (Y.nbins / 4 + nt - 1) / nt <= QMAX && A >= 2 && A <= nt / 64;
+  return Y.total <= 160 * 1024 && Y.wp <= 255 && Y.rw <= 64 && (d.bs_maxbins / 4 + 63) / 64 <= QMAX && A >= 2 && A <= nt / 64;
 }
 
 size_t gnx_smooth_bs_scratch_bytes(int64_t N, int W, int A) { return (size_t)N * W * A * 2 + 64; }

@@ -8,6 +8,7 @@
 #   cf / rf = chr22 with the boosted-tree / random-forest bases      c5a   = chr1 WGS, A = 12, logistic + CRF
 #   c5b     = Gnofix re-phasing loop (host staging included)         c3    = chr1 array, CovRSK/SVC base + xgb
 #   c5br    = the same Gnofix workload device-resident, int8 and 2-bit rows (the counters README / DESIGN quote for k_gnofix)
+#   smbs    = the tree smoother alone, k_smooth_xgb_rk against k_smooth_xgb_bs (scripts/dev/bs_check.py bench)
 #   c4      = whole genome, 22 chromosome models (JSON only: scripts/bench_configs.py c4)
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -20,6 +21,9 @@ for cfg in $WHICH; do
   if [ "$cfg" = "bench" ]; then
     CMD="python bench.py --steps 3 --warmup 1 --passes 1 --cpu-seconds 0 --e2e-steps 0 --vcf-reps 0 --trained 0"
     STATS="python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --e2e-steps 0 --vcf-reps 0 --trained 0"
+  elif [ "$cfg" = "smbs" ]; then   # the tree smoother alone: rank walk (pointer nodes) against the bit-sliced kernel (k_smooth_xgb_bs)
+    CMD="python scripts/dev/bs_check.py bench"
+    STATS="$CMD"
   elif [ "$cfg" = "c4" ]; then
     python scripts/bench_configs.py c4 > $OUT/c4.log 2>&1
     cp gpurun_out/bench_configs.json $OUT/c4.json
