@@ -42,6 +42,11 @@ if "check" in sys.argv or len(sys.argv) == 1:
 if "bench" in sys.argv or len(sys.argv) == 1:
     W, A, S, N = 370, 7, 75, int(os.environ.get("N", 10000))
     d = synth.synthetic_model(seed=0, n_rounds=100, **synth.CHR22)
+    if os.environ.get("GEOM") == "chr1a12":   # config 5's smoother: chr1, 12 ancestries
+        W, A, N = 1431, 12, int(os.environ.get("N", 4096))
+        d = gnomix_amd.GnxModelData(C=W * 10 + 3, M=10, A=A, S=S, context=5, smooth_kind="xgb")
+        for k, v in synth.synthetic_trees(100, A, S * A, depth=4, seed=0).items():
+            setattr(d, k, v)
     rng = np.random.RandomState(1)
     B = rng.dirichlet(np.ones(A) * 0.5, size=(N, W)).astype(np.float32)
     Bd = torch.from_numpy(B).cuda()
