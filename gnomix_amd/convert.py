@@ -142,6 +142,155 @@ def forest_from_parts(parts, missing=2):
                 fb_base_score=float(base_score), fb_missing=int(missing))
 
 
+def _int_threshold_as_less_than(thr):
+    """SNPs only take the values 0..3, the forest loader asks `x < cond` (xgboost): `x <= thr` of LightGBM / CatBoost is
+    `x < floor(thr) + 1` on integers, and floor(thr) + 1 is exact in float32 wherever it matters (clamped to [-1, 5])"""
+    return np.float32(min(max(np.floor(float(thr)) + 1.0, -1.0), 5.0))
+
+
+def trees_from_lgbm_text(model_str, n_class, missing=2):
+    """A LightGBM model string (Booster.model_to_string(), the `handle` a pickled LGBMClassifier's booster carries) ->
+    xgboost-schema arrays for the forest base (LGBMBase, src/Base/models.py:38-52: 20 rounds, max_depth 4).
+
+    LightGBM's text format, per tree: `num_leaves`, and for the num_leaves - 1 internal nodes `split_feature`, `threshold`,
+    `decision_type`, `left_child`, `right_child` (a child >= 0 is an internal node, a child < 0 is leaf ~child), then `leaf_value`
+    per leaf; a numerical node sends `x <= threshold` LEFT.  decision_type: bit 0 categorical, bit 1 default-left, bits 2-3 the
+    missing type (0 none, 1 zero, 2 NaN).  The reference feeds int8 SNPs with the missing code 2 as an ordinary number (its own
+    comment: "use np.nan for missing encoding" — it does not), so value 2 simply compares: default direction = (2 <= threshold).
+    Multiclass: tree t adds to class t % num_tree_per_iteration, probabilities = softmax of the sums (the constant xgboost's
+    base_score adds to every class cancels); binary: ONE tree per round, P(class 1) = sigmoid(sigmoid_param * sum).
+    The first round's leaves already contain the initial score (boost_from_average)."""
+    head, *blocks = model_str.split("\nTree=")
+    hp = dict(l.split("=", 1) for l in head.splitlines() if "=" in l)
+    per_iter = int(hp.get("num_tree_per_iteration", 1))
+    n_out = int(hp.get("num_class", 1))
+    if n_out > 1 and n_out != n_class:
+        raise ValueError(f"LightGBM model: num_class={n_out} but the Gnomix model has A={n_class}")
+    if n_out == 1 and n_class != 2:
+        raise ValueError("LightGBM model: single-output booster for a model with more than 2 ancestries")
+    obj = hp.get("objective", "")
+    scale = 1.0
+    if n_out == 1:
+        for tok in obj.split():
+            if tok.startswith("sigmoid:"):
+                scale = float(tok.split(":", 1)[1])
+    off, L, R, F, Cd, Dl, cls = [0], [], [], [], [], [], []
+    for t, blk in enumerate(blocks):
+        body = blk.split("end of trees")[0]
+        kv = dict(l.split("=", 1) for l in body.splitlines() if "=" in l)
+        nl = int(kv["num_leaves"])
+        if int(kv.get("num_cat", 0)) != 0:
+            raise NotImplementedError("LightGBM model: categorical splits (SNPs are numerical features)")
+        if int(kv.get("is_linear", 0)) != 0:
+            raise NotImplementedError("LightGBM model: linear trees")
+        lv = [float(x) for x in kv["leaf_value"].split()]
+        if nl == 1:
+            L.append(-1); R.append(-1); F.append(0); Cd.append(np.float32(lv[0] * scale)); Dl.append(0)
+        else:
+            sf = [int(x) for x in kv["split_feature"].split()]
+            th = [float(x) for x in kv["threshold"].split()]
+            dt = [int(x) for x in kv["decision_type"].split()]
+            lc = [int(x) for x in kv["left_child"].split()]
+            rc = [int(x) for x in kv["right_child"].split()]
+            if not (len(sf) == len(th) == len(dt) == len(lc) == len(rc) == nl - 1 and len(lv) == nl):
+                raise ValueError(f"LightGBM model: tree {t} has inconsistent array lengths")
+            # node ids of this tree: internal node i -> i, leaf j -> (nl - 1) + j; the root is internal node 0
+            nid = lambda c: c if c >= 0 else (nl - 1) + (~c)
+            for i in range(nl - 1):
+                if dt[i] & 1:
+                    raise NotImplementedError("LightGBM model: categorical split")
+                if (dt[i] >> 2) & 3 == 1:
+                    raise NotImplementedError("LightGBM model: zero_as_missing splits (value 0 would take the default direction)")
+                L.append(nid(lc[i])); R.append(nid(rc[i])); F.append(sf[i]); Cd.append(_int_threshold_as_less_than(th[i]))
+                Dl.append(int(float(missing) <= th[i]))
+            for j in range(nl):
+                L.append(-1); R.append(-1); F.append(0); Cd.append(np.float32(lv[j] * scale)); Dl.append(0)
+        off.append(len(L))
+        cls.append(t % per_iter if n_out > 1 else 0)
+    return dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
+                feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32),
+                base_score=0.5, default_left=np.array(Dl, np.uint8))
+
+
+def forest_from_lgbm_text(window_model_strs, n_class, missing=2):
+    """Per-window LightGBM model strings (LGBMBase: one LGBMClassifier per window) -> the fb_* arrays of GnxModelData"""
+    return forest_from_parts([trees_from_lgbm_text(s, n_class, missing) for s in window_model_strs], missing=missing)
+
+
+def lgbm_text_of(lgbm_obj):
+    """the model string of a fitted LGBMClassifier: from the live booster, or from the attribute bag a stubbed pickle carries
+    (lightgbm.Booster.__getstate__ replaces the native handle by model_to_string())"""
+    b = getattr(lgbm_obj, "_Booster", None) or getattr(lgbm_obj, "booster_", None)
+    if b is None:
+        raise ValueError("LGBMClassifier without a fitted booster")
+    if hasattr(b, "model_to_string"):
+        return b.model_to_string()
+    h = getattr(b, "handle", None) or getattr(b, "_handle", None)
+    if isinstance(h, bytes):
+        h = h.decode()
+    if not isinstance(h, str):
+        raise ValueError("pickled LightGBM booster without its model string")
+    return h
+
+
+def trees_from_catboost_json(model, n_class, missing=2):
+    """A CatBoost model exported with save_model(..., format="json") (dict or str) -> xgboost-schema arrays for the forest base
+    (CBBase, src/Base/models.py:68-81: 20 oblivious trees of depth 4).
+
+    An oblivious tree is a list of `splits` (float_feature_index, border) — the SAME split for every node of a level — and
+    2^depth leaves; the leaf index has bit i set iff x[feature_i] > border_i.  MultiClass: leaf_values holds n_class numbers per
+    leaf (leaf-major), raw_c = scale * sum over trees + bias_c, probabilities = softmax; Logloss (two classes): one number per leaf,
+    P(class 1) = sigmoid(raw).  Every oblivious tree becomes one complete binary tree per class (split depth-1 at the root: the
+    index's most significant bit first), `x > border` = right; the bias goes into the class's first tree."""
+    m = json.loads(model) if isinstance(model, str) else model
+    ot = m["oblivious_trees"]
+    sb = m.get("scale_and_bias", [1.0, [0.0]])
+    scale = float(sb[0])
+    bias = sb[1] if isinstance(sb[1], (list, tuple)) else [sb[1]]
+    dims = 1
+    if ot:
+        dims = max(1, len(ot[0]["leaf_values"]) >> len(ot[0].get("splits", [])))
+    if dims > 1 and dims != n_class:
+        raise ValueError(f"CatBoost model: {dims} output dimensions but the Gnomix model has A={n_class}")
+    if dims == 1 and n_class != 2:
+        raise ValueError("CatBoost model: single-output model for a model with more than 2 ancestries")
+    bias = [float(b) for b in bias] + [0.0] * max(0, dims - len(bias))
+    off, L, R, F, Cd, Dl, cls = [0], [], [], [], [], [], []
+    for t, tree in enumerate(ot):
+        splits = tree.get("splits", [])
+        d = len(splits)
+        for sp in splits:
+            if sp.get("split_type", "FloatFeature") != "FloatFeature":
+                raise NotImplementedError("CatBoost model: only float-feature splits (SNPs are numerical features)")
+        lv = tree["leaf_values"]
+        if len(lv) != (dims << d):
+            raise ValueError(f"CatBoost model: tree {t} has {len(lv)} leaf values for depth {d}")
+        for c in range(dims):
+            base = len(L)
+            n_int = (1 << d) - 1
+            # heap order inside the tree: internal node h (0-based) at level l tests split d-1-l; children 2h+1, 2h+2
+            for h in range(n_int):
+                lvl = (h + 1).bit_length() - 1
+                sp = splits[d - 1 - lvl]
+                L.append(2 * h + 1); R.append(2 * h + 2); F.append(int(sp["float_feature_index"]))
+                Cd.append(_int_threshold_as_less_than(sp["border"]))
+                Dl.append(int(float(missing) <= float(sp["border"])))
+            for leaf in range(1 << d):   # heap leaf order = index with the root's bit as the most significant one
+                v = scale * float(lv[leaf * dims + c]) + (bias[c] if t == 0 else 0.0)
+                L.append(-1); R.append(-1); F.append(0); Cd.append(np.float32(v)); Dl.append(0)
+            assert len(L) - base == n_int + (1 << d)
+            off.append(len(L))
+            cls.append(c)
+    return dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
+                feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32),
+                base_score=0.5, default_left=np.array(Dl, np.uint8))
+
+
+def forest_from_catboost_json(window_models, n_class, missing=2):
+    """Per-window CatBoost JSON exports (CBBase: one CatBoostClassifier per window) -> the fb_* arrays of GnxModelData"""
+    return forest_from_parts([trees_from_catboost_json(m, n_class, missing) for m in window_models], missing=missing)
+
+
 class _TreeView:
     """sklearn.tree._tree.Tree, real or as the attribute bag a stubbed pickle carries (Tree.__getstate__: `nodes` is a
     structured array with left_child / right_child / feature / threshold, `values` the (n_nodes, n_outputs, n_classes) array)"""
@@ -241,6 +390,27 @@ def from_reference_model(model) -> GnxModelData:
         d.base_kind = "forest"
         parts = [xgb_trees_of(m, A) for m in models]
         for k, v in forest_from_parts(parts, missing=int(getattr(model.base, "missing_encoding", 2))).items():
+            setattr(d, k, v)
+    elif first == "LGBMClassifier":  # LGBMBase (src/Base/models.py:38-52): the boosters' own model strings, no lightgbm needed
+        d.base_kind = "forest"
+        for k, v in forest_from_lgbm_text([lgbm_text_of(m) for m in models], A,
+                                          missing=int(getattr(model.base, "missing_encoding", 2))).items():
+            setattr(d, k, v)
+    elif first == "CatBoostClassifier":  # CBBase (src/Base/models.py:68-81): through CatBoost's JSON export (needs catboost:
+        import json as _json              # its pickle carries the binary model blob)
+        import os as _os
+        import tempfile
+        d.base_kind = "forest"
+        exports = []
+        for m in models:
+            if not hasattr(m, "save_model"):
+                raise NotImplementedError("CBBase from a stubbed pickle: export every window with save_model(format='json') and use "
+                                          "gnomix_amd.convert.forest_from_catboost_json")
+            with tempfile.TemporaryDirectory() as td:
+                fn = _os.path.join(td, "m.json")
+                m.save_model(fn, format="json")
+                exports.append(_json.load(open(fn)))
+        for k, v in forest_from_catboost_json(exports, A, missing=int(getattr(model.base, "missing_encoding", 2))).items():
             setattr(d, k, v)
     elif first == "RandomForestClassifier":  # RFBase (src/Base/models.py:54-66)
         d.base_kind = "rforest"

@@ -805,6 +805,36 @@ def test_smooth_bitsliced_kernel_equals_rank_kernel(ga, monkeypatch, W, A, S, ro
     assert np.array_equal(pr, p64, equal_nan=True)
 
 
+def test_forest_kernels_on_lgbm_and_catboost_models(ga, oracle, forest_ctx):
+    """LGBMBase / CBBase (src/Base/models.py:38-52, 68-81): LightGBM model strings and CatBoost JSON exports converted to the forest
+    base's arrays (gnomix_amd.convert) run through the forest kernels == the oracle on the same arrays (which tests/test_host_cpu.py
+    checks against each library's own prediction rule evaluated directly)"""
+    import json
+    from gnomix_amd import convert
+    from test_host_cpu import _lgbm_model_string
+    rng = np.random.RandomState(77)
+    C, M, A, ctx = 1237, 100, 7, 50
+    W = C // M
+    widths = [M + 2 * ctx + (C - M * W if w == W - 1 else 0) for w in range(W)]
+    lg = convert.forest_from_lgbm_text([_lgbm_model_string(rng, wd, A, rounds=20)[0] for wd in widths], A)
+    cb_models = []
+    for wd in widths:
+        trees = []
+        for t in range(20):
+            splits = [{"float_feature_index": int(rng.randint(wd)), "border": float(rng.choice([0.5, 1.5])), "split_type": "FloatFeature"}
+                      for _ in range(4)]
+            trees.append({"splits": splits, "leaf_values": [float(np.float32(v)) for v in rng.randn(A << 4) * 0.3]})
+        cb_models.append(json.dumps({"oblivious_trees": trees, "scale_and_bias": [1.0, [float(b) for b in rng.randn(A) * 0.1]]}))
+    cb = convert.forest_from_catboost_json(cb_models, A)
+    X = rng.randint(0, 3, size=(300, C)).astype(np.int8)
+    for fb in (lg, cb):
+        d = ga.GnxModelData(C=C, M=M, A=A, S=5, context=ctx, base_kind="forest", **fb)
+        b32, _ = ga.DeviceModel(d, ctx=forest_ctx).base_predict(X, want_f32=True, want_f64=False)
+        ref = oracle.base_forest(_forest_oracle_trees(oracle, d), d.fb_win_tree0, X, M, ctx, A, missing=2)
+        assert np.array_equal(np.argmax(b32, -1), np.argmax(ref, -1))
+        _close_f32(b32, ref)
+
+
 # ---------------------------------------------------------------- random-forest base (RFBase) -----
 def _rf_dict(d):
     return {k[3:]: getattr(d, k) for k in ("rf_win_tree0", "rf_tree_off", "rf_left", "rf_right", "rf_feat", "rf_thr", "rf_value")}

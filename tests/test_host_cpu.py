@@ -355,3 +355,141 @@ def test_no_default_dispatch_kernel_carries_scratch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "scratch_audit.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "0 of those on a default dispatch" in r.stdout
+
+
+# ---------------------------------------------------------------- LGBMBase / CBBase: third-party tree formats -> forest base ----
+def _lgbm_model_string(rng, n_feat, n_class, rounds, max_leaves=16):
+    """a LightGBM model string with random leaf-wise trees (the text layout of Booster.model_to_string()), and the same trees as
+    Python structures for the direct evaluator below"""
+    per_iter = 1 if n_class == 2 else n_class
+    head = ["tree", "version=v3", "num_class=%d" % (1 if n_class == 2 else n_class), "num_tree_per_iteration=%d" % per_iter,
+            "label_index=0", "max_feature_idx=%d" % (n_feat - 1),
+            "objective=" + ("binary sigmoid:1" if n_class == 2 else "multiclass num_class:%d" % n_class),
+            "feature_names=" + " ".join("Column_%d" % i for i in range(n_feat)), "feature_infos=" + " ".join("[0:2]" for _ in range(n_feat)), ""]
+    out, trees = ["\n".join(head)], []
+    for t in range(rounds * per_iter):
+        nl = int(rng.randint(1, max_leaves + 1))
+        # grow leaf-wise: split a random leaf until nl leaves; LightGBM numbers internal nodes in creation order and keeps the
+        # split leaf's index for the left child, the new leaf index for the right one
+        depth_of = {0: 0}
+        parent_slot = {}                       # leaf -> (internal node, "l" / "r")
+        sf, th, dt, lc, rc = [], [], [], [], []
+        for i in range(nl - 1):
+            cand = [l for l, d in depth_of.items() if d < 4]
+            if not cand:
+                nl = i + 1
+                break
+            leaf = cand[rng.randint(len(cand))]
+            new_leaf = len(depth_of)
+            sf.append(int(rng.randint(n_feat))); th.append(float(rng.choice([0.5, 1.5, 1.0000000180025095e-35, 2.5, 0.9999])))
+            dt.append(int(rng.choice([2, 0, 8, 10])))          # default-left / none, missing type none / NaN
+            lc.append(~leaf); rc.append(~new_leaf)
+            if leaf in parent_slot:
+                p, side = parent_slot[leaf]
+                (lc if side == "l" else rc)[p] = i
+            parent_slot[leaf] = (i, "l"); parent_slot[new_leaf] = (i, "r")
+            depth_of[new_leaf] = depth_of[leaf] = depth_of[leaf] + 1
+        lv = [float(np.float32(rng.randn() * 0.3)) for _ in range(nl)]
+        blk = ["Tree=%d" % t, "num_leaves=%d" % nl, "num_cat=0"]
+        if nl > 1:
+            blk += ["split_feature=" + " ".join(map(str, sf)), "split_gain=" + " ".join("1" for _ in sf),
+                    "threshold=" + " ".join(repr(x) for x in th), "decision_type=" + " ".join(map(str, dt)),
+                    "left_child=" + " ".join(map(str, lc)), "right_child=" + " ".join(map(str, rc))]
+        blk += ["leaf_value=" + " ".join(repr(x) for x in lv), "is_linear=0", "shrinkage=0.1", "", ""]
+        out.append("\n".join(blk))
+        trees.append((sf, th, lc, rc, lv))
+    out.append("end of trees\n\nfeature_importances:\n\nparameters:\n[boosting: gbdt]\nend of parameters\n\npandas_categorical:null\n")
+    return "\n".join(out), trees, per_iter
+
+
+def _lgbm_predict(trees, per_iter, n_class, x):
+    """LightGBM's own rule on the structures above: x <= threshold -> left child; a negative child c is leaf ~c"""
+    raw = np.zeros(per_iter)
+    for t, (sf, th, lc, rc, lv) in enumerate(trees):
+        if not sf:
+            raw[t % per_iter] += lv[0]
+            continue
+        node = 0
+        while node >= 0:
+            node = lc[node] if float(x[sf[node]]) <= th[node] else rc[node]
+        raw[t % per_iter] += lv[~node]
+    if n_class == 2:
+        p1 = 1.0 / (1.0 + np.exp(-raw[0]))
+        return np.array([1 - p1, p1])
+    e = np.exp(raw - raw.max())
+    return e / e.sum()
+
+
+@pytest.mark.parametrize("A", [2, 3, 7])
+def test_forest_from_lgbm_text(oracle, A):
+    """LGBMBase (src/Base/models.py:38-52): LightGBM model strings -> fb_* arrays; the oracle's forest on them == LightGBM's own
+    prediction rule evaluated directly on the strings' trees (x <= threshold left, leaf ~child, class = tree % num_tree_per_iteration).
+    Unpinned to lightgbm itself (absent from this image): the format is restated from its documented text layout."""
+    from gnomix_amd import convert
+    rng = np.random.RandomState(100 + A)
+    M, ctx, W = 6, 2, 4
+    C = M * W + 1
+    strs, structs = [], []
+    for w in range(W):
+        width = M + 2 * ctx + (1 if w == W - 1 else 0)
+        s, trees, per_iter = _lgbm_model_string(rng, width, A, rounds=5)
+        strs.append(s); structs.append((trees, per_iter))
+    f = convert.forest_from_lgbm_text(strs, A)
+    T = oracle.Trees(f["fb_tree_off"], f["fb_left"], f["fb_right"], f["fb_feat"], f["fb_cond"], f["fb_tree_class"], max(A, 2),
+                     default_left=f["fb_default_left"])
+    X = rng.randint(0, 3, size=(40, C)).astype(np.int8)
+    B = oracle.base_forest(T, f["fb_win_tree0"], X, M, ctx, A, missing=2)
+    Xp = np.concatenate([X[:, :ctx][:, ::-1], X, X[:, -ctx:][:, ::-1]], axis=1)     # Base.pad (base.py:41-44)
+    for w in range(W):
+        width = M + 2 * ctx + (1 if w == W - 1 else 0)
+        for n in range(len(X)):
+            ref = _lgbm_predict(structs[w][0], structs[w][1], A, Xp[n, w * M: w * M + width])
+            assert np.allclose(B[n, w], ref, atol=2e-6), (w, n)
+    with pytest.raises(ValueError, match="num_class|single-output"):
+        convert.trees_from_lgbm_text(strs[0], A + 1 if A > 2 else 3)
+
+
+@pytest.mark.parametrize("A", [2, 5])
+def test_forest_from_catboost_json(oracle, A):
+    """CBBase (src/Base/models.py:68-81): CatBoost JSON exports (oblivious trees) -> fb_* arrays; the oracle's forest on them ==
+    CatBoost's own rule evaluated directly (leaf index bit i = x[feature_i] > border_i, leaf-major class values, scale and bias).
+    Unpinned to catboost itself (absent from this image)."""
+    from gnomix_amd import convert
+    rng = np.random.RandomState(7 + A)
+    M, ctx, W = 5, 1, 3
+    C = M * W + 2
+    dims = 1 if A == 2 else A
+    models = []
+    for w in range(W):
+        width = M + 2 * ctx + (2 if w == W - 1 else 0)
+        trees = []
+        for t in range(6):
+            d = int(rng.randint(0, 5))
+            splits = [{"float_feature_index": int(rng.randint(width)), "border": float(rng.choice([0.5, 1.5, 0.25])),
+                       "split_type": "FloatFeature", "split_index": i} for i in range(d)]
+            trees.append({"splits": splits, "leaf_values": [float(np.float32(v)) for v in rng.randn(dims << d) * 0.4],
+                          "leaf_weights": [1] * (1 << d)})
+        models.append({"oblivious_trees": trees, "scale_and_bias": [0.75, [float(b) for b in rng.randn(dims) * 0.2]],
+                       "features_info": {"float_features": []}})
+    f = convert.forest_from_catboost_json([models[0], __import__("json").dumps(models[1]), models[2]], A)
+    T = oracle.Trees(f["fb_tree_off"], f["fb_left"], f["fb_right"], f["fb_feat"], f["fb_cond"], f["fb_tree_class"], max(A, 2),
+                     default_left=f["fb_default_left"])
+    X = rng.randint(0, 3, size=(30, C)).astype(np.int8)
+    B = oracle.base_forest(T, f["fb_win_tree0"], X, M, ctx, A, missing=2)
+    Xp = np.concatenate([X[:, :ctx][:, ::-1], X, X[:, -ctx:][:, ::-1]], axis=1)
+    for w in range(W):
+        width = M + 2 * ctx + (2 if w == W - 1 else 0)
+        m = models[w]
+        for n in range(len(X)):
+            x = Xp[n, w * M: w * M + width]
+            raw = np.array(m["scale_and_bias"][1], dtype=np.float64)
+            for tr in m["oblivious_trees"]:
+                idx = sum((1 << i) for i, sp in enumerate(tr["splits"]) if float(x[sp["float_feature_index"]]) > sp["border"])
+                raw = raw + m["scale_and_bias"][0] * np.array(tr["leaf_values"][idx * dims:(idx + 1) * dims])
+            if A == 2:
+                p1 = 1.0 / (1.0 + np.exp(-raw[0]))
+                ref = np.array([1 - p1, p1])
+            else:
+                e = np.exp(raw - raw.max())
+                ref = e / e.sum()
+            assert np.allclose(B[n, w], ref, atol=2e-6), (w, n)
