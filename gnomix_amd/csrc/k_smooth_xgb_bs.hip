@@ -99,7 +99,6 @@ struct BsRankArgs {
   const int32_t* binoff;
   int64_t total;
   int32_t A, b_is_f64, steps, nthr;
-  uint32_t invA;  // ceil(2^32 / A)
 };
 
 // persistent blocks: the bucket table (A x 1024 words) and the threshold lists sit in the LDS, so the dependent look-ups of the
