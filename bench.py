@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline core-seconds budget scale (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="host-pointer (PCIe-inclusive) passes at N=1 (0 = skip)")
+    ap.add_argument("--bgzf-level", type=int, default=6, help="deflate level of the BGZF leg's input (6 = bgzip's default; earlier rounds used 1)")
     ap.add_argument("--vcf-reps", type=int, default=5, help="file-to-file passes (VCF text in, .msp/.fb out) at N=1 (0 = skip)")
     ap.add_argument("--phase-leg", type=int, default=1, help="file-to-file with phase=True on admixed individuals through a device-trained model (N=1; needs --vcf-reps > 0)")
     ap.add_argument("--vcf-dir", default="", help="where the synthetic VCF and the outputs go (default: /dev/shm when it has room, else a temp dir)")
@@ -590,13 +591,17 @@ def _e2e_vcf(args, model, data, X, out_dev, devices=None):
         # ---- the same query as BGZF ----
         try:
             t0 = time.perf_counter()
-            gz_path = synth.bgzf_compress_file(vcf_path, os.path.join(work, "query.vcf.gz"), n_threads=io_threads)
+            gz_path = synth.bgzf_compress_file(vcf_path, os.path.join(work, "query.vcf.gz"), n_threads=io_threads, level=args.bgzf_level)
             t_gz = time.perf_counter() - t0
             gz_args = dict(base_args, query_file=gz_path)
             lg = _vcf_legs(lambda T: cli.run_inference(gz_args, gm, verbose=False, timings=T, devices=group), min(args.vcf_reps, 3))
             res["bgzf"] = {"haplotypes_per_s": N / lg["seconds"], "haplotypes_per_s_median": N / lg["median_s"], "seconds": lg["seconds"],
                            "stages_s": lg["stages_s"], "file_GB": os.path.getsize(gz_path) / 1e9, "text_GBps": vcf_bytes / lg["stages_s"]["read_vcf"] / 1e9,
-                           "compressed_in_s": round(t_gz, 2), "msp_identical": open(os.path.join(work, "query_results.msp")).read() == msp_text}
+                           "compressed_in_s": round(t_gz, 2), "deflate_level": args.bgzf_level,
+                           "msp_identical": open(os.path.join(work, "query_results.msp")).read() == msp_text,
+                           "note": "deflate level 6 = bgzip's (zlib's) default, what a .vcf.gz in the wild is written with; level 1 streams (the "
+                                   "figure of earlier rounds: shorter matches, more literals) inflate 1.7x slower per byte of text "
+                                   "(scripts/dev/inflate_bench.py)"}
             os.remove(gz_path)
         except Exception as e:
             res["bgzf"] = {"error": repr(e)}
