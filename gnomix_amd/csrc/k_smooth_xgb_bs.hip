@@ -456,6 +456,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 int bs_threads(int A) { return A <= 8 ? 512 : 1024; }  // one wave per class
 
+// LDS of k_bs_ranks: the bucket table, the threshold lists, the two per-class offset tables
+size_t bs_rank_lds_bytes(const SmoothXGBDev& d, int A) { return ((size_t)A * 1024 + (size_t)d.bs_nthr + 2 * ((size_t)A + 1)) * 4; }
+
 }  // namespace
 
 GnxBsLayout gnx_bs_layout(int A, int S, int wc, int nbins) {
@@ -491,6 +494,7 @@ bool gnx_smooth_bs_fits(const SmoothXGBDev& d, int A, int S) {
   if (!d.bs_nodes || d.bs_wc != 128) return false;
   const GnxBsLayout Y = gnx_bs_layout(A, S, d.bs_wc, d.bs_nbins);
   const int nt = bs_threads(A);
+  if (bs_rank_lds_bytes(d, A) > (size_t)160 * 1024) return false;  // the pre-pass keeps its tables in the LDS
   return Y.total <= 160 * 1024 && Y.wp <= 255 && Y.rw <= 64 && (d.bs_maxbins / 4 + 63) / 64 <= QMAX && A >= 2 && A <= nt / 64;
 }
 
@@ -503,8 +507,7 @@ hipError_t gnx_launch_smooth_xgb_bs(const SmoothXGBLaunch& L, uint16_t* bins, in
     BsRankArgs R{};
     R.B = L.B; R.bins = bins; R.thr = L.d.bs_thr; R.lut = L.d.bs_lut; R.uoff = L.d.bs_uoff; R.binoff = L.d.bs_binoff;
     R.total = L.N * L.W * L.A; R.A = L.A; R.b_is_f64 = L.b_is_f64; R.steps = L.d.bs_steps; R.nthr = L.d.bs_nthr;
-    const size_t rl = ((size_t)L.A * 1024 + (size_t)L.d.bs_nthr + 2 * ((size_t)L.A + 1)) * 4;
-    if (rl > (size_t)160 * 1024) return hipErrorInvalidValue;
+    const size_t rl = bs_rank_lds_bytes(L.d, L.A);
     GNX_LDS_OPTIN(rl, k_bs_ranks);
     const unsigned g = (unsigned)std::min<int64_t>((R.total + 4095) / 4096, (int64_t)n_cu * (rl <= (size_t)80 * 1024 ? 2 : 1));
     hipLaunchKernelGGL(k_bs_ranks, dim3(g), dim3(1024), rl, s, R);
