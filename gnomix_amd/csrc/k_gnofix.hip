@@ -160,16 +160,27 @@ __global__ __launch_bounds__(256) void k_gnofix_dif(const int8_t* __restrict__ X
   if (ln == 0) dif[(size_t)ind * NWD + q] = word;
 }
 
+// j / ws without the 32-bit division (two of them per word made k_gnofix_swap_p2 VALU-bound: ~25 instructions each):
+// q = umulhi(j, ceil(2^32 / ws)) is j / ws or one more, exact after one comparison for every j < 2^32
+struct WsDiv {
+  uint32_t ws, inv;
+  __device__ __forceinline__ uint32_t operator()(uint32_t j) const {
+    uint32_t q = __umulhi(j, inv);
+    return q - (q * ws > j ? 1u : 0u);
+  }
+};
+__host__ inline uint32_t gnx_ws_inv(uint32_t ws) { return (uint32_t)((((uint64_t)1 << 32) + ws - 1) / ws); }
+
 // ---- post-pass: correct_phase_error applied once from the final parity (phasing.py:188-198): windows of odd parity exchange their
 // SNP blocks.  grid = (16 KB pieces of the chromosome, individuals); a block whose windows are all even leaves without a load. ----
-__global__ __launch_bounds__(256) void k_gnofix_swap(int8_t* __restrict__ X, int64_t ldx, int64_t C, int W, const uint32_t* __restrict__ par) {
+__global__ __launch_bounds__(256) void k_gnofix_swap(int8_t* __restrict__ X, int64_t ldx, int64_t C, int W, const uint32_t* __restrict__ par, uint32_t ws, uint32_t ws_inv) {
   constexpr int PER = 4;  // 16-byte pieces per thread
   const int NWD = (W + 31) / 32;
   const int64_t ind = blockIdx.y;
   const uint32_t* P = par + (size_t)ind * NWD;
-  const uint32_t ws = (uint32_t)(C / W);
+  const WsDiv wdiv{ws, ws_inv};
   const int64_t b0 = (int64_t)blockIdx.x * (256 * PER * 16), b1 = min(b0 + 256 * PER * 16, C);
-  const int ua = (int)min((int64_t)W - 1, b0 / ws), ub = (int)min((int64_t)W - 1, (b1 - 1) / ws);
+  const int ua = (int)min((uint32_t)(W - 1), wdiv((uint32_t)b0)), ub = (int)min((uint32_t)(W - 1), wdiv((uint32_t)(b1 - 1)));  // C < 2^31 (launcher)
   bool any = false;
   for (int q = ua >> 5; q <= ub >> 5; ++q) {  // block-uniform
     uint32_t m = P[q];
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256) void k_gnofix_swap(int8_t* __restrict__ X, int
     const int64_t j = b0 + ((int64_t)k * 256 + threadIdx.x) * 16;
     mode[k] = 0;
     if (j >= C) continue;
-    const int u0 = (int)min((uint32_t)(W - 1), (uint32_t)j / ws), u1 = (int)min((uint32_t)(W - 1), (uint32_t)min(j + 15, C - 1) / ws);
+    const int u0 = (int)min((uint32_t)(W - 1), wdiv((uint32_t)j)), u1 = (int)min((uint32_t)(W - 1), wdiv((uint32_t)min(j + 15, C - 1)));
     if (j + 16 <= C && (u0 == u1 || (u1 == u0 + 1 && odd(u0) == odd(u1)))) mode[k] = odd(u0) ? 1 : 0;
     else mode[k] = 2;
     if (mode[k] == 1) { xa[k] = ld16(Xm + j); xb[k] = ld16(Xp + j); }
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gnofix_swap(int8_t* __restrict__ X, int
     if (mode[k] == 1) { st16(Xm + j, xb[k]); st16(Xp + j, xa[k]); }
     else if (mode[k] == 2) {
       for (int64_t i = j; i < min(j + 16, C); ++i)
-        if (odd((int)min((uint32_t)(W - 1), (uint32_t)i / ws))) { const int8_t t = Xm[i]; Xm[i] = Xp[i]; Xp[i] = t; }
+        if (odd((int)min((uint32_t)(W - 1), wdiv((uint32_t)i)))) { const int8_t t = Xm[i]; Xm[i] = Xp[i]; Xp[i] = t; }
     }
   }
 }
@@ -940,15 +951,15 @@ __global__ __launch_bounds__(256) void k_gnofix_dif_p2(const uint8_t* __restrict
   if (ln == 0) dif[(size_t)ind * NWD + q] = word;
 }
 
-__global__ __launch_bounds__(256) void k_gnofix_swap_p2(uint8_t* __restrict__ P, int64_t ldp, int64_t C, int W, const uint32_t* __restrict__ par) {
-  constexpr int PER = 4;  // 32-bit words (16 SNPs) per thread
+__global__ __launch_bounds__(256) void k_gnofix_swap_p2(uint8_t* __restrict__ P, int64_t ldp, int64_t C, int W, const uint32_t* __restrict__ par, uint32_t ws, uint32_t ws_inv) {
+  constexpr int PER = 4;  // 16-byte pieces (64 SNPs) per thread
   const int NWD = (W + 31) / 32;
   const int64_t ind = blockIdx.y;
   const uint32_t* Q = par + (size_t)ind * NWD;
-  const uint32_t ws = (uint32_t)(C / W);
-  const int64_t b0 = (int64_t)blockIdx.x * (256 * PER * 16), b1 = min(b0 + 256 * PER * 16, C);  // SNP range of the block
+  const WsDiv wdiv{ws, ws_inv};
+  const int64_t b0 = (int64_t)blockIdx.x * (256 * PER * 64), b1 = min(b0 + 256 * PER * 64, C);  // SNP range of the block
   if (b0 >= C) return;
-  const int ua = (int)min((int64_t)W - 1, b0 / ws), ub = (int)min((int64_t)W - 1, (b1 - 1) / ws);
+  const int ua = (int)min((uint32_t)(W - 1), wdiv((uint32_t)b0)), ub = (int)min((uint32_t)(W - 1), wdiv((uint32_t)(b1 - 1)));  // C < 2^31 (launcher)
   bool any = false;
   for (int q = ua >> 5; q <= ub >> 5; ++q) {  // block-uniform
     uint32_t m = Q[q];
@@ -960,21 +971,49 @@ __global__ __launch_bounds__(256) void k_gnofix_swap_p2(uint8_t* __restrict__ P,
   uint32_t* Pm = reinterpret_cast<uint32_t*>(P + 2 * ind * ldp);
   uint32_t* Pp = reinterpret_cast<uint32_t*>(P + (2 * ind + 1) * ldp);
   auto odd = [&](int u) { return ((Q[u >> 5] >> (u & 31)) & 1u) != 0; };
+  // mask of the 16 SNPs starting at j (a multiple of 16): fields of odd-parity windows
+  auto word_mask = [&](int64_t j) -> uint32_t {
+    if (j >= C) return 0u;
+    const int nf = (int)min((int64_t)16, C - j);
+    const int u0 = (int)min((uint32_t)(W - 1), wdiv((uint32_t)j)), u1 = (int)min((uint32_t)(W - 1), wdiv((uint32_t)(j + nf - 1)));
+    const uint32_t valid = nf == 16 ? 0xffffffffu : (1u << (2 * nf)) - 1u;
+    if (u0 == u1) return odd(u0) ? valid : 0u;
+    if (u1 == u0 + 1) {  // one window boundary inside the word (every boundary when windows are >= 16 SNPs): fields below it / from it on.
+      // (a per-field loop here ran in EVERY wave — 4 096 SNPs of a wave's pieces always hold a boundary — and made the kernel VALU-bound)
+      const uint32_t f0 = (uint32_t)u1 * ws - (uint32_t)j;  // 1..15 fields belong to window u0
+      const uint32_t lowm = (1u << (2 * f0)) - 1u;
+      return ((odd(u0) ? lowm : 0u) | (odd(u1) ? ~lowm : 0u)) & valid;
+    }
+    uint32_t mask = 0;
+    for (int f = 0; f < nf; ++f)
+      if (odd((int)min((uint32_t)(W - 1), wdiv((uint32_t)(j + f))))) mask |= 3u << (2 * f);
+    return mask;
+  };
+  // rows are 64-byte aligned with a pitch that is a multiple of 16 (gnx_gt2_to_p2 / gnx_pack_x callers): 16-byte pieces where the
+  // whole piece lies inside the row and inside ONE window (94 % of them at 1000-SNP windows), words otherwise
+  const bool wide = ((reinterpret_cast<uintptr_t>(P) | (uintptr_t)ldp) & 15) == 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const int64_t j = b0 + ((int64_t)k * 256 + threadIdx.x) * 16;
+    const int64_t j = b0 + ((int64_t)k * 256 + threadIdx.x) * 64;
     if (j >= C) continue;
-    const int nf = (int)min((int64_t)16, C - j);
-    const int u0 = (int)min((uint32_t)(W - 1), (uint32_t)j / ws), u1 = (int)min((uint32_t)(W - 1), (uint32_t)(j + nf - 1) / ws);
-    uint32_t mask = 0;
-    if (u0 == u1) mask = odd(u0) ? (nf == 16 ? 0xffffffffu : (1u << (2 * nf)) - 1u) : 0u;
-    else
-      for (int f = 0; f < nf; ++f)
-        if (odd((int)min((uint32_t)(W - 1), (uint32_t)(j + f) / ws))) mask |= 3u << (2 * f);
-    if (!mask) continue;
-    const uint32_t a = Pm[j >> 4], b = Pp[j >> 4];
-    Pm[j >> 4] = (a & ~mask) | (b & mask);
-    Pp[j >> 4] = (b & ~mask) | (a & mask);
+    const int u0 = (int)min((uint32_t)(W - 1), wdiv((uint32_t)j)), u1 = (int)min((uint32_t)(W - 1), wdiv((uint32_t)min(j + 63, C - 1)));
+    if (wide && j + 64 <= C && (u0 == u1 || (u1 == u0 + 1 && odd(u0) == odd(u1)))) {
+      if (!odd(u0)) continue;
+      uint4* pa = reinterpret_cast<uint4*>(Pm + (j >> 4));
+      uint4* pb = reinterpret_cast<uint4*>(Pp + (j >> 4));
+      const uint4 a = *pa, b = *pb;
+      *pa = b;
+      *pb = a;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t mask = word_mask(j + 16 * q);
+        if (!mask) continue;
+        const uint32_t a = Pm[(j >> 4) + q], b = Pp[(j >> 4) + q];
+        Pm[(j >> 4) + q] = (a & ~mask) | (b & mask);
+        Pp[(j >> 4) + q] = (b & ~mask) | (a & mask);
+      }
+    }
   }
 }
 
@@ -1048,14 +1087,15 @@ hipError_t gnx_launch_gnofix(const GnofixLaunch& L, int64_t n_ind, int threads, 
   else e = launch_t<512>(L, n_ind, s);
   if (e != hipSuccess) return e;
   const int NWD = (L.W + 31) / 32;
+  const uint32_t ws = (uint32_t)(L.C / L.W);
   for (int64_t i0 = 0; i0 < n_ind; i0 += 65535) {  // the individual is grid.y: at most 65535 per launch
     const unsigned ny = (unsigned)std::min<int64_t>(65535, n_ind - i0);
     const uint32_t* par = L.par + (size_t)i0 * NWD;
     if (L.x_packed)
-      hipLaunchKernelGGL(k_gnofix_swap_p2, dim3((unsigned)((L.C + 16383) / 16384), ny), dim3(256), 0, s, reinterpret_cast<uint8_t*>(L.X) + 2 * i0 * L.ldx,
-                         L.ldx, L.C, L.W, par);
+      hipLaunchKernelGGL(k_gnofix_swap_p2, dim3((unsigned)((L.C + 65535) / 65536), ny), dim3(256), 0, s, reinterpret_cast<uint8_t*>(L.X) + 2 * i0 * L.ldx,
+                         L.ldx, L.C, L.W, par, ws, gnx_ws_inv(ws));
     else
-      hipLaunchKernelGGL(k_gnofix_swap, dim3((unsigned)((L.C + 16383) / 16384), ny), dim3(256), 0, s, L.X + 2 * i0 * L.ldx, L.ldx, L.C, L.W, par);
+      hipLaunchKernelGGL(k_gnofix_swap, dim3((unsigned)((L.C + 16383) / 16384), ny), dim3(256), 0, s, L.X + 2 * i0 * L.ldx, L.ldx, L.C, L.W, par, ws, gnx_ws_inv(ws));
   }
   return hipGetLastError();
 }
