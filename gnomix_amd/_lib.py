@@ -14,7 +14,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
-GNX_ABI_VERSION = 13
+GNX_ABI_VERSION = 14
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
@@ -108,6 +108,7 @@ SYMBOLS = {
     "gnx_host_alloc": (_I, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "gnx_host_free": (_I, [_VP, _VP]),
     "gnx_host_flags": (_I, [_VP, C.POINTER(C.c_uint)]),
+    "gnx_debug_ws_devices": (_I, [_VP, _VP, C.c_int32]),
     "gnx_init": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "gnx_ctx_free": (None, [_VP]),
     "gnx_last_error": (C.c_char_p, [_VP]),
@@ -265,6 +266,15 @@ class Context:
         weakref.finalize(buf, lambda: lib.gnx_host_free(h, C.c_void_p(addr)))
         arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
         return arr
+
+    def workspace_devices(self):
+        """device ordinal of every live device workspace of this context (gnx_debug_ws_devices): all equal to self.device"""
+        import numpy as np
+        out = np.full(64, -1, np.int32)
+        n = self.lib.gnx_debug_ws_devices(self.h, out.ctypes.data, out.size)
+        if n < 0:
+            self.check(n)
+        return [int(v) for v in out[:min(n, out.size)]]
 
     def profile_enable(self, on=True):
         self.check(self.lib.gnx_profile_enable(self.h, int(bool(on))))

@@ -148,6 +148,20 @@ def _int_threshold_as_less_than(thr):
     return np.float32(min(max(np.floor(float(thr)) + 1.0, -1.0), 5.0))
 
 
+def _fold_two_outputs(d):
+    """A two-output softmax model (LightGBM multiclass with num_class=2, CatBoost MultiClass on two labels) for a two-ancestry
+    Gnomix model: the forest kernels treat A == 2 as ONE margin through a sigmoid (xgboost's binary:logistic, k_base_forest.hip),
+    and softmax([m0, m1])[1] = sigmoid(m1 - m0) — so class 0's trees enter with their leaves negated and every tree feeds the one
+    margin."""
+    leaf = d["left"] < 0
+    cls_of_node = np.repeat(d["tree_class"], np.diff(d["tree_off"]))
+    cond = d["cond"].copy()
+    cond[leaf & (cls_of_node == 0)] *= np.float32(-1.0)
+    d["cond"] = cond
+    d["tree_class"] = np.zeros_like(d["tree_class"])
+    return d
+
+
 def trees_from_lgbm_text(model_str, n_class, missing=2):
     """A LightGBM model string (Booster.model_to_string(), the `handle` a pickled LGBMClassifier's booster carries) ->
     xgboost-schema arrays for the forest base (LGBMBase, src/Base/models.py:38-52: 20 rounds, max_depth 4).
@@ -168,7 +182,11 @@ def trees_from_lgbm_text(model_str, n_class, missing=2):
         raise ValueError(f"LightGBM model: num_class={n_out} but the Gnomix model has A={n_class}")
     if n_out == 1 and n_class != 2:
         raise ValueError("LightGBM model: single-output booster for a model with more than 2 ancestries")
+    if "average_output" in head.split():
+        raise NotImplementedError("LightGBM model: average_output (boosting=rf) averages its trees instead of summing them")
     obj = hp.get("objective", "")
+    if n_out > 1 and obj.split()[:1] == ["multiclassova"]:
+        raise NotImplementedError("LightGBM model: multiclassova (per-class sigmoids, not a softmax)")
     scale = 1.0
     if n_out == 1:
         for tok in obj.split():
@@ -207,9 +225,10 @@ def trees_from_lgbm_text(model_str, n_class, missing=2):
                 L.append(-1); R.append(-1); F.append(0); Cd.append(np.float32(lv[j] * scale)); Dl.append(0)
         off.append(len(L))
         cls.append(t % per_iter if n_out > 1 else 0)
-    return dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
-                feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32),
-                base_score=0.5, default_left=np.array(Dl, np.uint8))
+    d = dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
+             feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32),
+             base_score=0.5, default_left=np.array(Dl, np.uint8))
+    return _fold_two_outputs(d) if n_out == 2 else d
 
 
 def forest_from_lgbm_text(window_model_strs, n_class, missing=2):
@@ -281,9 +300,10 @@ def trees_from_catboost_json(model, n_class, missing=2):
             assert len(L) - base == n_int + (1 << d)
             off.append(len(L))
             cls.append(c)
-    return dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
-                feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32),
-                base_score=0.5, default_left=np.array(Dl, np.uint8))
+    d = dict(tree_off=np.array(off, np.int32), left=np.array(L, np.int32), right=np.array(R, np.int32),
+             feat=np.array(F, np.int32), cond=np.array(Cd, np.float32), tree_class=np.array(cls, np.int32),
+             base_score=0.5, default_left=np.array(Dl, np.uint8))
+    return _fold_two_outputs(d) if dims == 2 else d
 
 
 def forest_from_catboost_json(window_models, n_class, missing=2):

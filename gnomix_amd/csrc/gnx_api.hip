@@ -32,6 +32,7 @@ static int ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes);
 int gnx_ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes) { return ws_reserve(ctx, b, bytes); }
 static int ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes) {
   if (bytes <= b.cap) return GNX_OK;
+  GNX_BIND_DEVICE(ctx);  // hipMalloc allocates on the calling thread's current device
   if (b.p) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipFree(b.p));
@@ -87,6 +88,13 @@ static void prof_drain(gnx_ctx* ctx) {
   ctx->prof_pending.clear();
 }
 
+// every grow-only device workspace of a context (gnx_ctx_free releases them, gnx_debug_ws_devices reports where they live)
+static std::vector<gnx_devbuf*> ctx_workspaces(gnx_ctx* ctx) {
+  return {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits,
+          &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal, &ctx->ws_marg, &ctx->ws_pk, &ctx->ws_xu, &ctx->ws_xu2, &ctx->ws_psi,
+          &ctx->ws_gt2, &ctx->ws_src, &ctx->ws_gt2o, &ctx->ws_rank, &ctx->ws_fb, &ctx->ws_fb_body};
+}
+
 // ------------------------------------------------------------------------------------------------
 // ABI
 // ------------------------------------------------------------------------------------------------
@@ -104,6 +112,7 @@ static void read_tune(gnx_tune& t) {
   t.lr_ws_pw = geti("GNX_LR_WS_PW", 2);
   t.lr_nbuf = geti("GNX_LR_NBUF", 0);
   t.lr_p2 = geti("GNX_LR_P2", 1);
+  t.p2_decline = geti("GNX_P2_DECLINE", 0);
   if (const char* e = std::getenv("GNX_P2_TUNE")) std::sscanf(e, "%d,%d,%d,%d,%d", &t.p2_mt, &t.p2_cw, &t.p2_ew, &t.p2_xsn, &t.p2_nbuf);
   t.sm_nw = geti("GNX_SM_NW", 0);
   t.sm_pair = geti("GNX_SM_PAIR", 1);
@@ -146,7 +155,8 @@ int gnx_init(int device, gnx_ctx** out) {
   if (!ctx) return GNX_ENOMEM;
   ctx->device = device;
   want_hw_queues();
-  hipError_t e = hipSetDevice(device);
+  gnx_device_scope bind(ctx);  // the caller's current device is put back on return
+  hipError_t e = bind.err;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     // the context is returned so the caller can read the message, but it is unusable
@@ -166,6 +176,7 @@ int gnx_init(int device, gnx_ctx** out) {
 
 void gnx_ctx_free(gnx_ctx* ctx) {
   if (!ctx) return;
+  gnx_device_scope bind(ctx);
   if (ctx->usable) (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -176,9 +187,7 @@ void gnx_ctx_free(gnx_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
   if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
-  for (gnx_devbuf* b : {&ctx->ws_pk, &ctx->ws_xu, &ctx->ws_psi, &ctx->ws_gt2, &ctx->ws_src, &ctx->ws_gt2o, &ctx->ws_rank, &ctx->ws_fb, &ctx->ws_fb_body})
-    if (b->p) (void)hipFree(b->p);
-  for (gnx_devbuf* b : {&ctx->ws_x, &ctx->ws_b32, &ctx->ws_b64, &ctx->ws_p32, &ctx->ws_p64, &ctx->ws_lab, &ctx->ws_misc, &ctx->ws_scale, &ctx->ws_bits, &ctx->ws_lastrow, &ctx->ws_rpair, &ctx->ws_y0, &ctx->ws_cal, &ctx->ws_marg})
+  for (gnx_devbuf* b : ctx_workspaces(ctx))
     if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -189,6 +198,7 @@ const char* gnx_last_error(const gnx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int gnx_set_stream(gnx_ctx* ctx, void* hip_stream) {
   if (!ctx) return GNX_EINVAL;
   if (!ctx->own_stream && ctx->stream == (hipStream_t)hip_stream) return GNX_OK;
+  GNX_BIND_DEVICE(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->own_stream) {
     (void)hipStreamDestroy(ctx->stream);
@@ -201,6 +211,7 @@ int gnx_set_stream(gnx_ctx* ctx, void* hip_stream) {
 int gnx_reset_stream(gnx_ctx* ctx) {
   if (!ctx) return GNX_EINVAL;
   if (ctx->own_stream) return GNX_OK;
+  GNX_BIND_DEVICE(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   ctx->own_stream = true;
@@ -287,7 +298,7 @@ int gnx_host_alloc(gnx_ctx* ctx, size_t bytes, void** out) {
   if (!ctx || !out) return GNX_EINVAL;
   *out = nullptr;
   if (!ctx->usable) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   *out = gnx_pin_alloc(bytes);
   if (!*out) return fail(ctx, GNX_ENOMEM, "hipHostMalloc(" + std::to_string(bytes) + ") failed");
   return GNX_OK;
@@ -304,8 +315,22 @@ int gnx_host_free(gnx_ctx* ctx, void* p) {
   return GNX_OK;
 }
 
+int gnx_debug_ws_devices(gnx_ctx* ctx, int32_t* out, int32_t n) {
+  if (!ctx || n < 0 || (n > 0 && !out)) return GNX_EINVAL;
+  int32_t live = 0;
+  for (gnx_devbuf* b : ctx_workspaces(ctx)) {
+    if (!b->p) continue;
+    hipPointerAttribute_t at;
+    HIPCHK(ctx, hipPointerGetAttributes(&at, b->p));
+    if (live < n) out[live] = (int32_t)at.device;
+    ++live;
+  }
+  return live;
+}
+
 int gnx_synchronize(gnx_ctx* ctx) {
   if (!ctx) return GNX_EINVAL;
+  GNX_BIND_DEVICE(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return GNX_OK;
 }
@@ -321,7 +346,7 @@ int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* d, gnx_model** out) {
   if (d->C % d->M == 0)  // src/Base/base.py:158 + gnomix.py:124-125
     return fail(ctx, GNX_EINVAL, "C % M == 0: the reference's window slicing (base.py:158) requires a remainder");
   if (d->C > (int64_t)1 << 30) return fail(ctx, GNX_EINVAL, "C too large");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   gnx_model* m = new (std::nothrow) gnx_model();
   if (!m) return fail(ctx, GNX_ENOMEM, "host allocation failed");
   m->ctx = ctx;
@@ -391,6 +416,9 @@ int gnx_model_set_calibrate(gnx_model* m, int on) {
 
 void gnx_model_free(gnx_model* m) {
   if (!m) return;
+  gnx_ctx unbound;  // (a model without a context frees on the caller's device)
+  if (!m->ctx) (void)hipGetDevice(&unbound.device);
+  gnx_device_scope bind(m->ctx ? m->ctx : &unbound);
   if (m->ctx && m->ctx->usable) (void)hipStreamSynchronize(m->ctx->stream);
   for (void* p : m->dev_allocs) (void)hipFree(p);
   delete m;
@@ -408,6 +436,7 @@ int gnx_base_predict_dev(gnx_model* m, const int8_t* dX, int64_t N, int64_t ldx,
   gnx_ctx* ctx = m->ctx;
   if (N < 0 || ldx < m->info.C || (N > 0 && !dX)) return fail(ctx, GNX_EINVAL, "base_predict: bad X / N / ldx");
   if (N == 0 || (!d_b32 && !d_b64)) return GNX_OK;
+  GNX_BIND_DEVICE(ctx);
   if (m->info.base_kind == GNX_BASE_COVRSK_SVC) {
     const int64_t Cp = m->info.C + 2 * m->info.ctx, nwp = (Cp + 31) / 32 + 2;
     int rc = ws_reserve(ctx, ctx->ws_bits, (size_t)N * 2 * nwp * 4);
@@ -504,6 +533,7 @@ int gnx_smooth_predict_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N
                            int32_t* d_lab) {
   if (!m) return GNX_EINVAL;
   gnx_ctx* ctx = m->ctx;
+  GNX_BIND_DEVICE(ctx);
   if (!(m->calibrate_on && m->calib_off)) return smooth_raw_dev(m, dB, b_is_f64, N, d_p32, d_p64, d_lab);
   if (N < 0 || (N > 0 && !dB)) return fail(ctx, GNX_EINVAL, "smooth_predict: bad B / N");
   if (N == 0) return GNX_OK;
@@ -612,6 +642,7 @@ int gnx_base_predict_packed_dev(gnx_model* m, const uint8_t* dP, int64_t N, int6
   const int64_t C = m->info.C, rowb = (C + 3) / 4;
   if (N < 0 || ldp < rowb || (N > 0 && !dP)) return fail(ctx, GNX_EINVAL, "base_predict_packed: bad P / N / ldp");
   if (N == 0 || (!d_b32 && !d_b64)) return GNX_OK;
+  GNX_BIND_DEVICE(ctx);
   if (lr_p2_usable(m)) {
     // the kernel fetches 64-byte runs unconditionally: only the last row could read past the matrix
     const size_t need = (size_t)C + 128;
@@ -630,23 +661,31 @@ int gnx_base_predict_packed_dev(gnx_model* m, const uint8_t* dP, int64_t N, int6
     L.W = (int32_t)m->info.W; L.A = m->info.A;
     L.b32 = d_b32; L.b64 = d_b64;
     ProfScope ps(ctx, GNX_K_BASE_LOGISTIC);
-    const hipError_t e = gnx_launch_base_logistic_p2(L, ctx->n_cu, ctx->tune, ctx->stream);
+    // GNX_P2_DECLINE=1 (tests): behave as if no instantiation fitted, so that the widening fallback below runs
+    const hipError_t e = ctx->tune.p2_decline ? hipErrorNotSupported : gnx_launch_base_logistic_p2(L, ctx->n_cu, ctx->tune, ctx->stream);
     if (e != hipErrorNotSupported) {
       HIPCHK(ctx, e);
       return GNX_OK;
     }
   }
+  // widen to int8 and run the int8 kernels.  The file routes (gnx_infer_gt2_range / gnx_phase_gt2_range) build their packed rows IN
+  // ws_xu: widening those in place would read and write one buffer at overlapping strides (and growing ws_xu would free the input),
+  // so rows that live in ws_xu are widened into a workspace of their own.
   const int64_t ldx = ((C + 15) / 16) * 16;
-  int rc = ws_reserve(ctx, ctx->ws_xu, (size_t)N * ldx + 256);
+  const char* in0 = reinterpret_cast<const char*>(dP);
+  const bool in_xu = ctx->ws_xu.p && in0 >= (const char*)ctx->ws_xu.p && in0 < (const char*)ctx->ws_xu.p + ctx->ws_xu.cap;
+  gnx_devbuf& wide = in_xu ? ctx->ws_xu2 : ctx->ws_xu;
+  int rc = ws_reserve(ctx, wide, (size_t)N * ldx + 256);
   if (rc != GNX_OK) return rc;
-  HIPCHK(ctx, gnx_launch_unpack2(dP, N, ldp, C, (int8_t*)ctx->ws_xu.p, ldx, ctx->stream));
-  return gnx_base_predict_dev(m, (const int8_t*)ctx->ws_xu.p, N, ldx, d_b32, d_b64);
+  HIPCHK(ctx, gnx_launch_unpack2(dP, N, ldp, C, (int8_t*)wide.p, ldx, ctx->stream));
+  return gnx_base_predict_dev(m, (const int8_t*)wide.p, N, ldx, d_b32, d_b64);
 }
 
 // base + smoother with B kept in context scratch; X int8 (packed == false) or 2-bit rows
 static int infer_any_dev(gnx_model* m, const void* dIn, bool packed, int64_t N, int64_t ld, float* d_p32, double* d_p64, int32_t* d_lab) {
   gnx_ctx* ctx = m->ctx;
   if (N <= 0) return N == 0 ? GNX_OK : fail(ctx, GNX_EINVAL, "infer: N < 0");
+  GNX_BIND_DEVICE(ctx);
   const size_t n = (size_t)N * m->info.W * m->info.A;
   const bool f64 = (m->info.smooth_kind == GNX_SMOOTH_CRF);  // CRF consumes float64 base probabilities
   int rc = ws_reserve(ctx, f64 ? ctx->ws_b64 : ctx->ws_b32, n * (f64 ? 8 : 4));
@@ -677,7 +716,7 @@ int gnx_base_predict(gnx_model* m, const int8_t* X, int64_t N, int64_t ldx, floa
   gnx_ctx* ctx = m->ctx;
   if (N < 0 || ldx < m->info.C || (N > 0 && !X)) return fail(ctx, GNX_EINVAL, "base_predict: bad X / N / ldx");
   if (N == 0) return GNX_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const size_t WA = (size_t)m->info.W * m->info.A;
   const int64_t nb = hap_batch(m, N, ldx);
   int rc;
@@ -703,7 +742,7 @@ int gnx_smooth_predict(gnx_model* m, const void* B, int b_is_f64, int64_t N, flo
   gnx_ctx* ctx = m->ctx;
   if (N < 0 || (N > 0 && !B)) return fail(ctx, GNX_EINVAL, "smooth_predict: bad B / N");
   if (N == 0) return GNX_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const size_t WA = (size_t)m->info.W * m->info.A, Wn = (size_t)m->info.W;
   const size_t esz = b_is_f64 ? 8 : 4;
   int rc;
@@ -743,7 +782,7 @@ static int pipe_init(gnx_ctx* ctx) {
 static int infer_host(gnx_model* m, const void* src, bool packed, int64_t N, int64_t ld, float* p32, double* p64, int32_t* lab) {
   gnx_ctx* ctx = m->ctx;
   const int64_t C = m->info.C;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const size_t WA = (size_t)m->info.W * m->info.A, Wn = (size_t)m->info.W;
   const int64_t row_bytes = packed ? (C + 3) / 4 : C;
   // batch: whole individuals, ~1 GiB of staged input at most; when overlapping, at least ~4 batches so the pipeline fills
@@ -889,6 +928,7 @@ int gnx_pack_x(const int8_t* X, int64_t N, int64_t ldx, int64_t C, uint8_t* P, i
 int gnx_unpack_x_dev(gnx_ctx* ctx, const uint8_t* dP, int64_t N, int64_t ldp, int64_t C, int8_t* dX, int64_t ldx) {
   if (!ctx) return GNX_EINVAL;
   if (N < 0 || C <= 0 || ldx < C || ldp < (C + 3) / 4 || (N > 0 && (!dP || !dX))) return fail(ctx, GNX_EINVAL, "unpack_x: bad arguments");
+  GNX_BIND_DEVICE(ctx);
   HIPCHK(ctx, gnx_launch_unpack2(dP, N, ldp, C, dX, ldx, ctx->stream));
   return GNX_OK;
 }
@@ -915,7 +955,7 @@ int gnx_smooth_rows(gnx_model* m, const float* rows, int64_t R, float* proba) {
   if (m->info.smooth_kind != GNX_SMOOTH_XGB) return fail(ctx, GNX_ESTATE, "smooth_rows needs the XGB smoother");
   if (R < 0 || (R > 0 && (!rows || !proba))) return fail(ctx, GNX_EINVAL, "smooth_rows: bad arguments");
   if (R == 0) return GNX_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const int F = m->info.S * m->info.A, A = m->info.A;
   int rc;
   if ((rc = ws_reserve(ctx, ctx->ws_misc, (size_t)R * F * 4)) != GNX_OK) return rc;
@@ -936,7 +976,7 @@ int gnx_calibrate_rows(gnx_model* m, const void* proba, int proba_is_f64, int64_
   if (!m->calib_off) return fail(ctx, GNX_ESTATE, "model has no calibrator");
   if (R < 0 || (R > 0 && (!proba || !out))) return fail(ctx, GNX_EINVAL, "calibrate_rows: bad arguments");
   if (R == 0) return GNX_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const size_t bytes = (size_t)R * m->info.A * sizeof(double);
   const size_t in_bytes = (size_t)R * m->info.A * (proba_is_f64 ? 8 : 4);
   int rc = ws_reserve(ctx, ctx->ws_cal, bytes);
@@ -1023,6 +1063,7 @@ static int gnofix_ws_reserve(gnx_model* m, int64_t n, int32_t max_it, bool in_ld
 static int gnofix_run_dev(gnx_model* m, int8_t* dX, int64_t ldx, const double* dB, int64_t n, int32_t max_it, int32_t* dY,
                           int32_t* dNs, bool in_lds, bool side_stream, bool packed = false) {
   gnx_ctx* ctx = m->ctx;
+  GNX_BIND_DEVICE(ctx);
   const int W = (int)m->info.W, A = m->info.A, S = m->info.S;
   int rc;
   GnofixWs ws;
@@ -1099,7 +1140,7 @@ int gnx_gnofix(gnx_model* m, int8_t* X, int64_t ldx, const double* B, int64_t n_
   bool in_lds = true;
   int rc = gnofix_check(m, ldx, n_ind, max_it, X && B && Y, &in_lds);
   if (rc != GNX_OK || n_ind == 0) return rc;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const int W = (int)m->info.W;
   const size_t WA = (size_t)W * m->info.A;
   // Batches of whole individuals alternate between the two halves of the staging workspaces: X and B of batch i+1 go up, and X / labels
@@ -1176,7 +1217,7 @@ int gnx_train_logistic_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ld
   if (C % M == 0) return fail(ctx, GNX_EINVAL, "C % M == 0: the reference's window slicing (base.py:158) requires a remainder");
   if (ldc < M + 2 * cx + C % M) return fail(ctx, GNX_EINVAL, "train_logistic: ldc < M + 2*ctx + C % M");
   if (!(C_reg > 0.0) || !(tol > 0.0)) return fail(ctx, GNX_EINVAL, "train_logistic: C_reg and tol must be positive");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const int newton = max_iter > 0 ? std::min(max_iter, 200) : 100;
   HIPCHK(ctx, gnx_train_lr_run(dX, N, ldx, dy, C, M, cx, A, C_reg, tol, newton, 250, coef, ldc, intercept, info, ctx->stream));
   return GNX_OK;
@@ -1187,7 +1228,7 @@ int gnx_train_logistic(gnx_ctx* ctx, const int8_t* X, int64_t N, int64_t ldx, co
   if (!ctx) return GNX_EINVAL;
   if (!ctx->usable) return fail(ctx, GNX_ESTATE, "context has no device (gnx_init failed)");
   if (N <= 0 || !X || !y || M <= 0 || C < M || ldx < C) return fail(ctx, GNX_EINVAL, "train_logistic: bad X / y / geometry");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const int64_t W = C / M;
   int rc;
   if ((rc = ws_reserve(ctx, ctx->ws_x, (size_t)N * ldx + 64)) != GNX_OK) return rc;
@@ -1224,7 +1265,7 @@ int gnx_train_gbt_dev(gnx_ctx* ctx, const void* dB, int32_t b_is_f64, const int3
   if (!ctx) return GNX_EINVAL;
   int rc = gbt_check(ctx, dB, dy, N, W, A, S, P, tree_off, tree_class, left, right, feat, cond, n_nodes);
   if (rc != GNX_OK) return rc;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   HIPCHK(ctx, gnx_train_gbt_run(dB, b_is_f64, dy, N, W, A, S, *P, tree_off, tree_class, left, right, feat, cond, n_nodes, loss, ctx->n_cu,
                                 ctx->stream));
   return GNX_OK;
@@ -1238,7 +1279,7 @@ int gnx_train_gbt(gnx_ctx* ctx, const void* B, int32_t b_is_f64, const int32_t* 
   if (rc != GNX_OK) return rc;
   for (int64_t i = 0; i < N * W; ++i)
     if (y[i] < 0 || y[i] >= A) return fail(ctx, GNX_EINVAL, "train_gbt: label outside [0, A)");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   const size_t nb = (size_t)N * W * A * (b_is_f64 ? 8 : 4), ny = (size_t)N * W * 4;
   gnx_devbuf& wsB = b_is_f64 ? ctx->ws_b64 : ctx->ws_b32;
   if ((rc = ws_reserve(ctx, wsB, nb)) != GNX_OK) return rc;
@@ -1308,6 +1349,7 @@ int gnx_fit_isotonic_f32(const float* x, const float* y, int64_t n, float* x_thr
 // ---- profiling ---------------------------------------------------------------------------------------
 int gnx_profile_enable(gnx_ctx* ctx, int on) {
   if (!ctx) return GNX_EINVAL;
+  GNX_BIND_DEVICE(ctx);
   if (!on) prof_drain(ctx);
   ctx->prof = on != 0;
   return GNX_OK;
@@ -1315,6 +1357,7 @@ int gnx_profile_enable(gnx_ctx* ctx, int on) {
 
 int gnx_profile_reset(gnx_ctx* ctx) {
   if (!ctx) return GNX_EINVAL;
+  GNX_BIND_DEVICE(ctx);
   prof_drain(ctx);
   for (int k = 0; k < GNX_K_COUNT; ++k) { ctx->prof_ms[k] = 0; ctx->prof_n[k] = 0; }
   return GNX_OK;
@@ -1322,6 +1365,7 @@ int gnx_profile_reset(gnx_ctx* ctx) {
 
 int gnx_profile_get(gnx_ctx* ctx, int kid, double* total_ms, int64_t* launches) {
   if (!ctx || kid < 0 || kid >= GNX_K_COUNT) return GNX_EINVAL;
+  GNX_BIND_DEVICE(ctx);
   prof_drain(ctx);
   if (total_ms) *total_ms = ctx->prof_ms[kid];
   if (launches) *launches = ctx->prof_n[kid];

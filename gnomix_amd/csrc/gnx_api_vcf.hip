@@ -19,7 +19,8 @@ static void* alloc_plain(void*, size_t bytes) { return malloc(bytes); }
 static void free_plain(void*, void* p) { free(p); }
 static void* alloc_pinned(void* user, size_t bytes) {
   gnx_ctx* ctx = (gnx_ctx*)user;
-  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  gnx_device_scope bind(ctx);  // (the reader's parsing threads call this: each binds, allocates, unbinds)
+  if (bind.err != hipSuccess) return nullptr;
   return gnx_pin_alloc(bytes);  // (released buffers of the same size are reused: gnx_api.hip)
 }
 static void free_pinned(void*, void* p) { gnx_pin_free(p); }
@@ -39,6 +40,7 @@ int gnx_gt2_to_x_dev(gnx_ctx* ctx, const uint8_t* dG, int64_t V, int64_t ldg, in
   if (!ctx) return GNX_EINVAL;
   if (N < 0 || C < 0 || V < 0 || n0 < 0 || (n0 & 3) || ldx < C || ldg < (n0 + N + 3) / 4 || (N > 0 && C > 0 && (!dG || !d_src || !dX)))
     return gnx_fail(ctx, GNX_EINVAL, "gt2_to_x: bad arguments (n0 must be a multiple of 4, ldg >= ceil((n0 + N) / 4), ldx >= C)");
+  GNX_BIND_DEVICE(ctx);
   HIPCHK(ctx, gnx_launch_gt2_to_x(dG, V, ldg, n0, N, d_src, C, dX, ldx, ctx->stream));
   return GNX_OK;
 }
@@ -48,6 +50,7 @@ int gnx_gt2_to_p2_dev(gnx_ctx* ctx, const uint8_t* dG, int64_t V, int64_t ldg, i
   if (!ctx) return GNX_EINVAL;
   if (N < 0 || C < 0 || V < 0 || n0 < 0 || (n0 & 3) || ldp < (C + 3) / 4 || ldg < (n0 + N + 3) / 4 || (N > 0 && C > 0 && (!dG || !d_src || !dP)))
     return gnx_fail(ctx, GNX_EINVAL, "gt2_to_p2: bad arguments (n0 must be a multiple of 4, ldg >= ceil((n0 + N) / 4), ldp >= ceil(C / 4))");
+  GNX_BIND_DEVICE(ctx);
   HIPCHK(ctx, gnx_launch_gt2_to_p2(dG, V, ldg, n0, N, d_src, C, dP, ldp, ctx->stream));
   return GNX_OK;
 }
@@ -57,6 +60,7 @@ int gnx_x_to_gt2_dev(gnx_ctx* ctx, const int8_t* dX, int64_t N, int64_t ldx, int
   if (!ctx) return GNX_EINVAL;
   if (N < 0 || V < 0 || n0 < 0 || (n0 & 3) || ldg < (n0 + N + 3) / 4 || (N > 0 && V > 0 && (!dX || !d_cols || !dG)))
     return gnx_fail(ctx, GNX_EINVAL, "x_to_gt2: bad arguments (n0 must be a multiple of 4, ldg >= ceil((n0 + N) / 4))");
+  GNX_BIND_DEVICE(ctx);
   HIPCHK(ctx, gnx_launch_x_to_gt2(dX, N, ldx, n0, d_cols, V, dG, ldg, ctx->stream));
   return GNX_OK;
 }
@@ -126,7 +130,7 @@ int gnx_infer_gt2_range(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, 
   if (N < 0 || V < 0 || h0 < 0 || (h0 & 3) || ldg < (h0 + N + 3) / 4 || !src || (N > 0 && V > 0 && !G))
     return gnx_fail(ctx, GNX_EINVAL, "infer_gt2: bad G / V / ldg / first haplotype (a multiple of 4) / N / src");
   if (N == 0) return GNX_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   Gt2Job J{};
   int rc = gt2_stage(m, G, V, ldg, h0, N, src, nullptr, 0, &J);
   if (rc != GNX_OK) return rc;
@@ -192,7 +196,7 @@ int gnx_phase_gt2_range(gnx_model* m, const uint8_t* G, int64_t V, int64_t ldg, 
   if (!G_out) n_out = 0;
   for (int64_t r = 0; r < n_out; ++r)
     if (out_cols[r] < 0 || out_cols[r] >= m->info.C) return gnx_fail(ctx, GNX_EINVAL, "phase_gt2: output column outside the model's SNPs");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   Gt2Job J{};
   int rc = gt2_stage(m, G, V, ldg, h0, N, src, out_cols, n_out, &J);
   if (rc != GNX_OK) return rc;
@@ -265,7 +269,7 @@ extern "C" int gnx_write_fb_dev(gnx_ctx* ctx, const char* path, const char* head
   if (!path || head_len < 0 || (head_len > 0 && !head) || N < 0 || W < 0 || A < 0 || (W > 0 && (!pb || !po)) || (N > 0 && W > 0 && A > 0 && !proba))
     return gnx_fail(ctx, GNX_EINVAL, "write_fb_dev: bad arguments");
   if (N == 0 || W == 0 || A == 0 || A > 4096) return gnx_write_fb(path, head, head_len, pb, po, proba, 0, N, W, A, 0);
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   hipStream_t s = ctx->stream;
   const int64_t NA = N * A, plen_all = po[W] - po[0];
   if (po[0] != 0 || plen_all < 0) return gnx_fail(ctx, GNX_EINVAL, "write_fb_dev: prefix offsets must start at 0 and not decrease");

@@ -33,6 +33,7 @@ struct gnx_tune {
   int lr_nbuf = 0;                      // GNX_LR_NBUF: ring slots of the LDS-direct kernel
   int p2_mt = 0, p2_cw = 0, p2_ew = 0, p2_xsn = 0, p2_nbuf = 0;  // GNX_P2_TUNE="mt,compute waves,epilogue waves,X stages,plane slots":
                                         // shape of the 2-bit-native logistic pass (development)
+  int p2_decline = 0;                   // GNX_P2_DECLINE=1 (tests): the 2-bit launcher reports "no instantiation fits" -> the widening fallback runs
   int lr_p2 = 1;                        // GNX_LR_P2=0: packed (2-bit) input is widened to int8 in HBM and run through the int8 kernels
                                         // instead of k_base_logistic_p2 (A/B runs; the outputs are bit-identical)
   int lr_flat = -1;                     // GNX_LR_FLAT: 1 = flat column tiles (k_base_logistic_i8_fl) wherever built, 0 = never
@@ -84,7 +85,7 @@ struct gnx_ctx {
   hipEvent_t ev_aux[2] = {nullptr, nullptr};
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-  gnx_devbuf ws_pk, ws_xu, ws_psi;
+  gnx_devbuf ws_pk, ws_xu, ws_xu2, ws_psi;  // ws_xu2: int8 rows widened from packed rows that themselves live in ws_xu
   gnx_devbuf ws_rank;  // k_smooth_ranks -> k_smooth_xgb_h64
   gnx_devbuf ws_fb, ws_fb_body;  // gnx_write_fb_dev: probabilities / lengths / tables, and the file's body as text
   gnx_devbuf ws_gt2, ws_src, ws_gt2o;  // file path (gnx_api_vcf.hip): variant-major 2-bit genotypes, column map, phased rows
@@ -435,6 +436,32 @@ struct gnx_model {
 
 // shared with gnx_api_vcf.hip (defined in gnx_api.hip)
 int gnx_fail(gnx_ctx* ctx, int code, const std::string& msg);
+
+// The HIP "current device" is per host THREAD (a new thread starts on device 0) and hipMalloc / kernel launches / event creation use
+// it, not the stream's device.  Every extern "C" entry that touches the GPU therefore binds its context's device for the duration of
+// the call and puts the caller's device back on return (one gnx_ctx per device, different contexts on different threads —
+// or, with torch tensors, several contexts driven from ONE thread).
+struct gnx_device_scope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit gnx_device_scope(const gnx_ctx* ctx) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != ctx->device) {
+      err = hipSetDevice(ctx->device);
+      switched = err == hipSuccess;
+    }
+  }
+  ~gnx_device_scope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  gnx_device_scope(const gnx_device_scope&) = delete;
+  gnx_device_scope& operator=(const gnx_device_scope&) = delete;
+};
+#define GNX_BIND_DEVICE(ctx)                                                                                       \
+  gnx_device_scope dev_scope__(ctx);                                                                               \
+  if (dev_scope__.err != hipSuccess)                                                                               \
+  return gnx_fail((ctx), GNX_EHIP, std::string("binding device ") + std::to_string((ctx)->device) + ": " + hipGetErrorString(dev_scope__.err))
 int gnx_ws_reserve(gnx_ctx* ctx, gnx_devbuf& b, size_t bytes);
 int gnx_pipe_init(gnx_ctx* ctx);
 bool gnx_gnofix_packed_ok(const gnx_model* m);  // gnx_gnofix_packed_dev can run (rank-strip Gnofix kernel)

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 
 #include "gnx_io.h"
 
@@ -58,8 +59,8 @@ struct Source {
     else free(owned);
     if (zmap) munmap(const_cast<uint8_t*>(zmap), zmap_n);
   }
-  static bool inflate_block(const uint8_t* in, size_t in_n, uint8_t* out, size_t out_n) {
-    static const bool use_zlib = getenv("GNX_VCF_ZLIB") != nullptr;  // A/B: zlib's inflate() instead of gnx_io_inflate_raw
+  bool use_zlib = false;  // GNX_VCF_ZLIB (read per open: an A/B switch): zlib's inflate() instead of gnx_io_inflate_raw
+  bool inflate_block(const uint8_t* in, size_t in_n, uint8_t* out, size_t out_n) const {
     if (out_n == 0) return true;
     if (!use_zlib && gnx_io_inflate_raw(in, in_n, out, out_n) == 0) return true;
     z_stream s;
@@ -95,7 +96,12 @@ struct Source {
         *err = "read past the end of the BGZF text";
         return nullptr;
       }
-      if (buf.size() < end - base) buf.resize(end - base);
+      try {
+        if (buf.size() < end - base) buf.resize(end - base);
+      } catch (const std::bad_alloc&) {  // (this runs inside a parsing thread: nothing may be thrown through it)
+        *err = "out of memory inflating a BGZF window";
+        return nullptr;
+      }
       for (size_t k = lo; k < j; ++k)
         if (!inflate_block(zmap + blocks[k].poff, blocks[k].psize, (uint8_t*)buf.data() + (blocks[k].uoff - base), blocks[k].usize)) {
           *err = "corrupt BGZF block";
@@ -145,6 +151,7 @@ bool bgzf_table(const uint8_t* z, size_t zn, std::vector<BgzfBlock>& blocks, siz
     b.poff = o + xend;
     b.psize = (size_t)bsize - xend - 8;
     b.usize = rd32(h + bsize - 4);
+    if (b.usize > 65536) return false;  // not BGZF (the format bounds a block's text at 64 KiB): the serial gzip path decides
     b.uoff = total;
     total += b.usize;
     blocks.push_back(b);
@@ -244,6 +251,7 @@ int open_source(const char* path, int n_threads, Source& t) {
     t.zmap = z;
     t.zmap_n = zn;
     t.blocks = std::move(blocks);
+    t.use_zlib = getenv("GNX_VCF_ZLIB") != nullptr;
     t.n = total;
     t.compression = 2;
     return GNX_OK;

@@ -165,11 +165,12 @@ __global__ __launch_bounds__(256) void k_gnofix_dif(const int8_t* __restrict__ X
 struct WsDiv {
   uint32_t ws, inv;
   __device__ __forceinline__ uint32_t operator()(uint32_t j) const {
+    if (inv == 0u) return j;  // ws == 1 (one SNP per window): ceil(2^32 / 1) does not fit 32 bits
     uint32_t q = __umulhi(j, inv);
     return q - (q * ws > j ? 1u : 0u);
   }
 };
-__host__ inline uint32_t gnx_ws_inv(uint32_t ws) { return (uint32_t)((((uint64_t)1 << 32) + ws - 1) / ws); }
+__host__ inline uint32_t gnx_ws_inv(uint32_t ws) { return ws <= 1u ? 0u : (uint32_t)((((uint64_t)1 << 32) + ws - 1) / ws); }  // 0: WsDiv is the identity
 
 // ---- post-pass: correct_phase_error applied once from the final parity (phasing.py:188-198): windows of odd parity exchange their
 // SNP blocks.  grid = (16 KB pieces of the chromosome, individuals); a block whose windows are all even leaves without a load. ----

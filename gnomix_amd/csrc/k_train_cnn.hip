@@ -204,7 +204,7 @@ extern "C" int gnx_train_cnn(gnx_ctx* ctx, const void* B, int32_t b_is_f64, cons
   if (order)
     for (int64_t i = 0; i < (int64_t)P->epochs * N; ++i)
       if (order[i] < 0 || order[i] >= N) return gnx_fail(ctx, GNX_EINVAL, "train_cnn: row index outside [0, N) in `order`");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   hipStream_t s = ctx->stream;
   const int nbmax = (int)std::min<int64_t>(P->batch, N);
   const int n_slices_max = (nbmax + SLICE - 1) / SLICE;

@@ -258,7 +258,7 @@ extern "C" int gnx_train_crf(gnx_ctx* ctx, const void* B, int32_t b_is_f64, cons
     return gnx_fail(ctx, GNX_EINVAL, "train_crf: need c2 > 0, epsilon > 0, max_iterations >= 0, 1 <= memory <= 64");
   for (int64_t i = 0; i < N * W; ++i)
     if (y[i] < 0 || y[i] >= A) return gnx_fail(ctx, GNX_EINVAL, "train_crf: label outside [0, A)");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GNX_BIND_DEVICE(ctx);
   hipStream_t s = ctx->stream;
   const int AA = A * A, NP = 2 * AA;
   size_t off = 0;

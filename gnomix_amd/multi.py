@@ -206,11 +206,14 @@ class DeviceGroup:
         if N % 2:
             raise ValueError("phase_gt2: N = 2 * individuals")
         p, lab = self._outputs(N, proba_dtype, out)
-        nsw = np.empty((N // 2,), np.int32)
+        nsw = m0.ctx.pinned_empty((N // 2,), np.int32)
         Go = cols = None
         if out_cols is not None:
             cols = np.ascontiguousarray(out_cols, dtype=np.int32)
-            Go = np.zeros((len(cols), G.shape[1]), np.uint8)
+            # page-locked (and portable: every device writes its byte columns of these rows with a strided D2H copy — pageable rows
+            # would go through the runtime's staging buffer and serialise the devices)
+            Go = m0.ctx.pinned_empty((len(cols), G.shape[1]), np.uint8)
+            Go[...] = 0
         WA, W = self.W * self.A, self.W
         jobs = []
         for m, (i0, n) in zip(self.models, shard_individuals(N // 2, len(self.models))):

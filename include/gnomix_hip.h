@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 13
+#define GNX_ABI_VERSION 14
 
 typedef struct gnx_ctx gnx_ctx;
 typedef struct gnx_model gnx_model;
@@ -212,6 +212,13 @@ int gnx_host_free(gnx_ctx* ctx, void* p);
  * rows and output arrays to contexts on different devices. */
 #define GNX_HOST_PORTABLE 0x1u
 int gnx_host_flags(const void* p, unsigned* flags);
+/* Device binding.  HIP's "current device" belongs to the calling THREAD (a new thread starts on device 0); every entry point of this
+ * library that touches the GPU binds its context's device for the duration of the call and restores the caller's on return, so
+ * several contexts may be driven from one thread (torch tensors on several GPUs) as well as one context per thread.
+ * Diagnostics for that contract: the device ordinal (hipPointerGetAttributes) of every LIVE device workspace of the context, at most
+ * n of them written to out; returns how many workspaces are live (may exceed n), negative on error.  A tripwire for multi-GPU
+ * nodes: every entry must equal the device the context was created on (tests/test_gpu_devices.py). */
+int gnx_debug_ws_devices(gnx_ctx* ctx, int32_t* out, int32_t n);
 
 /* model */
 int gnx_model_load(gnx_ctx* ctx, const gnx_model_desc* desc, gnx_model** out);

@@ -358,13 +358,14 @@ def test_no_default_dispatch_kernel_carries_scratch():
 
 
 # ---------------------------------------------------------------- LGBMBase / CBBase: third-party tree formats -> forest base ----
-def _lgbm_model_string(rng, n_feat, n_class, rounds, max_leaves=16):
+def _lgbm_model_string(rng, n_feat, n_class, rounds, max_leaves=16, softmax2=False):
     """a LightGBM model string with random leaf-wise trees (the text layout of Booster.model_to_string()), and the same trees as
-    Python structures for the direct evaluator below"""
-    per_iter = 1 if n_class == 2 else n_class
-    head = ["tree", "version=v3", "num_class=%d" % (1 if n_class == 2 else n_class), "num_tree_per_iteration=%d" % per_iter,
+    Python structures for the direct evaluator below (softmax2: two classes trained with objective=multiclass, num_class=2)"""
+    binary = n_class == 2 and not softmax2
+    per_iter = 1 if binary else n_class
+    head = ["tree", "version=v3", "num_class=%d" % (1 if binary else n_class), "num_tree_per_iteration=%d" % per_iter,
             "label_index=0", "max_feature_idx=%d" % (n_feat - 1),
-            "objective=" + ("binary sigmoid:1" if n_class == 2 else "multiclass num_class:%d" % n_class),
+            "objective=" + ("binary sigmoid:1" if binary else "multiclass num_class:%d" % n_class),
             "feature_names=" + " ".join("Column_%d" % i for i in range(n_feat)), "feature_infos=" + " ".join("[0:2]" for _ in range(n_feat)), ""]
     out, trees = ["\n".join(head)], []
     for t in range(rounds * per_iter):
@@ -413,26 +414,28 @@ def _lgbm_predict(trees, per_iter, n_class, x):
         while node >= 0:
             node = lc[node] if float(x[sf[node]]) <= th[node] else rc[node]
         raw[t % per_iter] += lv[~node]
-    if n_class == 2:
+    if n_class == 2 and per_iter == 1:
         p1 = 1.0 / (1.0 + np.exp(-raw[0]))
         return np.array([1 - p1, p1])
     e = np.exp(raw - raw.max())
     return e / e.sum()
 
 
-@pytest.mark.parametrize("A", [2, 3, 7])
+@pytest.mark.parametrize("A", [2, 3, 7, -2])
 def test_forest_from_lgbm_text(oracle, A):
     """LGBMBase (src/Base/models.py:38-52): LightGBM model strings -> fb_* arrays; the oracle's forest on them == LightGBM's own
     prediction rule evaluated directly on the strings' trees (x <= threshold left, leaf ~child, class = tree % num_tree_per_iteration).
     Unpinned to lightgbm itself (absent from this image): the format is restated from its documented text layout."""
     from gnomix_amd import convert
-    rng = np.random.RandomState(100 + A)
+    softmax2 = A < 0          # -2: a two-class model trained as multiclass (two trees per round, softmax) — folded into one margin
+    A = abs(A)
+    rng = np.random.RandomState(100 + A + 50 * softmax2)
     M, ctx, W = 6, 2, 4
     C = M * W + 1
     strs, structs = [], []
     for w in range(W):
         width = M + 2 * ctx + (1 if w == W - 1 else 0)
-        s, trees, per_iter = _lgbm_model_string(rng, width, A, rounds=5)
+        s, trees, per_iter = _lgbm_model_string(rng, width, A, rounds=5, softmax2=softmax2)
         strs.append(s); structs.append((trees, per_iter))
     f = convert.forest_from_lgbm_text(strs, A)
     T = oracle.Trees(f["fb_tree_off"], f["fb_left"], f["fb_right"], f["fb_feat"], f["fb_cond"], f["fb_tree_class"], max(A, 2),
@@ -447,18 +450,22 @@ def test_forest_from_lgbm_text(oracle, A):
             assert np.allclose(B[n, w], ref, atol=2e-6), (w, n)
     with pytest.raises(ValueError, match="num_class|single-output"):
         convert.trees_from_lgbm_text(strs[0], A + 1 if A > 2 else 3)
+    with pytest.raises(NotImplementedError, match="average_output"):
+        convert.trees_from_lgbm_text(strs[0].replace("label_index=0", "average_output\nlabel_index=0", 1), A)
 
 
-@pytest.mark.parametrize("A", [2, 5])
+@pytest.mark.parametrize("A", [2, 5, -2])
 def test_forest_from_catboost_json(oracle, A):
     """CBBase (src/Base/models.py:68-81): CatBoost JSON exports (oblivious trees) -> fb_* arrays; the oracle's forest on them ==
     CatBoost's own rule evaluated directly (leaf index bit i = x[feature_i] > border_i, leaf-major class values, scale and bias).
     Unpinned to catboost itself (absent from this image)."""
     from gnomix_amd import convert
-    rng = np.random.RandomState(7 + A)
+    softmax2 = A < 0          # -2: MultiClass on two labels (two values per leaf, softmax) — folded into one margin
+    A = abs(A)
+    rng = np.random.RandomState(7 + A + 50 * softmax2)
     M, ctx, W = 5, 1, 3
     C = M * W + 2
-    dims = 1 if A == 2 else A
+    dims = 1 if (A == 2 and not softmax2) else A
     models = []
     for w in range(W):
         width = M + 2 * ctx + (2 if w == W - 1 else 0)
@@ -486,7 +493,7 @@ def test_forest_from_catboost_json(oracle, A):
             for tr in m["oblivious_trees"]:
                 idx = sum((1 << i) for i, sp in enumerate(tr["splits"]) if float(x[sp["float_feature_index"]]) > sp["border"])
                 raw = raw + m["scale_and_bias"][0] * np.array(tr["leaf_values"][idx * dims:(idx + 1) * dims])
-            if A == 2:
+            if dims == 1:
                 p1 = 1.0 / (1.0 + np.exp(-raw[0]))
                 ref = np.array([1 - p1, p1])
             else:
