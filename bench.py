@@ -16,7 +16,10 @@ process-group / RCCL code (what a 1-GPU box can exercise of it).
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, measured
 with hipEvents on the launch stream inside libgnomix_hip), `e2e` (host pointers in, labels out, PCIe included —
 never `value`) and, at N=1, `cpu_baseline` (the oracle's C restatement timed on ALL of this box's host cores on a
-bounded sample, base and smoother timed separately).
+bounded sample, base and smoother timed separately) and `configs` (BASELINE.json's configs 3, 4, 5 at their one-GPU
+shard sizes: scripts/bench_configs.py bench_legs(); never `value`).  The line is kept compact (the driver's record
+holds its last ~8 KB: `configs`, `roofline` and `cpu_baseline` are printed last); what every field means is DESIGN.md 5;
+the same object, indented, is also written to gpurun_out/bench_last.json.
 """
 import argparse
 import json
@@ -49,6 +52,18 @@ def kernel_src_sha16():
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def checked_traffic(counters, kernel, alg_bytes):
+    """HBM bytes per launch of `kernel` from the committed counter summary -> (bytes or None, note or None).  A kernel cannot move
+    fewer bytes than its algorithmic ones: a counter below 0.95 x of them belongs to another kernel (round 5: the parked
+    k_smooth_xgb_bs was filed under the rank walk's key) and is never printed."""
+    t = counters.get(kernel) if isinstance(counters, dict) else None
+    if not isinstance(t, (int, float)) or isinstance(t, bool):
+        return None, None
+    if t < 0.95 * alg_bytes:
+        return None, "profiles/traffic_latest.json holds %.4g B for %s, below its algorithmic %.4g B: not this kernel's counter" % (t, kernel, alg_bytes)
+    return float(t), None
 
 
 def usable_cpus():
@@ -103,7 +118,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--haps", type=int, default=10000, help="haplotypes per GPU per pass")
-    ap.add_argument("--smoother-bs", type=int, default=1, help="0: skip the k_smooth_xgb_bs leg (kernels.k_smooth_xgb_bs)")
+    ap.add_argument("--configs", type=int, default=1, help="0: skip the `configs` legs (BASELINE configs 3, 4, 5 on one GPU: c3, c4_2bit, c5a_2bit, c5b_resident)")
+    ap.add_argument("--config-reps", type=int, default=3, help="timed repetitions per `configs` leg")
     ap.add_argument("--resident-2bit", type=int, default=1, help="0: skip the 2-bit-resident leg (resident_2bit, kernels.k_base_logistic_p2)")
     ap.add_argument("--passes", type=int, default=20, help="passes over the resident batch per step: a step is `passes` x `haps` haplotypes, so "
                     "that the 20 steps the driver asks for time > 1 s of device work instead of 57 ms")
@@ -112,7 +128,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="host-pointer (PCIe-inclusive) passes at N=1 (0 = skip)")
     ap.add_argument("--bgzf-level", type=int, default=6, help="deflate level of the BGZF leg's input (6 = bgzip's default; earlier rounds used 1)")
-    ap.add_argument("--vcf-reps", type=int, default=5, help="file-to-file passes (VCF text in, .msp/.fb out) at N=1 (0 = skip)")
+    ap.add_argument("--vcf-reps", type=int, default=3, help="file-to-file passes (VCF text in, .msp/.fb out) at N=1 (0 = skip)")
     ap.add_argument("--phase-leg", type=int, default=1, help="file-to-file with phase=True on admixed individuals through a device-trained model (N=1; needs --vcf-reps > 0)")
     ap.add_argument("--vcf-dir", default="", help="where the synthetic VCF and the outputs go (default: /dev/shm when it has room, else a temp dir)")
     ap.add_argument("--seed", type=int, default=94305)
@@ -243,23 +259,24 @@ def main():
     except Exception:
         counters = {}
     dom = "k_smooth_xgb" if avg_sm >= avg_base else "k_base_logistic"
-    traffic = counters.get(dom) if isinstance(counters.get(dom), (int, float)) else None
+    alg_dom = (bytes_sm if dom == "k_smooth_xgb" else bytes_base) * N
+    traffic, traffic_note = checked_traffic(counters, dom, alg_dom)
     if dom == "k_smooth_xgb":
         ach = kernels[dom]["node_steps_per_s"] or 0.0
         roofline = {"kernel": dom, "bound": "lds", "achieved": ach / 1e9, "peak": LDS_PEAK_NODE_STEPS / 1e9, "unit": "Gnode-steps/s",
-                    "frac": ach / LDS_PEAK_NODE_STEPS, "traffic": traffic,
+                    "frac": ach / LDS_PEAK_NODE_STEPS, "traffic": traffic, "alg_bytes": alg_dom,
                     "hbm_view": {"achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["hbm_frac"]},
-                    "note": "the tree pass moves %d B/haplotype (SURVEY.md 8d) but does %d node-steps/haplotype: it is bound by the LDS "
-                            "gather pipe, not by HBM (hbm_view is the HBM reading of the same launch).  peak = 256 CU x 2.4 GHz x 32 LDS "
-                            "lanes/clk with one data-dependent gather per node-step.  The HBM-bound kernel of the path is the logistic "
-                            "pass: %.0f GB/s algorithmic = %.1f%% of the 8 TB/s peak (kernels.k_base_logistic)" %
-                            (bytes_sm, node_steps, kernels["k_base_logistic"]["alg_GBps"] or 0, 100 * (kernels["k_base_logistic"]["hbm_frac"] or 0))}
+                    "note": "tree pass: %d B and %d node-steps per haplotype: LDS-gather bound (peak = 256 CU x 2.4 GHz x 32 lanes, one gather per "
+                            "node-step), hbm_view = the HBM reading of the same launch; the HBM-bound kernel of the path is kernels.k_base_logistic "
+                            "(%.1f%% of 8 TB/s)" % (bytes_sm, node_steps, 100 * (kernels["k_base_logistic"]["hbm_frac"] or 0))}
     else:
         ach = kernels[dom]["alg_GBps"] or 0.0
         roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic,
+                    "traffic": traffic, "alg_bytes": alg_dom,
                     "note": "algorithmic bytes/launch = %d B/haplotype x %d haplotypes (SURVEY.md 8d)" % (bytes_base, N)}
 
+    if traffic_note:
+        roofline["traffic_note"] = traffic_note
     hps = world * N * P * args.steps / dt
     res = {
         "metric": "haplotypes/sec (+ windows/sec) chr22 7-ancestry inference",
@@ -268,18 +285,16 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8 x 7-digit fixed-point weights -> exact i32/i64 logits, f64 sigmoid (logistic base); f32 (tree smoother)",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: chr22-like C=370500 M=1000 ctx=500 W=370 A=7 S=75, logistic base + xgb smoother "
-                               "(100 rounds x 7 trees of depth<=4 with UNIFORM RANDOM features and thresholds: the divergence / LDS-conflict worst "
-                               "case, see trained_ensemble), %d synthetic haplotypes per GPU resident in HBM, a step = %d passes over them" % (N, P),
+        "config": {"workload": "configs[1]: chr22-like C=370500 M=1000 ctx=500 W=370 A=7 S=75, logistic base + xgb smoother (100 rounds x 7 "
+                               "uniform-random depth-4 trees), %d synthetic haplotypes per GPU resident in HBM as int8, a step = %d passes" % (N, P),
                    "haplotypes_per_gpu": N, "haplotypes_per_step_per_gpu": N * P, "sharding": "haplotypes across ranks, no data-path collective",
                    "dist_backend": backend},
-        "windows_per_s": hps * W,
-        "roofline": roofline, "kernels": kernels, "label_checksum": lab_sum,
+        "windows_per_s": hps * W, "label_checksum": lab_sum,
     }
     if counters:
         sha = kernel_src_sha16()
         res["counters"] = {"source": counters.get("source", "profiles/traffic_latest.json"), "hbm_bytes_per_launch": {
-            k: v for k, v in counters.items() if isinstance(v, (int, float))},
+            k: v for k, v in counters.items() if isinstance(v, (int, float))}, "kernel_of_key": counters.get("kernel_of_key"),
             "collected_at_kernel_src": counters.get("kernel_src_sha16"), "this_run_kernel_src": sha,
             "stale": counters.get("kernel_src_sha16") != sha}
         if res["counters"]["stale"]:
@@ -310,52 +325,15 @@ def main():
             res["resident_2bit"] = {
                 "ms_per_pass": dt2 / n2 * 1e3, "haplotypes_per_s": N * n2 / dt2, "base_ms": avg_b2 * 1e3, "smoother_ms": ms_s2 / max(n_s2, 1),
                 "outputs_identical_to_int8": bool(torch.equal(o2[0], out[0]) and torch.equal(o2[1], out[1])),
-                "resident_bytes_per_haplotype": int(Pk.shape[1]),
-                "note": "X resident as 2-bit rows (%d B/haplotype instead of %d); same kernels after the base pass; B bit-identical" % (Pk.shape[1], C)}
+                "resident_bytes_per_haplotype": int(Pk.shape[1])}
             kernels["k_base_logistic_p2"] = {
                 "avg_ms": avg_b2 * 1e3, "launches": n_b2, "alg_GBps": bytes_p2 * N / avg_b2 / 1e9 if avg_b2 else None,
                 "hbm_frac": bytes_p2 * N / avg_b2 / 1e9 / HBM_PEAK_GBS if avg_b2 else None,
                 "alg_bytes_per_haplotype": bytes_p2, "int8_equiv_GBps": bytes_base * N / avg_b2 / 1e9 if avg_b2 else None,
-                "mfma_frac": i8_ops * N / avg_b2 / 1e12 / I8_MFMA_PEAK_TOPS if avg_b2 else None,
-                "note": "algorithmic bytes = ceil(C/4) + W*A*4 per haplotype (2-bit X read once, B f32 written once); the pass is bound by "
-                        "the 64-byte row runs of X and by the matrix + float64 vector pipes, not by the byte count (DESIGN.md 4.1c)"}
+                "mfma_frac": i8_ops * N / avg_b2 / 1e12 / I8_MFMA_PEAK_TOPS if avg_b2 else None}
             del Pk, o2
         except Exception as e:
             res["resident_2bit"] = {"error": repr(e)}
-
-    # ---- the parked alternative of the dominant kernel on the same base probabilities: k_smooth_xgb_bs (no tree walks:
-    # gnomix_amd/csrc/k_smooth_xgb_bs.hip; GNX_SMOOTH_IMPL=bs), timed alone and compared bit for bit; never `value` ------------------
-    if rank == 0 and world == 1 and args.smoother_bs:
-        try:
-            Bd = model.base_predict_device(X, f64=False)
-            p_ref, l_ref = model.smooth_predict_device(Bd)
-            prev = os.environ.get("GNX_SMOOTH_IMPL")
-            os.environ["GNX_SMOOTH_IMPL"] = "bs"
-            try:
-                m_bs = gnomix_amd.DeviceModel(data, ctx=ctx)
-            finally:
-                if prev is None:
-                    os.environ.pop("GNX_SMOOTH_IMPL")
-                else:
-                    os.environ["GNX_SMOOTH_IMPL"] = prev
-            p_bs, l_bs = m_bs.smooth_predict_device(Bd)
-            torch.cuda.synchronize()
-            ctx.profile_reset()
-            ctx.profile_enable(True)
-            for _ in range(10):
-                m_bs.smooth_predict_device(Bd)
-            torch.cuda.synchronize()
-            ctx.profile_enable(False)
-            ms_bs, n_bs = ctx.profile_get(_lib.K_SMOOTH_XGB)
-            kernels["k_smooth_xgb_bs"] = {
-                "avg_ms": ms_bs / max(n_bs, 1), "launches": n_bs, "node_steps_per_s_equiv": node_steps * N / (ms_bs / max(n_bs, 1) * 1e-3),
-                "outputs_identical_to_k_smooth_xgb_rk": bool(torch.equal(p_bs, p_ref) and torch.equal(l_bs, l_ref)),
-                "note": "parked (slower than the rank walk, DESIGN.md 4.2b): per chunk of 128 windows a counting sort of every class's base "
-                        "probabilities, prefix bitmaps, 15 shifted row reads + 11 v_bfi per tree and 32 windows, ordered leaf sums; "
-                        "avg_ms includes its rank pre-pass (k_bs_ranks)"}
-            del m_bs, Bd, p_bs, l_bs, p_ref, l_ref
-        except Exception as e:
-            kernels["k_smooth_xgb_bs"] = {"error": repr(e)}
 
     # ---- PCIe-inclusive rate: host pointers in, labels + probabilities out (never `value`) ----------------------------
     if rank == 0 and world == 1 and args.e2e_steps > 0:
@@ -398,14 +376,45 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         res["cpu_baseline"] = _cpu_baseline(args, data, X, out)
+    res["kernels"] = kernels
+    res["roofline"] = roofline
+    # ---- BASELINE.json's configs 3, 4, 5 at their one-GPU shard sizes (scripts/bench_configs.py; never `value`) -------------
+    if rank == 0 and world == 1 and args.configs:
+        try:
+            del X, out
+            torch.cuda.empty_cache()
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("gnx_bench_configs", os.path.join(ROOT, "scripts", "bench_configs.py"))
+            bc = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bc)
+            res["configs"] = bc.bench_legs(ctx=ctx, reps=max(1, args.config_reps), log=lambda m: sys.stderr.write("bench.py configs " + m + "\n"))
+        except Exception as e:
+            res["configs"] = {"error": repr(e)[:300]}
     if dist is not None:
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        try:   # the whole object, indented, where gpurun merges it back (the driver's record keeps the tail of stdout only)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            json.dump(res, open(os.path.join(ROOT, "gpurun_out", "bench_last.json"), "w"), indent=1)
+        except Exception:
+            pass
+        print(json.dumps(_compact(res)), flush=True)
     # RCCL prints a version banner to STDOUT from a library destructor at process exit (after anything Python can
     # print): point fd 1 at stderr from here on, on every rank, so the JSON line stays the last line of stdout
     os.dup2(2, 1)
+
+
+def _compact(x, nd=5, notes=False):
+    """the printed line: floats at `nd` significant digits, explanatory "note" strings dropped except under `roofline` (full precision
+    and every note stay in gpurun_out/bench_last.json; DESIGN.md 5 says what each field is)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _compact(v, nd, notes or k == "roofline") for k, v in x.items() if notes or k != "note"}
+    if isinstance(x, (list, tuple)):
+        return [_compact(v, nd, notes) for v in x]
+    return x
 
 
 def _e2e(model, X, steps, out_dev):
@@ -777,12 +786,11 @@ def _cpu_baseline(args, data, X, out_dev):
                              "threads": cores, "blas_threads_per_call": blas_threads,
                              "note": "numpy: Xw.astype(float64) @ coef.T per window (what sklearn's predict_proba does), windows cut over the "
                                      "same %d threads as the port, one BLAS thread per call (threadpoolctl)" % cores},
-            "sample": "%d haplotypes of the same workload through oracle/gnx_oracle.c — the SCALAR C port of the reference's "
-                      "algorithm, not the reference — on %d threads (host shows %d CPUs, %d schedulable, cgroup CPU quota %s): logistic base by windows "
-                      "(370 tasks) %.2f s, tree smoother by haplotypes %.2f s wall; labels identical to the GPU's on the sample: %s.  "
-                      "Context (BASELINE.md 2, the reference itself, 8 cores of the survey container): base 815 haplotypes/s, "
-                      "slide_window 225 haplotypes/s (xgboost itself absent there)" %
-                      (n_s, cores, os.cpu_count() or 0, avail, quota, t_base, t_sm, same)}
+            "labels_identical_to_gpu_on_sample": same,
+            "sample": "%d haplotypes of the same workload on %d threads (host shows %d CPUs, cgroup quota %s): base = numpy/BLAS product per window "
+                      "(the reference's arithmetic) or the oracle's scalar C port, whichever is faster; tree smoother = the oracle's C port "
+                      "(xgboost is absent from the image); base by windows %.2f s, smoother by haplotypes %.2f s wall" %
+                      (n_s, cores, os.cpu_count() or 0, quota, t_base, t_sm)}
 
 
 if __name__ == "__main__":

@@ -104,6 +104,7 @@ class ModelInfo(C.Structure):
 _VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64
 SYMBOLS = {
     "gnx_abi_version": (C.c_int, []),
+    "gnx_build_flags": (C.c_int, []),
     "gnx_device_count": (C.c_int, []),
     "gnx_host_alloc": (_I, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "gnx_host_free": (_I, [_VP, _VP]),

@@ -137,6 +137,14 @@ extern "C" {
 
 int gnx_abi_version(void) { return GNX_ABI_VERSION; }
 
+int gnx_build_flags(void) {
+#ifdef GNX_EXPERIMENTS
+  return GNX_BUILD_EXPERIMENTS;
+#else
+  return 0;
+#endif
+}
+
 // HIP maps streams onto 4 hardware queues by default and two streams on one queue serialise; a context uses up to five (see
 // gnomix_amd/_lib.py: load).  Effective when the runtime has not been initialised yet; an embedding application that has already
 // used HIP sets GPU_MAX_HW_QUEUES itself.
@@ -583,16 +591,20 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
       if (h64 && (rc = ws_reserve(ctx, ctx->ws_rank, gnx_smooth_h64_rank_bytes(N, L.W, L.A, L.S))) != GNX_OK) return rc;
 #endif
     }
+#ifdef GNX_EXPERIMENTS
     const bool bs = m->xgb.impl == 4 && gnx_smooth_bs_fits(m->xgb, m->info.A, m->info.S);
     if (bs) {  // the rank pre-pass parks one 16-bit counter index per probability
       int rc = ws_reserve(ctx, ctx->ws_marg, gnx_smooth_bs_scratch_bytes(N, L.W, L.A));
       if (rc != GNX_OK) return rc;
     }
+#endif
     ProfScope ps(ctx, GNX_K_SMOOTH_XGB);
+#ifdef GNX_EXPERIMENTS
     if (bs) {
       HIPCHK(ctx, gnx_launch_smooth_xgb_bs(L, (uint16_t*)ctx->ws_marg.p, ctx->n_cu, ctx->tune, ctx->stream));
       return GNX_OK;
     }
+#endif
 #ifdef GNX_EXPERIMENTS
     if (h64) HIPCHK(ctx, gnx_launch_smooth_xgb_h64(L, (uint16_t*)ctx->ws_rank.p, ctx->tune, ctx->stream));
     else

@@ -522,10 +522,13 @@ hipError_t gnx_launch_fb_emit(const float* d_proba, int64_t N, int64_t W, int A,
                               const int64_t* d_line_off, char* d_body, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
 hipError_t gnx_launch_smooth_xgb_rk(const SmoothXGBLaunch& L, const gnx_tune& tune, hipStream_t s);
-// bit-sliced tree smoother (k_smooth_xgb_bs.hip); bins = gnx_smooth_bs_scratch_bytes() of device scratch (the rank pre-pass's output)
+#ifdef GNX_EXPERIMENTS
+// bit-sliced tree smoother (scripts/dev/rejected/k_smooth_xgb_bs.hip, GNX_SMOOTH_IMPL=bs); bins = gnx_smooth_bs_scratch_bytes() of
+// device scratch (the rank pre-pass's output)
 hipError_t gnx_launch_smooth_xgb_bs(const SmoothXGBLaunch& L, uint16_t* bins, int n_cu, const gnx_tune& tune, hipStream_t s);
 size_t gnx_smooth_bs_scratch_bytes(int64_t N, int W, int A);
 bool gnx_smooth_bs_fits(const SmoothXGBDev& d, int A, int S);
+#endif
 hipError_t gnx_launch_smooth_rows(const SmoothXGBDev& d, const float* rows, int64_t R, int32_t F, int32_t A,
                                   float* proba, hipStream_t s);
 hipError_t gnx_launch_pack_bits(const int8_t* X, int64_t N, int64_t ldx, int64_t C, int64_t ctx, int64_t nwp,

@@ -23,6 +23,28 @@ static inline int fail(gnx_ctx* ctx, int code, const std::string& msg) { return 
       return fail((ctx), GNX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
   } while (0)
 
+// [0, n) cut into contiguous ranges, one per host thread (at most 16, at least `grain` items each): fn(lo, hi, thread index).
+// Model preparation is host arithmetic over tens of millions of weights (a whole-genome set of logistic models: 2.5e8): single-threaded
+// it was most of gnx_model_load's time.  A thread that cannot be started (resource limits) is run inline: nothing is thrown.
+template <typename F>
+static unsigned parallel_ranges(size_t n, size_t grain, F&& fn) {
+  unsigned nth = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  nth = (unsigned)std::min<size_t>(nth, std::max<size_t>(1, n / std::max<size_t>(grain, 1)));
+  if (nth <= 1) {
+    fn((size_t)0, n, 0u);
+    return 1;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nth);
+  for (unsigned t = 0; t < nth; ++t) {
+    const size_t lo = n * t / nth, hi = n * (t + 1) / nth;
+    try { th.emplace_back([&fn, lo, hi, t]() { fn(lo, hi, t); }); } catch (...) { fn(lo, hi, t); }
+  }
+  for (auto& t : th) t.join();
+  return nth;
+}
+static unsigned parallel_max_threads() { return std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u); }
+
 // ------------------------------------------------------------------------------------------------
 // model preparation: logistic base
 // ------------------------------------------------------------------------------------------------
@@ -95,7 +117,11 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
   std::vector<double> maxabs((size_t)W, 0.0);
   const double* coef = d->lr_coef;
   const int64_t ldc = d->lr_ldc;
-  for (size_t c = 0; c < n_chunks; ++c)
+  std::vector<std::vector<double>> maxabs_t(parallel_max_threads());  // per-thread window maxima, merged below
+  parallel_ranges(n_chunks, 64, [&](size_t c_lo, size_t c_hi, unsigned tid) {
+  std::vector<double>& maxabs = maxabs_t[tid];
+  maxabs.assign((size_t)W, 0.0);
+  for (size_t c = c_lo; c < c_hi; ++c)
     for (int t = 0; t < 16; ++t)
       for (int kq = 0; kq < 4; ++kq) {
         const int64_t j = (int64_t)chunk_j0[c] + 16 * kq + t;
@@ -131,6 +157,9 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
           }
         }
       }
+  });
+  for (const auto& mt : maxabs_t)
+    for (size_t i = 0; i < mt.size(); ++i) maxabs[i] = std::max(maxabs[i], mt[i]);
 
   std::vector<double> icpt(d->lr_intercept, d->lr_intercept + (size_t)W * A);
   int rc;
@@ -144,7 +173,8 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
       wscale[(size_t)i] = std::ldexp(1.0, -fexp[(size_t)i]);
     }
     std::vector<int8_t> V8(n_chunks * (size_t)NT * 7 * 64 * 16, 0);
-    for (size_t c = 0; c < n_chunks; ++c)
+    parallel_ranges(n_chunks, 64, [&](size_t c_lo, size_t c_hi, unsigned) {
+    for (size_t c = c_lo; c < c_hi; ++c)
       for (int t = 0; t < 16; ++t)
         for (int nt = 0; nt < NT; ++nt)
           for (int ln = 0; ln < 64; ++ln) {
@@ -158,6 +188,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
               q = (q - dg) / 256;
             }
           }
+    });
     if ((rc = gnx_dev_upload(m, V8, &m->lr.V8, 64)) != GNX_OK) return rc;
 #ifdef GNX_EXPERIMENTS
     // flat column tiles for k_base_logistic_i8_fl: column q = slot * 7 + limb, ceil(NC * 7 / 16) tiles instead of NT * 7
@@ -280,19 +311,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
                   }
                 }
         };
-        {
-          unsigned nth = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-          nth = (unsigned)std::min<size_t>(nth, std::max<size_t>(1, n_runs / 64));
-          if (nth <= 1) fill_runs(0, n_runs);
-          else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nth; ++t) {
-              const size_t lo = n_runs * t / nth, hi = n_runs * (t + 1) / nth;
-              try { th.emplace_back(fill_runs, lo, hi); } catch (...) { fill_runs(lo, hi); }
-            }
-            for (auto& t : th) t.join();
-          }
-        }
+        parallel_ranges(n_runs, 64, [&](size_t lo, size_t hi, unsigned) { fill_runs(lo, hi); });
         if ((rc = gnx_dev_upload(m, V2, &m->lr.V2, 64)) != GNX_OK) return rc;
         if ((rc = gnx_dev_upload(m, run_byte, &m->lr.run_byte)) != GNX_OK) return rc;
         if ((rc = gnx_dev_upload(m, run_flush0, &m->lr.run_flush0)) != GNX_OK) return rc;
@@ -601,6 +620,7 @@ static int build_xgb_rk(gnx_model* m, const gnx_model_desc* d, const std::vector
   return GNX_OK;
 }
 
+#ifdef GNX_EXPERIMENTS  // the bit-sliced smoother is parked (scripts/dev/rejected/k_smooth_xgb_bs.hip): its tables are built in that build only
 // bit-sliced trees (layout in gnx_internal.h: SmoothXGBDev::bs_nodes); Uc = per-class sorted thresholds, Y = the kernel's LDS map
 static void tree_fill_bs(const gnx_model_desc* d, int32_t o, int32_t nid, uint32_t j, int depth, const std::vector<std::vector<float>>& Uc,
                          const std::vector<int32_t>& binoff, const GnxBsLayout& Y, uint32_t* words, float* leaves) {
@@ -690,6 +710,7 @@ static int build_xgb_bs(gnx_model* m, const gnx_model_desc* d, const std::vector
   if (impl && std::string(impl) == "bs") m->xgb.impl = 4;
   return GNX_OK;
 }
+#endif  // GNX_EXPERIMENTS
 
 int gnx_build_xgb(gnx_model* m, const gnx_model_desc* d) {
   gnx_ctx* ctx = m->ctx;
@@ -750,7 +771,10 @@ int gnx_build_xgb(gnx_model* m, const gnx_model_desc* d) {
   m->info.n_trees = d->n_trees;
   m->info.tree_depth = D;
   if ((rc = build_xgb_rk(m, d, order, D)) != GNX_OK) return rc;
-  return build_xgb_bs(m, d, order, D);
+#ifdef GNX_EXPERIMENTS
+  if ((rc = build_xgb_bs(m, d, order, D)) != GNX_OK) return rc;
+#endif
+  return GNX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -192,6 +192,10 @@ typedef struct gnx_model_info {
 } gnx_model_info;
 
 int gnx_abi_version(void);
+/* how the library was built: bit 0 = `make EXPERIMENTS=1` (the measured-slower kernels parked under scripts/dev/rejected/ are linked in
+ * and reachable through their development knobs; the default build does not contain them) */
+#define GNX_BUILD_EXPERIMENTS 0x1
+int gnx_build_flags(void);
 /* GPUs this process sees (HIP_VISIBLE_DEVICES applied); 0 without a usable runtime.  One gnx_ctx per device: gnx_init(d), 0 <= d < count. */
 int gnx_device_count(void);
 

@@ -27,6 +27,40 @@ def short(name):
     return (m.group(1) + (m.group(2) or ""))[:60] if m else name[:60]
 
 
+# bench.py's kernel keys <- EXACT kernel names (the part before the template arguments).  A substring match once filed the parked
+# k_smooth_xgb_bs under the dominant kernel's key and the driver-run line carried its 197 MB as the rank walk's traffic (591 MB).
+TRAFFIC_KEYS = {
+    "k_base_logistic_i8": "k_base_logistic", "k_base_logistic_i8_dl": "k_base_logistic",   # the int8-resident base pass (one of the two runs)
+    "k_base_logistic_p2": "k_base_logistic_p2",
+    "k_smooth_xgb_rk": "k_smooth_xgb",                                                       # the default tree smoother
+    "k_smooth_xgb": "k_smooth_xgb_f32", "k_smooth_xgb_bs": "k_smooth_xgb_bs", "k_bs_ranks": "k_bs_ranks",
+}
+
+
+def traffic_table(pmc):
+    """{bench.py kernel key: HBM bytes per launch} from one workload's per-kernel counters.  Two instantiations of ONE kernel (same
+    name, other template arguments) share a key: the one with more launches is the workload's, the other is listed under
+    "also_seen"; two different kernels never share a key."""
+    out, owner, launches, also = {}, {}, {}, []
+    for k, v in sorted(pmc.items()):
+        b = v.get("derived", {}).get("hbm_bytes_per_launch")
+        if b is None:
+            continue
+        base = k.split("<")[0]
+        key = TRAFFIC_KEYS.get(base, base)
+        n = v.get("FETCH_SIZE", {}).get("launches", 0)
+        if key in out and launches[key] >= n:
+            also.append(k)
+            continue
+        if key in out:
+            also.append(owner[key])
+        out[key], owner[key], launches[key] = b, k, n
+    out["kernel_of_key"] = owner
+    if also:
+        out["also_seen"] = also
+    return out
+
+
 def one_workload(src, dst, tag, cfg):
     ks = glob.glob(os.path.join(src, cfg, "stats", "**", "*kernel_stats.csv"), recursive=True)
     avg_ns = {}
@@ -97,11 +131,7 @@ def main(src, dst, tag):
         print(cfg, {k: {c: round(x, 3) for c, x in v.get("derived", {}).items()} for k, v in pmc.items()})
         if cfg == "bench":
             traffic = {"source": f"profiles/{tag}_bench_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"}
-            for k, v in pmc.items():
-                b = v.get("derived", {}).get("hbm_bytes_per_launch")
-                if b is not None:
-                    name = "k_base_logistic_p2" if "k_base_logistic_p2" in k else "k_base_logistic" if "k_base_logistic" in k else "k_smooth_xgb" if "k_smooth_xgb" in k else k
-                    traffic[name] = b
+            traffic.update(traffic_table(pmc))
             # stamp: the kernel sources these counters were collected from (bench.py prints counters.stale when its own differ)
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             from bench import kernel_src_sha16

@@ -748,11 +748,12 @@ def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S
         assert np.array_equal(pf, pr, equal_nan=True), rpl
         assert np.array_equal(lf, lr), rpl
     monkeypatch.delenv("GNX_RK_RPL")
-    # the bit-sliced kernel (k_smooth_xgb_bs: no walks; depth <= 4, other ensembles keep the rank kernel)
-    monkeypatch.setenv("GNX_SMOOTH_IMPL", "bs")
-    pr, lr = ga.DeviceModel(d).smooth_predict(B)
-    assert np.array_equal(pf, pr, equal_nan=True)
-    assert np.array_equal(lf, lr)
+    # the bit-sliced kernel (k_smooth_xgb_bs: no walks; depth <= 4, other ensembles keep the rank kernel) — parked: `make EXPERIMENTS=1`
+    if ga.load_library().gnx_build_flags() & 1:
+        monkeypatch.setenv("GNX_SMOOTH_IMPL", "bs")
+        pr, lr = ga.DeviceModel(d).smooth_predict(B)
+        assert np.array_equal(pf, pr, equal_nan=True)
+        assert np.array_equal(lf, lr)
     finite = np.isfinite(B).all(axis=(1, 2))                                  # oracle as the third opinion
     T = _oracle_trees(oracle, d)
     p_ref, l_ref = oracle.smooth_xgb(T, B[finite], S)
@@ -772,8 +773,12 @@ def test_smooth_rank_kernel_equals_float_kernel(ga, oracle, monkeypatch, W, A, S
 def test_smooth_bitsliced_kernel_equals_rank_kernel(ga, monkeypatch, W, A, S, rounds, depth, drop):
     """k_smooth_xgb_bs (sorted prefixes + bit-sliced node evaluation, gnomix_amd/csrc/k_smooth_xgb_bs.hip) never walks a tree; its
     float32 margins are the same sums in the same order, so probabilities and labels must be BIT-identical to the rank kernel's,
-    whatever the chunking, the number of classes and trees per class, on thresholds hit exactly, NaN and infinities."""
+    whatever the chunking, the number of classes and trees per class, on thresholds hit exactly, NaN and infinities.
+    The kernel is parked (1.73 ms against the walk's 1.60 ms) under scripts/dev/rejected/ and linked by
+    `make -C gnomix_amd/csrc EXPERIMENTS=1` only: in the default build this test is skipped (GNX_SMOOTH_IMPL=bs does nothing there)."""
     from gnomix_amd import synth
+    if not ga.load_library().gnx_build_flags() & 1:
+        pytest.skip("k_smooth_xgb_bs is linked by `make EXPERIMENTS=1` only")
     rng = np.random.RandomState(W * 3 + A)
     d = ga.GnxModelData(C=W * 10 + 3, M=10, A=A, S=S, context=5, smooth_kind="xgb")
     T = synth.synthetic_trees(rounds, A, S * A, depth=depth, seed=W + 1, thr_lo=0.0, thr_hi=1.0, p_early_leaf=0.15)

@@ -500,3 +500,32 @@ def test_forest_from_catboost_json(oracle, A):
                 e = np.exp(raw - raw.max())
                 ref = e / e.sum()
             assert np.allclose(B[n, w], ref, atol=2e-6), (w, n)
+
+
+# ---------------------------------------------------------------- profile summaries -> bench.py's counter fields ----
+def test_traffic_keys_are_exact_kernel_names_and_bench_refuses_impossible_counters():
+    """scripts/summarize_prof.py filed the parked k_smooth_xgb_bs (197 MB per launch) under the rank walk's key and the
+    driver-run line printed it as the dominant kernel's traffic (truth: 591 MB).  Keys are exact kernel names now; bench.py refuses a
+    counter below 0.95 x the kernel's algorithmic bytes."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import importlib
+    sp = importlib.import_module("summarize_prof")
+    import bench
+
+    def k(b, n=3):
+        return {"FETCH_SIZE": {"avg_per_launch": 1.0, "launches": n}, "derived": {"hbm_bytes_per_launch": b}}
+    pmc = {"k_smooth_xgb_rk<3, 8, 4, true, true>": k(590.75e6), "k_smooth_xgb_bs<512>": k(197.4e6), "k_bs_ranks": k(156e6),
+           "k_base_logistic_i8<2, 1, 8, 2>": k(4.62e9), "k_base_logistic_p2<2, 8, 4, 3, 4, 4>": k(1.39e9),
+           "k_smooth_xgb_rk<1, 8, 4, true, true>": k(1e6, n=1), "k_pack2": {"derived": {}}}
+    t = sp.traffic_table(pmc)
+    assert t["k_smooth_xgb"] == 590.75e6 and t["k_smooth_xgb_bs"] == 197.4e6 and t["k_base_logistic"] == 4.62e9
+    assert t["k_base_logistic_p2"] == 1.39e9 and t["kernel_of_key"]["k_smooth_xgb"].startswith("k_smooth_xgb_rk<3")
+    assert t["also_seen"] == ["k_smooth_xgb_rk<1, 8, 4, true, true>"]
+    alg = 21090 * 10000
+    assert bench.checked_traffic(t, "k_smooth_xgb", alg) == (590.75e6, None)
+    val, note = bench.checked_traffic({"k_smooth_xgb": 197.4e6}, "k_smooth_xgb", alg)
+    assert val is None and "below its algorithmic" in note
+    assert bench.checked_traffic({}, "k_smooth_xgb", alg) == (None, None)
+    # the printed line drops explanatory notes (the driver's record keeps ~8 KB) but keeps the roofline's
+    c = bench._compact({"a": {"note": "x" * 500, "v": 1.23456789}, "roofline": {"note": "kept", "frac": 0.3333333}})
+    assert c == {"a": {"v": 1.2346}, "roofline": {"note": "kept", "frac": 0.33333}}
