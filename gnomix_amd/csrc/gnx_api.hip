@@ -645,7 +645,7 @@ static int smooth_raw_dev(gnx_model* m, const void* dB, int b_is_f64, int64_t N,
 
 // ---- packed (2-bit) input: the 2-bit-native logistic pass where the model has its planes, otherwise widen + the int8 kernels ----
 static bool lr_p2_usable(const gnx_model* m) {
-  return m->info.base_kind == GNX_BASE_LOGISTIC && m->lr_i8 && m->lr.V2 && m->ctx->tune.lr_p2 != 0;
+  return m->info.base_kind == GNX_BASE_LOGISTIC && m->lr_i8 && (m->lr.V2 || m->lr.V2F) && m->ctx->tune.lr_p2 != 0;
 }
 
 int gnx_base_predict_packed_dev(gnx_model* m, const uint8_t* dP, int64_t N, int64_t ldp, float* d_b32, double* d_b64) {
@@ -1388,6 +1388,4 @@ int gnx_profile_get(gnx_ctx* ctx, int kid, double* total_ms, int64_t* launches) 
 
 int gnx_pipe_init(gnx_ctx* ctx) { return pipe_init(ctx); }
 bool gnx_gnofix_packed_ok(const gnx_model* m) { return m->info.smooth_kind == GNX_SMOOTH_XGB && gnofix_use_rk(m); }
-bool gnx_lr_p2_usable(const gnx_model* m) {
-  return m->info.base_kind == GNX_BASE_LOGISTIC && m->lr_i8 && m->lr.V2 && m->ctx->tune.lr_p2 != 0;
-}
+bool gnx_lr_p2_usable(const gnx_model* m) { return lr_p2_usable(m); }

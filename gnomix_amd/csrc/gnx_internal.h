@@ -127,7 +127,13 @@ struct BaseLRDev {
   int32_t n_runs = 0;
   int32_t EPR = 0;   // MFMA entries per run of V2: 4 (runs of 256 SNPs, 64 packed bytes per row) or 8 (512 SNPs, 128 bytes)
   int32_t NT2 = 0;   // column tiles of V2: 1 (column = slot * A + class, R * A <= 16) or R (one tile per slot, column = class; A <= 16)
+  // FLAT column tiles of the 2-bit pass for R * A == 24 class columns (A = 12 at the default context): flat column q = 24 * limb + column,
+  // ceil(24 * 7 / 16) = 11 tiles instead of 2 x 7 — 21 % fewer plane bytes and MFMAs, and at 88 accumulator registers per 32 rows both
+  // slots fit one wave, so X is read ONCE (k_base_logistic_p2f); same runs and tables as V2.  NULL: not built.
+  const int8_t* V2F = nullptr;           // [n_runs][EPR entries][11 flat tiles][64 lanes][16 bytes]
 };
+constexpr int GNX_LR_FLAT_COLS = 24;     // class columns per SNP the flat layout is built for
+constexpr int GNX_LR_FLAT_TILES = 11;    // ceil(24 * 7 / 16)
 
 struct BaseLRLaunch {
   const int8_t* X;

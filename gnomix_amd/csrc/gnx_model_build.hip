@@ -268,7 +268,11 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
           const size_t kf = (size_t)(std::lower_bound(bounds.begin(), bounds.end(), fpos[(size_t)i]) - bounds.begin());
           win_run1[(size_t)i] = piece_run0[kf];
         }
-        const size_t entry_bytes = (size_t)NT2 * 7 * 64 * 16;
+        // R * A == 24 class columns: flat column tiles (BaseLRDev::V2F) instead of one tile per slot; GNX_LR_P2_FLAT=0 keeps the slot tiles
+        const char* flat_env = std::getenv("GNX_LR_P2_FLAT");
+        const bool flat = NC == GNX_LR_FLAT_COLS && A <= 16 && EPR == 4 && !(flat_env && std::atoi(flat_env) == 0);
+        const int NTB = flat ? GNX_LR_FLAT_TILES : NT2;  // 1 KB digit blocks per entry: flat tiles, or column tiles x 7 limbs below
+        const size_t entry_bytes = flat ? (size_t)NTB * 64 * 16 : (size_t)NT2 * 7 * 64 * 16;
         std::vector<int8_t> V2(n_runs * (size_t)EPR * entry_bytes, 0);
         auto fill_runs = [&](size_t r_lo, size_t r_hi) {
           std::vector<double> wsum((size_t)A);
@@ -299,11 +303,15 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
                           got = true;
                         }
                       if (!got || acc == 0.0) continue;
-                      const int64_t col = slot * cs2 + a;
+                      const int64_t col = flat ? slot * A + a : slot * cs2 + a;
                       const int nt = (int)(col / 16), c16 = (int)(col % 16);
                       long long q = std::llrint(std::ldexp(acc, fexp[(size_t)i]));
                       for (int l = 0; l < 7; ++l) {
                         const long long dg = (l < 6) ? ((((q + 128) % 256) + 256) % 256) - 128 : q;
+                        if (flat) {  // flat column 24 l + col: tile and lane column of it
+                          const int fq = GNX_LR_FLAT_COLS * l + (int)col;
+                          V2[(((r * (size_t)EPR + (size_t)k) * NTB + (size_t)(fq >> 4)) * 64 + (size_t)(kq * 16 + (fq & 15))) * 16 + (size_t)t] = (int8_t)dg;
+                        } else
                         V2[((((r * (size_t)EPR + (size_t)k) * NT2 + (size_t)nt) * 7 + (size_t)l) * 64 + (size_t)(kq * 16 + c16)) * 16 + (size_t)t] = (int8_t)dg;
                         q = (q - dg) / 256;
                       }
@@ -312,7 +320,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
                 }
         };
         parallel_ranges(n_runs, 64, [&](size_t lo, size_t hi, unsigned) { fill_runs(lo, hi); });
-        if ((rc = gnx_dev_upload(m, V2, &m->lr.V2, 64)) != GNX_OK) return rc;
+        if ((rc = gnx_dev_upload(m, V2, flat ? &m->lr.V2F : &m->lr.V2, 64)) != GNX_OK) return rc;
         if ((rc = gnx_dev_upload(m, run_byte, &m->lr.run_byte)) != GNX_OK) return rc;
         if ((rc = gnx_dev_upload(m, run_flush0, &m->lr.run_flush0)) != GNX_OK) return rc;
         if ((rc = gnx_dev_upload(m, run_nflush, &m->lr.run_nflush)) != GNX_OK) return rc;

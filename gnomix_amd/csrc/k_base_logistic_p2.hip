@@ -447,6 +447,383 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
   return hipGetLastError();
 }
 
+
+// =====================================================================================================================================
+// FLAT column tiles: R * A == 24 class columns per SNP (A = 12 ancestries at the default context, BASELINE config 5).
+//
+// One column tile per slot and one pass per tile (above) multiplies 2 x 7 = 14 tiles per 64 SNPs, a quarter of their columns empty,
+// and reads X twice; every kernel of this family sits on the same ~5-6 TB/s of L1 / LDS-DMA fill traffic, which at
+// config 5a was 30.7 GB of digit planes + 17.9 GB of X per launch.  Here the 24 class columns x 7 limbs are laid side by side as
+// 168 FLAT columns, q = 24 limb + column, in ceil(168 / 16) = 11 tiles: 21 % fewer plane bytes and MFMAs, and 11 x 4 = 44 accumulator
+// registers per 16 rows hold BOTH slots, so a wave of 32 rows carries 88 — the block keeps 256 rows, reads X ONCE, and fits 12
+// waves of <= 168 registers (8 compute, 2 epilogue, 2 loaders; three per SIMD).  Fill per launch: 24.1 + 8.9 GB.
+//
+// Where limb l of column c lives (tile, lane column) = ((24 l + c) >> 4, (24 l + c) & 15) repeats every two limbs (48 columns = 3 tiles):
+//     tile 3k      lanes 0-15: limb 2k   of columns 0-15
+//     tile 3k + 1  lanes 0-7 : limb 2k   of columns 16-23;  lanes 8-15: limb 2k+1 of columns 0-7
+//     tile 3k + 2  lanes 0-15: limb 2k+1 of columns 8-23                                    (k = 0, 1, 2)
+//     tile 9       limb 6 of columns 0-15;   tile 10 lanes 0-7: limb 6 of columns 16-23
+// so the HOME lane of column c (lane c for c < 16, lane c - 16 above) finds its even limbs in its own lane and its odd limbs in the
+// lane 8 away (one row_ror:8 DPP move each), which tile is a lane predicate: six DPP moves and seven selects per accumulator
+// register at a window's end, then the same exact combine() — Z, and with it B, stay BIT-IDENTICAL to the int8 kernels'.
+// A window's end zeroes only its slot's columns (the other slot's window is in mid-flight): lane-predicated moves, tile by tile.
+// =====================================================================================================================================
+constexpr int NFT = GNX_LR_FLAT_TILES;   // 11
+constexpr int NCF = GNX_LR_FLAT_COLS;    // 24
+
+__device__ __forceinline__ int ror8(int v) {  // the value of the lane 8 away within the 16-lane row
+  return __builtin_amdgcn_update_dpp(0, v, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ double combine7(int a0, int a1, int a2, int a3, int a4, int a5, int a6, double scale) {  // combine() on gathered limbs
+  const double lo = __builtin_fma(__builtin_fma((double)a2, 256.0, (double)a1), 256.0, (double)a0);
+  const double hi = __builtin_fma(__builtin_fma(__builtin_fma((double)a6, 256.0, (double)a5), 256.0, (double)a4), 256.0, (double)a3);
+  return (hi * 16777216.0 + lo) * scale;
+}
+
+template <int MT, int CW, int EW, int XSN, int NBUF>
+__global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLRLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int ENTRY_BYTES = NFT * 1024;         // digit planes of one entry (64 k positions): 11 flat tiles
+  constexpr int STEP_BYTES = 2 * ENTRY_BYTES;
+  constexpr int THREADS = (CW + EW + 2) * 64;
+  constexpr int NKB = STEP_BYTES / 1024;          // 22 one-KB loads per step
+  constexpr int D = NBUF - 1;
+  constexpr int ZROWS = MT * 16;
+  constexpr int XTILES = CW * MT;
+  constexpr int SPR = 2;                          // steps per run (256 SNPs = 4 entries)
+  constexpr int RWS = EW ? CW * ZROWS / EW : ZROWS;  // rows one finishing wave handles per window
+  constexpr int CHR = RWS < 64 ? RWS : 64;           // ... in chunks of CHR rows
+  constexpr int NCH = RWS / CHR;
+  static_assert((D - 1) * NKB < 64 && (XSN - 1) * XTILES < 64 && XSN >= 1 && D >= 1, "vmcnt is a 6-bit counter");
+  static_assert(64 % CHR == 0 && RWS % CHR == 0 && (!EW || (CW * ZROWS) % EW == 0), "an epilogue wave takes whole chunks of rows");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int A = L.A, W = L.W, R = L.d.R;
+  uint8_t* vbuf = lds;                                               // [NBUF][STEP_BYTES]
+  uint8_t* xl0 = vbuf + (size_t)NBUF * STEP_BYTES;                   // [XSN][CW][MT][64 lanes][16 B]
+  double* zq = reinterpret_cast<double*>(xl0 + (size_t)XSN * XTILES * 1024);  // [2][CW * ZROWS][A] parked logits
+  double* tab_ic = zq + (size_t)2 * CW * ZROWS * A;   // [max_wins][A] intercepts
+  double* tab_sc = tab_ic + (size_t)L.max_wins * A;    // [max_wins] 2^-f_w
+  int* tab_rb = reinterpret_cast<int*>(tab_sc + L.max_wins);
+  int* tab_nfl = tab_rb + L.max_chunks;
+  int* tab_fl0 = tab_nfl + L.max_chunks;
+  int* tab_gap = tab_fl0 + L.max_chunks;  // runs until the next run that ends a window (0: none follows)
+
+  int wrange, htile;
+  {  // all blocks of one window range on ONE XCD (its L2 serves the range's digit planes)
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int g = j / L.n_htiles;
+    htile = j - g * L.n_htiles;
+    wrange = xcd + 8 * g;
+  }
+  const int wa = wrange * L.wch;
+  if (wa >= W) return;  // whole block exits before any barrier
+  const int wb = min(W, wa + L.wch);
+  const int r_begin = L.d.win_run0[wa];
+  const int r_end = L.d.win_run1[wb - 1];
+  const int n_runs = r_end - r_begin;
+  const int n_steps = SPR * n_runs;
+  const int64_t n0b = (int64_t)htile * (CW * MT * 16);
+
+  for (int e = tid; e < n_runs; e += THREADS) {
+    tab_rb[e] = L.d.run_byte[r_begin + e];
+    tab_nfl[e] = L.d.run_nflush[r_begin + e];
+    tab_fl0[e] = L.d.run_flush0[r_begin + e];
+  }
+  const int wt0 = max(0, wa - R - 1);
+  for (int e = tid; e < L.max_wins * A; e += THREADS) {
+    const int ew = e / A, a = e - ew * A;
+    tab_ic[e] = L.d.icpt[min(wt0 + ew, W - 1) * A + a];
+  }
+  for (int e = tid; e < L.max_wins; e += THREADS) tab_sc[e] = L.d.wscale[min(wt0 + e, W - 1)];
+  __syncthreads();
+  if (tid == 0) {
+    int next = -1;
+    for (int r = n_runs - 1; r >= 0; --r) {
+      tab_gap[r] = next < 0 ? 0 : next - r;
+      if (tab_nfl[r] > 0) next = r;
+    }
+  }
+  __syncthreads();
+  const int abl = L.flags;  // GNX_LR_FLAGS (timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes, 32 no barriers / stores, 64 no combine
+  const bool nobar = (abl & 32) != 0;
+
+  if (wave == CW + EW) {
+    // ================================================== plane loader ==================================================
+    const int8_t* vsrc = L.d.V2F + (size_t)r_begin * 4 * ENTRY_BYTES + (size_t)lane * 16;
+    auto issue_planes = [&](int step) {
+      if (abl & 16) return;
+      const int8_t* src = vsrc + (size_t)min(step, n_steps - 1) * STEP_BYTES;   // a step's 22 KB are contiguous
+      uint8_t* vdst = vbuf + (size_t)(step % NBUF) * STEP_BYTES;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kb * 1024), (lptr_t)(vdst + (size_t)kb * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < D; ++p) issue_planes(p);
+    for (int s = 0; s < n_steps; ++s) {
+      wait_vm<(D - 1) * NKB>();
+      if (!nobar) __builtin_amdgcn_s_barrier();
+      issue_planes(s + D);
+    }
+    wait_vm<0>();
+    if (EW && !nobar) __builtin_amdgcn_s_barrier();
+    return;
+  }
+  if (wave == CW + EW + 1) {
+    // ================================================== X loader ==================================================
+    const uint8_t* xrow[XTILES];
+#pragma unroll
+    for (int t = 0; t < XTILES; ++t) {
+      const int64_t n = n0b + t * 16 + i16;  // rows >= N-1 read the zero-padded copy of the last row (rows past N are never written)
+      xrow[t] = (n >= L.N - 1 ? reinterpret_cast<const uint8_t*>(L.last_row) : reinterpret_cast<const uint8_t*>(L.X) + n * L.ldx) + 16 * kq;
+    }
+    auto issue_x = [&](int run) {
+      if (abl & 8) return;
+      const int rb = tab_rb[min(run, n_runs - 1)];
+      uint8_t* dst = xl0 + (size_t)(run % XSN) * (XTILES * 1024);
+#pragma unroll
+      for (int t = 0; t < XTILES; ++t) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[t] + rb), (lptr_t)(dst + t * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < XSN; ++p) issue_x(p);
+    for (int r = 0; r < n_runs; ++r) {
+      wait_vm<(XSN - 1) * XTILES>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!nobar) __builtin_amdgcn_s_barrier();   // first step of the run
+      if (!nobar) __builtin_amdgcn_s_barrier();   // second step: every compute wave has X(r) in registers
+      issue_x(r + XSN);
+    }
+    wait_vm<0>();
+    if (EW && !nobar) __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // ---- finishing `rows` (<= 64) rows x A classes parked at zr0: arithmetic and class order of k_base_logistic_i8 (bit-identical B) ----
+  const int e_r0 = lane / A, e_a0 = lane - e_r0 * A, e_dr = 64 / A, e_da = 64 - e_dr * A;
+  auto phase1 = [&](double* zr0, int w, int it0, int it1, int rows) {
+    if (abl & 1) return;
+    const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
+    double* zr = zr0 + frow * A;
+    const double* ic = tab_ic + (w - wt0) * A;
+    for (int it = it0; it < it1; ++it) {
+      const int a = fsub + it * lpr;
+      if (a < A) zr[a] = 1.0 / (1.0 + gnx_exp_sc(-(zr[a] + ic[a])));
+    }
+  };
+  auto finish = [&](double* zr0, int w, int64_t nrow0, int rows) {
+    if (!(abl & 1)) {
+      const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
+      double* zr = zr0 + frow * A;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double sum = 0.0;
+      for (int c = 0; c < A; ++c) sum += zr[c];
+      for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] / sum;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    int rl = e_r0, a = e_a0;
+    const size_t ow = (size_t)w * A;
+    for (int e = lane; e < rows * A; e += 64) {
+      const int64_t n = nrow0 + rl;
+      if (n < L.N && !(abl & 32)) {
+        const size_t o = (size_t)n * W * A + ow + a;
+        const double v = zr0[e];
+        if (L.b64) L.b64[o] = v;
+        if (L.b32) L.b32[o] = (float)v;
+      }
+      a += e_da; rl += e_dr;
+      if (a >= A) { a -= A; ++rl; }
+    }
+  };
+
+  if (EW && wave >= CW) {
+    // ================================================== epilogue waves ==================================================
+    // A window parked at the end of run r has 2 * gap steps until the next window ends; its RWS rows are NCH chunks of CHR rows,
+    // a chunk is n_it phase-1 iterations + one finish: NCH (n_it + 1) units, dealt evenly over the steps.
+    const int ew = wave - CW;
+    const int64_t nrow0 = n0b + (int64_t)ew * RWS;
+    const int n_it = (A + 64 / CHR - 1) / (64 / CHR);
+    const int n_units = NCH * (n_it + 1);
+    int parked = 0;
+    bool job = false;
+    int job_w = 0, job_step = 0, job_nst = 0, job_unit = 0;
+    double* job_z = nullptr;
+    auto run_units = [&](int u_end) {
+      for (; job_unit < u_end; ++job_unit) {
+        const int ch = job_unit / (n_it + 1), it = job_unit - ch * (n_it + 1);
+        double* z = job_z + (size_t)ch * CHR * A;
+        if (it < n_it) phase1(z, job_w, it, it + 1, CHR);
+        else finish(z, job_w, nrow0 + ch * CHR, CHR);
+      }
+    };
+    auto job_work = [&]() {
+      if (!job) return;
+      ++job_step;
+      run_units(job_step >= job_nst ? n_units : (int)((int64_t)n_units * job_step / job_nst));
+      if (job_step >= job_nst) job = false;
+    };
+    for (int r = 0; r < n_runs; ++r) {
+#pragma unroll
+      for (int h = 0; h < SPR; ++h) {
+        lds_barrier(nobar);
+        job_work();
+      }
+      const int nfl = (abl & 4) ? 0 : tab_nfl[r];
+      if (nfl == 1) {
+        const int w = tab_fl0[r];
+        if (w >= wa && w < wb) {
+          job = true;
+          job_w = w;
+          job_step = 0;
+          job_unit = 0;
+          job_nst = SPR * (tab_gap[r] > 0 ? tab_gap[r] : n_runs - 1 - r);  // 0 (last run): after the trailing barrier
+          job_z = zq + (size_t)(parked & 1) * (CW * ZROWS * A) + (size_t)ew * RWS * A;
+          ++parked;
+        }
+      }
+    }
+    lds_barrier(nobar);  // trailing barrier: the last run's windows are parked
+    if (job) run_units(n_units);
+    return;
+  }
+
+  // ================================================== compute waves ==================================================
+  const int64_t n0 = n0b + (int64_t)wave * (MT * 16);
+  v4i acc[MT][NFT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NFT; ++t) acc[mt][t] = v4i{0, 0, 0, 0};
+
+  auto mfma_entry = [&](const uint8_t* pb, const v4i (&xc)[MT], int k) {
+    if (abl & 2) return;
+    v4i xa[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xc[mt][k]);
+    const v4i* vb = reinterpret_cast<const v4i*>(pb) + lane;
+#pragma unroll
+    for (int t = 0; t < NFT; ++t) {
+      const v4i b = vb[t * 64];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][t], 0, 0, 0);
+    }
+  };
+
+  int parked = 0;
+  auto flush = [&](int rl) {
+    const int nfl = tab_nfl[rl];
+    if (nfl <= 0 || (abl & 4)) return;
+    const int w0 = tab_fl0[rl];
+    for (int w = w0; w < w0 + nfl; ++w) {
+      const int c0 = (w % R) * A;                  // the window's slot: flat class columns [c0, c0 + A)
+      const double scale = tab_sc[w - wt0];
+      const bool out = w >= wa && w < wb;
+      double* zw = zq + (size_t)(parked & 1) * (CW * ZROWS * A) + (size_t)wave * ZROWS * A;
+      // this lane as the HOME of one column of the slot: column i16 (< 16) or column i16 + 16 (lanes 0-7); never both (A <= 16)
+      const bool in_hi = i16 < 8 && i16 + 16 >= c0 && i16 + 16 < c0 + A;
+      const bool in_lo = i16 >= c0 && i16 < c0 + A;
+      const int col = in_hi ? i16 + 16 : i16;
+      const bool home = in_lo || in_hi;
+      const bool lo8 = col < 8;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (out && !(abl & 64)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {  // int32 16x16 C/D layout: column = lane & 15, row = 4 (lane >> 4) + reg
+            int ev[3], od[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const int x1 = ror8(acc[mt][3 * k + 1][r]), x2 = ror8(acc[mt][3 * k + 2][r]);
+              ev[k] = in_hi ? acc[mt][3 * k + 1][r] : acc[mt][3 * k][r];
+              od[k] = lo8 ? x1 : x2;
+            }
+            const int l6 = in_hi ? acc[mt][10][r] : acc[mt][9][r];
+            const double z = combine7(ev[0], od[0], ev[1], od[1], ev[2], od[2], l6, scale);
+            if (home) zw[(mt * 16 + 4 * kq + r) * A + (col - c0)] = z;
+          }
+        }
+        // zero the slot's columns: lane column i16 of tile t is flat column q = 16 t + i16 = 24 limb + column
+#pragma unroll
+        for (int t = 0; t < NFT; ++t) {
+          constexpr int dummy = 0; (void)dummy;
+          const int off = (16 * t) % NCF;                 // compile-time after unrolling
+          int c = off + i16;
+          c = c >= NCF ? c - NCF : c;
+          const bool z0 = c >= c0 && c < c0 + A && (16 * t + i16 < NCF * LIMBS);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][t][r] = z0 ? 0 : acc[mt][t][r];
+        }
+      }
+      if (!out) continue;
+      if (EW && nfl == 1) {
+        ++parked;  // an epilogue wave takes it from here (after the next barrier)
+      } else {     // several windows end at once (chromosome ends, wide contexts), or no epilogue waves: finish it here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        phase1(zw, w, 0, (A + 64 / ZROWS - 1) / (64 / ZROWS), ZROWS);
+        finish(zw, w, n0, ZROWS);
+      }
+    }
+  };
+
+  for (int r = 0; r < n_runs; ++r) {
+    v4i xc[MT];
+#pragma unroll
+    for (int h = 0; h < SPR; ++h) {
+      lds_barrier(nobar);  // step SPR r + h: its planes (and, at h = 0, X(r)) are in LDS
+      if (h == 0) {
+        const uint8_t* xs = xl0 + (size_t)(r % XSN) * (XTILES * 1024) + (size_t)wave * (MT * 1024);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xc[mt] = *reinterpret_cast<const v4i*>(xs + mt * 1024 + lane * 16);
+      }
+      const uint8_t* sb = vbuf + (size_t)((SPR * r + h) % NBUF) * STEP_BYTES;
+      mfma_entry(sb, xc, 2 * h);
+      mfma_entry(sb + ENTRY_BYTES, xc, 2 * h + 1);
+    }
+    flush(r);
+  }
+  if (EW) lds_barrier(nobar);  // trailing barrier: the last run's parked windows become visible to the epilogue waves
+}
+
+template <int MT, int CW, int EW, int XSN, int NBUF>
+hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
+  BaseLRLaunch P = L;
+  P.flags = tune.lr_flags;
+  const int haps_per_block = CW * MT * 16;
+  const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
+  const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : 4;
+  int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
+  want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
+  if (tune.lr_want > 0) want = tune.lr_want;
+  int wch = 0, n_ranges = 0;
+  size_t lds = 0;
+  for (;; want += 8) {
+    wch = (int)((L.W + want - 1) / want);
+    if (wch < 4) wch = 4;
+    n_ranges = (L.W + wch - 1) / wch;
+    int max_runs = 0;
+    for (int r = 0; r < n_ranges; ++r) {
+      const int wa = r * wch, wb = std::min(L.W, wa + wch);
+      max_runs = std::max(max_runs, L.h_win_chunk1[(size_t)wb - 1] - L.h_win_chunk0[(size_t)wa]);
+    }
+    P.max_chunks = max_runs + 8;
+    P.max_wins = wch + 2 * L.d.R + 4;
+    lds = (size_t)NBUF * (2 * NFT * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)2 * CW * MT * 16 * L.A * sizeof(double) +
+          (size_t)4 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
+    if (lds <= (size_t)160 * 1024 || wch == 4) break;
+  }
+  if (lds > (size_t)160 * 1024) return hipErrorNotSupported;
+  const int n_ranges8 = ((n_ranges + 7) / 8) * 8;
+  P.wch = wch;
+  P.n_htiles = (int)gx;
+  P.n_rg8 = n_ranges8 / 8;
+  if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2f<%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d\n", MT, CW, EW, XSN, NBUF, lds, (long long)(gx * n_ranges8), wch);
+  GNX_LDS_OPTIN(lds, k_base_logistic_p2f<MT, CW, EW, XSN, NBUF>);
+  hipLaunchKernelGGL((k_base_logistic_p2f<MT, CW, EW, XSN, NBUF>), dim3((unsigned)(gx * n_ranges8)), dim3((CW + EW + 2) * 64), lds, s, P);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 // L.X = packed matrix (gnx_pack_x layout), L.ldx = its row stride in bytes, L.last_row = zero-padded copy of packed row N-1,
@@ -454,6 +831,17 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
 // instantiation fits (the caller widens X to int8 and runs the int8 kernels).
 hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   if (L.N <= 0) return hipSuccess;
+  if (L.d.V2F && L.d.EPR == 4 && L.d.R * L.A == NCF && L.h_win_chunk0 && L.h_win_chunk1) {
+    // flat column tiles (24 class columns): 256 rows per block, X read once; the deepest configuration that fits the LDS
+    // (GNX_P2_TUNE = "2,8,2,xsn,nbuf" picks the depth: development)
+    const int tx = tune.p2_xsn, tb = tune.p2_nbuf;
+    if (tune.p2_mt == 2 && tx == 1 && tb == 3) return launch_flat<2, 8, 2, 1, 3>(L, n_cu, tune, s);
+    if (tune.p2_mt == 2 && tx == 3 && tb == 2) return launch_flat<2, 8, 2, 3, 2>(L, n_cu, tune, s);
+    hipError_t e = launch_flat<2, 8, 2, 2, 3>(L, n_cu, tune, s);
+    if (e == hipErrorNotSupported) e = launch_flat<2, 8, 2, 1, 3>(L, n_cu, tune, s);
+    if (e == hipErrorNotSupported) e = launch_flat<2, 8, 2, 2, 2>(L, n_cu, tune, s);
+    return e;
+  }
   if (!L.d.V2 || L.d.NT2 < 1 || (L.d.EPR != 4 && L.d.EPR != 8) || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
   const bool small = L.N <= 64 * 4;
   const int tm = tune.p2_mt, tw = tune.p2_cw, te = tune.p2_ew, tx = tune.p2_xsn, tb = tune.p2_nbuf ? tune.p2_nbuf : 3;
