@@ -150,6 +150,7 @@ struct BaseLRLaunch {
   int32_t max_wins;     // i8 path: upper bound of windows one block may flush
   float* b32;
   double* b64;
+  unsigned long long* dbg = nullptr;  // development (GNX_DEBUG & 2, k_base_logistic_p2f): per block 16 cycle counters (where the waves' time goes)
 };
 
 // ---- xgb smoother (k_smooth_xgb.hip) ----------------------------------------------------------------

@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "gnx_internal.h"
 #include "gnx_exp.h"
@@ -481,7 +482,7 @@ __device__ __forceinline__ double combine7(int a0, int a1, int a2, int a3, int a
   return (hi * 16777216.0 + lo) * scale;
 }
 
-template <int MT, int CW, int EW, int XSN, int NBUF>
+template <int MT, int CW, int EW, int XSN, int NBUF, bool DBG>
 __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLRLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int ENTRY_BYTES = NFT * 1024;         // digit planes of one entry (64 k positions): 11 flat tiles
@@ -495,7 +496,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   constexpr int RWS = EW ? CW * ZROWS / EW : ZROWS;  // rows one finishing wave handles per window
   constexpr int CHR = RWS < 64 ? RWS : 64;           // ... in chunks of CHR rows
   constexpr int NCH = RWS / CHR;
-  static_assert((D - 1) * NKB < 64 && (XSN - 1) * XTILES < 64 && XSN >= 1 && D >= 1, "vmcnt is a 6-bit counter");
+  static_assert((D - 1) * NKB < 64 && (XSN - 1) * XTILES < 64 && XSN >= 2 && D >= 1, "vmcnt is a 6-bit counter; two X stages at least");
   static_assert(64 % CHR == 0 && RWS % CHR == 0 && (!EW || (CW * ZROWS) % EW == 0), "an epilogue wave takes whole chunks of rows");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, kq = lane >> 4;
@@ -549,6 +550,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   __syncthreads();
   const int abl = L.flags;  // GNX_LR_FLAGS (timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes, 32 no barriers / stores, 64 no combine
   const bool nobar = (abl & 32) != 0;
+  const bool dbg_on = DBG && L.dbg != nullptr;   // development instantiation: cycle counters of wave 0 of every role, 16 per block
+  unsigned long long* dbg = L.dbg + (size_t)blockIdx.x * 16;
 
   if (wave == CW + EW) {
     // ================================================== plane loader ==================================================
@@ -557,19 +560,27 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       if (abl & 16) return;
       const int8_t* src = vsrc + (size_t)min(step, n_steps - 1) * STEP_BYTES;   // a step's 22 KB are contiguous
       uint8_t* vdst = vbuf + (size_t)(step % NBUF) * STEP_BYTES;
+      // (pacing the 22 loads with s_sleep so that the epilogue's stores to B do not queue behind a burst: measured 4 % SLOWER)
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+      for (int kb = 0; kb < NKB; ++kb) {
         __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kb * 1024), (lptr_t)(vdst + (size_t)kb * 1024), 16, 0, 0);
+      }
     };
 #pragma unroll
     for (int p = 0; p < D; ++p) issue_planes(p);
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0;
     for (int s = 0; s < n_steps; ++s) {
+      const unsigned long long t0 = dbg_on ? __builtin_readcyclecounter() : 0;
       wait_vm<(D - 1) * NKB>();
+      const unsigned long long t1 = dbg_on ? __builtin_readcyclecounter() : 0;
       if (!nobar) __builtin_amdgcn_s_barrier();
+      const unsigned long long t2 = dbg_on ? __builtin_readcyclecounter() : 0;
       issue_planes(s + D);
+      if (dbg_on) { c_wait += t1 - t0; c_bar += t2 - t1; c_issue += __builtin_readcyclecounter() - t2; }
     }
     wait_vm<0>();
     if (EW && !nobar) __builtin_amdgcn_s_barrier();
+    if (dbg_on && lane == 0) { dbg[8] = c_wait; dbg[9] = c_bar; dbg[10] = c_issue; }
     return;
   }
   if (wave == CW + EW + 1) {
@@ -585,47 +596,41 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       const int rb = tab_rb[min(run, n_runs - 1)];
       uint8_t* dst = xl0 + (size_t)(run % XSN) * (XTILES * 1024);
 #pragma unroll
-      for (int t = 0; t < XTILES; ++t) __builtin_amdgcn_global_load_lds((gptr_t)(xrow[t] + rb), (lptr_t)(dst + t * 1024), 16, 0, 0);
+      for (int t = 0; t < XTILES; ++t) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(xrow[t] + rb), (lptr_t)(dst + t * 1024), 16, 0, 0);
+      }
     };
+    // the compute waves read HALF of a run's words per step (8 bytes per lane and row tile: four accumulator-free registers), so
+    // stage r % XSN is busy through step 2r + 1 and takes X(r + XSN) only behind the first barrier of run r + 1
 #pragma unroll
-    for (int p = 0; p < XSN; ++p) issue_x(p);
+    for (int p = 0; p + 1 < XSN; ++p) issue_x(p);
     for (int r = 0; r < n_runs; ++r) {
-      wait_vm<(XSN - 1) * XTILES>();
+      wait_vm<(XSN >= 2 ? XSN - 2 : 0) * XTILES>();   // X(r) has landed (only X(r+1) .. X(r+XSN-2) are younger)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!nobar) __builtin_amdgcn_s_barrier();   // first step of the run
-      if (!nobar) __builtin_amdgcn_s_barrier();   // second step: every compute wave has X(r) in registers
-      issue_x(r + XSN);
+      if (!nobar) __builtin_amdgcn_s_barrier();   // first step of the run: every wave is done with run r - 1
+      if (XSN >= 2) issue_x(r + XSN - 1);
+      if (!nobar) __builtin_amdgcn_s_barrier();   // second step
     }
     wait_vm<0>();
     if (EW && !nobar) __builtin_amdgcn_s_barrier();
     return;
   }
 
-  // ---- finishing `rows` (<= 64) rows x A classes parked at zr0: arithmetic and class order of k_base_logistic_i8 (bit-identical B) ----
+  // ---- finishing `rows` (<= 64) rows x A classes parked at zr0: arithmetic and class order of k_base_logistic_i8 (bit-identical B).
+  // A finishing wave is ONE in-order instruction stream: a sigmoid is a chain of ~40 dependent float64 operations, so a lane works
+  // on PB classes at once (PB independent chains interleave: gnx_exp_scN) — per element the same operations in the same order ----
+  constexpr int PB = 4;
   const int e_r0 = lane / A, e_a0 = lane - e_r0 * A, e_dr = 64 / A, e_da = 64 - e_dr * A;
-  auto phase1 = [&](double* zr0, int w, int it0, int it1, int rows) {
-    if (abl & 1) return;
-    const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
-    double* zr = zr0 + frow * A;
-    const double* ic = tab_ic + (w - wt0) * A;
-    for (int it = it0; it < it1; ++it) {
-      const int a = fsub + it * lpr;
-      if (a < A) zr[a] = 1.0 / (1.0 + gnx_exp_sc(-(zr[a] + ic[a])));
-    }
-  };
-  auto finish = [&](double* zr0, int w, int64_t nrow0, int rows) {
-    if (!(abl & 1)) {
-      const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
-      double* zr = zr0 + frow * A;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      double sum = 0.0;
-      for (int c = 0; c < A; ++c) sum += zr[c];
-      for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] / sum;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+  // rows x A finished values -> B, 64 consecutive elements per store; iterations [i0, i1) of the ceil(rows A / 64)
+  auto store_rows = [&](const double* zr0, int w, int64_t nrow0, int rows, int i0 = 0, int i1 = 1 << 20) {
     int rl = e_r0, a = e_a0;
+    if (i0 > 0) {
+      rl = (lane + 64 * i0) / A;
+      a = lane + 64 * i0 - rl * A;
+    }
     const size_t ow = (size_t)w * A;
-    for (int e = lane; e < rows * A; e += 64) {
+    const int e_end = min(rows * A, 64 * i1);
+    for (int e = lane + 64 * i0; e < e_end; e += 64) {
       const int64_t n = nrow0 + rl;
       if (n < L.N && !(abl & 32)) {
         const size_t o = (size_t)n * W * A + ow + a;
@@ -637,25 +642,72 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       if (a >= A) { a -= A; ++rl; }
     }
   };
+  auto phase1 = [&](double* zr0, int w, int it0, int it1, int rows) {   // iteration `it` = classes fsub + (PB it + i) lpr, i < PB
+    if (abl & 1) return;
+    const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
+    double* zr = zr0 + frow * A;
+    const double* ic = tab_ic + (w - wt0) * A;
+    for (int it = it0; it < it1; ++it) {
+      double v[PB];
+      int a[PB];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        a[i] = fsub + (PB * it + i) * lpr;
+        const int ac = min(a[i], A - 1);
+        v[i] = -(zr[ac] + ic[ac]);
+      }
+      gnx_exp_scN<PB>(v);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) v[i] = 1.0 / (1.0 + v[i]);
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        if (a[i] < A) zr[a[i]] = v[i];
+    }
+  };
+  auto normalise = [&](double* zr0, int rows) {
+    if (abl & 1) return;
+    const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
+    double* zr = zr0 + frow * A;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double sum = 0.0;
+    for (int c = 0; c < A; ++c) sum += zr[c];
+    for (int a0 = fsub; a0 < A; a0 += PB * lpr) {   // PB independent divisions at a time
+      double q[PB];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) q[i] = zr[min(a0 + i * lpr, A - 1)] / sum;
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        if (a0 + i * lpr < A) zr[a0 + i * lpr] = q[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
 
   if (EW && wave >= CW) {
     // ================================================== epilogue waves ==================================================
     // A window parked at the end of run r has 2 * gap steps until the next window ends; its RWS rows are NCH chunks of CHR rows,
-    // a chunk is n_it phase-1 iterations + one finish: NCH (n_it + 1) units, dealt evenly over the steps.
+    // a chunk is n_it phase-1 iterations + the row normalisation + the stores in NSP parts: NCH (n_it + 1 + NSP) units, dealt evenly over the steps.
     const int ew = wave - CW;
     const int64_t nrow0 = n0b + (int64_t)ew * RWS;
-    const int n_it = (A + 64 / CHR - 1) / (64 / CHR);
-    const int n_units = NCH * (n_it + 1);
+    // the epilogue waves are the youngest waves of their SIMDs and lose the VALU arbitration (priority, then age) to the compute waves
+    // beside them: their float64 chains would get the left-over issue slots and every wave of the block would wait for them at the
+    // step's barrier.  Their work is short; let it go first.
+    if (!(abl & 128)) __builtin_amdgcn_s_setprio(2);   // (GNX_LR_FLAGS & 128: without, for A/B timing)
+    const int n_it = (A + PB * (64 / CHR) - 1) / (PB * (64 / CHR));   // phase-1 iterations of a lane: PB classes each
+    constexpr int NSP = 4;                                             // the stores of a chunk in NSP parts
+    const int n_sti = (CHR * A + 63) / 64, sti_part = (n_sti + NSP - 1) / NSP;
+    const int upc = n_it + 1 + NSP;                                    // units per chunk
+    const int n_units = NCH * upc;
     int parked = 0;
     bool job = false;
     int job_w = 0, job_step = 0, job_nst = 0, job_unit = 0;
     double* job_z = nullptr;
     auto run_units = [&](int u_end) {
       for (; job_unit < u_end; ++job_unit) {
-        const int ch = job_unit / (n_it + 1), it = job_unit - ch * (n_it + 1);
+        const int ch = job_unit / upc, it = job_unit - ch * upc;
         double* z = job_z + (size_t)ch * CHR * A;
         if (it < n_it) phase1(z, job_w, it, it + 1, CHR);
-        else finish(z, job_w, nrow0 + ch * CHR, CHR);
+        else if (it == n_it) normalise(z, CHR);
+        else store_rows(z, job_w, nrow0 + ch * CHR, CHR, (it - n_it - 1) * sti_part, (it - n_it) * sti_part);
       }
     };
     auto job_work = [&]() {
@@ -664,11 +716,18 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       run_units(job_step >= job_nst ? n_units : (int)((int64_t)n_units * job_step / job_nst));
       if (job_step >= job_nst) job = false;
     };
+    unsigned long long c_bar = 0, c_work = 0, c_max = 0;
     for (int r = 0; r < n_runs; ++r) {
 #pragma unroll
       for (int h = 0; h < SPR; ++h) {
+        const unsigned long long t0 = dbg_on ? __builtin_readcyclecounter() : 0;
         lds_barrier(nobar);
+        const unsigned long long t1 = dbg_on ? __builtin_readcyclecounter() : 0;
         job_work();
+        if (dbg_on) {
+          const unsigned long long t2 = __builtin_readcyclecounter();
+          c_bar += t1 - t0; c_work += t2 - t1; c_max = t2 - t1 > c_max ? t2 - t1 : c_max;
+        }
       }
       const int nfl = (abl & 4) ? 0 : tab_nfl[r];
       if (nfl == 1) {
@@ -686,6 +745,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     }
     lds_barrier(nobar);  // trailing barrier: the last run's windows are parked
     if (job) run_units(n_units);
+    if (dbg_on && lane == 0 && ew == 0) { dbg[4] = c_bar; dbg[5] = c_work; dbg[6] = c_max; dbg[7] = (unsigned long long)n_steps; }
     return;
   }
 
@@ -697,24 +757,43 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
 #pragma unroll
     for (int t = 0; t < NFT; ++t) acc[mt][t] = v4i{0, 0, 0, 0};
 
-  auto mfma_entry = [&](const uint8_t* pb, const v4i (&xc)[MT], int k) {
+  // one entry = 11 flat tiles x MT row tiles; the digit planes of tile t + 1 are on their way from LDS while tile t multiplies
+  // (hipcc, left alone, read two tiles, waited for both, multiplied, read the next two: the matrix pipe idled for an LDS round trip
+  // every four MFMAs)
+  auto mfma_entry = [&](const uint8_t* pb, const int (&xw)[MT]) {
     if (abl & 2) return;
     v4i xa[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xc[mt][k]);
+    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xw[mt]);
     const v4i* vb = reinterpret_cast<const v4i*>(pb) + lane;
+    v4i b = vb[0];
 #pragma unroll
     for (int t = 0; t < NFT; ++t) {
-      const v4i b = vb[t * 64];
+      v4i bn = b;
+      if (t + 1 < NFT) bn = vb[(t + 1) * 64];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][t], 0, 0, 0);
+      b = bn;
     }
+    // the order above, pinned for the machine scheduler: read (tile 0), then [read (tile t + 1), MT MFMAs (tile t)] ...
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int t = 0; t + 1 < NFT; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);  // MT MFMAs
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
   };
 
   int parked = 0;
   auto flush = [&](int rl) {
     const int nfl = tab_nfl[rl];
     if (nfl <= 0 || (abl & 4)) return;
+    // the lane's column / row group as the optimiser cannot see through: everything derived from them below (predicates, the LDS
+    // addresses of the parked logits) would otherwise be hoisted out of the run loop into a dozen registers held beside the
+    // 88 accumulators for the whole kernel — recomputing them once per window costs nothing
+    int i16 = lane & 15, kq = lane >> 4;
+    asm volatile("" : "+v"(i16), "+v"(kq));
     const int w0 = tab_fl0[rl];
     for (int w = w0; w < w0 + nfl; ++w) {
       const int c0 = (w % R) * A;                  // the window's slot: flat class columns [c0, c0 + A)
@@ -742,6 +821,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
             const int l6 = in_hi ? acc[mt][10][r] : acc[mt][9][r];
             const double z = combine7(ev[0], od[0], ev[1], od[1], ev[2], od[2], l6, scale);
             if (home) zw[(mt * 16 + 4 * kq + r) * A + (col - c0)] = z;
+            __builtin_amdgcn_sched_barrier(0);  // one register's gather at a time: the accumulators leave no room for four in flight
           }
         }
         // zero the slot's columns: lane column i16 of tile t is flat column q = 16 t + i16 = 24 limb + column
@@ -760,34 +840,57 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       if (EW && nfl == 1) {
         ++parked;  // an epilogue wave takes it from here (after the next barrier)
       } else {     // several windows end at once (chromosome ends, wide contexts), or no epilogue waves: finish it here
+        // (a rare path — never at the default context — kept narrow: one class at a time, no batch temporaries beside the accumulators)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        phase1(zw, w, 0, (A + 64 / ZROWS - 1) / (64 / ZROWS), ZROWS);
-        finish(zw, w, n0, ZROWS);
+        if (!(abl & 1)) {
+          const int lpr = 64 / ZROWS, frow = lane % ZROWS, fsub = lane / ZROWS;
+          double* zr = zw + frow * A;
+          const double* ic = tab_ic + (w - wt0) * A;
+          for (int a = fsub; a < A; a += lpr) zr[a] = 1.0 / (1.0 + gnx_exp_sc(-(zr[a] + ic[a])));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          double sum = 0.0;
+          for (int c = 0; c < A; ++c) sum += zr[c];
+          for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] / sum;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        store_rows(zw, w, n0, ZROWS);
       }
     }
   };
 
+  unsigned long long c_bar = 0, c_mm = 0, c_fl = 0, t_begin = dbg_on ? __builtin_readcyclecounter() : 0;
+  typedef int v2i __attribute__((ext_vector_type(2)));
   for (int r = 0; r < n_runs; ++r) {
-    v4i xc[MT];
 #pragma unroll
     for (int h = 0; h < SPR; ++h) {
+      const unsigned long long t0 = dbg_on ? __builtin_readcyclecounter() : 0;
       lds_barrier(nobar);  // step SPR r + h: its planes (and, at h = 0, X(r)) are in LDS
-      if (h == 0) {
-        const uint8_t* xs = xl0 + (size_t)(r % XSN) * (XTILES * 1024) + (size_t)wave * (MT * 1024);
+      const unsigned long long t1 = dbg_on ? __builtin_readcyclecounter() : 0;
+      // words 2h, 2h + 1 of the lane's 16 packed bytes of run r: the two entries of this step
+      const uint8_t* xs = xl0 + (size_t)(r % XSN) * (XTILES * 1024) + (size_t)wave * (MT * 1024) + lane * 16 + 8 * h;
+      int x0[MT], x1[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xc[mt] = *reinterpret_cast<const v4i*>(xs + mt * 1024 + lane * 16);
+      for (int mt = 0; mt < MT; ++mt) {
+        const v2i q = *reinterpret_cast<const v2i*>(xs + mt * 1024);
+        x0[mt] = q[0];
+        x1[mt] = q[1];
       }
       const uint8_t* sb = vbuf + (size_t)((SPR * r + h) % NBUF) * STEP_BYTES;
-      mfma_entry(sb, xc, 2 * h);
-      mfma_entry(sb + ENTRY_BYTES, xc, 2 * h + 1);
+      mfma_entry(sb, x0);
+      mfma_entry(sb + ENTRY_BYTES, x1);
+      if (dbg_on) { c_bar += t1 - t0; c_mm += __builtin_readcyclecounter() - t1; }
     }
+    const unsigned long long t2 = dbg_on ? __builtin_readcyclecounter() : 0;
     flush(r);
+    if (dbg_on) c_fl += __builtin_readcyclecounter() - t2;
   }
   if (EW) lds_barrier(nobar);  // trailing barrier: the last run's parked windows become visible to the epilogue waves
+  if (dbg_on && lane == 0 && wave == 0) { dbg[0] = c_bar; dbg[1] = c_mm; dbg[2] = c_fl; dbg[3] = __builtin_readcyclecounter() - t_begin; }
 }
 
 template <int MT, int CW, int EW, int XSN, int NBUF>
 hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
+  constexpr bool NODBG = false;
   BaseLRLaunch P = L;
   P.flags = tune.lr_flags;
   const int haps_per_block = CW * MT * 16;
@@ -819,9 +922,36 @@ hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hi
   P.n_htiles = (int)gx;
   P.n_rg8 = n_ranges8 / 8;
   if (tune.debug) std::fprintf(stderr, "k_base_logistic_p2f<%d,%d,%d,%d,%d>: lds=%zu grid=%lld wch=%d\n", MT, CW, EW, XSN, NBUF, lds, (long long)(gx * n_ranges8), wch);
-  GNX_LDS_OPTIN(lds, k_base_logistic_p2f<MT, CW, EW, XSN, NBUF>);
-  hipLaunchKernelGGL((k_base_logistic_p2f<MT, CW, EW, XSN, NBUF>), dim3((unsigned)(gx * n_ranges8)), dim3((CW + EW + 2) * 64), lds, s, P);
-  return hipGetLastError();
+  const size_t nblk = (size_t)(gx * n_ranges8);
+  if (!(tune.debug & 2)) {
+    GNX_LDS_OPTIN(lds, k_base_logistic_p2f<MT, CW, EW, XSN, NBUF, NODBG>);
+    hipLaunchKernelGGL((k_base_logistic_p2f<MT, CW, EW, XSN, NBUF, NODBG>), dim3((unsigned)nblk), dim3((CW + EW + 2) * 64), lds, s, P);
+    return hipGetLastError();
+  }
+  // GNX_DEBUG & 2 (development): the instrumented instantiation — where the waves' cycles go; synchronous, never on a production path
+  GNX_LDS_OPTIN(lds, k_base_logistic_p2f<MT, CW, EW, XSN, NBUF, true>);
+  if (hipMalloc(&P.dbg, nblk * 16 * sizeof(unsigned long long)) != hipSuccess) P.dbg = nullptr;
+  if (P.dbg) (void)hipMemsetAsync(P.dbg, 0, nblk * 16 * sizeof(unsigned long long), s);
+  hipLaunchKernelGGL((k_base_logistic_p2f<MT, CW, EW, XSN, NBUF, true>), dim3((unsigned)nblk), dim3((CW + EW + 2) * 64), lds, s, P);
+  hipError_t err = hipGetLastError();
+  if (P.dbg) {
+    std::vector<unsigned long long> h(nblk * 16);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), P.dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(P.dbg);
+    double sum[16] = {0};
+    size_t live = 0;
+    for (size_t b = 0; b < nblk; ++b) {
+      if (!h[b * 16 + 3]) continue;
+      ++live;
+      for (int k = 0; k < 16; ++k) sum[k] += (double)h[b * 16 + (size_t)k];
+    }
+    const double st = sum[7] > 0 ? sum[7] : 1;
+    std::fprintf(stderr, "p2f cycles per step (mean of %zu blocks, %.0f steps each): compute wave0: barrier %.0f mfma %.0f flush %.0f total %.0f | epilogue wave0: barrier %.0f "
+                 "work %.0f (longest step %.0f) | plane loader: wait %.0f barrier %.0f issue %.0f\n", live, st / (live ? live : 1), sum[0] / st, sum[1] / st, sum[2] / st, sum[3] / st,
+                 sum[4] / st, sum[5] / st, sum[6] / (live ? live : 1), sum[8] / st, sum[9] / st, sum[10] / st);
+  }
+  return err;
 }
 
 }  // namespace
@@ -835,11 +965,10 @@ hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gn
     // flat column tiles (24 class columns): 256 rows per block, X read once; the deepest configuration that fits the LDS
     // (GNX_P2_TUNE = "2,8,2,xsn,nbuf" picks the depth: development)
     const int tx = tune.p2_xsn, tb = tune.p2_nbuf;
-    if (tune.p2_mt == 2 && tx == 1 && tb == 3) return launch_flat<2, 8, 2, 1, 3>(L, n_cu, tune, s);
-    if (tune.p2_mt == 2 && tx == 3 && tb == 2) return launch_flat<2, 8, 2, 3, 2>(L, n_cu, tune, s);
-    hipError_t e = launch_flat<2, 8, 2, 2, 3>(L, n_cu, tune, s);
-    if (e == hipErrorNotSupported) e = launch_flat<2, 8, 2, 1, 3>(L, n_cu, tune, s);
-    if (e == hipErrorNotSupported) e = launch_flat<2, 8, 2, 2, 2>(L, n_cu, tune, s);
+    (void)tx; (void)tb;
+    if (tune.p2_ew == 2) return launch_flat<2, 8, 2, 2, 3>(L, n_cu, tune, s);
+    hipError_t e = launch_flat<2, 8, 4, 2, 3>(L, n_cu, tune, s);
+    if (e == hipErrorNotSupported) e = launch_flat<2, 8, 4, 2, 2>(L, n_cu, tune, s);
     return e;
   }
   if (!L.d.V2 || L.d.NT2 < 1 || (L.d.EPR != 4 && L.d.EPR != 8) || !L.h_win_chunk0 || !L.h_win_chunk1) return hipErrorNotSupported;
