@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "gnx_internal.h"
@@ -619,10 +620,34 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   // ---- finishing `rows` (<= 64) rows x A classes parked at zr0: arithmetic and class order of k_base_logistic_i8 (bit-identical B).
   // A finishing wave is ONE in-order instruction stream: a sigmoid is a chain of ~40 dependent float64 operations, so a lane works
   // on PB classes at once (PB independent chains interleave: gnx_exp_scN) — per element the same operations in the same order ----
-  constexpr int PB = 4;
+  constexpr int PB = EW ? 4 : 3;   // (self-service, 32 rows per wave: two lanes per row, six classes each at A = 12 = two rounds of three)
   const int e_r0 = lane / A, e_a0 = lane - e_r0 * A, e_dr = 64 / A, e_da = 64 - e_dr * A;
   // rows x A finished values -> B, 64 consecutive elements per store; iterations [i0, i1) of the ceil(rows A / 64)
+  // (a store to B waits ~800 cycles at issue behind the loaders' traffic — the L1's queue is full by design: with an even number of
+  // classes a lane stores TWO consecutive values of a row, 1 KB per float64 instruction, and every iteration counts double)
+  const bool wide_st = (A & 1) == 0 && ((reinterpret_cast<uintptr_t>(L.b64) & 15) | (reinterpret_cast<uintptr_t>(L.b32) & 7)) == 0;
+  const int spi = wide_st ? 128 : 64;   // values per store instruction: the iteration ranges below count in these
   auto store_rows = [&](const double* zr0, int w, int64_t nrow0, int rows, int i0 = 0, int i1 = 1 << 20) {
+    if (wide_st) {
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const int d_r = 128 / A, d_a = 128 - d_r * A;
+      int rl = (2 * lane + 128 * i0) / A, a = 2 * lane + 128 * i0 - rl * A;
+      const size_t ow = (size_t)w * A;
+      const int e_end = min(rows * A, 128 * i1);
+      for (int e = 2 * lane + 128 * i0; e < e_end; e += 128) {
+        const int64_t n = nrow0 + rl;
+        if (n < L.N && !(abl & 32)) {
+          const size_t o = (size_t)n * W * A + ow + a;
+          const v2d v = *reinterpret_cast<const v2d*>(zr0 + e);
+          if (L.b64) *reinterpret_cast<v2d*>(L.b64 + o) = v;
+          if (L.b32) *reinterpret_cast<v2f*>(L.b32 + o) = v2f{(float)v[0], (float)v[1]};
+        }
+        a += d_a; rl += d_r;
+        if (a >= A) { a -= A; ++rl; }
+      }
+      return;
+    }
     int rl = e_r0, a = e_a0;
     if (i0 > 0) {
       rl = (lane + 64 * i0) / A;
@@ -642,28 +667,30 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       if (a >= A) { a -= A; ++rl; }
     }
   };
-  auto phase1 = [&](double* zr0, int w, int it0, int it1, int rows) {   // iteration `it` = classes fsub + (PB it + i) lpr, i < PB
+  auto phase1_n = [&](auto nb, double* zr0, int w, int it0, int it1, int rows) {   // iteration `it` = classes fsub + (NB it + i) lpr, i < NB
+    constexpr int NB = decltype(nb)::value;
     if (abl & 1) return;
     const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
     double* zr = zr0 + frow * A;
     const double* ic = tab_ic + (w - wt0) * A;
     for (int it = it0; it < it1; ++it) {
-      double v[PB];
-      int a[PB];
+      double v[NB];
+      int a[NB];
 #pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        a[i] = fsub + (PB * it + i) * lpr;
+      for (int i = 0; i < NB; ++i) {
+        a[i] = fsub + (NB * it + i) * lpr;
         const int ac = min(a[i], A - 1);
         v[i] = -(zr[ac] + ic[ac]);
       }
-      gnx_exp_scN<PB>(v);
+      gnx_exp_scN<NB>(v);
 #pragma unroll
-      for (int i = 0; i < PB; ++i) v[i] = 1.0 / (1.0 + v[i]);
+      for (int i = 0; i < NB; ++i) v[i] = 1.0 / (1.0 + v[i]);
 #pragma unroll
-      for (int i = 0; i < PB; ++i)
+      for (int i = 0; i < NB; ++i)
         if (a[i] < A) zr[a[i]] = v[i];
     }
   };
+  auto phase1 = [&](double* zr0, int w, int it0, int it1, int rows) { phase1_n(std::integral_constant<int, PB>{}, zr0, w, it0, it1, rows); };
   auto normalise = [&](double* zr0, int rows) {
     if (abl & 1) return;
     const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
@@ -692,9 +719,12 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     // beside them: their float64 chains would get the left-over issue slots and every wave of the block would wait for them at the
     // step's barrier.  Their work is short; let it go first.
     if (!(abl & 128)) __builtin_amdgcn_s_setprio(2);   // (GNX_LR_FLAGS & 128: without, for A/B timing)
+    // (Float64 vector work runs on the SIMD's matrix pipe wherever it is issued — an epilogue wave's ~550 cycles per step come straight
+    // out of its SIMD's MFMA time — so the total is fixed and only the spread over the steps matters.  Smaller units (two sigmoids, one
+    // store instruction) with or without a per-step time budget measured 3-6 % SLOWER than these eight units per window.)
     const int n_it = (A + PB * (64 / CHR) - 1) / (PB * (64 / CHR));   // phase-1 iterations of a lane: PB classes each
-    constexpr int NSP = 4;                                             // the stores of a chunk in NSP parts
-    const int n_sti = (CHR * A + 63) / 64, sti_part = (n_sti + NSP - 1) / NSP;
+    constexpr int NSP = 2;                                             // the stores of a chunk in NSP parts
+    const int n_sti = (CHR * A + spi - 1) / spi, sti_part = (n_sti + NSP - 1) / NSP;
     const int upc = n_it + 1 + NSP;                                    // units per chunk
     const int n_units = NCH * upc;
     int parked = 0;
@@ -785,6 +815,34 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
   };
 
+  // ---- EW == 0: SELF-SERVICE epilogue.  Dedicated epilogue waves meet the compute waves at every step's barrier with a different
+  // amount of work each step, are the youngest waves of their SIMDs (they lose the VALU arbitration) and, two or four per block,
+  // run their float64 chains on one or two instruction streams: every compute wave waited 700-2200 cycles per step for them.
+  // Here a compute wave finishes its OWN 32 rows: the window parked at the end of run r is worked off in units (sigmoid rounds, the
+  // row normalisation, the stores in parts) over the steps until its next window ends — float64 VALU work of one wave beside the
+  // MFMAs of the wave it shares the SIMD with: the waves of a SIMD (w, w + 4) take their unit at opposite ends of the step.
+  const int s_nit = (A + PB * (64 / ZROWS) - 1) / (PB * (64 / ZROWS));
+  constexpr int S_NSP = 2;
+  const int s_nsti = (ZROWS * A + spi - 1) / spi, s_part = (s_nsti + S_NSP - 1) / S_NSP;
+  const int s_units = s_nit + 1 + S_NSP;
+  bool job = false;
+  int job_w = 0, job_step = 0, job_nst = 0, job_unit = 0;
+  double* job_z = nullptr;
+  auto run_units = [&](int u_end) {
+    for (; job_unit < u_end; ++job_unit) {
+      if (job_unit < s_nit) phase1(job_z, job_w, job_unit, job_unit + 1, ZROWS);
+      else if (job_unit == s_nit) normalise(job_z, ZROWS);
+      else store_rows(job_z, job_w, n0, ZROWS, (job_unit - s_nit - 1) * s_part, (job_unit - s_nit) * s_part);
+    }
+  };
+  auto job_work = [&]() {
+    if (EW || !job) return;
+    ++job_step;
+    run_units(job_step >= job_nst ? s_units : (int)((int64_t)s_units * job_step / job_nst));
+    if (job_step >= job_nst) job = false;
+  };
+  const bool late = ((wave >> 2) & 1) != 0;   // the second wave of its SIMD (waves go to SIMDs round robin): its unit follows its MFMAs
+
   int parked = 0;
   auto flush = [&](int rl) {
     const int nfl = tab_nfl[rl];
@@ -839,7 +897,18 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       if (!out) continue;
       if (EW && nfl == 1) {
         ++parked;  // an epilogue wave takes it from here (after the next barrier)
-      } else {     // several windows end at once (chromosome ends, wide contexts), or no epilogue waves: finish it here
+      } else if (!EW && nfl == 1) {
+        if (job) run_units(s_units);   // (the previous window's units were dealt over the steps up to here: nothing is left)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        job = true;
+        job_w = w;
+        job_step = 0;
+        job_unit = 0;
+        job_nst = max(1, SPR * (tab_gap[rl] > 0 ? tab_gap[rl] : n_runs - 1 - rl));
+        job_z = zw;
+        ++parked;
+      } else {     // several windows end at once (chromosome ends, wide contexts): finish it here
+        if (!EW && job) { run_units(s_units); job = false; }
         // (a rare path — never at the default context — kept narrow: one class at a time, no batch temporaries beside the accumulators)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(abl & 1)) {
@@ -876,8 +945,10 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
         x1[mt] = q[1];
       }
       const uint8_t* sb = vbuf + (size_t)((SPR * r + h) % NBUF) * STEP_BYTES;
+      if (!late) job_work();
       mfma_entry(sb, x0);
       mfma_entry(sb + ENTRY_BYTES, x1);
+      if (late) job_work();
       if (dbg_on) { c_bar += t1 - t0; c_mm += __builtin_readcyclecounter() - t1; }
     }
     const unsigned long long t2 = dbg_on ? __builtin_readcyclecounter() : 0;
@@ -885,7 +956,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     if (dbg_on) c_fl += __builtin_readcyclecounter() - t2;
   }
   if (EW) lds_barrier(nobar);  // trailing barrier: the last run's parked windows become visible to the epilogue waves
-  if (dbg_on && lane == 0 && wave == 0) { dbg[0] = c_bar; dbg[1] = c_mm; dbg[2] = c_fl; dbg[3] = __builtin_readcyclecounter() - t_begin; }
+  if (!EW && job) run_units(s_units);
+  if (dbg_on && lane == 0 && wave == 0) { dbg[0] = c_bar; dbg[1] = c_mm; dbg[2] = c_fl; dbg[3] = __builtin_readcyclecounter() - t_begin; dbg[7] = (unsigned long long)n_steps; }
 }
 
 template <int MT, int CW, int EW, int XSN, int NBUF>
@@ -895,8 +967,13 @@ hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hi
   P.flags = tune.lr_flags;
   const int haps_per_block = CW * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
-  const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : 4;
+  // window ranges: one block per CU at a time (150 KB of LDS), so the grid is walked in rounds and the last, partial round costs a
+  // whole block: ~18 blocks per CU keep that under 3 % (config 5a: 9.2 rounds of 60-window blocks measured 8.26 ms, 18.4 rounds of
+  // 30-window blocks 7.88); a range re-walks only the half window of context before its first window, so short ranges are cheap —
+  // down to ~24 windows, where the re-walk reaches 4 %
+  const int bpc = tune.lr_bpc > 0 ? tune.lr_bpc : 18;
   int64_t want = ((int64_t)bpc * n_cu + gx - 1) / gx;
+  want = std::min<int64_t>(want, std::max<int64_t>(8, L.W / 24));
   want = std::max<int64_t>(8, ((want + 7) / 8) * 8);
   if (tune.lr_want > 0) want = tune.lr_want;
   int wch = 0, n_ranges = 0;
@@ -964,9 +1041,13 @@ hipError_t gnx_launch_base_logistic_p2(const BaseLRLaunch& L, int n_cu, const gn
   if (L.d.V2F && L.d.EPR == 4 && L.d.R * L.A == NCF && L.h_win_chunk0 && L.h_win_chunk1) {
     // flat column tiles (24 class columns): 256 rows per block, X read once; the deepest configuration that fits the LDS
     // (GNX_P2_TUNE = "2,8,2,xsn,nbuf" picks the depth: development)
-    const int tx = tune.p2_xsn, tb = tune.p2_nbuf;
-    (void)tx; (void)tb;
-    if (tune.p2_ew == 2) return launch_flat<2, 8, 2, 2, 3>(L, n_cu, tune, s);
+    const int tb = tune.p2_nbuf;
+    if (tune.p2_mt == 2) {   // development: GNX_P2_TUNE = "2,8,ew,2,nbuf" with ew = 0 (self-service), 2 or 4 epilogue waves
+      if (tune.p2_ew == 0) return tb == 2 ? launch_flat<2, 8, 0, 2, 2>(L, n_cu, tune, s) : launch_flat<2, 8, 0, 2, 3>(L, n_cu, tune, s);
+      if (tune.p2_ew == 2) return launch_flat<2, 8, 2, 2, 3>(L, n_cu, tune, s);
+      if (tune.p2_ew == 4) return tb == 2 ? launch_flat<2, 8, 4, 2, 2>(L, n_cu, tune, s) : launch_flat<2, 8, 4, 2, 3>(L, n_cu, tune, s);
+      return hipErrorInvalidValue;
+    }
     hipError_t e = launch_flat<2, 8, 4, 2, 3>(L, n_cu, tune, s);
     if (e == hipErrorNotSupported) e = launch_flat<2, 8, 4, 2, 2>(L, n_cu, tune, s);
     return e;
