@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
 
 GNX_ABI_VERSION = 14
-GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE = 0, -1, -2, -3, -4, -5
+GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE, GNX_ESTALE = 0, -1, -2, -3, -4, -5, -6
 BASE_NONE, BASE_LOGISTIC, BASE_COVRSK_SVC, BASE_FOREST, BASE_RFOREST = 0, 1, 2, 3, 4
 SMOOTH_NONE, SMOOTH_XGB, SMOOTH_CRF, SMOOTH_CNN = 0, 1, 2, 3
 K_BASE_LOGISTIC, K_SMOOTH_XGB, K_BASE_COVRSK, K_SMOOTH_CRF, K_GNOFIX, K_SMOOTH_ROWS, K_CALIBRATE, K_BASE_FOREST, K_SMOOTH_CNN = range(9)
@@ -59,7 +59,8 @@ class ModelDesc(C.Structure):
                 ("fb_base_score", C.c_float), ("fb_n_nodes", C.c_int32),
                 ("rf_n_trees", C.c_int32), ("rf_n_nodes", C.c_int32), ("rf_win_tree0", C.c_void_p), ("rf_tree_off", C.c_void_p),
                 ("rf_left", C.c_void_p), ("rf_right", C.c_void_p), ("rf_feat", C.c_void_p), ("rf_thr", C.c_void_p),
-                ("rf_value", C.c_void_p), ("cnn_weight", C.c_void_p), ("cnn_bias", C.c_void_p)]
+                ("rf_value", C.c_void_p), ("cnn_weight", C.c_void_p), ("cnn_bias", C.c_void_p),
+                ("prepared", C.c_void_p), ("prepared_bytes", C.c_int64)]
 
 
 class TrainInfo(C.Structure):
@@ -120,6 +121,7 @@ SYMBOLS = {
     "gnx_model_free": (None, [_VP]),
     "gnx_model_get_info": (C.c_int, [_VP, C.POINTER(ModelInfo)]),
     "gnx_model_set_calibrate": (C.c_int, [_VP, _I]),
+    "gnx_model_export_prepared": (C.c_int, [_VP, _VP, _I64, C.POINTER(_I64)]),
     "gnx_base_predict": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP]),
     "gnx_base_predict_dev": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP]),
     "gnx_smooth_predict": (C.c_int, [_VP, _VP, _I, _I64, _VP, _VP, _VP]),

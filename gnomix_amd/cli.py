@@ -20,14 +20,75 @@ USAGE = ("Usage when using a pre-trained model:\n"
          "(training a model from scratch is not part of the MI355X inference path; train with the reference and export)")
 
 
-def load_model(path_to_model, device=0, verbose=True):
+PLANES_SUFFIX = ".planes"   # <model>.gnx.planes: the logistic base's prepared planes (DeviceModel.export_prepared), a cache
+
+
+def read_gnx_and_planes(path):
+    """the host half of loading a .gnx: the model file and, when present, the cache of its prepared planes -> (data, planes or None).
+    Touches no GPU: the command line runs it on a worker thread while the main thread starts the GPU runtime."""
+    from .model import GnxModelData
+    data = GnxModelData.load(path)
+    prepared = None
+    side = path + PLANES_SUFFIX
+    if os.environ.get("GNX_PLANES_CACHE", "1") != "0" and data.base_kind == "logistic" and os.path.exists(side):
+        try:
+            prepared = np.fromfile(side, dtype=np.uint8)
+        except OSError as e:
+            print("ignoring %s: %s" % (side, e), file=sys.stderr)
+    return data, prepared
+
+
+def _load_gnx_with_planes(path, device, verbose, timings=None, file_job=None):
+    """A .gnx and, beside it, the cache of its prepared planes (<model>.gnx.planes).  Starting the GPU runtime is the largest part
+    of a cold start (0.13-0.2 s of hipInit) and needs nothing of the model: the file reads run on a worker thread meanwhile
+    (`file_job`, started by main() before it first touches the GPU).  A cache that does not belong to the model / library / settings
+    is reported, ignored and rewritten.  GNX_PLANES_CACHE=0: neither read nor written."""
+    from time import perf_counter as clock
+    from . import _lib
+    from .gnomix import HipGnomix
+    t0 = clock()
+    if file_job is None:
+        file_job = _Prefetch(lambda: read_gnx_and_planes(path))
+    ctx = _lib.default_context(device)
+    t1 = clock()
+    data, prepared = file_job.result()
+    use_cache = os.environ.get("GNX_PLANES_CACHE", "1") != "0" and data.base_kind == "logistic"
+    side = path + PLANES_SUFFIX
+    t2 = clock()
+    model = None
+    if prepared is not None:
+        try:
+            model = HipGnomix(data, ctx=ctx, prepared=prepared)
+        except _lib.GnxError as e:
+            if e.code != _lib.GNX_ESTALE:
+                raise
+            print("%s is stale (%s): preparing the planes from the model and rewriting it" % (side, e.msg), file=sys.stderr)
+            prepared = None
+    if model is None:
+        model = HipGnomix(data, ctx=ctx)
+        if use_cache:
+            try:
+                blob = model.dev.export_prepared()
+                if blob.size:
+                    tmp = "%s.tmp%d" % (side, os.getpid())
+                    blob.tofile(tmp)
+                    os.replace(tmp, side)      # (atomic: a concurrent start reads the old file or the new one, never half of it)
+            except OSError as e:               # a read-only model directory: every start prepares the planes, as before
+                if verbose:
+                    print("not caching the prepared planes (%s)" % e, file=sys.stderr)
+    if timings is not None:
+        timings.update({"load_model.gpu_runtime": t1 - t0, "load_model.wait_file": t2 - t1, "load_model.device_model": clock() - t2,
+                        "load_model.planes_from_cache": float(prepared is not None)})
+    return model
+
+
+def load_model(path_to_model, device=0, verbose=True, timings=None, file_job=None):
     """gnomix.py:26-35 — .gnx directly, .pkl / .pkl.gz through the converter"""
     from .gnomix import HipGnomix
-    from .model import GnxModelData
     if verbose:
         print("Loading model...")
     if path_to_model.endswith(".gnx"):
-        return HipGnomix(GnxModelData.load(path_to_model), device=device)
+        return _load_gnx_with_planes(path_to_model, device, verbose, timings, file_job)
     from .convert import from_reference_model
     from .refpickle import load_reference_pickle
     # restricted unpickling: the reference's `src` package and xgboost are NOT needed (and nothing of them is executed)
@@ -188,10 +249,14 @@ def main(argv=None):
         # thread starts the GPU runtime (~0.16 s), reads the model and builds its device tables (~0.15 s)
         from . import vcfio
         query = _Prefetch(lambda: vcfio.read_vcf(base_args["query_file"], chm=base_args["chm"], ctx=None))
+    t_load = clock()
+    file_job, T_load = None, {}
+    if base_args["path_to_model"].endswith(".gnx"):   # the model file is read beside the GPU runtime's start (visible_devices is its first use)
+        mp = base_args["path_to_model"]
+        file_job = _Prefetch(lambda: read_gnx_and_planes(mp))
     from .multi import visible_devices
     devices = visible_devices()        # every GPU of the node (GNX_DEVICES="0,1,.." narrows it): individuals are cut over them
-    t_load = clock()
-    model = load_model(base_args["path_to_model"], device=devices[0])
+    model = load_model(base_args["path_to_model"], device=devices[0], timings=T_load, file_job=file_job)
     t_load = clock() - t_load
     model.n_cores = (config.get("model") or {}).get("n_cores")            # gnomix.py:365-367
     model.calibrate = (config.get("model") or {}).get("calibrate")
@@ -203,6 +268,7 @@ def main(argv=None):
         T = {"load_model": t_load}
         if t_startup is not None:
             T = {"interpreter_and_imports": t_startup, "load_model": t_load}
+        T.update(T_load)
         run_inference(base_args, model, snp_level=bool(inf.get("snp_level_inference")),
                       bed_file_output=bool(inf.get("bed_file_output")), verbose=True, timings=T, query=query, devices=devices)
         if os.environ.get("GNX_CLI_TIMING"):

@@ -422,6 +422,9 @@ struct gnx_model {
   std::vector<int32_t> lr_h_win_chunk0, lr_h_win_chunk1;
   std::vector<int32_t> lr_h_win_run0, lr_h_win_run1;   // host copies of lr.win_run0/1 (launcher of the 2-bit pass)
   bool lr_i8 = true;
+  // what gnx_model_export_prepared needs of the logistic base: the key of the coefficients the planes were made from and their sizes
+  uint64_t lr_key = 0;
+  int64_t lr_v8_bytes = 0, lr_v2_bytes = 0;   // V8 / V2 (or V2F) as uploaded, without padding
   SmoothXGBDev xgb;
   CovRSKDev svc;
   ForestDev forest;

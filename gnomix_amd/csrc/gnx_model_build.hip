@@ -45,6 +45,58 @@ static unsigned parallel_ranges(size_t n, size_t grain, F&& fn) {
 }
 static unsigned parallel_max_threads() { return std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u); }
 
+// ---- the logistic base's prepared planes as a relocatable blob (gnx_model_export_prepared -> gnx_model_desc.prepared) -------------
+// | GnxPreparedHdr | wscale[W] float64 | V8 | pad to 16 | V2 or V2F |  — valid for exactly one (coefficients, geometry, ABI, plane
+// settings); everything else of the model (chunk / run tables, intercepts) is cheap and always rebuilt from the description.
+struct GnxPreparedHdr {
+  char magic[8];                 // "GNXPLR1"
+  uint32_t hdr_bytes, abi;
+  int64_t C, M, ctx, W;
+  int32_t A, NT, NT2, EPR, flat, reserved;
+  int64_t n_chunks, n_runs;
+  uint64_t key;                  // lr_key(): the coefficient rows the planes were made from
+  int64_t v8_bytes, v2_bytes;
+};
+static const char kPreparedMagic[8] = {'G', 'N', 'X', 'P', 'L', 'R', '1', 0};
+
+// 64-bit hash of the coefficient rows a model uses (row i, class a: the first width_i float64 of its lr_ldc), one hash per window
+// folded in window order: different weights, window widths or row order give a different key (not cryptographic: a cache key)
+static uint64_t lr_key(const gnx_model_desc* d, int64_t W, int64_t M_, int64_t rem) {
+  std::vector<uint64_t> hw((size_t)W);
+  parallel_ranges((size_t)W, 16, [&](size_t lo, size_t hi, unsigned) {
+    for (size_t i = lo; i < hi; ++i) {
+      const int64_t width = M_ + ((int64_t)i == W - 1 ? rem : 0);
+      uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)i;
+      for (int a = 0; a < d->A; ++a) {
+        const double* row = d->lr_coef + ((size_t)i * d->A + a) * (size_t)d->lr_ldc;
+        for (int64_t k = 0; k < width; ++k) {
+          uint64_t x;
+          std::memcpy(&x, row + k, 8);
+          h = (h ^ x) * 0xD6E8FEB86659FD93ull;
+          h ^= h >> 29;
+        }
+      }
+      hw[i] = h;
+    }
+  });
+  uint64_t h = 0xA0761D6478BD642Full;
+  for (uint64_t x : hw) { h = (h ^ x) * 0xE7037ED1A0B428DBull; h ^= h >> 32; }
+  return h;
+}
+
+template <typename T>
+static int dev_upload_raw(gnx_model* m, const void* src, size_t bytes, const T** out, size_t pad_bytes) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes + pad_bytes + 16);
+  if (e != hipSuccess) return gnx_fail(m->ctx, GNX_ENOMEM, std::string("hipMalloc model: ") + hipGetErrorString(e));
+  m->dev_allocs.push_back(p);
+  m->info.device_bytes += (int64_t)(bytes + pad_bytes + 16);
+  if (bytes && (e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)) != hipSuccess) return gnx_fail(m->ctx, GNX_EHIP, std::string("hipMemcpy model: ") + hipGetErrorString(e));
+  if ((e = hipMemset((char*)p + bytes, 0, pad_bytes + 16)) != hipSuccess) return gnx_fail(m->ctx, GNX_EHIP, std::string("hipMemset model: ") + hipGetErrorString(e));
+  *out = (const T*)p;
+  return GNX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // model preparation: logistic base
 // ------------------------------------------------------------------------------------------------
@@ -112,13 +164,31 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
   // fragment-ordered, reflect-folded weights
   const char* impl = std::getenv("GNX_BASE_LR_IMPL");  // "i8" (default, exact fixed point) or "f64" (f64 MFMA)
   m->lr_i8 = !(impl && std::string(impl) == "f64");
-  std::vector<double> V(n_chunks * 16 * (size_t)NT * 64, 0.0);
-  std::vector<int32_t> Vwin(m->lr_i8 ? V.size() : 0, -1);
+  // prepared planes handed in with the description (gnx_model_desc.prepared): validated here and below, used instead of the two
+  // passes over the coefficients; ANY mismatch is GNX_ESTALE and loads nothing
+  const GnxPreparedHdr* ph = nullptr;
+  auto stale = [&](const char* what) { return fail(ctx, GNX_ESTALE, std::string("prepared planes: ") + what + " (load without them and export them again)"); };
+  if (m->lr_i8) m->lr_key = lr_key(d, W, M_, rem);
+  if (d->prepared) {
+    if (!m->lr_i8) return stale("made for the int8 kernels, GNX_BASE_LR_IMPL=f64 is set");
+    if (d->prepared_bytes < (int64_t)sizeof(GnxPreparedHdr)) return stale("truncated (no header)");
+    ph = static_cast<const GnxPreparedHdr*>(d->prepared);
+    if (std::memcmp(ph->magic, kPreparedMagic, 8) != 0 || ph->hdr_bytes != sizeof(GnxPreparedHdr)) return stale("not a prepared-planes blob of this library");
+    if (ph->abi != (uint32_t)GNX_ABI_VERSION) return stale("written by another ABI version");
+    if (ph->C != C || ph->M != M || ph->ctx != cx || ph->W != W || ph->A != A || ph->NT != NT || ph->n_chunks != (int64_t)n_chunks)
+      return stale("another model geometry");
+    if (ph->key != m->lr_key) return stale("other coefficients");
+    if (ph->v8_bytes != (int64_t)(n_chunks * (size_t)NT * 7 * 64 * 16) || ph->v2_bytes < 0 ||
+        d->prepared_bytes != (int64_t)sizeof(GnxPreparedHdr) + W * 8 + ((ph->v8_bytes + 15) & ~(int64_t)15) + ph->v2_bytes)
+      return stale("truncated or of an unexpected size");
+  }
+  std::vector<double> V(ph ? 0 : n_chunks * 16 * (size_t)NT * 64, 0.0);
+  std::vector<int32_t> Vwin(m->lr_i8 && !ph ? V.size() : 0, -1);
   std::vector<double> maxabs((size_t)W, 0.0);
   const double* coef = d->lr_coef;
   const int64_t ldc = d->lr_ldc;
   std::vector<std::vector<double>> maxabs_t(parallel_max_threads());  // per-thread window maxima, merged below
-  parallel_ranges(n_chunks, 64, [&](size_t c_lo, size_t c_hi, unsigned tid) {
+  if (!ph) parallel_ranges(n_chunks, 64, [&](size_t c_lo, size_t c_hi, unsigned tid) {
   std::vector<double>& maxabs = maxabs_t[tid];
   maxabs.assign((size_t)W, 0.0);
   for (size_t c = c_lo; c < c_hi; ++c)
@@ -167,13 +237,18 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
     // exact fixed point: q = round(c * 2^f_w), |q| < 2^54, seven balanced base-256 digits per weight
     std::vector<int> fexp((size_t)W, 0);
     std::vector<double> wscale((size_t)W, 1.0);
-    for (int64_t i = 0; i < W; ++i) {
+    const uint8_t* blob = static_cast<const uint8_t*>(d->prepared);
+    const uint8_t* blob_v8 = ph ? blob + sizeof(GnxPreparedHdr) + (size_t)W * 8 : nullptr;
+    const uint8_t* blob_v2 = ph ? blob_v8 + ((ph->v8_bytes + 15) & ~(int64_t)15) : nullptr;
+    if (ph) std::memcpy(wscale.data(), blob + sizeof(GnxPreparedHdr), (size_t)W * 8);
+    else for (int64_t i = 0; i < W; ++i) {
       if (!(maxabs[(size_t)i] < 1e300)) return fail(ctx, GNX_EINVAL, "logistic base: non-finite coefficient");
       if (maxabs[(size_t)i] > 0.0) fexp[(size_t)i] = 53 - std::ilogb(maxabs[(size_t)i]);
       wscale[(size_t)i] = std::ldexp(1.0, -fexp[(size_t)i]);
     }
-    std::vector<int8_t> V8(n_chunks * (size_t)NT * 7 * 64 * 16, 0);
-    parallel_ranges(n_chunks, 64, [&](size_t c_lo, size_t c_hi, unsigned) {
+    m->lr_v8_bytes = (int64_t)(n_chunks * (size_t)NT * 7 * 64 * 16);
+    std::vector<int8_t> V8(ph ? 0 : (size_t)m->lr_v8_bytes, 0);
+    if (!ph) parallel_ranges(n_chunks, 64, [&](size_t c_lo, size_t c_hi, unsigned) {
     for (size_t c = c_lo; c < c_hi; ++c)
       for (int t = 0; t < 16; ++t)
         for (int nt = 0; nt < NT; ++nt)
@@ -189,13 +264,15 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
             }
           }
     });
-    if ((rc = gnx_dev_upload(m, V8, &m->lr.V8, 64)) != GNX_OK) return rc;
+    if (ph) rc = dev_upload_raw(m, blob_v8, (size_t)ph->v8_bytes, &m->lr.V8, 64);
+    else rc = gnx_dev_upload(m, V8, &m->lr.V8, 64);
+    if (rc != GNX_OK) return rc;
 #ifdef GNX_EXPERIMENTS
     // flat column tiles for k_base_logistic_i8_fl: column q = slot * 7 + limb, ceil(NC * 7 / 16) tiles instead of NT * 7
     // (A = 12 at the default context: 11 instead of 14); an experiment that measured slower (see the kernel's header): built only
     // when GNX_LR_FLAT=1 asks for it at model load
     const int NF = (int)((NC * 7 + 15) / 16);
-    if (NF < NT * 7 && NF >= 8 && NF <= 11 && A <= 16 && std::getenv("GNX_LR_FLAT") && std::atoi(std::getenv("GNX_LR_FLAT")) > 0) {
+    if (!ph && NF < NT * 7 && NF >= 8 && NF <= 11 && A <= 16 && std::getenv("GNX_LR_FLAT") && std::atoi(std::getenv("GNX_LR_FLAT")) > 0) {
       std::vector<int8_t> V8F(n_chunks * (size_t)NF * 64 * 16, 0);
       for (size_t c = 0; c < n_chunks; ++c)
         for (int ft = 0; ft < NF; ++ft)
@@ -235,6 +312,7 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
       if (const char* e = std::getenv("GNX_LR_P2_RUN")) { const int v = std::atoi(e); if (v == 256 || v == 512) RS = v; }
       const int EPR = (int)(RS / 64);
       const bool want_p2 = NT2 > 0 && p2mode != 0 && (p2mode == 2 || padded_with(RS) * 4 <= C * 5);
+      if (ph && ((ph->v2_bytes > 0) != want_p2)) return stale("made with other GNX_LR_P2 settings");
       if (want_p2) {
         std::vector<int32_t> run_byte, run_flush0, run_nflush, piece_run0(n_pieces + 1);
         std::vector<int64_t> run_s, run_b0, run_b1;
@@ -273,7 +351,10 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
         const bool flat = NC == GNX_LR_FLAT_COLS && A <= 16 && EPR == 4 && !(flat_env && std::atoi(flat_env) == 0);
         const int NTB = flat ? GNX_LR_FLAT_TILES : NT2;  // 1 KB digit blocks per entry: flat tiles, or column tiles x 7 limbs below
         const size_t entry_bytes = flat ? (size_t)NTB * 64 * 16 : (size_t)NT2 * 7 * 64 * 16;
-        std::vector<int8_t> V2(n_runs * (size_t)EPR * entry_bytes, 0);
+        m->lr_v2_bytes = (int64_t)(n_runs * (size_t)EPR * entry_bytes);
+        if (ph && (ph->v2_bytes != m->lr_v2_bytes || ph->EPR != EPR || ph->NT2 != NT2 || ph->flat != (flat ? 1 : 0) || ph->n_runs != (int64_t)n_runs))
+          return stale("made with other GNX_LR_P2 / GNX_LR_P2_RUN / GNX_LR_P2_FLAT settings");
+        std::vector<int8_t> V2(ph ? 0 : (size_t)m->lr_v2_bytes, 0);
         auto fill_runs = [&](size_t r_lo, size_t r_hi) {
           std::vector<double> wsum((size_t)A);
           std::vector<uint8_t> any((size_t)A);
@@ -319,8 +400,10 @@ int gnx_build_lr(gnx_model* m, const gnx_model_desc* d) {
                   }
                 }
         };
-        parallel_ranges(n_runs, 64, [&](size_t lo, size_t hi, unsigned) { fill_runs(lo, hi); });
-        if ((rc = gnx_dev_upload(m, V2, flat ? &m->lr.V2F : &m->lr.V2, 64)) != GNX_OK) return rc;
+        if (!ph) parallel_ranges(n_runs, 64, [&](size_t lo, size_t hi, unsigned) { fill_runs(lo, hi); });
+        if (ph) rc = dev_upload_raw(m, blob_v2, (size_t)ph->v2_bytes, flat ? &m->lr.V2F : &m->lr.V2, 64);
+        else rc = gnx_dev_upload(m, V2, flat ? &m->lr.V2F : &m->lr.V2, 64);
+        if (rc != GNX_OK) return rc;
         if ((rc = gnx_dev_upload(m, run_byte, &m->lr.run_byte)) != GNX_OK) return rc;
         if ((rc = gnx_dev_upload(m, run_flush0, &m->lr.run_flush0)) != GNX_OK) return rc;
         if ((rc = gnx_dev_upload(m, run_nflush, &m->lr.run_nflush)) != GNX_OK) return rc;
@@ -1093,3 +1176,40 @@ int gnx_build_crf(gnx_model* m, const gnx_model_desc* d) {
   return GNX_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gnx_model_export_prepared (include/gnomix_hip.h): the planes of a loaded logistic model, read back from the device
+// ------------------------------------------------------------------------------------------------
+extern "C" int gnx_model_export_prepared(gnx_model* m, void* buf, int64_t cap, int64_t* bytes) {
+  if (!m || !bytes) return GNX_EINVAL;
+  gnx_ctx* ctx = m->ctx;
+  *bytes = 0;
+  if (m->info.base_kind != GNX_BASE_LOGISTIC || !m->lr_i8 || !m->lr.V8) return GNX_OK;   // nothing to prepare for other bases
+  const int64_t W = m->info.W;
+  const int64_t v8p = (m->lr_v8_bytes + 15) & ~(int64_t)15;
+  const int64_t total = (int64_t)sizeof(GnxPreparedHdr) + W * 8 + v8p + m->lr_v2_bytes;
+  *bytes = total;
+  if (!buf) return GNX_OK;
+  if (cap < total) return fail(ctx, GNX_EINVAL, "export_prepared: buffer smaller than *bytes");
+  GNX_BIND_DEVICE(ctx);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  uint8_t* out = static_cast<uint8_t*>(buf);
+  GnxPreparedHdr h{};
+  std::memcpy(h.magic, kPreparedMagic, 8);
+  h.hdr_bytes = (uint32_t)sizeof(GnxPreparedHdr);
+  h.abi = (uint32_t)GNX_ABI_VERSION;
+  h.C = m->info.C; h.M = m->info.M; h.ctx = m->info.ctx; h.W = W;
+  h.A = m->info.A; h.NT = m->lr.NT; h.NT2 = m->lr.NT2; h.EPR = m->lr.EPR; h.flat = m->lr.V2F ? 1 : 0;
+  h.n_chunks = m->lr.n_chunks; h.n_runs = m->lr.n_runs;
+  h.key = m->lr_key;
+  h.v8_bytes = m->lr_v8_bytes; h.v2_bytes = m->lr_v2_bytes;
+  std::memcpy(out, &h, sizeof(h));
+  out += sizeof(h);
+  HIPCHK(ctx, hipMemcpy(out, m->lr.wscale, (size_t)W * 8, hipMemcpyDeviceToHost));
+  out += W * 8;
+  HIPCHK(ctx, hipMemcpy(out, m->lr.V8, (size_t)m->lr_v8_bytes, hipMemcpyDeviceToHost));
+  std::memset(out + m->lr_v8_bytes, 0, (size_t)(v8p - m->lr_v8_bytes));
+  out += v8p;
+  if (m->lr_v2_bytes > 0) HIPCHK(ctx, hipMemcpy(out, m->lr.V2F ? m->lr.V2F : m->lr.V2, (size_t)m->lr_v2_bytes, hipMemcpyDeviceToHost));
+  return GNX_OK;
+}

@@ -14,9 +14,9 @@ from .smooth import HipSmoother
 
 class HipGnomix:
 
-    def __init__(self, data: GnxModelData, device: int = 0, ctx=None, calibrate=False, verbose=False):
+    def __init__(self, data: GnxModelData, device: int = 0, ctx=None, calibrate=False, verbose=False, prepared=None):
         self.data = data
-        self.dev = DeviceModel(data, ctx=ctx, device=device)
+        self.dev = DeviceModel(data, ctx=ctx, device=device, prepared=prepared)
         self.C, self.M, self.A, self.S = data.C, data.M, data.A, data.S
         self.W = self.C // self.M
         self.context = data.context

@@ -264,11 +264,17 @@ class GnxModelData:
 class DeviceModel:
     """gnx_model handle: the model resident in HBM of one device."""
 
-    def __init__(self, data: GnxModelData, ctx: _lib.Context | None = None, device: int = 0):
+    def __init__(self, data: GnxModelData, ctx: _lib.Context | None = None, device: int = 0, prepared=None):
+        """prepared: the logistic base's planes as export_prepared() of the SAME model wrote them (uint8 array / buffer): skips their
+        preparation; a blob of another model, library or setting raises GnxError with code GNX_ESTALE and loads nothing"""
         self.ctx = ctx or _lib.default_context(device)
         self.lib = self.ctx.lib
         self.data = data
         desc, keep = data.to_desc()
+        if prepared is not None:
+            pb = np.ascontiguousarray(np.frombuffer(prepared, dtype=np.uint8) if not isinstance(prepared, np.ndarray) else prepared.view(np.uint8).reshape(-1))
+            keep.append(pb)
+            desc.prepared, desc.prepared_bytes = pb.ctypes.data, pb.size
         h = C.c_void_p()
         self.ctx.check(self.lib.gnx_model_load(self.ctx.h, C.byref(desc), C.byref(h)))
         del keep
@@ -278,6 +284,15 @@ class DeviceModel:
         self.ctx.check(self.lib.gnx_model_get_info(h, C.byref(info)))
         self.info = info
         self.W, self.A, self.S, self.C, self.M = int(info.W), int(info.A), int(info.S), int(info.C), int(info.M)
+
+    def export_prepared(self):
+        """the logistic base's prepared planes as a uint8 array for DeviceModel(..., prepared=...) of the same model (empty for other bases)"""
+        n = C.c_int64()
+        self.ctx.check(self.lib.gnx_model_export_prepared(self.h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint8)
+        if n.value:
+            self.ctx.check(self.lib.gnx_model_export_prepared(self.h, out.ctypes.data, out.size, C.byref(n)))
+        return out
 
     def set_calibrate(self, on):
         self.ctx.check(self.lib.gnx_model_set_calibrate(self.h, int(bool(on))))

@@ -57,7 +57,9 @@ enum {
   GNX_ENOMEM = -2,       /* host or device allocation failed */
   GNX_EHIP = -3,         /* HIP runtime error (message has the hipError string) */
   GNX_EUNSUPPORTED = -4, /* valid in the reference but not built here (message says what) */
-  GNX_ESTATE = -5        /* call not valid for this model (e.g. phasing with a CRF smoother) */
+  GNX_ESTATE = -5,       /* call not valid for this model (e.g. phasing with a CRF smoother) */
+  GNX_ESTALE = -6        /* gnx_model_desc.prepared does not belong to this model / library / settings, or is truncated: nothing was
+                            loaded; load again without it (and write a new one) */
 };
 
 enum { GNX_SVC_KERNEL_SUBSTRINGS = 0, GNX_SVC_KERNEL_POLY = 1 };
@@ -182,6 +184,13 @@ typedef struct gnx_model_desc {
    * padding=(S-1)/2, zero padding — see k_smooth_cnn.hip) over the windows + softmax over the A output channels */
   const float* cnn_weight;          /* (A_out, A_in, S) smoothNet[0].weight */
   const float* cnn_bias;            /* (A_out,) smoothNet[0].bias */
+
+  /* optional: the logistic base's PREPARED digit planes as gnx_model_export_prepared wrote them for this very model (a command line
+   * that loads the same model.pkl / .gnx on every start keeps them in a file beside it: preparing the planes is most of what
+   * gnx_model_load does).  Checked against a hash of lr_coef, the geometry, the ABI version and the plane settings; anything that
+   * does not match -> GNX_ESTALE, nothing loaded.  NULL / 0: prepare from lr_coef. */
+  const void* prepared;
+  int64_t prepared_bytes;
 } gnx_model_desc;
 
 typedef struct gnx_model_info {
@@ -232,6 +241,9 @@ int gnx_model_get_info(const gnx_model* model, gnx_model_info* out);
  * labels derived from them) go through Calibrator.transform; without a calibrator the reference prints a notice and
  * returns the original probabilities (smooth.py:48-52) — so does this (GNX_OK, outputs unchanged). */
 int gnx_model_set_calibrate(gnx_model* model, int on);
+/* the prepared planes of a loaded logistic model as one relocatable blob for gnx_model_desc.prepared: *bytes = its size (0 for models
+ * without a logistic base); buf == NULL only reports the size; cap < size -> GNX_EINVAL. */
+int gnx_model_export_prepared(gnx_model* model, void* buf, int64_t cap, int64_t* bytes);
 
 /* Base.predict_proba: X (N, ldx>=C) int8 -> B (N, W, A).  Either output may be NULL.
  * b_f32 is what the XGB smoother consumes (src/Smooth/utils.py:20), b_f64 what the reference returns. */
