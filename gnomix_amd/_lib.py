@@ -159,6 +159,7 @@ SYMBOLS = {
     "gnx_vcf_strings": (C.c_int, [_VP, _I, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_I64)]),
     "gnx_vcf_gt_int8": (C.c_int, [_VP, _VP, _I]),
     "gnx_io_inflate_raw": (C.c_int, [_VP, C.c_size_t, _VP, C.c_size_t]),
+    "gnx_io_crc32": (C.c_uint32, [_VP, C.c_size_t]),
     "gnx_gt2_to_x_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),
     "gnx_gt2_to_p2_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),
     "gnx_x_to_gt2_dev": (C.c_int, [_VP, _VP, _I64, _I64, _I64, _VP, _I64, _VP, _I64]),

@@ -37,6 +37,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------------
 struct BgzfBlock {
   size_t poff, psize, uoff, usize;  // payload (raw deflate) in the file, place in the text
+  uint32_t crc;                     // CRC-32 of the block's text (the member's trailer)
 };
 
 struct Source {
@@ -103,8 +104,9 @@ struct Source {
         return nullptr;
       }
       for (size_t k = lo; k < j; ++k)
-        if (!inflate_block(zmap + blocks[k].poff, blocks[k].psize, (uint8_t*)buf.data() + (blocks[k].uoff - base), blocks[k].usize)) {
-          *err = "corrupt BGZF block";
+        if (!inflate_block(zmap + blocks[k].poff, blocks[k].psize, (uint8_t*)buf.data() + (blocks[k].uoff - base), blocks[k].usize) ||
+            gnx_io_crc32((const uint8_t*)buf.data() + (blocks[k].uoff - base), blocks[k].usize) != blocks[k].crc) {
+          *err = "corrupt BGZF block (does not inflate to its stored size and CRC-32)";
           return nullptr;
         }
       return buf.data() + (off - base);
@@ -151,6 +153,7 @@ bool bgzf_table(const uint8_t* z, size_t zn, std::vector<BgzfBlock>& blocks, siz
     b.poff = o + xend;
     b.psize = (size_t)bsize - xend - 8;
     b.usize = rd32(h + bsize - 4);
+    b.crc = rd32(h + bsize - 8);
     if (b.usize > 65536) return false;  // not BGZF (the format bounds a block's text at 64 KiB): the serial gzip path decides
     b.uoff = total;
     total += b.usize;

@@ -81,6 +81,9 @@ int gnx_vcf_gt_int8(const gnx_vcf* vcf, int8_t* out, int n_threads);
  * decoder gnx_vcf_read inflates .vcf.gz queries with (csrc/gnx_inflate.cpp; zlib remains the fallback for a block it rejects).
  * 0: ok; -1: corrupt or truncated input, or a size other than out_n.  No context, no GPU. */
 int gnx_io_inflate_raw(const uint8_t* in, size_t in_n, uint8_t* out, size_t out_n);
+/* CRC-32 of the gzip / BGZF trailer (zlib's crc32(0, data, n)), by carry-less multiplication where the host has PCLMULQDQ (> 10 GB/s
+ * per thread: every BGZF block the reader inflates is checked against its trailer) */
+uint32_t gnx_io_crc32(const uint8_t* data, size_t n);
 
 /* ---- gt2 <-> the int8 matrix of the models, on the device (context stream; device pointers) --------------------------
  * src (C,) int32 describes vcf_to_npy's column map: src[c] = v | (flip << 30) — model SNP c is variant row v of G, with

@@ -489,4 +489,36 @@ def test_bgzf_windows_are_inflated_by_the_parsing_threads(tmp_path, monkeypatch,
         damaged = not all(np.array_equal(b[k], ref[k]) for k in ("calldata/GT", "variants/POS"))
     except Exception:
         damaged = True
-    assert damaged      # (BGZF's CRC is not verified, like zlib's raw inflate before: a flipped byte shows as an error or as different records)
+    assert damaged      # (a payload that no longer inflates to its stored size AND CRC-32 is an error: gnx_io_crc32 checks every block)
+
+
+def test_crc32_by_carryless_multiplication_equals_zlib():
+    """gnx_io_crc32 (PCLMULQDQ folding; zlib's crc32 for the unaligned head / tail and on hosts without the instruction) == zlib.crc32
+    for every length around the 16- and 64-byte boundaries, at every alignment; it is what checks each BGZF block against its trailer"""
+    import zlib
+    import gnomix_amd
+    lib = gnomix_amd.load_library()
+    rng = np.random.RandomState(7)
+    for n in list(range(0, 200)) + [255, 256, 257, 1000, 4095, 4096, 65535, 65536, (1 << 20) + 7]:
+        b = rng.randint(0, 256, size=n + 5).astype(np.uint8)
+        for off in (0, 1, 5):
+            v = b[off:off + n]
+            assert lib.gnx_io_crc32(v.ctypes.data, n) == (zlib.crc32(v.tobytes()) & 0xFFFFFFFF), (n, off)
+
+
+def test_bgzf_block_with_a_valid_stream_but_wrong_crc_is_refused(tmp_path):
+    """a block replaced by ANOTHER valid deflate stream of the same uncompressed size (sizes alone cannot tell) fails its CRC-32"""
+    import zlib
+    rng = np.random.default_rng(3)
+    txt = _vcf_text(rng, nv=60, ns=9).encode()
+    z = bytearray(_bgzf(txt, block=4096))
+    n0 = struct.unpack_from("<H", z, 16)[0] + 1                     # first member
+    isize = struct.unpack_from("<I", z, n0 - 4)[0]
+    other = bytes(reversed(txt[:isize]))                            # the same length, other text
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    payload = co.compress(other) + co.flush()
+    member = bytes(z[:16]) + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload + bytes(z[n0 - 8:n0])   # the ORIGINAL trailer (CRC of txt)
+    p = str(tmp_path / "q.vcf.gz")
+    open(p, "wb").write(member + bytes(z[n0:]))
+    with pytest.raises(Exception, match="corrupt BGZF"):
+        vcfio.read_vcf(p, n_threads=2)
