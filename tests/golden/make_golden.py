@@ -19,6 +19,8 @@ input/output pair produced by executing its own functions:
   G9 / G10 / G11   RFBase, PolynomialStringKernelBase, CNN smoother (see the functions)
   G12 / G13 / G14  third-party pins: xgboost smoother, CRFsuite smoother, XGBBase — generated only on a host that has
                    xgboost / sklearn_crfsuite (absent here: they print "skipped"); tests/test_pins_thirdparty.py consumes them
+  G18 / G19        third-party pins of the other tree bases: LGBMBase (lightgbm model strings), CBBase (catboost JSON exports)
+                   (models.py:38-52, 68-81) — likewise generated only where the packages exist
   G15_lr_binary.npz  A = 2 logistic base (sklearn's one-row binary form)
   G16_lr_train.npz   LogisticRegressionBase.train (base.py:104-127): training data + the reference's fitted coefficients
   G17_cnn_train.npz  CNN.fit (Smooth/cnn.py:104-118): data, initial and trained Conv1d parameters, the DataLoader's row order
@@ -697,6 +699,89 @@ def make_G14(out):
     return True
 
 
+def _tree_base_data(A, seed):
+    """training / query haplotypes of the per-window tree bases' pins (G14, G18, G19): every window sees every class"""
+    rng = np.random.RandomState(seed)
+    C, M = 1237, 100
+    W, ctx = C // M, 50
+    Xt, yt = synth_admixed(rng, 150, C, A, W, M, miss=0.04)
+    for w in range(W):
+        for a in range(A):
+            yt[a, w] = a
+    Xq, _ = synth_admixed(rng, 21, C, A, W, M, miss=0.06, switch_p=0.1)
+    return C, M, W, ctx, Xt, yt, Xq
+
+
+def _fit_windows(make_model, base_cls_name, C, M, A, ctx, Xt, yt, Xq, seed):
+    """the reference's own Base subclass when the checkout is present (src/Base/base.py:104-180), else one model per window with
+    the constructor arguments of src/Base/models.py on the oracle's window slices (pinned by G1) -> (B (N, W, A), fitted models)"""
+    sys.path.insert(0, ROOT)
+    from oracle import gnx_oracle as O
+    if os.path.isdir(REF):
+        import src.Base.models as RM
+        base = getattr(RM, base_cls_name)(chm_len=C, window_size=M, num_ancestry=A, missing_encoding=2, context=ctx, n_jobs=1,
+                                          seed=seed, verbose=False)
+        base.base_multithread = False
+        base.train(Xt, yt)
+        return np.asarray(base.predict_proba(Xq)), base.models
+    models, cols = [], []
+    wins_t, wins_q = dict(O.base_windows(Xt, M, ctx)), dict(O.base_windows(Xq, M, ctx))
+    for w in range(C // M):
+        m = make_model()
+        m.fit(wins_t[w], yt[:, w])
+        models.append(m)
+        cols.append(np.asarray(m.predict_proba(wins_q[w])))
+    return np.stack(cols, axis=1), models
+
+
+def make_G18(out):
+    """LGBMBase (src/Base/models.py:38-52): LGBMClassifier(n_estimators=20, max_depth=4, learning_rate=0.1, reg_lambda=1, reg_alpha=0)
+    per window on the window's int8 SNPs (the missing code 2 is an ordinary number to LightGBM: "use np.nan for missing encoding" is
+    only a comment there) -> per-window model strings (Booster.model_to_string()) + Base.predict_proba; A = 3 (multiclass) and A = 2
+    (binary: one tree per round, sigmoid)."""
+    if not have_real("lightgbm"):
+        print("G18 skipped: lightgbm is not installed (pip install lightgbm)")
+        return False
+    import lightgbm
+    d = dict(lightgbm_version=np.array(lightgbm.__version__), via_reference=os.path.isdir(REF))
+    for tag, A in (("m", 3), ("b", 2)):
+        C, M, W, ctx, Xt, yt, Xq = _tree_base_data(A, 94318 + A)
+        Bq, models = _fit_windows(lambda: lightgbm.LGBMClassifier(n_estimators=20, max_depth=4, learning_rate=0.1, reg_lambda=1, reg_alpha=0,
+                                                                  n_jobs=1, random_state=94318), "LGBMBase", C, M, A, ctx, Xt, yt, Xq, 94318)
+        strs = [m.booster_.model_to_string() for m in models]
+        d.update({tag + "_C": C, tag + "_M": M, tag + "_A": A, tag + "_ctx": ctx, tag + "_X": Xq, tag + "_B": Bq, tag + "_models": np.array(strs)})
+        print("G18", tag, "A", A, "B", Bq.shape, Bq.dtype)
+    np.savez_compressed(out, **d)
+    return True
+
+
+def make_G19(out):
+    """CBBase (src/Base/models.py:68-81): catboost.CatBoostClassifier(n_estimators=20, max_depth=4, reg_lambda=1) per window ->
+    per-window JSON exports (save_model(format="json"): oblivious trees, scale and bias) + Base.predict_proba; A = 3 (MultiClass)
+    and A = 2 (Logloss)."""
+    if not have_real("catboost"):
+        print("G19 skipped: catboost is not installed (pip install catboost)")
+        return False
+    import json
+    import tempfile
+    import catboost
+    d = dict(catboost_version=np.array(catboost.__version__), via_reference=os.path.isdir(REF))
+    for tag, A in (("m", 3), ("b", 2)):
+        C, M, W, ctx, Xt, yt, Xq = _tree_base_data(A, 94319 + A)
+        Bq, models = _fit_windows(lambda: catboost.CatBoostClassifier(n_estimators=20, max_depth=4, reg_lambda=1, thread_count=1, verbose=0),
+                                  "CBBase", C, M, A, ctx, Xt, yt, Xq, 94319)
+        exports = []
+        with tempfile.TemporaryDirectory() as td:
+            for w, m in enumerate(models):
+                fn = os.path.join(td, "w%d.json" % w)
+                m.save_model(fn, format="json")
+                exports.append(json.dumps(json.load(open(fn))))
+        d.update({tag + "_C": C, tag + "_M": M, tag + "_A": A, tag + "_ctx": ctx, tag + "_X": Xq, tag + "_B": Bq, tag + "_models": np.array(exports)})
+        print("G19", tag, "A", A, "B", Bq.shape, Bq.dtype)
+    np.savez_compressed(out, **d)
+    return True
+
+
 def make_G15(out):
     """A = 2 logistic base: sklearn keeps ONE coefficient row for a binary LogisticRegression(liblinear) and
     `_predict_proba_lr` returns [1 - expit(z), expit(z)] (no OvR normalisation).  Pins
@@ -770,12 +855,12 @@ def make_G16(out):
 
 
 def main():
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19"]
     have_ref = import_reference()
     if not have_ref:
         _stub_modules()
-        print("reference not found at", REF, "- only the third-party pins (G12-G14) can be generated")
-        which = [w for w in which if w in ("G12", "G13", "G14")]
+        print("reference not found at", REF, "- only the third-party pins (G12-G14, G18, G19) can be generated")
+        which = [w for w in which if w in ("G12", "G13", "G14", "G18", "G19")]
     if "G1" in which: make_G1(os.path.join(HERE, "G1_lr.npz"))
     if "G2" in which: make_G2(os.path.join(HERE, "G2_covrsk.npz"))
     if "G3" in which: make_G3(os.path.join(HERE, "G3_slide.npz"))
@@ -793,6 +878,8 @@ def main():
     if "G15" in which: make_G15(os.path.join(HERE, "G15_lr_binary.npz"))
     if "G16" in which: make_G16(os.path.join(HERE, "G16_lr_train.npz"))
     if "G17" in which: make_G17(os.path.join(HERE, "G17_cnn_train.npz"))
+    if "G18" in which: make_G18(os.path.join(HERE, "G18_lgbm_base.npz"))
+    if "G19" in which: make_G19(os.path.join(HERE, "G19_catboost_base.npz"))
     return 0
 
 

@@ -1,4 +1,4 @@
-"""Third-party pins for SURVEY §8 rows a6 (xgboost smoother), a7 (CRFsuite smoother) and XGBBase.
+"""Third-party pins for SURVEY §8 rows a6 (xgboost smoother), a7 (CRFsuite smoother), XGBBase, LGBMBase and CBBase.
 
 The arithmetic of those rows lives in xgboost==1.1.1 / sklearn-crfsuite==0.3.6 (reference requirements.txt:9,11),
 which are absent from the build image, so the oracle's restatement of them is "parity unpinned" (oracle/gnx_oracle.c
@@ -6,6 +6,7 @@ header).  The fixtures these tests read are produced by ONE comma
 
     pip install xgboost==1.1.1 sklearn-crfsuite==0.3.6
     python tests/golden/make_golden.py G12 G13 G14          # writes tests/golden/G1{2,3,4}_*.npz
+    pip install lightgbm catboost && python tests/golden/make_golden.py G18 G19      # LGBMBase / CBBase (src/Base/models.py:38-52, 68-81)
     python -m pytest tests/test_pins_thirdparty.py           # CPU: oracle + booster-bytes parser vs the real packages
     python -m pytest tests/test_pins_thirdparty.py -m gpu    # GPU box: the HIP kernels vs the same fixtures
 
@@ -25,7 +26,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT
 
-HOW = "generate it on a host with the package: python tests/golden/make_golden.py G12 G13 G14 (see this file's docstring)"
+HOW = "generate it on a host with the package: python tests/golden/make_golden.py G12 G13 G14 G18 G19 (see this file's docstring)"
 
 
 def _load(name, directory=GOLDEN):
@@ -130,9 +131,61 @@ def check_xgb_base(O, g, hip=None):
             assert np.array_equal(np.argmax(b32, -1), np.argmax(ref, -1))
 
 
+def _check_forest_base(O, g, convert_fn, hip=None, tol=2e-6):
+    """G18 / G19: per-window tree models of another library converted to the forest base's arrays -> oracle (and HIP) vs the library's
+    own predict_proba.  The library sums in float64, the forest kernels in float32 (xgboost's arithmetic): 2e-6 on probabilities."""
+    for tag in ("m", "b"):
+        C, M, A, ctx = (int(g[tag + "_" + k]) for k in ("C", "M", "A", "ctx"))
+        fb = convert_fn([str(x) for x in g[tag + "_models"]], A)
+        T = O.Trees(fb["fb_tree_off"], fb["fb_left"], fb["fb_right"], fb["fb_feat"], fb["fb_cond"], fb["fb_tree_class"], max(A, 2),
+                    default_left=fb["fb_default_left"])
+        ref = g[tag + "_B"]
+        X = g[tag + "_X"]
+        B = O.base_forest(T, fb["fb_win_tree0"], X, M, ctx, A, missing=2)
+        assert B.shape == ref.shape and np.max(np.abs(B - ref)) <= tol
+        sure = np.abs(np.sort(ref, -1)[..., -1] - np.sort(ref, -1)[..., -2]) > 10 * tol      # (an exact tie has no defined arg-max)
+        assert np.array_equal(np.argmax(B, -1)[sure], np.argmax(ref, -1)[sure])
+        assert (X == 2).any()                      # the missing code is compared as the number 2 somewhere
+        if hip is not None:
+            d = hip.GnxModelData(C=C, M=M, A=A, S=5, context=ctx, base_kind="forest", **fb)
+            b32, _ = hip.DeviceModel(d).base_predict(X, want_f32=True, want_f64=False)
+            assert np.max(np.abs(b32 - ref)) <= tol
+            assert np.array_equal(np.argmax(b32, -1)[sure], np.argmax(ref, -1)[sure])
+
+
+def check_lgbm_base(O, g, hip=None):
+    from gnomix_amd import convert
+    _check_forest_base(O, g, lambda models, A: convert.forest_from_lgbm_text(models, A, missing=2), hip)
+
+
+def check_catboost_base(O, g, hip=None):
+    from gnomix_amd import convert
+    _check_forest_base(O, g, lambda models, A: convert.forest_from_catboost_json(models, A, missing=2), hip)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the real pins (skip until generated)
 # ---------------------------------------------------------------------------------------------------------------------
+def test_pin_G18_lightgbm_base_vs_oracle(oracle):
+    check_lgbm_base(oracle, _load("G18_lgbm_base.npz"))
+
+
+def test_pin_G19_catboost_base_vs_oracle(oracle):
+    check_catboost_base(oracle, _load("G19_catboost_base.npz"))
+
+
+@pytest.mark.gpu
+def test_pin_G18_lightgbm_base_vs_hip(oracle):
+    import gnomix_amd
+    check_lgbm_base(oracle, _load("G18_lgbm_base.npz"), hip=gnomix_amd)
+
+
+@pytest.mark.gpu
+def test_pin_G19_catboost_base_vs_hip(oracle):
+    import gnomix_amd
+    check_catboost_base(oracle, _load("G19_catboost_base.npz"), hip=gnomix_amd)
+
+
 def test_pin_G12_xgboost_smoother_vs_oracle(oracle):
     check_xgb_smoother(oracle, _load("G12_xgb_smoother.npz"))
 
@@ -270,3 +323,107 @@ def test_generator_plumbing_with_standin_xgboost(oracle, tmp_path):
     check_xgb_smoother(oracle, g12)
     check_xgb_base(oracle, _load("G14_xgb_base.npz", str(outdir)))
     assert not os.path.exists(os.path.join(str(outdir), "G13_crf_smoother.npz"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# plumbing self-check for G18 / G19: STAND-IN lightgbm / catboost modules that write each library's documented model format around
+# random trees and evaluate the library's documented prediction rule directly.  Pins nothing.
+# ---------------------------------------------------------------------------------------------------------------------
+_STANDIN_LGBM = textwrap.dedent('''
+    """STAND-IN for lightgbm: random leaf-wise trees in Booster.model_to_string()'s text layout + LightGBM's own rule on them"""
+    import sys
+    import numpy as np
+    sys.path.insert(0, %(tests)r)
+    from test_host_cpu import _lgbm_model_string, _lgbm_predict
+    __version__ = "0.0-standin"
+
+    class _Booster:
+        def __init__(self, s):
+            self._s = s
+        def model_to_string(self):
+            return self._s
+
+    class LGBMClassifier:
+        def __init__(self, **kw):
+            self.kw = dict(kw)
+        def fit(self, X, y):
+            self.A = int(np.max(y)) + 1
+            rng = np.random.RandomState(int(self.kw.get("random_state", 0)) + X.shape[1])
+            s, self.trees, self.per_iter = _lgbm_model_string(rng, X.shape[1], self.A, rounds=int(self.kw.get("n_estimators", 10)))
+            self.booster_ = _Booster(s)
+            return self
+        def predict_proba(self, X):
+            return np.stack([_lgbm_predict(self.trees, self.per_iter, self.A, x) for x in np.asarray(X)])
+''')
+
+_STANDIN_CB = textwrap.dedent('''
+    """STAND-IN for catboost: random oblivious trees in save_model(format="json")'s layout + CatBoost's own rule on them"""
+    import json
+    import numpy as np
+    __version__ = "0.0-standin"
+
+    class CatBoostClassifier:
+        def __init__(self, **kw):
+            self.kw = dict(kw)
+        def fit(self, X, y):
+            self.A = int(np.max(y)) + 1
+            self.dims = 1 if self.A == 2 else self.A
+            rng = np.random.RandomState(7 + X.shape[1])
+            trees = []
+            for t in range(int(self.kw.get("n_estimators", 10))):
+                d = int(rng.randint(0, int(self.kw.get("max_depth", 4)) + 1))
+                splits = [{"float_feature_index": int(rng.randint(X.shape[1])), "border": float(rng.choice([0.5, 1.5, 0.25])),
+                           "split_type": "FloatFeature", "split_index": i} for i in range(d)]
+                trees.append({"splits": splits, "leaf_values": [float(np.float32(v)) for v in rng.randn(self.dims << d) * 0.4],
+                              "leaf_weights": [1] * (1 << d)})
+            self.model = {"oblivious_trees": trees, "scale_and_bias": [0.75, [float(b) for b in rng.randn(self.dims) * 0.2]],
+                          "features_info": {"float_features": []}}
+            return self
+        def save_model(self, fn, format="cbm"):
+            assert format == "json"
+            json.dump(self.model, open(fn, "w"))
+        def predict_proba(self, X):
+            m, out = self.model, []
+            for x in np.asarray(X):
+                raw = np.array(m["scale_and_bias"][1], dtype=np.float64)
+                for tr in m["oblivious_trees"]:
+                    idx = sum((1 << i) for i, sp in enumerate(tr["splits"]) if float(x[sp["float_feature_index"]]) > sp["border"])
+                    raw = raw + m["scale_and_bias"][0] * np.array(tr["leaf_values"][idx * self.dims:(idx + 1) * self.dims])
+                if self.dims == 1:
+                    p1 = 1.0 / (1.0 + np.exp(-raw[0]))
+                    out.append([1 - p1, p1])
+                else:
+                    e = np.exp(raw - raw.max())
+                    out.append(e / e.sum())
+            return np.array(out)
+''')
+
+
+def test_generator_plumbing_with_standin_lightgbm_and_catboost(oracle, tmp_path):
+    """NOT a pin.  Runs make_golden.py G18 / G19 in a fresh interpreter whose `lightgbm` / `catboost` are the stand-ins above (no
+    reference checkout: the constructor-arguments branch), then this file's checks on what they wrote: generator, converters and the
+    oracle comparison execute end to end and agree with each other."""
+    for name, src in (("lightgbm", _STANDIN_LGBM % {"tests": os.path.join(ROOT, "tests")}), ("catboost", _STANDIN_CB)):
+        pkg = tmp_path / name
+        pkg.mkdir()
+        (pkg / "__init__.py").write_text(src)
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    code = textwrap.dedent('''
+        import sys, os
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        os.environ["GNOMIX_REFERENCE"] = "/nonexistent"
+        import make_golden as mg
+        assert not mg.import_reference()
+        assert mg.have_real("lightgbm") and mg.have_real("catboost")
+        assert mg.make_G18(os.path.join(%r, "G18_lgbm_base.npz"))
+        assert mg.make_G19(os.path.join(%r, "G19_catboost_base.npz"))
+    ''') % (str(tmp_path), os.path.join(ROOT, "tests", "golden"), str(outdir), str(outdir))
+    env = dict(os.environ)
+    env["GNOMIX_REFERENCE"] = "/nonexistent"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    g18 = _load("G18_lgbm_base.npz", str(outdir))
+    assert str(g18["lightgbm_version"]) == "0.0-standin" and not bool(g18["via_reference"])
+    check_lgbm_base(oracle, g18)
+    check_catboost_base(oracle, _load("G19_catboost_base.npz", str(outdir)))
