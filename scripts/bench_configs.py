@@ -167,8 +167,9 @@ def c5a(N=25000, reps=2, reps_int8=None, verbose=True, ctx=None, only=None):
         k2 = prof(model.ctx)
         base_s = k2.get("k_base_logistic", float("nan")) * 1e-3
         alg_bytes = (C + 3) // 4 + W * A * 8                      # 2-bit X once + B float64 (the CRF's input) once
-        R = 2                                                      # windows a SNP feeds at context = M / 2: one 16-column tile per slot at A = 12
-        i8_ops = (C / 64.0) * 7 * R * (2 * 16 * 16 * 64) / 16.0    # per haplotype: chunks x limbs x tiles x one 16x16x64 MFMA per 16 rows
+        # R = 2 windows per SNP at context = M / 2: 24 class columns x 7 limbs = 168 flat columns = 11 MFMA tiles per 64 SNPs and 16 rows
+        # (k_base_logistic_p2f; one 16-column tile per slot would be 2 x 7 = 14)
+        i8_ops = (C / 64.0) * 11 * (2 * 16 * 16 * 64) / 16.0       # per haplotype
         res["resident_2bit"] = {"seconds": dt2, "haplotypes_per_s_per_gpu": N / dt2, "kernels_ms": k2, "outputs_identical_to_int8": same,
                                 "base_alg_bytes": alg_bytes * N, "base_hbm_frac": alg_bytes * N / base_s / HBM_PEAK,
                                 "base_i8_ops": i8_ops * N, "base_i8_mfma_frac": i8_ops * N / base_s / I8_MFMA_PEAK}
