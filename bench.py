@@ -372,6 +372,17 @@ def main():
         except Exception as e:
             res["e2e_vcf"] = {"error": repr(e)}
     if dist is not None:
+        # the other ranks wait for rank 0's file leg (a minute of work that drives THEIR GPUs too) on the rendezvous store, on the CPU:
+        # an RCCL barrier would sit on every GPU as a spinning kernel for that long, beside the leg's own kernels
+        try:
+            from datetime import timedelta
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("gnx_bench_rank0_legs_done", "1")
+            else:
+                store.wait(["gnx_bench_rank0_legs_done"], timedelta(minutes=30))
+        except Exception:
+            pass
         dist.barrier()
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:

@@ -70,10 +70,54 @@ __device__ __forceinline__ double gnx_exp_sc(double x) {
   gnx_exp_scN<1>(v);
   return v[0];
 }
+
+// ---- the logistic bases' sigmoid and row normaliser: ONE definition for every logistic kernel (k_base_logistic_i8 / _i8_dl / _p2 /
+// _p2f are bit-identical to each other and stay so).  The compiler's IEEE division is eleven float64 instructions (two v_div_scale,
+// v_rcp, four fma, mul, fma, v_div_fmas, v_div_fixup) and a logistic output divided twice — 1 / (1 + e^-t), then p / sum(p); float64
+// vector instructions come out of the SIMD's matrix-pipe time, so the epilogues were a fifth of the 2-bit passes.
+// The operands here are benign (1 + e^-t in [1, 3e307], sum(p) in [3e-308, A]: normal numbers, no scaling needed):
+//   gnx_rcp_nr(y)   v_rcp_f64 + two Newton steps: within 1 ulp of 1 / y (five instructions)
+//   gnx_sigmoid     1 / (1 + e^-t) with -t capped at 708 (e^708 = 3e307 stays finite: beyond it the reference's own value is below
+//                   1e-307 — or, past 709.78, exactly 0 — and its row normaliser 0 / 0)
+//   normaliser      p * gnx_rcp_nr(sum): one reciprocal per row, one multiplication per class
+// against the reference's float64 division each result differs by at most ~2 ulp; the tests' bar on B is 1e-12.
+__device__ __forceinline__ double gnx_rcp_nr(double y) {
+  double r = __builtin_amdgcn_rcp(y);
+  double e = __builtin_fma(-y, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-y, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+template <int N>
+__device__ __forceinline__ void gnx_sigmoidN(double (&v)[N]) {  // in: t (logit + intercept); out: 1 / (1 + e^-t); N independent chains
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __builtin_fmin(-v[i], 708.0);
+  gnx_exp_scN<N>(v);
+  double r[N], e[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { v[i] = 1.0 + v[i]; r[i] = __builtin_amdgcn_rcp(v[i]); }
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-v[i], r[i], 1.0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_fma(r[i], e[i], r[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-v[i], r[i], 1.0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __builtin_fma(r[i], e[i], r[i]);
+}
+__device__ __forceinline__ double gnx_sigmoid(double t) {
+  double v[1] = {t};
+  gnx_sigmoidN<1>(v);
+  return v[0];
+}
 #else   // host pass: never called
 __device__ inline double gnx_exp_sc(double x) { return x; }
 template <int N>
 __device__ inline void gnx_exp_scN(double (&)[N]) {}
+__device__ inline double gnx_rcp_nr(double y) { return y; }
+template <int N>
+__device__ inline void gnx_sigmoidN(double (&)[N]) {}
+__device__ inline double gnx_sigmoid(double t) { return t; }
 #endif
 
 // xgboost's Softmax exponentiates a float32 margin difference with expf; glibc's expf is correctly rounded in all but a vanishing

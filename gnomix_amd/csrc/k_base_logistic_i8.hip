@@ -224,14 +224,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8(BaseLRLaunch L)
             double* z = zb + lane * A;
             double sum = 0.0;
             for (int a = 0; a < A; ++a) {
-              const double p = 1.0 / (1.0 + gnx_exp_sc(-(z[a] + tab_ic[(w - wt0) * A + a])));
+              const double p = gnx_sigmoid(z[a] + tab_ic[(w - wt0) * A + a]);
               z[a] = p;
               sum += p;
             }
             if (n < L.N) {
               const size_t o = ((size_t)n * W + w) * A;
+              const double rs = gnx_rcp_nr(sum);
               for (int a = 0; a < A; ++a) {
-                const double v = z[a] / sum;
+                const double v = z[a] * rs;
                 if (L.b64) L.b64[o + a] = v;
                 if (L.b32) L.b32[o + a] = (float)v;
               }

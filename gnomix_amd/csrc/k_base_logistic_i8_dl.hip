@@ -215,7 +215,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8_dl(BaseLRLaunch
             const double* ic = tab_ic + (w - wt0) * A;
             for (int e = lane; e < ne; e += 64) {
               const int a = e % A;
-              zb[e] = 1.0 / (1.0 + gnx_exp_sc(-(zb[e] + ic[a])));
+              zb[e] = gnx_sigmoid(zb[e] + ic[a]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (int e = lane; e < ne; e += 64) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_base_logistic_i8_dl(BaseLRLaunch
               const double* z = zb + rl * A;
               double sum = 0.0;
               for (int c = 0; c < A; ++c) sum += z[c];
-              const double v = z[a] / sum;
+              const double v = z[a] * gnx_rcp_nr(sum);
               const int64_t n = n0 + rl;
               if (n < L.N) {
                 const size_t o = ((size_t)n * W + w) * A + a;

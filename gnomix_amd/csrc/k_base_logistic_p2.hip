@@ -245,7 +245,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
     const double* ic = tab_ic + (w - wt0) * A;
     for (int it = it0; it < it1; ++it) {
       const int a = fsub + it * lpr;
-      if (a < A) zr[a] = 1.0 / (1.0 + gnx_exp_sc(-(zr[a] + ic[a])));
+      if (a < A) zr[a] = gnx_sigmoid(zr[a] + ic[a]);
     }
   };
   auto finish = [&](double* zr0, int w, int64_t nrow0, int rows) {
@@ -255,7 +255,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own phase-1 writes (LDS ops of one wave complete in order)
       double sum = 0.0;
       for (int c = 0; c < A; ++c) sum += zr[c];
-      for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] / sum;
+      const double rs = gnx_rcp_nr(sum);
+      for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] * rs;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     int rl = e_r0, a = e_a0;
@@ -680,11 +681,9 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       for (int i = 0; i < NB; ++i) {
         a[i] = fsub + (NB * it + i) * lpr;
         const int ac = min(a[i], A - 1);
-        v[i] = -(zr[ac] + ic[ac]);
+        v[i] = zr[ac] + ic[ac];
       }
-      gnx_exp_scN<NB>(v);
-#pragma unroll
-      for (int i = 0; i < NB; ++i) v[i] = 1.0 / (1.0 + v[i]);
+      gnx_sigmoidN<NB>(v);
 #pragma unroll
       for (int i = 0; i < NB; ++i)
         if (a[i] < A) zr[a[i]] = v[i];
@@ -698,14 +697,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     double sum = 0.0;
     for (int c = 0; c < A; ++c) sum += zr[c];
-    for (int a0 = fsub; a0 < A; a0 += PB * lpr) {   // PB independent divisions at a time
-      double q[PB];
-#pragma unroll
-      for (int i = 0; i < PB; ++i) q[i] = zr[min(a0 + i * lpr, A - 1)] / sum;
-#pragma unroll
-      for (int i = 0; i < PB; ++i)
-        if (a0 + i * lpr < A) zr[a0 + i * lpr] = q[i];
-    }
+    const double rs = gnx_rcp_nr(sum);
+    for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] * rs;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
@@ -915,11 +908,12 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
           const int lpr = 64 / ZROWS, frow = lane % ZROWS, fsub = lane / ZROWS;
           double* zr = zw + frow * A;
           const double* ic = tab_ic + (w - wt0) * A;
-          for (int a = fsub; a < A; a += lpr) zr[a] = 1.0 / (1.0 + gnx_exp_sc(-(zr[a] + ic[a])));
+          for (int a = fsub; a < A; a += lpr) zr[a] = gnx_sigmoid(zr[a] + ic[a]);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           double sum = 0.0;
           for (int c = 0; c < A; ++c) sum += zr[c];
-          for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] / sum;
+          const double rs = gnx_rcp_nr(sum);
+          for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] * rs;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         store_rows(zw, w, n0, ZROWS);

@@ -68,7 +68,7 @@ def test_bench_force_dist_runs_the_rccl_path_on_one_gpu():
     e = _env()
     e["GNX_BENCH_FORCE_DIST"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--haps", "512",
-                        "--cpu-seconds", "0", "--e2e-steps", "0"], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+                        "--cpu-seconds", "0", "--e2e-steps", "0", "--configs", "0"], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-4000:]
     assert r.stdout.strip().splitlines()[-1].startswith("{"), r.stdout[-500:]   # the JSON line is the last line
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -83,7 +83,7 @@ def test_bench_force_dist_with_the_file_leg_on_two_contexts():
     e["GNX_BENCH_FORCE_DIST"] = "1"
     e["GNX_BENCH_VCF_DEVICES"] = "0,0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--haps", "512",
-                        "--cpu-seconds", "0", "--e2e-steps", "0", "--vcf-reps", "1", "--trained", "0"], capture_output=True, text=True,
+                        "--cpu-seconds", "0", "--e2e-steps", "0", "--vcf-reps", "1", "--trained", "0", "--configs", "0"], capture_output=True, text=True,
                        timeout=900, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
