@@ -30,9 +30,10 @@
 //        compute wave, run r:   barrier(2r), X(r) LDS -> registers, entries 0, 1, barrier(2r+1), entries 2, 3, park finished windows
 //        epilogue wave:         barrier, its share of the parked window, barrier, ...
 //  * COLUMN TILES.  Up to 16 class columns per SNP (R A <= 16, e.g. A = 7 at the default context): one tile, column = slot A + class,
-//    as in the int8 kernels.  More (A = 12: 24 columns): one tile PER SLOT (column = class) and one PASS per tile — blocks of pass t
-//    multiply only tile t and finish only the windows w with w % R == t, so every pass is the one-tile kernel (256 rows per block, 119
-//    VGPRs) and X is read R times, at a quarter byte per SNP (the two-tile int8 kernels need 112 accumulator registers per 32 rows).
+//    as in the int8 kernels.  More: one tile PER SLOT (column = class) and one PASS per tile — blocks of pass t multiply only tile t
+//    and finish only the windows w with w % R == t, so every pass is the one-tile kernel (256 rows per block) and X is read R times,
+//    at a quarter byte per SNP (the two-tile int8 kernels need 112 accumulator registers per 32 rows).  EXACTLY 24 columns (A = 12 at
+//    the default context, BASELINE config 5) run k_base_logistic_p2f below instead: flat column tiles, both slots per wave, X once.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
