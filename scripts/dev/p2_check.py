@@ -14,7 +14,7 @@ from gnomix_amd import synth
 
 GEOMS = [(20500, 1000, 7, 500, 2100), (30500, 1000, 12, 500, 1100), (4037, 100, 7, 50, 24), (4037, 100, 7, 0, 5), (2531, 100, 3, 30, 70), (1999, 64, 2, 32, 130), (3001, 100, 12, 50, 33),
          (2201, 100, 9, 50, 600), (1801, 60, 7, 45, 50), (1503, 100, 16, 50, 9), (2777, 100, 5, 120, 40), (1237, 50, 7, 25, 600),
-         (1237, 50, 7, 25, 1), (937, 300, 4, 150, 66), (20500, 1000, 7, 500, 700), (20500, 1000, 12, 500, 300)]
+         (1237, 50, 7, 25, 1), (937, 300, 4, 150, 66), (20500, 1000, 7, 500, 700), (20500, 1000, 12, 500, 300), (2401, 100, 8, 100, 70)]
 
 
 def check():

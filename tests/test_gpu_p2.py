@@ -49,7 +49,10 @@ GEOMS = [
     (1237, 50, 7, 25, 1),        # a single haplotype
     (937, 300, 4, 150, 66),      # W = 3 windows only
     (20500, 1000, 7, 500, 700),  # the chr22 window shape (two 256-SNP runs per piece), three row tiles, epilogue waves
-    (30500, 1000, 12, 500, 1100),  # the same with two passes
+    (30500, 1000, 12, 500, 1100),  # the same with 24 class columns: flat column tiles (k_base_logistic_p2f) at 256-SNP runs, two passes at 512
+    (2401, 100, 8, 100, 70),     # ratio 1.0: R = 3 slots x A = 8 = 24 columns: the flat kernel with three slots of eight columns
+    (3001, 100, 12, 50, 700),    # flat tiles, three row tiles of 256
+    (3107, 100, 12, 50, 1),      # flat tiles, one haplotype
 ]
 
 
@@ -239,3 +242,39 @@ def test_gnofix_packed_goldens_G5(ga):
         assert np.array_equal(Xq[0], g[name + "_oXm"]) and np.array_equal(Xq[1], g[name + "_oXp"]), name
         assert np.array_equal(Yq[0], g[name + "_oYm"]) and np.array_equal(Yq[1], g[name + "_oYp"]), name
         assert int(nq[0]) == int(g[name + "_nhist"]) - 2
+
+
+@pytest.mark.parametrize("C,M,A,ctx,N", [(5003, 100, 12, 50, 300), (20500, 1000, 12, 500, 520), (2401, 100, 8, 100, 33)])
+def test_p2_flat_tiles_every_variant(ga, monkeypatch, C, M, A, ctx, N):
+    """24 class columns: the flat-tile kernel's block shapes (4 / 2 / no epilogue waves, 3- and 2-step plane rings; GNX_P2_TUNE) and the
+    slot-tile two-pass kernel it replaces (GNX_LR_P2_FLAT=0) all give the int8 kernels' B bit for bit — also with an output base that
+    is not 16-byte aligned (the 1 KB stores fall back to 512-byte ones)"""
+    import torch
+    from gnomix_amd import synth, _lib
+    monkeypatch.setenv("GNX_LR_P2", "2")
+    d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=ctx, seed=C, smooth=None)
+    X = synth.synthetic_X(N, C, seed=N, miss=0.03)
+    ref = None
+    for flat, tune in (("1", None), ("1", "2,8,2,2,3"), ("1", "2,8,0,2,3"), ("1", "2,8,4,2,2"), ("1", "2,8,0,2,2"), ("0", None)):
+        monkeypatch.setenv("GNX_LR_P2_FLAT", flat)
+        if tune:
+            monkeypatch.setenv("GNX_P2_TUNE", tune)
+        else:
+            monkeypatch.delenv("GNX_P2_TUNE", raising=False)
+        ctx_ = _lib.Context(0)
+        dev = ga.DeviceModel(d, ctx=ctx_)
+        for f64 in (True, False):
+            b_i8, b_p2 = _both(dev, X, f64)
+            assert np.array_equal(b_i8, b_p2), (flat, tune, f64)
+        if ref is None:
+            ref = b_p2
+        if flat == "1" and tune is None:      # unaligned output: B at an odd element offset of a larger tensor
+            P = torch.from_numpy(np.asarray(dev.pack_x(X))).cuda()
+            W = C // M
+            big = torch.zeros(N * W * A + 1, dtype=torch.float64, device="cuda")
+            dev._bind_torch_stream()
+            dev.ctx.check(dev.lib.gnx_base_predict_packed_dev(dev.h, P.data_ptr(), N, P.stride(0), None, big.data_ptr() + 8))
+            torch.cuda.synchronize()
+            assert np.array_equal(big[1:].cpu().numpy().reshape(N, W, A), _both(dev, X, True)[1])
+        dev.close()
+        ctx_.close()
