@@ -551,7 +551,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     }
   }
   __syncthreads();
-  const int abl = L.flags;  // GNX_LR_FLAGS (timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes, 32 no barriers / stores, 64 no combine
+  const int abl = L.flags;  // GNX_LR_FLAGS (timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes, 32 no barriers / stores, 64 no combine,
+                            // 128 no epilogue priority, 1024 no stores to B (config 5a, one box: 7.46 ms; 1024: 7.03; 4: 5.38)
   const bool nobar = (abl & 32) != 0;
   const bool dbg_on = DBG && L.dbg != nullptr;   // development instantiation: cycle counters of wave 0 of every role, 16 per block
   unsigned long long* dbg = L.dbg + (size_t)blockIdx.x * 16;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       const int e_end = min(rows * A, 128 * i1);
       for (int e = 2 * lane + 128 * i0; e < e_end; e += 128) {
         const int64_t n = nrow0 + rl;
-        if (n < L.N && !(abl & 32)) {
+        if (n < L.N && !(abl & (32 | 1024))) {
           const size_t o = (size_t)n * W * A + ow + a;
           const v2d v = *reinterpret_cast<const v2d*>(zr0 + e);
           if (L.b64) *reinterpret_cast<v2d*>(L.b64 + o) = v;
@@ -659,7 +660,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     const int e_end = min(rows * A, 64 * i1);
     for (int e = lane + 64 * i0; e < e_end; e += 64) {
       const int64_t n = nrow0 + rl;
-      if (n < L.N && !(abl & 32)) {
+      if (n < L.N && !(abl & (32 | 1024))) {
         const size_t o = (size_t)n * W * A + ow + a;
         const double v = zr0[e];
         if (L.b64) L.b64[o] = v;
