@@ -472,11 +472,23 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
 // register at a window's end, then the same exact combine() — Z, and with it B, stay BIT-IDENTICAL to the int8 kernels'.
 // A window's end zeroes only its slot's columns (the other slot's window is in mid-flight): lane-predicated moves, tile by tile.
 // =====================================================================================================================================
+#ifndef GNX_P2F_PD
+#define GNX_P2F_PD 2
+#endif
+#ifndef GNX_P2F_FLUSH_GROUP
+#define GNX_P2F_FLUSH_GROUP 1
+#endif
+#ifndef GNX_P2F_PBR
+#define GNX_P2F_PBR 4
+#endif
+#ifndef GNX_P2F_NSP
+#define GNX_P2F_NSP 2
+#endif
 constexpr int NFT = GNX_LR_FLAT_TILES;   // 11
 constexpr int NCF = GNX_LR_FLAT_COLS;    // 24
 
 __device__ __forceinline__ int ror8(int v) {  // the value of the lane 8 away within the 16-lane row
-  return __builtin_amdgcn_update_dpp(0, v, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, 0x128 /* row_ror:8 */, 0xf, 0xf, true);  // (every lane has a source: bound_ctrl spares the move that would preset the result)
 }
 
 __device__ __forceinline__ double combine7(int a0, int a1, int a2, int a3, int a4, int a5, int a6, double scale) {  // combine() on gathered limbs
@@ -554,8 +566,15 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   const int abl = L.flags;  // GNX_LR_FLAGS (timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes, 32 no barriers / stores, 64 no combine,
                             // 128 no epilogue priority, 1024 no stores to B (config 5a, one box: 7.46 ms; 1024: 7.03; 4: 5.38)
   const bool nobar = (abl & 32) != 0;
+  const bool pair_ok = (abl & (1 << 24)) != 0;   // set by the launcher: every window spans few enough SNPs for limb pairs in int32
   const bool dbg_on = DBG && L.dbg != nullptr;   // development instantiation: cycle counters of wave 0 of every role, 16 per block
   unsigned long long* dbg = L.dbg + (size_t)blockIdx.x * 16;
+  // ... and of block 8 a trace: [step][16] = when each of the 14 waves reached the step's barrier, [14] = when wave 0 left it, [15] = flush cycles
+  constexpr int TRACE_STEPS = 256;
+  unsigned long long* trace = dbg_on && blockIdx.x == 8 ? L.dbg + (size_t)gridDim.x * 16 : nullptr;
+  auto tr = [&](int step, int slot, unsigned long long v) {
+    if (DBG && trace && lane == 0 && step < TRACE_STEPS) trace[(size_t)step * 16 + slot] = v;
+  };
 
   if (wave == CW + EW) {
     // ================================================== plane loader ==================================================
@@ -577,6 +596,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       const unsigned long long t0 = dbg_on ? __builtin_readcyclecounter() : 0;
       wait_vm<(D - 1) * NKB>();
       const unsigned long long t1 = dbg_on ? __builtin_readcyclecounter() : 0;
+      tr(s, wave, t1);
       if (!nobar) __builtin_amdgcn_s_barrier();
       const unsigned long long t2 = dbg_on ? __builtin_readcyclecounter() : 0;
       issue_planes(s + D);
@@ -611,8 +631,10 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     for (int r = 0; r < n_runs; ++r) {
       wait_vm<(XSN >= 2 ? XSN - 2 : 0) * XTILES>();   // X(r) has landed (only X(r+1) .. X(r+XSN-2) are younger)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (DBG) tr(2 * r, wave, __builtin_readcyclecounter());
       if (!nobar) __builtin_amdgcn_s_barrier();   // first step of the run: every wave is done with run r - 1
       if (XSN >= 2) issue_x(r + XSN - 1);
+      if (DBG) tr(2 * r + 1, wave, __builtin_readcyclecounter());
       if (!nobar) __builtin_amdgcn_s_barrier();   // second step
     }
     wait_vm<0>();
@@ -717,8 +739,9 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     // (Float64 vector work runs on the SIMD's matrix pipe wherever it is issued — an epilogue wave's ~550 cycles per step come straight
     // out of its SIMD's MFMA time — so the total is fixed and only the spread over the steps matters.  Smaller units (two sigmoids, one
     // store instruction) with or without a per-step time budget measured 3-6 % SLOWER than these eight units per window.)
-    const int n_it = (A + PB * (64 / CHR) - 1) / (PB * (64 / CHR));   // phase-1 iterations of a lane: PB classes each
-    constexpr int NSP = 2;                                             // the stores of a chunk in NSP parts
+    const int pbr = ((abl >> 16) & 7) ? min((abl >> 16) & 7, 4) : GNX_P2F_PBR;   // classes of a lane per phase-1 unit (GNX_LR_FLAGS bits 16-18: A/B timing)
+    const int n_it = (A + pbr * (64 / CHR) - 1) / (pbr * (64 / CHR));   // phase-1 iterations of a lane: pbr classes each
+    const int NSP = ((abl >> 20) & 7) ? ((abl >> 20) & 7) : GNX_P2F_NSP;  // the stores of a chunk in NSP parts (bits 20-22)
     const int n_sti = (CHR * A + spi - 1) / spi, sti_part = (n_sti + NSP - 1) / NSP;
     const int upc = n_it + 1 + NSP;                                    // units per chunk
     const int n_units = NCH * upc;
@@ -730,8 +753,14 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       for (; job_unit < u_end; ++job_unit) {
         const int ch = job_unit / upc, it = job_unit - ch * upc;
         double* z = job_z + (size_t)ch * CHR * A;
-        if (it < n_it) phase1(z, job_w, it, it + 1, CHR);
-        else if (it == n_it) normalise(z, CHR);
+        if (it < n_it) {
+          switch (pbr) {
+            case 1: phase1_n(std::integral_constant<int, 1>{}, z, job_w, it, it + 1, CHR); break;
+            case 2: phase1_n(std::integral_constant<int, 2>{}, z, job_w, it, it + 1, CHR); break;
+            case 3: phase1_n(std::integral_constant<int, 3>{}, z, job_w, it, it + 1, CHR); break;
+            default: phase1_n(std::integral_constant<int, 4>{}, z, job_w, it, it + 1, CHR); break;
+          }
+        } else if (it == n_it) normalise(z, CHR);
         else store_rows(z, job_w, nrow0 + ch * CHR, CHR, (it - n_it - 1) * sti_part, (it - n_it) * sti_part);
       }
     };
@@ -746,6 +775,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
 #pragma unroll
       for (int h = 0; h < SPR; ++h) {
         const unsigned long long t0 = dbg_on ? __builtin_readcyclecounter() : 0;
+        tr(SPR * r + h, wave, t0);
         lds_barrier(nobar);
         const unsigned long long t1 = dbg_on ? __builtin_readcyclecounter() : 0;
         job_work();
@@ -782,32 +812,43 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
 #pragma unroll
     for (int t = 0; t < NFT; ++t) acc[mt][t] = v4i{0, 0, 0, 0};
 
-  // one entry = 11 flat tiles x MT row tiles; the digit planes of tile t + 1 are on their way from LDS while tile t multiplies
-  // (hipcc, left alone, read two tiles, waited for both, multiplied, read the next two: the matrix pipe idled for an LDS round trip
-  // every four MFMAs)
-  auto mfma_entry = [&](const uint8_t* pb, const int (&xw)[MT]) {
+  // one step = 2 entries x 11 flat tiles x MT row tiles, ONE software pipeline over its 22 KB of digit planes: the planes of tiles
+  // t + 1 .. t + PD are on their way from LDS while tile t multiplies.  hipcc would not build it: whatever the source order, every
+  // wait it places in a kernel that also holds LDS-DMA loads is `s_waitcnt lgkmcnt(0)` — "all LDS reads back" — so a read issued ahead
+  // is waited for together with the one that is needed, and the wave sat through one LDS round trip (~100 cycles) per tile with 32
+  // cycles of MFMA to show for it (2 370 cycles per step for 44 MFMAs).  The reads and their waits are therefore written out:
+  // ds_read_b128 as inline asm (the compiler does not know the register is pending, the wait that covers it is tied to it by a
+  // "+v" operand and comes before its only uses) and s_waitcnt lgkmcnt(n) with n = the reads issued behind the tile; a
+  // sched_barrier per tile keeps the stages in this order.  LDS returns in order, so the count is exact.
+  constexpr int PD = GNX_P2F_PD;   // prefetch distance in tiles
+  auto mfma_step = [&](const uint8_t* pb, const int (&xw0)[MT], const int (&xw1)[MT]) {
     if (abl & 2) return;
+    constexpr int NT = 2 * NFT;
+    const unsigned la = (unsigned)(uintptr_t)(lptr_t)(pb) + (unsigned)lane * 16u;
+    v4i buf[PD + 1];
+#pragma unroll
+    for (int t = 0; t < PD; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(buf[t]) : "v"(la), "n"(t * 1024));
     v4i xa[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xw[mt]);
-    const v4i* vb = reinterpret_cast<const v4i*>(pb) + lane;
-    v4i b = vb[0];
+    for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xw0[mt]);
 #pragma unroll
-    for (int t = 0; t < NFT; ++t) {
-      v4i bn = b;
-      if (t + 1 < NFT) bn = vb[(t + 1) * 64];
+    for (int t = 0; t < NT; ++t) {
+      // read (tile t + PD) and wait for tile t in ONE asm statement whose only output is the NEW register set: a separate wait tied
+      // to the set the MFMAs are about to read made it look freshly written, and the hazard recogniser put an s_nop before them
+      if (t + PD < NT)
+        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(%3)" : "=v"(buf[(t + PD) % (PD + 1)]) : "v"(la), "n"((t + PD) * 1024), "n"(PD) : "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NT - 1 - t) : "memory");
+      if (t == NFT) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][t], 0, 0, 0);
-      b = bn;
+        for (int mt = 0; mt < MT; ++mt) xa[mt] = unpack16(xw1[mt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the MFMAs stay behind the wait ...
+      const int tt = t < NFT ? t : t - NFT;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], buf[t % (PD + 1)], acc[mt][tt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // ... and ahead of the next read, which overwrites the set two tiles on
     }
-    // the order above, pinned for the machine scheduler: read (tile 0), then [read (tile t + 1), MT MFMAs (tile t)] ...
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-    for (int t = 0; t + 1 < NFT; ++t) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);  // MT MFMAs
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
   };
 
   // ---- EW == 0: SELF-SERVICE epilogue.  Dedicated epilogue waves meet the compute waves at every step's barrier with a different
@@ -859,34 +900,62 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       const int col = in_hi ? i16 + 16 : i16;
       const bool home = in_lo || in_hi;
       const bool lo8 = col < 8;
+      // ... and as the SOURCE of the odd limbs of the lane 8 away, whose column decides which tile they come from: choosing here,
+      // ahead of the move, is one select + one DPP move per odd limb (choosing there: two moves + one select)
+      const bool plo8 = ror8(lo8 ? 1 : 0) != 0;
+      // where the lane parks (row 4 kq of the wave's rows, class col - c0) and whether it does, worked out ONCE per window: left to
+      // itself the compiler re-derived both for each of the eight accumulator registers (~20 instructions each) rather than hold them
+      const unsigned long long home_mask = __builtin_amdgcn_ballot_w64(home);
+      int zoff = 4 * kq * A + (col - c0);
+      asm volatile("" : "+v"(zoff));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         if (out && !(abl & 64)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {  // int32 16x16 C/D layout: column = lane & 15, row = 4 (lane >> 4) + reg
-            int ev[3], od[3];
+            double z;
+            if (pair_ok) {
+              // limbs in pairs, p_k = a_2k + 256 a_2k+1 in int32 (|a| <= 256 K for a window of K SNPs: the launcher checks the span),
+              // V = p_0 + 2^16 p_1 + 2^32 p_2 + 2^48 a_6 as P + 2^32 Q with P, Q exact in float64: ONE rounding, that of combine()
+              int pk[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const int x1 = ror8(acc[mt][3 * k + 1][r]), x2 = ror8(acc[mt][3 * k + 2][r]);
-              ev[k] = in_hi ? acc[mt][3 * k + 1][r] : acc[mt][3 * k][r];
-              od[k] = lo8 ? x1 : x2;
+              for (int k = 0; k < 3; ++k) {
+                const int ev = in_hi ? acc[mt][3 * k + 1][r] : acc[mt][3 * k][r];
+                const int od = ror8(plo8 ? acc[mt][3 * k + 1][r] : acc[mt][3 * k + 2][r]);
+                pk[k] = (int)(((unsigned)od << 8) + (unsigned)ev);
+              }
+              const int l6 = in_hi ? acc[mt][10][r] : acc[mt][9][r];
+              const double P = __builtin_fma((double)pk[1], 65536.0, (double)pk[0]);
+              const double Q = __builtin_fma((double)l6, 65536.0, (double)pk[2]);
+              z = __builtin_fma(Q, 4294967296.0, P) * scale;
+            } else {
+              int ev[3], od[3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                ev[k] = in_hi ? acc[mt][3 * k + 1][r] : acc[mt][3 * k][r];
+                od[k] = ror8(plo8 ? acc[mt][3 * k + 1][r] : acc[mt][3 * k + 2][r]);
+              }
+              const int l6 = in_hi ? acc[mt][10][r] : acc[mt][9][r];
+              z = combine7(ev[0], od[0], ev[1], od[1], ev[2], od[2], l6, scale);
             }
-            const int l6 = in_hi ? acc[mt][10][r] : acc[mt][9][r];
-            const double z = combine7(ev[0], od[0], ev[1], od[1], ev[2], od[2], l6, scale);
-            if (home) zw[(mt * 16 + 4 * kq + r) * A + (col - c0)] = z;
-            __builtin_amdgcn_sched_barrier(0);  // one register's gather at a time: the accumulators leave no room for four in flight
+            if (__builtin_amdgcn_inverse_ballot_w64(home_mask)) zw[zoff + (mt * 16 + r) * A] = z;
+            if (GNX_P2F_FLUSH_GROUP == 1 || (r % GNX_P2F_FLUSH_GROUP) == GNX_P2F_FLUSH_GROUP - 1)
+              __builtin_amdgcn_sched_barrier(0);  // GROUP registers' gathers at a time: the accumulators leave no room for four in flight
           }
         }
-        // zero the slot's columns: lane column i16 of tile t is flat column q = 16 t + i16 = 24 limb + column
+      }
+      // zero the slot's columns: lane column i16 of tile t is flat column q = 16 t + i16 = 24 limb + column, so the lanes to zero
+      // repeat every three tiles — three predicated REGIONS (exec masks, plain moves) instead of a select per register
+      // (flat columns >= 168 of the last tile are padding: their planes are zero, zeroing their accumulators too changes nothing)
 #pragma unroll
-        for (int t = 0; t < NFT; ++t) {
-          constexpr int dummy = 0; (void)dummy;
-          const int off = (16 * t) % NCF;                 // compile-time after unrolling
-          int c = off + i16;
-          c = c >= NCF ? c - NCF : c;
-          const bool z0 = c >= c0 && c < c0 + A && (16 * t + i16 < NCF * LIMBS);
+      for (int kk = 0; kk < 3; ++kk) {
+        int c = (16 * kk) % NCF + i16;
+        c = c >= NCF ? c - NCF : c;
+        if (c >= c0 && c < c0 + A) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mt][t][r] = z0 ? 0 : acc[mt][t][r];
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = kk; t < NFT; t += 3) acc[mt][t] = v4i{0, 0, 0, 0};
         }
       }
       if (!out) continue;
@@ -929,8 +998,10 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
 #pragma unroll
     for (int h = 0; h < SPR; ++h) {
       const unsigned long long t0 = dbg_on ? __builtin_readcyclecounter() : 0;
+      tr(SPR * r + h, wave, t0);
       lds_barrier(nobar);  // step SPR r + h: its planes (and, at h = 0, X(r)) are in LDS
       const unsigned long long t1 = dbg_on ? __builtin_readcyclecounter() : 0;
+      if (wave == 0) tr(SPR * r + h, 14, t1);
       // words 2h, 2h + 1 of the lane's 16 packed bytes of run r: the two entries of this step
       const uint8_t* xs = xl0 + (size_t)(r % XSN) * (XTILES * 1024) + (size_t)wave * (MT * 1024) + lane * 16 + 8 * h;
       int x0[MT], x1[MT];
@@ -942,14 +1013,16 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       }
       const uint8_t* sb = vbuf + (size_t)((SPR * r + h) % NBUF) * STEP_BYTES;
       if (!late) job_work();
-      mfma_entry(sb, x0);
-      mfma_entry(sb + ENTRY_BYTES, x1);
+      __builtin_amdgcn_sched_barrier(0);   // (the X words' DS read stays out of the pipeline's scheduling region)
+      mfma_step(sb, x0, x1);
+      __builtin_amdgcn_sched_barrier(0);
       if (late) job_work();
       if (dbg_on) { c_bar += t1 - t0; c_mm += __builtin_readcyclecounter() - t1; }
     }
     const unsigned long long t2 = dbg_on ? __builtin_readcyclecounter() : 0;
     flush(r);
     if (dbg_on) c_fl += __builtin_readcyclecounter() - t2;
+    if (DBG && wave == 0) tr(SPR * r + SPR - 1, 15, __builtin_readcyclecounter() - t2);
   }
   if (EW) lds_barrier(nobar);  // trailing barrier: the last run's parked windows become visible to the epilogue waves
   if (!EW && job) run_units(s_units);
@@ -960,7 +1033,13 @@ template <int MT, int CW, int EW, int XSN, int NBUF>
 hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   constexpr bool NODBG = false;
   BaseLRLaunch P = L;
-  P.flags = tune.lr_flags;
+  P.flags = tune.lr_flags & ~(3 << 24);
+  {  // limb pairs in int32 at a window's end (flush): |a_2k + 256 a_2k+1| <= 257 * 256 K for a window of K SNPs — K < 32 640;
+     // wider windows (none of the reference's configurations) take the seven conversions of combine().  GNX_LR_FLAGS bit 25: never (tests)
+    int span = 0;
+    for (int64_t w = 0; w < L.W; ++w) span = std::max(span, L.h_win_chunk1[(size_t)w] - L.h_win_chunk0[(size_t)w]);
+    if (span <= 120 && !(tune.lr_flags & (1 << 25))) P.flags |= 1 << 24;
+  }
   const int haps_per_block = CW * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
   // window ranges: one block per CU at a time (150 KB of LDS), so the grid is walked in rounds and the last, partial round costs a
@@ -1003,12 +1082,13 @@ hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hi
   }
   // GNX_DEBUG & 2 (development): the instrumented instantiation — where the waves' cycles go; synchronous, never on a production path
   GNX_LDS_OPTIN(lds, k_base_logistic_p2f<MT, CW, EW, XSN, NBUF, true>);
-  if (hipMalloc(&P.dbg, nblk * 16 * sizeof(unsigned long long)) != hipSuccess) P.dbg = nullptr;
-  if (P.dbg) (void)hipMemsetAsync(P.dbg, 0, nblk * 16 * sizeof(unsigned long long), s);
+  constexpr size_t TRACE = 256 * 16;
+  if (hipMalloc(&P.dbg, (nblk * 16 + TRACE) * sizeof(unsigned long long)) != hipSuccess) P.dbg = nullptr;
+  if (P.dbg) (void)hipMemsetAsync(P.dbg, 0, (nblk * 16 + TRACE) * sizeof(unsigned long long), s);
   hipLaunchKernelGGL((k_base_logistic_p2f<MT, CW, EW, XSN, NBUF, true>), dim3((unsigned)nblk), dim3((CW + EW + 2) * 64), lds, s, P);
   hipError_t err = hipGetLastError();
   if (P.dbg) {
-    std::vector<unsigned long long> h(nblk * 16);
+    std::vector<unsigned long long> h(nblk * 16 + TRACE);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), P.dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(P.dbg);
@@ -1023,6 +1103,22 @@ hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hi
     std::fprintf(stderr, "p2f cycles per step (mean of %zu blocks, %.0f steps each): compute wave0: barrier %.0f mfma %.0f flush %.0f total %.0f | epilogue wave0: barrier %.0f "
                  "work %.0f (longest step %.0f) | plane loader: wait %.0f barrier %.0f issue %.0f\n", live, st / (live ? live : 1), sum[0] / st, sum[1] / st, sum[2] / st, sum[3] / st,
                  sum[4] / st, sum[5] / st, sum[6] / (live ? live : 1), sum[8] / st, sum[9] / st, sum[10] / st);
+    if (tune.debug & 4) {  // block 8's steps: how long after the previous barrier opened each role reached this one, and who came last
+      const unsigned long long* t = h.data() + nblk * 16;
+      std::fprintf(stderr, "p2f trace of block 8: step | cycles since the previous release: compute waves (max, which) | epilogue waves (max) | plane loader | X loader | release | flush\n");
+      for (int st2 = 1; st2 < 80 && t[(size_t)st2 * 16 + 14]; ++st2) {
+        const unsigned long long rel0 = t[(size_t)(st2 - 1) * 16 + 14];
+        auto at = [&](int slot) { const unsigned long long v = t[(size_t)st2 * 16 + slot]; return v > rel0 ? (long long)(v - rel0) : 0LL; };
+        long long cm = 0, em = 0; int cw = 0;
+        for (int k = 0; k < CW; ++k) if (at(k) > cm) { cm = at(k); cw = k; }
+        for (int k = CW; k < CW + EW; ++k) em = std::max(em, at(k));
+        std::fprintf(stderr, "  %3d | %6lld (w%d) | %6lld | %6lld | %6lld | %6lld | %6llu | compute", st2, cm, cw, em, at(CW + EW), at(CW + EW + 1), at(14), t[(size_t)(st2 - 1) * 16 + 15]);
+        for (int k = 0; k < CW; ++k) std::fprintf(stderr, " %5lld", at(k));
+        std::fprintf(stderr, " | epilogue");
+        for (int k = CW; k < CW + EW; ++k) std::fprintf(stderr, " %5lld", at(k));
+        std::fprintf(stderr, "\n");
+      }
+    }
   }
   return err;
 }
