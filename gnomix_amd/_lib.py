@@ -12,7 +12,7 @@ import os
 import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libgnomix_hip.so")
+SO_PATH = os.environ.get("GNX_LIBRARY") or os.path.join(_HERE, "libgnomix_hip.so")   # GNX_LIBRARY: another build of the same ABI (kernel A/B timing, scripts/dev)
 
 GNX_ABI_VERSION = 14
 GNX_OK, GNX_EINVAL, GNX_ENOMEM, GNX_EHIP, GNX_EUNSUPPORTED, GNX_ESTATE, GNX_ESTALE = 0, -1, -2, -3, -4, -5, -6

@@ -46,6 +46,20 @@
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+// development switches of the 2-bit kernels (compile time; scripts/dev/p2f_defs.sh): prefetch distance of the plane-read pipelines
+// (tiles), accumulator registers gathered at a time at a window's end, classes per sigmoid unit and store parts of the epilogue waves
+#ifndef GNX_P2F_PD
+#define GNX_P2F_PD 2
+#endif
+#ifndef GNX_P2F_FLUSH_GROUP
+#define GNX_P2F_FLUSH_GROUP 1
+#endif
+#ifndef GNX_P2F_PBR
+#define GNX_P2F_PBR 4
+#endif
+#ifndef GNX_P2F_NSP
+#define GNX_P2F_NSP 2
+#endif
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -346,6 +360,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2(BaseLRL
       for (int mt = 0; mt < MT; ++mt) acc[mt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[mt], b, acc[mt][l], 0, 0, 0);
     }
   };
+  // (the hand-written read pipeline of k_base_logistic_p2f's mfma_step, tried here too: 0.580 ms against 0.575 at config 2 — with seven
+  // tiles per entry and a third of the accumulators this kernel is not waiting for its LDS reads)
 
   // ---- piece end: the windows of this pass that finished with run rl (block-uniform) ----
   int parked = 0;
@@ -459,8 +475,8 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
 // and reads X twice; every kernel of this family sits on the same ~5-6 TB/s of L1 / LDS-DMA fill traffic, which at
 // config 5a was 30.7 GB of digit planes + 17.9 GB of X per launch.  Here the 24 class columns x 7 limbs are laid side by side as
 // 168 FLAT columns, q = 24 limb + column, in ceil(168 / 16) = 11 tiles: 21 % fewer plane bytes and MFMAs, and 11 x 4 = 44 accumulator
-// registers per 16 rows hold BOTH slots, so a wave of 32 rows carries 88 — the block keeps 256 rows, reads X ONCE, and fits 12
-// waves of <= 168 registers (8 compute, 2 epilogue, 2 loaders; three per SIMD).  Fill per launch: 24.1 + 8.9 GB.
+// registers per 16 rows hold BOTH slots, so a wave of 32 rows carries 88 — the block keeps 256 rows, reads X ONCE, and runs 14
+// waves of 128 registers (8 compute, 4 epilogue, 2 loaders).  Fill per launch: 24.1 + 8.9 GB.
 //
 // Where limb l of column c lives (tile, lane column) = ((24 l + c) >> 4, (24 l + c) & 15) repeats every two limbs (48 columns = 3 tiles):
 //     tile 3k      lanes 0-15: limb 2k   of columns 0-15
@@ -468,22 +484,12 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
 //     tile 3k + 2  lanes 0-15: limb 2k+1 of columns 8-23                                    (k = 0, 1, 2)
 //     tile 9       limb 6 of columns 0-15;   tile 10 lanes 0-7: limb 6 of columns 16-23
 // so the HOME lane of column c (lane c for c < 16, lane c - 16 above) finds its even limbs in its own lane and its odd limbs in the
-// lane 8 away (one row_ror:8 DPP move each), which tile is a lane predicate: six DPP moves and seven selects per accumulator
-// register at a window's end, then the same exact combine() — Z, and with it B, stay BIT-IDENTICAL to the int8 kernels'.
-// A window's end zeroes only its slot's columns (the other slot's window is in mid-flight): lane-predicated moves, tile by tile.
+// lane 8 away (one row_ror:8 DPP move each; WHICH tile is chosen in the source lane, a lane predicate): three DPP moves and seven
+// selects per accumulator register at a window's end.  Limbs then go in pairs, a_2k + 256 a_2k+1 in int32 (the launcher checks that
+// no window is wide enough to overflow), four conversions and three fmas to Z — one rounding, the one combine() makes: Z, and with
+// it B, stay BIT-IDENTICAL to the int8 kernels'.  A window's end zeroes only its slot's columns (the other slot's window is in
+// mid-flight): the lanes to zero repeat every three tiles, three exec-masked regions of 64-bit moves.
 // =====================================================================================================================================
-#ifndef GNX_P2F_PD
-#define GNX_P2F_PD 2
-#endif
-#ifndef GNX_P2F_FLUSH_GROUP
-#define GNX_P2F_FLUSH_GROUP 1
-#endif
-#ifndef GNX_P2F_PBR
-#define GNX_P2F_PBR 4
-#endif
-#ifndef GNX_P2F_NSP
-#define GNX_P2F_NSP 2
-#endif
 constexpr int NFT = GNX_LR_FLAT_TILES;   // 11
 constexpr int NCF = GNX_LR_FLAT_COLS;    // 24
 
@@ -516,10 +522,13 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, kq = lane >> 4;
   const int A = L.A, W = L.W, R = L.d.R;
+  // parked rows are ZA float64 apart, ZA odd: the finishing waves work one row per lane, and rows an even number of 8-byte words
+  // apart (A = 12: 24 dwords, four distinct banks for 64 lanes) made every one of their LDS accesses an 8-way bank conflict
+  const int ZA = A | 1;
   uint8_t* vbuf = lds;                                               // [NBUF][STEP_BYTES]
   uint8_t* xl0 = vbuf + (size_t)NBUF * STEP_BYTES;                   // [XSN][CW][MT][64 lanes][16 B]
   double* zq = reinterpret_cast<double*>(xl0 + (size_t)XSN * XTILES * 1024);  // [2][CW * ZROWS][A] parked logits
-  double* tab_ic = zq + (size_t)2 * CW * ZROWS * A;   // [max_wins][A] intercepts
+  double* tab_ic = zq + (size_t)2 * CW * ZROWS * ZA;   // [max_wins][A] intercepts
   double* tab_sc = tab_ic + (size_t)L.max_wins * A;    // [max_wins] 2^-f_w
   int* tab_rb = reinterpret_cast<int*>(tab_sc + L.max_wins);
   int* tab_nfl = tab_rb + L.max_chunks;
@@ -651,8 +660,28 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   // (a store to B waits ~800 cycles at issue behind the loaders' traffic — the L1's queue is full by design: with an even number of
   // classes a lane stores TWO consecutive values of a row, 1 KB per float64 instruction, and every iteration counts double)
   const bool wide_st = (A & 1) == 0 && ((reinterpret_cast<uintptr_t>(L.b64) & 15) | (reinterpret_cast<uintptr_t>(L.b32) & 7)) == 0;
-  const int spi = wide_st ? 128 : 64;   // values per store instruction: the iteration ranges below count in these
+  // ... and FOUR float32 values (16 bytes a lane) when the classes come in fours and only the float32 output is asked for: 1 KB per
+  // instruction there too, half the instructions of the pairs
+  const bool quad_st = (A & 3) == 0 && !L.b64 && L.b32 && (reinterpret_cast<uintptr_t>(L.b32) & 15) == 0 && !(abl & 2048);
+  const int spi = quad_st ? 256 : wide_st ? 128 : 64;   // values per store instruction: the iteration ranges below count in these
   auto store_rows = [&](const double* zr0, int w, int64_t nrow0, int rows, int i0 = 0, int i1 = 1 << 20) {
+    if (quad_st) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const int d_r = 256 / A, d_a = 256 - d_r * A;
+      int rl = (4 * lane + 256 * i0) / A, a = 4 * lane + 256 * i0 - rl * A;
+      const size_t ow = (size_t)w * A;
+      const int e_end = min(rows * A, 256 * i1);
+      for (int e = 4 * lane + 256 * i0; e < e_end; e += 256) {
+        const int64_t n = nrow0 + rl;
+        if (n < L.N && !(abl & (32 | 1024))) {
+          const double* zp = zr0 + rl * ZA + a;
+          *reinterpret_cast<v4f*>(L.b32 + (size_t)n * W * A + ow + a) = v4f{(float)zp[0], (float)zp[1], (float)zp[2], (float)zp[3]};
+        }
+        a += d_a; rl += d_r;
+        if (a >= A) { a -= A; ++rl; }
+      }
+      return;
+    }
     if (wide_st) {
       typedef double v2d __attribute__((ext_vector_type(2)));
       typedef float v2f __attribute__((ext_vector_type(2)));
@@ -664,7 +693,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
         const int64_t n = nrow0 + rl;
         if (n < L.N && !(abl & (32 | 1024))) {
           const size_t o = (size_t)n * W * A + ow + a;
-          const v2d v = *reinterpret_cast<const v2d*>(zr0 + e);
+          const double* zp = zr0 + rl * ZA + a;
+          const v2d v = v2d{zp[0], zp[1]};
           if (L.b64) *reinterpret_cast<v2d*>(L.b64 + o) = v;
           if (L.b32) *reinterpret_cast<v2f*>(L.b32 + o) = v2f{(float)v[0], (float)v[1]};
         }
@@ -684,7 +714,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       const int64_t n = nrow0 + rl;
       if (n < L.N && !(abl & (32 | 1024))) {
         const size_t o = (size_t)n * W * A + ow + a;
-        const double v = zr0[e];
+        const double v = zr0[rl * ZA + a];
         if (L.b64) L.b64[o] = v;
         if (L.b32) L.b32[o] = (float)v;
       }
@@ -696,7 +726,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     constexpr int NB = decltype(nb)::value;
     if (abl & 1) return;
     const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
-    double* zr = zr0 + frow * A;
+    double* zr = zr0 + frow * ZA;
     const double* ic = tab_ic + (w - wt0) * A;
     for (int it = it0; it < it1; ++it) {
       double v[NB];
@@ -708,6 +738,10 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
         v[i] = zr[ac] + ic[ac];
       }
       gnx_sigmoidN<NB>(v);
+      // (the stores below are conditional, and the compiler moved each chain's last dozen instructions — ldexp, 1 + e, the reciprocal
+      // and its Newton steps — INTO its store's branch: four chains one after the other.  Every result is due here, chains interleaved.)
+#pragma unroll
+      for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(v[i]));
 #pragma unroll
       for (int i = 0; i < NB; ++i)
         if (a[i] < A) zr[a[i]] = v[i];
@@ -717,12 +751,28 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   auto normalise = [&](double* zr0, int rows) {
     if (abl & 1) return;
     const int lpr = 64 / rows, frow = lane % rows, fsub = lane / rows;
-    double* zr = zr0 + frow * A;
+    double* zr = zr0 + frow * ZA;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    double sum = 0.0;
-    for (int c = 0; c < A; ++c) sum += zr[c];
-    const double rs = gnx_rcp_nr(sum);
-    for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] * rs;
+    if (lpr == 1) {
+      // one lane per row (the epilogue waves): the row's A <= 16 values in registers — ONE LDS round trip for the reads instead of
+      // one per class for the sum and another per class for the scaling; the additions in class order, as everywhere
+      double t[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) t[c] = c < A ? zr[c] : 0.0;
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < A) sum += t[c];
+      const double rs = gnx_rcp_nr(sum);
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < A) zr[c] = t[c] * rs;
+    } else {
+      double sum = 0.0;
+      for (int c = 0; c < A; ++c) sum += zr[c];
+      const double rs = gnx_rcp_nr(sum);
+      for (int a = fsub; a < A; a += lpr) zr[a] = zr[a] * rs;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
@@ -739,7 +789,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     // (Float64 vector work runs on the SIMD's matrix pipe wherever it is issued — an epilogue wave's ~550 cycles per step come straight
     // out of its SIMD's MFMA time — so the total is fixed and only the spread over the steps matters.  Smaller units (two sigmoids, one
     // store instruction) with or without a per-step time budget measured 3-6 % SLOWER than these eight units per window.)
-    const int pbr = ((abl >> 16) & 7) ? min((abl >> 16) & 7, 4) : GNX_P2F_PBR;   // classes of a lane per phase-1 unit (GNX_LR_FLAGS bits 16-18: A/B timing)
+    const int pbr = ((abl >> 16) & 7) ? ((abl >> 16) & 7) : GNX_P2F_PBR;   // classes of a lane per phase-1 unit (GNX_LR_FLAGS bits 16-18: A/B timing)
     const int n_it = (A + pbr * (64 / CHR) - 1) / (pbr * (64 / CHR));   // phase-1 iterations of a lane: pbr classes each
     const int NSP = ((abl >> 20) & 7) ? ((abl >> 20) & 7) : GNX_P2F_NSP;  // the stores of a chunk in NSP parts (bits 20-22)
     const int n_sti = (CHR * A + spi - 1) / spi, sti_part = (n_sti + NSP - 1) / NSP;
@@ -752,12 +802,13 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     auto run_units = [&](int u_end) {
       for (; job_unit < u_end; ++job_unit) {
         const int ch = job_unit / upc, it = job_unit - ch * upc;
-        double* z = job_z + (size_t)ch * CHR * A;
+        double* z = job_z + (size_t)ch * CHR * ZA;
         if (it < n_it) {
           switch (pbr) {
             case 1: phase1_n(std::integral_constant<int, 1>{}, z, job_w, it, it + 1, CHR); break;
             case 2: phase1_n(std::integral_constant<int, 2>{}, z, job_w, it, it + 1, CHR); break;
             case 3: phase1_n(std::integral_constant<int, 3>{}, z, job_w, it, it + 1, CHR); break;
+            case 6: phase1_n(std::integral_constant<int, 6>{}, z, job_w, it, it + 1, CHR); break;
             default: phase1_n(std::integral_constant<int, 4>{}, z, job_w, it, it + 1, CHR); break;
           }
         } else if (it == n_it) normalise(z, CHR);
@@ -766,8 +817,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     };
     auto job_work = [&]() {
       if (!job) return;
-      ++job_step;
-      run_units(job_step >= job_nst ? n_units : (int)((int64_t)n_units * job_step / job_nst));
+      ++job_step;   // (32-bit arithmetic: the 64-bit quotient this once was is a ~100-instruction routine, run every step)
+      run_units(job_step >= job_nst ? n_units : (n_units * job_step) / job_nst);
       if (job_step >= job_nst) job = false;
     };
     unsigned long long c_bar = 0, c_work = 0, c_max = 0;
@@ -793,7 +844,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
           job_step = 0;
           job_unit = 0;
           job_nst = SPR * (tab_gap[r] > 0 ? tab_gap[r] : n_runs - 1 - r);  // 0 (last run): after the trailing barrier
-          job_z = zq + (size_t)(parked & 1) * (CW * ZROWS * A) + (size_t)ew * RWS * A;
+          job_z = zq + (size_t)(parked & 1) * (CW * ZROWS * ZA) + (size_t)ew * RWS * ZA;
           ++parked;
         }
       }
@@ -813,13 +864,15 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     for (int t = 0; t < NFT; ++t) acc[mt][t] = v4i{0, 0, 0, 0};
 
   // one step = 2 entries x 11 flat tiles x MT row tiles, ONE software pipeline over its 22 KB of digit planes: the planes of tiles
-  // t + 1 .. t + PD are on their way from LDS while tile t multiplies.  hipcc would not build it: whatever the source order, every
-  // wait it places in a kernel that also holds LDS-DMA loads is `s_waitcnt lgkmcnt(0)` — "all LDS reads back" — so a read issued ahead
-  // is waited for together with the one that is needed, and the wave sat through one LDS round trip (~100 cycles) per tile with 32
-  // cycles of MFMA to show for it (2 370 cycles per step for 44 MFMAs).  The reads and their waits are therefore written out:
-  // ds_read_b128 as inline asm (the compiler does not know the register is pending, the wait that covers it is tied to it by a
-  // "+v" operand and comes before its only uses) and s_waitcnt lgkmcnt(n) with n = the reads issued behind the tile; a
-  // sched_barrier per tile keeps the stages in this order.  LDS returns in order, so the count is exact.
+  // t + 1 .. t + PD are on their way from LDS while tile t multiplies.  hipcc does not build it: in this kernel every wait it places
+  // is `s_waitcnt lgkmcnt(0)` — "all LDS reads back" (a micro-kernel with the same loop gets counted waits; here none of the 126
+  // is) — so a read issued ahead was waited for together with the one that was needed, and behind a first attempt at pinning the
+  // order with sched_group_barrier the X words' read took the list's first slot and every read came AFTER its tile's MFMAs: the wave
+  // sat through an LDS round trip per tile, 2 370 cycles per step for 44 MFMAs.  The reads and their waits are therefore written out:
+  // ds_read_b128 + s_waitcnt lgkmcnt(PD) as ONE inline-asm statement whose output is the register set of tile t + PD (the compiler
+  // does not know it is pending; nothing touches it before the MFMAs of tile t + PD, PD statements later), a sched_barrier either side
+  // of a tile's MFMAs keeps the stages in order.  LDS returns in order, so the count is exact; a compiler-issued read older than the
+  // pipeline (the run's table entries) only makes a wait stricter.  1 450 cycles per step for a SIMD's first wave, 2 100 for its second.
   constexpr int PD = GNX_P2F_PD;   // prefetch distance in tiles
   auto mfma_step = [&](const uint8_t* pb, const int (&xw0)[MT], const int (&xw1)[MT]) {
     if (abl & 2) return;
@@ -880,20 +933,18 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   const bool late = ((wave >> 2) & 1) != 0;   // the second wave of its SIMD (waves go to SIMDs round robin): its unit follows its MFMAs
 
   int parked = 0;
-  auto flush = [&](int rl) {
-    const int nfl = tab_nfl[rl];
+  auto flush = [&](int rl, int nfl, int w0) {   // (nfl, w0 = tab_nfl[rl], tab_fl0[rl]: read by the caller ahead of the run's MFMAs)
     if (nfl <= 0 || (abl & 4)) return;
     // the lane's column / row group as the optimiser cannot see through: everything derived from them below (predicates, the LDS
     // addresses of the parked logits) would otherwise be hoisted out of the run loop into a dozen registers held beside the
     // 88 accumulators for the whole kernel — recomputing them once per window costs nothing
     int i16 = lane & 15, kq = lane >> 4;
     asm volatile("" : "+v"(i16), "+v"(kq));
-    const int w0 = tab_fl0[rl];
     for (int w = w0; w < w0 + nfl; ++w) {
       const int c0 = (w % R) * A;                  // the window's slot: flat class columns [c0, c0 + A)
       const double scale = tab_sc[w - wt0];
       const bool out = w >= wa && w < wb;
-      double* zw = zq + (size_t)(parked & 1) * (CW * ZROWS * A) + (size_t)wave * ZROWS * A;
+      double* zw = zq + (size_t)(parked & 1) * (CW * ZROWS * ZA) + (size_t)wave * ZROWS * ZA;
       // this lane as the HOME of one column of the slot: column i16 (< 16) or column i16 + 16 (lanes 0-7); never both (A <= 16)
       const bool in_hi = i16 < 8 && i16 + 16 >= c0 && i16 + 16 < c0 + A;
       const bool in_lo = i16 >= c0 && i16 < c0 + A;
@@ -906,7 +957,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       // where the lane parks (row 4 kq of the wave's rows, class col - c0) and whether it does, worked out ONCE per window: left to
       // itself the compiler re-derived both for each of the eight accumulator registers (~20 instructions each) rather than hold them
       const unsigned long long home_mask = __builtin_amdgcn_ballot_w64(home);
-      int zoff = 4 * kq * A + (col - c0);
+      int zoff = 4 * kq * ZA + (col - c0);
       asm volatile("" : "+v"(zoff));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -938,7 +989,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
               const int l6 = in_hi ? acc[mt][10][r] : acc[mt][9][r];
               z = combine7(ev[0], od[0], ev[1], od[1], ev[2], od[2], l6, scale);
             }
-            if (__builtin_amdgcn_inverse_ballot_w64(home_mask)) zw[zoff + (mt * 16 + r) * A] = z;
+            if (__builtin_amdgcn_inverse_ballot_w64(home_mask)) zw[zoff + (mt * 16 + r) * ZA] = z;
             if (GNX_P2F_FLUSH_GROUP == 1 || (r % GNX_P2F_FLUSH_GROUP) == GNX_P2F_FLUSH_GROUP - 1)
               __builtin_amdgcn_sched_barrier(0);  // GROUP registers' gathers at a time: the accumulators leave no room for four in flight
           }
@@ -977,7 +1028,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(abl & 1)) {
           const int lpr = 64 / ZROWS, frow = lane % ZROWS, fsub = lane / ZROWS;
-          double* zr = zw + frow * A;
+          double* zr = zw + frow * ZA;
           const double* ic = tab_ic + (w - wt0) * A;
           for (int a = fsub; a < A; a += lpr) zr[a] = gnx_sigmoid(zr[a] + ic[a]);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -995,6 +1046,9 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   unsigned long long c_bar = 0, c_mm = 0, c_fl = 0, t_begin = dbg_on ? __builtin_readcyclecounter() : 0;
   typedef int v2i __attribute__((ext_vector_type(2)));
   for (int r = 0; r < n_runs; ++r) {
+    // what ends after this run, asked for now: the answer is back long before the run's MFMAs are through (asked for behind them it
+    // cost every wave an LDS round trip per run, windows ending or not)
+    const int r_nfl = tab_nfl[r], r_fl0 = tab_fl0[r];
 #pragma unroll
     for (int h = 0; h < SPR; ++h) {
       const unsigned long long t0 = dbg_on ? __builtin_readcyclecounter() : 0;
@@ -1020,7 +1074,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       if (dbg_on) { c_bar += t1 - t0; c_mm += __builtin_readcyclecounter() - t1; }
     }
     const unsigned long long t2 = dbg_on ? __builtin_readcyclecounter() : 0;
-    flush(r);
+    flush(r, r_nfl, r_fl0);
     if (dbg_on) c_fl += __builtin_readcyclecounter() - t2;
     if (DBG && wave == 0) tr(SPR * r + SPR - 1, 15, __builtin_readcyclecounter() - t2);
   }
@@ -1064,7 +1118,7 @@ hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hi
     }
     P.max_chunks = max_runs + 8;
     P.max_wins = wch + 2 * L.d.R + 4;
-    lds = (size_t)NBUF * (2 * NFT * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)2 * CW * MT * 16 * L.A * sizeof(double) +
+    lds = (size_t)NBUF * (2 * NFT * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)2 * CW * MT * 16 * (L.A | 1) * sizeof(double) +
           (size_t)4 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
     if (lds <= (size_t)160 * 1024 || wch == 4) break;
   }

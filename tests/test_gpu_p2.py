@@ -255,8 +255,14 @@ def test_p2_flat_tiles_every_variant(ga, monkeypatch, C, M, A, ctx, N):
     d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=ctx, seed=C, smooth=None)
     X = synth.synthetic_X(N, C, seed=N, miss=0.03)
     ref = None
-    for flat, tune in (("1", None), ("1", "2,8,2,2,3"), ("1", "2,8,0,2,3"), ("1", "2,8,4,2,2"), ("1", "2,8,0,2,2"), ("0", None)):
+    # GNX_LR_FLAGS (development switches that keep the output): bit 25 = the seven-conversion combine of wide windows instead of limb
+    # pairs, 2048 = no 16-byte float32 stores, bits 16-18 / 20-22 = classes per sigmoid unit / store parts of the epilogue waves
+    variants = [("1", None, 0), ("1", "2,8,2,2,3", 0), ("1", "2,8,0,2,3", 0), ("1", "2,8,4,2,2", 0), ("1", "2,8,0,2,2", 0), ("0", None, 0),
+                ("1", None, 1 << 25), ("1", None, 2048), ("1", None, (1 << 16) | (4 << 20)), ("1", None, 6 << 16), ("1", None, (3 << 16) | (1 << 20)),
+                ("1", "2,8,0,2,3", (1 << 25) | 2048)]
+    for flat, tune, flags in variants:
         monkeypatch.setenv("GNX_LR_P2_FLAT", flat)
+        monkeypatch.setenv("GNX_LR_FLAGS", str(flags))
         if tune:
             monkeypatch.setenv("GNX_P2_TUNE", tune)
         else:
@@ -265,16 +271,24 @@ def test_p2_flat_tiles_every_variant(ga, monkeypatch, C, M, A, ctx, N):
         dev = ga.DeviceModel(d, ctx=ctx_)
         for f64 in (True, False):
             b_i8, b_p2 = _both(dev, X, f64)
-            assert np.array_equal(b_i8, b_p2), (flat, tune, f64)
+            assert np.array_equal(b_i8, b_p2), (flat, tune, flags, f64)
         if ref is None:
             ref = b_p2
-        if flat == "1" and tune is None:      # unaligned output: B at an odd element offset of a larger tensor
+        if flat == "1" and tune is None and flags == 0:      # unaligned outputs: B at odd element offsets of a larger tensor
             P = torch.from_numpy(np.asarray(dev.pack_x(X))).cuda()
             W = C // M
             big = torch.zeros(N * W * A + 1, dtype=torch.float64, device="cuda")
             dev._bind_torch_stream()
             dev.ctx.check(dev.lib.gnx_base_predict_packed_dev(dev.h, P.data_ptr(), N, P.stride(0), None, big.data_ptr() + 8))
             torch.cuda.synchronize()
-            assert np.array_equal(big[1:].cpu().numpy().reshape(N, W, A), _both(dev, X, True)[1])
+            b64 = _both(dev, X, True)[1]
+            assert np.array_equal(big[1:].cpu().numpy().reshape(N, W, A), b64)
+            b32 = _both(dev, X, False)[1]
+            for off in (1, 2, 3):           # float32: 4 / 8 / 12 bytes past a 16-byte boundary (512-byte, 1 KB pair, 512-byte stores)
+                big32 = torch.zeros(N * W * A + 4, dtype=torch.float32, device="cuda")
+                dev.ctx.check(dev.lib.gnx_base_predict_packed_dev(dev.h, P.data_ptr(), N, P.stride(0), big32.data_ptr() + 4 * off, None))
+                torch.cuda.synchronize()
+                assert np.array_equal(big32[off:off + N * W * A].cpu().numpy().reshape(N, W, A), b32), off
+                assert float(big32[:off].abs().sum()) == 0.0 and float(big32[off + N * W * A:].abs().sum()) == 0.0
         dev.close()
         ctx_.close()
