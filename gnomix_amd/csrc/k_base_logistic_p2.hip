@@ -933,6 +933,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   const bool late = ((wave >> 2) & 1) != 0;   // the second wave of its SIMD (waves go to SIMDs round robin): its unit follows its MFMAs
 
   int parked = 0;
+  unsigned long long c_f1 = 0, c_f2 = 0, c_f3 = 0, c_fn = 0;   // (instrumented build) a window's end: set-up, gather + combine + park, zeroing; how many
   auto flush = [&](int rl, int nfl, int w0) {   // (nfl, w0 = tab_nfl[rl], tab_fl0[rl]: read by the caller ahead of the run's MFMAs)
     if (nfl <= 0 || (abl & 4)) return;
     // the lane's column / row group as the optimiser cannot see through: everything derived from them below (predicates, the LDS
@@ -941,6 +942,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     int i16 = lane & 15, kq = lane >> 4;
     asm volatile("" : "+v"(i16), "+v"(kq));
     for (int w = w0; w < w0 + nfl; ++w) {
+      const unsigned long long tf0 = dbg_on ? __builtin_readcyclecounter() : 0;
       const int c0 = (w % R) * A;                  // the window's slot: flat class columns [c0, c0 + A)
       const double scale = tab_sc[w - wt0];
       const bool out = w >= wa && w < wb;
@@ -959,6 +961,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       const unsigned long long home_mask = __builtin_amdgcn_ballot_w64(home);
       int zoff = 4 * kq * ZA + (col - c0);
       asm volatile("" : "+v"(zoff));
+      const unsigned long long tf1 = dbg_on ? __builtin_readcyclecounter() : 0;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         if (out && !(abl & 64)) {
@@ -995,6 +998,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
           }
         }
       }
+      const unsigned long long tf2 = dbg_on ? __builtin_readcyclecounter() : 0;
       // zero the slot's columns: lane column i16 of tile t is flat column q = 16 t + i16 = 24 limb + column, so the lanes to zero
       // repeat every three tiles — three predicated REGIONS (exec masks, plain moves) instead of a select per register
       // (flat columns >= 168 of the last tile are padding: their planes are zero, zeroing their accumulators too changes nothing)
@@ -1009,6 +1013,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
             for (int t = kk; t < NFT; t += 3) acc[mt][t] = v4i{0, 0, 0, 0};
         }
       }
+      if (dbg_on) { const unsigned long long tf3 = __builtin_readcyclecounter(); c_f1 += tf1 - tf0; c_f2 += tf2 - tf1; c_f3 += tf3 - tf2; ++c_fn; }
       if (!out) continue;
       if (EW && nfl == 1) {
         ++parked;  // an epilogue wave takes it from here (after the next barrier)
@@ -1027,7 +1032,9 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
         // (a rare path — never at the default context — kept narrow: one class at a time, no batch temporaries beside the accumulators)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(abl & 1)) {
-          const int lpr = 64 / ZROWS, frow = lane % ZROWS, fsub = lane / ZROWS;
+          int ln = lane;
+          asm volatile("" : "+v"(ln));   // (this path's addresses worked out HERE: hoisted, they were a spilled register the common path reloaded at every window's end)
+          const int lpr = 64 / ZROWS, frow = ln % ZROWS, fsub = ln / ZROWS;
           double* zr = zw + frow * ZA;
           const double* ic = tab_ic + (w - wt0) * A;
           for (int a = fsub; a < A; a += lpr) zr[a] = gnx_sigmoid(zr[a] + ic[a]);
@@ -1080,7 +1087,8 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   }
   if (EW) lds_barrier(nobar);  // trailing barrier: the last run's parked windows become visible to the epilogue waves
   if (!EW && job) run_units(s_units);
-  if (dbg_on && lane == 0 && wave == 0) { dbg[0] = c_bar; dbg[1] = c_mm; dbg[2] = c_fl; dbg[3] = __builtin_readcyclecounter() - t_begin; dbg[7] = (unsigned long long)n_steps; }
+  if (dbg_on && lane == 0 && wave == 0) { dbg[0] = c_bar; dbg[1] = c_mm; dbg[2] = c_fl; dbg[3] = __builtin_readcyclecounter() - t_begin; dbg[7] = (unsigned long long)n_steps;
+    dbg[11] = c_f1; dbg[12] = c_f2; dbg[13] = c_f3; dbg[14] = c_fn; }
 }
 
 template <int MT, int CW, int EW, int XSN, int NBUF>
@@ -1157,6 +1165,8 @@ hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hi
     std::fprintf(stderr, "p2f cycles per step (mean of %zu blocks, %.0f steps each): compute wave0: barrier %.0f mfma %.0f flush %.0f total %.0f | epilogue wave0: barrier %.0f "
                  "work %.0f (longest step %.0f) | plane loader: wait %.0f barrier %.0f issue %.0f\n", live, st / (live ? live : 1), sum[0] / st, sum[1] / st, sum[2] / st, sum[3] / st,
                  sum[4] / st, sum[5] / st, sum[6] / (live ? live : 1), sum[8] / st, sum[9] / st, sum[10] / st);
+    if (sum[14] > 0) std::fprintf(stderr, "p2f cycles per window's end (compute wave0, %.0f per block): set-up %.0f, gather + combine + park %.0f, zeroing %.0f\n",
+                                  sum[14] / (live ? live : 1), sum[11] / sum[14], sum[12] / sum[14], sum[13] / sum[14]);
     if (tune.debug & 4) {  // block 8's steps: how long after the previous barrier opened each role reached this one, and who came last
       const unsigned long long* t = h.data() + nblk * 16;
       std::fprintf(stderr, "p2f trace of block 8: step | cycles since the previous release: compute waves (max, which) | epilogue waves (max) | plane loader | X loader | release | flush\n");
