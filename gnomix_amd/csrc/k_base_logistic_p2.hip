@@ -52,7 +52,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define GNX_P2F_PD 2
 #endif
 #ifndef GNX_P2F_FLUSH_GROUP
-#define GNX_P2F_FLUSH_GROUP 1
+#define GNX_P2F_FLUSH_GROUP 2
 #endif
 #ifndef GNX_P2F_PBR
 #define GNX_P2F_PBR 4
@@ -485,9 +485,10 @@ hipError_t launch(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStre
 //     tile 9       limb 6 of columns 0-15;   tile 10 lanes 0-7: limb 6 of columns 16-23
 // so the HOME lane of column c (lane c for c < 16, lane c - 16 above) finds its even limbs in its own lane and its odd limbs in the
 // lane 8 away (one row_ror:8 DPP move each; WHICH tile is chosen in the source lane, a lane predicate): three DPP moves and seven
-// selects per accumulator register at a window's end.  Limbs then go in pairs, a_2k + 256 a_2k+1 in int32 (the launcher checks that
-// no window is wide enough to overflow), four conversions and three fmas to Z — one rounding, the one combine() makes: Z, and with
-// it B, stay BIT-IDENTICAL to the int8 kernels'.  A window's end zeroes only its slot's columns (the other slot's window is in
+// selects per accumulator register at a window's end.  Limbs then go in pairs, a_2k + 256 a_2k+1 in int32 (the launcher declines a
+// model whose windows are wide enough to overflow: the int8 kernels take it), four conversions and three fmas to Z — one rounding,
+// the one combine() makes: Z, and with it B, stay BIT-IDENTICAL to the int8 kernels'.  The eight registers' code is straight-line
+// (lanes that are home to no column park their value in the spare float64 behind a row's classes: no exec mask).  A window's end zeroes only its slot's columns (the other slot's window is in
 // mid-flight): the lanes to zero repeat every three tiles, three exec-masked regions of 64-bit moves.
 // =====================================================================================================================================
 constexpr int NFT = GNX_LR_FLAT_TILES;   // 11
@@ -495,12 +496,6 @@ constexpr int NCF = GNX_LR_FLAT_COLS;    // 24
 
 __device__ __forceinline__ int ror8(int v) {  // the value of the lane 8 away within the 16-lane row
   return __builtin_amdgcn_update_dpp(0, v, 0x128 /* row_ror:8 */, 0xf, 0xf, true);  // (every lane has a source: bound_ctrl spares the move that would preset the result)
-}
-
-__device__ __forceinline__ double combine7(int a0, int a1, int a2, int a3, int a4, int a5, int a6, double scale) {  // combine() on gathered limbs
-  const double lo = __builtin_fma(__builtin_fma((double)a2, 256.0, (double)a1), 256.0, (double)a0);
-  const double hi = __builtin_fma(__builtin_fma(__builtin_fma((double)a6, 256.0, (double)a5), 256.0, (double)a4), 256.0, (double)a3);
-  return (hi * 16777216.0 + lo) * scale;
 }
 
 template <int MT, int CW, int EW, int XSN, int NBUF, bool DBG>
@@ -524,7 +519,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   const int A = L.A, W = L.W, R = L.d.R;
   // parked rows are ZA float64 apart, ZA odd: the finishing waves work one row per lane, and rows an even number of 8-byte words
   // apart (A = 12: 24 dwords, four distinct banks for 64 lanes) made every one of their LDS accesses an 8-way bank conflict
-  const int ZA = A | 1;
+  const int ZA = (A & 1) ? A + 2 : A + 1;   // (... and at least one spare float64 behind a row's classes: see the window's end)
   uint8_t* vbuf = lds;                                               // [NBUF][STEP_BYTES]
   uint8_t* xl0 = vbuf + (size_t)NBUF * STEP_BYTES;                   // [XSN][CW][MT][64 lanes][16 B]
   double* zq = reinterpret_cast<double*>(xl0 + (size_t)XSN * XTILES * 1024);  // [2][CW * ZROWS][A] parked logits
@@ -575,7 +570,6 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   const int abl = L.flags;  // GNX_LR_FLAGS (timing only): 1 raw logits, 2 no MFMA, 4 no flush, 8 no X, 16 no planes, 32 no barriers / stores, 64 no combine,
                             // 128 no epilogue priority, 1024 no stores to B (config 5a, one box: 7.46 ms; 1024: 7.03; 4: 5.38)
   const bool nobar = (abl & 32) != 0;
-  const bool pair_ok = (abl & (1 << 24)) != 0;   // set by the launcher: every window spans few enough SNPs for limb pairs in int32
   const bool dbg_on = DBG && L.dbg != nullptr;   // development instantiation: cycle counters of wave 0 of every role, 16 per block
   unsigned long long* dbg = L.dbg + (size_t)blockIdx.x * 16;
   // ... and of block 8 a trace: [step][16] = when each of the 14 waves reached the step's barrier, [14] = when wave 0 left it, [15] = flush cycles
@@ -754,19 +748,31 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     double* zr = zr0 + frow * ZA;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lpr == 1) {
-      // one lane per row (the epilogue waves): the row's A <= 16 values in registers — ONE LDS round trip for the reads instead of
-      // one per class for the sum and another per class for the scaling; the additions in class order, as everywhere
-      double t[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) t[c] = c < A ? zr[c] : 0.0;
+      // one lane per row (the epilogue waves): the row's values four at a time — A / 4 LDS round trips for the sum and as many for
+      // the scaling instead of one per class each; the additions in class order, as everywhere.  (Scalars, not an array: sixteen
+      // values in an array went to scratch whenever the inliner changed its mind about the code around it.)
       double sum = 0.0;
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        if (c < A) sum += t[c];
+      for (int g = 0; g < 16; g += 4) {
+        if (g < A) {
+          const double a0 = zr[g], a1 = g + 1 < A ? zr[g + 1] : 0.0, a2 = g + 2 < A ? zr[g + 2] : 0.0, a3 = g + 3 < A ? zr[g + 3] : 0.0;
+          sum += a0;
+          if (g + 1 < A) sum += a1;
+          if (g + 2 < A) sum += a2;
+          if (g + 3 < A) sum += a3;
+        }
+      }
       const double rs = gnx_rcp_nr(sum);
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        if (c < A) zr[c] = t[c] * rs;
+      for (int g = 0; g < 16; g += 4) {
+        if (g < A) {
+          const double a0 = zr[g], a1 = g + 1 < A ? zr[g + 1] : 0.0, a2 = g + 2 < A ? zr[g + 2] : 0.0, a3 = g + 3 < A ? zr[g + 3] : 0.0;
+          zr[g] = a0 * rs;
+          if (g + 1 < A) zr[g + 1] = a1 * rs;
+          if (g + 2 < A) zr[g + 2] = a2 * rs;
+          if (g + 3 < A) zr[g + 3] = a3 * rs;
+        }
+      }
     } else {
       double sum = 0.0;
       for (int c = 0; c < A; ++c) sum += zr[c];
@@ -958,43 +964,39 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
       const bool plo8 = ror8(lo8 ? 1 : 0) != 0;
       // where the lane parks (row 4 kq of the wave's rows, class col - c0) and whether it does, worked out ONCE per window: left to
       // itself the compiler re-derived both for each of the eight accumulator registers (~20 instructions each) rather than hold them
-      const unsigned long long home_mask = __builtin_amdgcn_ballot_w64(home);
-      int zoff = 4 * kq * ZA + (col - c0);
+      // (a parked row has a spare float64 behind its classes: the lanes that are home to no column of the slot park their —
+      // meaningless — value there, and the stores need no exec mask: the eight registers' code is straight-line)
+      int zoff = 4 * kq * ZA + (home ? col - c0 : A);
       asm volatile("" : "+v"(zoff));
       const unsigned long long tf1 = dbg_on ? __builtin_readcyclecounter() : 0;
+      // Straight-line: no branch and no exec mask between the eight registers (with a uniform branch and a predicated store per
+      // register this part took 1 690 cycles per window's end; like this 960).  A window's end is latency-bound, not issue-bound — it
+      // takes a wave as long alone on its SIMD as beside the other compute wave doing the same; how many registers' chains the
+      // scheduler may interleave (GNX_P2F_FLUSH_GROUP = 1, 2, 4, 8) measured the same.
+      if (out && !(abl & 64)) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (out && !(abl & 64)) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {  // int32 16x16 C/D layout: column = lane & 15, row = 4 (lane >> 4) + reg
-            double z;
-            if (pair_ok) {
-              // limbs in pairs, p_k = a_2k + 256 a_2k+1 in int32 (|a| <= 256 K for a window of K SNPs: the launcher checks the span),
-              // V = p_0 + 2^16 p_1 + 2^32 p_2 + 2^48 a_6 as P + 2^32 Q with P, Q exact in float64: ONE rounding, that of combine()
-              int pk[3];
+            // limbs in pairs, p_k = a_2k + 256 a_2k+1 in int32 (|a| <= 256 K for a window of K SNPs: the launcher declines models with
+            // wider windows), V = p_0 + 2^16 p_1 + 2^32 p_2 + 2^48 a_6 as P + 2^32 Q with P, Q exact in float64: ONE rounding, that of combine()
+            int pk[3];
 #pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                const int ev = in_hi ? acc[mt][3 * k + 1][r] : acc[mt][3 * k][r];
-                const int od = ror8(plo8 ? acc[mt][3 * k + 1][r] : acc[mt][3 * k + 2][r]);
-                pk[k] = (int)(((unsigned)od << 8) + (unsigned)ev);
-              }
-              const int l6 = in_hi ? acc[mt][10][r] : acc[mt][9][r];
-              const double P = __builtin_fma((double)pk[1], 65536.0, (double)pk[0]);
-              const double Q = __builtin_fma((double)l6, 65536.0, (double)pk[2]);
-              z = __builtin_fma(Q, 4294967296.0, P) * scale;
-            } else {
-              int ev[3], od[3];
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                ev[k] = in_hi ? acc[mt][3 * k + 1][r] : acc[mt][3 * k][r];
-                od[k] = ror8(plo8 ? acc[mt][3 * k + 1][r] : acc[mt][3 * k + 2][r]);
-              }
-              const int l6 = in_hi ? acc[mt][10][r] : acc[mt][9][r];
-              z = combine7(ev[0], od[0], ev[1], od[1], ev[2], od[2], l6, scale);
+            for (int k = 0; k < 3; ++k) {
+              // (values first, THEN the selects: a conditional between two accumulator elements is a select of ADDRESSES to the front
+              // end, and in this straight-line form ten accumulator tiles then lived in scratch)
+              const int t0 = acc[mt][3 * k][r], t1 = acc[mt][3 * k + 1][r], t2 = acc[mt][3 * k + 2][r];
+              const int ev = in_hi ? t1 : t0;
+              const int od = ror8(plo8 ? t1 : t2);
+              pk[k] = (int)(((unsigned)od << 8) + (unsigned)ev);
             }
-            if (__builtin_amdgcn_inverse_ballot_w64(home_mask)) zw[zoff + (mt * 16 + r) * ZA] = z;
-            if (GNX_P2F_FLUSH_GROUP == 1 || (r % GNX_P2F_FLUSH_GROUP) == GNX_P2F_FLUSH_GROUP - 1)
-              __builtin_amdgcn_sched_barrier(0);  // GROUP registers' gathers at a time: the accumulators leave no room for four in flight
+            const int t9 = acc[mt][9][r], t10 = acc[mt][10][r];
+            const int l6 = in_hi ? t10 : t9;
+            const double P = __builtin_fma((double)pk[1], 65536.0, (double)pk[0]);
+            const double Q = __builtin_fma((double)l6, 65536.0, (double)pk[2]);
+            zw[zoff + (mt * 16 + r) * ZA] = __builtin_fma(Q, 4294967296.0, P) * scale;
+            if (GNX_P2F_FLUSH_GROUP == 1 || ((mt * 4 + r) % GNX_P2F_FLUSH_GROUP) == GNX_P2F_FLUSH_GROUP - 1)
+              __builtin_amdgcn_sched_barrier(0);  // GROUP registers' gathers at a time: the accumulators leave no room for all eight
           }
         }
       }
@@ -1095,12 +1097,13 @@ template <int MT, int CW, int EW, int XSN, int NBUF>
 hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hipStream_t s) {
   constexpr bool NODBG = false;
   BaseLRLaunch P = L;
-  P.flags = tune.lr_flags & ~(3 << 24);
-  {  // limb pairs in int32 at a window's end (flush): |a_2k + 256 a_2k+1| <= 257 * 256 K for a window of K SNPs — K < 32 640;
-     // wider windows (none of the reference's configurations) take the seven conversions of combine().  GNX_LR_FLAGS bit 25: never (tests)
+  P.flags = tune.lr_flags;
+  {  // limb pairs in int32 at a window's end: |a_2k + 256 a_2k+1| <= 257 * 256 K for a window of K SNPs — K < 32 640.  A model with
+     // wider windows (none of the reference's configurations) is declined: the caller widens the rows and runs the int8 kernels.
+     // GNX_LR_FLAGS bit 25: decline always (tests)
     int span = 0;
     for (int64_t w = 0; w < L.W; ++w) span = std::max(span, L.h_win_chunk1[(size_t)w] - L.h_win_chunk0[(size_t)w]);
-    if (span <= 120 && !(tune.lr_flags & (1 << 25))) P.flags |= 1 << 24;
+    if (span > 120 || (tune.lr_flags & (1 << 25))) return hipErrorNotSupported;
   }
   const int haps_per_block = CW * MT * 16;
   const int64_t gx = (L.N + haps_per_block - 1) / haps_per_block;
@@ -1126,7 +1129,7 @@ hipError_t launch_flat(const BaseLRLaunch& L, int n_cu, const gnx_tune& tune, hi
     }
     P.max_chunks = max_runs + 8;
     P.max_wins = wch + 2 * L.d.R + 4;
-    lds = (size_t)NBUF * (2 * NFT * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)2 * CW * MT * 16 * (L.A | 1) * sizeof(double) +
+    lds = (size_t)NBUF * (2 * NFT * 1024) + (size_t)XSN * CW * MT * 1024 + (size_t)2 * CW * MT * 16 * ((L.A & 1) ? L.A + 2 : L.A + 1) * sizeof(double) +
           (size_t)4 * P.max_chunks * sizeof(int) + (size_t)P.max_wins * (L.A + 1) * sizeof(double);
     if (lds <= (size_t)160 * 1024 || wch == 4) break;
   }

@@ -3,7 +3,7 @@
 # outputs are wrong by construction).  gpurun -- 'bash scripts/dev/p2f_ablate.sh > gpurun_out/r06_c5a_ablations.txt'
 # GNX_LR_FLAGS: 1 raw logits (no sigmoid / normaliser), 2 no MFMA, 4 no flush at all, 8 no X loads, 16 no plane loads, 64 no limb gather /
 # combine / park, 128 no epilogue-wave priority, 1024 no stores to B; switches that KEEP the output: 2048 no 16-byte float32 stores,
-# 1 << 25 the seven-conversion combine instead of limb pairs, bits 16-18 / 20-22 classes per sigmoid unit / store parts.
+# 1 << 25 the flat kernel declines (int8 kernels run), bits 16-18 / 20-22 classes per sigmoid unit / store parts.
 # GNX_P2_TUNE="2,8,ew,2,nbuf": block shape.  GNX_LR_P2_FLAT=0: the two-pass slot-tile kernel of round 5.  (Compile-time variants —
 # prefetch distance of the plane reads — are scripts/dev/p2f_defs.sh; two builds alternating on one box: scripts/dev/p2_ab.sh.)
 cd "${GRAFT_REPO_ROOT:-.}"

@@ -255,8 +255,8 @@ def test_p2_flat_tiles_every_variant(ga, monkeypatch, C, M, A, ctx, N):
     d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=ctx, seed=C, smooth=None)
     X = synth.synthetic_X(N, C, seed=N, miss=0.03)
     ref = None
-    # GNX_LR_FLAGS (development switches that keep the output): bit 25 = the seven-conversion combine of wide windows instead of limb
-    # pairs, 2048 = no 16-byte float32 stores, bits 16-18 / 20-22 = classes per sigmoid unit / store parts of the epilogue waves
+    # GNX_LR_FLAGS (development switches that keep the output): bit 25 = the flat kernel declines the model as it would one with windows
+    # too wide for its int32 limb pairs (the rows are widened and the int8 kernels run), 2048 = no 16-byte float32 stores, bits 16-18 / 20-22 = classes per sigmoid unit / store parts of the epilogue waves
     variants = [("1", None, 0), ("1", "2,8,2,2,3", 0), ("1", "2,8,0,2,3", 0), ("1", "2,8,4,2,2", 0), ("1", "2,8,0,2,2", 0), ("0", None, 0),
                 ("1", None, 1 << 25), ("1", None, 2048), ("1", None, (1 << 16) | (4 << 20)), ("1", None, 6 << 16), ("1", None, (3 << 16) | (1 << 20)),
                 ("1", "2,8,0,2,3", (1 << 25) | 2048)]
