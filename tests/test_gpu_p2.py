@@ -292,3 +292,28 @@ def test_p2_flat_tiles_every_variant(ga, monkeypatch, C, M, A, ctx, N):
                 assert float(big32[:off].abs().sum()) == 0.0 and float(big32[off + N * W * A:].abs().sum()) == 0.0
         dev.close()
         ctx_.close()
+
+
+@pytest.mark.parametrize("C,M,A,ctx,N", [(9001, 300, 6, 450, 200), (9001, 300, 4, 750, 150), (9001, 300, 3, 1050, 100), (12001, 300, 2, 1650, 90),
+                                         (3001, 100, 3, 350, 70), (3001, 100, 6, 150, 70), (2801, 128, 4, 320, 40)])
+def test_p2_flat_tiles_other_class_counts(ga, monkeypatch, C, M, A, ctx, N):
+    """R * A == 24 with other splits than 2 x 12 / 3 x 8: four, six, eight and twelve windows in flight (contexts of 1.5 to 5.5 windows),
+    an ODD class count (parked rows A + 2 float64 apart), windows shorter than a run (several end at once: the flat kernel's rare path)
+    — the flat-tile kernel, its block shapes and the slot-tile kernel against the int8 kernels, bit for bit"""
+    from gnomix_amd import synth, _lib
+    monkeypatch.setenv("GNX_LR_P2", "2")
+    d = synth.synthetic_model(C=C, M=M, A=A, S=5, context=ctx, seed=C + A, smooth=None)
+    X = synth.synthetic_X(N, C, seed=N, miss=0.03)
+    for flat, tune in (("1", None), ("1", "2,8,2,2,3"), ("1", "2,8,0,2,3"), ("0", None)):
+        monkeypatch.setenv("GNX_LR_P2_FLAT", flat)
+        if tune:
+            monkeypatch.setenv("GNX_P2_TUNE", tune)
+        else:
+            monkeypatch.delenv("GNX_P2_TUNE", raising=False)
+        ctx_ = _lib.Context(0)
+        dev = ga.DeviceModel(d, ctx=ctx_)
+        for f64 in (True, False):
+            b_i8, b_p2 = _both(dev, X, f64)
+            assert np.array_equal(b_i8, b_p2), (flat, tune, f64)
+        dev.close()
+        ctx_.close()
