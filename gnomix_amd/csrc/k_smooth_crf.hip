@@ -670,8 +670,15 @@ __global__ __launch_bounds__(256) void k_smooth_crf_row16(SmoothCRFLaunch L) {
 // (same instruction sequence: same bits) and runs beta through it.  Per launch: psi twice + marginals + 1/SEG of the alphas twice =
 // 11.2 GB instead of 16.9.  FWDPSI: the forward sweep computes psi from B itself (off the chain) and writes it for the backward
 // sweep — no k_crf_psi pass (B once + psi out instead of B once + psi out + psi in).
-template <int AT, bool FWDPSI, int NWB>   // NWB waves per workgroup
+// RECOMP (with FWDPSI): psi is never written — the backward sweep reads B again and recomputes its segment's psi with the same
+// instruction sequence (same bits): B twice + marginals + 1/SEG of the alphas twice = 11.2 GB -> the psi array (N W A float64) is not
+// needed at all; the price is the psi phase (A multiply-adds + one exp per window and lane) a second time and 146 registers instead of
+// 122 (three waves per SIMD instead of four).  MEASURED at config 5a (25 000 chr1 haplotypes, A = 12): 3.87-3.91 ms against 3.43-3.47 —
+// a quarter of the traffic less and 13 % slower: the kernel is bound by the length of its instruction stream, not by its bytes
+// (DESIGN.md 4.3).  Built in `make EXPERIMENTS=1` only (GNX_CRF_FLAGS=8); outputs bit-identical (the CRF parity tests pass with it).
+template <int AT, bool FWDPSI, int NWB, bool RECOMP = false>   // NWB waves per workgroup
 __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
+  static_assert(!RECOMP || FWDPSI, "recomputing psi needs the in-kernel psi phase");
   constexpr int SEG = 8, EXPW = 4;
   __shared__ double la[NWB][SEG][64];    // [wave][step][lane] recomputed alpha_t(y)
   __shared__ double2 lsc[NWB][SEG][4];   // [wave][step][row] (1/c_t, c_t)
@@ -776,7 +783,7 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
 #pragma unroll
         for (int i = 0; i < EXPW; ++i) {
           bc[k0 + i] = label ? sd[i] : 0.0;
-          if (active && (plain || t0 + k0 + i < W)) L.psi[row0 + (size_t)(t0 + k0 + i) * A + y] = bc[k0 + i];
+          if (!RECOMP && active && (plain || t0 + k0 + i < W)) L.psi[row0 + (size_t)(t0 + k0 + i) * A + y] = bc[k0 + i];
         }
       }
     }
@@ -834,7 +841,7 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
   {
     const int sg = NSEG - 1;
 #pragma unroll
-    for (int k = 0; k < SEG; ++k) bn[k] = loadPsi(clampt(sg * SEG + k));
+    for (int k = 0; k < SEG; ++k) bn[k] = RECOMP ? loadB(clampt(sg * SEG + k)) : loadPsi(clampt(sg * SEG + k));
     an = (active && sg > 0) ? ck[(size_t)(sg - 1) * A + y] : 0.0;
   }
   for (int sg = NSEG - 1; sg >= 0; --sg) {
@@ -845,7 +852,37 @@ __global__ __launch_bounds__(64 * NWB) void k_smooth_crf_ck(SmoothCRFLaunch L) {
     double a_in = an;
     {
       const int sp = sg > 0 ? sg - 1 : 0;
-      {  // segment sp always lies inside the chain: one per-lane address and scalar offsets k * A — no clamp, no 64-bit multiply per window
+      if constexpr (RECOMP) {   // this segment's psi from its B (the forward sweep's psi phase, instruction for instruction), then the next segment's B
+        double Th[AT];
+        {
+          int yo = y;
+          asm volatile("" : "+v"(yo));
+#pragma unroll
+          for (int i = 0; i < AT; ++i) Th[i] = lth[i][yo];
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < SEG; k0 += EXPW) {
+          double sd[EXPW];
+#pragma unroll
+          for (int i = 0; i < EXPW; ++i) {
+            sd[i] = 0.0;
+            row_dot<AT>(sd[i], dpp_ready(bc[k0 + i]), Th);
+          }
+          gnx_exp_scN<EXPW>(sd);
+#pragma unroll
+          for (int i = 0; i < EXPW; ++i) bc[k0 + i] = label ? sd[i] : 0.0;
+        }
+        const size_t e0 = rowy + (size_t)(sp * SEG * A);
+        if (L.b_is_f64) {
+          const double* pp = reinterpret_cast<const double*>(L.B) + e0;
+#pragma unroll
+          for (int k = 0; k < SEG; ++k) { const double v = pp[k * A]; bn[k] = label ? v : 0.0; }
+        } else {
+          const float* pp = reinterpret_cast<const float*>(L.B) + e0;
+#pragma unroll
+          for (int k = 0; k < SEG; ++k) { const double v = (double)pp[k * A]; bn[k] = label ? v : 0.0; }
+        }
+      } else {  // segment sp always lies inside the chain: one per-lane address and scalar offsets k * A — no clamp, no 64-bit multiply per window
         const double* pp = L.psi + (rowy + (size_t)(sp * SEG * A));
 #pragma unroll
         for (int k = 0; k < SEG; ++k) { const double v = pp[k * A]; bn[k] = label ? v : 0.0; }
@@ -987,11 +1024,18 @@ hipError_t gnx_launch_smooth_crf(const SmoothCRFLaunch& L, const gnx_tune& tune,
       const int nwb = nwb_env == 4 ? 4 : 1;   // (GNX_CRF_NWB=4: the four-wave workgroups of the first version, kept for comparison)
       const dim3 gridw((unsigned)((L.N + 4 * nwb - 1) / (4 * nwb)));
 #define GNX_CK1(AT_, F_, W_) hipLaunchKernelGGL((k_smooth_crf_ck<AT_, F_, W_>), gridw, dim3(64 * W_), 0, s, L)
+#ifdef GNX_EXPERIMENTS   /* GNX_CRF_FLAGS=8: psi recomputed by the backward sweep instead of written and read (RECOMP; measured slower, see the kernel's header) */
+#define GNX_CK_RECOMP(AT_) if (fwdpsi && (tune.crf_flags & 8)) { hipLaunchKernelGGL((k_smooth_crf_ck<AT_, true, 1, true>), dim3((unsigned)((L.N + 3) / 4)), dim3(64), 0, s, L); } else
+#else
+#define GNX_CK_RECOMP(AT_)
+#endif
 #define GNX_CK(AT_) \
+      GNX_CK_RECOMP(AT_) \
       if (fwdpsi) { if (nwb == 1) GNX_CK1(AT_, true, 1); else GNX_CK1(AT_, true, 4); } \
       else { if (nwb == 1) GNX_CK1(AT_, false, 1); else GNX_CK1(AT_, false, 4); }
       if (L.A <= 8) { GNX_CK(8) } else if (L.A <= 12) { GNX_CK(12) } else { GNX_CK(16) }
 #undef GNX_CK
+#undef GNX_CK_RECOMP
 #undef GNX_CK1
     } else if (tune.crf_flags & 2) {  // GNX_CRF_FLAGS=2: round 3's kernel (every alpha and scale pair parked), psi from the separate pass
       launch_psi(L, s);
