@@ -7,7 +7,7 @@
 # GNX_P2_TUNE="2,8,ew,2,nbuf": block shape.  GNX_LR_P2_FLAT=0: the two-pass slot-tile kernel of round 5.  (Compile-time variants —
 # prefetch distance of the plane reads — are scripts/dev/p2f_defs.sh; two builds alternating on one box: scripts/dev/p2_ab.sh.)
 cd "${GRAFT_REPO_ROOT:-.}"
-run() { "$@" python scripts/dev/p2_check.py c5 2>&1 | grep -E "config5|p2f cycles" | tail -2 | sed -E 's/\(.*GB\/s of int8 X\)  //' | cut -c1-330; }
+run() { "$@" python scripts/dev/p2_check.py c5 2>&1 | grep -E "config5|p2f cycles" | tail -3 | sed -E 's/\(.*GB\/s of int8 X\)  //' | cut -c1-330; }
 echo "== default (flat tiles, 4 epilogue waves, 3-step plane ring, ~18 blocks per CU)"; run env
 echo "== two-pass slot tiles (round 5's kernel)"; run env GNX_LR_P2_FLAT=0
 for f in 1 2 4 8 16 64 128 1024; do echo "== GNX_LR_FLAGS=$f"; run env GNX_LR_FLAGS=$f; done
