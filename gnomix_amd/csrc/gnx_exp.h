@@ -73,8 +73,8 @@ __device__ __forceinline__ double gnx_exp_sc(double x) {
 
 // ---- the logistic bases' sigmoid and row normaliser: ONE definition for every logistic kernel (k_base_logistic_i8 / _i8_dl / _p2 /
 // _p2f are bit-identical to each other and stay so).  The compiler's IEEE division is eleven float64 instructions (two v_div_scale,
-// v_rcp, four fma, mul, fma, v_div_fmas, v_div_fixup) and a logistic output divided twice — 1 / (1 + e^-t), then p / sum(p); float64
-// vector instructions come out of the SIMD's matrix-pipe time, so the epilogues were a fifth of the 2-bit passes.
+// v_rcp, four fma, mul, fma, v_div_fmas, v_div_fixup) and a logistic output divided twice — 1 / (1 + e^-t), then p / sum(p): the
+// epilogues were a fifth of the 2-bit passes (the shorter sequence below changed no kernel's time measurably: DESIGN.md 8).
 // The operands here are benign (1 + e^-t in [1, 3e307], sum(p) in [3e-308, A]: normal numbers, no scaling needed):
 //   gnx_rcp_nr(y)   v_rcp_f64 + two Newton steps: within 1 ulp of 1 / y (five instructions)
 //   gnx_sigmoid     1 / (1 + e^-t) with -t capped at 708 (e^708 = 3e307 stays finite: beyond it the reference's own value is below

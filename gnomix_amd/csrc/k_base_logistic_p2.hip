@@ -792,9 +792,9 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
     // beside them: their float64 chains would get the left-over issue slots and every wave of the block would wait for them at the
     // step's barrier.  Their work is short; let it go first.
     if (!(abl & 128)) __builtin_amdgcn_s_setprio(2);   // (GNX_LR_FLAGS & 128: without, for A/B timing)
-    // (Float64 vector work runs on the SIMD's matrix pipe wherever it is issued — an epilogue wave's ~550 cycles per step come straight
-    // out of its SIMD's MFMA time — so the total is fixed and only the spread over the steps matters.  Smaller units (two sigmoids, one
-    // store instruction) with or without a per-step time budget measured 3-6 % SLOWER than these eight units per window.)
+    // (A finishing wave is one latency-bound instruction stream — it takes ~1 650 cycles per step with the MFMAs switched off and
+    // ~1 800 with them — and how its work is cut does not move the kernel: 1, 2, 3, 4 or 6 classes per unit, 2 or 4 store parts, units
+    // under a per-step time budget all measure within 1-2 % of each other.  GNX_LR_FLAGS bits 16-22 keep the knobs for A/B runs.)
     const int pbr = ((abl >> 16) & 7) ? ((abl >> 16) & 7) : GNX_P2F_PBR;   // classes of a lane per phase-1 unit (GNX_LR_FLAGS bits 16-18: A/B timing)
     const int n_it = (A + pbr * (64 / CHR) - 1) / (pbr * (64 / CHR));   // phase-1 iterations of a lane: pbr classes each
     const int NSP = ((abl >> 20) & 7) ? ((abl >> 20) & 7) : GNX_P2F_NSP;  // the stores of a chunk in NSP parts (bits 20-22)
@@ -913,6 +913,7 @@ __global__ __launch_bounds__((CW + EW + 2) * 64) void k_base_logistic_p2f(BaseLR
   // ---- EW == 0: SELF-SERVICE epilogue.  Dedicated epilogue waves meet the compute waves at every step's barrier with a different
   // amount of work each step, are the youngest waves of their SIMDs (they lose the VALU arbitration) and, two or four per block,
   // run their float64 chains on one or two instruction streams: every compute wave waited 700-2200 cycles per step for them.
+  // (Measured again with the hand-written read pipeline: 7.20 against 6.57 ms for four dedicated waves — kept as a tune option.)
   // Here a compute wave finishes its OWN 32 rows: the window parked at the end of run r is worked off in units (sigmoid rounds, the
   // row normalisation, the stores in parts) over the steps until its next window ends — float64 VALU work of one wave beside the
   // MFMAs of the wave it shares the SIMD with: the waves of a SIMD (w, w + 4) take their unit at opposite ends of the step.
