@@ -529,3 +529,18 @@ def test_traffic_keys_are_exact_kernel_names_and_bench_refuses_impossible_counte
     # the printed line drops explanatory notes (the driver's record keeps ~8 KB) but keeps the roofline's
     c = bench._compact({"a": {"note": "x" * 500, "v": 1.23456789}, "roofline": {"note": "kept", "frac": 0.3333333}})
     assert c == {"a": {"v": 1.2346}, "roofline": {"note": "kept", "frac": 0.33333}}
+
+
+def test_committed_counter_files_are_stamped_with_the_kernel_sources():
+    """profiles/traffic_latest.json and trained_inputs_latest.json feed `roofline.traffic` / `roofline.trained_inputs` of the bench line
+    and carry the hash of gnomix_amd/csrc at the time they were collected; bench.py prints null (and `counters.stale`) when the
+    sources have moved on.  Whoever edits a kernel source re-collects them (scripts/collect_profiles.sh bench +
+    scripts/dev/trained_inputs_counters.py, see profiles/README.md) — this test is the reminder."""
+    import json
+    import bench
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = bench.kernel_src_sha16()
+    for name in ("traffic_latest.json", "trained_inputs_latest.json"):
+        with open(os.path.join(here, "profiles", name)) as f:
+            d = json.load(f)
+        assert d.get("kernel_src_sha16") == sha, f"profiles/{name} was collected at other kernel sources ({d.get('kernel_src_sha16')} != {sha}): re-collect it"
